@@ -1,0 +1,99 @@
+"""ctypes binding of the C-ABI in include/frz.h to libfrz_hip.so (hand-written HIP kernels, gfx950).
+
+There is NO CPU fallback: if the shared library is missing or a symbol cannot be resolved, loading fails loudly.
+"""
+import ctypes
+import os
+from typing import Any, Dict
+
+from ._cstruct import parse_header
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+REPO_ROOT = os.path.dirname(_PKG_DIR)
+HEADER = os.path.join(REPO_ROOT, 'include', 'frz.h')
+LIB_PATH = os.path.join(_PKG_DIR, 'csrc', 'libfrz_hip.so')
+
+DEFINES, STRUCTS = parse_header(HEADER)
+globals().update({k: v for k, v in DEFINES.items()})
+
+frz_wildfire_cfg = STRUCTS['frz_wildfire_cfg']
+frz_wildfire_bufs = STRUCTS['frz_wildfire_bufs']
+
+_lib = None
+
+# name -> (restype, argtypes); every function include/frz.h declares
+_P = ctypes.c_void_p
+SIGNATURES = {
+    'frz_abi_version': (ctypes.c_int, []),
+    'frz_wildfire_workspace_bytes': (ctypes.c_int64, [_P]),
+    'frz_wildfire_create': (ctypes.c_int, [_P, ctypes.POINTER(_P)]),
+    'frz_wildfire_destroy': (None, [_P]),
+    'frz_wildfire_bind': (ctypes.c_int, [_P, _P]),
+    'frz_wildfire_reset': (ctypes.c_int, [_P, _P]),
+    'frz_wildfire_rebuild': (ctypes.c_int, [_P, _P]),
+    'frz_wildfire_step': (ctypes.c_int, [_P, _P, ctypes.c_int, _P, _P, _P]),
+    'frz_wildfire_random_policy': (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_uint64, _P, _P]),
+    'frz_mt19937_seed': (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int64, ctypes.c_int64, _P]),
+    'frz_mt19937_generate': (ctypes.c_int, [_P, _P, _P, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _P]),
+}
+
+
+class FrzError(RuntimeError):
+    """A C-ABI entry point returned a negative FRZ_E_* code."""
+
+
+def lib() -> ctypes.CDLL:
+    """Load libfrz_hip.so once; raise (never fall back) if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f'{LIB_PATH} is missing: build the HIP extension first '
+                              f'(python -c "import __graft_entry__ as g; g.build()" or make -C free-range-zoo_amd/csrc). '
+                              f'There is no CPU fallback.')
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = restype
+            fn.argtypes = argtypes
+        if handle.frz_abi_version() != DEFINES['FRZ_ABI_VERSION']:
+            raise ImportError('libfrz_hip.so ABI version does not match include/frz.h; rebuild')
+        _lib = handle
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        names = {v: k for k, v in DEFINES.items() if k.startswith('FRZ_E_')}
+        raise FrzError(f'{what} failed: {names.get(code, code)}')
+
+
+def struct_to_dict(s: ctypes.Structure) -> Dict[str, Any]:
+    """Plain-python view of a scalar/array struct (used to store configurations in golden fixtures)."""
+    out = {}
+    for name, ctype in s._fields_:
+        value = getattr(s, name)
+        if isinstance(value, ctypes.Array):
+            def unroll(v):
+                return [unroll(x) for x in v] if isinstance(v, ctypes.Array) else v
+            value = unroll(value)
+        out[name] = value
+    return out
+
+
+def struct_from_dict(cls, values: Dict[str, Any]) -> ctypes.Structure:
+    s = cls()
+    for name, ctype in cls._fields_:
+        if name not in values:
+            continue
+        value = values[name]
+        if isinstance(value, (list, tuple)):
+            arr = getattr(s, name)
+            for i, row in enumerate(value):
+                if isinstance(row, (list, tuple)):
+                    for j, x in enumerate(row):
+                        arr[i][j] = x
+                else:
+                    arr[i] = row
+        else:
+            setattr(s, name, value)
+    return s

@@ -1,0 +1,323 @@
+"""Wildfire configuration dataclasses.
+
+Mirror of free_range_zoo/envs/wildfire/env/structures/configuration.py: same class names, field names, derived
+properties and ``ValueError`` conditions (RewardConfiguration :12-45, FireConfiguration :48-160,
+AgentConfiguration :163-273, StochasticConfiguration :276-328, WildfireConfiguration :331-390), so a
+configuration script written for the reference builds the same object here.  ``to_cstruct`` lowers a configuration
+to the plain-C ``frz_wildfire_cfg`` consumed by the HIP kernels (include/frz.h).
+"""
+from dataclasses import dataclass
+import functools
+from typing import List
+
+import numpy as np
+import torch
+
+from free_range_zoo_amd.utils.configuration import Configuration
+from free_range_zoo_amd import _capi
+
+
+def _require(condition: bool, message: str) -> None:
+    if not condition:
+        raise ValueError(message)
+
+
+def _probability(value: float, name: str) -> None:
+    _require(0 <= value <= 1, f'{name} should be between 0 and 1')
+
+
+@dataclass
+class RewardConfiguration(Configuration):
+    """Reward settings: per-cell put-out reward, bad-attack / burnout penalties, termination bonus."""
+
+    fire_rewards: torch.FloatTensor
+    bad_attack_penalty: float
+    burnout_penalty: float
+    burnout_penalty_scaled: bool = False
+    termination_reward: float = 0.0
+    termination_kappa: float = 0.0
+    localize_putouts: bool = False
+
+    def validate(self) -> bool:
+        _require(self.fire_rewards.dim() == 2, 'fire_rewards should be a 2D tensor')
+        _require(not (self.burnout_penalty != 0 and self.burnout_penalty_scaled),
+                 'burnout_penalty and burnout_penalty_scaled are mutually exclusive')
+        return True
+
+
+@dataclass
+class FireConfiguration(Configuration):
+    """Fire settings: required power per cell, intensity ladder, spread model, ignition temperature, fuel."""
+
+    fire_types: torch.IntTensor
+    num_fire_states: int
+    lit: torch.Tensor
+    intensity_increase_probability: float
+    intensity_decrease_probability: float
+    extra_power_decrease_bonus: float
+    burnout_probability: float
+    base_spread_rate: float
+    max_spread_rate: float
+    random_ignition_probability: float
+    cell_size: float
+    wind_direction: float
+    ignition_temp: torch.IntTensor
+    initial_fuel: int
+
+    @functools.cached_property
+    def burned_out(self) -> int:
+        return self.num_fire_states - 1
+
+    @functools.cached_property
+    def almost_burned_out(self) -> int:
+        return self.num_fire_states - 2
+
+    @functools.cached_property
+    def max_fire_type(self) -> int:
+        return self.fire_types.max().item()
+
+    @functools.cached_property
+    def realistic_spread_rates(self) -> List[float]:
+        """Spread rate towards N, E, S, W under the configured wind (reference configuration.py:116-130)."""
+        per_cell = self.base_spread_rate / self.cell_size
+        headroom = 1 - self.base_spread_rate / self.max_spread_rate
+        headings = (0.0, 0.5 * np.pi, np.pi, 1.5 * np.pi)
+        return [per_cell / (1 - np.cos(heading - self.wind_direction) * headroom) for heading in headings]
+
+    def validate(self) -> bool:
+        _require(self.fire_types.dim() == 2, 'fires should be a 2D tensor')
+        _require(self.num_fire_states >= 4, 'num_fire_states should be greater than 4')
+        _require(self.lit.dim() == 2, 'lit should be a 2D tensor')
+        _probability(self.intensity_increase_probability, 'intensity_increase_probability')
+        _probability(self.intensity_decrease_probability, 'intensity_decrease_probability')
+        _probability(self.burnout_probability, 'burnout_probability')
+        _probability(self.random_ignition_probability, 'random_ignition_probability')
+        _require(0.0 <= self.wind_direction <= 2 * np.pi, 'Wind direction must be between 0 and 2 * pi')
+        _require(self.lit.shape == self.fire_types.shape == self.ignition_temp.shape,
+                 'lit, fire_types, and ignition_temp must have the same shape')
+        return True
+
+
+@dataclass
+class AgentConfiguration(Configuration):
+    """Agent settings: positions, power, range, suppressant/equipment/capacity dynamics."""
+
+    agents: torch.IntTensor
+    fire_reduction_power: torch.FloatTensor
+    attack_range: torch.Tensor
+    suppressant_states: int
+    initial_suppressant: int
+    suppressant_decrease_probability: float
+    suppressant_refill_probability: float
+    initial_equipment_state: int
+    equipment_states: torch.FloatTensor
+    repair_probability: float
+    degrade_probability: float
+    critical_error_probability: float
+    initial_capacity: int
+    tank_switch_probability: float
+    possible_capacities: torch.Tensor
+    capacity_probabilities: torch.Tensor
+
+    @functools.cached_property
+    def num_agents(self) -> int:
+        return self.agents.shape[0]
+
+    @functools.cached_property
+    def max_fire_reduction_power(self) -> float:
+        return self.fire_reduction_power.max().item()
+
+    @functools.cached_property
+    def num_equipment_states(self) -> int:
+        return self.equipment_states.shape[0]
+
+    def validate(self) -> bool:
+        _require(self.agents.dim() == 2, 'agents should be a 2D tensor')
+        _require(self.fire_reduction_power.dim() == 1, 'fire_reduction_power should be a 1D tensor')
+        _require(self.attack_range.dim() == 1, 'attack_range should be a 1D tensor')
+        _require(self.agents.shape[0] == self.fire_reduction_power.shape[0],
+                 'agents, fire_reduction_power, and attack_range should have the same length')
+        _require(self.suppressant_states >= 2, 'suppressant_states should be greater than 2')
+        _require(self.initial_suppressant <= self.suppressant_states, 'init_suppressant should be less than suppressant_states')
+        _probability(self.suppressant_decrease_probability, 'suppressant_use_probability')
+        _probability(self.suppressant_refill_probability, 'suppressant_refill_probability')
+        _require(self.equipment_states.dim() == 2, 'equipment_states should be a 2D tensor')
+        _require(self.initial_equipment_state <= self.equipment_states.shape[0],
+                 'initial_equipment_state should be less than the number of equipment states')
+        _require(self.equipment_states.shape[1] == 3, 'equipment_states should have 3 modifers: suppressant maximum, power, range')
+        _probability(self.repair_probability, 'repair_probability')
+        _probability(self.degrade_probability, 'degrade_probability')
+        _probability(self.critical_error_probability, 'critical_error_probability')
+        _require(self.degrade_probability + self.critical_error_probability <= 1,
+                 'degrade_probability + critical_error_probability should be less than or equal to 1')
+        _probability(self.tank_switch_probability, 'tank_switch_probability')
+        _require(self.possible_capacities.dim() == 1, 'possible_suppressant_maximums should be a 1D tensor')
+        _require(self.capacity_probabilities.dim() == 1, 'suppressant_maximum_probabilities should be a 1D tensor')
+        _require(self.possible_capacities.shape[0] == self.capacity_probabilities.shape[0],
+                 'possible_suppressant_maximums and suppressant_maximum_probabilities should have the same length')
+        _require(self.possible_capacities.min() >= 1, 'possible_suppressant_maximums should be greater than 1')
+        _require(self.capacity_probabilities.sum().item() == 1, 'suppressant_maximum_probabilities should sum to 1')
+        return True
+
+
+@dataclass
+class StochasticConfiguration(Configuration):
+    """Switches for every stochastic element of the wildfire dynamics."""
+
+    special_burnout_probability: bool
+    suppressant_refill: bool
+    suppressant_decrease: bool
+    tank_switch: bool
+    critical_error: bool
+    degrade: bool
+    repair: bool
+    fire_increase: bool
+    fire_decrease: bool
+    fire_spread: bool
+    realistic_fire_spread: bool
+    random_fire_ignition: bool
+    fire_fuel: bool
+
+    def validate(self) -> bool:
+        _require(self.fire_spread or not self.realistic_fire_spread, 'Cannot use realistic fire spread without fire spread')
+        _require(self.degrade or not self.critical_error, 'Cannot have critical errors without equipment degradation')
+        return True
+
+
+@dataclass
+class WildfireConfiguration(Configuration):
+    """Top-level wildfire configuration (grid + fire / agent / reward / stochastic sub-configurations)."""
+
+    grid_width: int
+    grid_height: int
+    fire_config: FireConfiguration
+    agent_config: AgentConfiguration
+    reward_config: RewardConfiguration
+    stochastic_config: StochasticConfiguration
+
+    @functools.cached_property
+    def fire_spread_weights(self) -> torch.Tensor:
+        """[1,1,3,3] float32 cross filter (N top, W left, E right, S bottom); zeros when spread is off."""
+        if not self.stochastic_config.fire_spread:
+            return torch.zeros((1, 1, 3, 3), dtype=torch.float32)
+        if self.stochastic_config.realistic_fire_spread:
+            north, east, south, west = self.fire_config.realistic_spread_rates
+        else:
+            north = east = south = west = self.fire_config.base_spread_rate
+        weights = torch.tensor([[0.0, north, 0.0], [west, 0.0, east], [0.0, south, 0.0]], dtype=torch.float32)
+        return weights.reshape(1, 1, 3, 3)
+
+    @functools.cached_property
+    def fire_random_spread_weight(self) -> float:
+        return self.fire_config.random_ignition_probability if self.stochastic_config.random_fire_ignition else 0.0
+
+    def validate(self) -> bool:
+        super().validate()
+        _require(self.grid_width >= 1, 'grid_width should be greater than 0')
+        _require(self.grid_height >= 1, 'grid_height should be greater than 0')
+        _require(self.fire_config.lit.shape == self.reward_config.fire_rewards.shape, 'lit and fire_rewards should have the same shape')
+        return True
+
+
+def to_cstruct(configuration,
+               parallel_envs: int,
+               max_steps,
+               show_bad_actions: bool = False,
+               observe_other_power: bool = False,
+               observe_other_suppressant: bool = False,
+               track_cumulative_rewards: bool = True):
+    """Lower a (reference-shaped) WildfireConfiguration to ``frz_wildfire_cfg``.
+
+    Works on any object with the reference's attribute names, so the golden-vector generator can lower the
+    reference's own configuration objects with the same code.  Float fields are rounded to float32 exactly where
+    the reference rounds them (``torch.tensor(x, dtype=torch.float32)`` buffers in the transition modules).
+    """
+    fire, agent, reward, stoch = (configuration.fire_config, configuration.agent_config, configuration.reward_config,
+                                  configuration.stochastic_config)
+    H, W = int(configuration.grid_height), int(configuration.grid_width)
+    A = int(agent.agents.shape[0])
+    S = int(agent.equipment_states.shape[0])
+    K = int(agent.possible_capacities.shape[0])
+    if H * W > _capi.DEFINES['FRZ_MAX_CELLS']:
+        raise ValueError(f'grids above {_capi.DEFINES["FRZ_MAX_CELLS"]} cells are not supported by the env-per-lane kernels yet')
+    if A > _capi.DEFINES['FRZ_MAX_AGENTS'] or S > _capi.DEFINES['FRZ_MAX_EQUIPMENT_STATES'] or K > _capi.DEFINES['FRZ_MAX_CAPACITIES']:
+        raise ValueError('too many agents / equipment states / capacities for frz_wildfire_cfg')
+    if tuple(fire.lit.shape) != (H, W):
+        raise ValueError('lit must have shape (grid_height, grid_width)')
+
+    c = _capi.frz_wildfire_cfg()
+    c.parallel_envs, c.grid_height, c.grid_width, c.num_agents = int(parallel_envs), H, W, A
+    c.max_steps = -1 if max_steps is None else int(max_steps)
+    c.num_fire_states, c.num_equipment_states, c.num_capacities = int(fire.num_fire_states), S, K
+
+    c.stochastic_increase = int(stoch.fire_increase)
+    c.stochastic_burnouts = int(stoch.special_burnout_probability)
+    c.stochastic_decrease = int(stoch.fire_decrease)
+    c.use_fire_fuel = int(stoch.fire_fuel)
+    c.stochastic_suppressant_decrease = int(stoch.suppressant_decrease)
+    c.stochastic_refill = int(stoch.suppressant_refill)
+    c.stochastic_switch = int(stoch.tank_switch)
+    c.stochastic_repair = int(stoch.repair)
+    c.stochastic_degrade = int(stoch.degrade)
+    c.critical_error = int(stoch.critical_error)
+    c.show_bad_actions = int(show_bad_actions)
+    c.observe_other_power = int(observe_other_power)
+    c.observe_other_suppressant = int(observe_other_suppressant)
+    c.burnout_penalty_scaled = int(reward.burnout_penalty_scaled)
+    c.localize_putouts = int(reward.localize_putouts)
+    c.track_cumulative_rewards = int(track_cumulative_rewards)
+
+    c.intensity_increase_probability = fire.intensity_increase_probability
+    c.burnout_probability = fire.burnout_probability
+    c.intensity_decrease_probability = fire.intensity_decrease_probability
+    c.extra_power_decrease_bonus = fire.extra_power_decrease_bonus
+    c.suppressant_decrease_probability = agent.suppressant_decrease_probability
+    c.suppressant_refill_probability = agent.suppressant_refill_probability
+    c.tank_switch_probability = agent.tank_switch_probability
+    c.repair_probability = agent.repair_probability
+    c.degrade_probability = agent.degrade_probability
+    c.critical_error_probability = agent.critical_error_probability
+
+    weights = configuration.fire_spread_weights.detach().cpu().reshape(3, 3).to(torch.float32)
+    c.spread_n, c.spread_w, c.spread_e, c.spread_s = (weights[0, 1].item(), weights[1, 0].item(), weights[1, 2].item(),
+                                                      weights[2, 1].item())
+    c.random_ignition = configuration.fire_random_spread_weight
+
+    c.bad_attack_penalty = reward.bad_attack_penalty
+    c.burnout_penalty = reward.burnout_penalty
+    c.termination_reward = reward.termination_reward
+    c.termination_kappa = reward.termination_kappa
+
+    c.initial_fuel = int(fire.initial_fuel)
+    c.initial_suppressant = float(agent.initial_suppressant)
+    c.initial_capacity = float(agent.initial_capacity)
+    c.initial_equipment_state = int(agent.initial_equipment_state)
+
+    positions = agent.agents.detach().cpu().to(torch.int64)
+    power = agent.fire_reduction_power.detach().cpu().to(torch.float32)
+    reach = agent.attack_range.detach().cpu().to(torch.float32)
+    for a in range(A):
+        c.agent_y[a], c.agent_x[a] = int(positions[a, 0]), int(positions[a, 1])
+        c.fire_reduction_power[a] = power[a].item()
+        c.attack_range[a] = reach[a].item()
+    equipment = agent.equipment_states.detach().cpu().to(torch.float32)
+    for s in range(S):
+        for j in range(3):
+            c.equipment_states[s][j] = equipment[s, j].item()
+    capacities = agent.possible_capacities.detach().cpu().to(torch.float32)
+    # capacity.py:27 registers torch.cumsum(capacity_probabilities): a sequential float32 running sum
+    cumulative = np.cumsum(agent.capacity_probabilities.detach().cpu().to(torch.float32).numpy(), dtype=np.float32)
+    for k in range(K):
+        c.possible_capacities[k] = capacities[k].item()
+        c.capacity_cumprobs[k] = float(cumulative[k])
+
+    rewards = reward.fire_rewards.detach().cpu().to(torch.float32).reshape(-1)
+    ignition = fire.ignition_temp.detach().cpu().to(torch.int64).reshape(-1)
+    types = fire.fire_types.detach().cpu().to(torch.int64).reshape(-1)
+    lit = fire.lit.detach().cpu().to(torch.bool).reshape(-1)
+    for cell in range(H * W):
+        c.fire_rewards[cell] = rewards[cell].item()
+        c.ignition_temp[cell] = int(ignition[cell])
+        c.fire_types[cell] = int(types[cell])
+        c.lit[cell] = int(lit[cell])
+    return c

@@ -1,0 +1,210 @@
+/*
+ * frz.h — C-ABI of the MI355X-native batched environment step path.
+ *
+ * Drop-in boundary for free-range-zoo's batched parallel-env step loop
+ * (reference: free_range_zoo/utils/conversions.py:59-99 -> utils/env.py:203-242 ->
+ * envs/<domain>/env/<domain>.py step_environment/update_actions/update_observations).
+ *
+ * Two libraries export (a subset of) these symbols:
+ *   libfrz_hip.so    — the product: hand-written HIP kernels for gfx950 (free-range-zoo_amd/csrc)
+ *   libfrz_oracle.so — test infrastructure only: scalar CPU restatement (oracle/), prefix frz_oracle_
+ *
+ * Conventions
+ *   - plain C types only; every pointer inside a *_bufs struct is a DEVICE pointer for libfrz_hip
+ *     (HOST pointer for the oracle), owned by the caller, never retained after destroy().
+ *   - HBM layout is struct-of-arrays with the environment index innermost ("[k][B]"), so that the 64
+ *     lanes of a wavefront (one environment per lane) touch 256 contiguous bytes per field.
+ *   - jagged outputs are (values, offsets) pairs in the reference's order: env-major, row-major
+ *     inside an env; offsets are int64[B+1] (torch.nested jagged convention).
+ *   - all entry points are stream-ordered, never synchronise, never allocate; return 0 or FRZ_E_*.
+ */
+#ifndef FRZ_H_
+#define FRZ_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FRZ_ABI_VERSION 1
+
+#define FRZ_MAX_AGENTS 16
+#define FRZ_MAX_CELLS 64
+#define FRZ_MAX_EQUIPMENT_STATES 8
+#define FRZ_MAX_CAPACITIES 8
+#define FRZ_MAX_NODES 16
+#define FRZ_MAX_NETWORK_STATES 16
+
+/* error codes */
+#define FRZ_OK 0
+#define FRZ_E_INVALID (-1)     /* bad argument / unsupported size */
+#define FRZ_E_UNBOUND (-2)     /* buffers not bound */
+#define FRZ_E_LAUNCH (-3)      /* HIP launch failure (hipGetLastError != success) */
+#define FRZ_E_NODEVICE (-4)
+
+/* randomness source of a step */
+#define FRZ_RNG_INJECTED 0 /* caller passes the tensors RandomGenerator.generate() would return */
+#define FRZ_RNG_PHILOX 1   /* counter-based Philox4x32-10, key = per-env seed, counter = (draw, step) */
+#define FRZ_RNG_MT19937 2  /* per-env MT19937 streams, seed-identical to the reference's CPU generator */
+
+/* bits of the device-side error word (bufs.error_flags[0]); sticky until cleared by the caller */
+#define FRZ_ERR_BAD_ACTION_INDEX 1u /* task index outside the agent's action mapping */
+#define FRZ_ERR_SCAN_TIMEOUT 2u     /* inter-workgroup prefix hand-off spin bound hit (never expected) */
+#define FRZ_ERR_INVALID_TARGET 4u   /* cybersecurity: attack/move target outside [0, num_nodes) */
+#define FRZ_ERR_ABSENT_ACTION 8u    /* cybersecurity: non-noop action by an absent agent (show_bad_actions off) */
+#define FRZ_ERR_OVERFLOW 16u        /* rideshare: more live passengers than max_passengers slots */
+
+/* ------------------------------------------------------------------------------------------------
+ * Wildfire  (reference: free_range_zoo/envs/wildfire/env/wildfire.py, transitions/,
+ *            structures/configuration.py)
+ * ---------------------------------------------------------------------------------------------- */
+
+typedef struct frz_wildfire_cfg {
+    int32_t parallel_envs; /* B                                  utils/env.py:45 */
+    int32_t grid_height;   /* H                                  configuration.py:331 */
+    int32_t grid_width;    /* W */
+    int32_t num_agents;    /* A                                  configuration.py:206 */
+    int32_t max_steps;     /* < 0 means None (no truncation)     utils/env.py:229 */
+    int32_t num_fire_states;
+    int32_t num_equipment_states;
+    int32_t num_capacities;
+
+    /* StochasticConfiguration (configuration.py:276-316) + env flags (wildfire.py:174-179) */
+    int32_t stochastic_increase;
+    int32_t stochastic_burnouts; /* special_burnout_probability */
+    int32_t stochastic_decrease;
+    int32_t use_fire_fuel;
+    int32_t stochastic_suppressant_decrease;
+    int32_t stochastic_refill;
+    int32_t stochastic_switch;
+    int32_t stochastic_repair;
+    int32_t stochastic_degrade;
+    int32_t critical_error;
+    int32_t show_bad_actions;
+    int32_t observe_other_power;
+    int32_t observe_other_suppressant;
+    int32_t burnout_penalty_scaled;
+    int32_t localize_putouts;
+    int32_t track_cumulative_rewards; /* keep BatchedAECEnv._cumulative_rewards (utils/env.py:244-247) */
+
+    /* probabilities, float32 exactly as the reference's registered buffers */
+    float intensity_increase_probability;
+    float burnout_probability;
+    float intensity_decrease_probability;
+    float extra_power_decrease_bonus;
+    float suppressant_decrease_probability;
+    float suppressant_refill_probability;
+    float tank_switch_probability;
+    float repair_probability;
+    float degrade_probability;
+    float critical_error_probability;
+    /* fire_spread_weights 3x3 cross filter (configuration.py:346-363): p = N*lit[y-1,x] + W*lit[y,x-1]
+     * + E*lit[y,x+1] + S*lit[y+1,x], accumulated in that order in float32 */
+    float spread_n, spread_w, spread_e, spread_s;
+    float random_ignition; /* fire_random_spread_weight (configuration.py:365-371) */
+
+    /* RewardConfiguration (configuration.py:12-45) */
+    float bad_attack_penalty;
+    float burnout_penalty;
+    float termination_reward;
+    float termination_kappa;
+
+    /* initial state scalars (wildfire.py:347-354) */
+    int32_t initial_fuel;
+    float initial_suppressant;
+    float initial_capacity;
+    int32_t initial_equipment_state;
+
+    /* per agent (shared by all envs) */
+    int32_t agent_y[FRZ_MAX_AGENTS];
+    int32_t agent_x[FRZ_MAX_AGENTS];
+    float fire_reduction_power[FRZ_MAX_AGENTS];
+    float attack_range[FRZ_MAX_AGENTS];
+    float equipment_states[FRZ_MAX_EQUIPMENT_STATES][3]; /* (capacity, power, range) bonus per state */
+    float possible_capacities[FRZ_MAX_CAPACITIES];
+    float capacity_cumprobs[FRZ_MAX_CAPACITIES]; /* float32 running sum of capacity_probabilities (capacity.py:27) */
+
+    /* per cell, row-major c = y*W + x */
+    float fire_rewards[FRZ_MAX_CELLS];
+    int32_t ignition_temp[FRZ_MAX_CELLS];
+    int32_t fire_types[FRZ_MAX_CELLS];
+    int32_t lit[FRZ_MAX_CELLS];
+} frz_wildfire_cfg;
+
+/* Buffers of one wildfire env object.  "cap" = B*H*W rows (upper bound on lit fires). */
+typedef struct frz_wildfire_bufs {
+    /* state (WildfireState, structures/state.py:10-68), SoA */
+    int32_t* fires;      /* [H*W][B] */
+    int32_t* intensity;  /* [H*W][B] */
+    int32_t* fuel;       /* [H*W][B] */
+    float* suppressants; /* [A][B] */
+    float* capacity;     /* [A][B] */
+    int32_t* equipment;  /* [A][B] */
+    /* AEC bookkeeping (utils/env.py:94-160) */
+    int32_t* num_moves;        /* [B] */
+    int32_t* num_burnouts;     /* [B]            wildfire.py:357 */
+    float* rewards;            /* [A][B]  out */
+    float* cumulative_rewards; /* [A][B]  in/out (may be NULL if !track_cumulative_rewards) */
+    uint8_t* terminations;     /* [A][B]  in/out */
+    uint8_t* truncations;      /* [A][B]  out */
+    int64_t* burnouts;         /* [B] out  infos['burnouts'] (wildfire.py:581) */
+    int64_t* putouts;          /* [B] out  infos['putouts'] */
+    /* observations (wildfire.py:668-717) */
+    float* obs_self;         /* [A][B][4] */
+    float* obs_others;       /* [A][B][(A-1)*k], k = 2 + observe_other_power + observe_other_suppressant */
+    int64_t* task_values;    /* [cap][4]  (y, x, fires, intensity) of lit fires */
+    int64_t* task_offsets;   /* [B+1]  shared by task_values and obs_map_values */
+    /* action/observation index maps + counts (wildfire.py:586-666) */
+    int64_t* obs_map_values;    /* [cap]      local task indices 0..F_b-1 */
+    int64_t* act_map_values;    /* [A][cap]   local indices of attackable fires (unused if show_bad_actions) */
+    int64_t* act_map_offsets;   /* [A][B+1] */
+    int64_t* bad_map_values;    /* [A][cap]   only if show_bad_actions, else may be NULL */
+    int64_t* bad_map_offsets;   /* [A][B+1] */
+    int64_t* env_task_count;    /* [B] */
+    int32_t* agent_task_count;  /* [A][B] */
+    /* per-env RNG state */
+    int32_t* seeds;       /* [B]  (FRZ_RNG_PHILOX key) */
+    uint32_t* mt_state;   /* [624][B]  FRZ_RNG_MT19937 only, else may be NULL */
+    int32_t* mt_index;    /* [B]       number of draws consumed modulo 624 */
+    /* library scratch: zero-filled once by the caller, frz_wildfire_workspace_bytes() bytes */
+    void* workspace;
+    uint32_t* error_flags; /* [1] sticky FRZ_ERR_* bits */
+} frz_wildfire_bufs;
+
+typedef struct frz_wildfire_env frz_wildfire_env; /* opaque host handle */
+
+int frz_abi_version(void);
+int64_t frz_wildfire_workspace_bytes(const frz_wildfire_cfg* cfg);
+int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out);
+void frz_wildfire_destroy(frz_wildfire_env* env);
+int frz_wildfire_bind(frz_wildfire_env* env, const frz_wildfire_bufs* bufs);
+/* replaces raw_env.reset()'s state fill (wildfire.py:347-354) + bookkeeping zeroing (utils/env.py:137-160)
+ * followed by update_observations/update_actions */
+int frz_wildfire_reset(frz_wildfire_env* env, void* stream);
+/* replaces update_observations() + update_actions() (wildfire.py:586-717) on the bound state */
+int frz_wildfire_rebuild(frz_wildfire_env* env, void* stream);
+/* replaces one ParallelEnv.step(): BatchedAECEnv.step x A + step_environment + truncation + rebuild.
+ * actions: int32 [A][B][2] (each agent's block is the reference's per-agent IntTensor[B,2]).
+ * rng_mode FRZ_RNG_INJECTED: field_randomness float32 [3][B][H*W], agent_randomness float32 [5][B][A]
+ * (= generator.generate(B,3,(H,W)) / generate(B,5,(A,)), wildfire.py:409-410); otherwise both NULL. */
+int frz_wildfire_step(frz_wildfire_env* env, const int32_t* actions, int rng_mode, const float* field_randomness,
+                      const float* agent_randomness, void* stream);
+/* uniform random policy over OneOf([task]*n + [noop]) (spaces/actions.py:23-41): writes int32 [A][B][2] */
+int frz_wildfire_random_policy(frz_wildfire_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out,
+                               void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Per-env MT19937 streams  (reference: free_range_zoo/utils/random_generator.py:49-146; torch CPU
+ * generator = MT19937 init_genrand(seed), float32 = (u32 & 0xFFFFFF) * 2^-24)
+ * ---------------------------------------------------------------------------------------------- */
+int frz_mt19937_seed(uint32_t* mt_state /*[624][B]*/, int32_t* mt_index /*[B]*/, const int32_t* seeds /*[B]*/,
+                     const int32_t* batch_indices /* NULL = all */, int64_t n, int64_t B, void* stream);
+/* out float32 [events][B][count]: env b draws events*count consecutive floats (generate(), unbuffered) */
+int frz_mt19937_generate(uint32_t* mt_state, int32_t* mt_index, float* out, int64_t events, int64_t count, int64_t B,
+                         void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRZ_H_ */

@@ -1,0 +1,88 @@
+/*
+ * frz_oracle.h — CPU restatement of the reference algorithm.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only as the
+ * checker / reported CPU baseline — never as a product path.  The product (libfrz_hip.so) has no CPU fallback.
+ *
+ * Parity status: PINNED.  tests/test_oracle_*.py check every function here against (a) the reference's own
+ * known-answer transition tests, recorded as data under tests/golden/ka_*.npz, and (b) trajectories of the
+ * unmodified reference run in the build container (tests/golden/traj_*.npz, generator: tools/refharness/).
+ *
+ * Layout: the oracle keeps the REFERENCE's batch-major layout for state ([B][H*W], [B][A]) so that every loop
+ * reads like the reference's tensor expression; outputs use the same layout as include/frz.h.
+ */
+#ifndef FRZ_ORACLE_H_
+#define FRZ_ORACLE_H_
+
+#include "../include/frz.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct frz_oracle_wildfire_bufs {
+    /* state, batch-major as in WildfireState (structures/state.py:10-68) */
+    int32_t* fires;      /* [B][H*W] */
+    int32_t* intensity;  /* [B][H*W] */
+    int32_t* fuel;       /* [B][H*W] */
+    float* suppressants; /* [B][A] */
+    float* capacity;     /* [B][A] */
+    int32_t* equipment;  /* [B][A] */
+    int32_t* num_moves;  /* [B] */
+    int32_t* num_burnouts;
+    float* rewards;            /* [A][B] */
+    float* cumulative_rewards; /* [A][B] */
+    uint8_t* terminations;     /* [A][B] */
+    uint8_t* truncations;      /* [A][B] */
+    int64_t* burnouts;
+    int64_t* putouts;
+    float* obs_self;   /* [A][B][4] */
+    float* obs_others; /* [A][B][(A-1)*k] */
+    int64_t* task_values;
+    int64_t* task_offsets;
+    int64_t* obs_map_values;
+    int64_t* act_map_values;  /* [A][cap] */
+    int64_t* act_map_offsets; /* [A][B+1] */
+    int64_t* bad_map_values;
+    int64_t* bad_map_offsets;
+    int64_t* env_task_count;
+    int32_t* agent_task_count; /* [A][B] */
+    uint32_t* error_flags;
+    /* BatchedAECEnv.step early-out bookkeeping (utils/env.py:211-213): 1 once every env is terminated or every
+     * env is truncated; further steps leave everything untouched except rewards (see frz_oracle_wildfire_step) */
+    int32_t* frozen; /* [2]: {frozen, stale_rewards_already_scaled} */
+} frz_oracle_wildfire_bufs;
+
+int frz_oracle_wildfire_reset(const frz_wildfire_cfg* cfg, frz_oracle_wildfire_bufs* s);
+int frz_oracle_wildfire_rebuild(const frz_wildfire_cfg* cfg, frz_oracle_wildfire_bufs* s);
+int frz_oracle_wildfire_step(const frz_wildfire_cfg* cfg, frz_oracle_wildfire_bufs* s, const int32_t* actions,
+                             const float* field_randomness, const float* agent_randomness);
+
+/* single transitions on batch-major arrays, for the reference's known-answer transition tests */
+void frz_oracle_wf_suppressant_decrease(const frz_wildfire_cfg* cfg, float* supp, const uint8_t* users, const float* r,
+                                        int64_t n);
+void frz_oracle_wf_equipment(const frz_wildfire_cfg* cfg, int32_t* equipment, const float* r, int64_t n);
+void frz_oracle_wf_suppressant_refill(const frz_wildfire_cfg* cfg, float* supp, const float* cap, const int32_t* equipment,
+                                      const uint8_t* refills, const float* r, uint8_t* increased, int64_t n);
+void frz_oracle_wf_capacity(const frz_wildfire_cfg* cfg, float* supp, float* cap, const uint8_t* targets, const float* r_size,
+                            const float* r_switch, int64_t n);
+void frz_oracle_wf_fire_increase(const frz_wildfire_cfg* cfg, int32_t* fires, int32_t* intensity, int32_t* fuel,
+                                 const float* attack, const float* r, uint8_t* burned, int64_t n);
+void frz_oracle_wf_fire_decrease(const frz_wildfire_cfg* cfg, int32_t* fires, int32_t* intensity, int32_t* fuel,
+                                 const float* attack, const float* r, uint8_t* put_out, int64_t n);
+void frz_oracle_wf_fire_spread(const frz_wildfire_cfg* cfg, int32_t* fires, int32_t* intensity, const int32_t* fuel,
+                               const float* r, int64_t B);
+int frz_oracle_in_range_chebyshev(int32_t ay, int32_t ax, int32_t ty, int32_t tx, float attack_range);
+
+/* MT19937 per-env streams (utils/random_generator.py:76-114); state batch-major [B][624] */
+void frz_oracle_mt19937_seed(uint32_t* mt_state, int32_t* mt_index, const int32_t* seeds, int64_t B);
+void frz_oracle_mt19937_generate(uint32_t* mt_state, int32_t* mt_index, float* out, int64_t events, int64_t count, int64_t B);
+/* Philox4x32-10 (Salmon et al., SC'11) block function */
+void frz_oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+/* the float stream FRZ_RNG_PHILOX defines: draw d of env with seed s at step t */
+float frz_oracle_philox_uniform(int32_t seed, uint32_t step, uint32_t draw, uint32_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,79 @@
+/*
+ * frz_oracle_rng.c — CPU restatement of the random streams.  TEST INFRASTRUCTURE ONLY (see frz_oracle.h).
+ *
+ * MT19937: the reference's RandomGenerator (utils/random_generator.py:49-146) keeps one torch CPU generator state
+ * per env; torch's CPU generator is the standard MT19937 (Matsumoto & Nishimura 1998, init_genrand(seed)) and
+ * torch.rand(float32) maps ONE 32-bit output x per element to (x & 0xFFFFFF) * 2^-24, elements in row-major order.
+ * Pinned by tests/golden/mt19937_torch.npz (torch.Generator().manual_seed(s); torch.rand(n, generator=g)) and by the
+ * published first outputs of init_genrand(5489): 3499211612, 581869302, 3890346734.
+ *
+ * Philox4x32-10: Salmon, Moraes, Dror, Shaw, "Parallel random numbers: as easy as 1, 2, 3" (SC'11); pinned by the
+ * Random123 known-answer vectors in tests/test_oracle_rng.py.
+ */
+#include "frz_oracle.h"
+
+#define MT_N 624
+#define MT_M 397
+
+void frz_oracle_mt19937_seed(uint32_t* mt_state, int32_t* mt_index, const int32_t* seeds, int64_t B) {
+    for (int64_t b = 0; b < B; ++b) {
+        uint32_t* mt = mt_state + b * MT_N;
+        mt[0] = (uint32_t)seeds[b];
+        for (int j = 1; j < MT_N; ++j) mt[j] = 1812433253u * (mt[j - 1] ^ (mt[j - 1] >> 30)) + (uint32_t)j;
+        mt_index[b] = 0; /* number of outputs consumed from the NEXT generation, lazily twisted word by word */
+    }
+}
+
+/* One output.  The block twist of the textbook generator updates mt[] in place for i = 0..623 in order; doing
+ * the same update for word i just before it is read (same order, same operands) yields the identical stream. */
+static inline uint32_t mt_next(uint32_t* mt, int32_t* index) {
+    const int i = *index;
+    const uint32_t y = (mt[i] & 0x80000000u) | (mt[(i + 1) % MT_N] & 0x7fffffffu);
+    uint32_t v = mt[(i + MT_M) % MT_N] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    mt[i] = v;
+    *index = (i + 1) % MT_N;
+    v ^= v >> 11;
+    v ^= (v << 7) & 0x9d2c5680u;
+    v ^= (v << 15) & 0xefc60000u;
+    v ^= v >> 18;
+    return v;
+}
+
+/* RandomGenerator.generate(), unbuffered multi-seed branch (utils/random_generator.py:106-114): env b draws
+ * events*count consecutive floats; output is transposed to [events][B][count]. */
+void frz_oracle_mt19937_generate(uint32_t* mt_state, int32_t* mt_index, float* out, int64_t events, int64_t count, int64_t B) {
+    for (int64_t b = 0; b < B; ++b) {
+        uint32_t* mt = mt_state + b * MT_N;
+        for (int64_t e = 0; e < events; ++e)
+            for (int64_t k = 0; k < count; ++k) {
+                const uint32_t x = mt_next(mt, &mt_index[b]);
+                out[(e * B + b) * count + k] = (float)(x & 0xFFFFFFu) * (1.0f / 16777216.0f);
+            }
+    }
+}
+
+void frz_oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int round = 0; round < 10; ++round) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* FRZ_RNG_PHILOX stream definition: key = (seed, "FRZ" tag), counter = (draw / 4, step, stream, 0);
+ * float = (word >> 8) * 2^-24 with word = output[draw % 4]. */
+float frz_oracle_philox_uniform(int32_t seed, uint32_t step, uint32_t draw, uint32_t stream) {
+    const uint32_t ctr[4] = {draw >> 2, step, stream, 0u};
+    const uint32_t key[2] = {(uint32_t)seed, 0x46525A00u};
+    uint32_t out[4];
+    frz_oracle_philox4x32_10(ctr, key, out);
+    return (float)(out[draw & 3u] >> 8) * (1.0f / 16777216.0f);
+}
