@@ -1,0 +1,92 @@
+// frz_device.h — device-side building blocks shared by the gfx950 env-step kernels.
+//
+// Written for CDNA4 only: 64-lane wavefronts, one environment per lane, 256-thread workgroups (one wave per SIMD).
+// Compile with -ffp-contract=off: reward / probability arithmetic must round once per operation, like the
+// reference's eager float32 ops.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace frz {
+
+constexpr int kBlock = 256;  // threads (= environments) per workgroup
+constexpr int kWaves = kBlock / 64;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+// ------------------------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. SC'11).  FRZ_RNG_PHILOX stream definition (same as oracle/frz_oracle_rng.c):
+//   key = (seed, 0x46525A00), counter = (draw >> 2, step, stream, 0), float = (word[draw & 3] >> 8) * 2^-24
+// ------------------------------------------------------------------------------------------------------------
+struct Philox4 {
+    uint32_t w[4];
+};
+
+__device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int round = 0; round < 10; ++round) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0;
+        const uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0;
+        c1 = lo1;
+        c2 = n2;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return Philox4{{c0, c1, c2, c3}};
+}
+
+__device__ __forceinline__ float u32_to_unit_float(uint32_t word) { return (float)(word >> 8) * (1.0f / 16777216.0f); }
+
+// ------------------------------------------------------------------------------------------------------------
+// Wavefront / workgroup prefix sums of per-lane counts (variable-length task lists).
+// Counts are packed four 16-bit channels per 64-bit word: a 256-env workgroup with <= 64 tasks per env cannot
+// overflow a channel (256 * 64 = 16384 < 65536).
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t wave_inclusive_scan(uint64_t v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t up = __shfl_up(v, d, 64);
+        if (lane >= d) v += up;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Inter-workgroup hand-off granule: one naturally aligned 8-byte {tag, value} word written by ONE agent-scope
+// store and read by agent-scope (L1-bypassing) loads.  The tag carries the launch epoch, so a granule is
+// self-validating and needs neither fences nor clearing between launches (MI355X_MICROARCH.md, hand-off R2).
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void granule_store(uint64_t* slot, uint32_t tag, uint32_t value) {
+    __hip_atomic_store(slot, ((uint64_t)tag << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ uint64_t granule_load(const uint64_t* slot) {
+    return __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Spin (bounded) until the granule carries `tag`; returns its value, sets *timed_out on the bound.
+__device__ __forceinline__ uint32_t granule_wait(const uint64_t* slot, uint32_t tag, bool* timed_out) {
+    constexpr int kSpinBound = 1 << 22;  // ~seconds; every spin in this library is bounded
+    for (int spin = 0; spin < kSpinBound; ++spin) {
+        const uint64_t g = granule_load(slot);
+        if ((uint32_t)(g >> 32) == tag) return (uint32_t)g;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    *timed_out = true;
+    return 0;
+}
+
+}  // namespace frz

@@ -1,0 +1,4 @@
+"""Environment entry points, named as in the reference (``free_range_zoo/envs/__init__.py``)."""
+from free_range_zoo_amd.envs import wildfire_v0
+
+__all__ = ['wildfire_v0']

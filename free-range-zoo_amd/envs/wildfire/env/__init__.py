@@ -1,0 +1,2 @@
+from .structures.configuration import (WildfireConfiguration, FireConfiguration, AgentConfiguration, StochasticConfiguration,
+                                       RewardConfiguration)

@@ -1,0 +1,318 @@
+"""Wildfire environment: Python boundary over the fused HIP step kernel.
+
+Mirrors free_range_zoo/envs/wildfire/env/wildfire.py (``parallel_env`` :126-142, ``raw_env`` :163-762): same
+constructor keywords, agent names (``firefighter_i``), observation / action-mapping attributes, dtypes and shapes.
+All arithmetic of ``step_environment`` / ``update_actions`` / ``update_observations`` runs in
+``csrc/wildfire.hip`` through the C-ABI ``frz_wildfire_*`` (include/frz.h).
+"""
+import ctypes
+from typing import Any, Callable, Dict, List, Optional, Tuple
+
+import torch
+
+from free_range_zoo_amd import _capi
+from free_range_zoo_amd.utils.env import BatchedParallelEnv, jagged, stream_ptr
+from free_range_zoo_amd.utils.spaces import BatchedOneOfSpace
+from free_range_zoo_amd.utils.tensordict import TensorDict
+from free_range_zoo_amd.envs.wildfire.env.structures.configuration import to_cstruct
+from free_range_zoo_amd.envs.wildfire.env.structures.state import WildfireState
+
+
+def parallel_env(wrappers: List[Callable] = [], **kwargs) -> 'raw_env':
+    """Batched parallel wildfire environment (reference wildfire.py:126-142)."""
+    env = raw_env(**kwargs)
+    for wrapper in wrappers:
+        env = wrapper(env)
+    return env
+
+
+def env(wrappers: List[Callable] = [], **kwargs) -> 'raw_env':
+    """AEC-flavoured constructor of the reference (wildfire.py:145-160); the same object serves both APIs here."""
+    return parallel_env(wrappers, **kwargs)
+
+
+class raw_env(BatchedParallelEnv):
+    """Environment definition for the wildfire environment."""
+
+    metadata = {'render.modes': ['human', 'rgb_array'], 'name': 'wildfire_v0', 'is_parallelizable': True, 'render_fps': 2}
+
+    @torch.no_grad()
+    def __init__(self, *args, observe_other_suppressant: bool = False, observe_other_power: bool = False,
+                 show_bad_actions: bool = False, **kwargs) -> None:
+        super().__init__(*args, **kwargs)
+        self.observe_other_suppressant = observe_other_suppressant
+        self.observe_other_power = observe_other_power
+        self.show_bad_actions = show_bad_actions
+
+        A = self.agent_config.num_agents
+        self.possible_agents = tuple(f'firefighter_{i}' for i in range(1, A + 1))
+        self.agents = self.possible_agents
+        self.agent_name_mapping = dict(zip(self.possible_agents, torch.arange(0, A, device=self.device)))
+        self.agent_position_mapping = dict(zip(self.possible_agents, self.agent_config.agents))
+        self.ignition_temp = self.fire_config.ignition_temp
+        self.max_x, self.max_y = self.config.grid_width, self.config.grid_height
+        self.fire_spread_weights = self.config.fire_spread_weights.to(self.device)
+        self.fire_reduction_power = self.agent_config.fire_reduction_power
+        self.suppressant_states = self.agent_config.suppressant_states
+        self.agent_observation_bounds = (self.max_y, self.max_x, self.agent_config.max_fire_reduction_power,
+                                         self.agent_config.suppressant_states)
+        self.fire_observation_bounds = (self.max_y, self.max_x, self.fire_config.max_fire_type, self.fire_config.num_fire_states)
+        agent_ids = torch.arange(0, A, device=self.device)
+        self.observation_ordering = {agent: agent_ids[agent_ids != i] for i, agent in enumerate(self.possible_agents)}
+        self._allocate()
+        self._create_handle()
+
+    # ------------------------------------------------------------------------------------------------ buffers
+    def _allocate(self) -> None:
+        B, H, W, A = self.parallel_envs, self.max_y, self.max_x, len(self.possible_agents)
+        HW, cap = H * W, self.parallel_envs * H * W
+        self._k = 2 + int(self.observe_other_power) + int(self.observe_other_suppressant)
+        f32, i32, i64, u8 = torch.float32, torch.int32, torch.int64, torch.uint8
+        z = self._alloc
+        # struct-of-arrays HBM state: env index innermost
+        self._fires, self._intensity, self._fuel = z((HW, B), i32), z((HW, B), i32), z((HW, B), i32)
+        self._suppressants, self._capacity, self._equipment = z((A, B), f32), z((A, B), f32), z((A, B), i32)
+        self.num_moves, self.num_burnouts = z((B, ), i32), z((B, ), i32)
+        self._rewards, self._cumulative = z((A, B), f32), z((A, B), f32)
+        self._terminations, self._truncations = z((A, B), torch.bool), z((A, B), torch.bool)
+        self._burnouts, self._putouts = z((B, ), i64), z((B, ), i64)
+        self._obs_self, self._obs_others = z((A, B, 4), f32), z((A, B, max(A - 1, 0), self._k), f32)
+        self._task_values, self._task_offsets = z((cap, 4), i64), z((B + 1, ), i64)
+        self._obs_map_values = z((cap, ), i64)
+        self._act_map_values, self._act_map_offsets = z((A, cap), i64), z((A, B + 1), i64)
+        self._bad_map_values = z((A, cap), i64) if self.show_bad_actions else None
+        self._bad_map_offsets = z((A, B + 1), i64) if self.show_bad_actions else None
+        self.environment_task_count, self.agent_task_count = z((B, ), i64), z((A, B), i32)
+        self._frozen_scaled = z((B, ), u8)
+        self._error_flags = z((1, ), i32)
+        self._actions = z((A, B, 2), i32)
+        self.seeds = self.generator.seeds
+        self._state = WildfireState(
+            fires=self._fires.view(H, W, B).permute(2, 0, 1), intensity=self._intensity.view(H, W, B).permute(2, 0, 1),
+            fuel=self._fuel.view(H, W, B).permute(2, 0, 1), agents=self.agent_config.agents,
+            suppressants=self._suppressants.t(), capacity=self._capacity.t(), equipment=self._equipment.t())
+
+    def _create_handle(self) -> None:
+        if self._handle is not None:
+            self._lib.frz_wildfire_destroy(self._handle)
+        self._cfg = to_cstruct(self.config, self.parallel_envs, self.max_steps, show_bad_actions=self.show_bad_actions,
+                               observe_other_power=self.observe_other_power, observe_other_suppressant=self.observe_other_suppressant)
+        nbytes = self._lib.frz_wildfire_workspace_bytes(ctypes.byref(self._cfg))
+        if nbytes <= 0:
+            raise _capi.FrzError('frz_wildfire_workspace_bytes rejected the configuration')
+        if getattr(self, '_workspace', None) is None or self._workspace.numel() != nbytes:
+            self._workspace = self._alloc((nbytes, ), torch.uint8)
+        handle = ctypes.c_void_p()
+        _capi.check(self._lib.frz_wildfire_create(ctypes.byref(self._cfg), ctypes.byref(handle)), 'frz_wildfire_create')
+        self._handle = handle
+        bufs = _capi.frz_wildfire_bufs()
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        for name, tensor in (('fires', self._fires), ('intensity', self._intensity), ('fuel', self._fuel),
+                             ('suppressants', self._suppressants), ('capacity', self._capacity), ('equipment', self._equipment),
+                             ('num_moves', self.num_moves), ('num_burnouts', self.num_burnouts), ('rewards', self._rewards),
+                             ('cumulative_rewards', self._cumulative), ('terminations', self._terminations),
+                             ('truncations', self._truncations), ('burnouts', self._burnouts), ('putouts', self._putouts),
+                             ('obs_self', self._obs_self), ('obs_others', self._obs_others), ('task_values', self._task_values),
+                             ('task_offsets', self._task_offsets), ('obs_map_values', self._obs_map_values),
+                             ('act_map_values', self._act_map_values), ('act_map_offsets', self._act_map_offsets),
+                             ('bad_map_values', self._bad_map_values), ('bad_map_offsets', self._bad_map_offsets),
+                             ('env_task_count', self.environment_task_count), ('agent_task_count', self.agent_task_count),
+                             ('frozen_scaled', self._frozen_scaled), ('seeds', self.generator.seeds),
+                             ('mt_state', self.generator.generator_states), ('mt_index', self.generator.generator_index),
+                             ('workspace', self._workspace), ('error_flags', self._error_flags)):
+            setattr(bufs, name, ptr(tensor))
+        self._bufs = bufs
+        _capi.check(self._lib.frz_wildfire_bind(self._handle, ctypes.byref(bufs)), 'frz_wildfire_bind')
+
+    def _set_max_steps(self, max_steps) -> None:
+        if max_steps != self.max_steps:
+            self.max_steps = max_steps
+            self._create_handle()
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                self._lib.frz_wildfire_destroy(self._handle)
+                self._handle = None
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+    # ---------------------------------------------------------------------------------------- output plumbing
+    def _publish(self) -> None:
+        """Wrap the persistent output buffers in the reference's dict / TensorDict / nested-tensor structure."""
+        B, A = self.parallel_envs, len(self.agents)
+        HW = self.max_y * self.max_x
+        if self.exact_shapes:
+            # one small device->host read: total and maximum length of each jagged output
+            stats = torch.cat([self._task_offsets[-1:], self._act_map_offsets[:, -1],
+                               self.environment_task_count.max().reshape(1), self.agent_task_count.max(dim=1).values.to(torch.int64)])
+            if self.show_bad_actions:
+                bad = self.environment_task_count.unsqueeze(0) - self.agent_task_count
+                stats = torch.cat([stats, self._bad_map_offsets[:, -1], bad.max(dim=1).values])
+            stats = stats.tolist()
+            total_f, total_a, max_f, max_a = stats[0], stats[1:1 + A], stats[1 + A], stats[2 + A:2 + 2 * A]
+            tasks = jagged(self._task_values[:total_f], self._task_offsets, max_seqlen=max_f)
+            obs_map = jagged(self._obs_map_values[:total_f], self._task_offsets, max_seqlen=max_f)
+            act_maps = [jagged(self._act_map_values[a, :total_a[a]], self._act_map_offsets[a], max_seqlen=max_a[a]) for a in range(A)]
+            if self.show_bad_actions:
+                total_b, max_b = stats[2 + 2 * A:2 + 3 * A], stats[2 + 3 * A:]
+                bad_maps = [jagged(self._bad_map_values[a, :total_b[a]], self._bad_map_offsets[a], max_seqlen=max_b[a]) for a in range(A)]
+        elif getattr(self, '_static_views', None) is None:
+            counts = self.environment_task_count
+            tasks = jagged(self._task_values, self._task_offsets, max_seqlen=HW, lengths=counts)
+            obs_map = jagged(self._obs_map_values, self._task_offsets, max_seqlen=HW, lengths=counts)
+            act_maps = [jagged(self._act_map_values[a], self._act_map_offsets[a], max_seqlen=HW, lengths=self.agent_task_count[a])
+                        for a in range(A)]
+            if self.show_bad_actions:
+                self._bad_counts = self.environment_task_count.unsqueeze(0) - self.agent_task_count
+                bad_maps = [jagged(self._bad_map_values[a], self._bad_map_offsets[a], max_seqlen=HW, lengths=self._bad_counts[a])
+                            for a in range(A)]
+            self._static_views = True
+        else:
+            if self.show_bad_actions:
+                torch.sub(self.environment_task_count.unsqueeze(0), self.agent_task_count, out=self._bad_counts)
+            return  # persistent views already published
+
+        self.task_store = tasks
+        self.agent_action_mapping, self.agent_observation_mapping, self.agent_bad_actions, self.observations = {}, {}, {}, {}
+        for a, agent in enumerate(self.agents):
+            if self.show_bad_actions:  # wildfire.py:656-660
+                self.agent_action_mapping[agent] = obs_map
+                self.agent_bad_actions[agent] = bad_maps[a]
+            else:
+                self.agent_action_mapping[agent] = act_maps[a]
+                self.agent_bad_actions[agent] = None
+            self.agent_observation_mapping[agent] = obs_map
+            self.observations[agent] = TensorDict({'self': self._obs_self[a], 'others': self._obs_others[a], 'tasks': tasks},
+                                                  batch_size=[B], device=self.device)
+        if not hasattr(self, 'rewards') or self.rewards is None:
+            self._publish_dense()
+
+    def _publish_dense(self) -> None:
+        self.rewards = {agent: self._rewards[a] for a, agent in enumerate(self.agents)}
+        self._cumulative_rewards = {agent: self._cumulative[a] for a, agent in enumerate(self.agents)}
+        self.terminations = {agent: self._terminations[a] for a, agent in enumerate(self.agents)}
+        self.truncations = {agent: self._truncations[a] for a, agent in enumerate(self.agents)}
+        self.actions = {agent: self._actions[a] for a, agent in enumerate(self.agents)}
+
+    # ------------------------------------------------------------------------------------------------- reset
+    @torch.no_grad()
+    def reset(self, seed=None, options: Optional[Dict[str, Any]] = None):
+        """Reset every env; returns ``(observations, infos)`` like the parallel adapter (conversions.py:39-57)."""
+        self._reset_options(options)
+        if options and options.get('skip_seeding'):
+            if not self.generator.has_been_seeded:
+                raise ValueError('Seed must be set before skipping seeding is possible')
+        else:
+            self.generator.seed(seed, partial_seeding=None)
+        self.agents = self.possible_agents
+        self.rewards = None
+        self._static_views = None
+        stream = stream_ptr(self.device)
+        _capi.check(self._lib.frz_wildfire_reset(self._handle, stream), 'frz_wildfire_reset')
+        if options is not None and options.get('initial_state') is not None:
+            initial_state = options['initial_state']
+            if len(initial_state) != self.parallel_envs:
+                raise ValueError('Initial state must have the same number of environments as the parallel environments')
+            self._state.load_state(initial_state.to(self.device))
+            _capi.check(self._lib.frz_wildfire_rebuild(self._handle, stream), 'frz_wildfire_rebuild')
+        self._state.save_initial()
+        self.fire_rewards = self.reward_config.fire_rewards.unsqueeze(0).expand(self.parallel_envs, -1, -1)
+        self.infos = {agent: {} for agent in self.agents}
+        self._has_reset = True
+        self._publish()
+        self._publish_dense()
+        return {agent: self.observations[agent] for agent in self.agents}, self.infos
+
+    @torch.no_grad()
+    def reset_batches(self, batch_indices: torch.Tensor, seed: Optional[List[int]] = None, options: Optional[Dict[str, Any]] = None) -> None:
+        """Partial reset (wildfire.py:376-397 + utils/env.py:162-189): reseed, zero bookkeeping, restore initial state."""
+        batch_indices = torch.as_tensor(batch_indices, device=self.device).long()
+        self.generator.seed(seed, partial_seeding=batch_indices)
+        self._rewards[:, batch_indices] = 0
+        self._cumulative[:, batch_indices] = 0
+        self._terminations[:, batch_indices] = False
+        self._truncations[:, batch_indices] = False
+        self.num_moves[batch_indices] = 0
+        self.num_burnouts[batch_indices] = 0
+        self._frozen_scaled[batch_indices] = 0
+        self._state.restore_initial(batch_indices)
+        _capi.check(self._lib.frz_wildfire_rebuild(self._handle, stream_ptr(self.device)), 'frz_wildfire_rebuild')
+        self._publish()
+
+    # -------------------------------------------------------------------------------------------------- step
+    @torch.no_grad()
+    def step(self, actions, randomness: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+        """
+        One simultaneous step of every env.
+
+        Args:
+            actions: ``{agent: IntTensor[B, 2]}`` (column 0 = index into the agent's action mapping, column 1 = 0 to
+                fight / -1 to noop-refill), or an already stacked int32 ``[A, B, 2]`` device tensor.
+            randomness: optional ``(field [3,B,H,W], agent [5,B,A])`` float32 tensors to use instead of the env's
+                generator — the reference's own cross-device test convention (randomness as an input).
+        Returns:
+            ``(observations, rewards, terminations, truncations, infos)`` dicts keyed by agent name.
+        """
+        if not self._has_reset:
+            raise RuntimeError('reset() must be called before step()')
+        if isinstance(actions, dict):
+            for a, agent in enumerate(self.agents):
+                self._actions[a].copy_(actions[agent])
+            actions_ptr = self._actions.data_ptr()
+        else:
+            if actions.dtype != torch.int32 or not actions.is_contiguous() or tuple(actions.shape) != tuple(self._actions.shape):
+                raise ValueError('stacked actions must be a contiguous int32 [A, B, 2] tensor')
+            self._action_keepalive = actions
+            actions_ptr = actions.data_ptr()
+        stream = stream_ptr(self.device)
+        B, H, W, A = self.parallel_envs, self.max_y, self.max_x, len(self.agents)
+        if randomness is not None or self.rng == 'mt19937':
+            if randomness is None:  # wildfire.py:409-410
+                field = self.generator.generate(B, 3, (H, W), key='field')
+                agent = self.generator.generate(B, 5, (A, ), key='agent')
+            else:
+                field, agent = randomness
+            field = field.to(device=self.device, dtype=torch.float32).contiguous()
+            agent = agent.to(device=self.device, dtype=torch.float32).contiguous()
+            if field.numel() != 3 * B * H * W or agent.numel() != 5 * B * A:
+                raise ValueError('randomness tensors have the wrong size')
+            self._randomness_keepalive = (field, agent)
+            rc = self._lib.frz_wildfire_step(self._handle, actions_ptr, _capi.FRZ_RNG_INJECTED, field.data_ptr(), agent.data_ptr(), stream)
+        else:
+            rc = self._lib.frz_wildfire_step(self._handle, actions_ptr, _capi.FRZ_RNG_PHILOX, None, None, stream)
+        _capi.check(rc, 'frz_wildfire_step')
+        self._publish()
+        self.infos = {agent: {} for agent in self.agents}
+        self.infos['burnouts'] = self._burnouts
+        self.infos['putouts'] = self._putouts
+        return ({agent: self.observations[agent] for agent in self.agents}, self.rewards, self.terminations, self.truncations, self.infos)
+
+    @torch.no_grad()
+    def random_policy_actions(self, policy_seed: int, policy_step: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Device-side uniform random policy over each agent's current action space -> int32 ``[A, B, 2]``."""
+        out = self._actions if out is None else out
+        _capi.check(self._lib.frz_wildfire_random_policy(self._handle, policy_seed, policy_step, out.data_ptr(), stream_ptr(self.device)),
+                    'frz_wildfire_random_policy')
+        return out
+
+    # ------------------------------------------------------------------------------------------------ spaces
+    @torch.no_grad()
+    def action_space(self, agent: str) -> BatchedOneOfSpace:
+        """Per-env ``OneOf([fight task]*n + [noop])`` (wildfire.py:719-734, spaces/actions.py:23-41)."""
+        if self.show_bad_actions:
+            counts = self.environment_task_count
+        else:
+            counts = self.agent_task_count[self.possible_agents.index(agent)]
+        return BatchedOneOfSpace(counts, tail=[-1])
+
+    def observation_space(self, agent: str):
+        """Observation bounds per env (wildfire.py:736-753): dict of the static highs + the per-env task counts."""
+        return {
+            'self_high': self.agent_observation_bounds,
+            'others_high': tuple(b for b, keep in zip(self.agent_observation_bounds,
+                                                      (True, True, self.observe_other_power, self.observe_other_suppressant)) if keep),
+            'tasks_high': self.fire_observation_bounds,
+            'task_counts': self.environment_task_count,
+            'num_others': len(self.possible_agents) - 1,
+        }

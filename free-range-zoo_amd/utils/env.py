@@ -1,0 +1,152 @@
+"""Batched parallel environment base (mirrors the reference's L3 + L4 layers in one object).
+
+Reference: ``BatchedAECEnv`` (free_range_zoo/utils/env.py:18-359) wrapped by
+``batched_aec_to_batched_parallel_wrapper`` (free_range_zoo/utils/conversions.py:32-118).  The reference steps the
+AEC env once per agent and only the last call does work; here ``step(actions)`` is ONE fused HIP kernel launch over
+persistent struct-of-arrays HBM buffers, and the AEC facade (``env.aec_env``) is the same object.
+
+Behavioural notes kept from the reference:
+  * rewards / terminations / truncations / infos are dicts keyed by agent name; values are tensors over the env batch;
+  * ``finished = terminated | truncated`` with ``terminated`` / ``truncated`` = all agents' flags (env.py:331-359);
+  * once ALL envs are terminated or ALL are truncated, ``step`` changes nothing (env.py:211-213) and the adapter returns
+    the stale rewards summed once per agent (conversions.py:87-90) — reproduced on the device without a host sync.
+Returned tensors are views of persistent buffers: valid until the next ``step()`` / ``reset()``.
+"""
+import ctypes
+from typing import Any, Dict, List, Optional
+
+import torch
+
+from free_range_zoo_amd import _capi
+from free_range_zoo_amd.utils.configuration import Configuration
+from free_range_zoo_amd.utils.random_generator import RandomGenerator
+
+
+def stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def jagged(values: torch.Tensor, offsets: torch.Tensor, max_seqlen: Optional[int] = None, lengths: Optional[torch.Tensor] = None):
+    """torch.nested jagged tensor over (values, offsets) — O(1) Python objects instead of the reference's O(B) split."""
+    return torch.nested.nested_tensor_from_jagged(values, offsets, lengths=lengths, max_seqlen=max_seqlen)
+
+
+class BatchedParallelEnv:
+    """Common constructor / bookkeeping of the three domains."""
+
+    metadata: Dict[str, Any] = {}
+
+    def __init__(self,
+                 *args,
+                 configuration: Configuration = None,
+                 max_steps: int = 1,
+                 parallel_envs: int = 1,
+                 device: torch.device = torch.device('cuda'),
+                 render_mode: Optional[str] = None,
+                 log_directory: Optional[str] = None,
+                 single_seeding: bool = False,
+                 buffer_size: int = 0,
+                 override_initialization_check: bool = False,
+                 rng: str = 'mt19937',
+                 exact_shapes: bool = True,
+                 **kwargs):
+        """
+        Same keyword arguments as the reference (utils/env.py:21-34), plus:
+            rng: 'mt19937' — per-env streams identical to the reference's CPU generator for the same seeds (default);
+                 'philox'  — counter-based in-kernel Philox4x32-10 keyed by the env seed (no RNG state traffic).
+            exact_shapes: True — jagged outputs are sliced to their exact total length (one small host read per step,
+                 objects identical in shape to the reference's); False — sync-free: jagged outputs are persistent
+                 views over capacity buffers with explicit lengths.
+        """
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise ValueError('free_range_zoo_amd environments run on a GPU device only (device="cuda"); there is no CPU path')
+        if device.index is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        if log_directory is not None:
+            raise NotImplementedError('CSV/SQL logging is outside the step path and not implemented')
+        if rng not in ('mt19937', 'philox'):
+            raise ValueError("rng must be 'mt19937' or 'philox'")
+        self.parallel_envs = parallel_envs
+        self.max_steps = max_steps
+        self.device = device
+        self.render_mode = render_mode
+        self.log_directory = log_directory
+        self.single_seeding = single_seeding
+        self.buffer_size = buffer_size
+        self.rng = rng
+        self.exact_shapes = exact_shapes
+        self.log_description = None
+        self.logger = None
+        if configuration is not None:
+            self.config = configuration.to(device)
+            for key, value in vars(configuration).items():  # nested configurations become attributes (env.py:58-63)
+                if isinstance(value, Configuration):
+                    setattr(self, key, value)
+        self.generator = RandomGenerator(parallel_envs=parallel_envs, buffer_size=buffer_size, single_seeding=single_seeding,
+                                         device=device)
+        self._lib = _capi.lib()
+        self._handle = None
+        self._has_reset = False
+
+    # the reference exposes the AEC env under the parallel wrapper; one object plays both roles here
+    @property
+    def aec_env(self):
+        return self
+
+    @property
+    def unwrapped(self):
+        return self
+
+    @property
+    def num_agents(self) -> int:
+        return len(self.agents)
+
+    @property
+    def max_num_agents(self) -> int:
+        return len(self.possible_agents)
+
+    def _alloc(self, shape, dtype) -> torch.Tensor:
+        return torch.zeros(shape, dtype=dtype, device=self.device)
+
+    def _check_errors(self) -> None:
+        """Raise the data-dependent errors the kernels flagged (reads one word from the device)."""
+        flags = int(self._error_flags.item())
+        if flags:
+            self._error_flags.zero_()
+            names = [k for k, v in _capi.DEFINES.items() if k.startswith('FRZ_ERR_') and flags & v]
+            raise ValueError(f'invalid actions / internal error flagged by the device: {names}')
+
+    def check(self) -> None:
+        """Explicitly surface device-side error flags (the fast path never synchronises)."""
+        self._check_errors()
+
+    def _reset_options(self, options: Optional[Dict[str, Any]]) -> None:
+        if options is not None and options.get('max_steps') is not None:
+            self._set_max_steps(options['max_steps'])
+        self._log_label = options.get('log_label') if options else None
+        self.log_description = options.get('log_description') if options and options.get('log_description') else None
+
+    def observe(self, agent: Optional[str] = None):
+        """``observe(agent)`` (AEC, env.py:274-284) or ``observe()`` -> dict of all agents (adapter, conversions.py:101-108)."""
+        if agent is None:
+            return {name: self.observations[name] for name in self.agents}
+        return self.observations[agent]
+
+    def state(self):
+        return self._state
+
+    @property
+    def terminated(self) -> torch.Tensor:
+        return torch.all(torch.stack([self.terminations[agent] for agent in self.agents]), dim=0)
+
+    @property
+    def truncated(self) -> torch.Tensor:
+        return torch.all(torch.stack([self.truncations[agent] for agent in self.agents]), dim=0)
+
+    @property
+    def finished(self) -> torch.Tensor:
+        return torch.logical_or(self.terminated, self.truncated)
+
+    def close(self) -> None:
+        pass

@@ -1,0 +1,112 @@
+"""Per-environment random streams on the GPU (mirrors free_range_zoo/utils/random_generator.py:12-176).
+
+The reference keeps one torch CPU generator state per env and loops over envs in Python for every draw.  Here the
+same streams — MT19937 ``init_genrand(seed)``, float32 = (u32 & 0xFFFFFF) * 2**-24, env ``b`` drawing
+``events * prod(shape)`` consecutive floats per call — live in HBM (``[624, B]`` words, env innermost) and are advanced
+by the hand-written kernels of ``csrc/mt19937.hip``: the same seeds give bit-identical tensors to the reference's CPU path.
+"""
+from typing import Optional, Tuple
+
+import torch
+
+from free_range_zoo_amd import _capi
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class RandomGenerator:
+    """Random number generator for the environment (same public surface as the reference's class)."""
+
+    def __init__(self, parallel_envs: int, buffer_size: int = 0, single_seeding: bool = False,
+                 device: torch.device = torch.device('cuda')):
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise ValueError(f'Device {device} not supported: the HIP kernels need a GPU device (no CPU fallback)')
+        if single_seeding:
+            raise NotImplementedError('single_seeding (one shared stream for all envs) is not implemented yet')
+        self.parallel_envs = parallel_envs
+        self.buffer_size = buffer_size
+        self.single_seeding = single_seeding
+        self.device = device
+        self.seeds = torch.empty((parallel_envs, ), dtype=torch.int32, device=device)
+        self.generator_states = torch.empty((624, parallel_envs), dtype=torch.int32, device=device)  # uint32 words
+        self.generator_index = torch.zeros((parallel_envs, ), dtype=torch.int32, device=device)
+        self.buffer_count = {}
+        self.buffers = {}
+        self.has_been_seeded = False
+
+    @torch.no_grad()
+    def seed(self, seed: Optional[torch.Tensor] = None, partial_seeding: Optional[torch.Tensor] = None) -> None:
+        """Seed all envs (or the envs listed in ``partial_seeding``); random seeds below 1e8 if ``seed`` is None."""
+        if seed is None:
+            shape = self.seeds.shape if partial_seeding is None else torch.as_tensor(partial_seeding).shape
+            seed = torch.randint(100000000, shape, device=self.device)
+        seed = torch.as_tensor(seed, device=self.device).to(torch.int32)
+        lib = _capi.lib()
+        if partial_seeding is None:
+            self.seeds[:] = seed
+            indices_ptr, n = None, self.parallel_envs
+        else:
+            indices = torch.as_tensor(partial_seeding, device=self.device).to(torch.int32).contiguous().reshape(-1)
+            self.seeds[indices.long()] = seed
+            self._indices_keepalive = indices
+            indices_ptr, n = indices.data_ptr(), indices.numel()
+        _capi.check(lib.frz_mt19937_seed(self.generator_states.data_ptr(), self.generator_index.data_ptr(), self.seeds.data_ptr(),
+                                         indices_ptr, n, self.parallel_envs, _stream_ptr(self.device)), 'frz_mt19937_seed')
+        self.has_been_seeded = True
+
+    def _draw(self, events: int, count: int) -> torch.Tensor:
+        out = torch.empty((events, self.parallel_envs, count), dtype=torch.float32, device=self.device)
+        _capi.check(_capi.lib().frz_mt19937_generate(self.generator_states.data_ptr(), self.generator_index.data_ptr(), out.data_ptr(),
+                                                     events, count, self.parallel_envs, _stream_ptr(self.device)),
+                    'frz_mt19937_generate')
+        return out
+
+    @torch.no_grad()
+    def generate(self, parallel_envs: int, events: int, shape: Tuple[int], key: str = None) -> torch.Tensor:
+        """Random tensor ``[events, parallel_envs, *shape]``; buffered per ``key`` when ``buffer_size > 0``."""
+        if not self.has_been_seeded:
+            raise ValueError('The environment must be seeded before generating randomness')
+        if parallel_envs != self.parallel_envs:
+            raise ValueError('parallel_envs does not match the generator')
+        count = 1
+        for s in shape:
+            count *= int(s)
+        if key is None or self.buffer_size == 0:
+            return self._draw(events, count).reshape(events, parallel_envs, *shape)
+        buffer_key = (key, (parallel_envs, events, *shape))
+        if buffer_key not in self.buffers or self.buffer_count[buffer_key] >= self.buffer_size:
+            # each env draws buffer_size*events*count consecutive floats (random_generator.py:133-138)
+            block = self._draw(self.buffer_size * events, count)
+            self.buffers[buffer_key] = block.reshape(self.buffer_size, events, parallel_envs, *shape)
+            self.buffer_count[buffer_key] = 0
+        out = self.buffers[buffer_key][self.buffer_count[buffer_key]]
+        self.buffer_count[buffer_key] += 1
+        return out
+
+    def state_dict(self) -> dict:
+        return {
+            'parallel_envs': self.parallel_envs,
+            'buffer_size': self.buffer_size,
+            'single_seeding': self.single_seeding,
+            'device': str(self.device),
+            'seeds': self.seeds.clone(),
+            'generator_states': self.generator_states.clone(),
+            'generator_index': self.generator_index.clone(),
+            'buffer_count': dict(self.buffer_count),
+            'buffers': {k: v.clone() for k, v in self.buffers.items()},
+            'has_been_seeded': self.has_been_seeded,
+        }
+
+    def load_state_dict(self, state: dict) -> None:
+        self.parallel_envs = state['parallel_envs']
+        self.buffer_size = state['buffer_size']
+        self.single_seeding = state['single_seeding']
+        self.seeds.copy_(state['seeds'])
+        self.generator_states.copy_(state['generator_states'])
+        self.generator_index.copy_(state['generator_index'])
+        self.buffer_count = dict(state['buffer_count'])
+        self.buffers = {k: v.clone() for k, v in state['buffers'].items()}
+        self.has_been_seeded = state['has_been_seeded']

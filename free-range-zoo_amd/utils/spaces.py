@@ -1,0 +1,102 @@
+"""Count-based batched action spaces.
+
+The reference builds, per env, a ``free_range_rust.Space.OneOf([Discrete(1, start=s_t) for task t] + task-agnostic
+actions)`` (envs/*/env/spaces/actions.py) and callers sample it with ``Space.Vector(...).sample_nested()`` ->
+``[[member_index, member_value], ...]``.  free-range-rust is a native third-party dependency that is not part of the
+reference tree; this module gives the same *structure* (per-env member lists) computed from the task counts the HIP
+kernels maintain, with sampling done on the device.  Sampling distribution: uniform over the OneOf members (parity of
+the Rust sampler's stream is unpinned).
+"""
+from typing import List, Sequence
+
+import torch
+
+
+class Discrete:
+    def __init__(self, n: int, start: int = 0):
+        self.n, self.start = n, start
+
+    def __eq__(self, other):
+        return isinstance(other, Discrete) and (self.n, self.start) == (other.n, other.start)
+
+    def __repr__(self):
+        return f'Discrete({self.n}, start={self.start})'
+
+
+class OneOf:
+    def __init__(self, spaces: Sequence[Discrete]):
+        self.spaces = list(spaces)
+
+    def __len__(self):
+        return len(self.spaces)
+
+    def __eq__(self, other):
+        return isinstance(other, OneOf) and self.spaces == other.spaces
+
+    def __repr__(self):
+        return f'OneOf({self.spaces})'
+
+
+class BatchedOneOfSpace:
+    """Vector of per-env ``OneOf`` spaces described by (task member starts, task-agnostic tail)."""
+
+    def __init__(self, task_counts: torch.Tensor, tail: Sequence[int], task_starts: torch.Tensor = None,
+                 tail_mask: torch.Tensor = None):
+        """
+        task_counts: int tensor [B] — number of task members (Discrete(1, start=task_starts or 0)) per env
+        tail:        values of the task-agnostic members appended after the tasks (e.g. [-1] = noop)
+        task_starts: optional jagged start values per task member (rideshare: the passenger's state), padded [B, max]
+        tail_mask:   optional bool [B, len(tail)] — which tail members exist per env
+        """
+        self.task_counts = task_counts
+        self.tail = list(tail)
+        self.task_starts = task_starts
+        self.tail_mask = tail_mask
+
+    def __len__(self):
+        return int(self.task_counts.shape[0])
+
+    @property
+    def spaces(self) -> List[OneOf]:
+        """Materialise the per-env ``OneOf`` objects (host side, O(B); for inspection and tests)."""
+        counts = self.task_counts.tolist()
+        starts = self.task_starts.tolist() if self.task_starts is not None else None
+        masks = self.tail_mask.tolist() if self.tail_mask is not None else None
+        out = []
+        for b, n in enumerate(counts):
+            members = [Discrete(1, start=(starts[b][t] if starts is not None else 0)) for t in range(int(n))]
+            for j, value in enumerate(self.tail):
+                if masks is None or masks[b][j]:
+                    members.append(Discrete(1, start=value))
+            out.append(OneOf(members))
+        return out
+
+    @torch.no_grad()
+    def sample_nested(self, generator: torch.Generator = None) -> torch.Tensor:
+        """Uniform member per env -> int32 ``[B, 2]`` = (member index, member value), on the counts' device."""
+        counts = self.task_counts.to(torch.int64)
+        device = counts.device
+        B = counts.shape[0]
+        tail_values = torch.tensor(self.tail, dtype=torch.int64, device=device)
+        if self.tail_mask is not None:
+            n_tail = self.tail_mask.sum(dim=1).to(torch.int64)
+        else:
+            n_tail = torch.full((B, ), len(self.tail), dtype=torch.int64, device=device)
+        total = counts + n_tail
+        u = torch.rand((B, ), device=device, generator=generator)
+        member = torch.minimum((u * total).to(torch.int64), total - 1)
+        is_task = member < counts
+        if self.task_starts is not None and self.task_starts.shape[1] > 0:
+            idx = member.clamp(max=self.task_starts.shape[1] - 1).unsqueeze(1)
+            task_value = self.task_starts.to(torch.int64).gather(1, idx).squeeze(1)
+        else:
+            task_value = torch.zeros_like(member)
+        k = (member - counts).clamp(min=0)
+        if self.tail_mask is not None:  # k-th existing tail member
+            order = torch.cumsum(self.tail_mask.to(torch.int64), dim=1) - 1
+            pick = ((order == k.unsqueeze(1)) & self.tail_mask).to(torch.int64).argmax(dim=1)
+            tail_value = tail_values[pick]
+        else:
+            tail_value = tail_values[k.clamp(max=len(self.tail) - 1)]
+        value = torch.where(is_task, task_value, tail_value)
+        return torch.stack([member, value], dim=1).to(torch.int32)

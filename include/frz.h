@@ -163,6 +163,8 @@ typedef struct frz_wildfire_bufs {
     int64_t* bad_map_offsets;   /* [A][B+1] */
     int64_t* env_task_count;    /* [B] */
     int32_t* agent_task_count;  /* [A][B] */
+    uint8_t* frozen_scaled;     /* [B] 1 once the stale-reward scaling of a frozen step (utils/env.py:211-213 +
+                                   utils/conversions.py:87-90) was applied to env b; cleared by reset */
     /* per-env RNG state */
     int32_t* seeds;       /* [B]  (FRZ_RNG_PHILOX key) */
     uint32_t* mt_state;   /* [624][B]  FRZ_RNG_MT19937 only, else may be NULL */

@@ -77,3 +77,36 @@ float frz_oracle_philox_uniform(int32_t seed, uint32_t step, uint32_t draw, uint
     frz_oracle_philox4x32_10(ctr, key, out);
     return (float)(out[draw & 3u] >> 8) * (1.0f / 16777216.0f);
 }
+
+/* The randomness tensors a FRZ_RNG_PHILOX wildfire step consumes: stream e = field event e (draw = cell),
+ * stream 3 + e = agent event e (draw = agent); step = num_moves before the step. */
+void frz_oracle_wildfire_philox_randomness(const frz_wildfire_cfg* cfg, const int32_t* seeds, const int32_t* num_moves, float* field,
+                                           float* agent) {
+    const int64_t B = cfg->parallel_envs;
+    const int32_t HW = cfg->grid_height * cfg->grid_width, A = cfg->num_agents;
+    for (int64_t b = 0; b < B; ++b) {
+        for (int32_t e = 0; e < 3; ++e)
+            for (int32_t c = 0; c < HW; ++c)
+                field[(e * B + b) * HW + c] = frz_oracle_philox_uniform(seeds[b], (uint32_t)num_moves[b], (uint32_t)c, (uint32_t)e);
+        for (int32_t e = 0; e < 5; ++e)
+            for (int32_t a = 0; a < A; ++a)
+                agent[(e * B + b) * A + a] = frz_oracle_philox_uniform(seeds[b], (uint32_t)num_moves[b], (uint32_t)a, (uint32_t)(3 + e));
+    }
+}
+
+/* Uniform random policy over OneOf([task]*n + [noop]) (spaces/actions.py:23-41): member j = floor(u32 * (n+1) / 2^32)
+ * with u32 = word 0 of Philox(counter = (i lo, i hi, step lo, step hi), key = seed), i = a*B + b. */
+void frz_oracle_wildfire_random_policy(const frz_wildfire_cfg* cfg, const int32_t* agent_task_count, const int64_t* env_task_count,
+                                       uint64_t seed, uint64_t step, int32_t* actions) {
+    const int64_t B = cfg->parallel_envs;
+    for (int64_t i = 0; i < (int64_t)cfg->num_agents * B; ++i) {
+        const int32_t n = cfg->show_bad_actions ? (int32_t)env_task_count[i % B] : agent_task_count[i];
+        const uint32_t ctr[4] = {(uint32_t)i, (uint32_t)((uint64_t)i >> 32), (uint32_t)step, (uint32_t)(step >> 32)};
+        const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+        uint32_t out[4];
+        frz_oracle_philox4x32_10(ctr, key, out);
+        const int32_t j = (int32_t)(((uint64_t)out[0] * (uint64_t)(n + 1)) >> 32);
+        actions[i * 2 + 0] = j < n ? j : n;
+        actions[i * 2 + 1] = j < n ? 0 : -1;
+    }
+}

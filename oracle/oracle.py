@@ -141,3 +141,19 @@ def philox4x32_10(ctr, key):
 
 def philox_uniform(seed: int, step: int, draw: int, stream: int = 0) -> float:
     return float(lib().frz_oracle_philox_uniform(seed, step, draw, stream))
+
+
+def wildfire_philox_randomness(cfg, seeds: np.ndarray, num_moves: np.ndarray):
+    B, HW, A = cfg.parallel_envs, cfg.grid_height * cfg.grid_width, cfg.num_agents
+    field, agent = np.zeros((3, B, HW), np.float32), np.zeros((5, B, A), np.float32)
+    seeds, num_moves = np.ascontiguousarray(seeds, np.int32), np.ascontiguousarray(num_moves, np.int32)
+    lib().frz_oracle_wildfire_philox_randomness(ctypes.byref(cfg), _ptr(seeds), _ptr(num_moves), _ptr(field), _ptr(agent))
+    return field, agent
+
+
+def wildfire_random_policy(cfg, agent_task_count: np.ndarray, env_task_count: np.ndarray, seed: int, step: int) -> np.ndarray:
+    actions = np.zeros((cfg.num_agents, cfg.parallel_envs, 2), np.int32)
+    atc, etc = np.ascontiguousarray(agent_task_count, np.int32), np.ascontiguousarray(env_task_count, np.int64)
+    lib().frz_oracle_wildfire_random_policy(ctypes.byref(cfg), _ptr(atc), _ptr(etc), ctypes.c_uint64(seed), ctypes.c_uint64(step),
+                                            _ptr(actions))
+    return actions

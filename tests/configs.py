@@ -1,0 +1,96 @@
+"""Configurations used by the parity tests, built with THIS package's Configuration classes.
+
+Each mirrors (by value) a configuration the golden generator built with the reference's classes
+(tools/refharness/make_golden.py:wildfire_variants); tests assert that lowering them gives the recorded C structs."""
+from dataclasses import replace
+
+import numpy as np
+import torch
+
+from free_range_zoo_amd.envs.wildfire.env.structures import configuration as W
+from free_range_zoo_amd.envs.wildfire.configs.aaai_2024 import aaai_2025_ol_config
+
+
+def wildfire_non_stochastic() -> W.WildfireConfiguration:
+    """Values of the reference's tests/utils/wildfire_configs.py:non_stochastic()."""
+    reward = W.RewardConfiguration(fire_rewards=torch.tensor([[0, 0, 0], [20.0, 50.0, 20.0]], dtype=torch.float32),
+                                   bad_attack_penalty=-100.0, burnout_penalty=-1.0, termination_reward=0.0, termination_kappa=0.0,
+                                   localize_putouts=False)
+    fire = W.FireConfiguration(
+        fire_types=torch.tensor([[0, 0, 0], [1, 2, 1]], dtype=torch.int32), num_fire_states=5,
+        lit=torch.tensor([[0, 0, 0], [1, 1, 1]], dtype=torch.bool), intensity_increase_probability=1.0,
+        intensity_decrease_probability=1.0, extra_power_decrease_bonus=0.0, burnout_probability=1.0, base_spread_rate=3.0,
+        max_spread_rate=67.0, random_ignition_probability=0.0, cell_size=200.0, wind_direction=0.0,
+        ignition_temp=torch.full((2, 3), 2, dtype=torch.int32), initial_fuel=2)
+    agent = W.AgentConfiguration(
+        agents=torch.tensor([[0, 0], [0, 1], [0, 2]], dtype=torch.int32), fire_reduction_power=torch.tensor([1, 1, 1], dtype=torch.int32),
+        attack_range=torch.tensor([1, 1, 1], dtype=torch.int32), suppressant_states=3, initial_suppressant=2,
+        suppressant_decrease_probability=1.0, suppressant_refill_probability=1.0, initial_equipment_state=2,
+        equipment_states=torch.zeros((3, 3), dtype=torch.float32), repair_probability=1.0, degrade_probability=1.0,
+        critical_error_probability=0.0, initial_capacity=2, tank_switch_probability=1.0,
+        possible_capacities=torch.tensor([1, 2, 3], dtype=torch.float32), capacity_probabilities=torch.tensor([0.0, 1.0, 0.0]))
+    stoch = W.StochasticConfiguration(special_burnout_probability=False, suppressant_refill=False, suppressant_decrease=False,
+                                      tank_switch=False, critical_error=False, degrade=False, repair=False, fire_decrease=False,
+                                      fire_increase=False, fire_spread=False, realistic_fire_spread=False, random_fire_ignition=False,
+                                      fire_fuel=False)
+    return W.WildfireConfiguration(grid_width=3, grid_height=2, fire_config=fire, agent_config=agent, reward_config=reward,
+                                   stochastic_config=stoch)
+
+
+def wildfire_openness(level: int = 2, **stoch_over) -> W.WildfireConfiguration:
+    """BASELINE.json config 2: non_stochastic() layout + the AAAI openness stochastic block."""
+    base, aaai = wildfire_non_stochastic(), aaai_2025_ol_config(level)
+    fire = replace(aaai.fire_config, lit=base.fire_config.lit.clone())
+    agent = replace(base.agent_config, suppressant_decrease_probability=aaai.agent_config.suppressant_decrease_probability,
+                    suppressant_refill_probability=aaai.agent_config.suppressant_refill_probability)
+    return W.WildfireConfiguration(grid_width=3, grid_height=2, fire_config=fire, agent_config=agent, reward_config=base.reward_config,
+                                   stochastic_config=replace(aaai.stochastic_config, **stoch_over))
+
+
+def wildfire_rich() -> W.WildfireConfiguration:
+    g = torch.Generator().manual_seed(7)
+    H, Wd = 4, 5
+    types = torch.randint(0, 4, (H, Wd), generator=g, dtype=torch.int32)
+    lit = (torch.rand((H, Wd), generator=g) < 0.35) & (types > 0)
+    fire = W.FireConfiguration(
+        fire_types=types, num_fire_states=6, lit=lit, intensity_increase_probability=0.7, intensity_decrease_probability=0.6,
+        extra_power_decrease_bonus=0.17, burnout_probability=0.3, base_spread_rate=30.0, max_spread_rate=67.0,
+        random_ignition_probability=0.02, cell_size=200.0, wind_direction=1.1,
+        ignition_temp=torch.randint(1, 4, (H, Wd), generator=g, dtype=torch.int32), initial_fuel=2)
+    agent = W.AgentConfiguration(
+        agents=torch.tensor([[0, 0], [1, 3], [3, 4], [2, 1]], dtype=torch.int32),
+        fire_reduction_power=torch.tensor([1.0, 1.5, 0.75, 2.0], dtype=torch.float32),
+        attack_range=torch.tensor([1, 2, 1, 1], dtype=torch.int32), suppressant_states=4, initial_suppressant=2,
+        suppressant_decrease_probability=0.6, suppressant_refill_probability=0.5, initial_equipment_state=2,
+        equipment_states=torch.tensor([[-1.0, -0.5, -1.0], [0.0, 0.0, 0.0], [1.0, 0.25, 1.0]], dtype=torch.float32),
+        repair_probability=0.4, degrade_probability=0.3, critical_error_probability=0.1, initial_capacity=2,
+        tank_switch_probability=0.5, possible_capacities=torch.tensor([1, 2, 3], dtype=torch.float32),
+        capacity_probabilities=torch.tensor([0.25, 0.5, 0.25], dtype=torch.float32))
+    reward = W.RewardConfiguration(fire_rewards=torch.rand((H, Wd), generator=g) * 40 + 5, bad_attack_penalty=-3.5, burnout_penalty=0.0,
+                                   burnout_penalty_scaled=True, termination_reward=25.0, termination_kappa=4.0, localize_putouts=True)
+    stoch = W.StochasticConfiguration(special_burnout_probability=True, suppressant_refill=True, suppressant_decrease=True,
+                                      tank_switch=True, critical_error=True, degrade=True, repair=True, fire_increase=True,
+                                      fire_decrease=True, fire_spread=True, realistic_fire_spread=True, random_fire_ignition=True,
+                                      fire_fuel=True)
+    return W.WildfireConfiguration(grid_width=Wd, grid_height=H, fire_config=fire, agent_config=agent, reward_config=reward,
+                                   stochastic_config=stoch)
+
+
+def wildfire_rich_plain() -> W.WildfireConfiguration:
+    cfg = wildfire_rich()
+    cfg.reward_config = replace(cfg.reward_config, localize_putouts=False, burnout_penalty_scaled=False, burnout_penalty=-2.5)
+    cfg.stochastic_config = replace(cfg.stochastic_config, fire_fuel=False, special_burnout_probability=False)
+    return cfg
+
+
+# golden trajectory name -> (configuration builder, env kwargs)
+WILDFIRE_GOLDEN = {
+    'cfg1_nonstochastic': (wildfire_non_stochastic, {}),
+    'cfg2_openness': (wildfire_openness, {}),
+    'aaai_ol3_2agents': (lambda: aaai_2025_ol_config(3), {}),
+    'openness_bad_actions': (wildfire_openness, dict(show_bad_actions=True, observe_other_power=True)),
+    'openness_observe_all': (lambda: wildfire_openness(1), dict(observe_other_power=True, observe_other_suppressant=True)),
+    'rich_localized': (wildfire_rich, dict(observe_other_suppressant=True)),
+    'rich_plain_bad_actions': (wildfire_rich_plain, dict(show_bad_actions=True)),
+    'rich_no_truncation': (wildfire_rich, {}),
+}
