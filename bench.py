@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/s of wildfire_v0 random-policy rollouts on MI355X (BASELINE.json config 2).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of the hot path over one batch: the device-side random policy writes the actions, then the fused
+HIP kernel performs one ParallelEnv.step() for all parallel_envs (action decode, 7 transitions, rewards/termination,
+open action/observation space rebuild).  Episodes are max_steps = 50 long (BASELINE.md protocol); the reset between
+episodes is inside the timed region.  Inputs are resident in HBM; nothing crosses PCIe inside the timed region.
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+EPISODE = 50          # max_steps of the benchmark protocol
+BATCH_PER_GPU = 65536  # BASELINE.json configs[1]
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def algorithmic_bytes_per_env_step(HW, A, k, mean_tasks, mean_agent_tasks_sum, injected_randomness=False):
+    """reference-visible dtypes, every array read or written once per env-step."""
+    state = 2 * (3 * HW * 4 + 3 * A * 4)
+    io = 8 * A + 4 * A + 2 * A + 24
+    obs = 16 * A + 4 * k * A * (A - 1)
+    tasks = 32 * mean_tasks + 8
+    obs_map = 8 * mean_tasks + 8
+    act_maps = 8 * mean_agent_tasks_sum + 8 * A
+    counts = 8 + 4 * A
+    rnd = 4 * (3 * HW + 5 * A) if injected_randomness else 0
+    return state + io + obs + tasks + obs_map + act_maps + counts + rnd
+
+
+def cpu_baseline(budget_s=12.0):
+    """The CPU oracle (scalar C restatement, 1 thread) on a bounded sample of the same workload: same policy, same
+    Philox randomness, same step — reported beside the GPU number, never the thing measured above."""
+    import configs
+    from oracle import oracle
+    from free_range_zoo_amd.envs.wildfire.env.structures.configuration import to_cstruct
+    B = 16384
+    cfg = to_cstruct(configs.wildfire_openness(), B, EPISODE)
+    ref = oracle.WildfireOracle(cfg)
+    seeds = np.arange(B, dtype=np.int32)
+    oracle.lib()
+    steps, t_total = 0, 0.0
+    while t_total < budget_s:
+        ref.reset()
+        t0 = time.perf_counter()
+        for t in range(EPISODE):
+            actions = oracle.wildfire_random_policy(cfg, ref.agent_task_count, ref.env_task_count, 7, steps + t)
+            field, agent = oracle.wildfire_philox_randomness(cfg, seeds, ref.num_moves)
+            ref.step(actions, field, agent)
+        t_total += time.perf_counter() - t0
+        steps += EPISODE
+    return {
+        'value': B * steps / t_total,
+        'unit': 'env-steps/s',
+        'cores': 1,
+        'kind': 'port',
+        'sample': f'oracle (scalar C restatement): wildfire cfg2 B={B}, {steps // EPISODE} episodes x {EPISODE} steps incl. policy + Philox randomness, '
+                  f'{t_total:.1f} s on 1 of {os.cpu_count()} host cores',
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=500)
+    ap.add_argument('--warmup', type=int, default=150)
+    ap.add_argument('--rng', choices=['philox', 'mt19937'], default='philox')
+    ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='parallel_envs per GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', device_id=device)  # RCCL over xGMI
+
+    import configs
+    from free_range_zoo_amd.envs import wildfire_v0
+    B = args.batch
+    env = wildfire_v0.parallel_env(configuration=configs.wildfire_openness(), parallel_envs=B, max_steps=EPISODE, device=device,
+                                   rng=args.rng, exact_shapes=False)
+    A, HW = len(env.agents), env.max_y * env.max_x
+    base_seed = torch.arange(B, dtype=torch.int32) + rank * B  # global env index = rank * B + i
+    metrics = torch.zeros(A + 2, dtype=torch.float64, device=device)  # (sum reward per agent, env-steps, finished)
+    actions = torch.zeros((A, B, 2), dtype=torch.int32, device=device)
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    state = {'step': 0, 'episode': 0}
+
+    def one_step(events=None):
+        if state['step'] % EPISODE == 0:
+            if state['step'] > 0:
+                # episode end: the only collective of the job — a metrics reduction, nothing on the step path
+                metrics[:A] = env._cumulative.sum(dim=1, dtype=torch.float64)
+                metrics[A] = float(B * EPISODE)
+                metrics[A + 1] = env.finished.sum()
+                if dist is not None:
+                    dist.all_reduce(metrics)
+            env.reset(seed=base_seed + 1000003 * state['episode'])
+            state['episode'] += 1
+        env.random_policy_actions(policy_seed=20260104 + rank, policy_step=state['step'], out=actions)
+        if events is not None:
+            events[0].record()
+        env.step(actions)
+        if events is not None:
+            events[1].record()
+        state['step'] += 1
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    value = world * B * args.steps / elapsed
+
+    # ---- kernel-level pass (not part of `value`): HIP events around the fused step launch + mean task counts
+    n_probe = min(args.steps, 200)
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_probe)]
+    task_sum = torch.zeros(1 + A, dtype=torch.float64, device=device)
+    for i in range(n_probe):
+        one_step(pairs[i])
+        task_sum[0] += env.environment_task_count.sum()
+        task_sum[1:] += env.agent_task_count.sum(dim=1)
+    torch.cuda.synchronize(device)
+    kernel_ms = sorted(p[0].elapsed_time(p[1]) for p in pairs)
+    kernel_ms_avg = float(np.mean(kernel_ms))
+    kernel_ms_med = float(np.median(kernel_ms))
+    mean_tasks = float(task_sum[0].item()) / (n_probe * B)
+    mean_agent_tasks = float(task_sum[1:].sum().item()) / (n_probe * B)
+    per_env = algorithmic_bytes_per_env_step(HW, A, env._k, mean_tasks, mean_agent_tasks, injected_randomness=(args.rng == 'mt19937'))
+    achieved = per_env * B / (kernel_ms_avg * 1e-3) / 1e9
+    traffic = None
+    traffic_file = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
+    if os.path.exists(traffic_file):
+        try:
+            traffic = json.load(open(traffic_file)).get('wf_step_kernel_bytes_per_launch')
+        except Exception:  # noqa: BLE001
+            traffic = None
+
+    if rank == 0:
+        env.check()
+        line = {
+            'metric': 'env steps/sec (batch x agents) wildfire random-policy',
+            'value': value,
+            'unit': 'env-steps/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'i32/f32',
+            'data': 'synthetic',
+            'config': {'workload': f'wildfire_v0 cfg2 (2x3 grid, 3 agents, agent+task openness on), batch={B} per GPU, '
+                                   f'max_steps={EPISODE}, device random policy, rng={args.rng}, reset inside timed region',
+                       'parallel_envs_per_gpu': B, 'agents': A, 'sharding': f'env-batch axis x{world}, no step-path collective'},
+            'agent_steps_per_s': value * A,
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': traffic, 'kernel': 'wf_step_kernel<8,4>', 'kernel_ms_avg': kernel_ms_avg,
+                         'kernel_ms_median': kernel_ms_med, 'algorithmic_bytes_per_env_step': per_env,
+                         'mean_tasks_per_env': mean_tasks, 'mean_agent_tasks_per_env': mean_agent_tasks},
+            'reference_cpu_env_steps_per_s': {'value': 21112, 'source': 'BASELINE.md §2: unmodified reference, 8 vCPU, B=65536 (survey container)'},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -411,7 +411,11 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(const WfParams p) {
             for (int a = 0; a < AMAX; ++a)
                 if (a < A) terminated = terminated && term[a] != 0;
             const bool newly = !terminated && dead;
-            const float penalty = __fmul_rn(p.termination_kappa, logf((float)nb + 1.0f));
+            // correctly rounded float32 log via double (matches the oracle bit for bit; the reference's torch.log is
+            // a <=1-ulp float32 log).  Only evaluated by wavefronts that hold a newly terminated env.
+            float log_burnouts = 0.0f;
+            if (newly && p.termination_kappa != 0.0f) log_burnouts = (float)log((double)nb + 1.0);
+            const float penalty = __fmul_rn(p.termination_kappa, log_burnouts);
             float term_reward = __fsub_rn(p.termination_reward, penalty);
             term_reward = term_reward < 0.0f ? 0.0f : term_reward;
             const int n_burn = __popcll(burned), n_put = __popcll(put_out);

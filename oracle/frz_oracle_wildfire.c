@@ -421,7 +421,9 @@ int frz_oracle_wildfire_step(const frz_wildfire_cfg* cfg, frz_oracle_wildfire_bu
         for (int32_t a = 0; a < A; ++a) terminated = terminated && s->terminations[(int64_t)a * B + b];
         const int newly = !terminated && dead;
         /* termination_reward - kappa*log(num_burnouts + 1) clamped at 0, with num_burnouts BEFORE this step (:573-580) */
-        const float penalty = cfg->termination_kappa * logf((float)s->num_burnouts[b] + 1.0f);
+        /* torch.log(float32) is a <=1-ulp vectorised logf; the restatement (and the HIP kernel) round a double log to
+         * float32 so that both agree bit for bit with each other (and within 1 ulp of the reference) */
+        const float penalty = cfg->termination_kappa * (float)log((double)s->num_burnouts[b] + 1.0);
         float term_reward = cfg->termination_reward - penalty;
         term_reward = term_reward < 0.0f ? 0.0f : term_reward;
         for (int32_t a = 0; a < A; ++a) {
