@@ -25,10 +25,11 @@ _lib = None
 _P = ctypes.c_void_p
 SIGNATURES = {
     'frz_abi_version': (ctypes.c_int, []),
-    'frz_wildfire_workspace_bytes': (ctypes.c_int64, [_P]),
     'frz_wildfire_create': (ctypes.c_int, [_P, ctypes.POINTER(_P)]),
     'frz_wildfire_destroy': (None, [_P]),
-    'frz_wildfire_bind': (ctypes.c_int, [_P, _P]),
+    'frz_wildfire_arena_bytes': (ctypes.c_int64, [_P]),
+    'frz_wildfire_bind': (ctypes.c_int, [_P, _P, _P]),
+    'frz_wildfire_get_bufs': (ctypes.c_int, [_P, _P]),
     'frz_wildfire_reset': (ctypes.c_int, [_P, _P]),
     'frz_wildfire_rebuild': (ctypes.c_int, [_P, _P]),
     'frz_wildfire_step': (ctypes.c_int, [_P, _P, ctypes.c_int, _P, _P, _P]),

@@ -6,152 +6,191 @@
 //   -> update_observations + update_actions (wildfire.py:586-717) with the variable-length task lists compacted by
 //      wavefront prefix sums and a single-pass inter-workgroup prefix hand-off.
 //
-// Memory: state is struct-of-arrays with the env index innermost (include/frz.h) so every per-field access of a
-// wavefront is one contiguous 256-byte segment.  A lane keeps its whole env (grid cells, agents) in registers; the
-// lit-fire set and the per-agent attackable sets are 64-bit cell masks.  Nothing is re-read: algorithmic bytes per
-// env-step are each touched once.
+// Memory: ONE device arena per env object.  Every per-env 4-byte array is a row of a [rows][B] block (env index
+// innermost), so a wavefront touches one contiguous 256-byte segment per field and the kernel needs a single base
+// pointer; the configuration lives in a device block read through the scalar cache; per-lane-indexed tables
+// (in-range cell sets, equipment bonuses) sit in LDS.  A lane keeps its env (grid cells, agents) in registers; the lit
+// set and the per-agent attackable sets are cell bitmasks.  Nothing is re-read: the algorithmic bytes per env-step
+//  are each touched once.
 //
 // HBM-bound integer/byte work: no MFMA.  Built with -ffp-contract=off (float32 ops round once, like eager torch).
 #include "frz_device.h"
 
 #include "../../include/frz.h"
 
-#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
+#include <type_traits>
 
 namespace {
 
 using frz::kBlock;
 
-constexpr int kMaxChannels = FRZ_MAX_AGENTS + 3;  // F, F_a..., not-terminated, not-truncated
-constexpr int kTotalsStride = 32;                 // uint32 words per totals slot (128 B)
+constexpr int kTotalsStride = 32;  // uint32 words per totals slot (128 B)
 
 enum Mode { kStep = 0, kRebuild = 1 };
 
-struct WfParams {
-    frz_wildfire_bufs buf;
-    // workspace carve-up
-    uint32_t* epoch;    // [1]   launch epoch, bumped by the workgroup that owns the last chunk
-    uint32_t* totals;   // [2][kTotalsStride] batch totals of the scan channels, slot = epoch & 1
-    uint64_t* agg;      // [nchunks][nch]  per-chunk channel sums   (granules)
-    uint64_t* prefix;   // [nchunks][nch]  inclusive prefix after a round's last chunk (granules)
-    const int32_t* actions;
-    const float* field_rand;
-    const float* agent_rand;
-    int B, H, W, HW, A, S, K, nchunks, nch, others_k, max_steps, num_fire_states;
-    int stochastic_increase, stochastic_burnouts, stochastic_decrease, use_fire_fuel, stochastic_supp_decrease, stochastic_refill,
-        stochastic_switch, stochastic_repair, stochastic_degrade, critical_error, show_bad_actions, observe_other_power,
-        observe_other_suppressant, burnout_penalty_scaled, localize_putouts, track_cumulative;
+enum Flag : uint32_t {
+    kStochIncrease = 1u << 0, kStochBurnouts = 1u << 1, kStochDecrease = 1u << 2, kUseFuel = 1u << 3, kStochSuppDecrease = 1u << 4,
+    kStochRefill = 1u << 5, kStochSwitch = 1u << 6, kStochRepair = 1u << 7, kStochDegrade = 1u << 8, kCritical = 1u << 9,
+    kShowBad = 1u << 10, kObsPower = 1u << 11, kObsSupp = 1u << 12, kPenaltyScaled = 1u << 13, kLocalize = 1u << 14,
+    kTrackCumulative = 1u << 15, kTruncate = 1u << 16,
+};
+
+// Device-resident configuration block at arena offset 0 (uniform address -> scalar loads at the point of use).
+struct WfDev {
+    int32_t B, H, W, HW, A, S, K, nchunks, nch, others_k, max_steps, num_fire_states;
+    uint32_t flags;
+    int32_t initial_fuel, initial_equipment;
+    float initial_suppressant, initial_capacity;
     float p_increase, p_burnout, p_decrease, decrease_bonus, p_supp_decrease, p_refill, p_switch, p_repair, p_degrade, p_critical;
     float spread_n, spread_w, spread_e, spread_s, random_ignition;
     float bad_attack_penalty, burnout_penalty, termination_reward, termination_kappa;
-    float eq[FRZ_MAX_EQUIPMENT_STATES][3];
     float caps[FRZ_MAX_CAPACITIES], cum[FRZ_MAX_CAPACITIES];
-    int ay[FRZ_MAX_AGENTS], ax[FRZ_MAX_AGENTS];
+    float eq[FRZ_MAX_EQUIPMENT_STATES][4];  // (capacity, power, range, -)
+    int32_t ay[FRZ_MAX_AGENTS], ax[FRZ_MAX_AGENTS];
     float power[FRZ_MAX_AGENTS];
     uint64_t range_mask[FRZ_MAX_AGENTS][FRZ_MAX_EQUIPMENT_STATES];  // cells agent a reaches at equipment state s
     uint64_t has_n, has_w, has_e, has_s;                            // cells that have a north/west/east/south neighbour
     float fire_rewards[FRZ_MAX_CELLS];
-    int ignition[FRZ_MAX_CELLS];
-    int cell_yx[FRZ_MAX_CELLS];  // (y << 16) | x
+    int32_t ignition[FRZ_MAX_CELLS];
+    int32_t cell_yx[FRZ_MAX_CELLS];  // (y << 16) | x
+    int32_t fire_types[FRZ_MAX_CELLS], lit[FRZ_MAX_CELLS];
+    // row indices of the [rows][B] blocks
+    int32_t r_fires, r_intensity, r_fuel, r_supp, r_cap, r_equip, r_moves, r_burnouts, r_rewards, r_cum, r_atc, r_seeds, r_mti, n_rows4;
+    int32_t q_burnouts, q_putouts, q_etc, n_rows8;
+    int32_t u_term, u_trunc, u_frozen, n_rows1;
+    // byte offsets from the arena base
+    int64_t off_rows4, off_rows8, off_rows1, off_obs_self, off_obs_others, off_task_values, off_task_offsets, off_obs_map,
+        off_act_values, off_act_offsets, off_bad_values, off_bad_offsets, off_mt_state, off_actions, off_error, off_epoch, off_totals,
+        off_agg, off_prefix, off_rand_field, off_rand_agent, total_bytes;
+};
+static_assert(sizeof(WfDev) <= 8192, "configuration block too large");
+constexpr int64_t kDevBlockBytes = 8192;
+
+struct WfArgs {
+    char* arena;
+    const int32_t* actions;
+    const float* field_rand;
+    const float* agent_rand;
 };
 
-struct FillParams {
-    frz_wildfire_bufs buf;
-    int B, HW, A, initial_fuel, initial_equipment;
-    float initial_suppressant, initial_capacity;
-    int fire_types[FRZ_MAX_CELLS], lit[FRZ_MAX_CELLS], ignition[FRZ_MAX_CELLS];
-};
+// 4-byte row access with a 32-bit element index: lets the compiler address as (uniform base) + (32-bit lane offset)
+template <typename T>
+__device__ __forceinline__ T& at32(T* base, uint32_t index) {
+    return *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + (uint64_t)(index * (uint32_t)sizeof(T)));
+}
 
 __device__ __forceinline__ float clamp01(float p) {
     p = p < 0.0f ? 0.0f : p;
     return p > 1.0f ? 1.0f : p;
 }
 
-template <int N>
-__device__ __forceinline__ float table3(const float (&tab)[N][3], int n, int index, int col) {
-    float v = tab[0][col];
-#pragma unroll
-    for (int s = 1; s < N; ++s)
-        if (s < n) v = index == s ? tab[s][col] : v;
-    return v;
-}
-
-__device__ __forceinline__ uint64_t mask_lookup(const uint64_t (&tab)[FRZ_MAX_EQUIPMENT_STATES], int n, int index) {
-    uint64_t v = tab[0];
-#pragma unroll
-    for (int s = 1; s < FRZ_MAX_EQUIPMENT_STATES; ++s)
-        if (s < n) v = index == s ? tab[s] : v;
-    return v;
+template <typename M>
+__device__ __forceinline__ int popc(M m) {
+    if constexpr (sizeof(M) == 8)
+        return __popcll(m);
+    else
+        return __popc(m);
 }
 
 // wildfire.py:347-354 + utils/env.py:137-160: state from the configuration, bookkeeping zeroed.
-__global__ void __launch_bounds__(kBlock) wf_fill_kernel(const FillParams p) {
+__global__ void __launch_bounds__(kBlock) wf_fill_kernel(char* arena) {
+    const WfDev& d = *reinterpret_cast<const WfDev*>(arena);
     const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (b >= p.B) return;
-    const int64_t B = p.B;
-    for (int c = 0; c < p.HW; ++c) {
-        const int type = p.fire_types[c];
-        const int f = p.lit[c] ? type : -type;
-        p.buf.fires[c * B + b] = f;
-        p.buf.intensity[c * B + b] = p.lit[c] ? p.ignition[c] : 0;
-        p.buf.fuel[c * B + b] = f != 0 ? p.initial_fuel : 0;
+    const int64_t B = d.B;
+    if (b >= B) return;
+    int32_t* rows = reinterpret_cast<int32_t*>(arena + d.off_rows4);
+    float* rowsf = reinterpret_cast<float*>(arena + d.off_rows4);
+    int64_t* rows8 = reinterpret_cast<int64_t*>(arena + d.off_rows8);
+    uint8_t* rows1 = reinterpret_cast<uint8_t*>(arena + d.off_rows1);
+    for (int c = 0; c < d.HW; ++c) {
+        const int type = d.fire_types[c];
+        const int f = d.lit[c] ? type : -type;
+        rows[(d.r_fires + c) * B + b] = f;
+        rows[(d.r_intensity + c) * B + b] = d.lit[c] ? d.ignition[c] : 0;
+        rows[(d.r_fuel + c) * B + b] = f != 0 ? d.initial_fuel : 0;
     }
-    for (int a = 0; a < p.A; ++a) {
-        p.buf.suppressants[a * B + b] = p.initial_suppressant;
-        p.buf.capacity[a * B + b] = p.initial_capacity;
-        p.buf.equipment[a * B + b] = p.initial_equipment;
-        p.buf.rewards[a * B + b] = 0.0f;
-        if (p.buf.cumulative_rewards) p.buf.cumulative_rewards[a * B + b] = 0.0f;
-        p.buf.terminations[a * B + b] = 0;
-        p.buf.truncations[a * B + b] = 0;
+    for (int a = 0; a < d.A; ++a) {
+        rowsf[(d.r_supp + a) * B + b] = d.initial_suppressant;
+        rowsf[(d.r_cap + a) * B + b] = d.initial_capacity;
+        rows[(d.r_equip + a) * B + b] = d.initial_equipment;
+        rowsf[(d.r_rewards + a) * B + b] = 0.0f;
+        rowsf[(d.r_cum + a) * B + b] = 0.0f;
+        rows1[(d.u_term + a) * B + b] = 0;
+        rows1[(d.u_trunc + a) * B + b] = 0;
     }
-    p.buf.num_moves[b] = 0;
-    p.buf.num_burnouts[b] = 0;
-    p.buf.burnouts[b] = 0;
-    p.buf.putouts[b] = 0;
-    p.buf.frozen_scaled[b] = 0;
+    rows[d.r_moves * B + b] = 0;
+    rows[d.r_burnouts * B + b] = 0;
+    rows8[d.q_burnouts * B + b] = 0;
+    rows8[d.q_putouts * B + b] = 0;
+    rows1[d.u_frozen * B + b] = 0;
 }
 
-template <int CMAX, int AMAX, int RNG, int MODE>
-__global__ void __launch_bounds__(kBlock) wf_step_kernel(const WfParams p) {
-    __shared__ uint64_t s_wave_scan[frz::kWaves][(AMAX + 1 + 3) / 4];
+// EXACT: the grid has exactly CMAX cells and AMAX agents (every loop bound is a compile-time constant).
+template <int CMAX, int AMAX, bool EXACT, int RNG, int MODE>
+__global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ arena, const WfDev* __restrict__ dev,
+                                                          const int32_t* __restrict__ actions, const float* __restrict__ field_rand,
+                                                          const float* __restrict__ agent_rand) {
+    using mask_t = std::conditional_t<(CMAX <= 32), uint32_t, uint64_t>;
+    constexpr int PW = (AMAX + 1 + 3) / 4;                                // packed scan words (four 16-bit channels each)
+    constexpr int NCHP = AMAX + 3 <= 8 ? 8 : (AMAX + 3 <= 16 ? 16 : 32);  // scan channels padded to a power of two
+
+    __shared__ uint64_t s_wave_scan[frz::kWaves][PW];
     __shared__ uint32_t s_wave_live[frz::kWaves][2];
     __shared__ uint32_t s_reduce[frz::kWaves][32];
     __shared__ uint32_t s_prefix[32];
+    __shared__ mask_t s_range[AMAX][FRZ_MAX_EQUIPMENT_STATES];  // per-lane lookup: cells in range at equipment state s
+    __shared__ float s_eq[FRZ_MAX_EQUIPMENT_STATES][4];         // per-lane lookup: equipment bonuses
+    __shared__ float s_caps[FRZ_MAX_CAPACITIES];                // per-lane lookup: possible capacities
 
-    constexpr int PW = (AMAX + 1 + 3) / 4;  // packed scan words (four 16-bit channels each)
-    constexpr int NCHP = AMAX + 3 <= 8 ? 8 : (AMAX + 3 <= 16 ? 16 : 32);  // channels padded to a power of two
+    const WfDev& d = *dev;  // lives at arena offset 0; never written by a kernel
     const int tid = threadIdx.x, lane = frz::lane_id(), wave = frz::wave_id();
-    const int64_t B = p.B;
-    const int HW = p.HW, A = p.A, W = p.W;
-    const int nch = p.nch;  // A + 3
+    const int64_t B = d.B;
+    const uint32_t Bu = (uint32_t)d.B;
+    const int HW = EXACT ? CMAX : d.HW, A = EXACT ? AMAX : d.A, W = d.W;
+    const int nch = d.nch;  // A + 3
     const int ch_nt = A + 1, ch_ntr = A + 2;
+    const uint32_t flags = d.flags;
 
-    const uint32_t epoch = __hip_atomic_load(p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t tag = epoch + 1u;  // never 0 on a zero-filled workspace
-    const uint32_t* prev = p.totals + ((epoch + 1u) & 1u) * kTotalsStride;
-    uint32_t* cur = p.totals + (epoch & 1u) * kTotalsStride;
+    if (tid < AMAX * FRZ_MAX_EQUIPMENT_STATES)
+        (&s_range[0][0])[tid] = (mask_t)d.range_mask[tid / FRZ_MAX_EQUIPMENT_STATES][tid % FRZ_MAX_EQUIPMENT_STATES];
+    if (tid < FRZ_MAX_EQUIPMENT_STATES * 4) (&s_eq[0][0])[tid] = (&d.eq[0][0])[tid];
+    if (tid < FRZ_MAX_CAPACITIES) s_caps[tid] = d.caps[tid];
+
+    uint32_t* const epoch_ptr = reinterpret_cast<uint32_t*>(arena + d.off_epoch);
+    uint32_t* const totals = reinterpret_cast<uint32_t*>(arena + d.off_totals);
+    const uint32_t epoch = __hip_atomic_load(epoch_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t tag = epoch + 1u;  // never 0 on a zero-filled arena
+    const uint32_t* prev = totals + ((epoch + 1u) & 1u) * kTotalsStride;
+    uint32_t* cur = totals + (epoch & 1u) * kTotalsStride;
+
+    int32_t* const rows = reinterpret_cast<int32_t*>(arena + d.off_rows4);
+    float* const rowsf = reinterpret_cast<float*>(arena + d.off_rows4);
+    int64_t* const rows8 = reinterpret_cast<int64_t*>(arena + d.off_rows8);
+    uint8_t* const rows1 = reinterpret_cast<uint8_t*>(arena + d.off_rows1);
 
     // utils/env.py:211-213 — every per-agent step() is a no-op once ALL envs are terminated or ALL are truncated.
     bool frozen = false;
     if (MODE == kStep) frozen = prev[ch_nt] == 0u || prev[ch_ntr] == 0u;
+    __syncthreads();
 
-    for (int chunk = blockIdx.x; chunk < p.nchunks; chunk += gridDim.x) {
+    for (int chunk = blockIdx.x; chunk < d.nchunks; chunk += gridDim.x) {
         const int64_t b = (int64_t)chunk * kBlock + tid;
         const bool active = b < B;
+        const int64_t bl = active ? b : B - 1;  // inactive lanes of the last chunk shadow the last env (stores are masked)
 
         if (frozen) {
             // The parallel adapter (utils/conversions.py:87-90) then adds the stale aec rewards once per agent call.
-            if (active && !p.buf.frozen_scaled[b]) {
+            if (active && !at32(rows1, (uint32_t)(d.u_frozen) * Bu + (uint32_t)b)) {
                 for (int a = 0; a < A; ++a) {
-                    const float r = p.buf.rewards[a * B + b];
+                    const float r = at32(rowsf, (uint32_t)((d.r_rewards + a)) * Bu + (uint32_t)b);
                     float acc = 0.0f;
-                    for (int k = 0; k < A; ++k) acc = acc + r;
-                    p.buf.rewards[a * B + b] = acc;
+                    for (int j = 0; j < A; ++j) acc = acc + r;
+                    at32(rowsf, (uint32_t)((d.r_rewards + a)) * Bu + (uint32_t)b) = acc;
                 }
-                p.buf.frozen_scaled[b] = 1;
+                at32(rows1, (uint32_t)(d.u_frozen) * Bu + (uint32_t)b) = 1;
             }
             continue;
         }
@@ -160,23 +199,29 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(const WfParams p) {
         int f[CMAX], in[CMAX], fu[CMAX];
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) {
-            const bool on = active && c < HW;
-            f[c] = on ? p.buf.fires[c * B + b] : 0;
-            in[c] = on ? p.buf.intensity[c * B + b] : 0;
-            fu[c] = on ? p.buf.fuel[c * B + b] : 0;
+            f[c] = in[c] = fu[c] = 0;
+            if (c < HW) {
+                f[c] = at32(rows, (uint32_t)((d.r_fires + c)) * Bu + (uint32_t)bl);
+                in[c] = at32(rows, (uint32_t)((d.r_intensity + c)) * Bu + (uint32_t)bl);
+                fu[c] = at32(rows, (uint32_t)((d.r_fuel + c)) * Bu + (uint32_t)bl);
+            }
         }
         float supp[AMAX], capa[AMAX];
         int eqs[AMAX];
-        uint8_t term[AMAX];
 #pragma unroll
         for (int a = 0; a < AMAX; ++a) {
-            const bool on = active && a < A;
-            supp[a] = on ? p.buf.suppressants[a * B + b] : 0.0f;
-            capa[a] = on ? p.buf.capacity[a * B + b] : 0.0f;
-            eqs[a] = on ? p.buf.equipment[a * B + b] : 0;
-            term[a] = on ? p.buf.terminations[a * B + b] : (uint8_t)1;
+            supp[a] = capa[a] = 0.0f;
+            eqs[a] = 0;
+            if (a < A) {
+                supp[a] = at32(rowsf, (uint32_t)((d.r_supp + a)) * Bu + (uint32_t)bl);
+                capa[a] = at32(rowsf, (uint32_t)((d.r_cap + a)) * Bu + (uint32_t)bl);
+                eqs[a] = at32(rows, (uint32_t)((d.r_equip + a)) * Bu + (uint32_t)bl);
+            }
         }
-        uint8_t trunc0 = active ? p.buf.truncations[b] : (uint8_t)1;
+        // agents share one termination / truncation value (wildfire.py:579, utils/env.py:231-233): row 0 is read,
+        // all A rows are written
+        bool term = at32(rows1, (uint32_t)(d.u_term) * Bu + (uint32_t)bl) != 0;
+        bool trunc = at32(rows1, (uint32_t)(d.u_trunc) * Bu + (uint32_t)bl) != 0;
 
         float rew[AMAX];
         uint32_t err = 0;
@@ -185,13 +230,16 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(const WfParams p) {
             int act_idx[AMAX], act_id[AMAX];
 #pragma unroll
             for (int a = 0; a < AMAX; ++a) {
-                const bool on = active && a < A;
-                const int2 v = on ? reinterpret_cast<const int2*>(p.actions)[a * B + b] : make_int2(0, -1);
-                act_idx[a] = v.x;
-                act_id[a] = v.y;
+                act_idx[a] = 0;
+                act_id[a] = -1;
+                if (a < A) {
+                    const int2 v = reinterpret_cast<const int2*>(actions)[a * B + bl];
+                    act_idx[a] = v.x;
+                    act_id[a] = v.y;
+                }
             }
-            int nm = active ? p.buf.num_moves[b] : 0;
-            int nb = active ? p.buf.num_burnouts[b] : 0;
+            int nm = at32(rows, (uint32_t)(d.r_moves) * Bu + (uint32_t)bl);
+            int nb = at32(rows, (uint32_t)(d.r_burnouts) * Bu + (uint32_t)bl);
 
             // ---------------------------------------------------------------------------------- randomness
             float r_field[3][CMAX], r_agent[5][AMAX];
@@ -199,18 +247,24 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(const WfParams p) {
 #pragma unroll
                 for (int e = 0; e < 3; ++e)
 #pragma unroll
-                    for (int c = 0; c < CMAX; ++c) r_field[e][c] = (active && c < HW) ? p.field_rand[((int64_t)e * B + b) * HW + c] : 1.0f;
+                    for (int c = 0; c < CMAX; ++c) r_field[e][c] = c < HW ? field_rand[((int64_t)e * B + bl) * HW + c] : 1.0f;
 #pragma unroll
                 for (int e = 0; e < 5; ++e)
 #pragma unroll
-                    for (int a = 0; a < AMAX; ++a) r_agent[e][a] = (active && a < A) ? p.agent_rand[((int64_t)e * B + b) * A + a] : 1.0f;
+                    for (int a = 0; a < AMAX; ++a) r_agent[e][a] = a < A ? agent_rand[((int64_t)e * B + bl) * A + a] : 1.0f;
             } else {
-                // FRZ_RNG_PHILOX: stream e = field event e (draw = cell), stream 3 + e = agent event e (draw = agent)
-                const uint32_t seed = active ? (uint32_t)p.buf.seeds[b] : 0u;
+                // FRZ_RNG_PHILOX: stream e = field event e (draw = cell), stream 3 + e = agent event e (draw = agent);
+                // events whose every use is disabled by the configuration are not generated
+                const uint32_t seed = (uint32_t)at32(rows, (uint32_t)(d.r_seeds) * Bu + (uint32_t)bl);
+                const bool need[5] = {(flags & kStochSuppDecrease) != 0, (flags & (kStochRepair | kStochDegrade | kCritical)) != 0,
+                                      (flags & kStochRefill) != 0, d.K > 1, (flags & kStochSwitch) != 0};
 #pragma unroll
                 for (int e = 0; e < 3; ++e)
 #pragma unroll
                     for (int q = 0; q < (CMAX + 3) / 4; ++q) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (q * 4 + j < CMAX) r_field[e][q * 4 + j] = 1.0f;
                         if (q * 4 < HW) {
                             const frz::Philox4 w = frz::philox4x32_10((uint32_t)q, (uint32_t)nm, (uint32_t)e, 0u, seed, 0x46525A00u);
 #pragma unroll
@@ -222,7 +276,10 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(const WfParams p) {
                 for (int e = 0; e < 5; ++e)
 #pragma unroll
                     for (int q = 0; q < (AMAX + 3) / 4; ++q) {
-                        if (q * 4 < A) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (q * 4 + j < AMAX) r_agent[e][q * 4 + j] = 0.0f;
+                        if (q * 4 < A && need[e]) {
                             const frz::Philox4 w = frz::philox4x32_10((uint32_t)q, (uint32_t)nm, (uint32_t)(3 + e), 0u, seed, 0x46525A00u);
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
@@ -235,15 +292,16 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(const WfParams p) {
             // The action mapping of the previous rebuild is a pure function of the state it was built from, which is
             // the state just loaded: attackable set of agent a = lit fires within its (equipment-adjusted) range,
             // non-empty only while it has suppressant (wildfire.py:604-623).
-            uint64_t lit0 = 0;
+            mask_t lit0 = 0;
 #pragma unroll
-            for (int c = 0; c < CMAX; ++c) lit0 |= (uint64_t)(f[c] > 0) << c;
+            for (int c = 0; c < CMAX; ++c) lit0 |= (mask_t)(f[c] > 0) << c;
 
             float ap[CMAX];
 #pragma unroll
             for (int c = 0; c < CMAX; ++c) ap[c] = 0.0f;
             bool users[AMAX], refill[AMAX];
             int hit[AMAX];
+            const bool show_bad = (flags & kShowBad) != 0;
 #pragma unroll
             for (int a = 0; a < AMAX; ++a) {
                 users[a] = false;
@@ -251,139 +309,129 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(const WfParams p) {
                 hit[a] = -1;
                 rew[a] = 0.0f;
                 if (a < A) {
-                    const uint64_t ok = supp[a] > 0.0f ? (lit0 & mask_lookup(p.range_mask[a], p.S, eqs[a])) : 0ull;
+                    const mask_t ok = supp[a] > 0.0f ? (lit0 & s_range[a][eqs[a]]) : (mask_t)0;
                     refill[a] = act_id[a] == -1;
                     // quirk wildfire.py:434-435: an agent with no attackable task in ANY env of the batch is skipped
                     const bool skipped = prev[1 + a] == 0u;
-                    const bool fight = active && !refill[a] && !skipped;
-                    const uint64_t sel = p.show_bad_actions ? lit0 : ok;
-                    const bool valid = act_idx[a] >= 0 && act_idx[a] < __popcll(sel);
+                    const bool fight = !refill[a] && !skipped;
+                    const mask_t sel = show_bad ? lit0 : ok;
+                    const bool valid = act_idx[a] >= 0 && act_idx[a] < popc(sel);
                     int target = 0, seen = 0;
 #pragma unroll
                     for (int c = 0; c < CMAX; ++c) {
-                        const int bit = (int)((sel >> c) & 1ull);
+                        const int bit = (int)((sel >> c) & 1);
                         target = (bit && seen == act_idx[a]) ? c : target;
                         seen += bit;
                     }
-                    const bool attackable = ((ok >> target) & 1ull) != 0ull;
-                    const bool good = fight && valid && (!p.show_bad_actions || attackable);
-                    if (fight && !valid) err |= FRZ_ERR_BAD_ACTION_INDEX;
-                    const float power = p.power[a] + table3(p.eq, p.S, eqs[a], 1);
+                    const bool attackable = ((ok >> target) & 1) != 0;
+                    const bool good = fight && valid && (!show_bad || attackable);
+                    if (fight && !valid && active) err |= FRZ_ERR_BAD_ACTION_INDEX;
+                    const float power = d.power[a] + s_eq[eqs[a]][1];
 #pragma unroll
                     for (int c = 0; c < CMAX; ++c) ap[c] = ap[c] + ((good && target == c) ? power : 0.0f);  // agent order
                     users[a] = good;
                     hit[a] = good ? target : -1;
-                    rew[a] = (fight && !good) ? p.bad_attack_penalty : 0.0f;  // assignment, :477
+                    rew[a] = (fight && !good) ? d.bad_attack_penalty : 0.0f;  // assignment, :477
                 }
             }
 
             // ---------------------------------------------- agent transitions (suppressant/equipment/capacity)
-            bool increased[AMAX];
 #pragma unroll
             for (int a = 0; a < AMAX; ++a) {
-                increased[a] = false;
                 if (a < A) {
                     // transitions/suppressant_decrease.py:56-61
-                    const bool dec = users[a] && (!p.stochastic_supp_decrease || r_agent[0][a] < p.p_supp_decrease);
+                    const bool dec = users[a] && (!(flags & kStochSuppDecrease) || r_agent[0][a] < d.p_supp_decrease);
                     float s = dec ? supp[a] - 1.0f : supp[a];
                     s = s < 0.0f ? 0.0f : s;
                     // transitions/equipment.py:51-75 (masks from the value before any write)
-                    const int e0 = eqs[a], top = p.S - 1;
+                    const int e0 = eqs[a], top = d.S - 1;
                     const bool pristine = e0 == top, damaged = e0 == 0, inter = !pristine && !damaged;
                     const float r1 = r_agent[1][a];
-                    const bool repairs = p.stochastic_repair ? (damaged && r1 < p.p_repair) : damaged;
-                    const bool crit = p.critical_error && pristine && r1 < p.p_critical;
-                    bool degr = p.stochastic_degrade ? ((pristine || inter) && r1 < p.p_degrade) : (inter || pristine);
+                    const bool repairs = (flags & kStochRepair) ? (damaged && r1 < d.p_repair) : damaged;
+                    const bool crit = (flags & kCritical) && pristine && r1 < d.p_critical;
+                    bool degr = (flags & kStochDegrade) ? ((pristine || inter) && r1 < d.p_degrade) : (inter || pristine);
                     degr = degr && !crit;
                     int e = repairs ? top : e0;
                     e = crit ? 0 : e;
                     e = degr ? e - 1 : e;
                     // transitions/suppressant_refill.py:63-70 (bonus from the NEW equipment state)
-                    const bool inc = refill[a] && (!p.stochastic_refill || r_agent[2][a] < p.p_refill);
-                    s = inc ? capa[a] + table3(p.eq, p.S, e, 0) : s;
-                    // transitions/capacity.py:52-64
+                    const bool inc = refill[a] && (!(flags & kStochRefill) || r_agent[2][a] < d.p_refill);
+                    s = inc ? capa[a] + s_eq[e][0] : s;
+                    // transitions/capacity.py:52-64: bucketize(r, cumsum) = #{j : cum[j] < r} (cum padded with +inf,
+                    // clamped to the last capacity where the reference would raise IndexError)
                     int ci = 0;
 #pragma unroll
-                    for (int k = 0; k < FRZ_MAX_CAPACITIES; ++k)
-                        if (k < p.K) ci += r_agent[3][a] > p.cum[k] ? 1 : 0;
-                    ci = ci > p.K - 1 ? p.K - 1 : ci;
-                    float new_max = p.caps[0];
-#pragma unroll
-                    for (int k = 1; k < FRZ_MAX_CAPACITIES; ++k)
-                        if (k < p.K) new_max = ci == k ? p.caps[k] : new_max;
-                    const bool sw = inc && (!p.stochastic_switch || r_agent[4][a] < p.p_switch);
+                    for (int j = 0; j < FRZ_MAX_CAPACITIES; ++j) ci += r_agent[3][a] > d.cum[j] ? 1 : 0;
+                    ci = ci > d.K - 1 ? d.K - 1 : ci;
+                    const float new_max = s_caps[ci];
+                    const bool sw = inc && (!(flags & kStochSwitch) || r_agent[4][a] < d.p_switch);
                     const float bonus = s - capa[a];
                     capa[a] = sw ? new_max : capa[a];
                     s = sw ? new_max + bonus : s;
                     supp[a] = s;
                     eqs[a] = e;
-                    increased[a] = inc;
                 }
             }
-            (void)increased;
 
             // ------------------------------------------------------------ fire increase / decrease per cell
-            uint64_t burned = 0, put_out = 0, lit2 = 0;
-            const int almost_state = p.num_fire_states - 2, burnout_state = p.num_fire_states - 1;
+            mask_t burned = 0, put_out = 0, lit2 = 0;
+            const int almost_state = d.num_fire_states - 2, burnout_state = d.num_fire_states - 1;
+            const float p_unmet = (flags & kStochIncrease) ? d.p_increase : 1.0f;
+            const float p_almost = (flags & kStochBurnouts) ? d.p_burnout : d.p_increase;  // fire_increase.py:77-80
 #pragma unroll
             for (int c = 0; c < CMAX; ++c) {
                 if (c < HW) {
-                    // transitions/fire_increase.py:61-91
-                    {
+                    {  // transitions/fire_increase.py:61-91
                         const int required = f[c] >= 0 ? f[c] : 0;
                         const float diff = (float)required - ap[c];
                         const bool lit = f[c] > 0 && in[c] > 0;
                         const bool unmet = diff > 0.0f && lit;
                         const bool almost = unmet && in[c] == almost_state;
-                        const bool increasing = unmet && !almost;
-                        float prob = 0.0f;
-                        prob = increasing ? (p.stochastic_increase ? p.p_increase : 1.0f) : prob;
-                        prob = almost ? (p.stochastic_burnouts ? p.p_burnout : p.p_increase) : prob;
+                        float prob = unmet ? (almost ? p_almost : p_unmet) : 0.0f;
                         prob = clamp01(prob);
                         const bool inc = r_field[0][c] < prob;
                         in[c] += inc ? 1 : 0;
                         const bool bo = inc && in[c] >= burnout_state;
                         f[c] = bo ? -f[c] : f[c];
                         fu[c] = bo ? (fu[c] - 1 < 0 ? 0 : fu[c] - 1) : fu[c];
-                        burned |= (uint64_t)bo << c;
+                        burned |= (mask_t)bo << c;
                     }
-                    // transitions/fire_decrease.py:56-77: p = p_dec + ((-1 * diff) * bonus), each op rounded
-                    {
+                    {  // transitions/fire_decrease.py:56-77: p = p_dec + ((-1 * diff) * bonus), each op rounded
                         const int required = f[c] >= 0 ? f[c] : 0;
                         const float diff = (float)required - ap[c];
                         const bool lit = f[c] > 0 && in[c] > 0;
                         const bool met = diff <= 0.0f && lit;
-                        const float stoch_p = __fadd_rn(p.p_decrease, __fmul_rn(__fmul_rn(-1.0f, diff), p.decrease_bonus));
-                        float prob = met ? (p.stochastic_decrease ? stoch_p : 1.0f) : 0.0f;
+                        const float stoch_p = __fadd_rn(d.p_decrease, __fmul_rn(__fmul_rn(-1.0f, diff), d.decrease_bonus));
+                        float prob = met ? ((flags & kStochDecrease) ? stoch_p : 1.0f) : 0.0f;
                         prob = clamp01(prob);
                         const bool dec = r_field[1][c] < prob;
                         in[c] -= dec ? 1 : 0;
                         const bool po = dec && in[c] <= 0;
                         f[c] = po ? -f[c] : f[c];
                         fu[c] = po ? fu[c] - 1 : fu[c];  // unclamped, :75
-                        put_out |= (uint64_t)po << c;
+                        put_out |= (mask_t)po << c;
                     }
-                    lit2 |= (uint64_t)(f[c] > 0 && in[c] > 0) << c;
+                    lit2 |= (mask_t)(f[c] > 0 && in[c] > 0) << c;
                 }
             }
             // ---------------------------------------- fire spread stencil (transitions/fire_spreads.py:44-57)
             {
-                const uint64_t from_n = (lit2 << W) & p.has_n, from_s = (lit2 >> W) & p.has_s;
-                const uint64_t from_w = (lit2 << 1) & p.has_w, from_e = (lit2 >> 1) & p.has_e;
+                const mask_t from_n = (lit2 << W) & (mask_t)d.has_n, from_s = (lit2 >> W) & (mask_t)d.has_s;
+                const mask_t from_w = (lit2 << 1) & (mask_t)d.has_w, from_e = (lit2 >> 1) & (mask_t)d.has_e;
 #pragma unroll
                 for (int c = 0; c < CMAX; ++c) {
                     if (c < HW) {
                         float prob = 0.0f;  // conv2d accumulation order: N, W, E, S
-                        prob = __fadd_rn(prob, ((from_n >> c) & 1ull) ? p.spread_n : 0.0f);
-                        prob = __fadd_rn(prob, ((from_w >> c) & 1ull) ? p.spread_w : 0.0f);
-                        prob = __fadd_rn(prob, ((from_e >> c) & 1ull) ? p.spread_e : 0.0f);
-                        prob = __fadd_rn(prob, ((from_s >> c) & 1ull) ? p.spread_s : 0.0f);
+                        prob = __fadd_rn(prob, ((from_n >> c) & 1) ? d.spread_n : 0.0f);
+                        prob = __fadd_rn(prob, ((from_w >> c) & 1) ? d.spread_w : 0.0f);
+                        prob = __fadd_rn(prob, ((from_e >> c) & 1) ? d.spread_e : 0.0f);
+                        prob = __fadd_rn(prob, ((from_s >> c) & 1) ? d.spread_s : 0.0f);
                         bool unlit = f[c] < 0 && in[c] == 0;
-                        unlit = unlit && (!p.use_fire_fuel || fu[c] > 0);
-                        prob = unlit ? __fadd_rn(prob, p.random_ignition) : 0.0f;
+                        unlit = unlit && (!(flags & kUseFuel) || fu[c] > 0);
+                        prob = unlit ? __fadd_rn(prob, d.random_ignition) : 0.0f;
                         const bool spread = r_field[2][c] < prob;
                         f[c] = spread ? -f[c] : f[c];
-                        in[c] = spread ? p.ignition[c] : in[c];
+                        in[c] = spread ? d.ignition[c] : in[c];
                     }
                 }
             }
@@ -395,50 +443,45 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(const WfParams p) {
 #pragma unroll
             for (int c = 0; c < CMAX; ++c) {
                 if (c < HW) {
-                    fire_reward_sum = __fadd_rn(fire_reward_sum, ((put_out >> c) & 1ull) ? p.fire_rewards[c] : 0.0f);
-                    const float pen = p.burnout_penalty_scaled ? __fmul_rn(-1.0f, p.fire_rewards[c]) : p.burnout_penalty;
-                    burnout_total = __fadd_rn(burnout_total, ((burned >> c) & 1ull) ? pen : 0.0f);
+                    const float fr = d.fire_rewards[c];
+                    fire_reward_sum = __fadd_rn(fire_reward_sum, ((put_out >> c) & 1) ? fr : 0.0f);
+                    const float pen = (flags & kPenaltyScaled) ? __fmul_rn(-1.0f, fr) : d.burnout_penalty;
+                    burnout_total = __fadd_rn(burnout_total, ((burned >> c) & 1) ? pen : 0.0f);
                     fuel_sum += fu[c];
                     any_fire = any_fire || f[c] > 0;
                 }
             }
             bool dead = !any_fire;
-            if (p.use_fire_fuel) dead = dead && fuel_sum <= 0;
+            if (flags & kUseFuel) dead = dead && fuel_sum <= 0;
 #pragma unroll
             for (int c = 0; c < CMAX; ++c) f[c] = dead ? 0 : f[c];  // :570
-            bool terminated = true;
-#pragma unroll
-            for (int a = 0; a < AMAX; ++a)
-                if (a < A) terminated = terminated && term[a] != 0;
-            const bool newly = !terminated && dead;
+            const bool newly = !term && dead;
             // correctly rounded float32 log via double (matches the oracle bit for bit; the reference's torch.log is
             // a <=1-ulp float32 log).  Only evaluated by wavefronts that hold a newly terminated env.
             float log_burnouts = 0.0f;
-            if (newly && p.termination_kappa != 0.0f) log_burnouts = (float)log((double)nb + 1.0);
-            const float penalty = __fmul_rn(p.termination_kappa, log_burnouts);
-            float term_reward = __fsub_rn(p.termination_reward, penalty);
+            if (newly && d.termination_kappa != 0.0f) log_burnouts = (float)log((double)nb + 1.0);
+            const float penalty = __fmul_rn(d.termination_kappa, log_burnouts);
+            float term_reward = __fsub_rn(d.termination_reward, penalty);
             term_reward = term_reward < 0.0f ? 0.0f : term_reward;
-            const int n_burn = __popcll(burned), n_put = __popcll(put_out);
+            const int n_burn = popc(burned), n_put = popc(put_out);
             nb += n_burn;
             nm += 1;
-            const bool truncated = p.max_steps >= 0 ? nm >= p.max_steps : trunc0 != 0;
-            trunc0 = (uint8_t)truncated;
+            trunc = (flags & kTruncate) ? nm >= d.max_steps : trunc;
+            term = term || dead;
 
+            const bool localize = (flags & kLocalize) != 0;
 #pragma unroll
             for (int a = 0; a < AMAX; ++a) {
                 if (a < A) {
-                    float add;
-                    if (p.localize_putouts) {
-                        float mine = 0.0f;
+                    float base_reward = fire_reward_sum;
+                    if (localize) {
+                        base_reward = 0.0f;
 #pragma unroll
-                        for (int c = 0; c < CMAX; ++c) mine = (hit[a] == c && ((put_out >> c) & 1ull)) ? p.fire_rewards[c] : mine;
-                        add = __fadd_rn(mine, burnout_total);
-                    } else {
-                        add = __fadd_rn(fire_reward_sum, burnout_total);
+                        for (int c = 0; c < CMAX; ++c)
+                            if (c < HW) base_reward = (hit[a] == c && ((put_out >> c) & 1)) ? d.fire_rewards[c] : base_reward;
                     }
-                    rew[a] = __fadd_rn(rew[a], add);
+                    rew[a] = __fadd_rn(rew[a], __fadd_rn(base_reward, burnout_total));
                     rew[a] = newly ? __fadd_rn(rew[a], term_reward) : rew[a];
-                    term[a] = (uint8_t)(term[a] | (dead ? 1 : 0));
                 }
             }
 
@@ -447,46 +490,48 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(const WfParams p) {
 #pragma unroll
                 for (int c = 0; c < CMAX; ++c)
                     if (c < HW) {
-                        p.buf.fires[c * B + b] = f[c];
-                        p.buf.intensity[c * B + b] = in[c];
-                        p.buf.fuel[c * B + b] = fu[c];
+                        at32(rows, (uint32_t)((d.r_fires + c)) * Bu + (uint32_t)b) = f[c];
+                        at32(rows, (uint32_t)((d.r_intensity + c)) * Bu + (uint32_t)b) = in[c];
+                        at32(rows, (uint32_t)((d.r_fuel + c)) * Bu + (uint32_t)b) = fu[c];
                     }
+                const bool track = (flags & kTrackCumulative) != 0, write_trunc = (flags & kTruncate) != 0;
 #pragma unroll
                 for (int a = 0; a < AMAX; ++a)
                     if (a < A) {
-                        p.buf.suppressants[a * B + b] = supp[a];
-                        p.buf.capacity[a * B + b] = capa[a];
-                        p.buf.equipment[a * B + b] = eqs[a];
-                        p.buf.rewards[a * B + b] = rew[a];
-                        p.buf.terminations[a * B + b] = term[a];
-                        if (p.max_steps >= 0) p.buf.truncations[a * B + b] = trunc0;
-                        if (p.track_cumulative) p.buf.cumulative_rewards[a * B + b] = __fadd_rn(p.buf.cumulative_rewards[a * B + b], rew[a]);
+                        at32(rowsf, (uint32_t)((d.r_supp + a)) * Bu + (uint32_t)b) = supp[a];
+                        at32(rowsf, (uint32_t)((d.r_cap + a)) * Bu + (uint32_t)b) = capa[a];
+                        at32(rows, (uint32_t)((d.r_equip + a)) * Bu + (uint32_t)b) = eqs[a];
+                        at32(rowsf, (uint32_t)((d.r_rewards + a)) * Bu + (uint32_t)b) = rew[a];
+                        at32(rows1, (uint32_t)((d.u_term + a)) * Bu + (uint32_t)b) = (uint8_t)term;
+                        if (write_trunc) at32(rows1, (uint32_t)((d.u_trunc + a)) * Bu + (uint32_t)b) = (uint8_t)trunc;
+                        if (track) at32(rowsf, (uint32_t)((d.r_cum + a)) * Bu + (uint32_t)b) = __fadd_rn(at32(rowsf, (uint32_t)((d.r_cum + a)) * Bu + (uint32_t)b), rew[a]);
                     }
-                p.buf.num_moves[b] = nm;
-                p.buf.num_burnouts[b] = nb;
-                p.buf.burnouts[b] = n_burn;
-                p.buf.putouts[b] = n_put;
+                at32(rows, (uint32_t)(d.r_moves) * Bu + (uint32_t)b) = nm;
+                at32(rows, (uint32_t)(d.r_burnouts) * Bu + (uint32_t)b) = nb;
+                at32(rows8, (uint32_t)(d.q_burnouts) * Bu + (uint32_t)b) = n_burn;
+                at32(rows8, (uint32_t)(d.q_putouts) * Bu + (uint32_t)b) = n_put;
             }
         }
 
         // ======================================================================================================
         // update_observations + update_actions on the new state (wildfire.py:586-717)
         // ======================================================================================================
-        uint64_t lit1 = 0;
+        mask_t lit1 = 0;
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c) lit1 |= (uint64_t)(f[c] > 0) << c;
-        uint64_t ok1[AMAX];
+        for (int c = 0; c < CMAX; ++c) lit1 |= (mask_t)(f[c] > 0) << c;
+        lit1 = active ? lit1 : (mask_t)0;
+        mask_t ok1[AMAX];
         uint64_t packed[PW];
 #pragma unroll
         for (int w = 0; w < PW; ++w) packed[w] = 0;
-        const int F = __popcll(lit1);
+        const int F = popc(lit1);
         packed[0] = (uint64_t)F;
 #pragma unroll
         for (int a = 0; a < AMAX; ++a) {
             ok1[a] = 0;
             if (a < A) {
-                ok1[a] = supp[a] > 0.0f ? (lit1 & mask_lookup(p.range_mask[a], p.S, eqs[a])) : 0ull;
-                packed[(a + 1) >> 2] |= (uint64_t)__popcll(ok1[a]) << (16 * ((a + 1) & 3));
+                ok1[a] = supp[a] > 0.0f ? (lit1 & s_range[a][eqs[a]]) : (mask_t)0;
+                packed[(a + 1) >> 2] |= (uint64_t)popc(ok1[a]) << (16 * ((a + 1) & 3));
             }
         }
 
@@ -494,9 +539,8 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(const WfParams p) {
         uint64_t incl[PW];
 #pragma unroll
         for (int w = 0; w < PW; ++w) incl[w] = frz::wave_inclusive_scan(packed[w]);
-        const bool alive = active && !(term[0] != 0);  // agents share one termination value (wildfire.py:579)
-        const uint32_t live_nt = (uint32_t)__popcll(__ballot(alive));
-        const uint32_t live_ntr = (uint32_t)__popcll(__ballot(active && trunc0 == 0));
+        const uint32_t live_nt = (uint32_t)__popcll(__ballot(active && !term));
+        const uint32_t live_ntr = (uint32_t)__popcll(__ballot(active && !trunc));
         __syncthreads();  // LDS reuse across chunks of a persistent workgroup
         if (lane == 63) {
 #pragma unroll
@@ -511,169 +555,186 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(const WfParams p) {
             base[w] = 0;
             block_total[w] = 0;
 #pragma unroll
-            for (int k = 0; k < frz::kWaves; ++k) {
-                const uint64_t t = s_wave_scan[k][w];
-                base[w] += k < wave ? t : 0ull;
+            for (int j = 0; j < frz::kWaves; ++j) {
+                const uint64_t t = s_wave_scan[j][w];
+                base[w] += j < wave ? t : 0ull;
                 block_total[w] += t;
             }
         }
 
         // publish this chunk's channel sums, then (while the hand-off is in flight) do the dense observation stores
+        uint64_t* const agg = reinterpret_cast<uint64_t*>(arena + d.off_agg);
+        uint64_t* const prefix = reinterpret_cast<uint64_t*>(arena + d.off_prefix);
         const int round_first = chunk - blockIdx.x;  // first chunk of this round
+        uint32_t my_total = 0;                         // this chunk's sum of channel `tid` (tid < nch)
         if (tid < nch) {
-            uint32_t v;
-            if (tid <= A)
-                v = (uint32_t)((block_total[tid >> 2] >> (16 * (tid & 3))) & 0xFFFFull);
-            else {
-                v = 0;
+            if (tid <= A) {
+                uint64_t word = block_total[0];
+#pragma unroll
+                for (int w = 1; w < PW; ++w) word = (tid >> 2) == w ? block_total[w] : word;
+                my_total = (uint32_t)((word >> (16 * (tid & 3))) & 0xFFFFull);
+            } else {
                 const int which = tid - ch_nt;
 #pragma unroll
-                for (int k = 0; k < frz::kWaves; ++k) v += s_wave_live[k][which];
+                for (int j = 0; j < frz::kWaves; ++j) my_total += s_wave_live[j][which];
             }
-            frz::granule_store(p.agg + (int64_t)chunk * nch + tid, tag, v);
+            frz::granule_store(agg + (int64_t)chunk * nch + tid, tag, my_total);
         }
 
         if (active) {
             // agent observations (wildfire.py:677-681, 704-716)
+            float* const obs_self = reinterpret_cast<float*>(arena + d.off_obs_self);
+            float* const obs_others = reinterpret_cast<float*>(arena + d.off_obs_others);
+            const int width = (A - 1) * d.others_k;
+            const bool op = (flags & kObsPower) != 0, os = (flags & kObsSupp) != 0;
 #pragma unroll
             for (int a = 0; a < AMAX; ++a)
                 if (a < A) {
-                    reinterpret_cast<float4*>(p.buf.obs_self)[a * B + b] =
-                        make_float4((float)p.ay[a], (float)p.ax[a], p.power[a], supp[a]);
-                    float* others = p.buf.obs_others + (a * B + b) * (int64_t)((A - 1) * p.others_k);
+                    reinterpret_cast<float4*>(obs_self)[a * B + b] = make_float4((float)d.ay[a], (float)d.ax[a], d.power[a], supp[a]);
+                    float* others = obs_others + (a * B + b) * (int64_t)width;
                     int col = 0;
 #pragma unroll
                     for (int o = 0; o < AMAX; ++o)
                         if (o < A && o != a) {
-                            others[col++] = (float)p.ay[o];
-                            others[col++] = (float)p.ax[o];
-                            if (p.observe_other_power) others[col++] = p.power[o];
-                            if (p.observe_other_suppressant) others[col++] = supp[o];
+                            others[col++] = (float)d.ay[o];
+                            others[col++] = (float)d.ax[o];
+                            if (op) others[col++] = d.power[o];
+                            if (os) others[col++] = supp[o];
                         }
-                    p.buf.agent_task_count[a * B + b] = __popcll(ok1[a]);
+                    at32(rows, (uint32_t)((d.r_atc + a)) * Bu + (uint32_t)b) = popc(ok1[a]);
                 }
-            p.buf.env_task_count[b] = F;
+            at32(rows8, (uint32_t)(d.q_etc) * Bu + (uint32_t)b) = F;
         }
 
         // -------------------------------------------------- inter-workgroup exclusive prefix (single pass)
-        // chunk j needs sum of channel sums of all chunks < j: the chunks of this round that precede it (their
-        // workgroups are co-resident and have published or are about to) + the inclusive prefix the previous
-        // round's last chunk published.
+        // chunk j needs the channel sums of all chunks < j: those of this round that precede it (their workgroups
+        // are co-resident and have published or are about to) + the inclusive prefix the previous round's last
+        // chunk published.  Thread t sums channel (t % NCHP) over predecessors t / NCHP, t / NCHP + PP, ...; loads
+        // are issued in batches so one L2 round trip covers the window when the granules are already there.
         bool timed_out = false;
         uint32_t acc = 0;
         {
-            // thread t sums channel (t % NCHP) over predecessors t / NCHP, t / NCHP + PP, ...; loads are issued in
-            // batches so one L2 round trip covers the whole window when the granules are already published
             const int ch = tid & (NCHP - 1), slot = tid / NCHP;
             constexpr int PP = kBlock / NCHP, UNR = 8;
             for (int first = round_first; first < chunk; first += PP * UNR) {
-                uint64_t g[UNR];
+                uint32_t part = 0;
+                for (int spin = 0;; ++spin) {  // bounded: every granule of the window must carry this launch's tag
+                    bool all = true;
+                    part = 0;
 #pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const int pred = first + u * PP + slot;
-                    g[u] = (pred < chunk && ch < nch) ? frz::granule_load(p.agg + (int64_t)pred * nch + ch) : ((uint64_t)tag << 32);
+                    for (int u = 0; u < UNR; ++u) {
+                        const int pred = first + u * PP + slot;
+                        if (pred < chunk && ch < nch) {
+                            const uint64_t g = frz::granule_load(agg + (int64_t)pred * nch + ch);
+                            all = all && (uint32_t)(g >> 32) == tag;
+                            part += (uint32_t)g;
+                        }
+                    }
+                    if (all) break;
+                    if (spin >= (1 << 22)) {
+                        timed_out = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
                 }
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    uint32_t v = (uint32_t)g[u];
-                    if ((uint32_t)(g[u] >> 32) != tag) v = frz::granule_wait(p.agg + (int64_t)(first + u * PP + slot) * nch + ch, tag, &timed_out);
-                    acc += v;
-                }
+                acc += part;
             }
-            if (round_first > 0 && tid < nch) acc += frz::granule_wait(p.prefix + (int64_t)(round_first - 1) * nch + tid, tag, &timed_out);
+            if (round_first > 0 && tid < nch) acc += frz::granule_wait(prefix + (int64_t)(round_first - 1) * nch + tid, tag, &timed_out);
 #pragma unroll
-            for (int d = NCHP; d < 64; d <<= 1) acc += __shfl_xor(acc, d, 64);
+            for (int dd = NCHP; dd < 64; dd <<= 1) acc += __shfl_xor(acc, dd, 64);
             if (lane < NCHP) s_reduce[wave][lane] = acc;
         }
         __syncthreads();
         if (tid < nch) {
             uint32_t s = 0;
 #pragma unroll
-            for (int k = 0; k < frz::kWaves; ++k) s += s_reduce[k][tid];
+            for (int j = 0; j < frz::kWaves; ++j) s += s_reduce[j][tid];
             s_prefix[tid] = s;
+            const bool round_last = blockIdx.x == gridDim.x - 1 || chunk == d.nchunks - 1;
+            if (round_last) {
+                frz::granule_store(prefix + (int64_t)chunk * nch + tid, tag, s + my_total);
+                if (chunk == d.nchunks - 1) cur[tid] = s + my_total;  // batch totals, read by the next launch
+            }
         }
         __syncthreads();
         if (timed_out) err |= FRZ_ERR_SCAN_TIMEOUT;
 
-        const bool round_last = blockIdx.x == gridDim.x - 1 || chunk == p.nchunks - 1;
-        if (round_last && tid < nch) {
-            uint32_t mine;
-            if (tid <= A)
-                mine = (uint32_t)((block_total[tid >> 2] >> (16 * (tid & 3))) & 0xFFFFull);
-            else {
-                mine = 0;
-#pragma unroll
-                for (int k = 0; k < frz::kWaves; ++k) mine += s_wave_live[k][tid - ch_nt];
-            }
-            const uint32_t inclusive = s_prefix[tid] + mine;
-            frz::granule_store(p.prefix + (int64_t)chunk * nch + tid, tag, inclusive);
-            if (chunk == p.nchunks - 1) cur[tid] = inclusive;  // batch totals, read by the next launch
-        }
-
         // ------------------------------------------------------------------ jagged stores (values + offsets)
         if (active) {
             const int64_t cap = B * HW;
-            const int64_t off_f = (int64_t)s_prefix[0] + (int64_t)(((base[0] + incl[0] - packed[0]) >> 0) & 0xFFFFull);
-            p.buf.task_offsets[b] = off_f;
-            if (b == B - 1) p.buf.task_offsets[B] = off_f + F;
+            int64_t* const task_values = reinterpret_cast<int64_t*>(arena + d.off_task_values);
+            int64_t* const task_offsets = reinterpret_cast<int64_t*>(arena + d.off_task_offsets);
+            int64_t* const obs_map = reinterpret_cast<int64_t*>(arena + d.off_obs_map);
+            const int64_t off_f = (int64_t)s_prefix[0] + (int64_t)((base[0] + incl[0] - packed[0]) & 0xFFFFull);
+            task_offsets[b] = off_f;
+            if (b == B - 1) task_offsets[B] = off_f + F;
             int r = 0;
 #pragma unroll
             for (int c = 0; c < CMAX; ++c) {
-                if ((lit1 >> c) & 1ull) {
-                    int64_t* row = p.buf.task_values + (off_f + r) * 4;
-                    const int yx = p.cell_yx[c];
+                if ((lit1 >> c) & 1) {
+                    int64_t* row = task_values + (off_f + r) * 4;
+                    const int yx = d.cell_yx[c];
                     reinterpret_cast<longlong2*>(row)[0] = make_longlong2(yx >> 16, yx & 0xFFFF);
                     reinterpret_cast<longlong2*>(row)[1] = make_longlong2(f[c], in[c]);
-                    p.buf.obs_map_values[off_f + r] = r;
+                    obs_map[off_f + r] = r;
                     ++r;
                 }
             }
+            int64_t* const act_values = reinterpret_cast<int64_t*>(arena + d.off_act_values);
+            int64_t* const act_offsets = reinterpret_cast<int64_t*>(arena + d.off_act_offsets);
+            int64_t* const bad_values = reinterpret_cast<int64_t*>(arena + d.off_bad_values);
+            int64_t* const bad_offsets = reinterpret_cast<int64_t*>(arena + d.off_bad_offsets);
+            const bool show_bad = (flags & kShowBad) != 0;
 #pragma unroll
             for (int a = 0; a < AMAX; ++a)
                 if (a < A) {
                     const int w = (a + 1) >> 2, sh = 16 * ((a + 1) & 3);
-                    const int64_t off_a = (int64_t)s_prefix[a + 1] + (int64_t)(((base[w] + incl[w] - packed[w]) >> sh) & 0xFFFFull);
-                    const int fa = __popcll(ok1[a]);
-                    p.buf.act_map_offsets[a * (B + 1) + b] = off_a;
-                    if (b == B - 1) p.buf.act_map_offsets[a * (B + 1) + B] = off_a + fa;
-                    int64_t* av = p.buf.act_map_values + a * cap + off_a;
-                    int64_t* bv = nullptr;
-                    if (p.show_bad_actions) {
-                        const int64_t off_bad = off_f - off_a;  // bad = listed but not attackable
-                        p.buf.bad_map_offsets[a * (B + 1) + b] = off_bad;
-                        if (b == B - 1) p.buf.bad_map_offsets[a * (B + 1) + B] = off_bad + (F - fa);
-                        bv = p.buf.bad_map_values + a * cap + off_bad;
+                    uint64_t excl = base[0] + incl[0] - packed[0];
+#pragma unroll
+                    for (int ww = 1; ww < PW; ++ww) excl = w == ww ? base[ww] + incl[ww] - packed[ww] : excl;
+                    const int64_t off_a = (int64_t)s_prefix[a + 1] + (int64_t)((excl >> sh) & 0xFFFFull);
+                    const int fa = popc(ok1[a]);
+                    act_offsets[a * (B + 1) + b] = off_a;
+                    if (b == B - 1) act_offsets[a * (B + 1) + B] = off_a + fa;
+                    int64_t* av = act_values + a * cap + off_a;
+                    int64_t* bv = bad_values + a * cap + (off_f - off_a);  // bad = listed but not attackable
+                    if (show_bad) {
+                        bad_offsets[a * (B + 1) + b] = off_f - off_a;
+                        if (b == B - 1) bad_offsets[a * (B + 1) + B] = (off_f - off_a) + (F - fa);
                     }
                     int local = 0, n_ok = 0, n_bad = 0;
 #pragma unroll
                     for (int c = 0; c < CMAX; ++c) {
-                        if ((lit1 >> c) & 1ull) {
-                            if ((ok1[a] >> c) & 1ull)
+                        if ((lit1 >> c) & 1) {
+                            if ((ok1[a] >> c) & 1)
                                 av[n_ok++] = local;
-                            else if (bv)
+                            else if (show_bad)
                                 bv[n_bad++] = local;
                             ++local;
                         }
                     }
                 }
         }
-        if (err) atomicOr(p.buf.error_flags, err);
+        if (err) atomicOr(reinterpret_cast<uint32_t*>(arena + d.off_error), err);
 
         // The workgroup owning the last chunk finished its look-back only after every other chunk published, i.e.
         // after every workgroup of this launch read the epoch: it can advance it for the next launch.
-        if (chunk == p.nchunks - 1 && tid == 0) __hip_atomic_store(p.epoch, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (chunk == d.nchunks - 1 && tid == 0) __hip_atomic_store(epoch_ptr, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
 // uniform random policy over OneOf([task] * n + [noop]) (spaces/actions.py:23-41; baselines/random.py:20):
 // member index j ~ U{0..n}; j < n -> [j, 0] (fight task j of the action mapping), j == n -> [n, -1] (noop/refill)
-__global__ void __launch_bounds__(kBlock) wf_policy_kernel(const int32_t* agent_task_count, const int64_t* env_task_count,
-                                                             int show_bad_actions, int A, int64_t B, uint32_t seed_lo, uint32_t seed_hi,
-                                                             uint32_t step_lo, uint32_t step_hi, int32_t* actions) {
+__global__ void __launch_bounds__(kBlock) wf_policy_kernel(const char* arena, uint32_t seed_lo, uint32_t seed_hi, uint32_t step_lo,
+                                                             uint32_t step_hi, int32_t* actions) {
+    const WfDev& d = *reinterpret_cast<const WfDev*>(arena);
+    const int64_t B = d.B;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= (int64_t)A * B) return;
+    if (i >= (int64_t)d.A * B) return;
     const int64_t b = i % B;
-    const int n = show_bad_actions ? (int)env_task_count[b] : agent_task_count[i];
+    const int32_t* rows = reinterpret_cast<const int32_t*>(arena + d.off_rows4);
+    const int64_t* rows8 = reinterpret_cast<const int64_t*>(arena + d.off_rows8);
+    const int n = (d.flags & kShowBad) ? (int)rows8[d.q_etc * B + b] : rows[d.r_atc * B + i];
     const frz::Philox4 w = frz::philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), step_lo, step_hi, seed_lo, seed_hi);
     const int j = (int)(((uint64_t)w.w[0] * (uint64_t)(n + 1)) >> 32);
     reinterpret_cast<int2*>(actions)[i] = j < n ? make_int2(j, 0) : make_int2(n, -1);
@@ -686,68 +747,53 @@ __global__ void __launch_bounds__(kBlock) wf_policy_kernel(const int32_t* agent_
 // ================================================================================================================
 struct frz_wildfire_env {
     frz_wildfire_cfg cfg;
-    WfParams params;
-    FillParams fill;
-    bool bound = false;
+    WfDev dev;
+    char* arena = nullptr;
     bool was_reset = false;
     int grid = 0;
     int variant = 0;  // index into the (CMAX, AMAX) instantiation table
-    float* rand_field = nullptr;
-    float* rand_agent = nullptr;
 };
 
 namespace {
 
 struct Variant {
     int cmax, amax;
+    bool exact;
 };
-constexpr Variant kVariants[] = {{8, 4}, {24, 8}, {64, 16}};
+constexpr Variant kVariants[] = {{6, 3, true}, {6, 2, true}, {8, 4, false}, {24, 8, false}, {64, 16, false}};
+constexpr int kNumVariants = 5;
 
 int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
-struct WorkspaceLayout {
-    int64_t epoch, totals, agg, prefix, rand_field, rand_agent, total;
-};
-
-WorkspaceLayout workspace_layout(const frz_wildfire_cfg* cfg) {
-    const int64_t B = cfg->parallel_envs, HW = (int64_t)cfg->grid_height * cfg->grid_width, A = cfg->num_agents;
-    const int64_t nchunks = (B + kBlock - 1) / kBlock, nch = A + 3;
-    WorkspaceLayout l;
-    int64_t at = 0;
-    l.epoch = at;
-    at += 128;
-    l.totals = at;
-    at += 2 * kTotalsStride * 4;
-    l.agg = at;
-    at = align_up(at + nchunks * nch * 8, 128);
-    l.prefix = at;
-    at = align_up(at + nchunks * nch * 8, 128);
-    l.rand_field = at;
-    at = align_up(at + 3 * B * HW * 4, 128);
-    l.rand_agent = at;
-    at = align_up(at + 5 * B * A * 4, 128);
-    l.total = at;
-    return l;
-}
-
-template <int CMAX, int AMAX>
-void launch_variant(const WfParams& p, int grid, int rng, int mode, hipStream_t stream) {
+template <int CMAX, int AMAX, bool EXACT>
+void launch_variant(const WfArgs& a, int grid, int rng, int mode, hipStream_t stream) {
+    const WfDev* dev = reinterpret_cast<const WfDev*>(a.arena);
     if (mode == kRebuild) {
-        hipLaunchKernelGGL((wf_step_kernel<CMAX, AMAX, FRZ_RNG_INJECTED, kRebuild>), dim3(grid), dim3(kBlock), 0, stream, p);
+        hipLaunchKernelGGL((wf_step_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kRebuild>), dim3(grid), dim3(kBlock), 0, stream, a.arena,
+                           dev, a.actions, a.field_rand, a.agent_rand);
     } else if (rng == FRZ_RNG_PHILOX) {
-        hipLaunchKernelGGL((wf_step_kernel<CMAX, AMAX, FRZ_RNG_PHILOX, kStep>), dim3(grid), dim3(kBlock), 0, stream, p);
+        hipLaunchKernelGGL((wf_step_kernel<CMAX, AMAX, EXACT, FRZ_RNG_PHILOX, kStep>), dim3(grid), dim3(kBlock), 0, stream, a.arena, dev,
+                           a.actions, a.field_rand, a.agent_rand);
     } else {
-        hipLaunchKernelGGL((wf_step_kernel<CMAX, AMAX, FRZ_RNG_INJECTED, kStep>), dim3(grid), dim3(kBlock), 0, stream, p);
+        hipLaunchKernelGGL((wf_step_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kStep>), dim3(grid), dim3(kBlock), 0, stream, a.arena, dev,
+                           a.actions, a.field_rand, a.agent_rand);
     }
 }
 
-int launch(frz_wildfire_env* env, int rng, int mode, hipStream_t stream) {
+int launch(frz_wildfire_env* env, const WfArgs& args, int rng, int mode, hipStream_t stream) {
     switch (env->variant) {
-        case 0: launch_variant<8, 4>(env->params, env->grid, rng, mode, stream); break;
-        case 1: launch_variant<24, 8>(env->params, env->grid, rng, mode, stream); break;
-        default: launch_variant<64, 16>(env->params, env->grid, rng, mode, stream); break;
+        case 0: launch_variant<6, 3, true>(args, env->grid, rng, mode, stream); break;   // BASELINE.json cfg1/cfg2 shape
+        case 1: launch_variant<6, 2, true>(args, env->grid, rng, mode, stream); break;   // AAAI-2025 openness configs
+        case 2: launch_variant<8, 4, false>(args, env->grid, rng, mode, stream); break;
+        case 3: launch_variant<24, 8, false>(args, env->grid, rng, mode, stream); break;
+        default: launch_variant<64, 16, false>(args, env->grid, rng, mode, stream); break;
     }
     return hipGetLastError() == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;
+}
+
+template <typename T>
+T* at(char* arena, int64_t off) {
+    return reinterpret_cast<T*>(arena + off);
 }
 
 }  // namespace
@@ -756,11 +802,6 @@ extern "C" {
 
 int frz_abi_version(void) { return FRZ_ABI_VERSION; }
 
-int64_t frz_wildfire_workspace_bytes(const frz_wildfire_cfg* cfg) {
-    if (!cfg || cfg->parallel_envs <= 0) return FRZ_E_INVALID;
-    return workspace_layout(cfg).total;
-}
-
 int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
     if (!cfg || !out) return FRZ_E_INVALID;
     const int H = cfg->grid_height, W = cfg->grid_width, HW = H * W, A = cfg->num_agents;
@@ -768,21 +809,28 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
     if (cfg->num_equipment_states <= 0 || cfg->num_equipment_states > FRZ_MAX_EQUIPMENT_STATES) return FRZ_E_INVALID;
     if (cfg->num_capacities <= 0 || cfg->num_capacities > FRZ_MAX_CAPACITIES) return FRZ_E_INVALID;
     if (cfg->num_fire_states < 2) return FRZ_E_INVALID;
+    if (cfg->initial_equipment_state < 0 || cfg->initial_equipment_state >= cfg->num_equipment_states) return FRZ_E_INVALID;
     if ((int64_t)cfg->parallel_envs * HW >= (int64_t)1 << 31) return FRZ_E_INVALID;  // 32-bit scan channels
 
     frz_wildfire_env* env = new (std::nothrow) frz_wildfire_env();
     if (!env) return FRZ_E_INVALID;
     env->cfg = *cfg;
-    int variant = -1;
-    for (int i = 0; i < 3; ++i)
-        if (HW <= kVariants[i].cmax && A <= kVariants[i].amax) {
-            variant = i;
+    env->variant = kNumVariants - 1;
+    for (int i = 0; i < kNumVariants; ++i) {
+        const Variant& v = kVariants[i];
+        if (v.exact ? (HW == v.cmax && A == v.amax) : (HW <= v.cmax && A <= v.amax)) {
+            env->variant = i;
             break;
         }
-    env->variant = variant;
+    }
+    if ((int64_t)(3 * HW + 6 * A + 8) * cfg->parallel_envs >= (int64_t)1 << 30) {  // 32-bit row indices
+        delete env;
+        return FRZ_E_INVALID;
+    }
 
-    WfParams& p = env->params;
+    WfDev& p = env->dev;
     std::memset(&p, 0, sizeof(p));
+    const int64_t B = cfg->parallel_envs;
     p.B = cfg->parallel_envs;
     p.H = H;
     p.W = W;
@@ -795,22 +843,28 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
     p.others_k = 2 + (cfg->observe_other_power ? 1 : 0) + (cfg->observe_other_suppressant ? 1 : 0);
     p.max_steps = cfg->max_steps;
     p.num_fire_states = cfg->num_fire_states;
-    p.stochastic_increase = cfg->stochastic_increase;
-    p.stochastic_burnouts = cfg->stochastic_burnouts;
-    p.stochastic_decrease = cfg->stochastic_decrease;
-    p.use_fire_fuel = cfg->use_fire_fuel;
-    p.stochastic_supp_decrease = cfg->stochastic_suppressant_decrease;
-    p.stochastic_refill = cfg->stochastic_refill;
-    p.stochastic_switch = cfg->stochastic_switch;
-    p.stochastic_repair = cfg->stochastic_repair;
-    p.stochastic_degrade = cfg->stochastic_degrade;
-    p.critical_error = cfg->critical_error;
-    p.show_bad_actions = cfg->show_bad_actions;
-    p.observe_other_power = cfg->observe_other_power;
-    p.observe_other_suppressant = cfg->observe_other_suppressant;
-    p.burnout_penalty_scaled = cfg->burnout_penalty_scaled;
-    p.localize_putouts = cfg->localize_putouts;
-    p.track_cumulative = cfg->track_cumulative_rewards;
+    auto flag = [&](int on, uint32_t bit) { p.flags |= on ? bit : 0u; };
+    flag(cfg->stochastic_increase, kStochIncrease);
+    flag(cfg->stochastic_burnouts, kStochBurnouts);
+    flag(cfg->stochastic_decrease, kStochDecrease);
+    flag(cfg->use_fire_fuel, kUseFuel);
+    flag(cfg->stochastic_suppressant_decrease, kStochSuppDecrease);
+    flag(cfg->stochastic_refill, kStochRefill);
+    flag(cfg->stochastic_switch, kStochSwitch);
+    flag(cfg->stochastic_repair, kStochRepair);
+    flag(cfg->stochastic_degrade, kStochDegrade);
+    flag(cfg->critical_error, kCritical);
+    flag(cfg->show_bad_actions, kShowBad);
+    flag(cfg->observe_other_power, kObsPower);
+    flag(cfg->observe_other_suppressant, kObsSupp);
+    flag(cfg->burnout_penalty_scaled, kPenaltyScaled);
+    flag(cfg->localize_putouts, kLocalize);
+    flag(cfg->track_cumulative_rewards, kTrackCumulative);
+    flag(cfg->max_steps >= 0, kTruncate);
+    p.initial_fuel = cfg->initial_fuel;
+    p.initial_equipment = cfg->initial_equipment_state;
+    p.initial_suppressant = cfg->initial_suppressant;
+    p.initial_capacity = cfg->initial_capacity;
     p.p_increase = cfg->intensity_increase_probability;
     p.p_burnout = cfg->burnout_probability;
     p.p_decrease = cfg->intensity_decrease_probability;
@@ -830,14 +884,17 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
     p.burnout_penalty = cfg->burnout_penalty;
     p.termination_reward = cfg->termination_reward;
     p.termination_kappa = cfg->termination_kappa;
-    std::memcpy(p.eq, cfg->equipment_states, sizeof(p.eq));
     std::memcpy(p.caps, cfg->possible_capacities, sizeof(p.caps));
-    std::memcpy(p.cum, cfg->capacity_cumprobs, sizeof(p.cum));
+    for (int j = 0; j < FRZ_MAX_CAPACITIES; ++j) p.cum[j] = j < cfg->num_capacities ? cfg->capacity_cumprobs[j] : __builtin_inff();
+    for (int s = 0; s < FRZ_MAX_EQUIPMENT_STATES; ++s)
+        for (int j = 0; j < 3; ++j) p.eq[s][j] = cfg->equipment_states[s][j];
     std::memcpy(p.ay, cfg->agent_y, sizeof(p.ay));
     std::memcpy(p.ax, cfg->agent_x, sizeof(p.ax));
     std::memcpy(p.power, cfg->fire_reduction_power, sizeof(p.power));
     std::memcpy(p.fire_rewards, cfg->fire_rewards, sizeof(p.fire_rewards));
     std::memcpy(p.ignition, cfg->ignition_temp, sizeof(p.ignition));
+    std::memcpy(p.fire_types, cfg->fire_types, sizeof(p.fire_types));
+    std::memcpy(p.lit, cfg->lit, sizeof(p.lit));
     for (int c = 0; c < HW; ++c) {
         const int y = c / W, x = c % W;
         p.cell_yx[c] = (y << 16) | x;
@@ -854,24 +911,59 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
             uint64_t m = 0;
             for (int c = 0; c < HW; ++c) {
                 const int dy = std::abs(cfg->agent_y[a] - c / W), dx = std::abs(cfg->agent_x[a] - c % W);
-                const int d = dy > dx ? dy : dx;
-                if ((float)d <= true_range) m |= 1ull << c;
+                const int dist = dy > dx ? dy : dx;
+                if ((float)dist <= true_range) m |= 1ull << c;
             }
             p.range_mask[a][s] = m;
         }
 
-    FillParams& fp = env->fill;
-    std::memset(&fp, 0, sizeof(fp));
-    fp.B = cfg->parallel_envs;
-    fp.HW = HW;
-    fp.A = A;
-    fp.initial_fuel = cfg->initial_fuel;
-    fp.initial_equipment = cfg->initial_equipment_state;
-    fp.initial_suppressant = cfg->initial_suppressant;
-    fp.initial_capacity = cfg->initial_capacity;
-    std::memcpy(fp.fire_types, cfg->fire_types, sizeof(fp.fire_types));
-    std::memcpy(fp.lit, cfg->lit, sizeof(fp.lit));
-    std::memcpy(fp.ignition, cfg->ignition_temp, sizeof(fp.ignition));
+    // ---- arena layout
+    int r = 0;
+    p.r_fires = r, r += HW;
+    p.r_intensity = r, r += HW;
+    p.r_fuel = r, r += HW;
+    p.r_supp = r, r += A;
+    p.r_cap = r, r += A;
+    p.r_equip = r, r += A;
+    p.r_moves = r++;
+    p.r_burnouts = r++;
+    p.r_rewards = r, r += A;
+    p.r_cum = r, r += A;
+    p.r_atc = r, r += A;
+    p.r_seeds = r++;
+    p.r_mti = r++;
+    p.n_rows4 = r;
+    p.q_burnouts = 0, p.q_putouts = 1, p.q_etc = 2, p.n_rows8 = 3;
+    p.u_term = 0, p.u_trunc = A, p.u_frozen = 2 * A, p.n_rows1 = 2 * A + 1;
+    const int64_t cap = B * HW, ok = p.others_k;
+    int64_t off = kDevBlockBytes;
+    auto take = [&](int64_t bytes) {
+        const int64_t here = off;
+        off = align_up(off + bytes, 256);
+        return here;
+    };
+    p.off_rows4 = take((int64_t)p.n_rows4 * B * 4);
+    p.off_rows8 = take((int64_t)p.n_rows8 * B * 8);
+    p.off_rows1 = take((int64_t)p.n_rows1 * B);
+    p.off_obs_self = take((int64_t)A * B * 16);
+    p.off_obs_others = take((int64_t)A * B * (A - 1) * ok * 4);
+    p.off_task_offsets = take((B + 1) * 8);
+    p.off_act_offsets = take((int64_t)A * (B + 1) * 8);
+    p.off_bad_offsets = take((int64_t)A * (B + 1) * 8);
+    p.off_task_values = take(cap * 32);
+    p.off_obs_map = take(cap * 8);
+    p.off_act_values = take((int64_t)A * cap * 8);
+    p.off_bad_values = take(cfg->show_bad_actions ? (int64_t)A * cap * 8 : 256);
+    p.off_actions = take((int64_t)A * B * 8);
+    p.off_error = take(256);
+    p.off_epoch = take(256);
+    p.off_totals = take(2 * kTotalsStride * 4);
+    p.off_agg = take((int64_t)p.nchunks * p.nch * 8);
+    p.off_prefix = take((int64_t)p.nchunks * p.nch * 8);
+    p.off_rand_field = take(3 * B * HW * 4);
+    p.off_rand_agent = take(5 * B * A * 4);
+    p.off_mt_state = take(624 * B * 4);
+    p.total_bytes = off;
 
     // Co-resident persistent grid: every workgroup of the launch must be resident for the single-pass prefix hand-off
     // (a chunk waits on chunks owned by other workgroups).  One 256-thread workgroup per CU is always resident.
@@ -880,7 +972,7 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     }
-    int per_cu = p.nchunks >= 4 * cus ? 2 : 1;
+    const int per_cu = p.nchunks >= 4 * cus ? 2 : 1;
     env->grid = p.nchunks < cus * per_cu ? p.nchunks : cus * per_cu;
     *out = env;
     return FRZ_OK;
@@ -888,36 +980,75 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
 
 void frz_wildfire_destroy(frz_wildfire_env* env) { delete env; }
 
-int frz_wildfire_bind(frz_wildfire_env* env, const frz_wildfire_bufs* bufs) {
-    if (!env || !bufs || !bufs->workspace || !bufs->error_flags || !bufs->fires || !bufs->frozen_scaled) return FRZ_E_INVALID;
-    if (env->cfg.show_bad_actions && (!bufs->bad_map_values || !bufs->bad_map_offsets)) return FRZ_E_INVALID;
-    env->params.track_cumulative = env->cfg.track_cumulative_rewards && bufs->cumulative_rewards != nullptr;
-    env->params.buf = *bufs;
-    env->fill.buf = *bufs;
-    const WorkspaceLayout l = workspace_layout(&env->cfg);
-    char* ws = static_cast<char*>(bufs->workspace);
-    env->params.epoch = reinterpret_cast<uint32_t*>(ws + l.epoch);
-    env->params.totals = reinterpret_cast<uint32_t*>(ws + l.totals);
-    env->params.agg = reinterpret_cast<uint64_t*>(ws + l.agg);
-    env->params.prefix = reinterpret_cast<uint64_t*>(ws + l.prefix);
-    env->rand_field = reinterpret_cast<float*>(ws + l.rand_field);
-    env->rand_agent = reinterpret_cast<float*>(ws + l.rand_agent);
-    env->bound = true;
+int64_t frz_wildfire_arena_bytes(const frz_wildfire_env* env) { return env ? env->dev.total_bytes : FRZ_E_INVALID; }
+
+int frz_wildfire_bind(frz_wildfire_env* env, void* arena, void* stream) {
+    if (!env || !arena) return FRZ_E_INVALID;
+    if (reinterpret_cast<uintptr_t>(arena) % 256 != 0) return FRZ_E_INVALID;
+    env->arena = static_cast<char*>(arena);
+    env->was_reset = false;
+    if (hipMemcpyAsync(arena, &env->dev, sizeof(WfDev), hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)) != hipSuccess)
+        return FRZ_E_LAUNCH;
+    // the handle owns the pageable source for the life of the copy
+    return hipStreamSynchronize(static_cast<hipStream_t>(stream)) == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;
+}
+
+int frz_wildfire_get_bufs(const frz_wildfire_env* env, frz_wildfire_bufs* out) {
+    if (!env || !out) return FRZ_E_INVALID;
+    if (!env->arena) return FRZ_E_UNBOUND;
+    const WfDev& p = env->dev;
+    char* a = env->arena;
+    const int64_t B = p.B;
+    auto row4 = [&](int r) { return a + p.off_rows4 + (int64_t)r * B * 4; };
+    auto row8 = [&](int r) { return a + p.off_rows8 + (int64_t)r * B * 8; };
+    auto row1 = [&](int r) { return a + p.off_rows1 + (int64_t)r * B; };
+    out->fires = reinterpret_cast<int32_t*>(row4(p.r_fires));
+    out->intensity = reinterpret_cast<int32_t*>(row4(p.r_intensity));
+    out->fuel = reinterpret_cast<int32_t*>(row4(p.r_fuel));
+    out->suppressants = reinterpret_cast<float*>(row4(p.r_supp));
+    out->capacity = reinterpret_cast<float*>(row4(p.r_cap));
+    out->equipment = reinterpret_cast<int32_t*>(row4(p.r_equip));
+    out->num_moves = reinterpret_cast<int32_t*>(row4(p.r_moves));
+    out->num_burnouts = reinterpret_cast<int32_t*>(row4(p.r_burnouts));
+    out->rewards = reinterpret_cast<float*>(row4(p.r_rewards));
+    out->cumulative_rewards = reinterpret_cast<float*>(row4(p.r_cum));
+    out->agent_task_count = reinterpret_cast<int32_t*>(row4(p.r_atc));
+    out->seeds = reinterpret_cast<int32_t*>(row4(p.r_seeds));
+    out->mt_index = reinterpret_cast<int32_t*>(row4(p.r_mti));
+    out->burnouts = reinterpret_cast<int64_t*>(row8(p.q_burnouts));
+    out->putouts = reinterpret_cast<int64_t*>(row8(p.q_putouts));
+    out->env_task_count = reinterpret_cast<int64_t*>(row8(p.q_etc));
+    out->terminations = reinterpret_cast<uint8_t*>(row1(p.u_term));
+    out->truncations = reinterpret_cast<uint8_t*>(row1(p.u_trunc));
+    out->frozen_scaled = reinterpret_cast<uint8_t*>(row1(p.u_frozen));
+    out->obs_self = at<float>(a, p.off_obs_self);
+    out->obs_others = at<float>(a, p.off_obs_others);
+    out->task_values = at<int64_t>(a, p.off_task_values);
+    out->task_offsets = at<int64_t>(a, p.off_task_offsets);
+    out->obs_map_values = at<int64_t>(a, p.off_obs_map);
+    out->act_map_values = at<int64_t>(a, p.off_act_values);
+    out->act_map_offsets = at<int64_t>(a, p.off_act_offsets);
+    out->bad_map_values = at<int64_t>(a, p.off_bad_values);
+    out->bad_map_offsets = at<int64_t>(a, p.off_bad_offsets);
+    out->mt_state = at<uint32_t>(a, p.off_mt_state);
+    out->actions = at<int32_t>(a, p.off_actions);
+    out->error_flags = at<uint32_t>(a, p.off_error);
     return FRZ_OK;
 }
 
 int frz_wildfire_rebuild(frz_wildfire_env* env, void* stream) {
     if (!env) return FRZ_E_INVALID;
-    if (!env->bound) return FRZ_E_UNBOUND;
+    if (!env->arena) return FRZ_E_UNBOUND;
     env->was_reset = true;
-    return launch(env, FRZ_RNG_INJECTED, kRebuild, static_cast<hipStream_t>(stream));
+    const WfArgs args{env->arena, nullptr, nullptr, nullptr};
+    return launch(env, args, FRZ_RNG_INJECTED, kRebuild, static_cast<hipStream_t>(stream));
 }
 
 int frz_wildfire_reset(frz_wildfire_env* env, void* stream) {
     if (!env) return FRZ_E_INVALID;
-    if (!env->bound) return FRZ_E_UNBOUND;
+    if (!env->arena) return FRZ_E_UNBOUND;
     const int blocks = (env->cfg.parallel_envs + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(wf_fill_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), env->fill);
+    hipLaunchKernelGGL(wf_fill_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), env->arena);
     if (hipGetLastError() != hipSuccess) return FRZ_E_LAUNCH;
     return frz_wildfire_rebuild(env, stream);
 }
@@ -927,43 +1058,43 @@ int frz_mt19937_generate(uint32_t* mt_state, int32_t* mt_index, float* out, int6
 int frz_wildfire_step(frz_wildfire_env* env, const int32_t* actions, int rng_mode, const float* field_randomness,
                       const float* agent_randomness, void* stream) {
     if (!env || !actions) return FRZ_E_INVALID;
-    if (!env->bound) return FRZ_E_UNBOUND;
+    if (!env->arena) return FRZ_E_UNBOUND;
     if (!env->was_reset) return FRZ_E_INVALID;  // reset()/rebuild() must precede the first step
     const frz_wildfire_cfg& c = env->cfg;
-    env->params.actions = actions;
+    const WfDev& p = env->dev;
+    WfArgs args{env->arena, actions, nullptr, nullptr};
     if (rng_mode == FRZ_RNG_INJECTED) {
         if (!field_randomness || !agent_randomness) return FRZ_E_INVALID;
-        env->params.field_rand = field_randomness;
-        env->params.agent_rand = agent_randomness;
+        args.field_rand = field_randomness;
+        args.agent_rand = agent_randomness;
     } else if (rng_mode == FRZ_RNG_MT19937) {
-        // per-env MT19937 streams: field draws first, then agent draws (wildfire.py:409-410), staged in the workspace
-        if (!env->params.buf.mt_state || !env->params.buf.mt_index) return FRZ_E_INVALID;
+        // per-env MT19937 streams: field draws first, then agent draws (wildfire.py:409-410), staged in the arena
         const int64_t B = c.parallel_envs;
-        int rc = frz_mt19937_generate(env->params.buf.mt_state, env->params.buf.mt_index, env->rand_field, 3,
-                                      (int64_t)c.grid_height * c.grid_width, B, stream);
+        uint32_t* mt_state = at<uint32_t>(env->arena, p.off_mt_state);
+        int32_t* mt_index = at<int32_t>(env->arena, p.off_rows4 + (int64_t)p.r_mti * B * 4);
+        float* rf = at<float>(env->arena, p.off_rand_field);
+        float* ra = at<float>(env->arena, p.off_rand_agent);
+        int rc = frz_mt19937_generate(mt_state, mt_index, rf, 3, (int64_t)c.grid_height * c.grid_width, B, stream);
         if (rc != FRZ_OK) return rc;
-        rc = frz_mt19937_generate(env->params.buf.mt_state, env->params.buf.mt_index, env->rand_agent, 5, c.num_agents, B, stream);
+        rc = frz_mt19937_generate(mt_state, mt_index, ra, 5, c.num_agents, B, stream);
         if (rc != FRZ_OK) return rc;
-        env->params.field_rand = env->rand_field;
-        env->params.agent_rand = env->rand_agent;
+        args.field_rand = rf;
+        args.agent_rand = ra;
         rng_mode = FRZ_RNG_INJECTED;
-    } else if (rng_mode == FRZ_RNG_PHILOX) {
-        if (!env->params.buf.seeds) return FRZ_E_INVALID;
-    } else {
+    } else if (rng_mode != FRZ_RNG_PHILOX) {
         return FRZ_E_INVALID;
     }
-    return launch(env, rng_mode, kStep, static_cast<hipStream_t>(stream));
+    return launch(env, args, rng_mode, kStep, static_cast<hipStream_t>(stream));
 }
 
 int frz_wildfire_random_policy(frz_wildfire_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out, void* stream) {
     if (!env || !actions_out) return FRZ_E_INVALID;
-    if (!env->bound) return FRZ_E_UNBOUND;
+    if (!env->arena) return FRZ_E_UNBOUND;
     const int64_t n = (int64_t)env->cfg.num_agents * env->cfg.parallel_envs;
     const int blocks = (int)((n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(wf_policy_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
-                       env->params.buf.agent_task_count, env->params.buf.env_task_count, env->cfg.show_bad_actions, env->cfg.num_agents,
-                       (int64_t)env->cfg.parallel_envs, (uint32_t)policy_seed, (uint32_t)(policy_seed >> 32), (uint32_t)policy_step,
-                       (uint32_t)(policy_step >> 32), actions_out);
+    hipLaunchKernelGGL(wf_policy_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), env->arena,
+                       (uint32_t)policy_seed, (uint32_t)(policy_seed >> 32), (uint32_t)policy_step, (uint32_t)(policy_step >> 32),
+                       actions_out);
     return hipGetLastError() == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;
 }
 

@@ -63,29 +63,54 @@ class raw_env(BatchedParallelEnv):
         self._create_handle()
 
     # ------------------------------------------------------------------------------------------------ buffers
+    def _view(self, ptr: int, shape, dtype) -> torch.Tensor:
+        """Typed view of a region of the arena (``ptr`` is an absolute device address reported by the library)."""
+        offset = ptr - self._arena.data_ptr()
+        numel = 1
+        for s in shape:
+            numel *= int(s)
+        nbytes = numel * torch.empty((), dtype=dtype).element_size()
+        return self._arena[offset:offset + nbytes].view(dtype).view(*shape)
+
     def _allocate(self) -> None:
+        """Create the C handle, allocate its single device arena and wrap every array as a view."""
         B, H, W, A = self.parallel_envs, self.max_y, self.max_x, len(self.possible_agents)
         HW, cap = H * W, self.parallel_envs * H * W
         self._k = 2 + int(self.observe_other_power) + int(self.observe_other_suppressant)
+        self._cfg = to_cstruct(self.config, B, self.max_steps, show_bad_actions=self.show_bad_actions,
+                               observe_other_power=self.observe_other_power, observe_other_suppressant=self.observe_other_suppressant)
+        handle = ctypes.c_void_p()
+        _capi.check(self._lib.frz_wildfire_create(ctypes.byref(self._cfg), ctypes.byref(handle)), 'frz_wildfire_create')
+        self._handle = handle
+        nbytes = self._lib.frz_wildfire_arena_bytes(self._handle)
+        if nbytes <= 0:
+            raise _capi.FrzError('frz_wildfire_arena_bytes rejected the configuration')
+        self._arena = self._alloc((nbytes, ), torch.uint8)  # zero-filled, 256-byte aligned by the caching allocator
+        _capi.check(self._lib.frz_wildfire_bind(self._handle, self._arena.data_ptr(), stream_ptr(self.device)), 'frz_wildfire_bind')
+        bufs = _capi.frz_wildfire_bufs()
+        _capi.check(self._lib.frz_wildfire_get_bufs(self._handle, ctypes.byref(bufs)), 'frz_wildfire_get_bufs')
+        self._bufs = bufs
         f32, i32, i64, u8 = torch.float32, torch.int32, torch.int64, torch.uint8
-        z = self._alloc
+        v = self._view
         # struct-of-arrays HBM state: env index innermost
-        self._fires, self._intensity, self._fuel = z((HW, B), i32), z((HW, B), i32), z((HW, B), i32)
-        self._suppressants, self._capacity, self._equipment = z((A, B), f32), z((A, B), f32), z((A, B), i32)
-        self.num_moves, self.num_burnouts = z((B, ), i32), z((B, ), i32)
-        self._rewards, self._cumulative = z((A, B), f32), z((A, B), f32)
-        self._terminations, self._truncations = z((A, B), torch.bool), z((A, B), torch.bool)
-        self._burnouts, self._putouts = z((B, ), i64), z((B, ), i64)
-        self._obs_self, self._obs_others = z((A, B, 4), f32), z((A, B, max(A - 1, 0), self._k), f32)
-        self._task_values, self._task_offsets = z((cap, 4), i64), z((B + 1, ), i64)
-        self._obs_map_values = z((cap, ), i64)
-        self._act_map_values, self._act_map_offsets = z((A, cap), i64), z((A, B + 1), i64)
-        self._bad_map_values = z((A, cap), i64) if self.show_bad_actions else None
-        self._bad_map_offsets = z((A, B + 1), i64) if self.show_bad_actions else None
-        self.environment_task_count, self.agent_task_count = z((B, ), i64), z((A, B), i32)
-        self._frozen_scaled = z((B, ), u8)
-        self._error_flags = z((1, ), i32)
-        self._actions = z((A, B, 2), i32)
+        self._fires, self._intensity, self._fuel = v(bufs.fires, (HW, B), i32), v(bufs.intensity, (HW, B), i32), v(bufs.fuel, (HW, B), i32)
+        self._suppressants, self._capacity = v(bufs.suppressants, (A, B), f32), v(bufs.capacity, (A, B), f32)
+        self._equipment = v(bufs.equipment, (A, B), i32)
+        self.num_moves, self.num_burnouts = v(bufs.num_moves, (B, ), i32), v(bufs.num_burnouts, (B, ), i32)
+        self._rewards, self._cumulative = v(bufs.rewards, (A, B), f32), v(bufs.cumulative_rewards, (A, B), f32)
+        self._terminations, self._truncations = v(bufs.terminations, (A, B), torch.bool), v(bufs.truncations, (A, B), torch.bool)
+        self._burnouts, self._putouts = v(bufs.burnouts, (B, ), i64), v(bufs.putouts, (B, ), i64)
+        self._obs_self, self._obs_others = v(bufs.obs_self, (A, B, 4), f32), v(bufs.obs_others, (A, B, max(A - 1, 0), self._k), f32)
+        self._task_values, self._task_offsets = v(bufs.task_values, (cap, 4), i64), v(bufs.task_offsets, (B + 1, ), i64)
+        self._obs_map_values = v(bufs.obs_map_values, (cap, ), i64)
+        self._act_map_values, self._act_map_offsets = v(bufs.act_map_values, (A, cap), i64), v(bufs.act_map_offsets, (A, B + 1), i64)
+        self._bad_map_values = v(bufs.bad_map_values, (A, cap), i64) if self.show_bad_actions else None
+        self._bad_map_offsets = v(bufs.bad_map_offsets, (A, B + 1), i64)
+        self.environment_task_count, self.agent_task_count = v(bufs.env_task_count, (B, ), i64), v(bufs.agent_task_count, (A, B), i32)
+        self._frozen_scaled = v(bufs.frozen_scaled, (B, ), u8)
+        self._error_flags = v(bufs.error_flags, (1, ), i32)
+        self._actions = v(bufs.actions, (A, B, 2), i32)
+        self.generator.attach(seeds=v(bufs.seeds, (B, ), i32), states=v(bufs.mt_state, (624, B), i32), index=v(bufs.mt_index, (B, ), i32))
         self.seeds = self.generator.seeds
         self._state = WildfireState(
             fires=self._fires.view(H, W, B).permute(2, 0, 1), intensity=self._intensity.view(H, W, B).permute(2, 0, 1),
@@ -93,41 +118,18 @@ class raw_env(BatchedParallelEnv):
             suppressants=self._suppressants.t(), capacity=self._capacity.t(), equipment=self._equipment.t())
 
     def _create_handle(self) -> None:
-        if self._handle is not None:
-            self._lib.frz_wildfire_destroy(self._handle)
-        self._cfg = to_cstruct(self.config, self.parallel_envs, self.max_steps, show_bad_actions=self.show_bad_actions,
-                               observe_other_power=self.observe_other_power, observe_other_suppressant=self.observe_other_suppressant)
-        nbytes = self._lib.frz_wildfire_workspace_bytes(ctypes.byref(self._cfg))
-        if nbytes <= 0:
-            raise _capi.FrzError('frz_wildfire_workspace_bytes rejected the configuration')
-        if getattr(self, '_workspace', None) is None or self._workspace.numel() != nbytes:
-            self._workspace = self._alloc((nbytes, ), torch.uint8)
-        handle = ctypes.c_void_p()
-        _capi.check(self._lib.frz_wildfire_create(ctypes.byref(self._cfg), ctypes.byref(handle)), 'frz_wildfire_create')
-        self._handle = handle
-        bufs = _capi.frz_wildfire_bufs()
-        ptr = lambda t: t.data_ptr() if t is not None else None
-        for name, tensor in (('fires', self._fires), ('intensity', self._intensity), ('fuel', self._fuel),
-                             ('suppressants', self._suppressants), ('capacity', self._capacity), ('equipment', self._equipment),
-                             ('num_moves', self.num_moves), ('num_burnouts', self.num_burnouts), ('rewards', self._rewards),
-                             ('cumulative_rewards', self._cumulative), ('terminations', self._terminations),
-                             ('truncations', self._truncations), ('burnouts', self._burnouts), ('putouts', self._putouts),
-                             ('obs_self', self._obs_self), ('obs_others', self._obs_others), ('task_values', self._task_values),
-                             ('task_offsets', self._task_offsets), ('obs_map_values', self._obs_map_values),
-                             ('act_map_values', self._act_map_values), ('act_map_offsets', self._act_map_offsets),
-                             ('bad_map_values', self._bad_map_values), ('bad_map_offsets', self._bad_map_offsets),
-                             ('env_task_count', self.environment_task_count), ('agent_task_count', self.agent_task_count),
-                             ('frozen_scaled', self._frozen_scaled), ('seeds', self.generator.seeds),
-                             ('mt_state', self.generator.generator_states), ('mt_index', self.generator.generator_index),
-                             ('workspace', self._workspace), ('error_flags', self._error_flags)):
-            setattr(bufs, name, ptr(tensor))
-        self._bufs = bufs
-        _capi.check(self._lib.frz_wildfire_bind(self._handle, ctypes.byref(bufs)), 'frz_wildfire_bind')
+        pass  # handle, arena and views are created together in _allocate()
 
     def _set_max_steps(self, max_steps) -> None:
+        """A new horizon changes the device configuration block: re-create the handle over the same arena."""
         if max_steps != self.max_steps:
             self.max_steps = max_steps
-            self._create_handle()
+            self._cfg.max_steps = -1 if max_steps is None else int(max_steps)
+            self._lib.frz_wildfire_destroy(self._handle)
+            handle = ctypes.c_void_p()
+            _capi.check(self._lib.frz_wildfire_create(ctypes.byref(self._cfg), ctypes.byref(handle)), 'frz_wildfire_create')
+            self._handle = handle
+            _capi.check(self._lib.frz_wildfire_bind(self._handle, self._arena.data_ptr(), stream_ptr(self.device)), 'frz_wildfire_bind')
 
     def __del__(self):
         try:

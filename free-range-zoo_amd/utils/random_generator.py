@@ -31,11 +31,19 @@ class RandomGenerator:
         self.single_seeding = single_seeding
         self.device = device
         self.seeds = torch.empty((parallel_envs, ), dtype=torch.int32, device=device)
-        self.generator_states = torch.empty((624, parallel_envs), dtype=torch.int32, device=device)  # uint32 words
+        self.generator_states = None  # [624, B] uint32 words, allocated on first use (or attached by the env)
         self.generator_index = torch.zeros((parallel_envs, ), dtype=torch.int32, device=device)
         self.buffer_count = {}
         self.buffers = {}
         self.has_been_seeded = False
+        self._streams_valid = False  # MT19937 states match self.seeds (seeding 624 words per env is done lazily)
+        self._pending_partial = None
+
+    def attach(self, seeds: torch.Tensor, states: torch.Tensor, index: torch.Tensor) -> None:
+        """Use caller-provided storage (views of an env's device arena) for seeds / MT19937 states / stream positions."""
+        seeds.copy_(self.seeds)
+        self.seeds, self.generator_states, self.generator_index = seeds, states, index
+        self._streams_valid = False
 
     @torch.no_grad()
     def seed(self, seed: Optional[torch.Tensor] = None, partial_seeding: Optional[torch.Tensor] = None) -> None:
@@ -44,20 +52,28 @@ class RandomGenerator:
             shape = self.seeds.shape if partial_seeding is None else torch.as_tensor(partial_seeding).shape
             seed = torch.randint(100000000, shape, device=self.device)
         seed = torch.as_tensor(seed, device=self.device).to(torch.int32)
-        lib = _capi.lib()
         if partial_seeding is None:
             self.seeds[:] = seed
-            indices_ptr, n = None, self.parallel_envs
+            self._streams_valid = False  # all streams restart: expanded to MT19937 states when first drawn from
+            self._pending_partial = None
         else:
             indices = torch.as_tensor(partial_seeding, device=self.device).to(torch.int32).contiguous().reshape(-1)
             self.seeds[indices.long()] = seed
-            self._indices_keepalive = indices
-            indices_ptr, n = indices.data_ptr(), indices.numel()
-        _capi.check(lib.frz_mt19937_seed(self.generator_states.data_ptr(), self.generator_index.data_ptr(), self.seeds.data_ptr(),
-                                         indices_ptr, n, self.parallel_envs, _stream_ptr(self.device)), 'frz_mt19937_seed')
+            if self._streams_valid:
+                self._seed_streams(indices)
         self.has_been_seeded = True
 
+    def _seed_streams(self, indices: Optional[torch.Tensor]) -> None:
+        if self.generator_states is None:
+            self.generator_states = torch.empty((624, self.parallel_envs), dtype=torch.int32, device=self.device)
+        indices_ptr, n = (None, self.parallel_envs) if indices is None else (indices.data_ptr(), indices.numel())
+        _capi.check(_capi.lib().frz_mt19937_seed(self.generator_states.data_ptr(), self.generator_index.data_ptr(), self.seeds.data_ptr(),
+                                                 indices_ptr, n, self.parallel_envs, _stream_ptr(self.device)), 'frz_mt19937_seed')
+
     def _draw(self, events: int, count: int) -> torch.Tensor:
+        if not self._streams_valid:
+            self._seed_streams(None)
+            self._streams_valid = True
         out = torch.empty((events, self.parallel_envs, count), dtype=torch.float32, device=self.device)
         _capi.check(_capi.lib().frz_mt19937_generate(self.generator_states.data_ptr(), self.generator_index.data_ptr(), out.data_ptr(),
                                                      events, count, self.parallel_envs, _stream_ptr(self.device)),
@@ -93,7 +109,8 @@ class RandomGenerator:
             'single_seeding': self.single_seeding,
             'device': str(self.device),
             'seeds': self.seeds.clone(),
-            'generator_states': self.generator_states.clone(),
+            'generator_states': self.generator_states.clone() if self._streams_valid else None,
+            'streams_valid': self._streams_valid,
             'generator_index': self.generator_index.clone(),
             'buffer_count': dict(self.buffer_count),
             'buffers': {k: v.clone() for k, v in self.buffers.items()},
@@ -105,7 +122,11 @@ class RandomGenerator:
         self.buffer_size = state['buffer_size']
         self.single_seeding = state['single_seeding']
         self.seeds.copy_(state['seeds'])
-        self.generator_states.copy_(state['generator_states'])
+        self._streams_valid = state.get('streams_valid', True)
+        if self._streams_valid:
+            if self.generator_states is None:
+                self.generator_states = torch.empty((624, self.parallel_envs), dtype=torch.int32, device=self.device)
+            self.generator_states.copy_(state['generator_states'])
         self.generator_index.copy_(state['generator_index'])
         self.buffer_count = dict(state['buffer_count'])
         self.buffers = {k: v.clone() for k, v in state['buffers'].items()}

@@ -132,7 +132,10 @@ typedef struct frz_wildfire_cfg {
     int32_t lit[FRZ_MAX_CELLS];
 } frz_wildfire_cfg;
 
-/* Buffers of one wildfire env object.  "cap" = B*H*W rows (upper bound on lit fires). */
+/* Arrays of one wildfire env object.  They all live in ONE contiguous device arena whose layout the library fixes
+ * (frz_wildfire_arena_bytes / frz_wildfire_bind); frz_wildfire_get_bufs() reports where each array sits so the caller
+ * can wrap it as a typed view.  One base pointer keeps the kernels' scalar-register footprint small: every per-env
+ * 4-byte array is a row of one [rows][B] block, addressed as base + (row * B + env) * 4.  "cap" = B*H*W rows. */
 typedef struct frz_wildfire_bufs {
     /* state (WildfireState, structures/state.py:10-68), SoA */
     int32_t* fires;      /* [H*W][B] */
@@ -145,7 +148,7 @@ typedef struct frz_wildfire_bufs {
     int32_t* num_moves;        /* [B] */
     int32_t* num_burnouts;     /* [B]            wildfire.py:357 */
     float* rewards;            /* [A][B]  out */
-    float* cumulative_rewards; /* [A][B]  in/out (may be NULL if !track_cumulative_rewards) */
+    float* cumulative_rewards; /* [A][B]  in/out BatchedAECEnv._cumulative_rewards */
     uint8_t* terminations;     /* [A][B]  in/out */
     uint8_t* truncations;      /* [A][B]  out */
     int64_t* burnouts;         /* [B] out  infos['burnouts'] (wildfire.py:581) */
@@ -157,30 +160,33 @@ typedef struct frz_wildfire_bufs {
     int64_t* task_offsets;   /* [B+1]  shared by task_values and obs_map_values */
     /* action/observation index maps + counts (wildfire.py:586-666) */
     int64_t* obs_map_values;    /* [cap]      local task indices 0..F_b-1 */
-    int64_t* act_map_values;    /* [A][cap]   local indices of attackable fires (unused if show_bad_actions) */
+    int64_t* act_map_values;    /* [A][cap]   local indices of attackable fires */
     int64_t* act_map_offsets;   /* [A][B+1] */
-    int64_t* bad_map_values;    /* [A][cap]   only if show_bad_actions, else may be NULL */
+    int64_t* bad_map_values;    /* [A][cap]   listed-but-not-attackable fires (filled only if show_bad_actions) */
     int64_t* bad_map_offsets;   /* [A][B+1] */
     int64_t* env_task_count;    /* [B] */
     int32_t* agent_task_count;  /* [A][B] */
     uint8_t* frozen_scaled;     /* [B] 1 once the stale-reward scaling of a frozen step (utils/env.py:211-213 +
                                    utils/conversions.py:87-90) was applied to env b; cleared by reset */
     /* per-env RNG state */
-    int32_t* seeds;       /* [B]  (FRZ_RNG_PHILOX key) */
-    uint32_t* mt_state;   /* [624][B]  FRZ_RNG_MT19937 only, else may be NULL */
+    int32_t* seeds;       /* [B]  (FRZ_RNG_PHILOX key; the seeds the MT19937 streams were started from) */
+    uint32_t* mt_state;   /* [624][B] */
     int32_t* mt_index;    /* [B]       number of draws consumed modulo 624 */
-    /* library scratch: zero-filled once by the caller, frz_wildfire_workspace_bytes() bytes */
-    void* workspace;
+    int32_t* actions;     /* [A][B][2] default action buffer (frz_wildfire_step accepts any device pointer) */
     uint32_t* error_flags; /* [1] sticky FRZ_ERR_* bits */
 } frz_wildfire_bufs;
 
 typedef struct frz_wildfire_env frz_wildfire_env; /* opaque host handle */
 
 int frz_abi_version(void);
-int64_t frz_wildfire_workspace_bytes(const frz_wildfire_cfg* cfg);
 int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out);
 void frz_wildfire_destroy(frz_wildfire_env* env);
-int frz_wildfire_bind(frz_wildfire_env* env, const frz_wildfire_bufs* bufs);
+/* size of the device arena (state + outputs + RNG state + library scratch) for this configuration */
+int64_t frz_wildfire_arena_bytes(const frz_wildfire_env* env);
+/* attach a ZERO-FILLED device arena of frz_wildfire_arena_bytes(); uploads the configuration block (stream-ordered) */
+int frz_wildfire_bind(frz_wildfire_env* env, void* arena, void* stream);
+/* where each array of the bound arena lives */
+int frz_wildfire_get_bufs(const frz_wildfire_env* env, frz_wildfire_bufs* out);
 /* replaces raw_env.reset()'s state fill (wildfire.py:347-354) + bookkeeping zeroing (utils/env.py:137-160)
  * followed by update_observations/update_actions */
 int frz_wildfire_reset(frz_wildfire_env* env, void* stream);

@@ -70,15 +70,21 @@ def test_header_symbols_are_bound_and_exported():
     assert handle.frz_abi_version() == _capi.DEFINES['FRZ_ABI_VERSION']
 
 
-def test_workspace_and_create_argument_checks():
+def test_create_argument_checks_and_arena_size():
     if not os.path.exists(_capi.LIB_PATH):
         pytest.skip('libfrz_hip.so not built')
     lib = _capi.lib()
     cfg = W.to_cstruct(configs.wildfire_non_stochastic(), 1000, 15)
-    assert lib.frz_wildfire_workspace_bytes(ctypes.byref(cfg)) > 0
+    handle = ctypes.c_void_p()
+    assert lib.frz_wildfire_create(ctypes.byref(cfg), ctypes.byref(handle)) == 0
+    nbytes = lib.frz_wildfire_arena_bytes(handle)
+    assert nbytes > 1000 * (3 * 6 * 4 + 624 * 4)  # state rows + MT19937 words at least
+    bufs = _capi.frz_wildfire_bufs()
+    assert lib.frz_wildfire_get_bufs(handle, ctypes.byref(bufs)) == _capi.DEFINES['FRZ_E_UNBOUND']
+    assert lib.frz_wildfire_reset(handle, None) == _capi.DEFINES['FRZ_E_UNBOUND']
+    lib.frz_wildfire_destroy(handle)
     bad = W.to_cstruct(configs.wildfire_non_stochastic(), 1000, 15)
     bad.num_agents = 99
-    handle = ctypes.c_void_p()
     assert lib.frz_wildfire_create(ctypes.byref(bad), ctypes.byref(handle)) == _capi.DEFINES['FRZ_E_INVALID']
 
 
