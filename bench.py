@@ -56,7 +56,7 @@ def cpu_baseline(budget_s=12.0):
         ref.reset()
         t0 = time.perf_counter()
         for t in range(EPISODE):
-            actions = oracle.wildfire_random_policy(cfg, ref.agent_task_count, ref.env_task_count, 7, steps + t)
+            actions = oracle.wildfire_random_policy(cfg, ref.agent_task_count, ref.env_task_count, seeds, 7, steps + t)
             field, agent = oracle.wildfire_philox_randomness(cfg, seeds, ref.num_moves)
             ref.step(actions, field, agent)
         t_total += time.perf_counter() - t0

@@ -17,8 +17,8 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
 // ------------------------------------------------------------------------------------------------------------
-// Philox4x32-10 (Salmon et al. SC'11).  FRZ_RNG_PHILOX stream definition (same as oracle/frz_oracle_rng.c):
-//   key = (seed, 0x46525A00), counter = (draw >> 2, step, stream, 0), float = (word[draw & 3] >> 8) * 2^-24
+// Philox4x32-10 (Salmon et al. SC'11).  The FRZ_RNG_PHILOX stream definitions live with each domain's step entry
+// point in include/frz.h (and oracle/frz_oracle_rng.c); float = (word >> 8) * 2^-24.
 // ------------------------------------------------------------------------------------------------------------
 struct Philox4 {
     uint32_t w[4];

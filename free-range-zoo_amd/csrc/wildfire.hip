@@ -23,77 +23,11 @@
 #include <new>
 #include <type_traits>
 
+#include "wildfire_common.h"
+
 namespace {
 
-using frz::kBlock;
-
-constexpr int kTotalsStride = 32;  // uint32 words per totals slot (128 B)
-
-enum Mode { kStep = 0, kRebuild = 1 };
-
-enum Flag : uint32_t {
-    kStochIncrease = 1u << 0, kStochBurnouts = 1u << 1, kStochDecrease = 1u << 2, kUseFuel = 1u << 3, kStochSuppDecrease = 1u << 4,
-    kStochRefill = 1u << 5, kStochSwitch = 1u << 6, kStochRepair = 1u << 7, kStochDegrade = 1u << 8, kCritical = 1u << 9,
-    kShowBad = 1u << 10, kObsPower = 1u << 11, kObsSupp = 1u << 12, kPenaltyScaled = 1u << 13, kLocalize = 1u << 14,
-    kTrackCumulative = 1u << 15, kTruncate = 1u << 16,
-};
-
-// Device-resident configuration block at arena offset 0 (uniform address -> scalar loads at the point of use).
-struct WfDev {
-    int32_t B, H, W, HW, A, S, K, nchunks, nch, others_k, max_steps, num_fire_states;
-    uint32_t flags;
-    int32_t initial_fuel, initial_equipment;
-    float initial_suppressant, initial_capacity;
-    float p_increase, p_burnout, p_decrease, decrease_bonus, p_supp_decrease, p_refill, p_switch, p_repair, p_degrade, p_critical;
-    float spread_n, spread_w, spread_e, spread_s, random_ignition;
-    float bad_attack_penalty, burnout_penalty, termination_reward, termination_kappa;
-    float caps[FRZ_MAX_CAPACITIES], cum[FRZ_MAX_CAPACITIES];
-    float eq[FRZ_MAX_EQUIPMENT_STATES][4];  // (capacity, power, range, -)
-    int32_t ay[FRZ_MAX_AGENTS], ax[FRZ_MAX_AGENTS];
-    float power[FRZ_MAX_AGENTS];
-    uint64_t range_mask[FRZ_MAX_AGENTS][FRZ_MAX_EQUIPMENT_STATES];  // cells agent a reaches at equipment state s
-    uint64_t has_n, has_w, has_e, has_s;                            // cells that have a north/west/east/south neighbour
-    float fire_rewards[FRZ_MAX_CELLS];
-    int32_t ignition[FRZ_MAX_CELLS];
-    int32_t cell_yx[FRZ_MAX_CELLS];  // (y << 16) | x
-    int32_t fire_types[FRZ_MAX_CELLS], lit[FRZ_MAX_CELLS];
-    // row indices of the [rows][B] blocks
-    int32_t r_fires, r_intensity, r_fuel, r_supp, r_cap, r_equip, r_moves, r_burnouts, r_rewards, r_cum, r_atc, r_seeds, r_mti, n_rows4;
-    int32_t q_burnouts, q_putouts, q_etc, n_rows8;
-    int32_t u_term, u_trunc, u_frozen, n_rows1;
-    // byte offsets from the arena base
-    int64_t off_rows4, off_rows8, off_rows1, off_obs_self, off_obs_others, off_task_values, off_task_offsets, off_obs_map,
-        off_act_values, off_act_offsets, off_bad_values, off_bad_offsets, off_mt_state, off_actions, off_error, off_epoch, off_totals,
-        off_agg, off_prefix, off_rand_field, off_rand_agent, total_bytes;
-};
-static_assert(sizeof(WfDev) <= 8192, "configuration block too large");
-constexpr int64_t kDevBlockBytes = 8192;
-
-struct WfArgs {
-    char* arena;
-    const int32_t* actions;
-    const float* field_rand;
-    const float* agent_rand;
-};
-
-// 4-byte row access with a 32-bit element index: lets the compiler address as (uniform base) + (32-bit lane offset)
-template <typename T>
-__device__ __forceinline__ T& at32(T* base, uint32_t index) {
-    return *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + (uint64_t)(index * (uint32_t)sizeof(T)));
-}
-
-__device__ __forceinline__ float clamp01(float p) {
-    p = p < 0.0f ? 0.0f : p;
-    return p > 1.0f ? 1.0f : p;
-}
-
-template <typename M>
-__device__ __forceinline__ int popc(M m) {
-    if constexpr (sizeof(M) == 8)
-        return __popcll(m);
-    else
-        return __popc(m);
-}
+using namespace frz_wf;
 
 // wildfire.py:347-354 + utils/env.py:137-160: state from the configuration, bookkeeping zeroed.
 __global__ void __launch_bounds__(kBlock) wf_fill_kernel(char* arena) {
@@ -253,39 +187,36 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ aren
 #pragma unroll
                     for (int a = 0; a < AMAX; ++a) r_agent[e][a] = a < A ? agent_rand[((int64_t)e * B + bl) * A + a] : 1.0f;
             } else {
-                // FRZ_RNG_PHILOX: stream e = field event e (draw = cell), stream 3 + e = agent event e (draw = agent);
-                // events whose every use is disabled by the configuration are not generated
+                // FRZ_RNG_PHILOX stream (include/frz.h): counter (i, step, 0, 0) serves cell i's three field draws and
+                // agent i-1's first draw; counter (a + 1, step, 1, 0) serves agent a's other four draws.
                 const uint32_t seed = (uint32_t)at32(rows, (uint32_t)(d.r_seeds) * Bu + (uint32_t)bl);
-                const bool need[5] = {(flags & kStochSuppDecrease) != 0, (flags & (kStochRepair | kStochDegrade | kCritical)) != 0,
-                                      (flags & kStochRefill) != 0, d.K > 1, (flags & kStochSwitch) != 0};
+                const bool need_block1 = (flags & (kStochRepair | kStochDegrade | kCritical | kStochRefill | kStochSwitch)) != 0 || d.K > 1;
+                constexpr int NB0 = CMAX > AMAX + 1 ? CMAX : AMAX + 1;
 #pragma unroll
-                for (int e = 0; e < 3; ++e)
-#pragma unroll
-                    for (int q = 0; q < (CMAX + 3) / 4; ++q) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (q * 4 + j < CMAX) r_field[e][q * 4 + j] = 1.0f;
-                        if (q * 4 < HW) {
-                            const frz::Philox4 w = frz::philox4x32_10((uint32_t)q, (uint32_t)nm, (uint32_t)e, 0u, seed, 0x46525A00u);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                if (q * 4 + j < CMAX) r_field[e][q * 4 + j] = frz::u32_to_unit_float(w.w[j]);
+                for (int i = 0; i < NB0; ++i) {
+                    if (i < CMAX) r_field[0][i] = r_field[1][i] = r_field[2][i] = 1.0f;
+                    if (i >= 1 && i <= AMAX) r_agent[0][i - 1] = 0.0f;
+                    if (i < HW || i <= A) {
+                        const frz::Philox4 w = frz::philox4x32_10((uint32_t)i, (uint32_t)nm, 0u, 0u, seed, 0x46525A00u);
+                        if (i < CMAX) {
+                            r_field[0][i] = frz::u32_to_unit_float(w.w[0]);
+                            r_field[1][i] = frz::u32_to_unit_float(w.w[1]);
+                            r_field[2][i] = frz::u32_to_unit_float(w.w[2]);
                         }
+                        if (i >= 1 && i <= AMAX) r_agent[0][i - 1] = frz::u32_to_unit_float(w.w[3]);
                     }
+                }
 #pragma unroll
-                for (int e = 0; e < 5; ++e)
-#pragma unroll
-                    for (int q = 0; q < (AMAX + 3) / 4; ++q) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (q * 4 + j < AMAX) r_agent[e][q * 4 + j] = 0.0f;
-                        if (q * 4 < A && need[e]) {
-                            const frz::Philox4 w = frz::philox4x32_10((uint32_t)q, (uint32_t)nm, (uint32_t)(3 + e), 0u, seed, 0x46525A00u);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                if (q * 4 + j < AMAX) r_agent[e][q * 4 + j] = frz::u32_to_unit_float(w.w[j]);
-                        }
+                for (int a = 0; a < AMAX; ++a) {
+                    r_agent[1][a] = r_agent[2][a] = r_agent[3][a] = r_agent[4][a] = 0.0f;
+                    if (a < A && need_block1) {
+                        const frz::Philox4 w = frz::philox4x32_10((uint32_t)(a + 1), (uint32_t)nm, 1u, 0u, seed, 0x46525A00u);
+                        r_agent[1][a] = frz::u32_to_unit_float(w.w[0]);
+                        r_agent[2][a] = frz::u32_to_unit_float(w.w[1]);
+                        r_agent[3][a] = frz::u32_to_unit_float(w.w[2]);
+                        r_agent[4][a] = frz::u32_to_unit_float(w.w[3]);
                     }
+                }
             }
 
             // ------------------------------------------------------------- action decode (wildfire.py:427-483)
@@ -723,6 +654,32 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ aren
     }
 }
 
+// FRZ_RNG_PHILOX randomness staged in the arena for the large lane-per-env variants (their in-kernel generation would
+// unroll up to 64 + 16 Philox blocks per lane): one thread per (env, counter index i), see include/frz.h for the stream.
+__global__ void __launch_bounds__(kBlock) wf_philox_fill_kernel(char* __restrict__ arena, const WfDev* __restrict__ dev) {
+    const WfDev& d = *dev;
+    const int64_t B = d.B;
+    const int HW = d.HW, A = d.A;
+    const int per_env = HW > A + 1 ? HW : A + 1;
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= B * per_env) return;
+    const int64_t b = t / per_env;
+    const int i = (int)(t % per_env);
+    const int32_t* rows = reinterpret_cast<const int32_t*>(arena + d.off_rows4);
+    float* field = reinterpret_cast<float*>(arena + d.off_rand_field);
+    float* agent = reinterpret_cast<float*>(arena + d.off_rand_agent);
+    const uint32_t seed = (uint32_t)rows[d.r_seeds * B + b], step = (uint32_t)rows[d.r_moves * B + b];
+    const frz::Philox4 w0 = frz::philox4x32_10((uint32_t)i, step, 0u, 0u, seed, 0x46525A00u);
+    if (i < HW)
+        for (int e = 0; e < 3; ++e) field[((int64_t)e * B + b) * HW + i] = frz::u32_to_unit_float(w0.w[e]);
+    if (i >= 1 && i <= A) {
+        const int a = i - 1;
+        agent[((int64_t)0 * B + b) * A + a] = frz::u32_to_unit_float(w0.w[3]);
+        const frz::Philox4 w1 = frz::philox4x32_10((uint32_t)i, step, 1u, 0u, seed, 0x46525A00u);
+        for (int e = 1; e < 5; ++e) agent[((int64_t)e * B + b) * A + a] = frz::u32_to_unit_float(w1.w[e - 1]);
+    }
+}
+
 // uniform random policy over OneOf([task] * n + [noop]) (spaces/actions.py:23-41; baselines/random.py:20):
 // member index j ~ U{0..n}; j < n -> [j, 0] (fight task j of the action mapping), j == n -> [n, -1] (noop/refill)
 __global__ void __launch_bounds__(kBlock) wf_policy_kernel(const char* arena, uint32_t seed_lo, uint32_t seed_hi, uint32_t step_lo,
@@ -735,7 +692,8 @@ __global__ void __launch_bounds__(kBlock) wf_policy_kernel(const char* arena, ui
     const int32_t* rows = reinterpret_cast<const int32_t*>(arena + d.off_rows4);
     const int64_t* rows8 = reinterpret_cast<const int64_t*>(arena + d.off_rows8);
     const int n = (d.flags & kShowBad) ? (int)rows8[d.q_etc * B + b] : rows[d.r_atc * B + i];
-    const frz::Philox4 w = frz::philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), step_lo, step_hi, seed_lo, seed_hi);
+    const uint32_t env_seed = (uint32_t)rows[d.r_seeds * B + b];
+    const frz::Philox4 w = frz::philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), step_lo, step_hi, seed_lo ^ env_seed, seed_hi);
     const int j = (int)(((uint64_t)w.w[0] * (uint64_t)(n + 1)) >> 32);
     reinterpret_cast<int2*>(actions)[i] = j < n ? make_int2(j, 0) : make_int2(n, -1);
 }
@@ -766,14 +724,27 @@ constexpr int kNumVariants = 5;
 int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
 template <int CMAX, int AMAX, bool EXACT>
-void launch_variant(const WfArgs& a, int grid, int rng, int mode, hipStream_t stream) {
+void launch_variant(const WfArgs& args, int grid, int rng, int mode, hipStream_t stream) {
+    WfArgs a = args;
     const WfDev* dev = reinterpret_cast<const WfDev*>(a.arena);
+    if constexpr (CMAX > 8) {
+        if (mode == kStep && rng == FRZ_RNG_PHILOX) {  // stage the Philox draws, then run the injected-randomness step
+            const WfDev* host = a.host_dev;
+            const int per_env = host->HW > host->A + 1 ? host->HW : host->A + 1;
+            const int64_t n = (int64_t)host->B * per_env;
+            hipLaunchKernelGGL(wf_philox_fill_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, a.arena, dev);
+            a.field_rand = reinterpret_cast<const float*>(a.arena + host->off_rand_field);
+            a.agent_rand = reinterpret_cast<const float*>(a.arena + host->off_rand_agent);
+            rng = FRZ_RNG_INJECTED;
+        }
+    }
     if (mode == kRebuild) {
         hipLaunchKernelGGL((wf_step_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kRebuild>), dim3(grid), dim3(kBlock), 0, stream, a.arena,
                            dev, a.actions, a.field_rand, a.agent_rand);
     } else if (rng == FRZ_RNG_PHILOX) {
-        hipLaunchKernelGGL((wf_step_kernel<CMAX, AMAX, EXACT, FRZ_RNG_PHILOX, kStep>), dim3(grid), dim3(kBlock), 0, stream, a.arena, dev,
-                           a.actions, a.field_rand, a.agent_rand);
+        if constexpr (CMAX <= 8)
+            hipLaunchKernelGGL((wf_step_kernel<CMAX, AMAX, EXACT, FRZ_RNG_PHILOX, kStep>), dim3(grid), dim3(kBlock), 0, stream, a.arena,
+                               dev, a.actions, a.field_rand, a.agent_rand);
     } else {
         hipLaunchKernelGGL((wf_step_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kStep>), dim3(grid), dim3(kBlock), 0, stream, a.arena, dev,
                            a.actions, a.field_rand, a.agent_rand);
@@ -781,6 +752,7 @@ void launch_variant(const WfArgs& a, int grid, int rng, int mode, hipStream_t st
 }
 
 int launch(frz_wildfire_env* env, const WfArgs& args, int rng, int mode, hipStream_t stream) {
+    if (env->dev.group_width > 0) return launch_group(args, env->dev.group_width, env->grid, rng, mode, stream);
     switch (env->variant) {
         case 0: launch_variant<6, 3, true>(args, env->grid, rng, mode, stream); break;   // BASELINE.json cfg1/cfg2 shape
         case 1: launch_variant<6, 2, true>(args, env->grid, rng, mode, stream); break;   // AAAI-2025 openness configs
@@ -838,7 +810,11 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
     p.A = A;
     p.S = cfg->num_equipment_states;
     p.K = cfg->num_capacities;
-    p.nchunks = (cfg->parallel_envs + kBlock - 1) / kBlock;
+    // small shapes run the group-per-env kernel (8 lanes per env); everything else one env per lane
+    const char* force_lane = std::getenv("FRZ_WF_LANE_KERNEL");
+    p.group_width = (HW <= 8 && A + 1 <= 8 && !(force_lane && force_lane[0] == '1')) ? 8 : 0;
+    const int envs_per_chunk = p.group_width ? kBlock / p.group_width : kBlock;
+    p.nchunks = (cfg->parallel_envs + envs_per_chunk - 1) / envs_per_chunk;
     p.nch = A + 3;
     p.others_k = 2 + (cfg->observe_other_power ? 1 : 0) + (cfg->observe_other_suppressant ? 1 : 0);
     p.max_steps = cfg->max_steps;
@@ -959,21 +935,36 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
     p.off_epoch = take(256);
     p.off_totals = take(2 * kTotalsStride * 4);
     p.off_agg = take((int64_t)p.nchunks * p.nch * 8);
+    p.off_gtot = take((int64_t)p.nchunks * p.nch * 8);
     p.off_prefix = take((int64_t)p.nchunks * p.nch * 8);
     p.off_rand_field = take(3 * B * HW * 4);
     p.off_rand_agent = take(5 * B * A * 4);
     p.off_mt_state = take(624 * B * 4);
     p.total_bytes = off;
 
-    // Co-resident persistent grid: every workgroup of the launch must be resident for the single-pass prefix hand-off
-    // (a chunk waits on chunks owned by other workgroups).  One 256-thread workgroup per CU is always resident.
+    // Co-resident persistent grid: every workgroup of a launch must be resident for the single-pass prefix hand-off
+    // (a chunk waits on chunks owned by other workgroups).  One 256-thread workgroup per CU is always resident; the
+    // group kernel asks the runtime and keeps one workgroup per CU of margin (the occupancy query can over-report by
+    // one for SGPR-heavy kernels, MI355X_MICROARCH.md); rounds are balanced.
     int device = 0, cus = 256;
     if (hipGetDevice(&device) == hipSuccess) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     }
-    const int per_cu = p.nchunks >= 4 * cus ? 2 : 1;
-    env->grid = p.nchunks < cus * per_cu ? p.nchunks : cus * per_cu;
+    int per_cu = 1;
+    if (p.group_width > 0) {
+        per_cu = group_blocks_per_cu(p.group_width) - 1;
+        per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
+    } else {
+        per_cu = p.nchunks >= 4 * cus ? 2 : 1;
+    }
+    if (const char* forced = std::getenv("FRZ_WF_BLOCKS_PER_CU")) {
+        const int v = std::atoi(forced);
+        if (v >= 1 && v <= 8) per_cu = v;
+    }
+    const int64_t capacity = (int64_t)cus * per_cu;
+    const int64_t rounds = (p.nchunks + capacity - 1) / capacity;
+    env->grid = (int)((p.nchunks + rounds - 1) / rounds);
     *out = env;
     return FRZ_OK;
 }
@@ -1040,7 +1031,7 @@ int frz_wildfire_rebuild(frz_wildfire_env* env, void* stream) {
     if (!env) return FRZ_E_INVALID;
     if (!env->arena) return FRZ_E_UNBOUND;
     env->was_reset = true;
-    const WfArgs args{env->arena, nullptr, nullptr, nullptr};
+    const WfArgs args{env->arena, nullptr, nullptr, nullptr, &env->dev};
     return launch(env, args, FRZ_RNG_INJECTED, kRebuild, static_cast<hipStream_t>(stream));
 }
 
@@ -1062,7 +1053,7 @@ int frz_wildfire_step(frz_wildfire_env* env, const int32_t* actions, int rng_mod
     if (!env->was_reset) return FRZ_E_INVALID;  // reset()/rebuild() must precede the first step
     const frz_wildfire_cfg& c = env->cfg;
     const WfDev& p = env->dev;
-    WfArgs args{env->arena, actions, nullptr, nullptr};
+    WfArgs args{env->arena, actions, nullptr, nullptr, &env->dev};
     if (rng_mode == FRZ_RNG_INJECTED) {
         if (!field_randomness || !agent_randomness) return FRZ_E_INVALID;
         args.field_rand = field_randomness;

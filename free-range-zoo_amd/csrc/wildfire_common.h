@@ -1,0 +1,90 @@
+// wildfire_common.h — declarations shared by the wildfire kernels (lane-per-env and group-per-env) and the host C-ABI.
+#pragma once
+
+#include "frz_device.h"
+
+#include "../../include/frz.h"
+
+#include <type_traits>
+
+namespace frz_wf {
+
+using frz::kBlock;
+
+constexpr int kTotalsStride = 32;  // uint32 words per totals slot (128 B)
+
+enum Mode { kStep = 0, kRebuild = 1 };
+
+enum Flag : uint32_t {
+    kStochIncrease = 1u << 0, kStochBurnouts = 1u << 1, kStochDecrease = 1u << 2, kUseFuel = 1u << 3, kStochSuppDecrease = 1u << 4,
+    kStochRefill = 1u << 5, kStochSwitch = 1u << 6, kStochRepair = 1u << 7, kStochDegrade = 1u << 8, kCritical = 1u << 9,
+    kShowBad = 1u << 10, kObsPower = 1u << 11, kObsSupp = 1u << 12, kPenaltyScaled = 1u << 13, kLocalize = 1u << 14,
+    kTrackCumulative = 1u << 15, kTruncate = 1u << 16,
+};
+
+// Device-resident configuration block at arena offset 0 (uniform address -> scalar loads at the point of use).
+struct WfDev {
+    int32_t B, H, W, HW, A, S, K, nchunks, nch, others_k, max_steps, num_fire_states;
+    uint32_t flags;
+    int32_t initial_fuel, initial_equipment;
+    float initial_suppressant, initial_capacity;
+    float p_increase, p_burnout, p_decrease, decrease_bonus, p_supp_decrease, p_refill, p_switch, p_repair, p_degrade, p_critical;
+    float spread_n, spread_w, spread_e, spread_s, random_ignition;
+    float bad_attack_penalty, burnout_penalty, termination_reward, termination_kappa;
+    float caps[FRZ_MAX_CAPACITIES], cum[FRZ_MAX_CAPACITIES];
+    float eq[FRZ_MAX_EQUIPMENT_STATES][4];  // (capacity, power, range, -)
+    int32_t ay[FRZ_MAX_AGENTS], ax[FRZ_MAX_AGENTS];
+    float power[FRZ_MAX_AGENTS];
+    uint64_t range_mask[FRZ_MAX_AGENTS][FRZ_MAX_EQUIPMENT_STATES];  // cells agent a reaches at equipment state s
+    uint64_t has_n, has_w, has_e, has_s;                            // cells that have a north/west/east/south neighbour
+    float fire_rewards[FRZ_MAX_CELLS];
+    int32_t ignition[FRZ_MAX_CELLS];
+    int32_t cell_yx[FRZ_MAX_CELLS];  // (y << 16) | x
+    int32_t fire_types[FRZ_MAX_CELLS], lit[FRZ_MAX_CELLS];
+    // row indices of the [rows][B] blocks
+    int32_t r_fires, r_intensity, r_fuel, r_supp, r_cap, r_equip, r_moves, r_burnouts, r_rewards, r_cum, r_atc, r_seeds, r_mti, n_rows4;
+    int32_t q_burnouts, q_putouts, q_etc, n_rows8;
+    int32_t u_term, u_trunc, u_frozen, n_rows1;
+    // byte offsets from the arena base
+    int64_t off_rows4, off_rows8, off_rows1, off_obs_self, off_obs_others, off_task_values, off_task_offsets, off_obs_map,
+        off_act_values, off_act_offsets, off_bad_values, off_bad_offsets, off_mt_state, off_actions, off_error, off_epoch, off_totals,
+        off_agg, off_gtot, off_prefix, off_rand_field, off_rand_agent, total_bytes;
+    int32_t group_width;  // lanes per env of the group-per-env kernel, 0 = lane-per-env kernel
+};
+static_assert(sizeof(WfDev) <= 8192, "configuration block too large");
+constexpr int64_t kDevBlockBytes = 8192;
+
+struct WfArgs {
+    char* arena;
+    const int32_t* actions;
+    const float* field_rand;
+    const float* agent_rand;
+    const WfDev* host_dev;  // host copy of the configuration block (launch-side decisions)
+};
+
+// 4-byte row access with a 32-bit element index: lets the compiler address as (uniform base) + (32-bit lane offset)
+template <typename T>
+__device__ __forceinline__ T& at32(T* base, uint32_t index) {
+    return *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + (uint64_t)(index * (uint32_t)sizeof(T)));
+}
+
+__device__ __forceinline__ float clamp01(float p) {
+    p = p < 0.0f ? 0.0f : p;
+    return p > 1.0f ? 1.0f : p;
+}
+
+template <typename M>
+__device__ __forceinline__ int popc(M m) {
+    if constexpr (sizeof(M) == 8)
+        return __popcll(m);
+    else
+        return __popc(m);
+}
+
+
+
+// group-per-env kernels (wildfire_group.hip)
+int launch_group(const WfArgs& args, int G, int grid, int rng, int mode, hipStream_t stream);
+int group_blocks_per_cu(int G);
+
+}  // namespace frz_wf

@@ -45,7 +45,7 @@ extern "C" {
 
 /* randomness source of a step */
 #define FRZ_RNG_INJECTED 0 /* caller passes the tensors RandomGenerator.generate() would return */
-#define FRZ_RNG_PHILOX 1   /* counter-based Philox4x32-10, key = per-env seed, counter = (draw, step) */
+#define FRZ_RNG_PHILOX 1   /* counter-based Philox4x32-10 keyed by the env seed; stream definition at frz_wildfire_step */
 #define FRZ_RNG_MT19937 2  /* per-env MT19937 streams, seed-identical to the reference's CPU generator */
 
 /* bits of the device-side error word (bufs.error_flags[0]); sticky until cleared by the caller */
@@ -195,10 +195,16 @@ int frz_wildfire_rebuild(frz_wildfire_env* env, void* stream);
 /* replaces one ParallelEnv.step(): BatchedAECEnv.step x A + step_environment + truncation + rebuild.
  * actions: int32 [A][B][2] (each agent's block is the reference's per-agent IntTensor[B,2]).
  * rng_mode FRZ_RNG_INJECTED: field_randomness float32 [3][B][H*W], agent_randomness float32 [5][B][A]
- * (= generator.generate(B,3,(H,W)) / generate(B,5,(A,)), wildfire.py:409-410); otherwise both NULL. */
+ * (= generator.generate(B,3,(H,W)) / generate(B,5,(A,)), wildfire.py:409-410); otherwise both NULL.
+ * rng_mode FRZ_RNG_PHILOX draws the same tensors from Philox4x32-10 with key (seeds[b], 0x46525A00), step = num_moves[b]
+ * before the step and float = (word >> 8) * 2^-24:
+ *   field event e of cell c  = word e     of counter (c, step, 0, 0)
+ *   agent event 0 of agent a = word 3     of counter (a + 1, step, 0, 0)
+ *   agent event e of agent a = word e - 1 of counter (a + 1, step, 1, 0),  e = 1..4 */
 int frz_wildfire_step(frz_wildfire_env* env, const int32_t* actions, int rng_mode, const float* field_randomness,
                       const float* agent_randomness, void* stream);
-/* uniform random policy over OneOf([task]*n + [noop]) (spaces/actions.py:23-41): writes int32 [A][B][2] */
+/* uniform random policy over OneOf([task]*n + [noop]) (spaces/actions.py:23-41): writes int32 [A][B][2];
+ * member j = (word 0 of Philox(counter (i, i >> 32, step, step >> 32), key (seed ^ seeds[b], seed >> 32)) * (n + 1)) >> 32 */
 int frz_wildfire_random_policy(frz_wildfire_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out,
                                void* stream);
 

@@ -84,7 +84,7 @@ float frz_oracle_philox_uniform(int32_t seed, uint32_t step, uint32_t draw, uint
 void frz_oracle_wildfire_philox_randomness(const frz_wildfire_cfg* cfg, const int32_t* seeds, const int32_t* num_moves, float* field,
                                            float* agent);
 void frz_oracle_wildfire_random_policy(const frz_wildfire_cfg* cfg, const int32_t* agent_task_count, const int64_t* env_task_count,
-                                       uint64_t seed, uint64_t step, int32_t* actions);
+                                       const int32_t* env_seeds, uint64_t seed, uint64_t step, int32_t* actions);
 
 #ifdef __cplusplus
 }

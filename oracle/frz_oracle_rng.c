@@ -78,31 +78,44 @@ float frz_oracle_philox_uniform(int32_t seed, uint32_t step, uint32_t draw, uint
     return (float)(out[draw & 3u] >> 8) * (1.0f / 16777216.0f);
 }
 
-/* The randomness tensors a FRZ_RNG_PHILOX wildfire step consumes: stream e = field event e (draw = cell),
- * stream 3 + e = agent event e (draw = agent); step = num_moves before the step. */
+/* The randomness tensors a FRZ_RNG_PHILOX wildfire step consumes (include/frz.h), step = num_moves before the step,
+ * key = (seed, 0x46525A00), float = (word >> 8) * 2^-24:
+ *   field event e of cell c   = word e     of Philox(counter = (c, step, 0, 0))
+ *   agent event 0 of agent a  = word 3     of Philox(counter = (a + 1, step, 0, 0))
+ *   agent event e of agent a  = word e - 1 of Philox(counter = (a + 1, step, 1, 0)),  e = 1..4
+ * (one block serves a cell's three draws and the next agent's first one; a second block the agent's other four). */
+static float philox_word(int32_t seed, uint32_t c0, uint32_t step, uint32_t block, int word) {
+    const uint32_t ctr[4] = {c0, step, block, 0u};
+    const uint32_t key[2] = {(uint32_t)seed, 0x46525A00u};
+    uint32_t out[4];
+    frz_oracle_philox4x32_10(ctr, key, out);
+    return (float)(out[word] >> 8) * (1.0f / 16777216.0f);
+}
+
 void frz_oracle_wildfire_philox_randomness(const frz_wildfire_cfg* cfg, const int32_t* seeds, const int32_t* num_moves, float* field,
                                            float* agent) {
     const int64_t B = cfg->parallel_envs;
     const int32_t HW = cfg->grid_height * cfg->grid_width, A = cfg->num_agents;
     for (int64_t b = 0; b < B; ++b) {
+        const uint32_t step = (uint32_t)num_moves[b];
         for (int32_t e = 0; e < 3; ++e)
-            for (int32_t c = 0; c < HW; ++c)
-                field[(e * B + b) * HW + c] = frz_oracle_philox_uniform(seeds[b], (uint32_t)num_moves[b], (uint32_t)c, (uint32_t)e);
-        for (int32_t e = 0; e < 5; ++e)
-            for (int32_t a = 0; a < A; ++a)
-                agent[(e * B + b) * A + a] = frz_oracle_philox_uniform(seeds[b], (uint32_t)num_moves[b], (uint32_t)a, (uint32_t)(3 + e));
+            for (int32_t c = 0; c < HW; ++c) field[(e * B + b) * HW + c] = philox_word(seeds[b], (uint32_t)c, step, 0u, e);
+        for (int32_t a = 0; a < A; ++a) {
+            agent[(0 * B + b) * A + a] = philox_word(seeds[b], (uint32_t)(a + 1), step, 0u, 3);
+            for (int32_t e = 1; e < 5; ++e) agent[(e * B + b) * A + a] = philox_word(seeds[b], (uint32_t)(a + 1), step, 1u, e - 1);
+        }
     }
 }
 
 /* Uniform random policy over OneOf([task]*n + [noop]) (spaces/actions.py:23-41): member j = floor(u32 * (n+1) / 2^32)
- * with u32 = word 0 of Philox(counter = (i lo, i hi, step lo, step hi), key = seed), i = a*B + b. */
+ * with u32 = word 0 of Philox(counter = (i lo, i hi, step lo, step hi), key = (seed lo ^ env seed, seed hi)), i = a*B + b. */
 void frz_oracle_wildfire_random_policy(const frz_wildfire_cfg* cfg, const int32_t* agent_task_count, const int64_t* env_task_count,
-                                       uint64_t seed, uint64_t step, int32_t* actions) {
+                                       const int32_t* env_seeds, uint64_t seed, uint64_t step, int32_t* actions) {
     const int64_t B = cfg->parallel_envs;
     for (int64_t i = 0; i < (int64_t)cfg->num_agents * B; ++i) {
         const int32_t n = cfg->show_bad_actions ? (int32_t)env_task_count[i % B] : agent_task_count[i];
         const uint32_t ctr[4] = {(uint32_t)i, (uint32_t)((uint64_t)i >> 32), (uint32_t)step, (uint32_t)(step >> 32)};
-        const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+        const uint32_t key[2] = {(uint32_t)seed ^ (uint32_t)env_seeds[i % B], (uint32_t)(seed >> 32)};
         uint32_t out[4];
         frz_oracle_philox4x32_10(ctr, key, out);
         const int32_t j = (int32_t)(((uint64_t)out[0] * (uint64_t)(n + 1)) >> 32);

@@ -151,9 +151,11 @@ def wildfire_philox_randomness(cfg, seeds: np.ndarray, num_moves: np.ndarray):
     return field, agent
 
 
-def wildfire_random_policy(cfg, agent_task_count: np.ndarray, env_task_count: np.ndarray, seed: int, step: int) -> np.ndarray:
+def wildfire_random_policy(cfg, agent_task_count: np.ndarray, env_task_count: np.ndarray, env_seeds: np.ndarray, seed: int,
+                           step: int) -> np.ndarray:
     actions = np.zeros((cfg.num_agents, cfg.parallel_envs, 2), np.int32)
     atc, etc = np.ascontiguousarray(agent_task_count, np.int32), np.ascontiguousarray(env_task_count, np.int64)
-    lib().frz_oracle_wildfire_random_policy(ctypes.byref(cfg), _ptr(atc), _ptr(etc), ctypes.c_uint64(seed), ctypes.c_uint64(step),
-                                            _ptr(actions))
+    seeds = np.ascontiguousarray(env_seeds, np.int32)
+    lib().frz_oracle_wildfire_random_policy(ctypes.byref(cfg), _ptr(atc), _ptr(etc), _ptr(seeds), ctypes.c_uint64(seed),
+                                            ctypes.c_uint64(step), _ptr(actions))
     return actions

@@ -111,7 +111,7 @@ def run_against_oracle(oracle, build, kwargs, B, max_steps, steps, seed, rng='in
         counts_a, counts_e = o.agent_task_count, o.env_task_count
         if policy == 'device':
             actions_dev = env.random_policy_actions(policy_seed=1234 + seed, policy_step=t).clone()
-            actions = oracle.wildfire_random_policy(cfg, counts_a, counts_e, 1234 + seed, t)
+            actions = oracle.wildfire_random_policy(cfg, counts_a, counts_e, seeds.numpy(), 1234 + seed, t)
             G.assert_same(np_(actions_dev), actions, f'policy step {t}')
         else:
             n = (counts_e[None, :] if cfg.show_bad_actions else counts_a).astype(np.int64)

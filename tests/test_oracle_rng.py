@@ -34,9 +34,22 @@ def test_philox_known_answers(oracle):
                                 [0xa4093822, 0x299f31d0]) == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
 
 
-def test_philox_uniform_definition(oracle):
-    u = [oracle.philox_uniform(7, 3, d) for d in range(8)]
-    blocks = [oracle.philox4x32_10([d >> 2, 3, 0, 0], [7, 0x46525A00]) for d in (0, 4)]
-    want = [np.float32(w >> 8) / np.float32(16777216.0) for blk in blocks for w in blk]
-    assert u == [float(x) for x in want]
-    assert all(0.0 <= x < 1.0 for x in u)
+def test_wildfire_philox_stream_definition(oracle):
+    """include/frz.h FRZ_RNG_PHILOX: one block per cell (3 field draws + the next agent's first draw), one per agent."""
+    import ctypes
+    from free_range_zoo_amd import _capi
+    cfg = _capi.frz_wildfire_cfg()
+    cfg.parallel_envs, cfg.grid_height, cfg.grid_width, cfg.num_agents = 2, 2, 3, 3
+    seeds, moves = np.array([7, 11], np.int32), np.array([3, 5], np.int32)
+    field, agent = oracle.wildfire_philox_randomness(cfg, seeds, moves)
+    f32 = lambda w: np.float32(w >> 8) / np.float32(16777216.0)
+    for b in range(2):
+        for c in range(6):
+            blk = oracle.philox4x32_10([c, int(moves[b]), 0, 0], [int(seeds[b]), 0x46525A00])
+            assert [field[e, b, c] for e in range(3)] == [f32(blk[e]) for e in range(3)]
+        for a in range(3):
+            blk0 = oracle.philox4x32_10([a + 1, int(moves[b]), 0, 0], [int(seeds[b]), 0x46525A00])
+            blk1 = oracle.philox4x32_10([a + 1, int(moves[b]), 1, 0], [int(seeds[b]), 0x46525A00])
+            assert agent[0, b, a] == f32(blk0[3])
+            assert [agent[e, b, a] for e in range(1, 5)] == [f32(blk1[e - 1]) for e in range(1, 5)]
+    assert field.min() >= 0.0 and field.max() < 1.0
