@@ -95,7 +95,10 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ aren
 
     uint32_t* const epoch_ptr = reinterpret_cast<uint32_t*>(arena + d.off_epoch);
     uint32_t* const totals = reinterpret_cast<uint32_t*>(arena + d.off_totals);
-    const uint32_t epoch = __hip_atomic_load(epoch_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // plain (cacheable, wave-uniform) load: the word was last written by the previous launch, and this launch only
+    // rewrites it after every workgroup has read it — an agent-scope load here would send one L2 request per wavefront
+    // of the grid to a single address
+    const uint32_t epoch = *epoch_ptr;
     const uint32_t tag = epoch + 1u;  // never 0 on a zero-filled arena
     const uint32_t* prev = totals + ((epoch + 1u) & 1u) * kTotalsStride;
     uint32_t* cur = totals + (epoch & 1u) * kTotalsStride;
@@ -810,9 +813,12 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
     p.A = A;
     p.S = cfg->num_equipment_states;
     p.K = cfg->num_capacities;
-    // small shapes run the group-per-env kernel (8 lanes per env); everything else one env per lane
-    const char* force_lane = std::getenv("FRZ_WF_LANE_KERNEL");
-    p.group_width = (HW <= 8 && A + 1 <= 8 && !(force_lane && force_lane[0] == '1')) ? 8 : 0;
+    // Kernel choice.  Default: one env per lane (every lane does identical work: least total instructions).  The
+    // group-per-env kernel (8 lanes per env, wildfire_group.hip) trades ~3x more wave-instructions for 8x more
+    // wavefronts; measured on MI355X it is slower at every batch size tried, so it is opt-in:
+    // FRZ_WF_GROUP_KERNEL=1.
+    const char* want_group = std::getenv("FRZ_WF_GROUP_KERNEL");
+    p.group_width = (HW <= 8 && A + 1 <= 8 && want_group && want_group[0] == '1') ? 8 : 0;
     const int envs_per_chunk = p.group_width ? kBlock / p.group_width : kBlock;
     p.nchunks = (cfg->parallel_envs + envs_per_chunk - 1) / envs_per_chunk;
     p.nch = A + 3;

@@ -73,7 +73,10 @@ __global__ void __launch_bounds__(kBlock) wf_group_kernel(char* __restrict__ are
 
     uint32_t* const epoch_ptr = reinterpret_cast<uint32_t*>(arena + d.off_epoch);
     uint32_t* const totals = reinterpret_cast<uint32_t*>(arena + d.off_totals);
-    const uint32_t epoch = __hip_atomic_load(epoch_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // plain (cacheable, wave-uniform) load: the word was last written by the previous launch, and this launch only
+    // rewrites it after every workgroup has read it — an agent-scope load here would send one L2 request per wavefront
+    // of the grid to a single address
+    const uint32_t epoch = *epoch_ptr;
     const uint32_t tag = epoch + 1u;
     const uint32_t* prev = totals + ((epoch + 1u) & 1u) * kTotalsStride;
     uint32_t* cur = totals + (epoch & 1u) * kTotalsStride;
@@ -452,58 +455,41 @@ __global__ void __launch_bounds__(kBlock) wf_group_kernel(char* __restrict__ are
         const bool round_last = blockIdx.x == gridDim.x - 1 || chunk == d.nchunks - 1;
         const bool group_last = chunk == group_first + GRP - 1 || round_last;
         bool timed_out = false;
+        const int ch = tid & (NCHP - 1), slot = tid / NCHP;  // slot in [0, GRP)
+        // ---- level 1: sums of the preceding chunks of my group; the group's last chunk publishes the group total at once
+        // (it must not wait for level 2 first, or the groups of a round would form a serial chain)
         {
-            const int ch = tid & (NCHP - 1), slot = tid / NCHP;  // slot in [0, GRP)
             const int pred = group_first + slot;
-            const bool want1 = ch < nch && pred < chunk;
-            uint32_t acc1 = 0, acc2 = 0;
-            for (int spin = 0;; ++spin) {  // bounded
-                bool all = true;
-                uint32_t a1 = 0, a2 = 0;
-                if (want1) {
-                    const uint64_t g = frz::granule_load(agg + (int64_t)pred * nch + ch);
-                    all = all && (uint32_t)(g >> 32) == tag;
-                    a1 = (uint32_t)g;
-                }
-                if (ch < nch)
-                    for (int pg = slot; pg < gi; pg += GRP) {
-                        const uint64_t g = frz::granule_load(gtot + (int64_t)(round_first + pg * GRP) * nch + ch);
-                        all = all && (uint32_t)(g >> 32) == tag;
-                        a2 += (uint32_t)g;
-                    }
-                if (all) {
-                    acc1 = a1;
-                    acc2 = a2;
-                    break;
-                }
-                if (spin >= (1 << 22)) {
-                    timed_out = true;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
+            uint32_t acc1 = 0;
+            if (ch < nch && pred < chunk) acc1 = frz::granule_wait(agg + (int64_t)pred * nch + ch, tag, &timed_out);
+#pragma unroll
+            for (int dd = NCHP; dd < 64; dd <<= 1) acc1 += __shfl_xor(acc1, dd, 64);
+            if (lane < NCHP) s_reduce[wave][lane] = acc1;
+        }
+        __syncthreads();
+        uint32_t level1 = 0;
+        if (tid < nch) {
+#pragma unroll
+            for (int j = 0; j < frz::kWaves; ++j) level1 += s_reduce[j][tid];
+            if (group_last) frz::granule_store(gtot + (int64_t)group_first * nch + tid, tag, level1 + my_total);
+        }
+        // ---- level 2: totals of the preceding groups of this round + the previous round's inclusive prefix
+        {
+            uint32_t acc2 = 0;
+            if (ch < nch)
+                for (int pg = slot; pg < gi; pg += GRP) acc2 += frz::granule_wait(gtot + (int64_t)(round_first + pg * GRP) * nch + ch, tag, &timed_out);
             if (round_first > 0 && tid < nch) acc2 += frz::granule_wait(prefix + (int64_t)(round_first - 1) * nch + tid, tag, &timed_out);
 #pragma unroll
-            for (int dd = NCHP; dd < 64; dd <<= 1) {
-                acc1 += __shfl_xor(acc1, dd, 64);
-                acc2 += __shfl_xor(acc2, dd, 64);
-            }
-            if (lane < NCHP) {
-                s_reduce[wave][lane] = acc1;
-                s_reduce2[wave][lane] = acc2;
-            }
+            for (int dd = NCHP; dd < 64; dd <<= 1) acc2 += __shfl_xor(acc2, dd, 64);
+            if (lane < NCHP) s_reduce2[wave][lane] = acc2;
         }
         __syncthreads();
         if (tid < nch) {
-            uint32_t level1 = 0, level2 = 0;
+            uint32_t level2 = 0;
 #pragma unroll
-            for (int j = 0; j < frz::kWaves; ++j) {
-                level1 += s_reduce[j][tid];
-                level2 += s_reduce2[j][tid];
-            }
+            for (int j = 0; j < frz::kWaves; ++j) level2 += s_reduce2[j][tid];
             const uint32_t exclusive = level1 + level2;
             s_prefix[tid] = exclusive;
-            if (group_last) frz::granule_store(gtot + (int64_t)group_first * nch + tid, tag, level1 + my_total);
             if (round_last) {
                 frz::granule_store(prefix + (int64_t)chunk * nch + tid, tag, exclusive + my_total);
                 if (chunk == d.nchunks - 1) cur[tid] = exclusive + my_total;  // batch totals, read by the next launch
