@@ -112,31 +112,52 @@ def main():
 
     state = {'step': 0, 'episode': 0}
 
+    def episode_metrics():
+        # episode end: the only collective of the job — a metrics reduction over xGMI, nothing on the step path
+        metrics[:A] = env._cumulative.sum(dim=1, dtype=torch.float64)
+        metrics[A] = float(B * EPISODE)
+        metrics[A + 1] = env.finished.sum()
+        if dist is not None:
+            dist.all_reduce(metrics)
+
     def one_step(events=None):
+        """Eager path: the same launches the graphs replay, issued one by one through the Python boundary."""
         if state['step'] % EPISODE == 0:
             if state['step'] > 0:
-                # episode end: the only collective of the job — a metrics reduction, nothing on the step path
-                metrics[:A] = env._cumulative.sum(dim=1, dtype=torch.float64)
-                metrics[A] = float(B * EPISODE)
-                metrics[A + 1] = env.finished.sum()
-                if dist is not None:
-                    dist.all_reduce(metrics)
+                episode_metrics()
             env.reset(seed=base_seed + 1000003 * state['episode'])
             state['episode'] += 1
-        env.random_policy_actions(policy_seed=20260104 + rank, policy_step=state['step'], out=actions)
+        env.random_policy_actions(policy_seed=20260104 + rank, policy_step=state['step'] % EPISODE, out=env._actions)
         if events is not None:
             events[0].record()
-        env.step(actions)
+        env.step(env._actions)
         if events is not None:
             events[1].record()
         state['step'] += 1
 
-    for _ in range(args.warmup):
-        one_step()
+    # ---- timed region: K steps as HIP-graph replays of whole episodes (reset + 50 x (policy, step) per replay)
+    env.reset(seed=base_seed)
+    full = env.capture_random_rollout(EPISODE, policy_seed=20260104 + rank, include_reset=True)
+    rem_steps = args.steps % EPISODE
+    rem = env.capture_random_rollout(rem_steps, policy_seed=20260104 + rank, include_reset=True) if rem_steps else None
+    seed_stride = torch.tensor(1000003, dtype=torch.int32, device=device)
+
+    def run(steps):
+        done = 0
+        while done < steps:
+            env.seeds.add_(seed_stride)  # fresh env seeds for every episode
+            if steps - done >= EPISODE:
+                full.replay()
+                done += EPISODE
+            else:
+                rem.replay()
+                done += steps - done
+            episode_metrics()
+
+    run(max(EPISODE, (args.warmup // EPISODE) * EPISODE))
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
+    run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -144,6 +165,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     value = world * B * args.steps / elapsed
+
+    # ---- the drop-in Python API path (env.step per call, host-bound), reported beside the headline
+    api_steps = min(args.steps, 200)
+    for _ in range(20):
+        one_step()
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(api_steps):
+        one_step()
+    barrier()
+    api_value = world * B * api_steps / (time.perf_counter() - t1)
 
     # ---- kernel-level pass (not part of `value`): HIP events around the fused step launch + mean task counts
     n_probe = min(args.steps, 200)
@@ -185,11 +217,12 @@ def main():
             'dtype': 'i32/f32',
             'data': 'synthetic',
             'config': {'workload': f'wildfire_v0 cfg2 (2x3 grid, 3 agents, agent+task openness on), batch={B} per GPU, '
-                                   f'max_steps={EPISODE}, device random policy, rng={args.rng}, reset inside timed region',
+                                   f'max_steps={EPISODE}, device random policy, rng={args.rng}, reset inside timed region, one HIP graph replay per episode',
                        'parallel_envs_per_gpu': B, 'agents': A, 'sharding': f'env-batch axis x{world}, no step-path collective'},
             'agent_steps_per_s': value * A,
+            'python_api_env_steps_per_s': api_value,
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic, 'kernel': 'wf_step_kernel<8,4>', 'kernel_ms_avg': kernel_ms_avg,
+                         'traffic': traffic, 'kernel': 'wf_step_kernel<6,3,exact,philox>' if args.rng == 'philox' else 'wf_step_kernel<6,3,exact,injected>', 'kernel_ms_avg': kernel_ms_avg,
                          'kernel_ms_median': kernel_ms_med, 'algorithmic_bytes_per_env_step': per_env,
                          'mean_tasks_per_env': mean_tasks, 'mean_agent_tasks_per_env': mean_agent_tasks},
             'reference_cpu_env_steps_per_s': {'value': 21112, 'source': 'BASELINE.md §2: unmodified reference, 8 vCPU, B=65536 (survey container)'},

@@ -298,6 +298,37 @@ class raw_env(BatchedParallelEnv):
                     'frz_wildfire_random_policy')
         return out
 
+    @torch.no_grad()
+    def capture_random_rollout(self, steps: int, policy_seed: int = 0, include_reset: bool = True) -> 'torch.cuda.CUDAGraph':
+        """
+        Capture ``[reset] + steps x (device random policy -> fused step)`` into a HIP graph and return it.
+
+        Launch-bound rollouts (one ~20 us kernel per step) are replayed with ``graph.replay()`` without per-step host
+        work; results land in the same persistent buffers ``step()`` fills.  The env seeds are read at replay time
+        (``env.seeds`` may be changed between replays); the reset inside the graph restores the configured initial
+        state (it does not re-run the Python-side ``save_initial``).
+        """
+        if not self._has_reset:
+            raise RuntimeError('reset() must be called once before capturing a rollout')
+        lib, handle, actions = self._lib, self._handle, self._actions.data_ptr()
+        mt = self.rng == 'mt19937'
+        if mt:
+            self.generator._ensure_streams()
+        mode = _capi.FRZ_RNG_MT19937 if mt else _capi.FRZ_RNG_PHILOX
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            stream = stream_ptr(self.device)
+            if include_reset:
+                if mt:
+                    _capi.check(lib.frz_mt19937_seed(self._bufs.mt_state, self._bufs.mt_index, self._bufs.seeds, None, 0,
+                                                     self.parallel_envs, stream), 'frz_mt19937_seed')
+                _capi.check(lib.frz_wildfire_reset(handle, stream), 'frz_wildfire_reset')
+            for t in range(steps):
+                _capi.check(lib.frz_wildfire_random_policy(handle, policy_seed, t, actions, stream), 'frz_wildfire_random_policy')
+                _capi.check(lib.frz_wildfire_step(handle, actions, mode, None, None, stream), 'frz_wildfire_step')
+        return graph
+
     # ------------------------------------------------------------------------------------------------ spaces
     @torch.no_grad()
     def action_space(self, agent: str) -> BatchedOneOfSpace:

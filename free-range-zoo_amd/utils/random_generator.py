@@ -70,10 +70,13 @@ class RandomGenerator:
         _capi.check(_capi.lib().frz_mt19937_seed(self.generator_states.data_ptr(), self.generator_index.data_ptr(), self.seeds.data_ptr(),
                                                  indices_ptr, n, self.parallel_envs, _stream_ptr(self.device)), 'frz_mt19937_seed')
 
-    def _draw(self, events: int, count: int) -> torch.Tensor:
+    def _ensure_streams(self) -> None:
         if not self._streams_valid:
             self._seed_streams(None)
             self._streams_valid = True
+
+    def _draw(self, events: int, count: int) -> torch.Tensor:
+        self._ensure_streams()
         out = torch.empty((events, self.parallel_envs, count), dtype=torch.float32, device=self.device)
         _capi.check(_capi.lib().frz_mt19937_generate(self.generator_states.data_ptr(), self.generator_index.data_ptr(), out.data_ptr(),
                                                      events, count, self.parallel_envs, _stream_ptr(self.device)),

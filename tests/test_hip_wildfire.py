@@ -272,3 +272,27 @@ def test_action_space_sampling_is_valid():
     env.check()
     spaces = env.action_space(env.agents[0]).spaces
     assert len(spaces) == 2048 and len(spaces[0]) == int(env.agent_task_count[0][0]) + 1
+
+
+@pytest.mark.parametrize('rng', ['philox', 'mt19937'])
+def test_graph_replayed_rollout_equals_eager_rollout(rng):
+    """capture_random_rollout() replays exactly the launches of the eager loop (reset + policy + step)."""
+    B, steps = 3000, 12
+    seeds = torch.arange(B, dtype=torch.int32) * 3 + 1
+    eager = make_env(configs.wildfire_openness, B, 50, rng=rng, exact_shapes=False)
+    eager.reset(seed=seeds)
+    for t in range(steps):
+        eager.step(eager.random_policy_actions(policy_seed=77, policy_step=t))
+    graphed = make_env(configs.wildfire_openness, B, 50, rng=rng, exact_shapes=False)
+    graphed.reset(seed=seeds)
+    graph = graphed.capture_random_rollout(steps, policy_seed=77, include_reset=True)
+    for _ in range(2):  # the second replay starts from the in-graph reset again
+        graphed.seeds.copy_(seeds)
+        graph.replay()
+    torch.cuda.synchronize()
+    for name in ('_fires', '_intensity', '_fuel', '_suppressants', '_capacity', '_equipment', '_rewards', '_cumulative', 'num_moves',
+                 '_task_offsets', '_act_map_offsets', 'environment_task_count', 'agent_task_count', '_obs_self'):
+        assert torch.equal(getattr(eager, name), getattr(graphed, name)), name
+    total = int(eager._task_offsets[-1])
+    assert torch.equal(eager._task_values[:total], graphed._task_values[:total])
+    graphed.check()
