@@ -177,12 +177,27 @@ def main():
     barrier()
     api_value = world * B * api_steps / (time.perf_counter() - t1)
 
-    # ---- kernel-level pass (not part of `value`): HIP events around the fused step launch + mean task counts
+    # ---- kernel-level pass (not part of `value`): HIP events on the launch stream around the fused step launch alone
+    # (C-ABI calls, no Python-side tensor work between the two records) + mean task counts for the algorithmic bytes
+    from free_range_zoo_amd import _capi
+    from free_range_zoo_amd.utils.env import stream_ptr
+    lib, handle = env._lib, env._handle
+    mode = _capi.FRZ_RNG_MT19937 if args.rng == 'mt19937' else _capi.FRZ_RNG_PHILOX
     n_probe = min(args.steps, 200)
     pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_probe)]
     task_sum = torch.zeros(1 + A, dtype=torch.float64, device=device)
+    env.reset(seed=base_seed + 17)
+    stream = stream_ptr(device)
     for i in range(n_probe):
-        one_step(pairs[i])
+        if i % EPISODE == 0 and i > 0:
+            env.seeds.add_(seed_stride)
+            if args.rng == 'mt19937':
+                env.generator._seed_streams(None)
+            lib.frz_wildfire_reset(handle, stream)
+        lib.frz_wildfire_random_policy(handle, 20260104 + rank, i % EPISODE, env._actions.data_ptr(), stream)
+        pairs[i][0].record()
+        lib.frz_wildfire_step(handle, env._actions.data_ptr(), mode, None, None, stream)
+        pairs[i][1].record()
         task_sum[0] += env.environment_task_count.sum()
         task_sum[1:] += env.agent_task_count.sum(dim=1)
     torch.cuda.synchronize(device)
