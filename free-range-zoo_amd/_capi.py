@@ -18,6 +18,8 @@ globals().update({k: v for k, v in DEFINES.items()})
 
 frz_wildfire_cfg = STRUCTS['frz_wildfire_cfg']
 frz_wildfire_bufs = STRUCTS['frz_wildfire_bufs']
+frz_cybersecurity_cfg = STRUCTS['frz_cybersecurity_cfg']
+frz_cybersecurity_bufs = STRUCTS['frz_cybersecurity_bufs']
 
 _lib = None
 
@@ -34,6 +36,15 @@ SIGNATURES = {
     'frz_wildfire_rebuild': (ctypes.c_int, [_P, _P]),
     'frz_wildfire_step': (ctypes.c_int, [_P, _P, ctypes.c_int, _P, _P, _P]),
     'frz_wildfire_random_policy': (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_uint64, _P, _P]),
+    'frz_cybersecurity_create': (ctypes.c_int, [_P, ctypes.POINTER(_P)]),
+    'frz_cybersecurity_destroy': (None, [_P]),
+    'frz_cybersecurity_arena_bytes': (ctypes.c_int64, [_P]),
+    'frz_cybersecurity_bind': (ctypes.c_int, [_P, _P, _P]),
+    'frz_cybersecurity_get_bufs': (ctypes.c_int, [_P, _P]),
+    'frz_cybersecurity_reset': (ctypes.c_int, [_P, _P]),
+    'frz_cybersecurity_rebuild': (ctypes.c_int, [_P, _P]),
+    'frz_cybersecurity_step': (ctypes.c_int, [_P, _P, ctypes.c_int, _P, _P, _P]),
+    'frz_cybersecurity_random_policy': (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_uint64, _P, _P]),
     'frz_mt19937_seed': (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int64, ctypes.c_int64, _P]),
     'frz_mt19937_generate': (ctypes.c_int, [_P, _P, _P, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _P]),
 }

@@ -209,6 +209,91 @@ int frz_wildfire_random_policy(frz_wildfire_env* env, uint64_t policy_seed, uint
                                void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Cybersecurity  (reference: free_range_zoo/envs/cybersecurity/env/cybersecurity.py, transitions/,
+ *                 structures/configuration.py, utils/masking.py)
+ * Agents are ordered attackers first, then defenders (cybersecurity.py:189-193).
+ * ---------------------------------------------------------------------------------------------- */
+
+typedef struct frz_cybersecurity_cfg {
+    int32_t parallel_envs;  /* B */
+    int32_t num_nodes;      /* N   configuration.py:205 */
+    int32_t num_attackers;
+    int32_t num_defenders;
+    int32_t max_steps;      /* < 0 means None */
+    int32_t num_states;     /* patched + vulnerable + exploited (configuration.py:210) */
+    int32_t stochastic_state;          /* StochasticConfiguration.network_state */
+    int32_t show_bad_actions;          /* cybersecurity.py:161-170 env flags */
+    int32_t partially_observable;
+    int32_t observe_other_power;
+    int32_t observe_other_presence;
+    int32_t observe_other_location;
+    int32_t track_cumulative_rewards;
+    float temperature;
+    float bad_action_penalty;
+    float patch_reward;
+    float threat[FRZ_MAX_AGENTS];        /* per attacker */
+    float mitigation[FRZ_MAX_AGENTS];    /* per defender */
+    float persist_probs[FRZ_MAX_AGENTS]; /* all agents, attackers first (configuration.py:61-64) */
+    float return_probs[FRZ_MAX_AGENTS];
+    int32_t initial_presence[FRZ_MAX_AGENTS]; /* all agents */
+    int32_t initial_location[FRZ_MAX_AGENTS]; /* per defender, -1 = home */
+    int32_t initial_state[FRZ_MAX_NODES];
+    int32_t criticality[FRZ_MAX_NODES]; /* adjacency row sums (configuration.py:199-201) */
+    float network_state_rewards[FRZ_MAX_NETWORK_STATES];
+} frz_cybersecurity_cfg;
+
+/* Arrays of one cybersecurity env object (one device arena, like wildfire).  A = attackers + defenders. */
+typedef struct frz_cybersecurity_bufs {
+    int32_t* network_state; /* [N][B]   0 = best .. num_states-1 */
+    int32_t* location;      /* [D][B]   -1 = home node */
+    uint8_t* presence;      /* [A][B] */
+    int32_t* last_action;   /* [D][B]   action id of the defender's last action (monitor = -3), -2 after reset */
+    int32_t* num_moves;     /* [B] */
+    float* rewards;            /* [A][B] */
+    float* cumulative_rewards; /* [A][B] */
+    uint8_t* terminations;     /* [A][B] always 0 (cybersecurity.py:298) */
+    uint8_t* truncations;      /* [A][B] */
+    float* obs_self_attackers;   /* [Att][B][2]  (threat, presence)               cybersecurity.py:481-484 */
+    float* obs_self_defenders;   /* [D][B][3]    (mitigation, presence, location) cybersecurity.py:475-479 */
+    float* obs_others_attackers; /* [Att][B][(Att-1)*ka] columns kept by utils/masking.py:6-28 */
+    float* obs_others_defenders; /* [D][B][(D-1)*kd] */
+    int64_t* obs_tasks;          /* [A][B][N][2] (state, criticality); -100 for a defender whose last action was not monitor */
+    int32_t* act_map_values;     /* [A][B*N]  arange(N) per present env (cybersecurity.py:441-451) */
+    int64_t* act_map_offsets;    /* [A][B+1] */
+    int32_t* obs_map_values;     /* [B][N]    arange(N) per env; offsets are arange(B+1) (cybersecurity.py:434-439) */
+    int64_t* obs_map_offsets;    /* [B+1] */
+    int32_t* env_task_count;     /* [B]  = N  (int32: filled in place, cybersecurity.py:422) */
+    int32_t* agent_task_count;   /* [A][B] = N * presence */
+    uint8_t* frozen_scaled;      /* [B] */
+    int32_t* seeds;       /* [B] */
+    uint32_t* mt_state;   /* [624][B] */
+    int32_t* mt_index;    /* [B] */
+    int32_t* actions;     /* [A][B][2] default action buffer */
+    uint32_t* error_flags;
+} frz_cybersecurity_bufs;
+
+typedef struct frz_cybersecurity_env frz_cybersecurity_env;
+
+int frz_cybersecurity_create(const frz_cybersecurity_cfg* cfg, frz_cybersecurity_env** out);
+void frz_cybersecurity_destroy(frz_cybersecurity_env* env);
+int64_t frz_cybersecurity_arena_bytes(const frz_cybersecurity_env* env);
+int frz_cybersecurity_bind(frz_cybersecurity_env* env, void* arena, void* stream);
+int frz_cybersecurity_get_bufs(const frz_cybersecurity_env* env, frz_cybersecurity_bufs* out);
+/* cybersecurity.py:218-266 (state from the configuration, last actions = -2) + update_observations/update_actions */
+int frz_cybersecurity_reset(frz_cybersecurity_env* env, void* stream);
+int frz_cybersecurity_rebuild(frz_cybersecurity_env* env, void* stream);
+/* one ParallelEnv.step() (cybersecurity.py:295-526).  actions int32 [A][B][2]: attackers (node, 0) attack / (_, -1) noop;
+ * defenders (node, 0) move / (_, -1) noop / (_, -2) patch / (_, -3) monitor.
+ * FRZ_RNG_INJECTED: network_randomness float32 [1][B][N], agent_randomness float32 [1][B][A] (cybersecurity.py:304-315).
+ * FRZ_RNG_PHILOX (key (seeds[b], 0x46525A01), step = num_moves[b] before the step, float = (word >> 8) * 2^-24):
+ *   node n draw  = word n & 3 of counter (n >> 2, step, 0, 0);  agent a draw = word a & 3 of counter (a >> 2, step, 1, 0) */
+int frz_cybersecurity_step(frz_cybersecurity_env* env, const int32_t* actions, int rng_mode, const float* network_randomness,
+                           const float* agent_randomness, void* stream);
+/* uniform random policy over each agent's OneOf action space (spaces/actions.py:11-99), Philox keyed like wildfire's */
+int frz_cybersecurity_random_policy(frz_cybersecurity_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out,
+                                    void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Per-env MT19937 streams  (reference: free_range_zoo/utils/random_generator.py:49-146; torch CPU
  * generator = MT19937 init_genrand(seed), float32 = (u32 & 0xFFFFFF) * 2^-24)
  * ---------------------------------------------------------------------------------------------- */

@@ -74,6 +74,46 @@ void frz_oracle_wf_fire_spread(const frz_wildfire_cfg* cfg, int32_t* fires, int3
                                const float* r, int64_t B);
 int frz_oracle_in_range_chebyshev(int32_t ay, int32_t ax, int32_t ty, int32_t tx, float attack_range);
 
+/* ---------------------------------------------------------------------------------------------- cybersecurity */
+typedef struct frz_oracle_cybersecurity_bufs {
+    /* state, batch-major as in CybersecurityState (structures/state.py:12-53) */
+    int32_t* network_state; /* [B][N] */
+    int32_t* location;      /* [B][D] */
+    uint8_t* presence;      /* [B][A] */
+    int32_t* last_action;   /* [B][D] */
+    int32_t* num_moves;
+    float* rewards;            /* [A][B] */
+    float* cumulative_rewards; /* [A][B] */
+    uint8_t* terminations;
+    uint8_t* truncations;
+    float* obs_self_attackers;
+    float* obs_self_defenders;
+    float* obs_others_attackers;
+    float* obs_others_defenders;
+    int64_t* obs_tasks;
+    int32_t* act_map_values;
+    int64_t* act_map_offsets;
+    int32_t* obs_map_values;
+    int64_t* obs_map_offsets;
+    int32_t* env_task_count;
+    int32_t* agent_task_count;
+    uint32_t* error_flags;
+    int32_t* frozen;
+} frz_oracle_cybersecurity_bufs;
+
+int frz_oracle_cybersecurity_reset(const frz_cybersecurity_cfg* cfg, frz_oracle_cybersecurity_bufs* s);
+int frz_oracle_cybersecurity_rebuild(const frz_cybersecurity_cfg* cfg, frz_oracle_cybersecurity_bufs* s);
+int frz_oracle_cybersecurity_step(const frz_cybersecurity_cfg* cfg, frz_oracle_cybersecurity_bufs* s, const int32_t* actions,
+                                  const float* network_randomness, const float* agent_randomness);
+void frz_oracle_cy_movement(int32_t* location, const int32_t* targets, const uint8_t* mask, int64_t n);
+void frz_oracle_cy_presence(const frz_cybersecurity_cfg* cfg, uint8_t* presence, int32_t* location, const float* r, int64_t B);
+void frz_oracle_cy_subnetwork(const frz_cybersecurity_cfg* cfg, int32_t* network_state, const float* patches, const float* attacks,
+                              const float* r, int64_t n);
+void frz_oracle_cybersecurity_philox_randomness(const frz_cybersecurity_cfg* cfg, const int32_t* seeds, const int32_t* num_moves,
+                                                float* network, float* agent);
+void frz_oracle_cybersecurity_random_policy(const frz_cybersecurity_cfg* cfg, const int32_t* agent_task_count, const int32_t* location,
+                                            const int32_t* env_seeds, uint64_t seed, uint64_t step, int32_t* actions);
+
 /* MT19937 per-env streams (utils/random_generator.py:76-114); state batch-major [B][624] */
 void frz_oracle_mt19937_seed(uint32_t* mt_state, int32_t* mt_index, const int32_t* seeds, int64_t B);
 void frz_oracle_mt19937_generate(uint32_t* mt_state, int32_t* mt_index, float* out, int64_t events, int64_t count, int64_t B);

@@ -21,6 +21,7 @@ from free_range_zoo_amd._cstruct import parse_header  # noqa: E402
 LIB_PATH = os.path.join(_HERE, 'libfrz_oracle.so')
 _, _STRUCTS = parse_header(os.path.join(_HERE, 'frz_oracle.h'), known=_capi.STRUCTS)
 frz_oracle_wildfire_bufs = _STRUCTS['frz_oracle_wildfire_bufs']
+frz_oracle_cybersecurity_bufs = _STRUCTS['frz_oracle_cybersecurity_bufs']
 
 _lib = None
 
@@ -158,4 +159,82 @@ def wildfire_random_policy(cfg, agent_task_count: np.ndarray, env_task_count: np
     seeds = np.ascontiguousarray(env_seeds, np.int32)
     lib().frz_oracle_wildfire_random_policy(ctypes.byref(cfg), _ptr(atc), _ptr(etc), _ptr(seeds), ctypes.c_uint64(seed),
                                             ctypes.c_uint64(step), _ptr(actions))
+    return actions
+
+
+class _ArrayOracle:
+    """Common plumbing: named numpy arrays bound to a ctypes bufs struct."""
+
+    def _bind(self, struct_cls, arrays):
+        self.arrays = arrays
+        self.bufs = struct_cls()
+        for name, arr in arrays.items():
+            setattr(self.bufs, name, _ptr(arr))
+
+    def __getattr__(self, name):
+        arrays = self.__dict__.get('arrays', {})
+        if name in arrays:
+            return arrays[name]
+        raise AttributeError(name)
+
+
+def cyber_others_cols(cfg):
+    ka = int(bool(cfg.observe_other_power)) + int(bool(cfg.observe_other_presence))
+    return ka, ka + int(bool(cfg.observe_other_location))
+
+
+class CybersecurityOracle(_ArrayOracle):
+    """One cybersecurity env batch in the reference's batch-major layout, stepped by the C oracle."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        B, N, Att, D = cfg.parallel_envs, cfg.num_nodes, cfg.num_attackers, cfg.num_defenders
+        A = Att + D
+        ka, kd = cyber_others_cols(cfg)
+        z = np.zeros
+        self._bind(frz_oracle_cybersecurity_bufs, dict(
+            network_state=z((B, N), np.int32), location=z((B, D), np.int32), presence=z((B, A), np.uint8),
+            last_action=z((B, D), np.int32), num_moves=z(B, np.int32), rewards=z((A, B), np.float32),
+            cumulative_rewards=z((A, B), np.float32), terminations=z((A, B), np.uint8), truncations=z((A, B), np.uint8),
+            obs_self_attackers=z((Att, B, 2), np.float32), obs_self_defenders=z((D, B, 3), np.float32),
+            obs_others_attackers=z((Att, B, max(Att - 1, 0) * ka), np.float32),
+            obs_others_defenders=z((D, B, max(D - 1, 0) * kd), np.float32), obs_tasks=z((A, B, N, 2), np.int64),
+            act_map_values=z((A, B * N), np.int32), act_map_offsets=z((A, B + 1), np.int64), obs_map_values=z((B, N), np.int32),
+            obs_map_offsets=z(B + 1, np.int64), env_task_count=z(B, np.int32), agent_task_count=z((A, B), np.int32),
+            error_flags=z(1, np.uint32), frozen=z(2, np.int32)))
+
+    def reset(self):
+        assert lib().frz_oracle_cybersecurity_reset(ctypes.byref(self.cfg), ctypes.byref(self.bufs)) == 0
+
+    def rebuild(self):
+        assert lib().frz_oracle_cybersecurity_rebuild(ctypes.byref(self.cfg), ctypes.byref(self.bufs)) == 0
+
+    def step(self, actions, network_randomness, agent_randomness):
+        """actions int32 [A,B,2]; network_randomness f32 [1,B,N]; agent_randomness f32 [1,B,A]."""
+        actions = np.ascontiguousarray(actions, np.int32)
+        nr, ar = np.ascontiguousarray(network_randomness, np.float32), np.ascontiguousarray(agent_randomness, np.float32)
+        B, N, A = self.cfg.parallel_envs, self.cfg.num_nodes, self.cfg.num_attackers + self.cfg.num_defenders
+        assert actions.shape == (A, B, 2) and nr.size == B * N and ar.size == B * A
+        assert lib().frz_oracle_cybersecurity_step(ctypes.byref(self.cfg), ctypes.byref(self.bufs), _ptr(actions), _ptr(nr), _ptr(ar)) == 0
+
+    def action_map(self, a):
+        off = self.act_map_offsets[a]
+        return self.act_map_values[a, :int(off[-1])], off
+
+
+def cybersecurity_philox_randomness(cfg, seeds, num_moves):
+    B, N, A = cfg.parallel_envs, cfg.num_nodes, cfg.num_attackers + cfg.num_defenders
+    network, agent = np.zeros((1, B, N), np.float32), np.zeros((1, B, A), np.float32)
+    seeds, num_moves = np.ascontiguousarray(seeds, np.int32), np.ascontiguousarray(num_moves, np.int32)
+    lib().frz_oracle_cybersecurity_philox_randomness(ctypes.byref(cfg), _ptr(seeds), _ptr(num_moves), _ptr(network), _ptr(agent))
+    return network, agent
+
+
+def cybersecurity_random_policy(cfg, agent_task_count, location, env_seeds, seed, step):
+    A = cfg.num_attackers + cfg.num_defenders
+    actions = np.zeros((A, cfg.parallel_envs, 2), np.int32)
+    atc, loc = np.ascontiguousarray(agent_task_count, np.int32), np.ascontiguousarray(location, np.int32)
+    seeds = np.ascontiguousarray(env_seeds, np.int32)
+    lib().frz_oracle_cybersecurity_random_policy(ctypes.byref(cfg), _ptr(atc), _ptr(loc), _ptr(seeds), ctypes.c_uint64(seed),
+                                                 ctypes.c_uint64(step), _ptr(actions))
     return actions
