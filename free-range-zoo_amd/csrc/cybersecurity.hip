@@ -1,0 +1,678 @@
+// cybersecurity.hip — fused cybersecurity environment step for gfx950 (MI355X), one environment per lane.
+//
+// One launch = one ParallelEnv.step() of the reference (cybersecurity.py:295-526) for the whole batch:
+//   attacker / defender action decode (attack sets, patch sets, moves) -> movement -> presence (agent openness)
+//   -> subnetwork danger-score transition -> criticality-weighted rewards -> truncation bookkeeping
+//   -> update_observations (partial observability) + update_actions (presence-gated action mappings, compacted with
+//      the launch-wide single-pass prefix scan of frz_scan.h).
+//
+// The state is dense and tiny (N nodes, D defenders, A agents per env): struct-of-arrays rows [k][B] in one device
+// arena, every access a contiguous 256-byte segment per wavefront.  The danger score tanh((patches - attacks) / T) only
+// depends on WHICH defenders patch and WHICH attackers attack a node (sums accumulated in agent order), so it is a
+// 2^A-entry table built on the host with the same libm tanhf the oracle uses; the kernel looks it up (LDS when small).
+// HBM-bound integer/byte work: no MFMA.  Built with -ffp-contract=off.
+#include "frz_scan.h"
+
+#include "../../include/frz.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+namespace {
+
+using frz::kBlock;
+
+enum Mode { kStep = 0, kRebuild = 1 };
+enum Flag : uint32_t {
+    kStochState = 1u << 0, kShowBad = 1u << 1, kPartial = 1u << 2, kObsPower = 1u << 3, kObsPresence = 1u << 4, kObsLocation = 1u << 5,
+    kTrackCumulative = 1u << 6, kTruncate = 1u << 7,
+};
+constexpr int kLdsLutEntries = 1024;  // danger tables up to this size are staged in LDS
+
+struct CyDev {
+    int32_t B, N, Att, D, A, S, nchunks, max_steps, lut_entries;
+    uint32_t flags;
+    float patch_reward;
+    float threat[FRZ_MAX_AGENTS], mitigation[FRZ_MAX_AGENTS], persist[FRZ_MAX_AGENTS], back[FRZ_MAX_AGENTS];
+    int32_t initial_presence[FRZ_MAX_AGENTS], initial_location[FRZ_MAX_AGENTS], initial_state[FRZ_MAX_NODES];
+    int32_t criticality[FRZ_MAX_NODES];
+    float state_rewards[FRZ_MAX_NETWORK_STATES];
+    int32_t r_state, r_loc, r_last, r_moves, r_rewards, r_cum, r_atc, r_etc, r_seeds, r_mti, n_rows4;
+    int32_t u_presence, u_term, u_trunc, u_frozen, n_rows1;
+    int64_t off_rows4, off_rows1, off_self_att, off_self_def, off_others_att, off_others_def, off_tasks, off_act_values,
+        off_act_offsets, off_obs_map, off_obs_map_offsets, off_lut, off_actions, off_error, off_epoch, off_totals, off_agg, off_prefix,
+        off_rand_net, off_rand_agent, off_mt_state, total_bytes;
+};
+constexpr int64_t kDevBlockBytes = 4096;
+static_assert(sizeof(CyDev) <= kDevBlockBytes, "configuration block too large");
+
+template <typename T>
+__device__ __forceinline__ T& at32(T* base, uint32_t index) {
+    return *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + (uint64_t)(index * (uint32_t)sizeof(T)));
+}
+
+// cybersecurity.py:218-266 + utils/env.py:137-160
+__global__ void __launch_bounds__(kBlock) cy_fill_kernel(char* arena) {
+    const CyDev& d = *reinterpret_cast<const CyDev*>(arena);
+    const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x, B = d.B;
+    if (b >= B) return;
+    int32_t* rows = reinterpret_cast<int32_t*>(arena + d.off_rows4);
+    float* rowsf = reinterpret_cast<float*>(arena + d.off_rows4);
+    uint8_t* rows1 = reinterpret_cast<uint8_t*>(arena + d.off_rows1);
+    for (int n = 0; n < d.N; ++n) rows[(d.r_state + n) * B + b] = d.initial_state[n];
+    for (int k = 0; k < d.D; ++k) {
+        rows[(d.r_loc + k) * B + b] = d.initial_location[k];
+        rows[(d.r_last + k) * B + b] = -2;  // cybersecurity.py:233-236
+    }
+    for (int a = 0; a < d.A; ++a) {
+        rows1[(d.u_presence + a) * B + b] = (uint8_t)(d.initial_presence[a] != 0);
+        rowsf[(d.r_rewards + a) * B + b] = 0.0f;
+        rowsf[(d.r_cum + a) * B + b] = 0.0f;
+        rows1[(d.u_term + a) * B + b] = 0;
+        rows1[(d.u_trunc + a) * B + b] = 0;
+    }
+    rows[d.r_moves * B + b] = 0;
+    rows1[d.u_frozen * B + b] = 0;
+}
+
+template <int NMAX, int AMAX, int RNG, int MODE>
+__global__ void __launch_bounds__(kBlock) cy_step_kernel(char* __restrict__ arena, const CyDev* __restrict__ dev,
+                                                          const int32_t* __restrict__ actions, const float* __restrict__ net_rand,
+                                                          const float* __restrict__ agent_rand) {
+    __shared__ frz::ScanShared<AMAX> s_scan;
+    __shared__ float s_lut[kLdsLutEntries];
+    __shared__ float s_state_rewards[FRZ_MAX_NETWORK_STATES];
+
+    const CyDev& d = *dev;
+    const int tid = threadIdx.x;
+    const int64_t B = d.B;
+    const uint32_t Bu = (uint32_t)d.B;
+    const int N = d.N, Att = d.Att, D = d.D, A = d.A;
+    const uint32_t flags = d.flags;
+    const float* lut = reinterpret_cast<const float*>(arena + d.off_lut);
+    const bool lut_in_lds = d.lut_entries <= kLdsLutEntries;
+    if (MODE == kStep) {
+        if (lut_in_lds)
+            for (int i = tid; i < d.lut_entries; i += kBlock) s_lut[i] = lut[i];
+        if (tid < FRZ_MAX_NETWORK_STATES) s_state_rewards[tid] = d.state_rewards[tid];
+    }
+
+    frz::ScanWorkspace ws{reinterpret_cast<uint32_t*>(arena + d.off_epoch), reinterpret_cast<uint32_t*>(arena + d.off_totals),
+                          reinterpret_cast<uint64_t*>(arena + d.off_agg), reinterpret_cast<uint64_t*>(arena + d.off_prefix)};
+    const frz::ScanLaunch launch = frz::scan_begin(ws);
+    int32_t* const rows = reinterpret_cast<int32_t*>(arena + d.off_rows4);
+    float* const rowsf = reinterpret_cast<float*>(arena + d.off_rows4);
+    uint8_t* const rows1 = reinterpret_cast<uint8_t*>(arena + d.off_rows1);
+
+    // utils/env.py:211-213: no-op once ALL envs are terminated (never, cybersecurity.py:298) or ALL are truncated;
+    // totals channels A / A + 1 = number of envs not terminated / not truncated after the previous launch
+    bool frozen = false;
+    if (MODE == kStep) frozen = launch.prev[A] == 0u || launch.prev[A + 1] == 0u;
+    __syncthreads();
+
+    for (int chunk = blockIdx.x; chunk < d.nchunks; chunk += gridDim.x) {
+        const int64_t b = (int64_t)chunk * kBlock + tid;
+        const bool active = b < B;
+        const uint32_t bl = (uint32_t)(active ? b : B - 1);
+
+        if (frozen) {  // the parallel adapter sums the stale rewards once per agent call (utils/conversions.py:87-90)
+            if (active && !at32(rows1, (uint32_t)d.u_frozen * Bu + bl)) {
+                for (int a = 0; a < A; ++a) {
+                    const float r = at32(rowsf, (uint32_t)(d.r_rewards + a) * Bu + bl);
+                    float acc = 0.0f;
+                    for (int j = 0; j < A; ++j) acc = acc + r;
+                    at32(rowsf, (uint32_t)(d.r_rewards + a) * Bu + bl) = acc;
+                }
+                at32(rows1, (uint32_t)d.u_frozen * Bu + bl) = 1;
+            }
+            continue;
+        }
+
+        // ------------------------------------------------------------------------------------------ load state
+        int state[NMAX], loc[AMAX], last[AMAX];
+        bool pres[AMAX];
+#pragma unroll
+        for (int n = 0; n < NMAX; ++n) state[n] = n < N ? at32(rows, (uint32_t)(d.r_state + n) * Bu + bl) : 0;
+#pragma unroll
+        for (int k = 0; k < AMAX; ++k) {
+            loc[k] = k < D ? at32(rows, (uint32_t)(d.r_loc + k) * Bu + bl) : -1;
+            last[k] = k < D ? at32(rows, (uint32_t)(d.r_last + k) * Bu + bl) : -2;
+        }
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a) pres[a] = a < A ? at32(rows1, (uint32_t)(d.u_presence + a) * Bu + bl) != 0 : false;
+        bool trunc = at32(rows1, (uint32_t)d.u_trunc * Bu + bl) != 0;
+        uint32_t err = 0;
+
+        if (MODE == kStep) {
+            int nm = at32(rows, (uint32_t)d.r_moves * Bu + bl);
+            // ---------------------------------------------------------------------------------- randomness
+            float r_net[NMAX], r_agent[AMAX];
+            if (RNG == FRZ_RNG_INJECTED) {
+#pragma unroll
+                for (int n = 0; n < NMAX; ++n) r_net[n] = n < N ? net_rand[(int64_t)bl * N + n] : 0.0f;
+#pragma unroll
+                for (int a = 0; a < AMAX; ++a) r_agent[a] = a < A ? agent_rand[(int64_t)bl * A + a] : 0.0f;
+            } else {  // FRZ_RNG_PHILOX stream of include/frz.h
+                const uint32_t seed = (uint32_t)at32(rows, (uint32_t)d.r_seeds * Bu + bl);
+#pragma unroll
+                for (int q = 0; q < (NMAX + 3) / 4; ++q) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (q * 4 + j < NMAX) r_net[q * 4 + j] = 0.0f;
+                    if (q * 4 < N && (flags & kStochState)) {
+                        const frz::Philox4 w = frz::philox4x32_10((uint32_t)q, (uint32_t)nm, 0u, 0u, seed, 0x46525A01u);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (q * 4 + j < NMAX) r_net[q * 4 + j] = frz::u32_to_unit_float(w.w[j]);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < (AMAX + 3) / 4; ++q) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (q * 4 + j < AMAX) r_agent[q * 4 + j] = 0.0f;
+                    if (q * 4 < A) {
+                        const frz::Philox4 w = frz::philox4x32_10((uint32_t)q, (uint32_t)nm, 1u, 0u, seed, 0x46525A01u);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (q * 4 + j < AMAX) r_agent[q * 4 + j] = frz::u32_to_unit_float(w.w[j]);
+                    }
+                }
+            }
+
+            // ----------------------------------------------- action decode (cybersecurity.py:326-384), agent order
+            uint32_t attack_set[NMAX], patch_set[NMAX];  // bit a: attacker a attacks / defender a patches this node
+#pragma unroll
+            for (int n = 0; n < NMAX; ++n) attack_set[n] = patch_set[n] = 0u;
+            float rew[AMAX];
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a) {
+                rew[a] = 0.0f;
+                if (a < A) {
+                    const int2 v = reinterpret_cast<const int2*>(actions)[a * B + bl];
+                    const int idx = v.x, act = v.y;
+                    const bool bad_target = act == 0 && (idx < 0 || idx >= N);  // reference raises ValueError (:341-346, :358-363)
+                    if (bad_target && active) err |= FRZ_ERR_INVALID_TARGET;
+                    if (!bad_target && !(flags & kShowBad) && !pres[a] && act != -1 && active) err |= FRZ_ERR_ABSENT_ACTION;
+                    if (a < Att) {
+                        const bool attack = act == 0 && !bad_target;  // no presence check (:348-350)
+#pragma unroll
+                        for (int n = 0; n < NMAX; ++n) attack_set[n] |= (attack && idx == n) ? (1u << a) : 0u;
+                    }
+                }
+            }
+            // defenders: lane-local index k = a - Att (separate static loop keeps every array index a compile-time constant)
+#pragma unroll
+            for (int k = 0; k < AMAX; ++k) {
+                if (k < D) {
+                    const int2 v = reinterpret_cast<const int2*>(actions)[(Att + k) * B + bl];
+                    const int idx = v.x, act = v.y;
+                    const bool bad_target = act == 0 && (idx < 0 || idx >= N);
+                    const bool move = act == 0 && !bad_target;
+                    const bool patch = act == -2 && loc[k] != -1 && !bad_target;  // at the CURRENT (pre-move) location (:354)
+#pragma unroll
+                    for (int n = 0; n < NMAX; ++n) patch_set[n] |= (patch && loc[k] == n) ? (1u << k) : 0u;
+                    // patch reward lands in the defender's reward slot Att + k; bad_patch (:380-382) can never apply
+                    const float pr = patch ? d.patch_reward : 0.0f;
+#pragma unroll
+                    for (int a = 0; a < AMAX; ++a) rew[a] = (a == Att + k) ? rew[a] + pr : rew[a];
+                    loc[k] = move ? idx : loc[k];             // transitions/movement.py:30
+                    last[k] = bad_target ? last[k] : act;
+                }
+            }
+            // ------------------------------------------------- presence (transitions/presence.py:46-58), same draw for both tests
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a) {
+                if (a < A) {
+                    const bool ret = !pres[a] && r_agent[a] < d.back[a];
+                    const bool leave = pres[a] && r_agent[a] >= d.persist[a];
+                    pres[a] = ret ? true : (leave ? false : pres[a]);
+#pragma unroll
+                    for (int k = 0; k < AMAX; ++k) loc[k] = (ret && a == Att + k) ? -1 : loc[k];  // returning defenders start at home
+                }
+            }
+            // ------------------------------------------------- subnetwork transition (transitions/subnetwork.py:53-70)
+            float net_reward = 0.0f;
+#pragma unroll
+            for (int n = 0; n < NMAX; ++n) {
+                if (n < N) {
+                    const uint32_t index = (patch_set[n] << Att) | attack_set[n];
+                    const float danger = lut_in_lds ? s_lut[index] : lut[index];
+                    bool better = danger > 0.0f, worse = danger < 0.0f;
+                    if (flags & kStochState) {  // larger |danger| => LESS likely to move, as written (:57-59)
+                        const bool gate = fabsf(danger) <= r_net[n];
+                        better = better && gate;
+                        worse = worse && gate;
+                    }
+                    int s = state[n] - (better ? 1 : 0) + (worse ? 1 : 0);
+                    s = s < 0 ? 0 : (s > d.S - 1 ? d.S - 1 : s);
+                    state[n] = s;
+                    // :396-399 criticality-weighted state rewards, sequential float32 dot product
+                    net_reward = __fadd_rn(net_reward, __fmul_rn(s_state_rewards[s], (float)d.criticality[n]));
+                }
+            }
+            nm += 1;
+            trunc = (flags & kTruncate) ? nm >= d.max_steps : trunc;
+
+            if (active) {
+#pragma unroll
+                for (int n = 0; n < NMAX; ++n)
+                    if (n < N) at32(rows, (uint32_t)(d.r_state + n) * Bu + bl) = state[n];
+#pragma unroll
+                for (int k = 0; k < AMAX; ++k)
+                    if (k < D) {
+                        at32(rows, (uint32_t)(d.r_loc + k) * Bu + bl) = loc[k];
+                        at32(rows, (uint32_t)(d.r_last + k) * Bu + bl) = last[k];
+                    }
+#pragma unroll
+                for (int a = 0; a < AMAX; ++a)
+                    if (a < A) {
+                        const float r = a < Att ? __fadd_rn(rew[a], __fmul_rn(net_reward, -1.0f)) : __fadd_rn(rew[a], net_reward);
+                        at32(rows1, (uint32_t)(d.u_presence + a) * Bu + bl) = (uint8_t)pres[a];
+                        at32(rowsf, (uint32_t)(d.r_rewards + a) * Bu + bl) = r;
+                        if (flags & kTruncate) at32(rows1, (uint32_t)(d.u_trunc + a) * Bu + bl) = (uint8_t)trunc;
+                        if (flags & kTrackCumulative) {
+                            float& cum = at32(rowsf, (uint32_t)(d.r_cum + a) * Bu + bl);
+                            cum = __fadd_rn(cum, r);
+                        }
+                    }
+                at32(rows, (uint32_t)d.r_moves * Bu + bl) = nm;
+            }
+        }
+
+        // ======================================================================================================
+        // update_observations + update_actions (cybersecurity.py:413-526)
+        // ======================================================================================================
+        uint32_t cnt[AMAX], excl[AMAX];
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a) cnt[a] = (active && a < A && pres[a]) ? 1u : 0u;
+        frz::scan_chunk<AMAX>(s_scan, ws, launch, cnt, active, active && !trunc, A, chunk, d.nchunks, excl, &err);
+
+        if (active) {
+            float* const self_att = reinterpret_cast<float*>(arena + d.off_self_att);
+            float* const self_def = reinterpret_cast<float*>(arena + d.off_self_def);
+            float* const others_att = reinterpret_cast<float*>(arena + d.off_others_att);
+            float* const others_def = reinterpret_cast<float*>(arena + d.off_others_def);
+            int64_t* const tasks = reinterpret_cast<int64_t*>(arena + d.off_tasks);
+            int32_t* const act_values = reinterpret_cast<int32_t*>(arena + d.off_act_values);
+            int64_t* const act_offsets = reinterpret_cast<int64_t*>(arena + d.off_act_offsets);
+            const bool op = (flags & kObsPower) != 0, opr = (flags & kObsPresence) != 0, ol = (flags & kObsLocation) != 0;
+            const int ka = (op ? 1 : 0) + (opr ? 1 : 0), kd = ka + (ol ? 1 : 0);
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a) {
+                if (a < Att) {  // attackers: (threat, presence) (:481-484)
+                    reinterpret_cast<float2*>(self_att)[a * B + b] = make_float2(d.threat[a], pres[a] ? 1.0f : 0.0f);
+                    float* others = others_att + (a * B + b) * (int64_t)((Att - 1) * ka);
+                    int col = 0;
+#pragma unroll
+                    for (int o = 0; o < AMAX; ++o)
+                        if (o < Att && o != a) {
+                            if (op) others[col++] = d.threat[o];
+                            if (opr) others[col++] = pres[o] ? 1.0f : 0.0f;
+                        }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < AMAX; ++k) {
+                if (k < D) {  // defenders: (mitigation, presence, location) (:475-479)
+                    bool present_k = false;
+#pragma unroll
+                    for (int a = 0; a < AMAX; ++a) present_k = (a == Att + k) ? pres[a] : present_k;
+                    float* self = self_def + (k * B + b) * 3;
+                    self[0] = d.mitigation[k];
+                    self[1] = present_k ? 1.0f : 0.0f;
+                    self[2] = (float)loc[k];
+                    float* others = others_def + (k * B + b) * (int64_t)((D - 1) * kd);
+                    int col = 0;
+#pragma unroll
+                    for (int o = 0; o < AMAX; ++o)
+                        if (o < D && o != k) {
+                            bool present_o = false;
+#pragma unroll
+                            for (int a = 0; a < AMAX; ++a) present_o = (a == Att + o) ? pres[a] : present_o;
+                            if (op) others[col++] = d.mitigation[o];
+                            if (opr) others[col++] = present_o ? 1.0f : 0.0f;
+                            if (ol) others[col++] = (float)loc[o];
+                        }
+                }
+            }
+            // tasks (state, criticality) per agent; a defender sees them only right after monitoring (:497, :510-511)
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a) {
+                if (a < A) {
+                    bool hidden = false;
+                    if (flags & kPartial) {
+#pragma unroll
+                        for (int k = 0; k < AMAX; ++k) hidden = (a == Att + k && k < D) ? last[k] != -3 : hidden;
+                    }
+                    int64_t* t = tasks + (a * B + b) * (int64_t)(N * 2);
+#pragma unroll
+                    for (int n = 0; n < NMAX; ++n)
+                        if (n < N)
+                            reinterpret_cast<longlong2*>(t)[n] =
+                                hidden ? make_longlong2(-100, -100) : make_longlong2(state[n], d.criticality[n]);
+                    // action mapping: arange(N) while present, empty otherwise (:441-457)
+                    const int64_t off = (int64_t)excl[a] * N;
+                    act_offsets[a * (B + 1) + b] = off;
+                    if (b == B - 1) act_offsets[a * (B + 1) + B] = off + (pres[a] ? N : 0);
+                    if (pres[a]) {
+                        int32_t* v = act_values + a * B * N + off;
+#pragma unroll
+                        for (int n = 0; n < NMAX; ++n)
+                            if (n < N) v[n] = n;
+                    }
+                    at32(rows, (uint32_t)(d.r_atc + a) * Bu + bl) = pres[a] ? N : 0;
+                }
+            }
+            if (MODE == kRebuild) {  // constants of the env: written by reset()/rebuild() only
+                int32_t* const obs_map = reinterpret_cast<int32_t*>(arena + d.off_obs_map);
+                int64_t* const obs_map_offsets = reinterpret_cast<int64_t*>(arena + d.off_obs_map_offsets);
+                for (int n = 0; n < N; ++n) obs_map[b * N + n] = n;
+                obs_map_offsets[b] = b;
+                if (b == B - 1) obs_map_offsets[B] = B;
+                at32(rows, (uint32_t)d.r_etc * Bu + bl) = N;
+            }
+        }
+        if (err) atomicOr(reinterpret_cast<uint32_t*>(arena + d.off_error), err);
+        frz::scan_end(ws, launch, chunk, d.nchunks);
+    }
+}
+
+// uniform member of each agent's OneOf action space (spaces/actions.py:11-99), see oracle/frz_oracle_cybersecurity.c
+__global__ void __launch_bounds__(kBlock) cy_policy_kernel(const char* arena, uint32_t seed_lo, uint32_t seed_hi, uint32_t step_lo,
+                                                             uint32_t step_hi, int32_t* actions) {
+    const CyDev& d = *reinterpret_cast<const CyDev*>(arena);
+    const int64_t B = d.B;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (int64_t)d.A * B) return;
+    const int a = (int)(i / B);
+    const int64_t b = i % B;
+    const int32_t* rows = reinterpret_cast<const int32_t*>(arena + d.off_rows4);
+    const int n = (d.flags & kShowBad) ? d.N : rows[d.r_atc * B + i];
+    int tail[3], nt = 0;
+    tail[nt++] = -1;
+    if (a >= d.Att && n > 0) {
+        const bool home = rows[(d.r_loc + (a - d.Att)) * B + b] == -1;
+        if ((d.flags & kShowBad) || !home) tail[nt++] = -2;
+        tail[nt++] = -3;
+    }
+    const uint32_t env_seed = (uint32_t)rows[d.r_seeds * B + b];
+    const frz::Philox4 w = frz::philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), step_lo, step_hi, seed_lo ^ env_seed, seed_hi);
+    const int j = (int)(((uint64_t)w.w[0] * (uint64_t)(n + nt)) >> 32);
+    const int value = j < n ? 0 : (j - n == 0 ? tail[0] : (j - n == 1 ? tail[1] : tail[2]));
+    reinterpret_cast<int2*>(actions)[i] = make_int2(j, value);
+}
+
+}  // namespace
+
+// ================================================================================================================
+// host side of the C-ABI
+// ================================================================================================================
+struct frz_cybersecurity_env {
+    frz_cybersecurity_cfg cfg;
+    CyDev dev;
+    std::vector<float> lut;
+    char* arena = nullptr;
+    bool was_reset = false;
+    int grid = 0;
+    int variant = 0;
+};
+
+namespace {
+
+int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+template <int NMAX, int AMAX>
+void launch_variant(frz_cybersecurity_env* env, const int32_t* actions, const float* nr, const float* ar, int rng, int mode,
+                    hipStream_t stream) {
+    const CyDev* dev = reinterpret_cast<const CyDev*>(env->arena);
+    const dim3 grid(env->grid), block(kBlock);
+    if (mode == kRebuild)
+        hipLaunchKernelGGL((cy_step_kernel<NMAX, AMAX, FRZ_RNG_INJECTED, kRebuild>), grid, block, 0, stream, env->arena, dev, actions, nr, ar);
+    else if (rng == FRZ_RNG_PHILOX)
+        hipLaunchKernelGGL((cy_step_kernel<NMAX, AMAX, FRZ_RNG_PHILOX, kStep>), grid, block, 0, stream, env->arena, dev, actions, nr, ar);
+    else
+        hipLaunchKernelGGL((cy_step_kernel<NMAX, AMAX, FRZ_RNG_INJECTED, kStep>), grid, block, 0, stream, env->arena, dev, actions, nr, ar);
+}
+
+int launch(frz_cybersecurity_env* env, const int32_t* actions, const float* nr, const float* ar, int rng, int mode, hipStream_t stream) {
+    switch (env->variant) {
+        case 0: launch_variant<4, 4>(env, actions, nr, ar, rng, mode, stream); break;
+        case 1: launch_variant<8, 8>(env, actions, nr, ar, rng, mode, stream); break;
+        default: launch_variant<16, 16>(env, actions, nr, ar, rng, mode, stream); break;
+    }
+    return hipGetLastError() == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;
+}
+
+template <typename T>
+T* at(char* arena, int64_t off) {
+    return reinterpret_cast<T*>(arena + off);
+}
+
+}  // namespace
+
+extern "C" {
+
+int frz_cybersecurity_create(const frz_cybersecurity_cfg* cfg, frz_cybersecurity_env** out) {
+    if (!cfg || !out) return FRZ_E_INVALID;
+    const int N = cfg->num_nodes, Att = cfg->num_attackers, D = cfg->num_defenders, A = Att + D;
+    if (cfg->parallel_envs <= 0 || N <= 0 || N > FRZ_MAX_NODES || Att < 0 || D < 0 || A <= 0 || A > FRZ_MAX_AGENTS) return FRZ_E_INVALID;
+    if (cfg->num_states <= 0 || cfg->num_states > FRZ_MAX_NETWORK_STATES) return FRZ_E_INVALID;
+    if ((int64_t)(N + 2 * D + 4 * A + 8) * cfg->parallel_envs >= (int64_t)1 << 30) return FRZ_E_INVALID;
+    frz_cybersecurity_env* env = new (std::nothrow) frz_cybersecurity_env();
+    if (!env) return FRZ_E_INVALID;
+    env->cfg = *cfg;
+    env->variant = (N <= 4 && A <= 4) ? 0 : ((N <= 8 && A <= 8) ? 1 : 2);
+    CyDev& p = env->dev;
+    std::memset(&p, 0, sizeof(p));
+    const int64_t B = cfg->parallel_envs;
+    p.B = cfg->parallel_envs, p.N = N, p.Att = Att, p.D = D, p.A = A, p.S = cfg->num_states;
+    p.nchunks = (cfg->parallel_envs + kBlock - 1) / kBlock;
+    p.max_steps = cfg->max_steps;
+    p.lut_entries = 1 << A;
+    auto flag = [&](int on, uint32_t bit) { p.flags |= on ? bit : 0u; };
+    flag(cfg->stochastic_state, kStochState);
+    flag(cfg->show_bad_actions, kShowBad);
+    flag(cfg->partially_observable, kPartial);
+    flag(cfg->observe_other_power, kObsPower);
+    flag(cfg->observe_other_presence, kObsPresence);
+    flag(cfg->observe_other_location, kObsLocation);
+    flag(cfg->track_cumulative_rewards, kTrackCumulative);
+    flag(cfg->max_steps >= 0, kTruncate);
+    p.patch_reward = cfg->patch_reward;
+    std::memcpy(p.threat, cfg->threat, sizeof(p.threat));
+    std::memcpy(p.mitigation, cfg->mitigation, sizeof(p.mitigation));
+    std::memcpy(p.persist, cfg->persist_probs, sizeof(p.persist));
+    std::memcpy(p.back, cfg->return_probs, sizeof(p.back));
+    std::memcpy(p.initial_presence, cfg->initial_presence, sizeof(p.initial_presence));
+    std::memcpy(p.initial_location, cfg->initial_location, sizeof(p.initial_location));
+    std::memcpy(p.initial_state, cfg->initial_state, sizeof(p.initial_state));
+    std::memcpy(p.criticality, cfg->criticality, sizeof(p.criticality));
+    std::memcpy(p.state_rewards, cfg->network_state_rewards, sizeof(p.state_rewards));
+
+    // danger table: tanh((patches - attacks) / T) for every (defender subset, attacker subset); the sums are the float32
+    // accumulations the reference performs in agent order (cybersecurity.py:350, :377), tanhf is the libm the oracle uses
+    env->lut.resize((size_t)1 << A);
+    for (uint32_t pm = 0; pm < (1u << D); ++pm) {
+        float patches = 0.0f;
+        for (int k = 0; k < D; ++k)
+            if (pm & (1u << k)) patches = patches + cfg->mitigation[k];
+        for (uint32_t am = 0; am < (1u << Att); ++am) {
+            float attacks = 0.0f;
+            for (int a = 0; a < Att; ++a)
+                if (am & (1u << a)) attacks = attacks + cfg->threat[a];
+            const float diff = patches - attacks;
+            env->lut[((size_t)pm << Att) | am] = std::tanh(diff / cfg->temperature);
+        }
+    }
+
+    int r = 0;
+    p.r_state = r, r += N;
+    p.r_loc = r, r += D;
+    p.r_last = r, r += D;
+    p.r_moves = r++;
+    p.r_rewards = r, r += A;
+    p.r_cum = r, r += A;
+    p.r_atc = r, r += A;
+    p.r_etc = r++;
+    p.r_seeds = r++;
+    p.r_mti = r++;
+    p.n_rows4 = r;
+    p.u_presence = 0, p.u_term = A, p.u_trunc = 2 * A, p.u_frozen = 3 * A, p.n_rows1 = 3 * A + 1;
+    const int ka = (cfg->observe_other_power ? 1 : 0) + (cfg->observe_other_presence ? 1 : 0);
+    const int kd = ka + (cfg->observe_other_location ? 1 : 0);
+    const int nch_total = A + 2;
+    int64_t off = kDevBlockBytes;
+    auto take = [&](int64_t bytes) {
+        const int64_t here = off;
+        off = align_up(off + (bytes > 0 ? bytes : 1), 256);
+        return here;
+    };
+    p.off_rows4 = take((int64_t)p.n_rows4 * B * 4);
+    p.off_rows1 = take((int64_t)p.n_rows1 * B);
+    p.off_self_att = take((int64_t)Att * B * 8);
+    p.off_self_def = take((int64_t)D * B * 12);
+    p.off_others_att = take((int64_t)Att * B * (Att > 0 ? Att - 1 : 0) * ka * 4);
+    p.off_others_def = take((int64_t)D * B * (D > 0 ? D - 1 : 0) * kd * 4);
+    p.off_tasks = take((int64_t)A * B * N * 16);
+    p.off_act_values = take((int64_t)A * B * N * 4);
+    p.off_act_offsets = take((int64_t)A * (B + 1) * 8);
+    p.off_obs_map = take(B * N * 4);
+    p.off_obs_map_offsets = take((B + 1) * 8);
+    p.off_lut = take((int64_t)p.lut_entries * 4);
+    p.off_actions = take((int64_t)A * B * 8);
+    p.off_error = take(256);
+    p.off_epoch = take(256);
+    p.off_totals = take(2 * frz::kTotalsStride * 4);
+    p.off_agg = take((int64_t)p.nchunks * nch_total * 8);
+    p.off_prefix = take((int64_t)p.nchunks * nch_total * 8);
+    p.off_rand_net = take(B * N * 4);
+    p.off_rand_agent = take(B * A * 4);
+    p.off_mt_state = take(624 * B * 4);
+    p.total_bytes = off;
+
+    int device = 0, cus = 256;
+    if (hipGetDevice(&device) == hipSuccess) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    }
+    const int per_cu = p.nchunks >= 4 * cus ? 2 : 1;  // co-resident persistent grid (see wildfire.hip)
+    const int64_t capacity = (int64_t)cus * per_cu;
+    const int64_t rounds = (p.nchunks + capacity - 1) / capacity;
+    env->grid = (int)((p.nchunks + rounds - 1) / rounds);
+    *out = env;
+    return FRZ_OK;
+}
+
+void frz_cybersecurity_destroy(frz_cybersecurity_env* env) { delete env; }
+
+int64_t frz_cybersecurity_arena_bytes(const frz_cybersecurity_env* env) { return env ? env->dev.total_bytes : FRZ_E_INVALID; }
+
+int frz_cybersecurity_bind(frz_cybersecurity_env* env, void* arena, void* stream) {
+    if (!env || !arena || reinterpret_cast<uintptr_t>(arena) % 256 != 0) return FRZ_E_INVALID;
+    env->arena = static_cast<char*>(arena);
+    env->was_reset = false;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemcpyAsync(arena, &env->dev, sizeof(CyDev), hipMemcpyHostToDevice, s) != hipSuccess) return FRZ_E_LAUNCH;
+    if (hipMemcpyAsync(env->arena + env->dev.off_lut, env->lut.data(), env->lut.size() * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess)
+        return FRZ_E_LAUNCH;
+    return hipStreamSynchronize(s) == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;
+}
+
+int frz_cybersecurity_get_bufs(const frz_cybersecurity_env* env, frz_cybersecurity_bufs* out) {
+    if (!env || !out) return FRZ_E_INVALID;
+    if (!env->arena) return FRZ_E_UNBOUND;
+    const CyDev& p = env->dev;
+    char* a = env->arena;
+    const int64_t B = p.B;
+    auto row4 = [&](int r) { return a + p.off_rows4 + (int64_t)r * B * 4; };
+    auto row1 = [&](int r) { return a + p.off_rows1 + (int64_t)r * B; };
+    out->network_state = reinterpret_cast<int32_t*>(row4(p.r_state));
+    out->location = reinterpret_cast<int32_t*>(row4(p.r_loc));
+    out->last_action = reinterpret_cast<int32_t*>(row4(p.r_last));
+    out->num_moves = reinterpret_cast<int32_t*>(row4(p.r_moves));
+    out->rewards = reinterpret_cast<float*>(row4(p.r_rewards));
+    out->cumulative_rewards = reinterpret_cast<float*>(row4(p.r_cum));
+    out->agent_task_count = reinterpret_cast<int32_t*>(row4(p.r_atc));
+    out->env_task_count = reinterpret_cast<int32_t*>(row4(p.r_etc));
+    out->seeds = reinterpret_cast<int32_t*>(row4(p.r_seeds));
+    out->mt_index = reinterpret_cast<int32_t*>(row4(p.r_mti));
+    out->presence = reinterpret_cast<uint8_t*>(row1(p.u_presence));
+    out->terminations = reinterpret_cast<uint8_t*>(row1(p.u_term));
+    out->truncations = reinterpret_cast<uint8_t*>(row1(p.u_trunc));
+    out->frozen_scaled = reinterpret_cast<uint8_t*>(row1(p.u_frozen));
+    out->obs_self_attackers = at<float>(a, p.off_self_att);
+    out->obs_self_defenders = at<float>(a, p.off_self_def);
+    out->obs_others_attackers = at<float>(a, p.off_others_att);
+    out->obs_others_defenders = at<float>(a, p.off_others_def);
+    out->obs_tasks = at<int64_t>(a, p.off_tasks);
+    out->act_map_values = at<int32_t>(a, p.off_act_values);
+    out->act_map_offsets = at<int64_t>(a, p.off_act_offsets);
+    out->obs_map_values = at<int32_t>(a, p.off_obs_map);
+    out->obs_map_offsets = at<int64_t>(a, p.off_obs_map_offsets);
+    out->mt_state = at<uint32_t>(a, p.off_mt_state);
+    out->actions = at<int32_t>(a, p.off_actions);
+    out->error_flags = at<uint32_t>(a, p.off_error);
+    return FRZ_OK;
+}
+
+int frz_cybersecurity_rebuild(frz_cybersecurity_env* env, void* stream) {
+    if (!env) return FRZ_E_INVALID;
+    if (!env->arena) return FRZ_E_UNBOUND;
+    env->was_reset = true;
+    return launch(env, nullptr, nullptr, nullptr, FRZ_RNG_INJECTED, kRebuild, static_cast<hipStream_t>(stream));
+}
+
+int frz_cybersecurity_reset(frz_cybersecurity_env* env, void* stream) {
+    if (!env) return FRZ_E_INVALID;
+    if (!env->arena) return FRZ_E_UNBOUND;
+    const int blocks = (env->cfg.parallel_envs + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(cy_fill_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), env->arena);
+    if (hipGetLastError() != hipSuccess) return FRZ_E_LAUNCH;
+    return frz_cybersecurity_rebuild(env, stream);
+}
+
+int frz_mt19937_generate(uint32_t* mt_state, int32_t* mt_index, float* out, int64_t events, int64_t count, int64_t B, void* stream);
+
+int frz_cybersecurity_step(frz_cybersecurity_env* env, const int32_t* actions, int rng_mode, const float* network_randomness,
+                           const float* agent_randomness, void* stream) {
+    if (!env || !actions) return FRZ_E_INVALID;
+    if (!env->arena) return FRZ_E_UNBOUND;
+    if (!env->was_reset) return FRZ_E_INVALID;
+    const CyDev& p = env->dev;
+    if (rng_mode == FRZ_RNG_INJECTED) {
+        if (!network_randomness || !agent_randomness) return FRZ_E_INVALID;
+    } else if (rng_mode == FRZ_RNG_MT19937) {  // network draws first, then agent draws (cybersecurity.py:304-315)
+        const int64_t B = p.B;
+        uint32_t* mt_state = at<uint32_t>(env->arena, p.off_mt_state);
+        int32_t* mt_index = at<int32_t>(env->arena, p.off_rows4 + (int64_t)p.r_mti * B * 4);
+        float* rn = at<float>(env->arena, p.off_rand_net);
+        float* ra = at<float>(env->arena, p.off_rand_agent);
+        int rc = frz_mt19937_generate(mt_state, mt_index, rn, 1, p.N, B, stream);
+        if (rc != FRZ_OK) return rc;
+        rc = frz_mt19937_generate(mt_state, mt_index, ra, 1, p.A, B, stream);
+        if (rc != FRZ_OK) return rc;
+        network_randomness = rn;
+        agent_randomness = ra;
+        rng_mode = FRZ_RNG_INJECTED;
+    } else if (rng_mode != FRZ_RNG_PHILOX) {
+        return FRZ_E_INVALID;
+    }
+    return launch(env, actions, network_randomness, agent_randomness, rng_mode, kStep, static_cast<hipStream_t>(stream));
+}
+
+int frz_cybersecurity_random_policy(frz_cybersecurity_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out,
+                                    void* stream) {
+    if (!env || !actions_out) return FRZ_E_INVALID;
+    if (!env->arena) return FRZ_E_UNBOUND;
+    const int64_t n = (int64_t)env->dev.A * env->dev.B;
+    hipLaunchKernelGGL(cy_policy_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       env->arena, (uint32_t)policy_seed, (uint32_t)(policy_seed >> 32), (uint32_t)policy_step,
+                       (uint32_t)(policy_step >> 32), actions_out);
+    return hipGetLastError() == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;
+}
+
+}  // extern "C"

@@ -1,0 +1,299 @@
+"""Cybersecurity environment: Python boundary over the fused HIP step kernel.
+
+Mirrors free_range_zoo/envs/cybersecurity/env/cybersecurity.py (``parallel_env`` :112-128, ``raw_env`` :149-584): same
+constructor keywords and defaults, agent names (``attacker_i`` / ``defender_i``), observation / mapping attributes,
+dtypes and shapes.  The arithmetic runs in ``csrc/cybersecurity.hip`` through ``frz_cybersecurity_*`` (include/frz.h).
+"""
+import ctypes
+from typing import Any, Callable, Dict, List, Optional, Tuple
+
+import torch
+
+from free_range_zoo_amd import _capi
+from free_range_zoo_amd.utils.env import BatchedParallelEnv, jagged, stream_ptr
+from free_range_zoo_amd.utils.spaces import BatchedOneOfSpace
+from free_range_zoo_amd.utils.tensordict import TensorDict
+from free_range_zoo_amd.envs.cybersecurity.env.structures.configuration import to_cstruct
+from free_range_zoo_amd.envs.cybersecurity.env.structures.state import CybersecurityState
+from free_range_zoo_amd.envs.cybersecurity.env.utils import masking
+
+
+def parallel_env(wrappers: List[Callable] = [], **kwargs) -> 'raw_env':
+    env = raw_env(**kwargs)
+    for wrapper in wrappers:
+        env = wrapper(env)
+    return env
+
+
+def env(wrappers: List[Callable] = [], **kwargs) -> 'raw_env':
+    return parallel_env(wrappers, **kwargs)
+
+
+class raw_env(BatchedParallelEnv):
+    """Environment definition for the cybersecurity environment."""
+
+    metadata = {'render.modes': ['human', 'rgb_array'], 'name': 'cybersecurity_v0', 'is_parallelizable': True, 'render_fps': 2,
+                'null_value': -100}
+
+    @torch.no_grad()
+    def __init__(self, *args, observe_other_location: bool = False, observe_other_presence: bool = False, observe_other_power: bool = True,
+                 partially_observable: bool = True, show_bad_actions: bool = True, **kwargs) -> None:
+        super().__init__(*args, **kwargs)
+        self.observe_other_power = observe_other_power
+        self.observe_other_location = observe_other_location
+        self.observe_other_presence = observe_other_presence
+        self.partially_obserable = partially_observable  # attribute name as spelled by the reference (cybersecurity.py:185)
+        self.show_bad_actions = show_bad_actions
+        Att, D = self.attacker_config.num_attackers, self.defender_config.num_defenders
+        attackers = tuple(f'attacker_{i}' for i in range(1, Att + 1))
+        defenders = tuple(f'defender_{i}' for i in range(1, D + 1))
+        self.attacker_name_mapping = dict(zip(attackers, torch.arange(0, Att, device=self.device)))
+        self.defender_name_mapping = dict(zip(defenders, torch.arange(0, D, device=self.device)))
+        self.possible_agents = attackers + defenders
+        self.agents = self.possible_agents
+        self.agent_name_mapping = {**self.attacker_name_mapping, **self.defender_name_mapping}
+        self.offset_agent_name_mapping = dict(zip(self.possible_agents, torch.arange(0, Att + D, device=self.device)))
+        self.agent_observation_mask = lambda agent_name: masking.mask_observation(
+            agent_name=agent_name, observe_other_power=observe_other_power, observe_other_presence=observe_other_presence,
+            observe_other_location=observe_other_location)
+        self._allocate()
+
+    def _view(self, ptr: int, shape, dtype) -> torch.Tensor:
+        offset = ptr - self._arena.data_ptr()
+        numel = 1
+        for s in shape:
+            numel *= int(s)
+        nbytes = numel * torch.empty((), dtype=dtype).element_size()
+        return self._arena[offset:offset + nbytes].view(dtype).view(*shape)
+
+    def _allocate(self) -> None:
+        B = self.parallel_envs
+        N, Att, D = self.network_config.num_nodes, self.attacker_config.num_attackers, self.defender_config.num_defenders
+        A = Att + D
+        self._N, self._Att, self._D = N, Att, D
+        self._ka = int(self.observe_other_power) + int(self.observe_other_presence)
+        self._kd = self._ka + int(self.observe_other_location)
+        self._cfg = to_cstruct(self.config, B, self.max_steps, observe_other_location=self.observe_other_location,
+                               observe_other_presence=self.observe_other_presence, observe_other_power=self.observe_other_power,
+                               partially_observable=self.partially_obserable, show_bad_actions=self.show_bad_actions)
+        self._bind_handle(allocate=True)
+        bufs = self._bufs
+        f32, i32, i64, u8 = torch.float32, torch.int32, torch.int64, torch.uint8
+        v = self._view
+        self._network_state, self._location = v(bufs.network_state, (N, B), i32), v(bufs.location, (D, B), i32)
+        self._presence = v(bufs.presence, (A, B), torch.bool)
+        self._last_action = v(bufs.last_action, (D, B), i32)
+        self.num_moves = v(bufs.num_moves, (B, ), i32)
+        self._rewards, self._cumulative = v(bufs.rewards, (A, B), f32), v(bufs.cumulative_rewards, (A, B), f32)
+        self._terminations, self._truncations = v(bufs.terminations, (A, B), torch.bool), v(bufs.truncations, (A, B), torch.bool)
+        self._self_att, self._self_def = v(bufs.obs_self_attackers, (Att, B, 2), f32), v(bufs.obs_self_defenders, (D, B, 3), f32)
+        self._others_att = v(bufs.obs_others_attackers, (Att, B, max(Att - 1, 0), self._ka), f32)
+        self._others_def = v(bufs.obs_others_defenders, (D, B, max(D - 1, 0), self._kd), f32)
+        self._tasks = v(bufs.obs_tasks, (A, B, N, 2), i64)
+        self._act_map_values, self._act_map_offsets = v(bufs.act_map_values, (A, B * N), i32), v(bufs.act_map_offsets, (A, B + 1), i64)
+        self._obs_map_values, self._obs_map_offsets = v(bufs.obs_map_values, (B, N), i32), v(bufs.obs_map_offsets, (B + 1, ), i64)
+        self.environment_task_count, self.agent_task_count = v(bufs.env_task_count, (B, ), i32), v(bufs.agent_task_count, (A, B), i32)
+        self._frozen_scaled = v(bufs.frozen_scaled, (B, ), u8)
+        self._error_flags = v(bufs.error_flags, (1, ), i32)
+        self._actions = v(bufs.actions, (A, B, 2), i32)
+        self.generator.attach(seeds=v(bufs.seeds, (B, ), i32), states=v(bufs.mt_state, (624, B), i32), index=v(bufs.mt_index, (B, ), i32))
+        self.seeds = self.generator.seeds
+        self._state = CybersecurityState(network_state=self._network_state.t(), location=self._location.t(), presence=self._presence.t())
+
+    def _bind_handle(self, allocate: bool) -> None:
+        handle = ctypes.c_void_p()
+        _capi.check(self._lib.frz_cybersecurity_create(ctypes.byref(self._cfg), ctypes.byref(handle)), 'frz_cybersecurity_create')
+        self._handle = handle
+        if allocate:
+            nbytes = self._lib.frz_cybersecurity_arena_bytes(self._handle)
+            self._arena = self._alloc((nbytes, ), torch.uint8)
+        _capi.check(self._lib.frz_cybersecurity_bind(self._handle, self._arena.data_ptr(), stream_ptr(self.device)), 'frz_cybersecurity_bind')
+        bufs = _capi.frz_cybersecurity_bufs()
+        _capi.check(self._lib.frz_cybersecurity_get_bufs(self._handle, ctypes.byref(bufs)), 'frz_cybersecurity_get_bufs')
+        self._bufs = bufs
+
+    def _set_max_steps(self, max_steps) -> None:
+        if max_steps != self.max_steps:
+            self.max_steps = max_steps
+            self._cfg.max_steps = -1 if max_steps is None else int(max_steps)
+            self._lib.frz_cybersecurity_destroy(self._handle)
+            self._bind_handle(allocate=False)
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                self._lib.frz_cybersecurity_destroy(self._handle)
+                self._handle = None
+        except Exception:  # noqa: BLE001
+            pass
+
+    # ---------------------------------------------------------------------------------------- output plumbing
+    def _publish(self) -> None:
+        B, A, N, Att = self.parallel_envs, len(self.agents), self._N, self._Att
+        if self.exact_shapes:
+            totals = self._act_map_offsets[:, -1].tolist()  # one small device->host read per step
+            act_maps = [jagged(self._act_map_values[a, :totals[a]], self._act_map_offsets[a], max_seqlen=N if totals[a] else 0)
+                        for a in range(A)]
+        elif getattr(self, '_static_views', None) is None:
+            act_maps = [jagged(self._act_map_values[a], self._act_map_offsets[a], max_seqlen=N, lengths=self.agent_task_count[a])
+                        for a in range(A)]
+            self._static_views = True
+        else:
+            return
+        obs_map = jagged(self._obs_map_values, self._obs_map_offsets, max_seqlen=1)  # [B, j=1, N] (cybersecurity.py:434-439)
+        self.task_store = self._tasks[0]
+        self.agent_action_mapping, self.agent_observation_mapping, self.agent_bad_actions, self.observations = {}, {}, {}, {}
+        for a, agent in enumerate(self.agents):
+            self.agent_action_mapping[agent] = act_maps[a]
+            self.agent_observation_mapping[agent] = obs_map
+            self.agent_bad_actions[agent] = None
+            if a < Att:
+                own, others = self._self_att[a], self._others_att[a]
+            else:
+                own, others = self._self_def[a - Att], self._others_def[a - Att]
+            self.observations[agent] = TensorDict({'self': own, 'others': others, 'tasks': self._tasks[a]}, batch_size=[B],
+                                                  device=self.device)
+
+    def _publish_dense(self) -> None:
+        self.rewards = {agent: self._rewards[a] for a, agent in enumerate(self.agents)}
+        self._cumulative_rewards = {agent: self._cumulative[a] for a, agent in enumerate(self.agents)}
+        self.terminations = {agent: self._terminations[a] for a, agent in enumerate(self.agents)}
+        self.truncations = {agent: self._truncations[a] for a, agent in enumerate(self.agents)}
+        self.actions = {agent: self._actions[a] for a, agent in enumerate(self.agents)}
+
+    # ------------------------------------------------------------------------------------------------- reset
+    @torch.no_grad()
+    def reset(self, seed=None, options: Optional[Dict[str, Any]] = None):
+        self._reset_options(options)
+        if options and options.get('skip_seeding'):
+            if not self.generator.has_been_seeded:
+                raise ValueError('Seed must be set before skipping seeding is possible')
+        else:
+            self.generator.seed(seed, partial_seeding=None)
+        self.agents = self.possible_agents
+        self._static_views = None
+        stream = stream_ptr(self.device)
+        _capi.check(self._lib.frz_cybersecurity_reset(self._handle, stream), 'frz_cybersecurity_reset')
+        self._actions.fill_(-2)  # cybersecurity.py:233-236
+        if options is not None and options.get('initial_state') is not None:
+            initial_state = options['initial_state']
+            if len(initial_state) != self.parallel_envs:
+                raise ValueError('Initial state must have the same number of environments as the parallel environments')
+            self._state.load_state(initial_state.to(self.device))
+            _capi.check(self._lib.frz_cybersecurity_rebuild(self._handle, stream), 'frz_cybersecurity_rebuild')
+        self._state.save_initial()
+        self.infos = {agent: {} for agent in self.agents}
+        self._has_reset = True
+        self._publish()
+        self._publish_dense()
+        return {agent: self.observations[agent] for agent in self.agents}, self.infos
+
+    @torch.no_grad()
+    def reset_batches(self, batch_indices: torch.Tensor, seed: Optional[List[int]] = None, options: Optional[Dict[str, Any]] = None) -> None:
+        """Partial reset (cybersecurity.py:268-292 + utils/env.py:162-189)."""
+        batch_indices = torch.as_tensor(batch_indices, device=self.device).long()
+        self.generator.seed(seed, partial_seeding=batch_indices)
+        self._rewards[:, batch_indices] = 0
+        self._cumulative[:, batch_indices] = 0
+        self._terminations[:, batch_indices] = False
+        self._truncations[:, batch_indices] = False
+        self.num_moves[batch_indices] = 0
+        self._frozen_scaled[batch_indices] = 0
+        self._last_action[:, batch_indices] = -2
+        self._actions[:, batch_indices] = -2
+        self._state.restore_initial(batch_indices)
+        _capi.check(self._lib.frz_cybersecurity_rebuild(self._handle, stream_ptr(self.device)), 'frz_cybersecurity_rebuild')
+        self._publish()
+
+    # -------------------------------------------------------------------------------------------------- step
+    @torch.no_grad()
+    def step(self, actions, randomness: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+        """
+        One simultaneous step.  ``actions``: ``{agent: IntTensor[B, 2]}`` (attackers ``(node, 0)`` attack / ``(_, -1)`` noop;
+        defenders ``(node, 0)`` move / ``-1`` noop / ``-2`` patch / ``-3`` monitor) or a stacked int32 ``[A, B, 2]`` tensor.
+        ``randomness``: optional ``(network [1,B,N], agent [1,B,A])`` float32 tensors replacing the env's generator.
+        Invalid targets / actions of absent agents raise ``ValueError`` lazily (``env.check()``), not per step.
+        """
+        if not self._has_reset:
+            raise RuntimeError('reset() must be called before step()')
+        if isinstance(actions, dict):
+            for a, agent in enumerate(self.agents):
+                self._actions[a].copy_(actions[agent])
+            actions_ptr = self._actions.data_ptr()
+        else:
+            if actions.dtype != torch.int32 or not actions.is_contiguous() or tuple(actions.shape) != tuple(self._actions.shape):
+                raise ValueError('stacked actions must be a contiguous int32 [A, B, 2] tensor')
+            self._action_keepalive = actions
+            actions_ptr = actions.data_ptr()
+        stream = stream_ptr(self.device)
+        B, N, A = self.parallel_envs, self._N, len(self.agents)
+        if randomness is not None or self.rng == 'mt19937':
+            if randomness is None:  # cybersecurity.py:304-315
+                network = self.generator.generate(B, 1, (N, ), key='network')
+                agent = self.generator.generate(B, 1, (A, ), key='agent')
+            else:
+                network, agent = randomness
+            network = network.to(device=self.device, dtype=torch.float32).contiguous()
+            agent = agent.to(device=self.device, dtype=torch.float32).contiguous()
+            if network.numel() != B * N or agent.numel() != B * A:
+                raise ValueError('randomness tensors have the wrong size')
+            self._randomness_keepalive = (network, agent)
+            rc = self._lib.frz_cybersecurity_step(self._handle, actions_ptr, _capi.FRZ_RNG_INJECTED, network.data_ptr(), agent.data_ptr(), stream)
+        else:
+            rc = self._lib.frz_cybersecurity_step(self._handle, actions_ptr, _capi.FRZ_RNG_PHILOX, None, None, stream)
+        _capi.check(rc, 'frz_cybersecurity_step')
+        self._publish()
+        self.infos = {agent: {} for agent in self.agents}
+        return ({agent: self.observations[agent] for agent in self.agents}, self.rewards, self.terminations, self.truncations, self.infos)
+
+    @torch.no_grad()
+    def random_policy_actions(self, policy_seed: int, policy_step: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        out = self._actions if out is None else out
+        _capi.check(self._lib.frz_cybersecurity_random_policy(self._handle, policy_seed, policy_step, out.data_ptr(), stream_ptr(self.device)),
+                    'frz_cybersecurity_random_policy')
+        return out
+
+    @torch.no_grad()
+    def capture_random_rollout(self, steps: int, policy_seed: int = 0, include_reset: bool = True) -> 'torch.cuda.CUDAGraph':
+        """``[reset] + steps x (device random policy -> fused step)`` as one HIP graph (see the wildfire env)."""
+        if not self._has_reset:
+            raise RuntimeError('reset() must be called once before capturing a rollout')
+        lib, handle, actions = self._lib, self._handle, self._actions.data_ptr()
+        mt = self.rng == 'mt19937'
+        if mt:
+            self.generator._ensure_streams()
+        mode = _capi.FRZ_RNG_MT19937 if mt else _capi.FRZ_RNG_PHILOX
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            stream = stream_ptr(self.device)
+            if include_reset:
+                if mt:
+                    _capi.check(lib.frz_mt19937_seed(self._bufs.mt_state, self._bufs.mt_index, self._bufs.seeds, None, 0, self.parallel_envs,
+                                                     stream), 'frz_mt19937_seed')
+                _capi.check(lib.frz_cybersecurity_reset(handle, stream), 'frz_cybersecurity_reset')
+            for t in range(steps):
+                _capi.check(lib.frz_cybersecurity_random_policy(handle, policy_seed, t, actions, stream), 'frz_cybersecurity_random_policy')
+                _capi.check(lib.frz_cybersecurity_step(handle, actions, mode, None, None, stream), 'frz_cybersecurity_step')
+        return graph
+
+    # ------------------------------------------------------------------------------------------------ spaces
+    @torch.no_grad()
+    def action_space(self, agent: str) -> BatchedOneOfSpace:
+        """Per-env OneOf (cybersecurity.py:528-551, spaces/actions.py:11-99)."""
+        index = self.possible_agents.index(agent)
+        counts = self.environment_task_count if self.show_bad_actions else self.agent_task_count[index]
+        if index < self._Att:
+            return BatchedOneOfSpace(counts, tail=[-1])
+        has_tasks = counts > 0
+        can_patch = has_tasks & (torch.full_like(has_tasks, self.show_bad_actions) | (self._location[index - self._Att] != -1))
+        tail_mask = torch.stack([torch.ones_like(has_tasks), can_patch, has_tasks], dim=1)
+        return BatchedOneOfSpace(counts, tail=[-1, -2, -3], tail_mask=tail_mask)
+
+    def observation_space(self, agent: str):
+        kind = agent.split('_')[0]
+        high = self.config.attacker_observation_bounds if kind == 'attacker' else self.config.defender_observation_bounds
+        mask = self.agent_observation_mask(agent).tolist()
+        return {'self_high': tuple(high), 'others_high': tuple(h for h, keep in zip(high, mask) if keep),
+                'tasks_high': tuple(self.config.network_observation_bounds), 'num_tasks': self._N,
+                'num_others': (self._Att if kind == 'attacker' else self._D) - 1}

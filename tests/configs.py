@@ -94,3 +94,61 @@ WILDFIRE_GOLDEN = {
     'rich_plain_bad_actions': (wildfire_rich_plain, dict(show_bad_actions=True)),
     'rich_no_truncation': (wildfire_rich, {}),
 }
+
+
+# ------------------------------------------------------------------------------------------------ cybersecurity
+from free_range_zoo_amd.envs.cybersecurity.env.structures import configuration as C  # noqa: E402
+
+
+def cyber_non_stochastic() -> C.CybersecurityConfiguration:
+    """Values of the reference's tests/utils/cybersecurity_configs.py:non_stochastic()."""
+    ones, yes = torch.tensor([1.0, 1.0]), torch.tensor([True, True])
+    att = C.AttackerConfiguration(initial_presence=yes.clone(), threat=ones.clone(), persist_probs=ones.clone(), return_probs=ones.clone())
+    dfn = C.DefenderConfiguration(initial_location=torch.tensor([0, 1], dtype=torch.int32), initial_presence=yes.clone(),
+                                  mitigation=ones.clone(), persist_probs=ones.clone(), return_probs=ones.clone())
+    net = C.NetworkConfiguration(patched_states=1, vulnerable_states=1, exploited_states=3, temperature=1.0,
+                                 initial_state=torch.tensor([0, 0, 0], dtype=torch.int32),
+                                 adj_matrix=torch.tensor([[0, 1, 1], [1, 0, 1], [1, 1, 0]], dtype=torch.bool))
+    rew = C.RewardConfiguration(bad_action_penalty=-100.0, patch_reward=0.0,
+                                network_state_rewards=torch.tensor([4.0, 0.0, -2.0, -4.0, -8.0]))
+    return C.CybersecurityConfiguration(attacker_config=att, defender_config=dfn, network_config=net, reward_config=rew,
+                                        stochastic_config=C.StochasticConfiguration(network_state=False))
+
+
+def cyber_openness(network_state: bool = True) -> C.CybersecurityConfiguration:
+    """BASELINE.json config 4: non_stochastic() + agent openness (persist 0.9 / return 0.5) + stochastic states."""
+    base = cyber_non_stochastic()
+    att = replace(base.attacker_config, persist_probs=torch.tensor([0.9, 0.9]), return_probs=torch.tensor([0.5, 0.5]))
+    dfn = replace(base.defender_config, persist_probs=torch.tensor([0.9, 0.9]), return_probs=torch.tensor([0.5, 0.5]))
+    return C.CybersecurityConfiguration(attacker_config=att, defender_config=dfn, network_config=base.network_config,
+                                        reward_config=base.reward_config, stochastic_config=C.StochasticConfiguration(network_state=network_state))
+
+
+def cyber_rich() -> C.CybersecurityConfiguration:
+    g = torch.Generator().manual_seed(5)
+    N = 6
+    adj = torch.rand((N, N), generator=g) < 0.5
+    adj = (adj | adj.T) & ~torch.eye(N, dtype=torch.bool)
+    att = C.AttackerConfiguration(initial_presence=torch.tensor([True, False, True]), threat=torch.tensor([1.0, 0.5, 1.75]),
+                                  persist_probs=torch.tensor([0.8, 0.95, 0.7]), return_probs=torch.tensor([0.3, 0.6, 0.45]))
+    dfn = C.DefenderConfiguration(initial_location=torch.tensor([0, -1, 3, 5], dtype=torch.int32),
+                                  initial_presence=torch.tensor([True, True, False, True]), mitigation=torch.tensor([1.0, 0.75, 1.25, 0.6]),
+                                  persist_probs=torch.tensor([0.85, 0.9, 0.75, 0.95]), return_probs=torch.tensor([0.4, 0.5, 0.6, 0.35]))
+    net = C.NetworkConfiguration(patched_states=2, vulnerable_states=2, exploited_states=3, temperature=1.7,
+                                 initial_state=torch.randint(0, 7, (N, ), generator=g, dtype=torch.int32), adj_matrix=adj)
+    rew = C.RewardConfiguration(bad_action_penalty=-7.5, patch_reward=-0.25,
+                                network_state_rewards=torch.tensor([4.0, 2.5, 0.0, -1.0, -2.0, -4.5, -8.0]))
+    return C.CybersecurityConfiguration(attacker_config=att, defender_config=dfn, network_config=net, reward_config=rew,
+                                        stochastic_config=C.StochasticConfiguration(network_state=True))
+
+
+CYBER_DEFAULT_FLAGS = dict(observe_other_location=False, observe_other_presence=False, observe_other_power=True, partially_observable=True,
+                           show_bad_actions=True)
+CYBER_GOLDEN = {
+    'nonstochastic': (cyber_non_stochastic, {}),
+    'cfg4_openness': (cyber_openness, {}),
+    'openness_no_bad_actions': (cyber_openness, dict(show_bad_actions=False, observe_other_presence=True, observe_other_location=True)),
+    'rich': (cyber_rich, dict(partially_observable=True, observe_other_location=True)),
+    'rich_fully_observable': (cyber_rich, dict(partially_observable=False, observe_other_power=False, observe_other_presence=True,
+                                               show_bad_actions=False)),
+}

@@ -1,0 +1,177 @@
+"""GPU: the HIP cybersecurity step path against golden vectors of the reference and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+import configs
+import golden_util as G
+from free_range_zoo_amd import _capi
+from test_oracle_cybersecurity import compare_cyber, oracle_snapshot
+
+pytestmark = pytest.mark.gpu
+
+
+def make_env(build, B, max_steps, **kwargs):
+    from free_range_zoo_amd.envs import cybersecurity_v0
+    return cybersecurity_v0.parallel_env(configuration=build(), parallel_envs=B, max_steps=max_steps, device=torch.device('cuda'), **kwargs)
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def hip_snapshot(env):
+    st = env.state()
+    snap = {'network_state': np_(st.network_state), 'location': np_(st.location), 'presence': np_(st.presence),
+            'num_moves': np_(env.num_moves), 'env_task_count': np_(env.environment_task_count),
+            'agent_task_count': np_(env.agent_task_count)}
+    snap['rewards'] = np.stack([np_(env.rewards[a]) for a in env.agents])
+    snap['terminations'] = np.stack([np_(env.terminations[a]) for a in env.agents])
+    snap['truncations'] = np.stack([np_(env.truncations[a]) for a in env.agents])
+    for a, agent in enumerate(env.agents):
+        m = env.agent_action_mapping[agent]
+        snap[f'act_map_values_{a}'], snap[f'act_map_offsets_{a}'] = np_(m.values()), np_(m.offsets())
+        m = env.agent_observation_mapping[agent]
+        snap[f'obs_map_values_{a}'], snap[f'obs_map_offsets_{a}'] = np_(m.values()), np_(m.offsets())
+        obs = env.observe(agent)
+        snap[f'obs_self_{a}'], snap[f'obs_others_{a}'], snap[f'obs_tasks_{a}'] = np_(obs['self']), np_(obs['others']), np_(obs['tasks'])
+        snap[f'cumulative_rewards_{a}'] = np_(env._cumulative_rewards[agent])
+    return snap
+
+
+def compare_snapshots(got, want, what):
+    for key, w in want.items():
+        g = got[key]
+        if key in ('terminations', 'truncations', 'presence'):
+            g, w = np.asarray(g).astype(bool), np.asarray(w).astype(bool)
+        G.assert_same(g, w, f'{what} {key}')
+
+
+@pytest.mark.parametrize('name', sorted(configs.CYBER_GOLDEN))
+def test_golden_trajectory(name):
+    build, kwargs = configs.CYBER_GOLDEN[name]
+    data = np.load(G.golden_path(f'traj_cybersecurity_{name}.npz'))
+    cfg = G.load_cfg(data, _capi.frz_cybersecurity_cfg)
+    B, N, A = cfg.parallel_envs, cfg.num_nodes, cfg.num_attackers + cfg.num_defenders
+    env = make_env(build, B, None if cfg.max_steps < 0 else cfg.max_steps, **kwargs)
+    env.reset(seed=torch.arange(B, dtype=torch.int32))
+    compare_cyber(hip_snapshot(env), data, 'r_', A, f'{name} reset')
+    for t in range(int(data['steps'])):
+        p = f's{t}_'
+        if bool(data[p + 'stepped']):
+            rnd = (torch.from_numpy(data[p + 'network_randomness']), torch.from_numpy(data[p + 'agent_randomness']))
+        else:
+            rnd = (torch.zeros(1, B, N), torch.zeros(1, B, A))
+        actions = {agent: torch.from_numpy(data[p + 'actions'][a]).cuda() for a, agent in enumerate(env.agents)}
+        obs, rewards, terminations, truncations, infos = env.step(actions, randomness=rnd)
+        compare_cyber(hip_snapshot(env), data, p, A, f'{name} step {t}')
+        G.assert_same(np_(env.finished), data[p + 'finished'], f'{name} step {t} finished')
+    env.check()
+
+
+def run_against_oracle(oracle, build, kwargs, B, max_steps, steps, seed, rng='injected'):
+    from free_range_zoo_amd.envs.cybersecurity.env.structures.configuration import to_cstruct
+    flags = dict(configs.CYBER_DEFAULT_FLAGS)
+    flags.update(kwargs)
+    cfg = to_cstruct(build(), B, max_steps, **flags)
+    o = oracle.CybersecurityOracle(cfg)
+    o.reset()
+    env = make_env(build, B, max_steps, rng='philox' if rng == 'philox' else 'mt19937', **kwargs)
+    seeds = torch.arange(B, dtype=torch.int32) * 5 + seed
+    env.reset(seed=seeds)
+    compare_snapshots(hip_snapshot(env), oracle_snapshot(o), f'reset B={B}')
+    gen = np.random.default_rng(seed)
+    N, A = cfg.num_nodes, cfg.num_attackers + cfg.num_defenders
+    mt_state, mt_index = oracle.mt19937_seed(seeds.numpy())
+    for t in range(steps):
+        actions_dev = env.random_policy_actions(policy_seed=99 + seed, policy_step=t).clone()
+        actions = oracle.cybersecurity_random_policy(cfg, o.agent_task_count, o.location, seeds.numpy(), 99 + seed, t)
+        G.assert_same(np_(actions_dev), actions, f'policy step {t}')
+        if rng == 'injected':
+            nr, ar = gen.random((1, B, N), dtype=np.float32), gen.random((1, B, A), dtype=np.float32)
+            env.step(actions_dev, randomness=(torch.from_numpy(nr), torch.from_numpy(ar)))
+        elif rng == 'philox':
+            nr, ar = oracle.cybersecurity_philox_randomness(cfg, seeds.numpy(), o.num_moves)
+            env.step(actions_dev)
+        else:
+            nr = oracle.mt19937_generate(mt_state, mt_index, 1, N)
+            ar = oracle.mt19937_generate(mt_state, mt_index, 1, A)
+            env.step(actions_dev)
+        o.step(actions, nr, ar)
+        compare_snapshots(hip_snapshot(env), oracle_snapshot(o), f'B={B} rng={rng} step {t}')
+    env.check()
+    assert int(o.error_flags[0]) == 0
+
+
+@pytest.mark.parametrize('B', [1, 255, 257, 4000])
+def test_vs_oracle_ragged_batches(oracle, B):
+    run_against_oracle(oracle, configs.cyber_openness, {}, B, 30, 33, seed=B)
+
+
+@pytest.mark.parametrize('name', ['rich', 'rich_fully_observable', 'openness_no_bad_actions'])
+def test_vs_oracle_variants(oracle, name):
+    build, kwargs = configs.CYBER_GOLDEN[name]
+    run_against_oracle(oracle, build, kwargs, 2500, 25, 27, seed=4)
+
+
+def test_vs_oracle_multi_round_and_rng_modes(oracle):
+    run_against_oracle(oracle, configs.cyber_openness, {}, 300000, 10, 5, seed=6)
+    run_against_oracle(oracle, configs.cyber_openness, {}, 3001, 20, 12, seed=7, rng='philox')
+    run_against_oracle(oracle, configs.cyber_rich, {}, 700, 20, 12, seed=8, rng='philox')
+    run_against_oracle(oracle, configs.cyber_openness, {}, 1200, 30, 10, seed=9, rng='mt19937')
+
+
+def test_full_size_properties():
+    """BASELINE.json config 4: B = 65 536, 2 attackers + 2 defenders, agent openness on."""
+    B = 65536
+    envs = [make_env(configs.cyber_openness, B, 50, rng='philox', exact_shapes=False) for _ in range(2)]
+    for env in envs:
+        env.reset(seed=torch.arange(B, dtype=torch.int32))
+    for t in range(50):
+        for env in envs:
+            env.step(env.random_policy_actions(policy_seed=3, policy_step=t))
+        if t % 9 == 0 or t == 49:
+            a, b = envs
+            for name in ('_network_state', '_location', '_presence', '_rewards', '_act_map_offsets', '_tasks'):
+                assert torch.equal(getattr(a, name), getattr(b, name)), name
+            assert bool((a._network_state >= 0).all()) and bool((a._network_state <= 4).all())
+            assert bool((a._location >= -1).all()) and bool((a._location < 3).all())
+            for ag in range(4):
+                off, present = a._act_map_offsets[ag], a._presence[ag]
+                assert torch.equal(off[1:] - off[:-1], present.long() * 3)
+                assert torch.equal(a.agent_task_count[ag], present.int() * 3)
+                total = int(off[-1])
+                assert torch.equal(a._act_map_values[ag, :total].view(-1, 3), torch.arange(3, device='cuda', dtype=torch.int32).expand(total // 3, 3))
+            # zero-sum network reward between attackers and defenders (patch_reward = 0): cybersecurity.py:401-409
+            assert torch.equal(a._rewards[0], -a._rewards[2]) and torch.equal(a._rewards[0], a._rewards[1])
+    assert bool(envs[0].truncated.all()) and not bool(envs[0].terminated.any())
+    envs[0].check()
+
+
+def test_invalid_target_is_flagged():
+    env = make_env(configs.cyber_non_stochastic, 32, 10)
+    env.reset(seed=torch.arange(32, dtype=torch.int32))
+    actions = {agent: torch.tensor([[0, -1]], dtype=torch.int32).repeat(32, 1).cuda() for agent in env.agents}
+    actions['attacker_1'][3] = torch.tensor([7, 0], dtype=torch.int32)  # node 7 does not exist (cybersecurity.py:341-346 raises)
+    env.step(actions)
+    with pytest.raises(ValueError):
+        env.check()
+
+
+def test_action_space_members():
+    env = make_env(configs.cyber_openness, 512, 20, show_bad_actions=False)
+    env.reset(seed=torch.arange(512, dtype=torch.int32))
+    for t in range(6):
+        actions = {}
+        for a, agent in enumerate(env.agents):
+            sample = env.action_space(agent).sample_nested()
+            counts = env.agent_task_count[a].long()
+            move = sample[:, 1] == 0
+            assert bool((sample[move, 0] < counts[move]).all())
+            assert bool((sample[counts == 0, 1] == -1).all())  # absent agents can only noop
+            if agent.startswith('defender'):
+                home = env._location[a - 2] == -1
+                assert not bool(((sample[:, 1] == -2) & home).any())  # no patch at the home node (spaces/actions.py:62-68)
+            actions[agent] = sample
+        env.step(actions)
+    env.check()
