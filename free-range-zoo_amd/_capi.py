@@ -20,6 +20,8 @@ frz_wildfire_cfg = STRUCTS['frz_wildfire_cfg']
 frz_wildfire_bufs = STRUCTS['frz_wildfire_bufs']
 frz_cybersecurity_cfg = STRUCTS['frz_cybersecurity_cfg']
 frz_cybersecurity_bufs = STRUCTS['frz_cybersecurity_bufs']
+frz_rideshare_cfg = STRUCTS['frz_rideshare_cfg']
+frz_rideshare_bufs = STRUCTS['frz_rideshare_bufs']
 
 _lib = None
 
@@ -45,6 +47,15 @@ SIGNATURES = {
     'frz_cybersecurity_rebuild': (ctypes.c_int, [_P, _P]),
     'frz_cybersecurity_step': (ctypes.c_int, [_P, _P, ctypes.c_int, _P, _P, _P]),
     'frz_cybersecurity_random_policy': (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_uint64, _P, _P]),
+    'frz_rideshare_create': (ctypes.c_int, [_P, _P, ctypes.POINTER(_P)]),
+    'frz_rideshare_destroy': (None, [_P]),
+    'frz_rideshare_arena_bytes': (ctypes.c_int64, [_P]),
+    'frz_rideshare_bind': (ctypes.c_int, [_P, _P, _P]),
+    'frz_rideshare_get_bufs': (ctypes.c_int, [_P, _P]),
+    'frz_rideshare_reset': (ctypes.c_int, [_P, _P]),
+    'frz_rideshare_rebuild': (ctypes.c_int, [_P, _P]),
+    'frz_rideshare_step': (ctypes.c_int, [_P, _P, _P]),
+    'frz_rideshare_random_policy': (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_uint64, _P, _P]),
     'frz_mt19937_seed': (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int64, ctypes.c_int64, _P]),
     'frz_mt19937_generate': (ctypes.c_int, [_P, _P, _P, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _P]),
 }

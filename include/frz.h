@@ -294,6 +294,74 @@ int frz_cybersecurity_random_policy(frz_cybersecurity_env* env, uint64_t policy_
                                     void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Rideshare  (reference: free_range_zoo/envs/rideshare/env/rideshare.py, transitions/,
+ *             structures/configuration.py).  Deterministic: no randomness is drawn.
+ * The reference keeps ONE global passenger table sorted by env (stable: entry order inside an env); here every env owns
+ * max_passengers slots in that same order, struct-of-arrays [column][slot][B].
+ * ---------------------------------------------------------------------------------------------- */
+#define FRZ_MAX_PASSENGERS 128
+#define FRZ_PASSENGER_COLUMNS 10 /* y, x, y_dest, x_dest, fare, state, driver, entered, accepted, picked */
+
+typedef struct frz_rideshare_cfg {
+    int32_t parallel_envs;
+    int32_t grid_height, grid_width;
+    int32_t num_agents;
+    int32_t max_steps;       /* < 0 means None */
+    int32_t max_passengers;  /* slots per env (<= FRZ_MAX_PASSENGERS); overflow sets FRZ_ERR_OVERFLOW */
+    int32_t pool_limit;
+    int32_t use_fast_travel, use_diagonal_travel; /* transitions/movement.py:15-53 */
+    int32_t use_variable_move_cost, use_waiting_costs;
+    int32_t track_cumulative_rewards;
+    int32_t wait_limit[3]; /* per passenger state (unaccepted, accepted, riding) */
+    int32_t long_wait_time;
+    float move_cost, drop_cost, noop_cost, accept_cost, pool_limit_cost, general_wait_cost, long_wait_cost;
+    int32_t start_y[FRZ_MAX_AGENTS], start_x[FRZ_MAX_AGENTS];
+    int32_t schedule_rows;   /* rows of bufs.schedule */
+} frz_rideshare_cfg;
+
+typedef struct frz_rideshare_bufs {
+    int32_t* agents;           /* [A][2][B]  (y, x) */
+    int32_t* passengers;       /* [FRZ_PASSENGER_COLUMNS][max_passengers][B] */
+    int32_t* passenger_count;  /* [B] */
+    int32_t* num_moves;        /* [B] */
+    float* rewards;            /* [A][B] */
+    float* cumulative_rewards; /* [A][B] */
+    uint8_t* terminations;     /* [A][B] always 0 (rideshare.py:252) */
+    uint8_t* truncations;      /* [A][B] */
+    int32_t* obs_self;         /* [A][B][4]        (y, x, #accepted, #riding)  rideshare.py:427-441 */
+    int32_t* obs_others;       /* [A][B][A-1][4] */
+    int32_t* task_values;      /* [cap][8] all passengers (y, x, y_dest, x_dest, accepted_by|-100, riding_by|-100, fare, entered) */
+    int64_t* task_offsets;     /* [B+1]            task_store (rideshare.py:415-425); cap = B*max_passengers */
+    int32_t* agent_task_values;  /* [A][cap][8]    the tasks agent a sees: unaccepted or its own (rideshare.py:446-456) */
+    int64_t* agent_map_values;   /* [A][cap]       their positions in the env's passenger list (action = observation mapping) */
+    int64_t* agent_offsets;      /* [A][B+1] */
+    int32_t* agent_task_states;  /* [A][cap]       passenger state per visible task = the action id its OneOf member carries */
+    int64_t* env_task_count;   /* [B] */
+    int32_t* agent_task_count; /* [A][B] */
+    int32_t* schedule;         /* [S][7] (timestep, env or -1, y, x, y_dest, x_dest, fare), device copy owned by the arena */
+    uint8_t* frozen_scaled;    /* [B] */
+    int32_t* actions;          /* [A][B][2] */
+    uint32_t* error_flags;
+} frz_rideshare_bufs;
+
+typedef struct frz_rideshare_env frz_rideshare_env;
+
+/* schedule: host pointer to int32 [schedule_rows][7] (PassengerConfiguration.schedule), copied at create */
+int frz_rideshare_create(const frz_rideshare_cfg* cfg, const int32_t* schedule, frz_rideshare_env** out);
+void frz_rideshare_destroy(frz_rideshare_env* env);
+int64_t frz_rideshare_arena_bytes(const frz_rideshare_env* env);
+int frz_rideshare_bind(frz_rideshare_env* env, void* arena, void* stream);
+int frz_rideshare_get_bufs(const frz_rideshare_env* env, frz_rideshare_bufs* out);
+/* rideshare.py:185-222: agents at their start positions, passengers scheduled for step 0 enter, spaces rebuilt */
+int frz_rideshare_reset(frz_rideshare_env* env, void* stream);
+int frz_rideshare_rebuild(frz_rideshare_env* env, void* stream);
+/* one ParallelEnv.step() (rideshare.py:248-467).  actions int32 [A][B][2]: (task index in the agent's mapping, action id)
+ * with id -1 noop / 0 accept / 1 pick / 2 drop */
+int frz_rideshare_step(frz_rideshare_env* env, const int32_t* actions, void* stream);
+/* uniform member of OneOf([Discrete(1, start=state_t) for visible task t] + [noop]) (spaces/actions.py:10-50) */
+int frz_rideshare_random_policy(frz_rideshare_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Per-env MT19937 streams  (reference: free_range_zoo/utils/random_generator.py:49-146; torch CPU
  * generator = MT19937 init_genrand(seed), float32 = (u32 & 0xFFFFFF) * 2^-24)
  * ---------------------------------------------------------------------------------------------- */

@@ -114,6 +114,37 @@ void frz_oracle_cybersecurity_philox_randomness(const frz_cybersecurity_cfg* cfg
 void frz_oracle_cybersecurity_random_policy(const frz_cybersecurity_cfg* cfg, const int32_t* agent_task_count, const int32_t* location,
                                             const int32_t* env_seeds, uint64_t seed, uint64_t step, int32_t* actions);
 
+/* ------------------------------------------------------------------------------------------------- rideshare */
+typedef struct frz_oracle_rideshare_bufs {
+    int32_t* agents;           /* [B][A][2] batch-major as RideshareState.agents (structures/state.py:10-66) */
+    int32_t* passengers;       /* [B][max_passengers][10] the env's rows of the reference's global table, in table order */
+    int32_t* passenger_count;  /* [B] */
+    int32_t* num_moves;
+    float* rewards;
+    float* cumulative_rewards;
+    uint8_t* terminations;
+    uint8_t* truncations;
+    int32_t* obs_self;
+    int32_t* obs_others;
+    int32_t* task_values;
+    int64_t* task_offsets;
+    int32_t* agent_task_values;
+    int64_t* agent_map_values;
+    int64_t* agent_offsets;
+    int32_t* agent_task_states;
+    int64_t* env_task_count;
+    int32_t* agent_task_count;
+    uint32_t* error_flags;
+    int32_t* frozen;
+} frz_oracle_rideshare_bufs;
+
+int frz_oracle_rideshare_reset(const frz_rideshare_cfg* cfg, frz_oracle_rideshare_bufs* s, const int32_t* schedule);
+int frz_oracle_rideshare_rebuild(const frz_rideshare_cfg* cfg, frz_oracle_rideshare_bufs* s);
+int frz_oracle_rideshare_step(const frz_rideshare_cfg* cfg, frz_oracle_rideshare_bufs* s, const int32_t* schedule, const int32_t* actions);
+void frz_oracle_rs_move(const frz_rideshare_cfg* cfg, const int32_t vec[4], int32_t move[2], float* cost);
+void frz_oracle_rideshare_random_policy(const frz_rideshare_cfg* cfg, const frz_oracle_rideshare_bufs* s, uint64_t seed, uint64_t step,
+                                        int32_t* actions);
+
 /* MT19937 per-env streams (utils/random_generator.py:76-114); state batch-major [B][624] */
 void frz_oracle_mt19937_seed(uint32_t* mt_state, int32_t* mt_index, const int32_t* seeds, int64_t B);
 void frz_oracle_mt19937_generate(uint32_t* mt_state, int32_t* mt_index, float* out, int64_t events, int64_t count, int64_t B);

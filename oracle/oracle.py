@@ -22,6 +22,7 @@ LIB_PATH = os.path.join(_HERE, 'libfrz_oracle.so')
 _, _STRUCTS = parse_header(os.path.join(_HERE, 'frz_oracle.h'), known=_capi.STRUCTS)
 frz_oracle_wildfire_bufs = _STRUCTS['frz_oracle_wildfire_bufs']
 frz_oracle_cybersecurity_bufs = _STRUCTS['frz_oracle_cybersecurity_bufs']
+frz_oracle_rideshare_bufs = _STRUCTS['frz_oracle_rideshare_bufs']
 
 _lib = None
 
@@ -238,3 +239,51 @@ def cybersecurity_random_policy(cfg, agent_task_count, location, env_seeds, seed
     lib().frz_oracle_cybersecurity_random_policy(ctypes.byref(cfg), _ptr(atc), _ptr(loc), _ptr(seeds), ctypes.c_uint64(seed),
                                                  ctypes.c_uint64(step), _ptr(actions))
     return actions
+
+
+class RideshareOracle(_ArrayOracle):
+    """One rideshare env batch (per-env ordered passenger slots), stepped by the C oracle."""
+
+    def __init__(self, cfg, schedule):
+        self.cfg = cfg
+        self.schedule = np.ascontiguousarray(schedule, np.int32)
+        B, A, P = cfg.parallel_envs, cfg.num_agents, cfg.max_passengers
+        cap = B * P
+        z = np.zeros
+        self._bind(frz_oracle_rideshare_bufs, dict(
+            agents=z((B, A, 2), np.int32), passengers=z((B, P, 10), np.int32), passenger_count=z(B, np.int32), num_moves=z(B, np.int32),
+            rewards=z((A, B), np.float32), cumulative_rewards=z((A, B), np.float32), terminations=z((A, B), np.uint8),
+            truncations=z((A, B), np.uint8), obs_self=z((A, B, 4), np.int32), obs_others=z((A, B, max(A - 1, 0), 4), np.int32),
+            task_values=z((cap, 8), np.int32), task_offsets=z(B + 1, np.int64), agent_task_values=z((A, cap, 8), np.int32),
+            agent_map_values=z((A, cap), np.int64), agent_offsets=z((A, B + 1), np.int64), agent_task_states=z((A, cap), np.int32),
+            env_task_count=z(B, np.int64), agent_task_count=z((A, B), np.int32), error_flags=z(1, np.uint32), frozen=z(2, np.int32)))
+
+    def reset(self):
+        assert lib().frz_oracle_rideshare_reset(ctypes.byref(self.cfg), ctypes.byref(self.bufs), _ptr(self.schedule)) == 0
+
+    def rebuild(self):
+        assert lib().frz_oracle_rideshare_rebuild(ctypes.byref(self.cfg), ctypes.byref(self.bufs)) == 0
+
+    def step(self, actions):
+        actions = np.ascontiguousarray(actions, np.int32)
+        assert actions.shape == (self.cfg.num_agents, self.cfg.parallel_envs, 2)
+        assert lib().frz_oracle_rideshare_step(ctypes.byref(self.cfg), ctypes.byref(self.bufs), _ptr(self.schedule), _ptr(actions)) == 0
+
+    def random_policy(self, seed, step):
+        actions = np.zeros((self.cfg.num_agents, self.cfg.parallel_envs, 2), np.int32)
+        lib().frz_oracle_rideshare_random_policy(ctypes.byref(self.cfg), ctypes.byref(self.bufs), ctypes.c_uint64(seed), ctypes.c_uint64(step),
+                                                 _ptr(actions))
+        return actions
+
+    def table(self):
+        """The reference's global passenger table [P, 11] (env id first), rebuilt from the per-env slots."""
+        rows = []
+        for b in range(self.cfg.parallel_envs):
+            n = int(self.passenger_count[b])
+            rows.append(np.concatenate([np.full((n, 1), b, np.int32), self.passengers[b, :n]], axis=1))
+        return np.concatenate(rows, axis=0) if rows else np.zeros((0, 11), np.int32)
+
+    def agent_tasks(self, a):
+        off = self.agent_offsets[a]
+        n = int(off[-1])
+        return self.agent_task_values[a, :n], self.agent_map_values[a, :n], off

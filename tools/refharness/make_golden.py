@@ -444,6 +444,128 @@ def record_cyber_trajectories():
 
 
 # ----------------------------------------------------------------------------------------------------------
+# rideshare trajectories
+# ----------------------------------------------------------------------------------------------------------
+def rideshare_snapshot(env, prefix, out):
+    aec = env.aec_env
+    st = aec.state()
+    out[f'{prefix}agents'] = _np(st.agents)
+    out[f'{prefix}passengers'] = _np(st.passengers)
+    out[f'{prefix}num_moves'] = _np(aec.num_moves)
+    out[f'{prefix}env_task_count'] = _np(aec.environment_task_count)
+    out[f'{prefix}agent_task_count'] = _np(aec.agent_task_count)
+    tv, to = _jagged(aec.task_store)
+    out[f'{prefix}task_values'], out[f'{prefix}task_offsets'] = tv, to
+    for a, agent in enumerate(aec.agents):
+        v, o = _jagged(aec.agent_action_mapping[agent])
+        out[f'{prefix}act_map_values_{a}'], out[f'{prefix}act_map_offsets_{a}'] = v, o
+        v, o = _jagged(aec.agent_observation_mapping[agent])
+        out[f'{prefix}obs_map_values_{a}'], out[f'{prefix}obs_map_offsets_{a}'] = v, o
+        obs = aec.observe(agent)
+        out[f'{prefix}obs_self_{a}'] = _np(obs['self'])
+        out[f'{prefix}obs_others_{a}'] = _np(obs['others'])
+        v, o = _jagged(obs['tasks'])
+        out[f'{prefix}obs_tasks_values_{a}'], out[f'{prefix}obs_tasks_offsets_{a}'] = v, o
+        out[f'{prefix}cumulative_rewards_{a}'] = _np(aec._cumulative_rewards[agent])
+
+
+def rideshare_policy(aec, rng, p_noop=0.15, p_contest=0.35):
+    """Valid actions from the members the reference's action space holds: per visible task the action id = the passenger's
+    state (0 accept / 1 pick / 2 drop), or noop.  Agents are nudged towards the same unaccepted passenger now and then so
+    that the accept-conflict resolution is exercised."""
+    A, B = len(aec.agents), aec.parallel_envs
+    passengers = _np(aec.state().passengers)
+    actions = np.zeros((A, B, 2), np.int32)
+    starts = np.concatenate([[0], np.cumsum(_np(aec.environment_task_count))])
+    for b in range(B):
+        rows = passengers[starts[b]:starts[b + 1]]
+        for a in range(A):
+            visible = [k for k in range(len(rows)) if rows[k, 6] == 0 or rows[k, 7] == a]
+            n = len(visible)
+            if n == 0 or rng.random() < p_noop:
+                actions[a, b] = (n, -1)
+                continue
+            j = int(rng.integers(0, n))
+            unaccepted = [i for i, k in enumerate(visible) if rows[k, 6] == 0]
+            if unaccepted and rng.random() < p_contest:
+                j = unaccepted[0]
+            actions[a, b] = (j, rows[visible[j], 6])
+    return actions
+
+
+def rideshare_variants():
+    from dataclasses import replace
+    from tests.utils import rideshare_configs
+    from free_range_zoo.envs.rideshare.env.structures import configuration as C
+
+    def busy(A=8, steps=32, per_step=2, grid=10, seed=0, env_specific=0, B=1, **reward_over):
+        """cfg3 of SURVEY.md §8d: `per_step` wildcard passengers per step for `steps` steps, fares 1..10, 8 agents, pool 4."""
+        g = torch.Generator().manual_seed(seed)
+        rows = []
+        for t in range(steps):
+            for _ in range(per_step):
+                y, x, yd, xd = torch.randint(0, grid, (4, ), generator=g).tolist()
+                rows.append([t, -1, y, x, yd, xd, int(torch.randint(1, 11, (1, ), generator=g))])
+            for _ in range(env_specific):
+                y, x, yd, xd = torch.randint(0, grid, (4, ), generator=g).tolist()
+                rows.append([t, int(torch.randint(0, B, (1, ), generator=g)), y, x, yd, xd, int(torch.randint(1, 11, (1, ), generator=g))])
+        base = rideshare_configs.non_stochastic()
+        positions = [(0, 0), (grid - 1, grid - 1), (0, grid - 1), (grid - 1, 0), (0, 4), (grid - 1, 5), (4, 0), (5, grid - 1)][:A]
+        agent = C.AgentConfiguration(start_positions=torch.tensor(positions), pool_limit=4, use_fast_travel=False, use_diagonal_travel=False)
+        reward = replace(base.reward_config, **reward_over)
+        return C.RideshareConfiguration(grid_height=grid, grid_width=grid, agent_config=agent, reward_config=reward,
+                                        passenger_config=C.PassengerConfiguration(schedule=torch.tensor(rows, dtype=torch.int)))
+
+    def small_fast(diagonal, fast):
+        cfg = busy(A=3, steps=12, per_step=1, grid=5, seed=3, env_specific=1, B=6, use_waiting_costs=True, use_variable_move_cost=False,
+                   wait_limit=torch.tensor([1, 2, 2]), long_wait_time=3, drop_cost=0.5, accept_cost=-0.2)
+        cfg.agent_config = replace(cfg.agent_config, use_diagonal_travel=diagonal, use_fast_travel=fast, pool_limit=1)
+        return cfg
+
+    return [
+        ('nonstochastic', rideshare_configs.non_stochastic(), 4, 15, 18, 31),
+        ('cfg3_busy', busy(), 12, 50, 52, 32),
+        ('busy_waiting_costs', busy(A=4, steps=20, per_step=2, seed=1, use_waiting_costs=True, wait_limit=torch.tensor([2, 3, 4]),
+                                    long_wait_time=6), 10, 30, 32, 33),
+        ('small_diagonal', small_fast(True, False), 6, 20, 22, 34),
+        ('small_fast_travel', small_fast(False, True), 6, None, 18, 35),
+    ]
+
+
+def record_rideshare_trajectories():
+    from free_range_zoo.envs import rideshare_v0
+    from free_range_zoo_amd.envs.rideshare.env.structures.configuration import to_cstruct
+    from free_range_zoo_amd._capi import struct_to_dict
+
+    for name, configuration, B, max_steps, steps, seed in rideshare_variants():
+        cstruct, schedule = to_cstruct(configuration, B, max_steps)
+        env = rideshare_v0.parallel_env(parallel_envs=B, max_steps=max_steps, configuration=configuration, device=torch.device('cpu'))
+        env.reset(seed=torch.arange(B, dtype=torch.int32))
+        rng = np.random.default_rng(seed)
+        out = {'cfg': np.asarray(json.dumps(struct_to_dict(cstruct))), 'schedule': schedule, 'steps': np.asarray(steps)}
+        rideshare_snapshot(env, 'r_', out)
+        agents = list(env.aec_env.agents)
+        peak = 0
+        for t in range(steps):
+            actions = rideshare_policy(env.aec_env, rng)
+            moves_before = _np(env.aec_env.num_moves).copy()
+            _, rewards, terminations, truncations, infos = env.step(
+                {agent: torch.from_numpy(actions[a]) for a, agent in enumerate(agents)})
+            p = f's{t}_'
+            out[p + 'actions'] = actions
+            out[p + 'stepped'] = np.asarray(bool((_np(env.aec_env.num_moves) != moves_before).any()))
+            out[p + 'rewards'] = np.stack([_np(rewards[agent]) for agent in agents])
+            out[p + 'terminations'] = np.stack([_np(terminations[agent]) for agent in agents])
+            out[p + 'truncations'] = np.stack([_np(truncations[agent]) for agent in agents])
+            out[p + 'finished'] = _np(env.finished)
+            rideshare_snapshot(env, p, out)
+            peak = max(peak, int(out[p + 'env_task_count'].max()))
+        path = os.path.join(GOLDEN, f'traj_rideshare_{name}.npz')
+        np.savez_compressed(path, **out)
+        print(f'{path}: B={B} steps={steps} peak passengers/env={peak} slots={cstruct.max_passengers}')
+
+
+# ----------------------------------------------------------------------------------------------------------
 # torch-only vectors
 # ----------------------------------------------------------------------------------------------------------
 def record_misc():
@@ -473,6 +595,7 @@ def record_misc():
 
 
 PARTS = {'ka': record_known_answers, 'traj_wildfire': record_wildfire_trajectories, 'traj_cybersecurity': record_cyber_trajectories,
+         'traj_rideshare': record_rideshare_trajectories,
          'misc': record_misc}
 
 if __name__ == '__main__':
