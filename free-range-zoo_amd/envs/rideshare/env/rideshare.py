@@ -1,0 +1,276 @@
+"""Rideshare environment: Python boundary over the fused HIP step kernel.
+
+Mirrors free_range_zoo/envs/rideshare/env/rideshare.py (``parallel_env`` :98-114, ``raw_env`` :135-504): same
+constructor keywords, agent names (``driver_i``), observation / mapping attributes, dtypes and shapes.  The arithmetic
+runs in ``csrc/rideshare.hip`` through ``frz_rideshare_*`` (include/frz.h).  The reference's single global passenger
+table is kept as ``max_passengers`` ordered slots per env on the device; ``state().passengers`` rebuilds the table.
+"""
+import ctypes
+from typing import Any, Callable, Dict, List, Optional
+
+import torch
+
+from free_range_zoo_amd import _capi
+from free_range_zoo_amd.utils.env import BatchedParallelEnv, jagged, stream_ptr
+from free_range_zoo_amd.utils.spaces import BatchedOneOfSpace
+from free_range_zoo_amd.utils.tensordict import TensorDict
+from free_range_zoo_amd.envs.rideshare.env.structures.configuration import to_cstruct
+from free_range_zoo_amd.envs.rideshare.env.structures.state import RideshareState
+
+
+def parallel_env(wrappers: List[Callable] = [], **kwargs) -> 'raw_env':
+    env = raw_env(**kwargs)
+    for wrapper in wrappers:
+        env = wrapper(env)
+    return env
+
+
+def env(wrappers: List[Callable] = [], **kwargs) -> 'raw_env':
+    return parallel_env(wrappers, **kwargs)
+
+
+class raw_env(BatchedParallelEnv):
+    """Implementation of the dynamic rideshare environment."""
+
+    metadata = {'render.modes': ['human', 'rgb_array'], 'name': 'rideshare_v0', 'is_parallelizable': True, 'render_fps': 2}
+
+    @torch.no_grad()
+    def __init__(self, *args, max_passengers: Optional[int] = None, **kwargs):
+        """``max_passengers``: passenger slots per env (default: every passenger the schedule can ever give one env)."""
+        kwargs.setdefault('rng', 'philox')  # the domain draws no randomness; no MT19937 state is needed
+        super().__init__(*args, **kwargs)
+        A = self.agent_config.num_agents
+        self.possible_agents = tuple(f'driver_{i}' for i in range(1, A + 1))
+        self.agents = self.possible_agents
+        self.agent_name_mapping = {agent: idx for idx, agent in enumerate(self.possible_agents)}
+        self.max_x, self.max_y = self.config.grid_width, self.config.grid_height
+        self.agent_observation_bounds = (self.max_y, self.max_x, self.agent_config.pool_limit, self.agent_config.pool_limit)
+        self.passenger_observation_bounds = (self.max_y, self.max_x, self.max_y, self.max_x, A, A, self.config.max_fare, self.max_steps)
+        agent_ids = torch.arange(0, A, device=self.device)
+        self.observation_ordering = {agent: agent_ids[agent_ids != i] for i, agent in enumerate(self.possible_agents)}
+        self._max_passengers = max_passengers
+        self._allocate()
+
+    def _view(self, ptr: int, shape, dtype) -> torch.Tensor:
+        offset = ptr - self._arena.data_ptr()
+        numel = 1
+        for s in shape:
+            numel *= int(s)
+        nbytes = numel * torch.empty((), dtype=dtype).element_size()
+        return self._arena[offset:offset + nbytes].view(dtype).view(*shape)
+
+    def _allocate(self) -> None:
+        B, A = self.parallel_envs, len(self.possible_agents)
+        self._cfg, self._schedule = to_cstruct(self.config, B, self.max_steps, max_passengers=self._max_passengers)
+        P = self._cfg.max_passengers
+        self._P = P
+        cap = B * P
+        self._bind_handle(allocate=True)
+        bufs = self._bufs
+        f32, i32, i64, u8 = torch.float32, torch.int32, torch.int64, torch.uint8
+        v = self._view
+        self._agents = v(bufs.agents, (A, 2, B), i32)
+        self._passengers = v(bufs.passengers, (10, P, B), i32)
+        self._passenger_count = v(bufs.passenger_count, (B, ), i32)
+        self.num_moves = v(bufs.num_moves, (B, ), i32)
+        self._rewards, self._cumulative = v(bufs.rewards, (A, B), f32), v(bufs.cumulative_rewards, (A, B), f32)
+        self._terminations, self._truncations = v(bufs.terminations, (A, B), torch.bool), v(bufs.truncations, (A, B), torch.bool)
+        self._obs_self, self._obs_others = v(bufs.obs_self, (A, B, 4), i32), v(bufs.obs_others, (A, B, max(A - 1, 0), 4), i32)
+        self._task_values, self._task_offsets = v(bufs.task_values, (cap, 8), i32), v(bufs.task_offsets, (B + 1, ), i64)
+        self._agent_task_values = v(bufs.agent_task_values, (A, cap, 8), i32)
+        self._agent_map_values, self._agent_offsets = v(bufs.agent_map_values, (A, cap), i64), v(bufs.agent_offsets, (A, B + 1), i64)
+        self._agent_task_states = v(bufs.agent_task_states, (A, cap), i32)
+        self.environment_task_count, self.agent_task_count = v(bufs.env_task_count, (B, ), i64), v(bufs.agent_task_count, (A, B), i32)
+        self._frozen_scaled = v(bufs.frozen_scaled, (B, ), u8)
+        self._error_flags = v(bufs.error_flags, (1, ), i32)
+        self._actions = v(bufs.actions, (A, B, 2), i32)
+
+    def _bind_handle(self, allocate: bool) -> None:
+        handle = ctypes.c_void_p()
+        _capi.check(self._lib.frz_rideshare_create(ctypes.byref(self._cfg), self._schedule.ctypes.data, ctypes.byref(handle)),
+                    'frz_rideshare_create')
+        self._handle = handle
+        if allocate:
+            self._arena = self._alloc((self._lib.frz_rideshare_arena_bytes(self._handle), ), torch.uint8)
+        _capi.check(self._lib.frz_rideshare_bind(self._handle, self._arena.data_ptr(), stream_ptr(self.device)), 'frz_rideshare_bind')
+        bufs = _capi.frz_rideshare_bufs()
+        _capi.check(self._lib.frz_rideshare_get_bufs(self._handle, ctypes.byref(bufs)), 'frz_rideshare_get_bufs')
+        self._bufs = bufs
+
+    def _set_max_steps(self, max_steps) -> None:
+        if max_steps != self.max_steps:
+            self.max_steps = max_steps
+            self._cfg.max_steps = -1 if max_steps is None else int(max_steps)
+            self._lib.frz_rideshare_destroy(self._handle)
+            self._bind_handle(allocate=False)
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                self._lib.frz_rideshare_destroy(self._handle)
+                self._handle = None
+        except Exception:  # noqa: BLE001
+            pass
+
+    # ----------------------------------------------------------------------------------------------- state views
+    def state(self) -> RideshareState:
+        """Current state in the reference's form: agents ``[B, A, 2]`` (view) and the global passenger table ``[P, 11]``."""
+        B, P = self.parallel_envs, self._P
+        live = torch.arange(P, device=self.device).unsqueeze(1) < self._passenger_count.unsqueeze(0)  # [P, B]
+        envs, slots = live.t().nonzero(as_tuple=True)  # env-major, slot order = table order
+        columns = self._passengers[:, slots, envs].t()  # [n, 10]
+        table = torch.cat([envs.to(torch.int32).unsqueeze(1), columns], dim=1)
+        return RideshareState(agents=self._agents.permute(2, 0, 1), passengers=table)
+
+    def _load_state(self, state: RideshareState) -> None:
+        """Write a reference-shaped state (agents + global table sorted by env) into the per-env slots."""
+        self._agents.permute(2, 0, 1).copy_(state.agents.to(self.device))
+        table = state.passengers.to(self.device)
+        envs = table[:, 0].long()
+        counts = torch.bincount(envs, minlength=self.parallel_envs)
+        if int(counts.max()) > self._P:
+            raise ValueError('initial_state holds more passengers in one env than max_passengers slots')
+        starts = torch.cumsum(counts, 0) - counts
+        slots = torch.arange(table.shape[0], device=self.device) - starts[envs]
+        self._passengers[:, slots, envs] = table[:, 1:].t().to(torch.int32)
+        self._passenger_count.copy_(counts.to(torch.int32))
+
+    # ---------------------------------------------------------------------------------------- output plumbing
+    def _publish(self) -> None:
+        B, A, P = self.parallel_envs, len(self.agents), self._P
+        if self.exact_shapes:
+            stats = torch.cat([self._task_offsets[-1:], self._agent_offsets[:, -1], self.environment_task_count.max().reshape(1),
+                               self.agent_task_count.max(dim=1).values.to(torch.int64)]).tolist()
+            total, totals, most, mosts = stats[0], stats[1:1 + A], stats[1 + A], stats[2 + A:]
+            task_store = jagged(self._task_values[:total], self._task_offsets, max_seqlen=most)
+            tasks = [jagged(self._agent_task_values[a, :totals[a]], self._agent_offsets[a], max_seqlen=mosts[a]) for a in range(A)]
+            maps = [jagged(self._agent_map_values[a, :totals[a]], self._agent_offsets[a], max_seqlen=mosts[a]) for a in range(A)]
+        elif getattr(self, '_static_views', None) is None:
+            task_store = jagged(self._task_values, self._task_offsets, max_seqlen=P, lengths=self.environment_task_count)
+            tasks = [jagged(self._agent_task_values[a], self._agent_offsets[a], max_seqlen=P, lengths=self.agent_task_count[a]) for a in range(A)]
+            maps = [jagged(self._agent_map_values[a], self._agent_offsets[a], max_seqlen=P, lengths=self.agent_task_count[a]) for a in range(A)]
+            self._static_views = True
+        else:
+            return
+        self.task_store = task_store
+        self.agent_action_mapping, self.agent_observation_mapping, self.agent_bad_actions, self.observations = {}, {}, {}, {}
+        for a, agent in enumerate(self.agents):
+            self.agent_observation_mapping[agent] = maps[a]
+            self.agent_action_mapping[agent] = maps[a]  # the reference hands out a clone of the same values (rideshare.py:394-395)
+            self.agent_bad_actions[agent] = None
+            self.observations[agent] = TensorDict({'self': self._obs_self[a], 'others': self._obs_others[a], 'tasks': tasks[a]},
+                                                  batch_size=[B], device=self.device)
+
+    def _publish_dense(self) -> None:
+        self.rewards = {agent: self._rewards[a] for a, agent in enumerate(self.agents)}
+        self._cumulative_rewards = {agent: self._cumulative[a] for a, agent in enumerate(self.agents)}
+        self.terminations = {agent: self._terminations[a] for a, agent in enumerate(self.agents)}
+        self.truncations = {agent: self._truncations[a] for a, agent in enumerate(self.agents)}
+        self.actions = {agent: self._actions[a] for a, agent in enumerate(self.agents)}
+
+    # ------------------------------------------------------------------------------------------------- reset
+    @torch.no_grad()
+    def reset(self, seed=None, options: Optional[Dict[str, Any]] = None):
+        self._reset_options(options)
+        if not (options and options.get('skip_seeding')):
+            self.generator.seed(seed, partial_seeding=None)  # kept for API parity: the domain draws nothing
+        self.agents = self.possible_agents
+        self._static_views = None
+        stream = stream_ptr(self.device)
+        _capi.check(self._lib.frz_rideshare_reset(self._handle, stream), 'frz_rideshare_reset')
+        if options is not None and options.get('initial_state') is not None:
+            initial_state = options['initial_state']
+            if len(initial_state) != self.parallel_envs:
+                raise ValueError('Initial state must have the same number of environments as the parallel environments')
+            # rideshare.py:206-213: the given state replaces the fresh one, then the passengers scheduled for step 0 enter
+            self._load_state(initial_state)
+            self._enter_step_zero()
+            _capi.check(self._lib.frz_rideshare_rebuild(self._handle, stream), 'frz_rideshare_rebuild')
+        self._initial_state = self.state()
+        self.infos = {agent: {} for agent in self.agents}
+        self._has_reset = True
+        self._publish()
+        self._publish_dense()
+        return {agent: self.observations[agent] for agent in self.agents}, self.infos
+
+    def _enter_step_zero(self) -> None:
+        """Append the schedule rows of timestep 0 behind a loaded initial state (host-side; reset-only path)."""
+        state = self.state()
+        sched = torch.from_numpy(self._schedule).to(self.device)
+        now = sched[sched[:, 0] == 0]
+        if now.shape[0] == 0:
+            return
+        rows = []
+        for r in now.tolist():
+            envs = range(self.parallel_envs) if r[1] == -1 else [r[1]]
+            rows += [[b, r[2], r[3], r[4], r[5], r[6], 0, -1, 0, -1, -1] for b in envs]
+        new = torch.tensor(rows, dtype=torch.int32, device=self.device)
+        table = torch.cat([state.passengers, new], dim=0)
+        table = table[torch.argsort(table[:, 0], stable=True)]
+        self._load_state(RideshareState(agents=state.agents, passengers=table))
+
+    def reset_batches(self, batch_indices, seed=None, options=None) -> None:
+        raise NotImplementedError('Reset batches not implemented yet.')  # as the reference (rideshare.py:245-246)
+
+    # -------------------------------------------------------------------------------------------------- step
+    @torch.no_grad()
+    def step(self, actions):
+        """
+        One simultaneous step.  ``actions``: ``{agent: IntTensor[B, 2]}`` = (index into the agent's action mapping, action id)
+        with id -1 noop / 0 accept / 1 pick / 2 drop, or an already stacked int32 ``[A, B, 2]`` device tensor.
+        """
+        if not self._has_reset:
+            raise RuntimeError('reset() must be called before step()')
+        if isinstance(actions, dict):
+            for a, agent in enumerate(self.agents):
+                self._actions[a].copy_(actions[agent])
+            actions_ptr = self._actions.data_ptr()
+        else:
+            if actions.dtype != torch.int32 or not actions.is_contiguous() or tuple(actions.shape) != tuple(self._actions.shape):
+                raise ValueError('stacked actions must be a contiguous int32 [A, B, 2] tensor')
+            self._action_keepalive = actions
+            actions_ptr = actions.data_ptr()
+        _capi.check(self._lib.frz_rideshare_step(self._handle, actions_ptr, stream_ptr(self.device)), 'frz_rideshare_step')
+        self._publish()
+        self.infos = {agent: {} for agent in self.agents}
+        return ({agent: self.observations[agent] for agent in self.agents}, self.rewards, self.terminations, self.truncations, self.infos)
+
+    @torch.no_grad()
+    def random_policy_actions(self, policy_seed: int, policy_step: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        out = self._actions if out is None else out
+        _capi.check(self._lib.frz_rideshare_random_policy(self._handle, policy_seed, policy_step, out.data_ptr(), stream_ptr(self.device)),
+                    'frz_rideshare_random_policy')
+        return out
+
+    @torch.no_grad()
+    def capture_random_rollout(self, steps: int, policy_seed: int = 0, include_reset: bool = True) -> 'torch.cuda.CUDAGraph':
+        """``[reset] + steps x (device random policy -> fused step)`` as one HIP graph (see the wildfire env)."""
+        if not self._has_reset:
+            raise RuntimeError('reset() must be called once before capturing a rollout')
+        lib, handle, actions = self._lib, self._handle, self._actions.data_ptr()
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            stream = stream_ptr(self.device)
+            if include_reset:
+                _capi.check(lib.frz_rideshare_reset(handle, stream), 'frz_rideshare_reset')
+            for t in range(steps):
+                _capi.check(lib.frz_rideshare_random_policy(handle, policy_seed, t, actions, stream), 'frz_rideshare_random_policy')
+                _capi.check(lib.frz_rideshare_step(handle, actions, stream), 'frz_rideshare_step')
+        return graph
+
+    # ------------------------------------------------------------------------------------------------ spaces
+    @torch.no_grad()
+    def action_space(self, agent: str) -> BatchedOneOfSpace:
+        """Per-env ``OneOf([Discrete(1, start=state_t) for visible task t] + [noop])`` (rideshare.py:469-487, spaces/actions.py:10-50)."""
+        a = self.possible_agents.index(agent)
+        counts = self.agent_task_count[a]
+        total = int(self._agent_offsets[a, -1])
+        states = jagged(self._agent_task_states[a, :total], self._agent_offsets[a], max_seqlen=max(int(counts.max()), 1))
+        padded = states.to_padded_tensor(0) if total > 0 else torch.zeros((self.parallel_envs, 0), dtype=torch.int32, device=self.device)
+        return BatchedOneOfSpace(counts, tail=[-1], task_starts=padded)
+
+    def observation_space(self, agent: str):
+        return {'self_high': self.agent_observation_bounds, 'others_high': self.agent_observation_bounds,
+                'tasks_high': self.passenger_observation_bounds, 'task_counts': self.agent_task_count[self.possible_agents.index(agent)],
+                'num_others': len(self.possible_agents) - 1}

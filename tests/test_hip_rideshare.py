@@ -1,0 +1,167 @@
+"""GPU: the HIP rideshare step path against golden vectors of the reference and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+import configs
+import golden_util as G
+from free_range_zoo_amd import _capi
+from test_oracle_rideshare import compare_rideshare, oracle_snapshot
+
+pytestmark = pytest.mark.gpu
+
+
+def make_env(build, B, max_steps, **kwargs):
+    from free_range_zoo_amd.envs import rideshare_v0
+    return rideshare_v0.parallel_env(configuration=build(), parallel_envs=B, max_steps=max_steps, device=torch.device('cuda'), **kwargs)
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def hip_snapshot(env):
+    st = env.state()
+    snap = {'agents': np_(st.agents), 'passengers': np_(st.passengers), 'num_moves': np_(env.num_moves),
+            'env_task_count': np_(env.environment_task_count), 'agent_task_count': np_(env.agent_task_count),
+            'task_values': np_(env.task_store.values()), 'task_offsets': np_(env.task_store.offsets())}
+    snap['rewards'] = np.stack([np_(env.rewards[a]) for a in env.agents])
+    snap['terminations'] = np.stack([np_(env.terminations[a]) for a in env.agents])
+    snap['truncations'] = np.stack([np_(env.truncations[a]) for a in env.agents])
+    for a, agent in enumerate(env.agents):
+        m = env.agent_action_mapping[agent]
+        snap[f'act_map_values_{a}'], snap[f'act_map_offsets_{a}'] = np_(m.values()), np_(m.offsets())
+        m = env.agent_observation_mapping[agent]
+        snap[f'obs_map_values_{a}'], snap[f'obs_map_offsets_{a}'] = np_(m.values()), np_(m.offsets())
+        obs = env.observe(agent)
+        snap[f'obs_self_{a}'], snap[f'obs_others_{a}'] = np_(obs['self']), np_(obs['others'])
+        snap[f'obs_tasks_values_{a}'], snap[f'obs_tasks_offsets_{a}'] = np_(obs['tasks'].values()), np_(obs['tasks'].offsets())
+        snap[f'cumulative_rewards_{a}'] = np_(env._cumulative_rewards[agent])
+    return snap
+
+
+def compare_snapshots(got, want, what):
+    for key, w in want.items():
+        g = got[key]
+        if key in ('terminations', 'truncations'):
+            g, w = np.asarray(g).astype(bool), np.asarray(w).astype(bool)
+        G.assert_same(g, w, f'{what} {key}')
+
+
+@pytest.mark.parametrize('name', sorted(configs.RIDESHARE_GOLDEN))
+def test_golden_trajectory(name):
+    data = np.load(G.golden_path(f'traj_rideshare_{name}.npz'))
+    cfg = G.load_cfg(data, _capi.frz_rideshare_cfg)
+    B, A = cfg.parallel_envs, cfg.num_agents
+    env = make_env(configs.RIDESHARE_GOLDEN[name], B, None if cfg.max_steps < 0 else cfg.max_steps)
+    env.reset(seed=torch.arange(B, dtype=torch.int32))
+    compare_rideshare(hip_snapshot(env), data, 'r_', A, f'{name} reset')
+    for t in range(int(data['steps'])):
+        p = f's{t}_'
+        actions = {agent: torch.from_numpy(data[p + 'actions'][a]).cuda() for a, agent in enumerate(env.agents)}
+        obs, rewards, terminations, truncations, infos = env.step(actions)
+        compare_rideshare(hip_snapshot(env), data, p, A, f'{name} step {t}')
+        G.assert_same(np_(env.finished), data[p + 'finished'], f'{name} step {t} finished')
+    env.check()
+
+
+def run_against_oracle(oracle, build, B, max_steps, steps, seed, contest=0.3):
+    from free_range_zoo_amd.envs.rideshare.env.structures.configuration import to_cstruct
+    cfg, schedule = to_cstruct(build(), B, max_steps)
+    o = oracle.RideshareOracle(cfg, schedule)
+    o.reset()
+    env = make_env(build, B, max_steps)
+    env.reset(seed=torch.arange(B, dtype=torch.int32))
+    compare_snapshots(hip_snapshot(env), oracle_snapshot(o), f'reset B={B}')
+    gen = np.random.default_rng(seed)
+    A = cfg.num_agents
+    for t in range(steps):
+        actions_dev = env.random_policy_actions(policy_seed=5 + seed, policy_step=t).clone()
+        actions = o.random_policy(5 + seed, t)
+        G.assert_same(np_(actions_dev), actions, f'policy step {t}')
+        # push agents onto the same unaccepted passenger now and then (accept conflicts): first visible unaccepted task
+        cap = B * cfg.max_passengers
+        for a in range(A):
+            off = o.agent_offsets[a]
+            for b in np.nonzero(gen.random(B) < contest)[0]:
+                states = o.agent_task_states[a, off[b]:off[b + 1]]
+                free = np.nonzero(states == 0)[0]
+                if free.size:
+                    actions[a, b] = (free[0], 0)
+        env.step(torch.from_numpy(actions).cuda())
+        o.step(actions)
+        compare_snapshots(hip_snapshot(env), oracle_snapshot(o), f'B={B} step {t}')
+    env.check()
+    assert int(o.error_flags[0]) == 0
+    return env, o
+
+
+@pytest.mark.parametrize('B', [1, 255, 257, 2000])
+def test_vs_oracle_ragged_batches(oracle, B):
+    run_against_oracle(oracle, lambda: configs.rideshare_busy(A=4, steps=20, per_step=2, seed=2, env_specific=1, B=min(B, 50)), B, 30, 33,
+                       seed=B)
+
+
+@pytest.mark.parametrize('name', ['cfg3_busy', 'busy_waiting_costs', 'small_diagonal', 'small_fast_travel'])
+def test_vs_oracle_variants(oracle, name):
+    run_against_oracle(oracle, configs.RIDESHARE_GOLDEN[name], 1500, 40, 42, seed=3)
+
+
+def test_vs_oracle_multi_round(oracle):
+    run_against_oracle(oracle, lambda: configs.rideshare_busy(A=3, steps=6, per_step=1, seed=4), 140000, 8, 5, seed=5, contest=0.2)
+
+
+def test_full_size_properties():
+    """BASELINE.json config 3: B = 65 536, 8 agents, task openness on."""
+    B = 65536
+    envs = [make_env(configs.rideshare_busy, B, 50, exact_shapes=False) for _ in range(2)]
+    for env in envs:
+        env.reset(seed=torch.arange(B, dtype=torch.int32))
+    for t in range(50):
+        for env in envs:
+            env.step(env.random_policy_actions(policy_seed=11, policy_step=t))
+        if t in (0, 17, 49):
+            a, b = envs
+            for name in ('_agents', '_passenger_count', '_rewards', '_task_offsets', '_agent_offsets', 'agent_task_count'):
+                assert torch.equal(getattr(a, name), getattr(b, name)), name
+            counts = a._passenger_count.long()
+            off = a._task_offsets
+            assert int(off[0]) == 0 and torch.equal(off[1:] - off[:-1], counts) and torch.equal(a.environment_task_count, counts)
+            assert bool((a._agents >= 0).all()) and bool((a._agents < 10).all())
+            table = a.state().passengers
+            assert bool((table[1:, 0] >= table[:-1, 0]).all())  # sorted by env
+            states, drivers = table[:, 6], table[:, 7]
+            assert bool(((states == 0) == (drivers == -1)).all())  # with valid actions only accepted passengers have a driver
+            for ag in range(8):
+                visible = ((states == 0) | (drivers == ag))
+                assert torch.equal(torch.bincount(table[visible, 0].long(), minlength=B).int(), a.agent_task_count[ag])
+                aoff = a._agent_offsets[ag]
+                assert torch.equal(aoff[1:] - aoff[:-1], a.agent_task_count[ag].long())
+    assert bool(envs[0].truncated.all())
+    envs[0].check()
+
+
+def test_initial_state_and_action_space():
+    B = 300
+    env = make_env(lambda: configs.rideshare_busy(A=4, steps=10, per_step=2, seed=6), B, 20)
+    env.reset(seed=torch.arange(B, dtype=torch.int32))
+    for t in range(7):
+        actions = {}
+        for a, agent in enumerate(env.agents):
+            space = env.action_space(agent)
+            sample = space.sample_nested()
+            counts = env.agent_task_count[a].long()
+            task = sample[:, 0].long() < counts
+            assert bool((sample[~task, 1] == -1).all()) and bool((sample[task, 1] >= 0).all()) and bool((sample[task, 1] <= 2).all())
+            actions[agent] = sample
+        env.step(actions)
+    env.check()
+    saved = env.state()
+    env2 = make_env(lambda: configs.rideshare_busy(A=4, steps=10, per_step=2, seed=6), B, 20)
+    env2.reset(options={'initial_state': saved})
+    table = env2.state().passengers
+    # rideshare.py:206-213: the saved passengers plus the two wildcard passengers scheduled for step 0
+    assert table.shape[0] == saved.passengers.shape[0] + 2 * B
+    assert torch.equal(env2.state().agents, saved.agents)
+    with pytest.raises(NotImplementedError):
+        env2.reset_batches(torch.tensor([0]))
