@@ -100,7 +100,8 @@ def main():
     env = wildfire_v0.parallel_env(configuration=configs.wildfire_openness(), parallel_envs=B, max_steps=EPISODE, device=device,
                                    rng=args.rng, exact_shapes=False)
     A, HW = len(env.agents), env.max_y * env.max_x
-    base_seed = torch.arange(B, dtype=torch.int32) + rank * B  # global env index = rank * B + i
+    from free_range_zoo_amd.utils import sharding
+    base_seed = sharding.shard_seeds(rank, B)  # seed = global env index = rank * B + i
     metrics = torch.zeros(A + 2, dtype=torch.float64, device=device)  # (sum reward per agent, env-steps, finished)
     actions = torch.zeros((A, B, 2), dtype=torch.int32, device=device)
 
@@ -114,11 +115,8 @@ def main():
 
     def episode_metrics():
         # episode end: the only collective of the job — a metrics reduction over xGMI, nothing on the step path
-        metrics[:A] = env._cumulative.sum(dim=1, dtype=torch.float64)
-        metrics[A] = float(B * EPISODE)
-        metrics[A + 1] = env.finished.sum()
-        if dist is not None:
-            dist.all_reduce(metrics)
+        metrics.copy_(sharding.episode_metrics(env._cumulative, env.finished, B * EPISODE))
+        sharding.reduce_metrics(metrics)
 
     def one_step(events=None):
         """Eager path: the same launches the graphs replay, issued one by one through the Python boundary."""

@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(kBlock) cy_policy_kernel(const char* arena, ui
         tail[nt++] = -3;
     }
     const uint32_t env_seed = (uint32_t)rows[d.r_seeds * B + b];
-    const frz::Philox4 w = frz::philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), step_lo, step_hi, seed_lo ^ env_seed, seed_hi);
+    const frz::Philox4 w = frz::philox4x32_10((uint32_t)(i / B), 0u, step_lo, step_hi, seed_lo ^ env_seed, seed_hi);  // (agent, step) keyed by the env seed
     const int j = (int)(((uint64_t)w.w[0] * (uint64_t)(n + nt)) >> 32);
     const int value = j < n ? 0 : (j - n == 0 ? tail[0] : (j - n == 1 ? tail[1] : tail[2]));
     reinterpret_cast<int2*>(actions)[i] = make_int2(j, value);

@@ -31,7 +31,7 @@ enum Col { PY = 0, PX, PYD, PXD, PFARE, PSTATE, PDRIVER, PENTERED, PACCEPTED, PP
 constexpr int kNone = -100;
 
 struct RsDev {
-    int32_t B, A, P, nchunks, max_steps, pool_limit, long_wait_time, schedule_rows, max_time;
+    int32_t B, A, P, nchunks, max_steps, pool_limit, long_wait_time, schedule_rows, max_time, first_env_index;
     int32_t wait_limit[3];
     uint32_t flags;
     float move_cost, drop_cost, noop_cost, accept_cost, pool_limit_cost, general_wait_cost, long_wait_cost;
@@ -491,7 +491,8 @@ __global__ void __launch_bounds__(kBlock) rs_policy_kernel(const char* arena, ui
     const int64_t* agent_offsets = reinterpret_cast<const int64_t*>(arena + d.off_agent_offsets);
     const int32_t* agent_states = reinterpret_cast<const int32_t*>(arena + d.off_agent_task_states);
     const int n = rows[d.r_atc * B + i];
-    const frz::Philox4 w = frz::philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), step_lo, step_hi, seed_lo, seed_hi);
+    const int64_t env_global = b + d.first_env_index;  // sharding-invariant stream: (agent, global env index, step)
+    const frz::Philox4 w = frz::philox4x32_10((uint32_t)a, (uint32_t)env_global, step_lo, step_hi, seed_lo, seed_hi);
     const int j = (int)(((uint64_t)w.w[0] * (uint64_t)(n + 1)) >> 32);
     const int64_t cap = B * (int64_t)d.P;
     const int value = j < n ? agent_states[a * cap + agent_offsets[a * (B + 1) + b] + j] : -1;
@@ -564,6 +565,7 @@ int frz_rideshare_create(const frz_rideshare_cfg* cfg, const int32_t* schedule, 
     p.max_steps = cfg->max_steps;
     p.pool_limit = cfg->pool_limit;
     p.long_wait_time = cfg->long_wait_time;
+    p.first_env_index = cfg->first_env_index;
     p.schedule_rows = cfg->schedule_rows;
     std::memcpy(p.wait_limit, cfg->wait_limit, sizeof(p.wait_limit));
     auto flag = [&](int on, uint32_t bit) { p.flags |= on ? bit : 0u; };

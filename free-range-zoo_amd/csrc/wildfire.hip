@@ -696,7 +696,7 @@ __global__ void __launch_bounds__(kBlock) wf_policy_kernel(const char* arena, ui
     const int64_t* rows8 = reinterpret_cast<const int64_t*>(arena + d.off_rows8);
     const int n = (d.flags & kShowBad) ? (int)rows8[d.q_etc * B + b] : rows[d.r_atc * B + i];
     const uint32_t env_seed = (uint32_t)rows[d.r_seeds * B + b];
-    const frz::Philox4 w = frz::philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), step_lo, step_hi, seed_lo ^ env_seed, seed_hi);
+    const frz::Philox4 w = frz::philox4x32_10((uint32_t)(i / B), 0u, step_lo, step_hi, seed_lo ^ env_seed, seed_hi);  // (agent, step) keyed by the env seed
     const int j = (int)(((uint64_t)w.w[0] * (uint64_t)(n + 1)) >> 32);
     reinterpret_cast<int2*>(actions)[i] = j < n ? make_int2(j, 0) : make_int2(n, -1);
 }

@@ -35,8 +35,9 @@ class raw_env(BatchedParallelEnv):
     metadata = {'render.modes': ['human', 'rgb_array'], 'name': 'rideshare_v0', 'is_parallelizable': True, 'render_fps': 2}
 
     @torch.no_grad()
-    def __init__(self, *args, max_passengers: Optional[int] = None, **kwargs):
-        """``max_passengers``: passenger slots per env (default: every passenger the schedule can ever give one env)."""
+    def __init__(self, *args, max_passengers: Optional[int] = None, first_env_index: int = 0, **kwargs):
+        """``max_passengers``: passenger slots per env (default: every passenger the schedule can ever give one env);
+        ``first_env_index``: global index of this shard's env 0 (only the device random policy's stream uses it)."""
         kwargs.setdefault('rng', 'philox')  # the domain draws no randomness; no MT19937 state is needed
         super().__init__(*args, **kwargs)
         A = self.agent_config.num_agents
@@ -49,6 +50,7 @@ class raw_env(BatchedParallelEnv):
         agent_ids = torch.arange(0, A, device=self.device)
         self.observation_ordering = {agent: agent_ids[agent_ids != i] for i, agent in enumerate(self.possible_agents)}
         self._max_passengers = max_passengers
+        self._first_env_index = first_env_index
         self._allocate()
 
     def _view(self, ptr: int, shape, dtype) -> torch.Tensor:
@@ -61,7 +63,8 @@ class raw_env(BatchedParallelEnv):
 
     def _allocate(self) -> None:
         B, A = self.parallel_envs, len(self.possible_agents)
-        self._cfg, self._schedule = to_cstruct(self.config, B, self.max_steps, max_passengers=self._max_passengers)
+        self._cfg, self._schedule = to_cstruct(self.config, B, self.max_steps, max_passengers=self._max_passengers,
+                                                 first_env_index=self._first_env_index)
         P = self._cfg.max_passengers
         self._P = P
         cap = B * P

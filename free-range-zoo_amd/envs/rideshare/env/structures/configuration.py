@@ -100,7 +100,8 @@ def default_max_passengers(schedule: np.ndarray, parallel_envs: int) -> int:
     return max(1, wild + most)
 
 
-def to_cstruct(configuration, parallel_envs: int, max_steps, max_passengers: int = None, track_cumulative_rewards: bool = True):
+def to_cstruct(configuration, parallel_envs: int, max_steps, max_passengers: int = None, track_cumulative_rewards: bool = True,
+               first_env_index: int = 0):
     """Lower a (reference-shaped) RideshareConfiguration -> (frz_rideshare_cfg, schedule int32 [S, 7] numpy array)."""
     agent, reward = configuration.agent_config, configuration.reward_config
     schedule = np.ascontiguousarray(configuration.passenger_config.schedule.detach().cpu().numpy().astype(np.int32))
@@ -131,4 +132,5 @@ def to_cstruct(configuration, parallel_envs: int, max_steps, max_passengers: int
     for a in range(A):
         c.start_y[a], c.start_x[a] = int(positions[a, 0]), int(positions[a, 1])
     c.schedule_rows = int(schedule.shape[0])
+    c.first_env_index = int(first_env_index)
     return c, schedule

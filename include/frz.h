@@ -204,7 +204,8 @@ int frz_wildfire_rebuild(frz_wildfire_env* env, void* stream);
 int frz_wildfire_step(frz_wildfire_env* env, const int32_t* actions, int rng_mode, const float* field_randomness,
                       const float* agent_randomness, void* stream);
 /* uniform random policy over OneOf([task]*n + [noop]) (spaces/actions.py:23-41): writes int32 [A][B][2];
- * member j = (word 0 of Philox(counter (i, i >> 32, step, step >> 32), key (seed ^ seeds[b], seed >> 32)) * (n + 1)) >> 32 */
+ * member j = (word 0 of Philox(counter (agent, 0, step, step >> 32), key (seed ^ seeds[b], seed >> 32)) * (n + 1)) >> 32:
+ * the stream of an env depends on its seed only, so a sharded batch draws what the unsharded one draws */
 int frz_wildfire_random_policy(frz_wildfire_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out,
                                void* stream);
 
@@ -316,7 +317,8 @@ typedef struct frz_rideshare_cfg {
     int32_t long_wait_time;
     float move_cost, drop_cost, noop_cost, accept_cost, pool_limit_cost, general_wait_cost, long_wait_cost;
     int32_t start_y[FRZ_MAX_AGENTS], start_x[FRZ_MAX_AGENTS];
-    int32_t schedule_rows;   /* rows of bufs.schedule */
+    int32_t schedule_rows;   /* rows of the schedule passed to create() */
+    int32_t first_env_index; /* global index of env 0 of this shard (random-policy stream only) */
 } frz_rideshare_cfg;
 
 typedef struct frz_rideshare_bufs {

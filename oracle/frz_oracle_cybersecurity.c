@@ -264,7 +264,7 @@ void frz_oracle_cybersecurity_random_policy(const frz_cybersecurity_cfg* cfg, co
             if (cfg->show_bad_actions || !home) tail[nt++] = -2;
             tail[nt++] = -3;
         }
-        const uint32_t ctr[4] = {(uint32_t)i, (uint32_t)((uint64_t)i >> 32), (uint32_t)step, (uint32_t)(step >> 32)};
+        const uint32_t ctr[4] = {(uint32_t)a, 0u, (uint32_t)step, (uint32_t)(step >> 32)};
         const uint32_t key[2] = {(uint32_t)seed ^ (uint32_t)env_seeds[b], (uint32_t)(seed >> 32)};
         uint32_t out[4];
         frz_oracle_philox4x32_10(ctr, key, out);

@@ -317,7 +317,7 @@ void frz_oracle_rideshare_random_policy(const frz_rideshare_cfg* cfg, const frz_
         const int a = (int)(i / B);
         const int64_t b = i % B;
         const int n = s->agent_task_count[i];
-        const uint32_t ctr[4] = {(uint32_t)i, (uint32_t)((uint64_t)i >> 32), (uint32_t)step, (uint32_t)(step >> 32)};
+        const uint32_t ctr[4] = {(uint32_t)a, (uint32_t)(b + cfg->first_env_index), (uint32_t)step, (uint32_t)(step >> 32)};
         const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
         uint32_t out[4];
         frz_oracle_philox4x32_10(ctr, key, out);
