@@ -186,6 +186,11 @@ def main():
     task_sum = torch.zeros(1 + A, dtype=torch.float64, device=device)
     env.reset(seed=base_seed + 17)
     stream = stream_ptr(device)
+    # keep the device busy while the host enqueues the probe, so that the event pairs time the kernel on the device and
+    # not the host's launch latency (eager issue of ~20 us kernels is host-bound: an idle stream would make every
+    # bracket measure hipLaunchKernel + ctypes instead of the kernel)
+    torch.cuda.synchronize(device)
+    torch.cuda._sleep(int(2.0e9 * 0.05))
     for i in range(n_probe):
         if i % EPISODE == 0 and i > 0:
             env.seeds.add_(seed_stride)
