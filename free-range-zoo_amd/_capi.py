@@ -11,7 +11,8 @@ from ._cstruct import parse_header
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(_PKG_DIR)
 HEADER = os.path.join(REPO_ROOT, 'include', 'frz.h')
-LIB_PATH = os.path.join(_PKG_DIR, 'csrc', 'libfrz_hip.so')
+# FRZ_HIP_LIB selects another build of the same C-ABI (diagnostic builds only, e.g. libfrz_hip_stamps.so)
+LIB_PATH = os.environ.get('FRZ_HIP_LIB') or os.path.join(_PKG_DIR, 'csrc', 'libfrz_hip.so')
 
 DEFINES, STRUCTS = parse_header(HEADER)
 globals().update({k: v for k, v in DEFINES.items()})

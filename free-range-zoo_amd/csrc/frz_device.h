@@ -27,8 +27,8 @@ struct Philox4 {
 __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int round = 0; round < 10; ++round) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;  // one 32x32->64 multiply each
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         const uint32_t n0 = hi1 ^ c1 ^ k0;
         const uint32_t n2 = hi0 ^ c3 ^ k1;
         c0 = n0;
@@ -42,6 +42,26 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
 }
 
 __device__ __forceinline__ float u32_to_unit_float(uint32_t word) { return (float)(word >> 8) * (1.0f / 16777216.0f); }
+
+// A 128-bit Philox block read as five 24-bit uniforms (w[0] least significant; the top 8 bits of w[3] are unused):
+// field k = bits [24k, 24k + 24), float = field * 2^-24.  Used where a step needs many draws per env (wildfire).
+template <int K>
+__device__ __forceinline__ float philox_unit24(const Philox4& w) {
+    static_assert(K >= 0 && K < 5, "five 24-bit fields per block");
+    uint32_t v;
+    if constexpr (K == 0) v = w.w[0] & 0xFFFFFFu;
+    else if constexpr (K == 1) v = __builtin_amdgcn_alignbit(w.w[1], w.w[0], 24) & 0xFFFFFFu;
+    else if constexpr (K == 2) v = __builtin_amdgcn_alignbit(w.w[2], w.w[1], 16) & 0xFFFFFFu;
+    else if constexpr (K == 3) v = w.w[2] >> 8;
+    else v = w.w[3] & 0xFFFFFFu;
+    return (float)v * (1.0f / 16777216.0f);
+}
+__device__ __forceinline__ float philox_unit24(const Philox4& w, int k) {
+    const uint64_t lo = (uint64_t)w.w[0] | ((uint64_t)w.w[1] << 32), hi = (uint64_t)w.w[2] | ((uint64_t)w.w[3] << 32);
+    const int sh = 24 * k;
+    const uint64_t bits = sh < 64 ? ((lo >> sh) | (sh > 40 ? hi << (64 - sh) : 0ull)) : (hi >> (sh - 64));
+    return (float)(uint32_t)(bits & 0xFFFFFFull) * (1.0f / 16777216.0f);
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // Wavefront / workgroup prefix sums of per-lane counts (variable-length task lists).

@@ -63,10 +63,39 @@ __global__ void __launch_bounds__(kBlock) wf_fill_kernel(char* arena) {
 }
 
 // EXACT: the grid has exactly CMAX cells and AMAX agents (every loop bound is a compile-time constant).
+// Diagnostic build only (-DFRZ_WF_STAMPS, tools/stamps.py): thread 0 of workgroup 0 records the shader clock at phase
+// boundaries into a buffer nothing else reads.  No stamp executes in the production library.
+#ifdef FRZ_WF_STAMPS
+#define FRZ_STAMP(i)                                                                                          \
+    do {                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && MODE == kStep)                                             \
+            reinterpret_cast<unsigned long long*>(arena + d.off_rand_agent)[i] = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+    } while (0)
+#else
+#define FRZ_STAMP(i) \
+    do {             \
+    } while (0)
+#endif
+
+// One 256-env chunk per loop iteration.  Order of one iteration (what is stored where matters as much as the math: a
+// CU drains ~20-35 B/clk of stores, ~half that for record-strided ones (tools/ubench/store_rate.hip), so a 2x3 env-step
+// has ~8 K cycles of store traffic per workgroup; every store group is issued as soon as its values are final so that
+// the write path drains behind the arithmetic that follows instead of after it):
+//   loads (issued before the configuration is staged; the next chunk's are issued before the jagged tail)
+//   -> randomness -> action decode -> agent transitions            => agent rows + agent observations stored
+//   -> fire increase/decrease -> spread (per cell)                  => intensity / fuel rows stored cell by cell
+//   -> dead-env test                                                => fires rows stored
+//   -> open-task masks, per-env counts, wavefront + workgroup scan, chunk sums published
+//   -> rewards / termination / bookkeeping (hides the hand-off)     => reward / counter rows stored
+//   -> look-back over the preceding chunks -> jagged task / action lists.
+// Lanes past the batch end (last chunk only) shadow env B-1: they compute and store the same values as its owner (all
+// dense stores are pure functions of the loaded state), contribute nothing to the scan and write no list entries.
 template <int CMAX, int AMAX, bool EXACT, int RNG, int MODE>
 __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ arena, const WfDev* __restrict__ dev,
                                                           const int32_t* __restrict__ actions, const float* __restrict__ field_rand,
-                                                          const float* __restrict__ agent_rand) {
+                                                          const float* __restrict__ agent_rand, int32_t batch) {
     using mask_t = std::conditional_t<(CMAX <= 32), uint32_t, uint64_t>;
     constexpr int PW = (AMAX + 1 + 3) / 4;                                // packed scan words (four 16-bit channels each)
     constexpr int NCHP = AMAX + 3 <= 8 ? 8 : (AMAX + 3 <= 16 ? 16 : 32);  // scan channels padded to a power of two
@@ -78,150 +107,220 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ aren
     __shared__ mask_t s_range[AMAX][FRZ_MAX_EQUIPMENT_STATES];  // per-lane lookup: cells in range at equipment state s
     __shared__ float s_eq[FRZ_MAX_EQUIPMENT_STATES][4];         // per-lane lookup: equipment bonuses
     __shared__ float s_caps[FRZ_MAX_CAPACITIES];                // per-lane lookup: possible capacities
+    __shared__ WfHot s_hot;
 
-    const WfDev& d = *dev;  // lives at arena offset 0; never written by a kernel
     const int tid = threadIdx.x, lane = frz::lane_id(), wave = frz::wave_id();
-    const int64_t B = d.B;
-    const uint32_t Bu = (uint32_t)d.B;
-    const int HW = EXACT ? CMAX : d.HW, A = EXACT ? AMAX : d.A, W = d.W;
+    const int64_t B = batch;
+    const uint32_t Bu = (uint32_t)batch;
+    const int nchunks = (int)((B + kBlock - 1) / kBlock);
+    const int HW = EXACT ? CMAX : dev->HW, A = EXACT ? AMAX : dev->A;
+    // rows of the [rows][B] block: a fixed function of (HW, A) (create() lays them out in this order), and the block
+    // starts right after the configuration block: the state loads need nothing but the kernel arguments
+    const int r_fires = 0, r_intensity = HW, r_fuel = 2 * HW, r_supp = 3 * HW, r_cap = r_supp + A, r_equip = r_cap + A;
+    const int r_moves = r_equip + A, r_burnouts = r_moves + 1, r_rewards = r_moves + 2, r_cum = r_rewards + A, r_atc = r_cum + A;
+    const int r_seeds = r_atc + A;
+    int32_t* const rows = reinterpret_cast<int32_t*>(arena + kDevBlockBytes);
+    float* const rowsf = reinterpret_cast<float*>(arena + kDevBlockBytes);
+
+    struct Env {
+        int f[CMAX], in[CMAX], fu[CMAX], eqs[AMAX], act_idx[AMAX], act_id[AMAX], nm, nb;
+        float supp[AMAX], capa[AMAX], cum[AMAX];
+        uint32_t seed;
+    };
+    struct Injected {
+        float r_field[3][CMAX], r_agent[5][AMAX];
+    };
+    struct Nothing {};
+    using Draws = std::conditional_t<(RNG == FRZ_RNG_INJECTED && MODE == kStep), Injected, Nothing>;
+    auto load_env = [&](int chunk, Draws& draws) {
+        Env e;
+        const int64_t b = (int64_t)chunk * kBlock + tid;
+        const uint32_t bl = (uint32_t)(b < B ? b : B - 1);
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) {
+            e.f[c] = e.in[c] = e.fu[c] = 0;
+            if (c < HW) {
+                e.f[c] = at32(rows, (uint32_t)(r_fires + c) * Bu + bl);
+                e.in[c] = at32(rows, (uint32_t)(r_intensity + c) * Bu + bl);
+                e.fu[c] = at32(rows, (uint32_t)(r_fuel + c) * Bu + bl);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a) {
+            e.supp[a] = e.capa[a] = e.cum[a] = 0.0f;
+            e.eqs[a] = e.act_idx[a] = 0;
+            e.act_id[a] = -1;
+            if (a < A) {
+                e.supp[a] = at32(rowsf, (uint32_t)(r_supp + a) * Bu + bl);
+                e.capa[a] = at32(rowsf, (uint32_t)(r_cap + a) * Bu + bl);
+                e.eqs[a] = at32(rows, (uint32_t)(r_equip + a) * Bu + bl);
+                if (MODE == kStep) {
+                    const int2 v = reinterpret_cast<const int2*>(actions)[a * B + bl];
+                    e.act_idx[a] = v.x;
+                    e.act_id[a] = v.y;
+                    e.cum[a] = at32(rowsf, (uint32_t)(r_cum + a) * Bu + bl);
+                }
+            }
+        }
+        e.nm = e.nb = 0;
+        e.seed = 0;
+        if (MODE == kStep) {
+            e.nm = at32(rows, (uint32_t)r_moves * Bu + bl);
+            e.nb = at32(rows, (uint32_t)r_burnouts * Bu + bl);
+            if (RNG == FRZ_RNG_PHILOX) e.seed = (uint32_t)at32(rows, (uint32_t)r_seeds * Bu + bl);
+        }
+        if constexpr (RNG == FRZ_RNG_INJECTED && MODE == kStep) {
+#pragma unroll
+            for (int ev = 0; ev < 3; ++ev)
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) draws.r_field[ev][c] = c < HW ? field_rand[((int64_t)ev * B + bl) * HW + c] : 1.0f;
+#pragma unroll
+            for (int ev = 0; ev < 5; ++ev)
+#pragma unroll
+                for (int a = 0; a < AMAX; ++a) draws.r_agent[ev][a] = a < A ? agent_rand[((int64_t)ev * B + bl) * A + a] : 1.0f;
+        }
+        // A shadow lane reads rows its env's owner (another lane of this workgroup) stores later in the iteration: in
+        // the one chunk that has shadow lanes the loads complete before the workgroup barriers that precede those stores.
+        if (chunk == nchunks - 1 && (B % kBlock) != 0) __builtin_amdgcn_s_waitcnt(0);
+        return e;
+    };
+
+    Draws cur_draws;
+    Env cur = load_env(blockIdx.x, cur_draws);  // in flight while the configuration is staged
+
+    if (tid < AMAX * FRZ_MAX_EQUIPMENT_STATES)
+        (&s_range[0][0])[tid] = (mask_t)dev->range_mask[tid / FRZ_MAX_EQUIPMENT_STATES][tid % FRZ_MAX_EQUIPMENT_STATES];
+    if (tid < FRZ_MAX_EQUIPMENT_STATES * 4) (&s_eq[0][0])[tid] = (&dev->eq[0][0])[tid];
+    if (tid < FRZ_MAX_CAPACITIES) s_caps[tid] = dev->caps[tid];
+    const WfHot d = stage_hot(s_hot, dev);  // configuration block at arena offset 0; never written by a kernel
+    FRZ_STAMP(0);
+    const int W = d.W;
     const int nch = d.nch;  // A + 3
     const int ch_nt = A + 1, ch_ntr = A + 2;
     const uint32_t flags = d.flags;
 
-    if (tid < AMAX * FRZ_MAX_EQUIPMENT_STATES)
-        (&s_range[0][0])[tid] = (mask_t)d.range_mask[tid / FRZ_MAX_EQUIPMENT_STATES][tid % FRZ_MAX_EQUIPMENT_STATES];
-    if (tid < FRZ_MAX_EQUIPMENT_STATES * 4) (&s_eq[0][0])[tid] = (&d.eq[0][0])[tid];
-    if (tid < FRZ_MAX_CAPACITIES) s_caps[tid] = d.caps[tid];
-
     uint32_t* const epoch_ptr = reinterpret_cast<uint32_t*>(arena + d.off_epoch);
     uint32_t* const totals = reinterpret_cast<uint32_t*>(arena + d.off_totals);
-    // plain (cacheable, wave-uniform) load: the word was last written by the previous launch, and this launch only
-    // rewrites it after every workgroup has read it — an agent-scope load here would send one L2 request per wavefront
-    // of the grid to a single address
+    // plain (cacheable, wave-uniform) loads: the words were last written by the previous launch, and this launch only
+    // rewrites the epoch after every workgroup has read it.  Both totals slots are fetched beside the epoch (no dependent
+    // load) and the previous launch's slot is selected afterwards.
     const uint32_t epoch = *epoch_ptr;
     const uint32_t tag = epoch + 1u;  // never 0 on a zero-filled arena
-    const uint32_t* prev = totals + ((epoch + 1u) & 1u) * kTotalsStride;
-    uint32_t* cur = totals + (epoch & 1u) * kTotalsStride;
+    uint32_t* cur_totals = totals + (epoch & 1u) * kTotalsStride;
+    uint32_t prev[AMAX + 3];
+#pragma unroll
+    for (int i = 0; i < AMAX + 3; ++i) {
+        const uint32_t t0 = totals[i], t1 = totals[kTotalsStride + i];
+        prev[i] = (epoch & 1u) ? t0 : t1;
+    }
 
-    int32_t* const rows = reinterpret_cast<int32_t*>(arena + d.off_rows4);
-    float* const rowsf = reinterpret_cast<float*>(arena + d.off_rows4);
     int64_t* const rows8 = reinterpret_cast<int64_t*>(arena + d.off_rows8);
     uint8_t* const rows1 = reinterpret_cast<uint8_t*>(arena + d.off_rows1);
+    const uint32_t u_term = 0, u_trunc = (uint32_t)A, u_frozen = 2u * (uint32_t)A;
+    const uint32_t q_burnouts = 0, q_putouts = 1, q_etc = 2;
 
     // utils/env.py:211-213 — every per-agent step() is a no-op once ALL envs are terminated or ALL are truncated.
-    bool frozen = false;
-    if (MODE == kStep) frozen = prev[ch_nt] == 0u || prev[ch_ntr] == 0u;
-    __syncthreads();
+    if (MODE == kStep) {
+        uint32_t nt = prev[0], ntr = prev[0];
+#pragma unroll
+        for (int i = 0; i < AMAX + 3; ++i) {
+            nt = i == ch_nt ? prev[i] : nt;
+            ntr = i == ch_ntr ? prev[i] : ntr;
+        }
+        if (nt == 0u || ntr == 0u) {
+            // The parallel adapter (utils/conversions.py:87-90) then adds the stale aec rewards once per agent call.
+            for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+                const int64_t b = (int64_t)chunk * kBlock + tid;
+                if (b < B && !at32(rows1, u_frozen * Bu + (uint32_t)b)) {
+                    for (int a = 0; a < A; ++a) {
+                        const float r = at32(rowsf, (uint32_t)(r_rewards + a) * Bu + (uint32_t)b);
+                        float acc = 0.0f;
+                        for (int j = 0; j < A; ++j) acc = acc + r;
+                        at32(rowsf, (uint32_t)(r_rewards + a) * Bu + (uint32_t)b) = acc;
+                    }
+                    at32(rows1, u_frozen * Bu + (uint32_t)b) = 1;
+                }
+            }
+            return;
+        }
+    }
 
-    for (int chunk = blockIdx.x; chunk < d.nchunks; chunk += gridDim.x) {
+    float* const obs_self = reinterpret_cast<float*>(arena + d.off_obs_self);
+    float* const obs_others = reinterpret_cast<float*>(arena + d.off_obs_others);
+    uint64_t* const agg = reinterpret_cast<uint64_t*>(arena + d.off_agg);
+    uint64_t* const prefix = reinterpret_cast<uint64_t*>(arena + d.off_prefix);
+
+    FRZ_STAMP(1);
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         const int64_t b = (int64_t)chunk * kBlock + tid;
         const bool active = b < B;
-        const int64_t bl = active ? b : B - 1;  // inactive lanes of the last chunk shadow the last env (stores are masked)
+        const uint32_t bl = (uint32_t)(active ? b : B - 1);  // lanes past the end shadow the last env
 
-        if (frozen) {
-            // The parallel adapter (utils/conversions.py:87-90) then adds the stale aec rewards once per agent call.
-            if (active && !at32(rows1, (uint32_t)(d.u_frozen) * Bu + (uint32_t)b)) {
-                for (int a = 0; a < A; ++a) {
-                    const float r = at32(rowsf, (uint32_t)((d.r_rewards + a)) * Bu + (uint32_t)b);
-                    float acc = 0.0f;
-                    for (int j = 0; j < A; ++j) acc = acc + r;
-                    at32(rowsf, (uint32_t)((d.r_rewards + a)) * Bu + (uint32_t)b) = acc;
-                }
-                at32(rows1, (uint32_t)(d.u_frozen) * Bu + (uint32_t)b) = 1;
-            }
-            continue;
-        }
-
-        // ------------------------------------------------------------------------------------------ load state
-        int f[CMAX], in[CMAX], fu[CMAX];
-#pragma unroll
-        for (int c = 0; c < CMAX; ++c) {
-            f[c] = in[c] = fu[c] = 0;
-            if (c < HW) {
-                f[c] = at32(rows, (uint32_t)((d.r_fires + c)) * Bu + (uint32_t)bl);
-                in[c] = at32(rows, (uint32_t)((d.r_intensity + c)) * Bu + (uint32_t)bl);
-                fu[c] = at32(rows, (uint32_t)((d.r_fuel + c)) * Bu + (uint32_t)bl);
-            }
-        }
+        int f[CMAX], in[CMAX], fu[CMAX], eqs[AMAX];
         float supp[AMAX], capa[AMAX];
-        int eqs[AMAX];
 #pragma unroll
-        for (int a = 0; a < AMAX; ++a) {
-            supp[a] = capa[a] = 0.0f;
-            eqs[a] = 0;
-            if (a < A) {
-                supp[a] = at32(rowsf, (uint32_t)((d.r_supp + a)) * Bu + (uint32_t)bl);
-                capa[a] = at32(rowsf, (uint32_t)((d.r_cap + a)) * Bu + (uint32_t)bl);
-                eqs[a] = at32(rows, (uint32_t)((d.r_equip + a)) * Bu + (uint32_t)bl);
-            }
-        }
+        for (int c = 0; c < CMAX; ++c) f[c] = cur.f[c], in[c] = cur.in[c], fu[c] = cur.fu[c];
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a) supp[a] = cur.supp[a], capa[a] = cur.capa[a], eqs[a] = cur.eqs[a];
         // agents share one termination / truncation value (wildfire.py:579, utils/env.py:231-233): row 0 is read,
         // all A rows are written
-        bool term = at32(rows1, (uint32_t)(d.u_term) * Bu + (uint32_t)bl) != 0;
-        bool trunc = at32(rows1, (uint32_t)(d.u_trunc) * Bu + (uint32_t)bl) != 0;
+        const bool term0 = at32(rows1, u_term * Bu + bl) != 0;
+        const bool trunc0 = at32(rows1, u_trunc * Bu + bl) != 0;
+        bool term = term0, trunc = trunc0;
 
         float rew[AMAX];
+        int hit[AMAX];
         uint32_t err = 0;
+        mask_t burned = 0, put_out = 0;
+        int nm = cur.nm, nb = cur.nb;
+        bool dead = false;
 
+        float r_field[3][CMAX], r_agent[5][AMAX];  // uniform draws of this step (kStep only)
+        float ap[CMAX];                            // fire-fighting power applied to each cell
+        FRZ_STAMP(2);
         if (MODE == kStep) {
-            int act_idx[AMAX], act_id[AMAX];
-#pragma unroll
-            for (int a = 0; a < AMAX; ++a) {
-                act_idx[a] = 0;
-                act_id[a] = -1;
-                if (a < A) {
-                    const int2 v = reinterpret_cast<const int2*>(actions)[a * B + bl];
-                    act_idx[a] = v.x;
-                    act_id[a] = v.y;
-                }
-            }
-            int nm = at32(rows, (uint32_t)(d.r_moves) * Bu + (uint32_t)bl);
-            int nb = at32(rows, (uint32_t)(d.r_burnouts) * Bu + (uint32_t)bl);
-
             // ---------------------------------------------------------------------------------- randomness
-            float r_field[3][CMAX], r_agent[5][AMAX];
-            if (RNG == FRZ_RNG_INJECTED) {
+            if constexpr (RNG == FRZ_RNG_INJECTED && MODE == kStep) {
 #pragma unroll
                 for (int e = 0; e < 3; ++e)
 #pragma unroll
-                    for (int c = 0; c < CMAX; ++c) r_field[e][c] = c < HW ? field_rand[((int64_t)e * B + bl) * HW + c] : 1.0f;
+                    for (int c = 0; c < CMAX; ++c) r_field[e][c] = cur_draws.r_field[e][c];
 #pragma unroll
                 for (int e = 0; e < 5; ++e)
 #pragma unroll
-                    for (int a = 0; a < AMAX; ++a) r_agent[e][a] = a < A ? agent_rand[((int64_t)e * B + bl) * A + a] : 1.0f;
-            } else {
-                // FRZ_RNG_PHILOX stream (include/frz.h): counter (i, step, 0, 0) serves cell i's three field draws and
-                // agent i-1's first draw; counter (a + 1, step, 1, 0) serves agent a's other four draws.
-                const uint32_t seed = (uint32_t)at32(rows, (uint32_t)(d.r_seeds) * Bu + (uint32_t)bl);
-                const bool need_block1 = (flags & (kStochRepair | kStochDegrade | kCritical | kStochRefill | kStochSwitch)) != 0 || d.K > 1;
-                constexpr int NB0 = CMAX > AMAX + 1 ? CMAX : AMAX + 1;
+                    for (int a = 0; a < AMAX; ++a) r_agent[e][a] = cur_draws.r_agent[e][a];
+            } else if constexpr (RNG == FRZ_RNG_PHILOX) {
+                // FRZ_RNG_PHILOX stream (include/frz.h): draw u of the step = 24-bit field u % 5 of block (u / 5, step, 0, 0);
+                // field event e of cell c is draw e * HW + c, agent event e of agent a is draw 3 * HW + e * A + a.
+                // In-kernel only where HW and A are compile-time (every draw index is then a constant).
+                static_assert(EXACT || RNG != FRZ_RNG_PHILOX || MODE != kStep, "runtime shapes stage their draws (wf_philox_fill_kernel)");
+                constexpr int U = 3 * CMAX + 5 * AMAX, NB = (U + 4) / 5, NB_EVENT0 = (3 * CMAX + AMAX + 4) / 5;
+                const bool need_late = (flags & (kStochRepair | kStochDegrade | kCritical | kStochRefill | kStochSwitch)) != 0 || d.K > 1;
+                const int nb_needed = need_late ? NB : NB_EVENT0;  // agent events 1..4 are only drawn when something reads them
+                float uni[NB * 5];
 #pragma unroll
-                for (int i = 0; i < NB0; ++i) {
-                    if (i < CMAX) r_field[0][i] = r_field[1][i] = r_field[2][i] = 1.0f;
-                    if (i >= 1 && i <= AMAX) r_agent[0][i - 1] = 0.0f;
-                    if (i < HW || i <= A) {
-                        const frz::Philox4 w = frz::philox4x32_10((uint32_t)i, (uint32_t)nm, 0u, 0u, seed, 0x46525A00u);
-                        if (i < CMAX) {
-                            r_field[0][i] = frz::u32_to_unit_float(w.w[0]);
-                            r_field[1][i] = frz::u32_to_unit_float(w.w[1]);
-                            r_field[2][i] = frz::u32_to_unit_float(w.w[2]);
-                        }
-                        if (i >= 1 && i <= AMAX) r_agent[0][i - 1] = frz::u32_to_unit_float(w.w[3]);
+                for (int j = 0; j < NB; ++j) {
+                    uni[5 * j] = uni[5 * j + 1] = uni[5 * j + 2] = uni[5 * j + 3] = uni[5 * j + 4] = 0.0f;
+                    if (j < nb_needed) {
+                        const frz::Philox4 w = frz::philox4x32_10((uint32_t)j, (uint32_t)nm, 0u, 0u, cur.seed, 0x46525A00u);
+                        uni[5 * j] = frz::philox_unit24<0>(w);
+                        uni[5 * j + 1] = frz::philox_unit24<1>(w);
+                        uni[5 * j + 2] = frz::philox_unit24<2>(w);
+                        uni[5 * j + 3] = frz::philox_unit24<3>(w);
+                        uni[5 * j + 4] = frz::philox_unit24<4>(w);
                     }
                 }
 #pragma unroll
-                for (int a = 0; a < AMAX; ++a) {
-                    r_agent[1][a] = r_agent[2][a] = r_agent[3][a] = r_agent[4][a] = 0.0f;
-                    if (a < A && need_block1) {
-                        const frz::Philox4 w = frz::philox4x32_10((uint32_t)(a + 1), (uint32_t)nm, 1u, 0u, seed, 0x46525A00u);
-                        r_agent[1][a] = frz::u32_to_unit_float(w.w[0]);
-                        r_agent[2][a] = frz::u32_to_unit_float(w.w[1]);
-                        r_agent[3][a] = frz::u32_to_unit_float(w.w[2]);
-                        r_agent[4][a] = frz::u32_to_unit_float(w.w[3]);
-                    }
-                }
+                for (int e = 0; e < 3; ++e)
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c) r_field[e][c] = uni[e * CMAX + c];
+#pragma unroll
+                for (int e = 0; e < 5; ++e)
+#pragma unroll
+                    for (int a = 0; a < AMAX; ++a) r_agent[e][a] = uni[3 * CMAX + e * AMAX + a];
             }
 
+            FRZ_STAMP(3);
             // ------------------------------------------------------------- action decode (wildfire.py:427-483)
             // The action mapping of the previous rebuild is a pure function of the state it was built from, which is
             // the state just loaded: attackable set of agent a = lit fires within its (equipment-adjusted) range,
@@ -230,11 +329,9 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ aren
 #pragma unroll
             for (int c = 0; c < CMAX; ++c) lit0 |= (mask_t)(f[c] > 0) << c;
 
-            float ap[CMAX];
 #pragma unroll
             for (int c = 0; c < CMAX; ++c) ap[c] = 0.0f;
             bool users[AMAX], refill[AMAX];
-            int hit[AMAX];
             const bool show_bad = (flags & kShowBad) != 0;
 #pragma unroll
             for (int a = 0; a < AMAX; ++a) {
@@ -244,17 +341,17 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ aren
                 rew[a] = 0.0f;
                 if (a < A) {
                     const mask_t ok = supp[a] > 0.0f ? (lit0 & s_range[a][eqs[a]]) : (mask_t)0;
-                    refill[a] = act_id[a] == -1;
+                    refill[a] = cur.act_id[a] == -1;
                     // quirk wildfire.py:434-435: an agent with no attackable task in ANY env of the batch is skipped
                     const bool skipped = prev[1 + a] == 0u;
                     const bool fight = !refill[a] && !skipped;
                     const mask_t sel = show_bad ? lit0 : ok;
-                    const bool valid = act_idx[a] >= 0 && act_idx[a] < popc(sel);
+                    const bool valid = cur.act_idx[a] >= 0 && cur.act_idx[a] < popc(sel);
                     int target = 0, seen = 0;
 #pragma unroll
                     for (int c = 0; c < CMAX; ++c) {
                         const int bit = (int)((sel >> c) & 1);
-                        target = (bit && seen == act_idx[a]) ? c : target;
+                        target = (bit && seen == cur.act_idx[a]) ? c : target;
                         seen += bit;
                     }
                     const bool attackable = ((ok >> target) & 1) != 0;
@@ -269,6 +366,7 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ aren
                 }
             }
 
+            FRZ_STAMP(4);
             // ---------------------------------------------- agent transitions (suppressant/equipment/capacity)
 #pragma unroll
             for (int a = 0; a < AMAX; ++a) {
@@ -304,11 +402,47 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ aren
                     s = sw ? new_max + bonus : s;
                     supp[a] = s;
                     eqs[a] = e;
+                    at32(rowsf, (uint32_t)(r_supp + a) * Bu + bl) = supp[a];
+                    at32(rowsf, (uint32_t)(r_cap + a) * Bu + bl) = capa[a];
+                    at32(rows, (uint32_t)(r_equip + a) * Bu + bl) = eqs[a];
                 }
             }
+        }
 
+        // ------------------------------------------ agent observations (wildfire.py:677-681, 704-716)
+        // final as soon as the suppressants are: stored here so that they drain behind the fire transitions
+        {
+            const int k = d.others_k, width = (A - 1) * k;  // k = 2 + power column + suppressant column
+            const bool op = (flags & kObsPower) != 0;
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a)
+                if (a < A) {
+                    reinterpret_cast<float4*>(obs_self)[a * B + bl] = make_float4((float)d.ay[a], (float)d.ax[a], d.power[a], supp[a]);
+                    float* const others = obs_others + (a * B + bl) * (int64_t)width;
+                    int j = 0;  // record index: the other agents in agent order
+#pragma unroll
+                    for (int o = 0; o < AMAX; ++o)
+                        if (o < A && o != a) {
+                            float* const rec = others + j * k;
+                            const float y = (float)d.ay[o], x = (float)d.ax[o];
+                            if (k == 4) {
+                                *reinterpret_cast<float4*>(rec) = make_float4(y, x, d.power[o], supp[o]);
+                            } else if (k == 3) {
+                                rec[0] = y;
+                                rec[1] = x;
+                                rec[2] = op ? d.power[o] : supp[o];
+                            } else {
+                                *reinterpret_cast<float2*>(rec) = make_float2(y, x);
+                            }
+                            ++j;
+                        }
+                }
+        }
+
+        FRZ_STAMP(5);
+        if (MODE == kStep) {
             // ------------------------------------------------------------ fire increase / decrease per cell
-            mask_t burned = 0, put_out = 0, lit2 = 0;
+            mask_t lit2 = 0;
             const int almost_state = d.num_fire_states - 2, burnout_state = d.num_fire_states - 1;
             const float p_unmet = (flags & kStochIncrease) ? d.p_increase : 1.0f;
             const float p_almost = (flags & kStochBurnouts) ? d.p_burnout : d.p_increase;  // fire_increase.py:77-80
@@ -349,6 +483,8 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ aren
                 }
             }
             // ---------------------------------------- fire spread stencil (transitions/fire_spreads.py:44-57)
+            int fuel_sum = 0;
+            bool any_fire = false;
             {
                 const mask_t from_n = (lit2 << W) & (mask_t)d.has_n, from_s = (lit2 >> W) & (mask_t)d.has_s;
                 const mask_t from_w = (lit2 << 1) & (mask_t)d.has_w, from_e = (lit2 >> 1) & (mask_t)d.has_e;
@@ -366,90 +502,30 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ aren
                         const bool spread = r_field[2][c] < prob;
                         f[c] = spread ? -f[c] : f[c];
                         in[c] = spread ? d.ignition[c] : in[c];
+                        at32(rows, (uint32_t)(r_intensity + c) * Bu + bl) = in[c];  // final: stored cell by cell
+                        at32(rows, (uint32_t)(r_fuel + c) * Bu + bl) = fu[c];
+                        fuel_sum += fu[c];
+                        any_fire = any_fire || f[c] > 0;
                     }
                 }
             }
-
-            // -------------------------------------------------- rewards and termination (wildfire.py:534-582)
-            float fire_reward_sum = 0.0f, burnout_total = 0.0f;
-            int fuel_sum = 0;
-            bool any_fire = false;
-#pragma unroll
-            for (int c = 0; c < CMAX; ++c) {
-                if (c < HW) {
-                    const float fr = d.fire_rewards[c];
-                    fire_reward_sum = __fadd_rn(fire_reward_sum, ((put_out >> c) & 1) ? fr : 0.0f);
-                    const float pen = (flags & kPenaltyScaled) ? __fmul_rn(-1.0f, fr) : d.burnout_penalty;
-                    burnout_total = __fadd_rn(burnout_total, ((burned >> c) & 1) ? pen : 0.0f);
-                    fuel_sum += fu[c];
-                    any_fire = any_fire || f[c] > 0;
-                }
-            }
-            bool dead = !any_fire;
+            // termination test (wildfire.py:560-570): no lit fire left (and no fuel when fuel is tracked)
+            dead = !any_fire;
             if (flags & kUseFuel) dead = dead && fuel_sum <= 0;
 #pragma unroll
-            for (int c = 0; c < CMAX; ++c) f[c] = dead ? 0 : f[c];  // :570
-            const bool newly = !term && dead;
-            // correctly rounded float32 log via double (matches the oracle bit for bit; the reference's torch.log is
-            // a <=1-ulp float32 log).  Only evaluated by wavefronts that hold a newly terminated env.
-            float log_burnouts = 0.0f;
-            if (newly && d.termination_kappa != 0.0f) log_burnouts = (float)log((double)nb + 1.0);
-            const float penalty = __fmul_rn(d.termination_kappa, log_burnouts);
-            float term_reward = __fsub_rn(d.termination_reward, penalty);
-            term_reward = term_reward < 0.0f ? 0.0f : term_reward;
-            const int n_burn = popc(burned), n_put = popc(put_out);
-            nb += n_burn;
+            for (int c = 0; c < CMAX; ++c) {
+                f[c] = dead ? 0 : f[c];  // :570
+                if (c < HW) at32(rows, (uint32_t)(r_fires + c) * Bu + bl) = f[c];
+            }
             nm += 1;
-            trunc = (flags & kTruncate) ? nm >= d.max_steps : trunc;
-            term = term || dead;
-
-            const bool localize = (flags & kLocalize) != 0;
-#pragma unroll
-            for (int a = 0; a < AMAX; ++a) {
-                if (a < A) {
-                    float base_reward = fire_reward_sum;
-                    if (localize) {
-                        base_reward = 0.0f;
-#pragma unroll
-                        for (int c = 0; c < CMAX; ++c)
-                            if (c < HW) base_reward = (hit[a] == c && ((put_out >> c) & 1)) ? d.fire_rewards[c] : base_reward;
-                    }
-                    rew[a] = __fadd_rn(rew[a], __fadd_rn(base_reward, burnout_total));
-                    rew[a] = newly ? __fadd_rn(rew[a], term_reward) : rew[a];
-                }
-            }
-
-            // ------------------------------------------------------------------------ dense stores (state)
-            if (active) {
-#pragma unroll
-                for (int c = 0; c < CMAX; ++c)
-                    if (c < HW) {
-                        at32(rows, (uint32_t)((d.r_fires + c)) * Bu + (uint32_t)b) = f[c];
-                        at32(rows, (uint32_t)((d.r_intensity + c)) * Bu + (uint32_t)b) = in[c];
-                        at32(rows, (uint32_t)((d.r_fuel + c)) * Bu + (uint32_t)b) = fu[c];
-                    }
-                const bool track = (flags & kTrackCumulative) != 0, write_trunc = (flags & kTruncate) != 0;
-#pragma unroll
-                for (int a = 0; a < AMAX; ++a)
-                    if (a < A) {
-                        at32(rowsf, (uint32_t)((d.r_supp + a)) * Bu + (uint32_t)b) = supp[a];
-                        at32(rowsf, (uint32_t)((d.r_cap + a)) * Bu + (uint32_t)b) = capa[a];
-                        at32(rows, (uint32_t)((d.r_equip + a)) * Bu + (uint32_t)b) = eqs[a];
-                        at32(rowsf, (uint32_t)((d.r_rewards + a)) * Bu + (uint32_t)b) = rew[a];
-                        at32(rows1, (uint32_t)((d.u_term + a)) * Bu + (uint32_t)b) = (uint8_t)term;
-                        if (write_trunc) at32(rows1, (uint32_t)((d.u_trunc + a)) * Bu + (uint32_t)b) = (uint8_t)trunc;
-                        if (track) at32(rowsf, (uint32_t)((d.r_cum + a)) * Bu + (uint32_t)b) = __fadd_rn(at32(rowsf, (uint32_t)((d.r_cum + a)) * Bu + (uint32_t)b), rew[a]);
-                    }
-                at32(rows, (uint32_t)(d.r_moves) * Bu + (uint32_t)b) = nm;
-                at32(rows, (uint32_t)(d.r_burnouts) * Bu + (uint32_t)b) = nb;
-                at32(rows8, (uint32_t)(d.q_burnouts) * Bu + (uint32_t)b) = n_burn;
-                at32(rows8, (uint32_t)(d.q_putouts) * Bu + (uint32_t)b) = n_put;
-            }
+            trunc = (flags & kTruncate) ? nm >= d.max_steps : trunc0;
+            term = term0 || dead;
         }
 
         // ======================================================================================================
         // update_observations + update_actions on the new state (wildfire.py:586-717)
         // ======================================================================================================
+        FRZ_STAMP(6);
         mask_t lit1 = 0;
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) lit1 |= (mask_t)(f[c] > 0) << c;
@@ -496,9 +572,8 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ aren
             }
         }
 
-        // publish this chunk's channel sums, then (while the hand-off is in flight) do the dense observation stores
-        uint64_t* const agg = reinterpret_cast<uint64_t*>(arena + d.off_agg);
-        uint64_t* const prefix = reinterpret_cast<uint64_t*>(arena + d.off_prefix);
+        FRZ_STAMP(7);
+        // publish this chunk's channel sums; the bookkeeping below runs while the hand-off is in flight
         const int round_first = chunk - blockIdx.x;  // first chunk of this round
         uint32_t my_total = 0;                         // this chunk's sum of channel `tid` (tid < nch)
         if (tid < nch) {
@@ -515,36 +590,74 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ aren
             frz::granule_store(agg + (int64_t)chunk * nch + tid, tag, my_total);
         }
 
+        if (MODE == kStep) {
+            // -------------------------------------------------- rewards and termination (wildfire.py:534-582)
+            float fire_reward_sum = 0.0f, burnout_total = 0.0f;
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) {
+                if (c < HW) {
+                    const float fr = d.fire_rewards[c];
+                    fire_reward_sum = __fadd_rn(fire_reward_sum, ((put_out >> c) & 1) ? fr : 0.0f);
+                    const float pen = (flags & kPenaltyScaled) ? __fmul_rn(-1.0f, fr) : d.burnout_penalty;
+                    burnout_total = __fadd_rn(burnout_total, ((burned >> c) & 1) ? pen : 0.0f);
+                }
+            }
+            const bool newly = !term0 && dead;
+            // correctly rounded float32 log via double (matches the oracle bit for bit; the reference's torch.log is
+            // a <=1-ulp float32 log).  Only evaluated by wavefronts that hold a newly terminated env.
+            float log_burnouts = 0.0f;
+            if (newly && d.termination_kappa != 0.0f) log_burnouts = (float)log((double)nb + 1.0);
+            const float penalty = __fmul_rn(d.termination_kappa, log_burnouts);
+            float term_reward = __fsub_rn(d.termination_reward, penalty);
+            term_reward = term_reward < 0.0f ? 0.0f : term_reward;
+            const int n_burn = popc(burned), n_put = popc(put_out);
+            nb += n_burn;
+
+            const bool localize = (flags & kLocalize) != 0;
+            const bool track = (flags & kTrackCumulative) != 0, write_trunc = (flags & kTruncate) != 0;
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a) {
+                if (a < A) {
+                    float base_reward = fire_reward_sum;
+                    if (localize) {
+                        base_reward = 0.0f;
+#pragma unroll
+                        for (int c = 0; c < CMAX; ++c)
+                            if (c < HW) base_reward = (hit[a] == c && ((put_out >> c) & 1)) ? d.fire_rewards[c] : base_reward;
+                    }
+                    rew[a] = __fadd_rn(rew[a], __fadd_rn(base_reward, burnout_total));
+                    rew[a] = newly ? __fadd_rn(rew[a], term_reward) : rew[a];
+                    at32(rowsf, (uint32_t)(r_rewards + a) * Bu + bl) = rew[a];
+                    at32(rows1, (u_term + (uint32_t)a) * Bu + bl) = (uint8_t)term;
+                    if (write_trunc) at32(rows1, (u_trunc + (uint32_t)a) * Bu + bl) = (uint8_t)trunc;
+                    if (track) at32(rowsf, (uint32_t)(r_cum + a) * Bu + bl) = __fadd_rn(cur.cum[a], rew[a]);
+                }
+            }
+            at32(rows, (uint32_t)r_moves * Bu + bl) = nm;
+            at32(rows, (uint32_t)r_burnouts * Bu + bl) = nb;
+            at32(rows8, q_burnouts * Bu + bl) = n_burn;
+            at32(rows8, q_putouts * Bu + bl) = n_put;
+        }
         if (active) {
-            // agent observations (wildfire.py:677-681, 704-716)
-            float* const obs_self = reinterpret_cast<float*>(arena + d.off_obs_self);
-            float* const obs_others = reinterpret_cast<float*>(arena + d.off_obs_others);
-            const int width = (A - 1) * d.others_k;
-            const bool op = (flags & kObsPower) != 0, os = (flags & kObsSupp) != 0;
 #pragma unroll
             for (int a = 0; a < AMAX; ++a)
-                if (a < A) {
-                    reinterpret_cast<float4*>(obs_self)[a * B + b] = make_float4((float)d.ay[a], (float)d.ax[a], d.power[a], supp[a]);
-                    float* others = obs_others + (a * B + b) * (int64_t)width;
-                    int col = 0;
-#pragma unroll
-                    for (int o = 0; o < AMAX; ++o)
-                        if (o < A && o != a) {
-                            others[col++] = (float)d.ay[o];
-                            others[col++] = (float)d.ax[o];
-                            if (op) others[col++] = d.power[o];
-                            if (os) others[col++] = supp[o];
-                        }
-                    at32(rows, (uint32_t)((d.r_atc + a)) * Bu + (uint32_t)b) = popc(ok1[a]);
-                }
-            at32(rows8, (uint32_t)(d.q_etc) * Bu + (uint32_t)b) = F;
+                if (a < A) at32(rows, (uint32_t)(r_atc + a) * Bu + bl) = popc(ok1[a]);
+            at32(rows8, q_etc * Bu + bl) = F;
         }
 
+        // the next chunk's loads are issued before the hand-off wait and the list stores (multi-round launches)
+        const int next_chunk = chunk + (int)gridDim.x;
+        Env nxt = cur;
+        Draws nxt_draws = cur_draws;
+        if (next_chunk < nchunks) nxt = load_env(next_chunk, nxt_draws);
+
+        FRZ_STAMP(8);
         // -------------------------------------------------- inter-workgroup exclusive prefix (single pass)
         // chunk j needs the channel sums of all chunks < j: those of this round that precede it (their workgroups
         // are co-resident and have published or are about to) + the inclusive prefix the previous round's last
-        // chunk published.  Thread t sums channel (t % NCHP) over predecessors t / NCHP, t / NCHP + PP, ...; loads
-        // are issued in batches so one L2 round trip covers the window when the granules are already there.
+        // chunk published.  Thread t sums channel (t % NCHP) over predecessors t / NCHP, t / NCHP + PP, ...; the
+        // window's loads are unconditional (lanes without a predecessor read granule 0 and ignore it) so that they
+        // are in flight together: one L2 round trip when the granules are already there.
         bool timed_out = false;
         uint32_t acc = 0;
         {
@@ -558,11 +671,10 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ aren
 #pragma unroll
                     for (int u = 0; u < UNR; ++u) {
                         const int pred = first + u * PP + slot;
-                        if (pred < chunk && ch < nch) {
-                            const uint64_t g = frz::granule_load(agg + (int64_t)pred * nch + ch);
-                            all = all && (uint32_t)(g >> 32) == tag;
-                            part += (uint32_t)g;
-                        }
+                        const bool valid = pred < chunk && ch < nch;
+                        const uint64_t g = frz::granule_load(agg + (valid ? (int64_t)pred * nch + ch : (int64_t)0));
+                        all = all && (!valid || (uint32_t)(g >> 32) == tag);
+                        part += valid ? (uint32_t)g : 0u;
                     }
                     if (all) break;
                     if (spin >= (1 << 22)) {
@@ -584,15 +696,16 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ aren
 #pragma unroll
             for (int j = 0; j < frz::kWaves; ++j) s += s_reduce[j][tid];
             s_prefix[tid] = s;
-            const bool round_last = blockIdx.x == gridDim.x - 1 || chunk == d.nchunks - 1;
+            const bool round_last = blockIdx.x == gridDim.x - 1 || chunk == nchunks - 1;
             if (round_last) {
                 frz::granule_store(prefix + (int64_t)chunk * nch + tid, tag, s + my_total);
-                if (chunk == d.nchunks - 1) cur[tid] = s + my_total;  // batch totals, read by the next launch
+                if (chunk == nchunks - 1) cur_totals[tid] = s + my_total;  // batch totals, read by the next launch
             }
         }
         __syncthreads();
         if (timed_out) err |= FRZ_ERR_SCAN_TIMEOUT;
 
+        FRZ_STAMP(9);
         // ------------------------------------------------------------------ jagged stores (values + offsets)
         if (active) {
             const int64_t cap = B * HW;
@@ -602,16 +715,20 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ aren
             const int64_t off_f = (int64_t)s_prefix[0] + (int64_t)((base[0] + incl[0] - packed[0]) & 0xFFFFull);
             task_offsets[b] = off_f;
             if (b == B - 1) task_offsets[B] = off_f + F;
-            int r = 0;
+            // Row of cell c's task inside the env's segment = number of lit cells below it: every store address is a
+            // closed form of the lit mask (no running counter carried through divergent control flow).
+            int64_t* const trow = task_values + off_f * 4;
+            int64_t* const omap = obs_map + off_f;
+            int rk[CMAX];
 #pragma unroll
             for (int c = 0; c < CMAX; ++c) {
+                rk[c] = popc(lit1 & (mask_t)(((mask_t)1 << c) - 1));
                 if ((lit1 >> c) & 1) {
-                    int64_t* row = task_values + (off_f + r) * 4;
                     const int yx = d.cell_yx[c];
-                    reinterpret_cast<longlong2*>(row)[0] = make_longlong2(yx >> 16, yx & 0xFFFF);
-                    reinterpret_cast<longlong2*>(row)[1] = make_longlong2(f[c], in[c]);
-                    obs_map[off_f + r] = r;
-                    ++r;
+                    longlong2* const row = reinterpret_cast<longlong2*>(trow + rk[c] * 4);
+                    row[0] = make_longlong2(yx >> 16, yx & 0xFFFF);
+                    row[1] = make_longlong2(f[c], in[c]);
+                    omap[rk[c]] = rk[c];
                 }
             }
             int64_t* const act_values = reinterpret_cast<int64_t*>(arena + d.off_act_values);
@@ -636,50 +753,52 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ aren
                         bad_offsets[a * (B + 1) + b] = off_f - off_a;
                         if (b == B - 1) bad_offsets[a * (B + 1) + B] = (off_f - off_a) + (F - fa);
                     }
-                    int local = 0, n_ok = 0, n_bad = 0;
 #pragma unroll
                     for (int c = 0; c < CMAX; ++c) {
-                        if ((lit1 >> c) & 1) {
-                            if ((ok1[a] >> c) & 1)
-                                av[n_ok++] = local;
-                            else if (show_bad)
-                                bv[n_bad++] = local;
-                            ++local;
-                        }
+                        const mask_t below = (mask_t)(((mask_t)1 << c) - 1);
+                        if ((ok1[a] >> c) & 1)
+                            av[popc(ok1[a] & below)] = rk[c];
+                        else if (show_bad && ((lit1 >> c) & 1))
+                            bv[popc(lit1 & ~ok1[a] & below)] = rk[c];
                     }
                 }
         }
+        FRZ_STAMP(10);
         if (err) atomicOr(reinterpret_cast<uint32_t*>(arena + d.off_error), err);
 
         // The workgroup owning the last chunk finished its look-back only after every other chunk published, i.e.
         // after every workgroup of this launch read the epoch: it can advance it for the next launch.
-        if (chunk == d.nchunks - 1 && tid == 0) __hip_atomic_store(epoch_ptr, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (chunk == nchunks - 1 && tid == 0) __hip_atomic_store(epoch_ptr, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cur = nxt;
+        cur_draws = nxt_draws;
     }
 }
 
-// FRZ_RNG_PHILOX randomness staged in the arena for the large lane-per-env variants (their in-kernel generation would
-// unroll up to 64 + 16 Philox blocks per lane): one thread per (env, counter index i), see include/frz.h for the stream.
+// FRZ_RNG_PHILOX randomness staged in the arena for the variants with runtime grid shapes (their draw indices are not
+// compile-time constants): one thread per (env, Philox block), see include/frz.h for the stream.
 __global__ void __launch_bounds__(kBlock) wf_philox_fill_kernel(char* __restrict__ arena, const WfDev* __restrict__ dev) {
     const WfDev& d = *dev;
     const int64_t B = d.B;
     const int HW = d.HW, A = d.A;
-    const int per_env = HW > A + 1 ? HW : A + 1;
+    const int U = 3 * HW + 5 * A, per_env = (U + 4) / 5;
     const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (t >= B * per_env) return;
     const int64_t b = t / per_env;
-    const int i = (int)(t % per_env);
+    const int j = (int)(t % per_env);
     const int32_t* rows = reinterpret_cast<const int32_t*>(arena + d.off_rows4);
     float* field = reinterpret_cast<float*>(arena + d.off_rand_field);
     float* agent = reinterpret_cast<float*>(arena + d.off_rand_agent);
     const uint32_t seed = (uint32_t)rows[d.r_seeds * B + b], step = (uint32_t)rows[d.r_moves * B + b];
-    const frz::Philox4 w0 = frz::philox4x32_10((uint32_t)i, step, 0u, 0u, seed, 0x46525A00u);
-    if (i < HW)
-        for (int e = 0; e < 3; ++e) field[((int64_t)e * B + b) * HW + i] = frz::u32_to_unit_float(w0.w[e]);
-    if (i >= 1 && i <= A) {
-        const int a = i - 1;
-        agent[((int64_t)0 * B + b) * A + a] = frz::u32_to_unit_float(w0.w[3]);
-        const frz::Philox4 w1 = frz::philox4x32_10((uint32_t)i, step, 1u, 0u, seed, 0x46525A00u);
-        for (int e = 1; e < 5; ++e) agent[((int64_t)e * B + b) * A + a] = frz::u32_to_unit_float(w1.w[e - 1]);
+    const frz::Philox4 w = frz::philox4x32_10((uint32_t)j, step, 0u, 0u, seed, 0x46525A00u);
+    for (int k = 0; k < 5; ++k) {
+        const int u = 5 * j + k;
+        const float r = frz::philox_unit24(w, k);
+        if (u < 3 * HW) {
+            field[((int64_t)(u / HW) * B + b) * HW + u % HW] = r;
+        } else if (u < U) {
+            const int v = u - 3 * HW;
+            agent[((int64_t)(v / A) * B + b) * A + v % A] = r;
+        }
     }
 }
 
@@ -730,10 +849,10 @@ template <int CMAX, int AMAX, bool EXACT>
 void launch_variant(const WfArgs& args, int grid, int rng, int mode, hipStream_t stream) {
     WfArgs a = args;
     const WfDev* dev = reinterpret_cast<const WfDev*>(a.arena);
-    if constexpr (CMAX > 8) {
+    if constexpr (!EXACT) {
         if (mode == kStep && rng == FRZ_RNG_PHILOX) {  // stage the Philox draws, then run the injected-randomness step
             const WfDev* host = a.host_dev;
-            const int per_env = host->HW > host->A + 1 ? host->HW : host->A + 1;
+            const int per_env = (3 * host->HW + 5 * host->A + 4) / 5;
             const int64_t n = (int64_t)host->B * per_env;
             hipLaunchKernelGGL(wf_philox_fill_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, a.arena, dev);
             a.field_rand = reinterpret_cast<const float*>(a.arena + host->off_rand_field);
@@ -743,14 +862,39 @@ void launch_variant(const WfArgs& args, int grid, int rng, int mode, hipStream_t
     }
     if (mode == kRebuild) {
         hipLaunchKernelGGL((wf_step_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kRebuild>), dim3(grid), dim3(kBlock), 0, stream, a.arena,
-                           dev, a.actions, a.field_rand, a.agent_rand);
+                           dev, a.actions, a.field_rand, a.agent_rand, a.host_dev->B);
     } else if (rng == FRZ_RNG_PHILOX) {
-        if constexpr (CMAX <= 8)
+        if constexpr (EXACT)
             hipLaunchKernelGGL((wf_step_kernel<CMAX, AMAX, EXACT, FRZ_RNG_PHILOX, kStep>), dim3(grid), dim3(kBlock), 0, stream, a.arena,
-                               dev, a.actions, a.field_rand, a.agent_rand);
+                               dev, a.actions, a.field_rand, a.agent_rand, a.host_dev->B);
     } else {
         hipLaunchKernelGGL((wf_step_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kStep>), dim3(grid), dim3(kBlock), 0, stream, a.arena, dev,
-                           a.actions, a.field_rand, a.agent_rand);
+                           a.actions, a.field_rand, a.agent_rand, a.host_dev->B);
+    }
+}
+
+// Resident 256-thread workgroups per CU the runtime reports for every kernel a variant may launch (register bound).
+template <int CMAX, int AMAX, bool EXACT>
+int variant_occupancy() {
+    int lo = 8, n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_step_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kRebuild>, kBlock, 0) != hipSuccess) return 1;
+    lo = n < lo ? n : lo;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_step_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kStep>, kBlock, 0) != hipSuccess) return 1;
+    lo = n < lo ? n : lo;
+    if constexpr (EXACT) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_step_kernel<CMAX, AMAX, EXACT, FRZ_RNG_PHILOX, kStep>, kBlock, 0) != hipSuccess) return 1;
+        lo = n < lo ? n : lo;
+    }
+    return lo < 1 ? 1 : lo;
+}
+
+int lane_blocks_per_cu(int variant) {
+    switch (variant) {
+        case 0: return variant_occupancy<6, 3, true>();
+        case 1: return variant_occupancy<6, 2, true>();
+        case 2: return variant_occupancy<8, 4, false>();
+        case 3: return variant_occupancy<24, 8, false>();
+        default: return variant_occupancy<64, 16, false>();
     }
 }
 
@@ -925,6 +1069,15 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
         return here;
     };
     p.off_rows4 = take((int64_t)p.n_rows4 * B * 4);
+    // the step kernels derive these from (HW, A) and the batch size alone (their loads start before the configuration
+    // block is staged): keep both sides in step
+    if (p.off_rows4 != kDevBlockBytes || p.r_fires != 0 || p.r_intensity != HW || p.r_fuel != 2 * HW || p.r_supp != 3 * HW ||
+        p.r_cap != p.r_supp + A || p.r_equip != p.r_cap + A || p.r_moves != p.r_equip + A || p.r_burnouts != p.r_moves + 1 ||
+        p.r_rewards != p.r_moves + 2 || p.r_cum != p.r_rewards + A || p.r_atc != p.r_cum + A || p.r_seeds != p.r_atc + A ||
+        p.u_term != 0 || p.u_trunc != A || p.u_frozen != 2 * A || p.q_burnouts != 0 || p.q_putouts != 1 || p.q_etc != 2) {
+        delete env;
+        return FRZ_E_INVALID;
+    }
     p.off_rows8 = take((int64_t)p.n_rows8 * B * 8);
     p.off_rows1 = take((int64_t)p.n_rows1 * B);
     p.off_obs_self = take((int64_t)A * B * 16);
@@ -962,11 +1115,14 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
         per_cu = group_blocks_per_cu(p.group_width) - 1;
         per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
     } else {
-        per_cu = p.nchunks >= 4 * cus ? 2 : 1;
+        // a second resident workgroup per CU hides latency once there are several rounds; never ask for more than the
+        // register budget of the variant's kernels allows (a non-resident workgroup would stall the hand-off)
+        per_cu = (p.nchunks >= 4 * cus && lane_blocks_per_cu(env->variant) >= 2) ? 2 : 1;
     }
-    if (const char* forced = std::getenv("FRZ_WF_BLOCKS_PER_CU")) {
+    if (const char* forced = std::getenv("FRZ_WF_BLOCKS_PER_CU")) {  // diagnostics only; clamped to what is resident
         const int v = std::atoi(forced);
-        if (v >= 1 && v <= 8) per_cu = v;
+        const int resident = p.group_width > 0 ? group_blocks_per_cu(p.group_width) : lane_blocks_per_cu(env->variant);
+        if (v >= 1 && v <= 8) per_cu = v < resident ? v : (resident < 1 ? 1 : resident);
     }
     const int64_t capacity = (int64_t)cus * per_cu;
     const int64_t rounds = (p.nchunks + capacity - 1) / capacity;

@@ -22,34 +22,43 @@ enum Flag : uint32_t {
     kTrackCumulative = 1u << 15, kTruncate = 1u << 16,
 };
 
-// Device-resident configuration block at arena offset 0 (uniform address -> scalar loads at the point of use).
-struct WfDev {
+// Device-resident configuration block at arena offset 0.
+// WfHot = the scalars / small tables the step kernels read: every workgroup stages it through LDS once and keeps what
+// it uses in registers for the whole launch (in-kernel stamps showed scalar-cache loads at the point of use, each behind
+// its own wait, costing more than the arithmetic: a 2x3 env step spent ~50 % of its cycles waiting on them).
+struct WfHot {
     int32_t B, H, W, HW, A, S, K, nchunks, nch, others_k, max_steps, num_fire_states;
     uint32_t flags;
-    int32_t initial_fuel, initial_equipment;
-    float initial_suppressant, initial_capacity;
     float p_increase, p_burnout, p_decrease, decrease_bonus, p_supp_decrease, p_refill, p_switch, p_repair, p_degrade, p_critical;
     float spread_n, spread_w, spread_e, spread_s, random_ignition;
     float bad_attack_penalty, burnout_penalty, termination_reward, termination_kappa;
-    float caps[FRZ_MAX_CAPACITIES], cum[FRZ_MAX_CAPACITIES];
-    float eq[FRZ_MAX_EQUIPMENT_STATES][4];  // (capacity, power, range, -)
+    float cum[FRZ_MAX_CAPACITIES];
     int32_t ay[FRZ_MAX_AGENTS], ax[FRZ_MAX_AGENTS];
     float power[FRZ_MAX_AGENTS];
-    uint64_t range_mask[FRZ_MAX_AGENTS][FRZ_MAX_EQUIPMENT_STATES];  // cells agent a reaches at equipment state s
-    uint64_t has_n, has_w, has_e, has_s;                            // cells that have a north/west/east/south neighbour
-    float fire_rewards[FRZ_MAX_CELLS];
-    int32_t ignition[FRZ_MAX_CELLS];
-    int32_t cell_yx[FRZ_MAX_CELLS];  // (y << 16) | x
-    int32_t fire_types[FRZ_MAX_CELLS], lit[FRZ_MAX_CELLS];
+    uint64_t has_n, has_w, has_e, has_s;  // cells that have a north/west/east/south neighbour
     // row indices of the [rows][B] blocks
     int32_t r_fires, r_intensity, r_fuel, r_supp, r_cap, r_equip, r_moves, r_burnouts, r_rewards, r_cum, r_atc, r_seeds, r_mti, n_rows4;
     int32_t q_burnouts, q_putouts, q_etc, n_rows8;
     int32_t u_term, u_trunc, u_frozen, n_rows1;
+    int32_t group_width;  // lanes per env of the group-per-env kernel, 0 = lane-per-env kernel
+    int32_t pad_[3];
     // byte offsets from the arena base
     int64_t off_rows4, off_rows8, off_rows1, off_obs_self, off_obs_others, off_task_values, off_task_offsets, off_obs_map,
         off_act_values, off_act_offsets, off_bad_values, off_bad_offsets, off_mt_state, off_actions, off_error, off_epoch, off_totals,
         off_agg, off_gtot, off_prefix, off_rand_field, off_rand_agent, total_bytes;
-    int32_t group_width;  // lanes per env of the group-per-env kernel, 0 = lane-per-env kernel
+    float fire_rewards[FRZ_MAX_CELLS];
+    int32_t ignition[FRZ_MAX_CELLS];
+    int32_t cell_yx[FRZ_MAX_CELLS];  // (y << 16) | x
+};
+static_assert(sizeof(WfHot) % 16 == 0, "WfHot is staged with 16-byte copies");
+
+struct WfDev : WfHot {
+    int32_t initial_fuel, initial_equipment;
+    float initial_suppressant, initial_capacity;
+    float caps[FRZ_MAX_CAPACITIES];
+    float eq[FRZ_MAX_EQUIPMENT_STATES][4];  // (capacity, power, range, -)
+    uint64_t range_mask[FRZ_MAX_AGENTS][FRZ_MAX_EQUIPMENT_STATES];  // cells agent a reaches at equipment state s
+    int32_t fire_types[FRZ_MAX_CELLS], lit[FRZ_MAX_CELLS];
 };
 static_assert(sizeof(WfDev) <= 8192, "configuration block too large");
 constexpr int64_t kDevBlockBytes = 8192;
@@ -61,6 +70,15 @@ struct WfArgs {
     const float* agent_rand;
     const WfDev* host_dev;  // host copy of the configuration block (launch-side decisions)
 };
+
+// Stage the hot configuration through LDS and return it by value: the fields a kernel uses end up in registers.
+__device__ __forceinline__ WfHot stage_hot(WfHot& lds, const WfDev* dev) {
+    const uint4* src = reinterpret_cast<const uint4*>(static_cast<const WfHot*>(dev));
+    uint4* dst = reinterpret_cast<uint4*>(&lds);
+    for (int i = threadIdx.x; i < (int)(sizeof(WfHot) / 16); i += kBlock) dst[i] = src[i];
+    __syncthreads();
+    return lds;
+}
 
 // 4-byte row access with a 32-bit element index: lets the compiler address as (uniform base) + (32-bit lane offset)
 template <typename T>

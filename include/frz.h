@@ -197,10 +197,9 @@ int frz_wildfire_rebuild(frz_wildfire_env* env, void* stream);
  * rng_mode FRZ_RNG_INJECTED: field_randomness float32 [3][B][H*W], agent_randomness float32 [5][B][A]
  * (= generator.generate(B,3,(H,W)) / generate(B,5,(A,)), wildfire.py:409-410); otherwise both NULL.
  * rng_mode FRZ_RNG_PHILOX draws the same tensors from Philox4x32-10 with key (seeds[b], 0x46525A00), step = num_moves[b]
- * before the step and float = (word >> 8) * 2^-24:
- *   field event e of cell c  = word e     of counter (c, step, 0, 0)
- *   agent event 0 of agent a = word 3     of counter (a + 1, step, 0, 0)
- *   agent event e of agent a = word e - 1 of counter (a + 1, step, 1, 0),  e = 1..4 */
+ * before the step.  A 128-bit block (word 0 least significant) is read as five 24-bit uniforms:
+ *   draw u of the step = bits [24k, 24k + 24) of block counter (u / 5, step, 0, 0), k = u % 5, float = field * 2^-24
+ *   field event e of cell c = draw e * H*W + c;  agent event e of agent a = draw 3 * H*W + e * A + a */
 int frz_wildfire_step(frz_wildfire_env* env, const int32_t* actions, int rng_mode, const float* field_randomness,
                       const float* agent_randomness, void* stream);
 /* uniform random policy over OneOf([task]*n + [noop]) (spaces/actions.py:23-41): writes int32 [A][B][2];

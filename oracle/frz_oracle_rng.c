@@ -79,17 +79,24 @@ float frz_oracle_philox_uniform(int32_t seed, uint32_t step, uint32_t draw, uint
 }
 
 /* The randomness tensors a FRZ_RNG_PHILOX wildfire step consumes (include/frz.h), step = num_moves before the step,
- * key = (seed, 0x46525A00), float = (word >> 8) * 2^-24:
- *   field event e of cell c   = word e     of Philox(counter = (c, step, 0, 0))
- *   agent event 0 of agent a  = word 3     of Philox(counter = (a + 1, step, 0, 0))
- *   agent event e of agent a  = word e - 1 of Philox(counter = (a + 1, step, 1, 0)),  e = 1..4
- * (one block serves a cell's three draws and the next agent's first one; a second block the agent's other four). */
-static float philox_word(int32_t seed, uint32_t c0, uint32_t step, uint32_t block, int word) {
-    const uint32_t ctr[4] = {c0, step, block, 0u};
+ * key = (seed, 0x46525A00).  A 128-bit Philox block (word 0 least significant) is read as five 24-bit uniforms:
+ *   draw u of the step = bits [24k, 24k + 24) of block (u / 5, step, 0, 0), k = u % 5, float = field * 2^-24
+ *   field event e of cell c  = draw e * HW + c            agent event e of agent a = draw 3 * HW + e * A + a */
+static float philox_draw24(int32_t seed, uint32_t step, uint32_t u) {
+    const uint32_t ctr[4] = {u / 5u, step, 0u, 0u};
     const uint32_t key[2] = {(uint32_t)seed, 0x46525A00u};
     uint32_t out[4];
     frz_oracle_philox4x32_10(ctr, key, out);
-    return (float)(out[word] >> 8) * (1.0f / 16777216.0f);
+    const uint32_t sh = 24u * (u % 5u);
+    const uint64_t lo = (uint64_t)out[0] | ((uint64_t)out[1] << 32), hi = (uint64_t)out[2] | ((uint64_t)out[3] << 32);
+    uint64_t bits;
+    if (sh < 64u) {
+        bits = lo >> sh;
+        if (sh > 40u) bits |= hi << (64u - sh);
+    } else {
+        bits = hi >> (sh - 64u);
+    }
+    return (float)(uint32_t)(bits & 0xFFFFFFull) * (1.0f / 16777216.0f);
 }
 
 void frz_oracle_wildfire_philox_randomness(const frz_wildfire_cfg* cfg, const int32_t* seeds, const int32_t* num_moves, float* field,
@@ -99,11 +106,9 @@ void frz_oracle_wildfire_philox_randomness(const frz_wildfire_cfg* cfg, const in
     for (int64_t b = 0; b < B; ++b) {
         const uint32_t step = (uint32_t)num_moves[b];
         for (int32_t e = 0; e < 3; ++e)
-            for (int32_t c = 0; c < HW; ++c) field[(e * B + b) * HW + c] = philox_word(seeds[b], (uint32_t)c, step, 0u, e);
-        for (int32_t a = 0; a < A; ++a) {
-            agent[(0 * B + b) * A + a] = philox_word(seeds[b], (uint32_t)(a + 1), step, 0u, 3);
-            for (int32_t e = 1; e < 5; ++e) agent[(e * B + b) * A + a] = philox_word(seeds[b], (uint32_t)(a + 1), step, 1u, e - 1);
-        }
+            for (int32_t c = 0; c < HW; ++c) field[(e * B + b) * HW + c] = philox_draw24(seeds[b], step, (uint32_t)(e * HW + c));
+        for (int32_t e = 0; e < 5; ++e)
+            for (int32_t a = 0; a < A; ++a) agent[(e * B + b) * A + a] = philox_draw24(seeds[b], step, (uint32_t)(3 * HW + e * A + a));
     }
 }
 

@@ -35,21 +35,23 @@ def test_philox_known_answers(oracle):
 
 
 def test_wildfire_philox_stream_definition(oracle):
-    """include/frz.h FRZ_RNG_PHILOX: one block per cell (3 field draws + the next agent's first draw), one per agent."""
-    import ctypes
+    """include/frz.h FRZ_RNG_PHILOX: a 128-bit block is five 24-bit uniforms; draw u = field u % 5 of block u // 5."""
     from free_range_zoo_amd import _capi
     cfg = _capi.frz_wildfire_cfg()
     cfg.parallel_envs, cfg.grid_height, cfg.grid_width, cfg.num_agents = 2, 2, 3, 3
     seeds, moves = np.array([7, 11], np.int32), np.array([3, 5], np.int32)
     field, agent = oracle.wildfire_philox_randomness(cfg, seeds, moves)
-    f32 = lambda w: np.float32(w >> 8) / np.float32(16777216.0)
+
+    def draw(b, u):
+        blk = oracle.philox4x32_10([u // 5, int(moves[b]), 0, 0], [int(seeds[b]), 0x46525A00])
+        big = blk[0] | (blk[1] << 32) | (blk[2] << 64) | (blk[3] << 96)
+        return np.float32((big >> (24 * (u % 5))) & 0xFFFFFF) / np.float32(16777216.0)
+
     for b in range(2):
-        for c in range(6):
-            blk = oracle.philox4x32_10([c, int(moves[b]), 0, 0], [int(seeds[b]), 0x46525A00])
-            assert [field[e, b, c] for e in range(3)] == [f32(blk[e]) for e in range(3)]
-        for a in range(3):
-            blk0 = oracle.philox4x32_10([a + 1, int(moves[b]), 0, 0], [int(seeds[b]), 0x46525A00])
-            blk1 = oracle.philox4x32_10([a + 1, int(moves[b]), 1, 0], [int(seeds[b]), 0x46525A00])
-            assert agent[0, b, a] == f32(blk0[3])
-            assert [agent[e, b, a] for e in range(1, 5)] == [f32(blk1[e - 1]) for e in range(1, 5)]
+        for e in range(3):
+            for c in range(6):
+                assert field[e, b, c] == draw(b, e * 6 + c)
+        for e in range(5):
+            for a in range(3):
+                assert agent[e, b, a] == draw(b, 18 + e * 3 + a)
     assert field.min() >= 0.0 and field.max() < 1.0

@@ -1,0 +1,37 @@
+"""Where does ONE workgroup of the wildfire step kernel spend its cycles?  Runs the diagnostic build
+(free-range-zoo_amd/csrc/libfrz_hip_stamps.so: s_memtime stamps at phase boundaries, written by thread 0 of workgroup 0
+into a scratch region of the arena) and prints per-phase shares.  Shares, not absolute run time (stamps perturb)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ['FRZ_HIP_LIB'] = os.path.join(ROOT, 'free-range-zoo_amd', 'csrc', 'libfrz_hip_stamps.so')
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import ctypes
+import numpy as np, torch, configs
+from free_range_zoo_amd import _capi
+from free_range_zoo_amd.envs import wildfire_v0
+from free_range_zoo_amd.utils.env import stream_ptr
+names = ['loads+config/LDS init', 'epoch+totals+frozen test', 'loop top', 'randomness (philox)', 'decode', 'agent transitions+agent/obs stores',
+         'fire inc/dec+spread+cell stores', 'rebuild masks+scan', 'publish+rewards+reward stores+prefetch', 'look-back', 'jagged stores']
+NS = len(names)
+for B in [int(x) for x in sys.argv[1:]] or [256, 65536]:
+    env = wildfire_v0.parallel_env(configuration=configs.wildfire_openness(), parallel_envs=B, max_steps=50, device=torch.device('cuda'),
+                                   rng='philox', exact_shapes=False)
+    env.reset(seed=torch.arange(B, dtype=torch.int32))
+    # the stamps live at the start of the (otherwise unused in philox mode) agent-randomness staging region
+    bufs = env._bufs
+    lib, h, s = env._lib, env._handle, stream_ptr(env.device)
+    region = env._arena  # find offset of rand_agent: it follows rand_field; locate through the handle is not exposed -> scan via mt_state
+    rows = []
+    for t in range(30):
+        lib.frz_wildfire_random_policy(h, 1, t, env._actions.data_ptr(), s)
+        lib.frz_wildfire_step(h, env._actions.data_ptr(), _capi.FRZ_RNG_PHILOX, None, None, s)
+        torch.cuda.synchronize()
+        off = bufs.mt_state - env._arena.data_ptr() - ((5 * B * 3 * 4 + 255) // 256) * 256
+        st = env._arena[off:off + NS * 8].view(torch.int64).cpu().numpy().astype(np.int64)
+        rows.append(np.diff(st))
+    d = np.median(np.array(rows[5:]), axis=0)
+    total = d.sum()
+    print(f'--- B={B}: {total} shader cycles between first and last stamp (~{total / 2.4e3:.1f} us at 2.4 GHz)')
+    for n, v in zip(names[1:], d):
+        print(f'  {n:28s} {int(v):7d}  {100 * v / total:5.1f} %')
+    del env
