@@ -95,7 +95,8 @@ __global__ void __launch_bounds__(kBlock) wf_fill_kernel(char* arena) {
 template <int CMAX, int AMAX, bool EXACT, int RNG, int MODE>
 __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ arena, const WfDev* __restrict__ dev,
                                                           const int32_t* __restrict__ actions, const float* __restrict__ field_rand,
-                                                          const float* __restrict__ agent_rand, int32_t batch) {
+                                                          const float* __restrict__ agent_rand, const WfLaunch launch) {
+    const int32_t batch = launch.batch;
     using mask_t = std::conditional_t<(CMAX <= 32), uint32_t, uint64_t>;
     constexpr int PW = (AMAX + 1 + 3) / 4;                                // packed scan words (four 16-bit channels each)
     constexpr int NCHP = AMAX + 3 <= 8 ? 8 : (AMAX + 3 <= 16 ? 16 : 32);  // scan channels padded to a power of two
@@ -104,12 +105,10 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ aren
     __shared__ uint32_t s_wave_live[frz::kWaves][2];
     __shared__ uint32_t s_reduce[frz::kWaves][32];
     __shared__ uint32_t s_prefix[32];
-    __shared__ mask_t s_range[AMAX][FRZ_MAX_EQUIPMENT_STATES];  // per-lane lookup: cells in range at equipment state s
-    __shared__ float s_eq[FRZ_MAX_EQUIPMENT_STATES][4];         // per-lane lookup: equipment bonuses
-    __shared__ float s_caps[FRZ_MAX_CAPACITIES];                // per-lane lookup: possible capacities
-    __shared__ WfHot s_hot;
+    __shared__ WfStaged s_cfg;  // hot scalars (copied to registers below) + the per-lane lookup tables (range sets, equipment, capacities)
 
     const int tid = threadIdx.x, lane = frz::lane_id(), wave = frz::wave_id();
+    const uint4 cfg_piece = stage_request(dev);  // first vector-memory instruction of the kernel
     const int64_t B = batch;
     const uint32_t Bu = (uint32_t)batch;
     const int nchunks = (int)((B + kBlock - 1) / kBlock);
@@ -121,11 +120,23 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ aren
     const int r_seeds = r_atc + A;
     int32_t* const rows = reinterpret_cast<int32_t*>(arena + kDevBlockBytes);
     float* const rowsf = reinterpret_cast<float*>(arena + kDevBlockBytes);
+    uint8_t* const rows1 = reinterpret_cast<uint8_t*>(arena + launch.off_rows1);
+    const uint32_t u_term = 0, u_trunc = (uint32_t)A, u_frozen = 2u * (uint32_t)A;
+
+    // plain (cacheable, wave-uniform) loads: the words were last written by the previous launch, and this launch only
+    // rewrites the epoch after every workgroup has read it.  Both totals slots are fetched beside the epoch (no dependent
+    // load) and the previous launch's slot is selected afterwards.
+    uint32_t* const epoch_ptr = reinterpret_cast<uint32_t*>(arena + launch.off_epoch);
+    uint32_t* const totals = reinterpret_cast<uint32_t*>(arena + launch.off_totals);
+    const uint32_t epoch = *epoch_ptr;
+    uint32_t totals0[AMAX + 3], totals1[AMAX + 3];
+#pragma unroll
+    for (int i = 0; i < AMAX + 3; ++i) totals0[i] = totals[i], totals1[i] = totals[kTotalsStride + i];
 
     struct Env {
         int f[CMAX], in[CMAX], fu[CMAX], eqs[AMAX], act_idx[AMAX], act_id[AMAX], nm, nb;
         float supp[AMAX], capa[AMAX], cum[AMAX];
-        uint32_t seed;
+        uint32_t seed, term, trunc;
     };
     struct Injected {
         float r_field[3][CMAX], r_agent[5][AMAX];
@@ -162,6 +173,10 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ aren
                 }
             }
         }
+        // agents share one termination / truncation value (wildfire.py:579, utils/env.py:231-233): row 0 is read,
+        // all A rows are written
+        e.term = at32(rows1, u_term * Bu + bl);
+        e.trunc = at32(rows1, u_trunc * Bu + bl);
         e.nm = e.nb = 0;
         e.seed = 0;
         if (MODE == kStep) {
@@ -188,35 +203,20 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ aren
     Draws cur_draws;
     Env cur = load_env(blockIdx.x, cur_draws);  // in flight while the configuration is staged
 
-    if (tid < AMAX * FRZ_MAX_EQUIPMENT_STATES)
-        (&s_range[0][0])[tid] = (mask_t)dev->range_mask[tid / FRZ_MAX_EQUIPMENT_STATES][tid % FRZ_MAX_EQUIPMENT_STATES];
-    if (tid < FRZ_MAX_EQUIPMENT_STATES * 4) (&s_eq[0][0])[tid] = (&dev->eq[0][0])[tid];
-    if (tid < FRZ_MAX_CAPACITIES) s_caps[tid] = dev->caps[tid];
-    const WfHot d = stage_hot(s_hot, dev);  // configuration block at arena offset 0; never written by a kernel
+    const WfHot d = stage_commit(s_cfg, cfg_piece);  // configuration block at arena offset 0; never written by a kernel
     FRZ_STAMP(0);
     const int W = d.W;
     const int nch = d.nch;  // A + 3
     const int ch_nt = A + 1, ch_ntr = A + 2;
     const uint32_t flags = d.flags;
 
-    uint32_t* const epoch_ptr = reinterpret_cast<uint32_t*>(arena + d.off_epoch);
-    uint32_t* const totals = reinterpret_cast<uint32_t*>(arena + d.off_totals);
-    // plain (cacheable, wave-uniform) loads: the words were last written by the previous launch, and this launch only
-    // rewrites the epoch after every workgroup has read it.  Both totals slots are fetched beside the epoch (no dependent
-    // load) and the previous launch's slot is selected afterwards.
-    const uint32_t epoch = *epoch_ptr;
     const uint32_t tag = epoch + 1u;  // never 0 on a zero-filled arena
     uint32_t* cur_totals = totals + (epoch & 1u) * kTotalsStride;
     uint32_t prev[AMAX + 3];
 #pragma unroll
-    for (int i = 0; i < AMAX + 3; ++i) {
-        const uint32_t t0 = totals[i], t1 = totals[kTotalsStride + i];
-        prev[i] = (epoch & 1u) ? t0 : t1;
-    }
+    for (int i = 0; i < AMAX + 3; ++i) prev[i] = (epoch & 1u) ? totals0[i] : totals1[i];
 
     int64_t* const rows8 = reinterpret_cast<int64_t*>(arena + d.off_rows8);
-    uint8_t* const rows1 = reinterpret_cast<uint8_t*>(arena + d.off_rows1);
-    const uint32_t u_term = 0, u_trunc = (uint32_t)A, u_frozen = 2u * (uint32_t)A;
     const uint32_t q_burnouts = 0, q_putouts = 1, q_etc = 2;
 
     // utils/env.py:211-213 — every per-agent step() is a no-op once ALL envs are terminated or ALL are truncated.
@@ -262,10 +262,7 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ aren
         for (int c = 0; c < CMAX; ++c) f[c] = cur.f[c], in[c] = cur.in[c], fu[c] = cur.fu[c];
 #pragma unroll
         for (int a = 0; a < AMAX; ++a) supp[a] = cur.supp[a], capa[a] = cur.capa[a], eqs[a] = cur.eqs[a];
-        // agents share one termination / truncation value (wildfire.py:579, utils/env.py:231-233): row 0 is read,
-        // all A rows are written
-        const bool term0 = at32(rows1, u_term * Bu + bl) != 0;
-        const bool trunc0 = at32(rows1, u_trunc * Bu + bl) != 0;
+        const bool term0 = cur.term != 0, trunc0 = cur.trunc != 0;
         bool term = term0, trunc = trunc0;
 
         float rew[AMAX];
@@ -340,7 +337,7 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ aren
                 hit[a] = -1;
                 rew[a] = 0.0f;
                 if (a < A) {
-                    const mask_t ok = supp[a] > 0.0f ? (lit0 & s_range[a][eqs[a]]) : (mask_t)0;
+                    const mask_t ok = supp[a] > 0.0f ? (lit0 & (mask_t)s_cfg.range_mask[a][eqs[a]]) : (mask_t)0;
                     refill[a] = cur.act_id[a] == -1;
                     // quirk wildfire.py:434-435: an agent with no attackable task in ANY env of the batch is skipped
                     const bool skipped = prev[1 + a] == 0u;
@@ -357,7 +354,7 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ aren
                     const bool attackable = ((ok >> target) & 1) != 0;
                     const bool good = fight && valid && (!show_bad || attackable);
                     if (fight && !valid && active) err |= FRZ_ERR_BAD_ACTION_INDEX;
-                    const float power = d.power[a] + s_eq[eqs[a]][1];
+                    const float power = d.power[a] + s_cfg.eq[eqs[a]][1];
 #pragma unroll
                     for (int c = 0; c < CMAX; ++c) ap[c] = ap[c] + ((good && target == c) ? power : 0.0f);  // agent order
                     users[a] = good;
@@ -388,14 +385,14 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ aren
                     e = degr ? e - 1 : e;
                     // transitions/suppressant_refill.py:63-70 (bonus from the NEW equipment state)
                     const bool inc = refill[a] && (!(flags & kStochRefill) || r_agent[2][a] < d.p_refill);
-                    s = inc ? capa[a] + s_eq[e][0] : s;
+                    s = inc ? capa[a] + s_cfg.eq[e][0] : s;
                     // transitions/capacity.py:52-64: bucketize(r, cumsum) = #{j : cum[j] < r} (cum padded with +inf,
                     // clamped to the last capacity where the reference would raise IndexError)
                     int ci = 0;
 #pragma unroll
                     for (int j = 0; j < FRZ_MAX_CAPACITIES; ++j) ci += r_agent[3][a] > d.cum[j] ? 1 : 0;
                     ci = ci > d.K - 1 ? d.K - 1 : ci;
-                    const float new_max = s_caps[ci];
+                    const float new_max = s_cfg.caps[ci];
                     const bool sw = inc && (!(flags & kStochSwitch) || r_agent[4][a] < d.p_switch);
                     const float bonus = s - capa[a];
                     capa[a] = sw ? new_max : capa[a];
@@ -540,7 +537,7 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ aren
         for (int a = 0; a < AMAX; ++a) {
             ok1[a] = 0;
             if (a < A) {
-                ok1[a] = supp[a] > 0.0f ? (lit1 & s_range[a][eqs[a]]) : (mask_t)0;
+                ok1[a] = supp[a] > 0.0f ? (lit1 & (mask_t)s_cfg.range_mask[a][eqs[a]]) : (mask_t)0;
                 packed[(a + 1) >> 2] |= (uint64_t)popc(ok1[a]) << (16 * ((a + 1) & 3));
             }
         }
@@ -845,31 +842,35 @@ constexpr int kNumVariants = 5;
 
 int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
+// FRZ_RNG_PHILOX for the variants with runtime shapes: stage the draws, then run the injected-randomness step
+void stage_philox(WfArgs& a, int& rng, hipStream_t stream) {
+    const WfDev* host = a.host_dev;
+    const int per_env = (3 * host->HW + 5 * host->A + 4) / 5;
+    const int64_t n = (int64_t)host->B * per_env;
+    hipLaunchKernelGGL(wf_philox_fill_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, a.arena,
+                       reinterpret_cast<const WfDev*>(a.arena));
+    a.field_rand = reinterpret_cast<const float*>(a.arena + host->off_rand_field);
+    a.agent_rand = reinterpret_cast<const float*>(a.arena + host->off_rand_agent);
+    rng = FRZ_RNG_INJECTED;
+}
+
 template <int CMAX, int AMAX, bool EXACT>
 void launch_variant(const WfArgs& args, int grid, int rng, int mode, hipStream_t stream) {
     WfArgs a = args;
     const WfDev* dev = reinterpret_cast<const WfDev*>(a.arena);
     if constexpr (!EXACT) {
-        if (mode == kStep && rng == FRZ_RNG_PHILOX) {  // stage the Philox draws, then run the injected-randomness step
-            const WfDev* host = a.host_dev;
-            const int per_env = (3 * host->HW + 5 * host->A + 4) / 5;
-            const int64_t n = (int64_t)host->B * per_env;
-            hipLaunchKernelGGL(wf_philox_fill_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, a.arena, dev);
-            a.field_rand = reinterpret_cast<const float*>(a.arena + host->off_rand_field);
-            a.agent_rand = reinterpret_cast<const float*>(a.arena + host->off_rand_agent);
-            rng = FRZ_RNG_INJECTED;
-        }
+        if (mode == kStep && rng == FRZ_RNG_PHILOX) stage_philox(a, rng, stream);
     }
     if (mode == kRebuild) {
         hipLaunchKernelGGL((wf_step_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kRebuild>), dim3(grid), dim3(kBlock), 0, stream, a.arena,
-                           dev, a.actions, a.field_rand, a.agent_rand, a.host_dev->B);
+                           dev, a.actions, a.field_rand, a.agent_rand, make_launch(a.host_dev));
     } else if (rng == FRZ_RNG_PHILOX) {
         if constexpr (EXACT)
             hipLaunchKernelGGL((wf_step_kernel<CMAX, AMAX, EXACT, FRZ_RNG_PHILOX, kStep>), dim3(grid), dim3(kBlock), 0, stream, a.arena,
-                               dev, a.actions, a.field_rand, a.agent_rand, a.host_dev->B);
+                               dev, a.actions, a.field_rand, a.agent_rand, make_launch(a.host_dev));
     } else {
         hipLaunchKernelGGL((wf_step_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kStep>), dim3(grid), dim3(kBlock), 0, stream, a.arena, dev,
-                           a.actions, a.field_rand, a.agent_rand, a.host_dev->B);
+                           a.actions, a.field_rand, a.agent_rand, make_launch(a.host_dev));
     }
 }
 
@@ -899,7 +900,11 @@ int lane_blocks_per_cu(int variant) {
 }
 
 int launch(frz_wildfire_env* env, const WfArgs& args, int rng, int mode, hipStream_t stream) {
-    if (env->dev.group_width > 0) return launch_group(args, env->dev.group_width, env->grid, rng, mode, stream);
+    if (env->dev.roles) {
+        WfArgs a = args;
+        if (!kVariants[env->variant].exact && mode == kStep && rng == FRZ_RNG_PHILOX) stage_philox(a, rng, stream);
+        return launch_roles(a, env->variant, env->grid, rng, mode, stream);
+    }
     switch (env->variant) {
         case 0: launch_variant<6, 3, true>(args, env->grid, rng, mode, stream); break;   // BASELINE.json cfg1/cfg2 shape
         case 1: launch_variant<6, 2, true>(args, env->grid, rng, mode, stream); break;   // AAAI-2025 openness configs
@@ -957,13 +962,14 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
     p.A = A;
     p.S = cfg->num_equipment_states;
     p.K = cfg->num_capacities;
-    // Kernel choice.  Default: one env per lane (every lane does identical work: least total instructions).  The
-    // group-per-env kernel (8 lanes per env, wildfire_group.hip) trades ~3x more wave-instructions for 8x more
-    // wavefronts; measured on MI355X it is slower at every batch size tried, so it is opt-in:
-    // FRZ_WF_GROUP_KERNEL=1.
-    const char* want_group = std::getenv("FRZ_WF_GROUP_KERNEL");
-    p.group_width = (HW <= 8 && A + 1 <= 8 && want_group && want_group[0] == '1') ? 8 : 0;
-    const int envs_per_chunk = p.group_width ? kBlock / p.group_width : kBlock;
+    // Kernel choice for grids of <= 8 cells: the field/crew wavefront-pair kernel (wildfire_roles.hip, two wavefronts per
+    // 64 envs) or the lane-per-env kernel below; FRZ_WF_KERNEL=lane|roles overrides the default.
+    const char* want = std::getenv("FRZ_WF_KERNEL");
+    const bool small = HW <= 8 && A <= 4;
+    p.roles = small ? 1 : 0;
+    if (want && std::strcmp(want, "lane") == 0) p.roles = 0;
+    if (want && std::strcmp(want, "roles") == 0 && small) p.roles = 1;
+    const int envs_per_chunk = kBlock;
     p.nchunks = (cfg->parallel_envs + envs_per_chunk - 1) / envs_per_chunk;
     p.nch = A + 3;
     p.others_k = 2 + (cfg->observe_other_power ? 1 : 0) + (cfg->observe_other_suppressant ? 1 : 0);
@@ -1102,26 +1108,21 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
     p.total_bytes = off;
 
     // Co-resident persistent grid: every workgroup of a launch must be resident for the single-pass prefix hand-off
-    // (a chunk waits on chunks owned by other workgroups).  One 256-thread workgroup per CU is always resident; the
-    // group kernel asks the runtime and keeps one workgroup per CU of margin (the occupancy query can over-report by
-    // one for SGPR-heavy kernels, MI355X_MICROARCH.md); rounds are balanced.
+    // (a chunk waits on chunks owned by other workgroups).  One workgroup per CU is always resident (256 threads at <= 512
+    // registers, or 512 threads at <= 256); rounds are balanced.
     int device = 0, cus = 256;
     if (hipGetDevice(&device) == hipSuccess) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     }
     int per_cu = 1;
-    if (p.group_width > 0) {
-        per_cu = group_blocks_per_cu(p.group_width) - 1;
-        per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
-    } else {
-        // a second resident workgroup per CU hides latency once there are several rounds; never ask for more than the
-        // register budget of the variant's kernels allows (a non-resident workgroup would stall the hand-off)
-        per_cu = (p.nchunks >= 4 * cus && lane_blocks_per_cu(env->variant) >= 2) ? 2 : 1;
-    }
+    // a second resident workgroup per CU hides latency once there are several rounds; never ask for more than the
+    // register budget of the variant's kernels allows (a non-resident workgroup would stall the hand-off).  The
+    // field/crew kernel already runs two wavefronts per SIMD with one 512-thread workgroup per CU.
+    if (!p.roles) per_cu = (p.nchunks >= 4 * cus && lane_blocks_per_cu(env->variant) >= 2) ? 2 : 1;
     if (const char* forced = std::getenv("FRZ_WF_BLOCKS_PER_CU")) {  // diagnostics only; clamped to what is resident
         const int v = std::atoi(forced);
-        const int resident = p.group_width > 0 ? group_blocks_per_cu(p.group_width) : lane_blocks_per_cu(env->variant);
+        const int resident = p.roles ? 1 : lane_blocks_per_cu(env->variant);
         if (v >= 1 && v <= 8) per_cu = v < resident ? v : (resident < 1 ? 1 : resident);
     }
     const int64_t capacity = (int64_t)cus * per_cu;

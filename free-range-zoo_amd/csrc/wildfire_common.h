@@ -1,4 +1,4 @@
-// wildfire_common.h — declarations shared by the wildfire kernels (lane-per-env and group-per-env) and the host C-ABI.
+// wildfire_common.h — declarations shared by the wildfire kernels (lane-per-env and field/crew pairs) and the host C-ABI.
 #pragma once
 
 #include "frz_device.h"
@@ -40,7 +40,7 @@ struct WfHot {
     int32_t r_fires, r_intensity, r_fuel, r_supp, r_cap, r_equip, r_moves, r_burnouts, r_rewards, r_cum, r_atc, r_seeds, r_mti, n_rows4;
     int32_t q_burnouts, q_putouts, q_etc, n_rows8;
     int32_t u_term, u_trunc, u_frozen, n_rows1;
-    int32_t group_width;  // lanes per env of the group-per-env kernel, 0 = lane-per-env kernel
+    int32_t roles;  // 1: field/crew wavefront-pair kernel (wildfire_roles.hip), 0: lane-per-env kernel
     int32_t pad_[3];
     // byte offsets from the arena base
     int64_t off_rows4, off_rows8, off_rows1, off_obs_self, off_obs_others, off_task_values, off_task_offsets, off_obs_map,
@@ -52,16 +52,30 @@ struct WfHot {
 };
 static_assert(sizeof(WfHot) % 16 == 0, "WfHot is staged with 16-byte copies");
 
-struct WfDev : WfHot {
-    int32_t initial_fuel, initial_equipment;
-    float initial_suppressant, initial_capacity;
+// WfStaged = WfHot + the tables a lane indexes by its own state (they stay in LDS): one 16-byte load per thread stages it.
+struct WfStaged : WfHot {
     float caps[FRZ_MAX_CAPACITIES];
     float eq[FRZ_MAX_EQUIPMENT_STATES][4];  // (capacity, power, range, -)
     uint64_t range_mask[FRZ_MAX_AGENTS][FRZ_MAX_EQUIPMENT_STATES];  // cells agent a reaches at equipment state s
+};
+static_assert(sizeof(WfStaged) % 16 == 0 && sizeof(WfStaged) / 16 <= kBlock, "WfStaged is staged with one 16-byte copy per thread");
+
+struct WfDev : WfStaged {
+    int32_t initial_fuel, initial_equipment;
+    float initial_suppressant, initial_capacity;
     int32_t fire_types[FRZ_MAX_CELLS], lit[FRZ_MAX_CELLS];
 };
 static_assert(sizeof(WfDev) <= 8192, "configuration block too large");
 constexpr int64_t kDevBlockBytes = 8192;
+
+// What a step kernel needs before the configuration block is staged (passed by value: kernel arguments are there at
+// wave start, so the state loads, the byte rows and the epoch/totals words are all in flight from the first instruction)
+struct WfLaunch {
+    int32_t batch, pad_;
+    int64_t off_rows1, off_epoch, off_totals;
+};
+
+inline WfLaunch make_launch(const struct WfDev* host);
 
 struct WfArgs {
     char* arena;
@@ -71,11 +85,17 @@ struct WfArgs {
     const WfDev* host_dev;  // host copy of the configuration block (launch-side decisions)
 };
 
-// Stage the hot configuration through LDS and return it by value: the fields a kernel uses end up in registers.
-__device__ __forceinline__ WfHot stage_hot(WfHot& lds, const WfDev* dev) {
-    const uint4* src = reinterpret_cast<const uint4*>(static_cast<const WfHot*>(dev));
-    uint4* dst = reinterpret_cast<uint4*>(&lds);
-    for (int i = threadIdx.x; i < (int)(sizeof(WfHot) / 16); i += kBlock) dst[i] = src[i];
+inline WfLaunch make_launch(const WfDev* host) { return WfLaunch{host->B, 0, host->off_rows1, host->off_epoch, host->off_totals}; }
+
+// Staging the configuration: the 16-byte piece is requested by the kernel's FIRST vector-memory instruction (before the
+// state loads, so that waiting for it does not wait for them: the counter retires in issue order), parked in LDS, and the
+// hot scalars come back by value: the fields a kernel uses end up in registers.
+__device__ __forceinline__ uint4 stage_request(const WfDev* dev) {
+    const uint4* src = reinterpret_cast<const uint4*>(static_cast<const WfStaged*>(dev));
+    return threadIdx.x < sizeof(WfStaged) / 16 ? src[threadIdx.x] : make_uint4(0, 0, 0, 0);
+}
+__device__ __forceinline__ WfHot stage_commit(WfStaged& lds, const uint4& piece) {
+    if (threadIdx.x < sizeof(WfStaged) / 16) reinterpret_cast<uint4*>(&lds)[threadIdx.x] = piece;
     __syncthreads();
     return lds;
 }
@@ -101,8 +121,7 @@ __device__ __forceinline__ int popc(M m) {
 
 
 
-// group-per-env kernels (wildfire_group.hip)
-int launch_group(const WfArgs& args, int G, int grid, int rng, int mode, hipStream_t stream);
-int group_blocks_per_cu(int G);
+// field/crew wavefront-pair kernels for grids of <= 8 cells (wildfire_roles.hip); variant as in wildfire.hip's table
+int launch_roles(const WfArgs& args, int variant, int grid, int rng, int mode, hipStream_t stream);
 
 }  // namespace frz_wf

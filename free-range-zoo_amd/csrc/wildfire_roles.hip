@@ -1,0 +1,881 @@
+// wildfire_roles.hip — the fused wildfire step for small grids (<= 8 cells) with TWO wavefronts per 64 environments.
+//
+// Why: at batch 65 536 the lane-per-env kernel (wildfire.hip) puts ONE wavefront on each SIMD of the chip, and a lone
+// wavefront issues a vector instruction every ~4 cycles where the SIMD could take one every 2 (MI355X_MICROARCH.md,
+// 'vector-instruction ISSUE cost'); its stores also block its own arithmetic while they issue.  Here a 512-thread
+// workgroup owns a 256-env chunk and splits the step by ROLE, not by lane: wavefronts 0-3 ("field") run the fire
+// transitions, the cell rows and the task list of the chunk's envs, wavefronts 4-7 ("crew") run the action decode, the
+// agent transitions, rewards/bookkeeping, the open-action scan and the action lists of the SAME envs (lane i of wave w
+// and of wave w + 4 hold the same env).  Each SIMD then carries one field and one crew wavefront whose instruction
+// streams interleave, and the same total work finishes in roughly half the cycles.  The roles exchange four small
+// per-env words through LDS: applied power per cell (crew -> field), lit mask and burned/put-out/dead bits
+// (field -> crew), the env's offset inside the chunk's task segment (crew -> field).
+//
+// Same arena layout, same hand-off protocol, same results as wildfire.hip (the parity tests run both).
+#include "frz_device.h"
+
+#include "../../include/frz.h"
+
+#include <type_traits>
+
+#include "wildfire_common.h"
+
+namespace frz_wf {
+
+namespace {
+
+constexpr int kRoleBlock = 2 * kBlock;  // 4 field + 4 crew wavefronts per 256-env chunk
+
+// Diagnostic build only (-DFRZ_WF_STAMPS, tools/stamps.py): the first thread of each role of workgroup 0 records the
+// shader clock at phase boundaries into a buffer nothing else reads.  No stamp executes in the production library.
+#ifdef FRZ_WF_STAMPS
+#define FRZ_RSTAMP(i)                                                                                                       \
+    do {                                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                                  \
+        if (blockIdx.x == 0 && slot == 0 && MODE == kStep)                                                                  \
+            reinterpret_cast<unsigned long long*>(arena + dev->off_rand_agent)[(crew ? 16 : 0) + (i)] = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    } while (0)
+#else
+#define FRZ_RSTAMP(i) \
+    do {              \
+    } while (0)
+#endif
+
+template <int CMAX, int AMAX, bool EXACT, int RNG, int MODE>
+__global__ void __launch_bounds__(kRoleBlock) wf_roles_kernel(char* __restrict__ arena, const WfDev* __restrict__ dev,
+                                                               const int32_t* __restrict__ actions, const float* __restrict__ field_rand,
+                                                               const float* __restrict__ agent_rand, const WfLaunch launch) {
+    const int32_t batch = launch.batch;
+    static_assert(CMAX <= 8, "cell masks travel between the roles as bytes");
+    using mask_t = uint32_t;
+    constexpr int PW = (AMAX + 1 + 3) / 4;                                // packed scan words (four 16-bit channels each)
+    constexpr int NCHP = AMAX + 3 <= 8 ? 8 : (AMAX + 3 <= 16 ? 16 : 32);  // scan channels padded to a power of two
+    constexpr bool kPhilox = RNG == FRZ_RNG_PHILOX && MODE == kStep;
+    constexpr bool kInjected = RNG == FRZ_RNG_INJECTED && MODE == kStep;
+    static_assert(EXACT || !kPhilox, "runtime shapes stage their draws (wf_philox_fill_kernel)");
+
+    __shared__ uint64_t s_wave_scan[frz::kWaves][PW];
+    __shared__ uint32_t s_wave_live[frz::kWaves][2];
+    __shared__ uint32_t s_reduce[frz::kWaves][32];
+    __shared__ uint32_t s_prefix[32];
+    __shared__ WfStaged s_cfg;  // hot scalars (copied to registers below) + the per-lane lookup tables (range sets, equipment, capacities)
+    __shared__ float x_power[CMAX][kBlock];  // crew -> field: fire-fighting power applied to each cell
+    __shared__ uint32_t x_lit[kBlock];       // field -> crew: lit cells after the transitions
+    __shared__ uint32_t x_fate[kBlock];      // field -> crew: burned | put_out << 8 | dead << 16
+    __shared__ uint32_t x_task_off[kBlock];  // crew -> field: tasks of the preceding envs of the same wavefront
+
+    const int tid = threadIdx.x;
+    const uint4 cfg_piece = stage_request(dev);  // first vector-memory instruction of the kernel
+    const bool crew = __builtin_amdgcn_readfirstlane(tid >> 8) != 0;  // wave-uniform role
+    const int slot = tid & (kBlock - 1);                                // env slot inside the chunk; the role's thread index
+    const int lane = frz::lane_id(), wave = (tid >> 6) & 3;
+    const int64_t B = batch;
+    const uint32_t Bu = (uint32_t)batch;
+    const int nchunks = (int)((B + kBlock - 1) / kBlock);
+    const int HW = EXACT ? CMAX : dev->HW, A = EXACT ? AMAX : dev->A;
+    // rows of the [rows][B] block: a fixed function of (HW, A) (frz_wildfire_create lays them out in this order)
+    const int r_fires = 0, r_intensity = HW, r_fuel = 2 * HW, r_supp = 3 * HW, r_cap = r_supp + A, r_equip = r_cap + A;
+    const int r_moves = r_equip + A, r_burnouts = r_moves + 1, r_rewards = r_moves + 2, r_cum = r_rewards + A, r_atc = r_cum + A;
+    const int r_seeds = r_atc + A;
+    int32_t* const rows = reinterpret_cast<int32_t*>(arena + kDevBlockBytes);
+    float* const rowsf = reinterpret_cast<float*>(arena + kDevBlockBytes);
+    uint8_t* const rows1 = reinterpret_cast<uint8_t*>(arena + launch.off_rows1);
+    const uint32_t u_term = 0, u_trunc = (uint32_t)A, u_frozen = 2u * (uint32_t)A;
+
+    // plain (cacheable, wave-uniform) loads: the words were last written by the previous launch, and this launch only
+    // rewrites the epoch after every workgroup has read it.  Both totals slots are fetched beside the epoch (no dependent
+    // load) and the previous launch's slot is selected afterwards.
+    uint32_t* const epoch_ptr = reinterpret_cast<uint32_t*>(arena + launch.off_epoch);
+    uint32_t* const totals = reinterpret_cast<uint32_t*>(arena + launch.off_totals);
+    const uint32_t epoch = *epoch_ptr;
+    uint32_t totals0[AMAX + 3], totals1[AMAX + 3];
+#pragma unroll
+    for (int i = 0; i < AMAX + 3; ++i) totals0[i] = totals[i], totals1[i] = totals[kTotalsStride + i];
+
+    // ---- per-role registers of one env
+    struct Cells {  // both roles read the fires (the crew derives the open task set from them)
+        int f[CMAX];
+    };
+    struct FieldRegs {
+        int in[CMAX], fu[CMAX], nm;
+        uint32_t seed;
+    };
+    struct CrewRegs {
+        int eqs[AMAX], act_idx[AMAX], act_id[AMAX], nm, nb;
+        float supp[AMAX], capa[AMAX], cum[AMAX];
+        uint32_t seed, term, trunc;
+    };
+    struct FieldDraws {
+        float r[3][CMAX];
+    };
+    struct CrewDraws {
+        float r[5][AMAX];
+    };
+    struct Nothing {};
+    using FDraws = std::conditional_t<kInjected, FieldDraws, Nothing>;
+    using CDraws = std::conditional_t<kInjected, CrewDraws, Nothing>;
+
+    auto env_index = [&](int chunk) {
+        const int64_t b = (int64_t)chunk * kBlock + slot;
+        return (uint32_t)(b < B ? b : B - 1);  // lanes past the end shadow the last env
+    };
+    auto settle = [&](int chunk) {
+        // A shadow lane reads rows its env's owner stores later in the iteration: in the one chunk that has shadow
+        // lanes the loads complete before the workgroup barriers that precede those stores.
+        if (chunk == nchunks - 1 && (B % kBlock) != 0) __builtin_amdgcn_s_waitcnt(0);
+    };
+    auto load_cells = [&](int chunk) {
+        Cells e;
+        const uint32_t bl = env_index(chunk);
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) e.f[c] = c < HW ? at32(rows, (uint32_t)(r_fires + c) * Bu + bl) : 0;
+        return e;
+    };
+    auto load_field = [&](int chunk, FDraws& draws) {
+        FieldRegs e;
+        const uint32_t bl = env_index(chunk);
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) {
+            e.in[c] = c < HW ? at32(rows, (uint32_t)(r_intensity + c) * Bu + bl) : 0;
+            e.fu[c] = c < HW ? at32(rows, (uint32_t)(r_fuel + c) * Bu + bl) : 0;
+        }
+        e.nm = 0;
+        e.seed = 0;
+        if (MODE == kStep) {
+            e.nm = at32(rows, (uint32_t)r_moves * Bu + bl);
+            if (kPhilox) e.seed = (uint32_t)at32(rows, (uint32_t)r_seeds * Bu + bl);
+        }
+        if constexpr (kInjected) {
+#pragma unroll
+            for (int ev = 0; ev < 3; ++ev)
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) draws.r[ev][c] = c < HW ? field_rand[((int64_t)ev * B + bl) * HW + c] : 1.0f;
+        }
+        settle(chunk);
+        return e;
+    };
+    auto load_crew = [&](int chunk, CDraws& draws) {
+        CrewRegs e;
+        const uint32_t bl = env_index(chunk);
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a) {
+            e.supp[a] = e.capa[a] = e.cum[a] = 0.0f;
+            e.eqs[a] = e.act_idx[a] = 0;
+            e.act_id[a] = -1;
+            if (a < A) {
+                e.supp[a] = at32(rowsf, (uint32_t)(r_supp + a) * Bu + bl);
+                e.capa[a] = at32(rowsf, (uint32_t)(r_cap + a) * Bu + bl);
+                e.eqs[a] = at32(rows, (uint32_t)(r_equip + a) * Bu + bl);
+                if (MODE == kStep) {
+                    const int2 v = reinterpret_cast<const int2*>(actions)[a * B + bl];
+                    e.act_idx[a] = v.x;
+                    e.act_id[a] = v.y;
+                    e.cum[a] = at32(rowsf, (uint32_t)(r_cum + a) * Bu + bl);
+                }
+            }
+        }
+        // agents share one termination / truncation value (wildfire.py:579, utils/env.py:231-233): row 0 is read,
+        // all A rows are written
+        e.term = at32(rows1, u_term * Bu + bl);
+        e.trunc = at32(rows1, u_trunc * Bu + bl);
+        e.nm = e.nb = 0;
+        e.seed = 0;
+        if (MODE == kStep) {
+            e.nm = at32(rows, (uint32_t)r_moves * Bu + bl);
+            e.nb = at32(rows, (uint32_t)r_burnouts * Bu + bl);
+            if (kPhilox) e.seed = (uint32_t)at32(rows, (uint32_t)r_seeds * Bu + bl);
+        }
+        if constexpr (kInjected) {
+#pragma unroll
+            for (int ev = 0; ev < 5; ++ev)
+#pragma unroll
+                for (int a = 0; a < AMAX; ++a) draws.r[ev][a] = a < A ? agent_rand[((int64_t)ev * B + bl) * A + a] : 1.0f;
+        }
+        settle(chunk);
+        return e;
+    };
+
+    FRZ_RSTAMP(0);
+    // first chunk's loads: in flight while the configuration is staged
+    FDraws fdraws;
+    CDraws cdraws;
+    Cells cells = load_cells(blockIdx.x);
+    FieldRegs fld;
+    CrewRegs crw;
+    if (!crew) fld = load_field(blockIdx.x, fdraws);
+    else crw = load_crew(blockIdx.x, cdraws);
+
+    const WfHot d = stage_commit(s_cfg, cfg_piece);  // configuration block at arena offset 0; never written by a kernel
+    FRZ_RSTAMP(1);
+    const int W = d.W;
+    const int nch = d.nch;  // A + 3
+    const int ch_nt = A + 1, ch_ntr = A + 2;
+    const uint32_t flags = d.flags;
+
+    const uint32_t tag = epoch + 1u;  // never 0 on a zero-filled arena
+    uint32_t* const cur_totals = totals + (epoch & 1u) * kTotalsStride;
+    uint32_t prev[AMAX + 3];
+#pragma unroll
+    for (int i = 0; i < AMAX + 3; ++i) prev[i] = (epoch & 1u) ? totals0[i] : totals1[i];
+
+    int64_t* const rows8 = reinterpret_cast<int64_t*>(arena + d.off_rows8);
+    const uint32_t q_burnouts = 0, q_putouts = 1, q_etc = 2;
+
+    // utils/env.py:211-213 — every per-agent step() is a no-op once ALL envs are terminated or ALL are truncated.
+    if (MODE == kStep) {
+        uint32_t nt = prev[0], ntr = prev[0];
+#pragma unroll
+        for (int i = 0; i < AMAX + 3; ++i) {
+            nt = i == ch_nt ? prev[i] : nt;
+            ntr = i == ch_ntr ? prev[i] : ntr;
+        }
+        if (nt == 0u || ntr == 0u) {
+            // The parallel adapter (utils/conversions.py:87-90) then adds the stale aec rewards once per agent call.
+            if (!crew)
+                for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+                    const int64_t b = (int64_t)chunk * kBlock + slot;
+                    if (b < B && !at32(rows1, u_frozen * Bu + (uint32_t)b)) {
+                        for (int a = 0; a < A; ++a) {
+                            const float r = at32(rowsf, (uint32_t)(r_rewards + a) * Bu + (uint32_t)b);
+                            float acc = 0.0f;
+                            for (int j = 0; j < A; ++j) acc = acc + r;
+                            at32(rowsf, (uint32_t)(r_rewards + a) * Bu + (uint32_t)b) = acc;
+                        }
+                        at32(rows1, u_frozen * Bu + (uint32_t)b) = 1;
+                    }
+                }
+            return;
+        }
+    }
+
+    FRZ_RSTAMP(2);
+    float* const obs_self = reinterpret_cast<float*>(arena + d.off_obs_self);
+    float* const obs_others = reinterpret_cast<float*>(arena + d.off_obs_others);
+    uint64_t* const agg = reinterpret_cast<uint64_t*>(arena + d.off_agg);
+    uint64_t* const prefix = reinterpret_cast<uint64_t*>(arena + d.off_prefix);
+
+    uint32_t* const error_word = reinterpret_cast<uint32_t*>(arena + d.off_error);
+    // tasks of the envs of this chunk that precede this lane's env (after barrier 3) + the chunk's offset (after barrier 5)
+    auto task_offset = [&]() {
+        uint32_t before = x_task_off[slot];
+#pragma unroll
+        for (int j = 0; j < frz::kWaves; ++j) before += j < wave ? (uint32_t)(s_wave_scan[j][0] & 0xFFFFull) : 0u;
+        return (int64_t)s_prefix[0] + (int64_t)before;
+    };
+
+    // The two roles run the same chunk sequence and meet at five workgroup barriers per chunk; each role's loop is its own
+    // region of the program so that its registers are allocated for that role alone.
+    if (!crew) {
+        // ============================================================================================ FIELD ROLE
+        for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+            const int64_t b = (int64_t)chunk * kBlock + slot;
+            const bool active = b < B;
+            const uint32_t bl = (uint32_t)(active ? b : B - 1);
+            const int next_chunk = chunk + (int)gridDim.x;
+            int f[CMAX], in[CMAX], fu[CMAX];
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) f[c] = cells.f[c], in[c] = fld.in[c], fu[c] = fld.fu[c];
+
+            // ---- phase 1: the step's field draws
+            float r_field[3][CMAX];
+            if (MODE == kStep) {
+                if constexpr (kInjected) {
+#pragma unroll
+                    for (int e = 0; e < 3; ++e)
+#pragma unroll
+                        for (int c = 0; c < CMAX; ++c) r_field[e][c] = fdraws.r[e][c];
+                } else if constexpr (kPhilox) {
+                    // FRZ_RNG_PHILOX (include/frz.h): draw u = 24-bit field u % 5 of block (u / 5, step, 0, 0); field event e
+                    // of cell c is draw e * HW + c
+                    constexpr int NBF = (3 * CMAX + 4) / 5;
+                    float uni[NBF * 5];
+#pragma unroll
+                    for (int j = 0; j < NBF; ++j) {
+                        const frz::Philox4 w = frz::philox4x32_10((uint32_t)j, (uint32_t)fld.nm, 0u, 0u, fld.seed, 0x46525A00u);
+                        uni[5 * j] = frz::philox_unit24<0>(w);
+                        uni[5 * j + 1] = frz::philox_unit24<1>(w);
+                        uni[5 * j + 2] = frz::philox_unit24<2>(w);
+                        uni[5 * j + 3] = frz::philox_unit24<3>(w);
+                        uni[5 * j + 4] = frz::philox_unit24<4>(w);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 3; ++e)
+#pragma unroll
+                        for (int c = 0; c < CMAX; ++c) r_field[e][c] = uni[e * CMAX + c];
+                }
+            }
+            FRZ_RSTAMP(3);
+            __syncthreads();  // (1) applied power visible
+            FRZ_RSTAMP(4);
+
+            // ---- phase 2: fire increase / decrease, spread, dead test
+            mask_t burned = 0, put_out = 0, lit1 = 0;
+            bool dead = false;
+            if (MODE == kStep) {
+                float ap[CMAX];
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) ap[c] = c < HW ? x_power[c][slot] : 0.0f;
+                mask_t lit2 = 0;
+                const int almost_state = d.num_fire_states - 2, burnout_state = d.num_fire_states - 1;
+                const float p_unmet = (flags & kStochIncrease) ? d.p_increase : 1.0f;
+                const float p_almost = (flags & kStochBurnouts) ? d.p_burnout : d.p_increase;  // fire_increase.py:77-80
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) {
+                    if (c < HW) {
+                        {  // transitions/fire_increase.py:61-91
+                            const int required = f[c] >= 0 ? f[c] : 0;
+                            const float diff = (float)required - ap[c];
+                            const bool lit = f[c] > 0 && in[c] > 0;
+                            const bool unmet = diff > 0.0f && lit;
+                            const bool almost = unmet && in[c] == almost_state;
+                            float prob = unmet ? (almost ? p_almost : p_unmet) : 0.0f;
+                            prob = clamp01(prob);
+                            const bool inc = r_field[0][c] < prob;
+                            in[c] += inc ? 1 : 0;
+                            const bool bo = inc && in[c] >= burnout_state;
+                            f[c] = bo ? -f[c] : f[c];
+                            fu[c] = bo ? (fu[c] - 1 < 0 ? 0 : fu[c] - 1) : fu[c];
+                            burned |= (mask_t)bo << c;
+                        }
+                        {  // transitions/fire_decrease.py:56-77: p = p_dec + ((-1 * diff) * bonus), each op rounded
+                            const int required = f[c] >= 0 ? f[c] : 0;
+                            const float diff = (float)required - ap[c];
+                            const bool lit = f[c] > 0 && in[c] > 0;
+                            const bool met = diff <= 0.0f && lit;
+                            const float stoch_p = __fadd_rn(d.p_decrease, __fmul_rn(__fmul_rn(-1.0f, diff), d.decrease_bonus));
+                            float prob = met ? ((flags & kStochDecrease) ? stoch_p : 1.0f) : 0.0f;
+                            prob = clamp01(prob);
+                            const bool dec = r_field[1][c] < prob;
+                            in[c] -= dec ? 1 : 0;
+                            const bool po = dec && in[c] <= 0;
+                            f[c] = po ? -f[c] : f[c];
+                            fu[c] = po ? fu[c] - 1 : fu[c];  // unclamped, :75
+                            put_out |= (mask_t)po << c;
+                        }
+                        lit2 |= (mask_t)(f[c] > 0 && in[c] > 0) << c;
+                    }
+                }
+                // fire spread stencil (transitions/fire_spreads.py:44-57)
+                int fuel_sum = 0;
+                bool any_fire = false;
+                const mask_t from_n = (lit2 << W) & (mask_t)d.has_n, from_s = (lit2 >> W) & (mask_t)d.has_s;
+                const mask_t from_w = (lit2 << 1) & (mask_t)d.has_w, from_e = (lit2 >> 1) & (mask_t)d.has_e;
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) {
+                    if (c < HW) {
+                        float prob = 0.0f;  // conv2d accumulation order: N, W, E, S
+                        prob = __fadd_rn(prob, ((from_n >> c) & 1) ? d.spread_n : 0.0f);
+                        prob = __fadd_rn(prob, ((from_w >> c) & 1) ? d.spread_w : 0.0f);
+                        prob = __fadd_rn(prob, ((from_e >> c) & 1) ? d.spread_e : 0.0f);
+                        prob = __fadd_rn(prob, ((from_s >> c) & 1) ? d.spread_s : 0.0f);
+                        bool unlit = f[c] < 0 && in[c] == 0;
+                        unlit = unlit && (!(flags & kUseFuel) || fu[c] > 0);
+                        prob = unlit ? __fadd_rn(prob, d.random_ignition) : 0.0f;
+                        const bool spread = r_field[2][c] < prob;
+                        f[c] = spread ? -f[c] : f[c];
+                        in[c] = spread ? d.ignition[c] : in[c];
+                        fuel_sum += fu[c];
+                        any_fire = any_fire || f[c] > 0;
+                    }
+                }
+                // termination test (wildfire.py:560-570): no lit fire left (and no fuel when fuel is tracked)
+                dead = !any_fire;
+                if (flags & kUseFuel) dead = dead && fuel_sum <= 0;
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) f[c] = dead ? 0 : f[c];  // :570
+            }
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) lit1 |= (mask_t)(f[c] > 0) << c;
+            lit1 = active ? lit1 : (mask_t)0;
+            x_lit[slot] = lit1;
+            x_fate[slot] = burned | (put_out << 8) | ((uint32_t)dead << 16);
+            FRZ_RSTAMP(5);
+            __syncthreads();  // (2) lit mask and fates visible to the crew
+            FRZ_RSTAMP(6);
+
+            // ---- phase 3: cell rows (the crew scans meanwhile)
+            if (MODE == kStep) {
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c)
+                    if (c < HW) {
+                        at32(rows, (uint32_t)(r_fires + c) * Bu + bl) = f[c];
+                        at32(rows, (uint32_t)(r_intensity + c) * Bu + bl) = in[c];
+                        at32(rows, (uint32_t)(r_fuel + c) * Bu + bl) = fu[c];
+                    }
+            }
+            FRZ_RSTAMP(7);
+            __syncthreads();  // (3) wavefront sums visible
+
+            // ---- phase 4: next chunk's loads
+            Cells next_cells = cells;
+            FieldRegs next_fld = fld;
+            FDraws next_fdraws = fdraws;
+            if (next_chunk < nchunks) {
+                next_cells = load_cells(next_chunk);
+                next_fld = load_field(next_chunk, next_fdraws);
+            }
+            FRZ_RSTAMP(8);
+            __syncthreads();  // (4)
+            __syncthreads();  // (5) chunk prefix visible
+            FRZ_RSTAMP(9);
+
+            // ---- phase 6: task list (wildfire.py:586-717)
+            if (active) {
+                const int64_t off_f = task_offset();
+                int64_t* const task_values = reinterpret_cast<int64_t*>(arena + d.off_task_values);
+                int64_t* const task_offsets = reinterpret_cast<int64_t*>(arena + d.off_task_offsets);
+                int64_t* const obs_map = reinterpret_cast<int64_t*>(arena + d.off_obs_map);
+                task_offsets[b] = off_f;
+                if (b == B - 1) task_offsets[B] = off_f + popc(lit1);
+                // row of cell c's task inside the env's segment = number of lit cells below it
+                int64_t* const trow = task_values + off_f * 4;
+                int64_t* const omap = obs_map + off_f;
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) {
+                    const int rk = popc(lit1 & (mask_t)(((mask_t)1 << c) - 1));
+                    if ((lit1 >> c) & 1) {
+                        const int yx = d.cell_yx[c];
+                        longlong2* const row = reinterpret_cast<longlong2*>(trow + rk * 4);
+                        row[0] = make_longlong2(yx >> 16, yx & 0xFFFF);
+                        row[1] = make_longlong2(f[c], in[c]);
+                        omap[rk] = rk;
+                    }
+                }
+            }
+            FRZ_RSTAMP(10);
+            // The workgroup owning the last chunk finished its look-back only after every other chunk published, i.e.
+            // after every workgroup of this launch read the epoch: it can advance it for the next launch.
+            if (chunk == nchunks - 1 && tid == 0) __hip_atomic_store(epoch_ptr, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            cells = next_cells;
+            fld = next_fld;
+            fdraws = next_fdraws;
+        }
+    } else {
+        // ============================================================================================= CREW ROLE
+        for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+            const int64_t b = (int64_t)chunk * kBlock + slot;
+            const bool active = b < B;
+            const uint32_t bl = (uint32_t)(active ? b : B - 1);
+            const int next_chunk = chunk + (int)gridDim.x;
+            uint32_t err = 0;
+            float supp[AMAX], capa[AMAX], rew[AMAX];
+            int eqs[AMAX], hit[AMAX];
+            bool users[AMAX], refill[AMAX];
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a) {
+                supp[a] = crw.supp[a], capa[a] = crw.capa[a], eqs[a] = crw.eqs[a];
+                rew[a] = 0.0f, hit[a] = -1, users[a] = false, refill[a] = false;
+            }
+            const bool term0 = crw.term != 0, trunc0 = crw.trunc != 0;
+
+            // ---- phase 1: action decode (wildfire.py:427-483) -> applied power per cell
+            // The action mapping of the previous rebuild is a pure function of the state it was built from, which is the
+            // state just loaded: attackable set of agent a = lit fires within its (equipment-adjusted) range, non-empty
+            // only while it has suppressant (wildfire.py:604-623).
+            if (MODE == kStep) {
+                mask_t lit0 = 0;
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) lit0 |= (mask_t)(cells.f[c] > 0) << c;
+                float ap[CMAX];
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) ap[c] = 0.0f;
+                const bool show_bad = (flags & kShowBad) != 0;
+#pragma unroll
+                for (int a = 0; a < AMAX; ++a) {
+                    if (a < A) {
+                        const mask_t ok = supp[a] > 0.0f ? (lit0 & (mask_t)s_cfg.range_mask[a][eqs[a]]) : (mask_t)0;
+                        refill[a] = crw.act_id[a] == -1;
+                        // quirk wildfire.py:434-435: an agent with no attackable task in ANY env of the batch is skipped
+                        const bool skipped = prev[1 + a] == 0u;
+                        const bool fight = !refill[a] && !skipped;
+                        const mask_t sel = show_bad ? lit0 : ok;
+                        const bool valid = crw.act_idx[a] >= 0 && crw.act_idx[a] < popc(sel);
+                        int target = 0, seen = 0;
+#pragma unroll
+                        for (int c = 0; c < CMAX; ++c) {
+                            const int bit = (int)((sel >> c) & 1);
+                            target = (bit && seen == crw.act_idx[a]) ? c : target;
+                            seen += bit;
+                        }
+                        const bool attackable = ((ok >> target) & 1) != 0;
+                        const bool good = fight && valid && (!show_bad || attackable);
+                        if (fight && !valid && active) err |= FRZ_ERR_BAD_ACTION_INDEX;
+                        const float power = d.power[a] + s_cfg.eq[eqs[a]][1];
+#pragma unroll
+                        for (int c = 0; c < CMAX; ++c) ap[c] = ap[c] + ((good && target == c) ? power : 0.0f);  // agent order
+                        users[a] = good;
+                        hit[a] = good ? target : -1;
+                        rew[a] = (fight && !good) ? d.bad_attack_penalty : 0.0f;  // assignment, :477
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c)
+                    if (c < HW) x_power[c][slot] = ap[c];
+            }
+            FRZ_RSTAMP(3);
+            __syncthreads();  // (1) applied power visible to the field role
+            FRZ_RSTAMP(4);
+
+            // ---- phase 2: agent draws, agent transitions, agent rows, agent observations
+            if (MODE == kStep) {
+                float r_agent[5][AMAX];
+                if constexpr (kInjected) {
+#pragma unroll
+                    for (int e = 0; e < 5; ++e)
+#pragma unroll
+                        for (int a = 0; a < AMAX; ++a) r_agent[e][a] = cdraws.r[e][a];
+                } else if constexpr (kPhilox) {
+                    // agent event e of agent a is draw 3 * HW + e * A + a; events 1..4 are only drawn when something reads them
+                    constexpr int U = 3 * CMAX + 5 * AMAX, J0 = (3 * CMAX) / 5, NB = (U + 4) / 5, NB_EVENT0 = (3 * CMAX + AMAX + 4) / 5;
+                    const bool need_late = (flags & (kStochRepair | kStochDegrade | kCritical | kStochRefill | kStochSwitch)) != 0 || d.K > 1;
+                    const int nb_needed = need_late ? NB : NB_EVENT0;
+                    float uni[(NB - J0) * 5];
+#pragma unroll
+                    for (int j = J0; j < NB; ++j) {
+                        const int o = 5 * (j - J0);
+                        uni[o] = uni[o + 1] = uni[o + 2] = uni[o + 3] = uni[o + 4] = 0.0f;
+                        if (j < nb_needed) {
+                            const frz::Philox4 w = frz::philox4x32_10((uint32_t)j, (uint32_t)crw.nm, 0u, 0u, crw.seed, 0x46525A00u);
+                            uni[o] = frz::philox_unit24<0>(w);
+                            uni[o + 1] = frz::philox_unit24<1>(w);
+                            uni[o + 2] = frz::philox_unit24<2>(w);
+                            uni[o + 3] = frz::philox_unit24<3>(w);
+                            uni[o + 4] = frz::philox_unit24<4>(w);
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 5; ++e)
+#pragma unroll
+                        for (int a = 0; a < AMAX; ++a) r_agent[e][a] = uni[3 * CMAX + e * AMAX + a - 5 * J0];
+                }
+#pragma unroll
+                for (int a = 0; a < AMAX; ++a) {
+                    if (a < A) {
+                        // transitions/suppressant_decrease.py:56-61
+                        const bool dec = users[a] && (!(flags & kStochSuppDecrease) || r_agent[0][a] < d.p_supp_decrease);
+                        float s = dec ? supp[a] - 1.0f : supp[a];
+                        s = s < 0.0f ? 0.0f : s;
+                        // transitions/equipment.py:51-75 (masks from the value before any write)
+                        const int e0 = eqs[a], top = d.S - 1;
+                        const bool pristine = e0 == top, damaged = e0 == 0, inter = !pristine && !damaged;
+                        const float r1 = r_agent[1][a];
+                        const bool repairs = (flags & kStochRepair) ? (damaged && r1 < d.p_repair) : damaged;
+                        const bool crit = (flags & kCritical) && pristine && r1 < d.p_critical;
+                        bool degr = (flags & kStochDegrade) ? ((pristine || inter) && r1 < d.p_degrade) : (inter || pristine);
+                        degr = degr && !crit;
+                        int e = repairs ? top : e0;
+                        e = crit ? 0 : e;
+                        e = degr ? e - 1 : e;
+                        // transitions/suppressant_refill.py:63-70 (bonus from the NEW equipment state)
+                        const bool inc = refill[a] && (!(flags & kStochRefill) || r_agent[2][a] < d.p_refill);
+                        s = inc ? capa[a] + s_cfg.eq[e][0] : s;
+                        // transitions/capacity.py:52-64: bucketize(r, cumsum) = #{j : cum[j] < r} (cum padded with +inf,
+                        // clamped to the last capacity where the reference would raise IndexError)
+                        int ci = 0;
+#pragma unroll
+                        for (int j = 0; j < FRZ_MAX_CAPACITIES; ++j) ci += r_agent[3][a] > d.cum[j] ? 1 : 0;
+                        ci = ci > d.K - 1 ? d.K - 1 : ci;
+                        const float new_max = s_cfg.caps[ci];
+                        const bool sw = inc && (!(flags & kStochSwitch) || r_agent[4][a] < d.p_switch);
+                        const float bonus = s - capa[a];
+                        capa[a] = sw ? new_max : capa[a];
+                        s = sw ? new_max + bonus : s;
+                        supp[a] = s;
+                        eqs[a] = e;
+                        at32(rowsf, (uint32_t)(r_supp + a) * Bu + bl) = supp[a];
+                        at32(rowsf, (uint32_t)(r_cap + a) * Bu + bl) = capa[a];
+                        at32(rows, (uint32_t)(r_equip + a) * Bu + bl) = eqs[a];
+                    }
+                }
+            }
+            {  // agent observations (wildfire.py:677-681, 704-716)
+                const int k = d.others_k, width = (A - 1) * k;  // k = 2 + power column + suppressant column
+                const bool op = (flags & kObsPower) != 0;
+#pragma unroll
+                for (int a = 0; a < AMAX; ++a)
+                    if (a < A) {
+                        reinterpret_cast<float4*>(obs_self)[a * B + bl] = make_float4((float)d.ay[a], (float)d.ax[a], d.power[a], supp[a]);
+                        float* const others = obs_others + (a * B + bl) * (int64_t)width;
+                        int j = 0;  // record index: the other agents in agent order
+#pragma unroll
+                        for (int o = 0; o < AMAX; ++o)
+                            if (o < A && o != a) {
+                                float* const rec = others + j * k;
+                                const float y = (float)d.ay[o], x = (float)d.ax[o];
+                                if (k == 4) {
+                                    *reinterpret_cast<float4*>(rec) = make_float4(y, x, d.power[o], supp[o]);
+                                } else if (k == 3) {
+                                    rec[0] = y;
+                                    rec[1] = x;
+                                    rec[2] = op ? d.power[o] : supp[o];
+                                } else {
+                                    *reinterpret_cast<float2*>(rec) = make_float2(y, x);
+                                }
+                                ++j;
+                            }
+                    }
+            }
+            FRZ_RSTAMP(5);
+            __syncthreads();  // (2) lit mask and fates visible
+            FRZ_RSTAMP(6);
+
+            // ---- phase 3: open-task sets, per-env counts, wavefront scan
+            const mask_t lit1 = x_lit[slot];
+            const uint32_t fate = x_fate[slot];
+            const mask_t burned = fate & 0xFFu, put_out = (fate >> 8) & 0xFFu;
+            const bool dead = ((fate >> 16) & 1u) != 0;
+            bool term = term0, trunc = trunc0;
+            if (MODE == kStep) {
+                const int nm = crw.nm + 1;
+                trunc = (flags & kTruncate) ? nm >= d.max_steps : trunc0;
+                term = term0 || dead;
+                at32(rows, (uint32_t)r_moves * Bu + bl) = nm;
+            }
+            mask_t ok1[AMAX];
+            uint64_t packed[PW], incl[PW], base[PW];
+#pragma unroll
+            for (int w = 0; w < PW; ++w) packed[w] = 0;
+            const int F = popc(lit1);
+            packed[0] = (uint64_t)F;
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a) {
+                ok1[a] = 0;
+                if (a < A) {
+                    ok1[a] = supp[a] > 0.0f ? (lit1 & (mask_t)s_cfg.range_mask[a][eqs[a]]) : (mask_t)0;
+                    packed[(a + 1) >> 2] |= (uint64_t)popc(ok1[a]) << (16 * ((a + 1) & 3));
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < PW; ++w) incl[w] = frz::wave_inclusive_scan(packed[w]);
+            const uint32_t live_nt = (uint32_t)__popcll(__ballot(active && !term));
+            const uint32_t live_ntr = (uint32_t)__popcll(__ballot(active && !trunc));
+            if (lane == 63) {
+#pragma unroll
+                for (int w = 0; w < PW; ++w) s_wave_scan[wave][w] = incl[w];
+                s_wave_live[wave][0] = live_nt;
+                s_wave_live[wave][1] = live_ntr;
+            }
+            x_task_off[slot] = (uint32_t)((incl[0] - packed[0]) & 0xFFFFull);
+            FRZ_RSTAMP(7);
+            __syncthreads();  // (3) wavefront sums visible
+
+            // ---- phase 4: chunk sums published; rewards / bookkeeping hide the hand-off; look-back
+            const int round_first = chunk - blockIdx.x;  // first chunk of this round
+            uint64_t block_total[PW];
+#pragma unroll
+            for (int w = 0; w < PW; ++w) {
+                base[w] = 0;
+                block_total[w] = 0;
+#pragma unroll
+                for (int j = 0; j < frz::kWaves; ++j) {
+                    const uint64_t t = s_wave_scan[j][w];
+                    base[w] += j < wave ? t : 0ull;
+                    block_total[w] += t;
+                }
+            }
+            uint32_t my_total = 0;  // this chunk's sum of channel `slot` (slot < nch)
+            if (slot < nch) {
+                if (slot <= A) {
+                    uint64_t word = block_total[0];
+#pragma unroll
+                    for (int w = 1; w < PW; ++w) word = (slot >> 2) == w ? block_total[w] : word;
+                    my_total = (uint32_t)((word >> (16 * (slot & 3))) & 0xFFFFull);
+                } else {
+                    const int which = slot - ch_nt;
+#pragma unroll
+                    for (int j = 0; j < frz::kWaves; ++j) my_total += s_wave_live[j][which];
+                }
+                frz::granule_store(agg + (int64_t)chunk * nch + slot, tag, my_total);
+            }
+
+            if (MODE == kStep) {
+                // rewards and termination (wildfire.py:534-582)
+                float fire_reward_sum = 0.0f, burnout_total = 0.0f;
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) {
+                    if (c < HW) {
+                        const float fr = d.fire_rewards[c];
+                        fire_reward_sum = __fadd_rn(fire_reward_sum, ((put_out >> c) & 1) ? fr : 0.0f);
+                        const float pen = (flags & kPenaltyScaled) ? __fmul_rn(-1.0f, fr) : d.burnout_penalty;
+                        burnout_total = __fadd_rn(burnout_total, ((burned >> c) & 1) ? pen : 0.0f);
+                    }
+                }
+                const bool newly = !term0 && dead;
+                // correctly rounded float32 log via double (matches the oracle bit for bit; the reference's torch.log is
+                // a <=1-ulp float32 log).  Only evaluated by wavefronts that hold a newly terminated env.
+                float log_burnouts = 0.0f;
+                if (newly && d.termination_kappa != 0.0f) log_burnouts = (float)log((double)crw.nb + 1.0);
+                const float penalty = __fmul_rn(d.termination_kappa, log_burnouts);
+                float term_reward = __fsub_rn(d.termination_reward, penalty);
+                term_reward = term_reward < 0.0f ? 0.0f : term_reward;
+                const int n_burn = popc(burned), n_put = popc(put_out);
+                const bool localize = (flags & kLocalize) != 0;
+                const bool track = (flags & kTrackCumulative) != 0, write_trunc = (flags & kTruncate) != 0;
+#pragma unroll
+                for (int a = 0; a < AMAX; ++a) {
+                    if (a < A) {
+                        float base_reward = fire_reward_sum;
+                        if (localize) {
+                            base_reward = 0.0f;
+#pragma unroll
+                            for (int c = 0; c < CMAX; ++c)
+                                if (c < HW) base_reward = (hit[a] == c && ((put_out >> c) & 1)) ? d.fire_rewards[c] : base_reward;
+                        }
+                        rew[a] = __fadd_rn(rew[a], __fadd_rn(base_reward, burnout_total));
+                        rew[a] = newly ? __fadd_rn(rew[a], term_reward) : rew[a];
+                        at32(rowsf, (uint32_t)(r_rewards + a) * Bu + bl) = rew[a];
+                        at32(rows1, (u_term + (uint32_t)a) * Bu + bl) = (uint8_t)term;
+                        if (write_trunc) at32(rows1, (u_trunc + (uint32_t)a) * Bu + bl) = (uint8_t)trunc;
+                        if (track) at32(rowsf, (uint32_t)(r_cum + a) * Bu + bl) = __fadd_rn(crw.cum[a], rew[a]);
+                    }
+                }
+                at32(rows, (uint32_t)r_burnouts * Bu + bl) = crw.nb + n_burn;
+                at32(rows8, q_burnouts * Bu + bl) = n_burn;
+                at32(rows8, q_putouts * Bu + bl) = n_put;
+            }
+            if (active) {
+#pragma unroll
+                for (int a = 0; a < AMAX; ++a)
+                    if (a < A) at32(rows, (uint32_t)(r_atc + a) * Bu + bl) = popc(ok1[a]);
+                at32(rows8, q_etc * Bu + bl) = F;
+            }
+            Cells next_cells = cells;
+            CrewRegs next_crw = crw;
+            CDraws next_cdraws = cdraws;
+            if (next_chunk < nchunks) {
+                next_cells = load_cells(next_chunk);
+                next_crw = load_crew(next_chunk, next_cdraws);
+            }
+
+            // inter-workgroup exclusive prefix (single pass), as in wildfire.hip: crew thread t sums channel (t % NCHP) over
+            // predecessors t / NCHP, t / NCHP + PP, ...; the window's loads are unconditional so they are in flight together
+            bool timed_out = false;
+            uint32_t acc = 0;
+            {
+                const int ch = slot & (NCHP - 1), pslot = slot / NCHP;
+                constexpr int PP = kBlock / NCHP, UNR = 8;
+                for (int first = round_first; first < chunk; first += PP * UNR) {
+                    uint32_t part = 0;
+                    for (int spin = 0;; ++spin) {  // bounded: every granule of the window must carry this launch's tag
+                        bool all = true;
+                        part = 0;
+#pragma unroll
+                        for (int u = 0; u < UNR; ++u) {
+                            const int pred = first + u * PP + pslot;
+                            const bool valid = pred < chunk && ch < nch;
+                            const uint64_t g = frz::granule_load(agg + (valid ? (int64_t)pred * nch + ch : (int64_t)0));
+                            all = all && (!valid || (uint32_t)(g >> 32) == tag);
+                            part += valid ? (uint32_t)g : 0u;
+                        }
+                        if (all) break;
+                        if (spin >= (1 << 22)) {
+                            timed_out = true;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    acc += part;
+                }
+                if (round_first > 0 && slot < nch) acc += frz::granule_wait(prefix + (int64_t)(round_first - 1) * nch + slot, tag, &timed_out);
+#pragma unroll
+                for (int dd = NCHP; dd < 64; dd <<= 1) acc += __shfl_xor(acc, dd, 64);
+                if (lane < NCHP) s_reduce[wave][lane] = acc;
+            }
+            FRZ_RSTAMP(8);
+            __syncthreads();  // (4) look-back partial sums visible
+
+            // ---- phase 5: chunk prefix
+            if (slot < nch) {
+                uint32_t s = 0;
+#pragma unroll
+                for (int j = 0; j < frz::kWaves; ++j) s += s_reduce[j][slot];
+                s_prefix[slot] = s;
+                const bool round_last = blockIdx.x == gridDim.x - 1 || chunk == nchunks - 1;
+                if (round_last) {
+                    frz::granule_store(prefix + (int64_t)chunk * nch + slot, tag, s + my_total);
+                    if (chunk == nchunks - 1) cur_totals[slot] = s + my_total;  // batch totals, read by the next launch
+                }
+            }
+            __syncthreads();  // (5) chunk prefix visible
+            FRZ_RSTAMP(9);
+            if (timed_out) err |= FRZ_ERR_SCAN_TIMEOUT;
+
+            // ---- phase 6: action lists (wildfire.py:586-717)
+            if (active) {
+                const int64_t cap = B * HW;
+                const int64_t off_f = task_offset();
+                int64_t* const act_values = reinterpret_cast<int64_t*>(arena + d.off_act_values);
+                int64_t* const act_offsets = reinterpret_cast<int64_t*>(arena + d.off_act_offsets);
+                int64_t* const bad_values = reinterpret_cast<int64_t*>(arena + d.off_bad_values);
+                int64_t* const bad_offsets = reinterpret_cast<int64_t*>(arena + d.off_bad_offsets);
+                const bool show_bad = (flags & kShowBad) != 0;
+#pragma unroll
+                for (int a = 0; a < AMAX; ++a)
+                    if (a < A) {
+                        const int w = (a + 1) >> 2, sh = 16 * ((a + 1) & 3);
+                        uint64_t excl = base[0] + incl[0] - packed[0];
+#pragma unroll
+                        for (int ww = 1; ww < PW; ++ww) excl = w == ww ? base[ww] + incl[ww] - packed[ww] : excl;
+                        const int64_t off_a = (int64_t)s_prefix[a + 1] + (int64_t)((excl >> sh) & 0xFFFFull);
+                        const int fa = popc(ok1[a]);
+                        act_offsets[a * (B + 1) + b] = off_a;
+                        if (b == B - 1) act_offsets[a * (B + 1) + B] = off_a + fa;
+                        int64_t* av = act_values + a * cap + off_a;
+                        int64_t* bv = bad_values + a * cap + (off_f - off_a);  // bad = listed but not attackable
+                        if (show_bad) {
+                            bad_offsets[a * (B + 1) + b] = off_f - off_a;
+                            if (b == B - 1) bad_offsets[a * (B + 1) + B] = (off_f - off_a) + (F - fa);
+                        }
+#pragma unroll
+                        for (int c = 0; c < CMAX; ++c) {
+                            const mask_t below = (mask_t)(((mask_t)1 << c) - 1);
+                            const int rk = popc(lit1 & below);
+                            if ((ok1[a] >> c) & 1)
+                                av[popc(ok1[a] & below)] = rk;
+                            else if (show_bad && ((lit1 >> c) & 1))
+                                bv[popc(lit1 & ~ok1[a] & below)] = rk;
+                        }
+                    }
+            }
+            FRZ_RSTAMP(10);
+            if (err) atomicOr(error_word, err);
+            cells = next_cells;
+            crw = next_crw;
+            cdraws = next_cdraws;
+        }
+    }
+}
+
+template <int CMAX, int AMAX, bool EXACT>
+void launch_roles_variant(const WfArgs& a, const WfDev* dev, int grid, int rng, int mode, hipStream_t stream) {
+    const WfLaunch batch = make_launch(a.host_dev);
+    if (mode == kRebuild) {
+        hipLaunchKernelGGL((wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kRebuild>), dim3(grid), dim3(kRoleBlock), 0, stream, a.arena,
+                           dev, a.actions, a.field_rand, a.agent_rand, batch);
+    } else if (rng == FRZ_RNG_PHILOX) {
+        if constexpr (EXACT)
+            hipLaunchKernelGGL((wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_PHILOX, kStep>), dim3(grid), dim3(kRoleBlock), 0, stream, a.arena,
+                               dev, a.actions, a.field_rand, a.agent_rand, batch);
+    } else {
+        hipLaunchKernelGGL((wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kStep>), dim3(grid), dim3(kRoleBlock), 0, stream, a.arena,
+                           dev, a.actions, a.field_rand, a.agent_rand, batch);
+    }
+}
+
+}  // namespace
+
+// variant: 0 = (6 cells, 3 agents, exact), 1 = (6, 2, exact), 2 = (<= 8, <= 4); the caller has already staged the Philox
+// draws for variant 2 (rng arrives as FRZ_RNG_INJECTED)
+int launch_roles(const WfArgs& args, int variant, int grid, int rng, int mode, hipStream_t stream) {
+    const WfDev* dev = reinterpret_cast<const WfDev*>(args.arena);
+    switch (variant) {
+        case 0: launch_roles_variant<6, 3, true>(args, dev, grid, rng, mode, stream); break;
+        case 1: launch_roles_variant<6, 2, true>(args, dev, grid, rng, mode, stream); break;
+        case 2: launch_roles_variant<8, 4, false>(args, dev, grid, rng, mode, stream); break;
+        default: return FRZ_E_INVALID;
+    }
+    return hipGetLastError() == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;
+}
+
+}  // namespace frz_wf
