@@ -10,6 +10,7 @@ episodes is inside the timed region.  Inputs are resident in HBM; nothing crosse
 Prints ONE JSON line (rank 0).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -118,19 +119,14 @@ def main():
         metrics.copy_(sharding.episode_metrics(env._cumulative, env.finished, B * EPISODE))
         sharding.reduce_metrics(metrics)
 
-    def one_step(events=None):
+    def one_step():
         """Eager path: the same launches the graphs replay, issued one by one through the Python boundary."""
         if state['step'] % EPISODE == 0:
             if state['step'] > 0:
                 episode_metrics()
             env.reset(seed=base_seed + 1000003 * state['episode'])
             state['episode'] += 1
-        env.random_policy_actions(policy_seed=20260104 + rank, policy_step=state['step'] % EPISODE, out=env._actions)
-        if events is not None:
-            events[0].record()
-        env.step(env._actions)
-        if events is not None:
-            events[1].record()
+        env.step_random_policy(policy_seed=20260104 + rank, policy_step=state['step'] % EPISODE)
         state['step'] += 1
 
     # ---- timed region: K steps as HIP-graph replays of whole episodes (reset + 50 x (policy, step) per replay)
@@ -175,36 +171,32 @@ def main():
     barrier()
     api_value = world * B * api_steps / (time.perf_counter() - t1)
 
-    # ---- kernel-level pass (not part of `value`): HIP events on the launch stream around the fused step launch alone
-    # (C-ABI calls, no Python-side tensor work between the two records) + mean task counts for the algorithmic bytes
+    # ---- kernel-level pass (not part of `value`): two HIP events on the launch stream take the step dispatch's own begin
+    # and end timestamps (hipExtLaunchKernel start/stop events: what rocprofv3's kernel trace reports, profiles/) + mean
+    # task counts for the algorithmic bytes
     from free_range_zoo_amd import _capi
     from free_range_zoo_amd.utils.env import stream_ptr
     lib, handle = env._lib, env._handle
     mode = _capi.FRZ_RNG_MT19937 if args.rng == 'mt19937' else _capi.FRZ_RNG_PHILOX
     n_probe = min(args.steps, 200)
-    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_probe)]
+    kernel_ms = []
     task_sum = torch.zeros(1 + A, dtype=torch.float64, device=device)
     env.reset(seed=base_seed + 17)
     stream = stream_ptr(device)
-    # keep the device busy while the host enqueues the probe, so that the event pairs time the kernel on the device and
-    # not the host's launch latency (eager issue of ~20 us kernels is host-bound: an idle stream would make every
-    # bracket measure hipLaunchKernel + ctypes instead of the kernel)
     torch.cuda.synchronize(device)
-    torch.cuda._sleep(int(2.0e9 * 0.05))
     for i in range(n_probe):
         if i % EPISODE == 0 and i > 0:
             env.seeds.add_(seed_stride)
             if args.rng == 'mt19937':
                 env.generator._seed_streams(None)
             lib.frz_wildfire_reset(handle, stream)
-        lib.frz_wildfire_random_policy(handle, 20260104 + rank, i % EPISODE, env._actions.data_ptr(), stream)
-        pairs[i][0].record()
-        lib.frz_wildfire_step(handle, env._actions.data_ptr(), mode, None, None, stream)
-        pairs[i][1].record()
+        ms = ctypes.c_float(0.0)
+        _capi.check(lib.frz_wildfire_step_random_policy_timed(handle, 20260104 + rank, i % EPISODE, env._actions.data_ptr(), mode, None, None, stream,
+                                                              ctypes.byref(ms)), 'frz_wildfire_step_random_policy_timed')
+        kernel_ms.append(ms.value)
         task_sum[0] += env.environment_task_count.sum()
         task_sum[1:] += env.agent_task_count.sum(dim=1)
     torch.cuda.synchronize(device)
-    kernel_ms = sorted(p[0].elapsed_time(p[1]) for p in pairs)
     kernel_ms_avg = float(np.mean(kernel_ms))
     kernel_ms_med = float(np.median(kernel_ms))
     mean_tasks = float(task_sum[0].item()) / (n_probe * B)
@@ -235,12 +227,13 @@ def main():
             'dtype': 'i32/f32',
             'data': 'synthetic',
             'config': {'workload': f'wildfire_v0 cfg2 (2x3 grid, 3 agents, agent+task openness on), batch={B} per GPU, '
-                                   f'max_steps={EPISODE}, device random policy, rng={args.rng}, reset inside timed region, one HIP graph replay per episode',
+                                   f'max_steps={EPISODE}, uniform random policy sampled inside the step launch, rng={args.rng}, reset inside timed region, one HIP graph replay per episode',
                        'parallel_envs_per_gpu': B, 'agents': A, 'sharding': f'env-batch axis x{world}, no step-path collective'},
             'agent_steps_per_s': value * A,
             'python_api_env_steps_per_s': api_value,
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic, 'kernel': 'wf_step_kernel<6,3,exact,philox>' if args.rng == 'philox' else 'wf_step_kernel<6,3,exact,injected>', 'kernel_ms_avg': kernel_ms_avg,
+                         'traffic': traffic, 'kernel': 'wf_roles_kernel<6,3,exact,philox,step>' if args.rng == 'philox' else 'wf_roles_kernel<6,3,exact,injected,step>',
+                         'kernel_ms_avg': kernel_ms_avg,
                          'kernel_ms_median': kernel_ms_med, 'algorithmic_bytes_per_env_step': per_env,
                          'mean_tasks_per_env': mean_tasks, 'mean_agent_tasks_per_env': mean_agent_tasks},
             'reference_cpu_env_steps_per_s': {'value': 21112, 'source': 'BASELINE.md §2: unmodified reference, 8 vCPU, B=65536 (survey container)'},

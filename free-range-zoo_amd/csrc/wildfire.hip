@@ -829,6 +829,12 @@ struct frz_wildfire_env {
     bool was_reset = false;
     int grid = 0;
     int variant = 0;  // index into the (CMAX, AMAX) instantiation table
+    // set for the duration of one frz_wildfire_step_random_policy call
+    bool fused_policy = false;
+    uint64_t policy_seed = 0, policy_step = 0;
+    int32_t* actions_out = nullptr;
+    hipEvent_t start_event = nullptr, stop_event = nullptr;  // created on the first timed step
+    bool timed = false;
 };
 
 namespace {
@@ -861,16 +867,17 @@ void launch_variant(const WfArgs& args, int grid, int rng, int mode, hipStream_t
     if constexpr (!EXACT) {
         if (mode == kStep && rng == FRZ_RNG_PHILOX) stage_philox(a, rng, stream);
     }
+    const WfLaunch launch = make_launch(a);
     if (mode == kRebuild) {
-        hipLaunchKernelGGL((wf_step_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kRebuild>), dim3(grid), dim3(kBlock), 0, stream, a.arena,
-                           dev, a.actions, a.field_rand, a.agent_rand, make_launch(a.host_dev));
+        launch_step_kernel(a, wf_step_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kRebuild>, grid, kBlock, stream, a.arena, dev, a.actions,
+                           a.field_rand, a.agent_rand, launch);
     } else if (rng == FRZ_RNG_PHILOX) {
         if constexpr (EXACT)
-            hipLaunchKernelGGL((wf_step_kernel<CMAX, AMAX, EXACT, FRZ_RNG_PHILOX, kStep>), dim3(grid), dim3(kBlock), 0, stream, a.arena,
-                               dev, a.actions, a.field_rand, a.agent_rand, make_launch(a.host_dev));
+            launch_step_kernel(a, wf_step_kernel<CMAX, AMAX, EXACT, FRZ_RNG_PHILOX, kStep>, grid, kBlock, stream, a.arena, dev, a.actions,
+                               a.field_rand, a.agent_rand, launch);
     } else {
-        hipLaunchKernelGGL((wf_step_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kStep>), dim3(grid), dim3(kBlock), 0, stream, a.arena, dev,
-                           a.actions, a.field_rand, a.agent_rand, make_launch(a.host_dev));
+        launch_step_kernel(a, wf_step_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kStep>, grid, kBlock, stream, a.arena, dev, a.actions,
+                           a.field_rand, a.agent_rand, launch);
     }
 }
 
@@ -1132,7 +1139,12 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
     return FRZ_OK;
 }
 
-void frz_wildfire_destroy(frz_wildfire_env* env) { delete env; }
+void frz_wildfire_destroy(frz_wildfire_env* env) {
+    if (!env) return;
+    if (env->start_event) (void)hipEventDestroy(env->start_event);
+    if (env->stop_event) (void)hipEventDestroy(env->stop_event);
+    delete env;
+}
 
 int64_t frz_wildfire_arena_bytes(const frz_wildfire_env* env) { return env ? env->dev.total_bytes : FRZ_E_INVALID; }
 
@@ -1209,6 +1221,8 @@ int frz_wildfire_reset(frz_wildfire_env* env, void* stream) {
 
 int frz_mt19937_generate(uint32_t* mt_state, int32_t* mt_index, float* out, int64_t events, int64_t count, int64_t B, void* stream);
 
+int frz_wildfire_random_policy(frz_wildfire_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out, void* stream);
+
 int frz_wildfire_step(frz_wildfire_env* env, const int32_t* actions, int rng_mode, const float* field_randomness,
                       const float* agent_randomness, void* stream) {
     if (!env || !actions) return FRZ_E_INVALID;
@@ -1217,6 +1231,16 @@ int frz_wildfire_step(frz_wildfire_env* env, const int32_t* actions, int rng_mod
     const frz_wildfire_cfg& c = env->cfg;
     const WfDev& p = env->dev;
     WfArgs args{env->arena, actions, nullptr, nullptr, &env->dev};
+    if (env->fused_policy) {
+        args.policy = true;
+        args.policy_seed = env->policy_seed;
+        args.policy_step = env->policy_step;
+        args.actions_out = env->actions_out;
+    }
+    if (env->timed) {
+        args.start_event = env->start_event;
+        args.stop_event = env->stop_event;
+    }
     if (rng_mode == FRZ_RNG_INJECTED) {
         if (!field_randomness || !agent_randomness) return FRZ_E_INVALID;
         args.field_rand = field_randomness;
@@ -1239,6 +1263,37 @@ int frz_wildfire_step(frz_wildfire_env* env, const int32_t* actions, int rng_mod
         return FRZ_E_INVALID;
     }
     return launch(env, args, rng_mode, kStep, static_cast<hipStream_t>(stream));
+}
+
+int frz_wildfire_step_random_policy(frz_wildfire_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out, int rng_mode,
+                                    const float* field_randomness, const float* agent_randomness, void* stream) {
+    if (!env || !actions_out) return FRZ_E_INVALID;
+    if (!env->arena) return FRZ_E_UNBOUND;
+    if (!env->dev.roles) {  // no fused kernel for this grid shape: policy launch, then step launch
+        const int rc = frz_wildfire_random_policy(env, policy_seed, policy_step, actions_out, stream);
+        return rc != FRZ_OK ? rc : frz_wildfire_step(env, actions_out, rng_mode, field_randomness, agent_randomness, stream);
+    }
+    env->fused_policy = true;
+    env->policy_seed = policy_seed;
+    env->policy_step = policy_step;
+    env->actions_out = actions_out;
+    const int rc = frz_wildfire_step(env, actions_out, rng_mode, field_randomness, agent_randomness, stream);
+    env->fused_policy = false;
+    return rc;
+}
+
+int frz_wildfire_step_random_policy_timed(frz_wildfire_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out, int rng_mode,
+                                          const float* field_randomness, const float* agent_randomness, void* stream, float* kernel_ms) {
+    if (!env || !kernel_ms) return FRZ_E_INVALID;
+    if (!env->start_event && (hipEventCreate(&env->start_event) != hipSuccess || hipEventCreate(&env->stop_event) != hipSuccess))
+        return FRZ_E_LAUNCH;
+    env->timed = true;
+    const int rc = frz_wildfire_step_random_policy(env, policy_seed, policy_step, actions_out, rng_mode, field_randomness, agent_randomness, stream);
+    env->timed = false;
+    if (rc != FRZ_OK) return rc;
+    if (hipEventSynchronize(env->stop_event) != hipSuccess || hipEventElapsedTime(kernel_ms, env->start_event, env->stop_event) != hipSuccess)
+        return FRZ_E_LAUNCH;
+    return FRZ_OK;
 }
 
 int frz_wildfire_random_policy(frz_wildfire_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out, void* stream) {

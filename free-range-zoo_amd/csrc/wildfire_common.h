@@ -3,6 +3,8 @@
 
 #include "frz_device.h"
 
+#include <hip/hip_ext.h>
+
 #include "../../include/frz.h"
 
 #include <type_traits>
@@ -71,11 +73,12 @@ constexpr int64_t kDevBlockBytes = 8192;
 // What a step kernel needs before the configuration block is staged (passed by value: kernel arguments are there at
 // wave start, so the state loads, the byte rows and the epoch/totals words are all in flight from the first instruction)
 struct WfLaunch {
-    int32_t batch, pad_;
+    int32_t batch;
+    uint32_t policy;  // 1: sample the actions in-kernel (uniform random policy, frz_wildfire_step_random_policy)
     int64_t off_rows1, off_epoch, off_totals;
+    uint32_t policy_seed_lo, policy_seed_hi, policy_step_lo, policy_step_hi;
+    int32_t* actions_out;  // where the sampled actions are left (policy == 1), int32 [A][B][2]
 };
-
-inline WfLaunch make_launch(const struct WfDev* host);
 
 struct WfArgs {
     char* arena;
@@ -83,9 +86,27 @@ struct WfArgs {
     const float* field_rand;
     const float* agent_rand;
     const WfDev* host_dev;  // host copy of the configuration block (launch-side decisions)
+    bool policy = false;    // fused uniform random policy (field/crew kernels only)
+    uint64_t policy_seed = 0, policy_step = 0;
+    int32_t* actions_out = nullptr;
+    // optional: events that receive the step dispatch's own begin / end timestamps (frz_wildfire_step_random_policy_timed)
+    hipEvent_t start_event = nullptr, stop_event = nullptr;
 };
 
-inline WfLaunch make_launch(const WfDev* host) { return WfLaunch{host->B, 0, host->off_rows1, host->off_epoch, host->off_totals}; }
+// launch a step kernel; with timing events the dispatch itself is bracketed (what a profiler's kernel trace reports)
+template <typename K, typename... Args>
+inline void launch_step_kernel(const WfArgs& a, K kernel, int grid, int block, hipStream_t stream, Args... args) {
+    if (a.start_event && a.stop_event)
+        hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, a.start_event, a.stop_event, 0, args...);
+    else
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, args...);
+}
+
+inline WfLaunch make_launch(const WfArgs& a) {
+    const WfDev* host = a.host_dev;
+    return WfLaunch{host->B, a.policy ? 1u : 0u, host->off_rows1, host->off_epoch, host->off_totals, (uint32_t)a.policy_seed,
+                    (uint32_t)(a.policy_seed >> 32), (uint32_t)a.policy_step, (uint32_t)(a.policy_step >> 32), a.actions_out};
+}
 
 // Staging the configuration: the 16-byte piece is requested by the kernel's FIRST vector-memory instruction (before the
 // state loads, so that waiting for it does not wait for them: the counter retires in issue order), parked in LDS, and the

@@ -36,9 +36,19 @@ constexpr int kRoleBlock = 2 * kBlock;  // 4 field + 4 crew wavefronts per 256-e
             reinterpret_cast<unsigned long long*>(arena + dev->off_rand_agent)[(crew ? 16 : 0) + (i)] = __builtin_amdgcn_s_memtime(); \
         __builtin_amdgcn_sched_barrier(0);                                                                                  \
     } while (0)
+// per-workgroup wall clock (100 MHz): [2 * blockIdx.x] = first instruction, [2 * blockIdx.x + 1] = last, both roles' minimum/maximum
+#define FRZ_RWALL(which)                                                                                                     \
+    do {                                                                                                                     \
+        if (slot == 0 && MODE == kStep)                                                                                      \
+            reinterpret_cast<unsigned long long*>(arena + dev->off_rand_field)[4 * blockIdx.x + 2 * (crew ? 1 : 0) + (which)] = \
+                __builtin_amdgcn_s_memrealtime();                                                                            \
+    } while (0)
 #else
 #define FRZ_RSTAMP(i) \
     do {              \
+    } while (0)
+#define FRZ_RWALL(which) \
+    do {                 \
     } while (0)
 #endif
 
@@ -47,7 +57,7 @@ __global__ void __launch_bounds__(kRoleBlock) wf_roles_kernel(char* __restrict__
                                                                const int32_t* __restrict__ actions, const float* __restrict__ field_rand,
                                                                const float* __restrict__ agent_rand, const WfLaunch launch) {
     const int32_t batch = launch.batch;
-    static_assert(CMAX <= 8, "cell masks travel between the roles as bytes");
+    static_assert(CMAX <= 8 && AMAX <= 4, "cell masks travel between the roles as bytes");
     using mask_t = uint32_t;
     constexpr int PW = (AMAX + 1 + 3) / 4;                                // packed scan words (four 16-bit channels each)
     constexpr int NCHP = AMAX + 3 <= 8 ? 8 : (AMAX + 3 <= 16 ? 16 : 32);  // scan channels padded to a power of two
@@ -63,7 +73,10 @@ __global__ void __launch_bounds__(kRoleBlock) wf_roles_kernel(char* __restrict__
     __shared__ float x_power[CMAX][kBlock];  // crew -> field: fire-fighting power applied to each cell
     __shared__ uint32_t x_lit[kBlock];       // field -> crew: lit cells after the transitions
     __shared__ uint32_t x_fate[kBlock];      // field -> crew: burned | put_out << 8 | dead << 16
-    __shared__ uint32_t x_task_off[kBlock];  // crew -> field: tasks of the preceding envs of the same wavefront
+    __shared__ uint64_t x_excl[PW][kBlock];  // crew -> both: packed per-env counts of the preceding envs of the same wavefront
+    __shared__ uint32_t x_ok[kBlock];        // crew -> both: attackable cells of agent a in byte a (AMAX <= 4)
+    __shared__ float x_supp[AMAX][kBlock];   // crew -> field: suppressant after the agent transitions (agent observations)
+    __shared__ float x_draw[kPhilox ? 5 * AMAX : 1][kBlock];  // field -> crew: the step's agent draws (FRZ_RNG_PHILOX)
 
     const int tid = threadIdx.x;
     const uint4 cfg_piece = stage_request(dev);  // first vector-memory instruction of the kernel
@@ -168,9 +181,11 @@ __global__ void __launch_bounds__(kRoleBlock) wf_roles_kernel(char* __restrict__
                 e.capa[a] = at32(rowsf, (uint32_t)(r_cap + a) * Bu + bl);
                 e.eqs[a] = at32(rows, (uint32_t)(r_equip + a) * Bu + bl);
                 if (MODE == kStep) {
-                    const int2 v = reinterpret_cast<const int2*>(actions)[a * B + bl];
-                    e.act_idx[a] = v.x;
-                    e.act_id[a] = v.y;
+                    if (!launch.policy) {
+                        const int2 v = reinterpret_cast<const int2*>(actions)[a * B + bl];
+                        e.act_idx[a] = v.x;
+                        e.act_id[a] = v.y;
+                    }
                     e.cum[a] = at32(rowsf, (uint32_t)(r_cum + a) * Bu + bl);
                 }
             }
@@ -184,7 +199,7 @@ __global__ void __launch_bounds__(kRoleBlock) wf_roles_kernel(char* __restrict__
         if (MODE == kStep) {
             e.nm = at32(rows, (uint32_t)r_moves * Bu + bl);
             e.nb = at32(rows, (uint32_t)r_burnouts * Bu + bl);
-            if (kPhilox) e.seed = (uint32_t)at32(rows, (uint32_t)r_seeds * Bu + bl);
+            if (kPhilox || launch.policy) e.seed = (uint32_t)at32(rows, (uint32_t)r_seeds * Bu + bl);
         }
         if constexpr (kInjected) {
 #pragma unroll
@@ -197,6 +212,7 @@ __global__ void __launch_bounds__(kRoleBlock) wf_roles_kernel(char* __restrict__
     };
 
     FRZ_RSTAMP(0);
+    FRZ_RWALL(0);
     // first chunk's loads: in flight while the configuration is staged
     FDraws fdraws;
     CDraws cdraws;
@@ -211,7 +227,7 @@ __global__ void __launch_bounds__(kRoleBlock) wf_roles_kernel(char* __restrict__
     const int W = d.W;
     const int nch = d.nch;  // A + 3
     const int ch_nt = A + 1, ch_ntr = A + 2;
-    const uint32_t flags = d.flags;
+    const uint32_t flags_word = d.flags;
 
     const uint32_t tag = epoch + 1u;  // never 0 on a zero-filled arena
     uint32_t* const cur_totals = totals + (epoch & 1u) * kTotalsStride;
@@ -256,12 +272,54 @@ __global__ void __launch_bounds__(kRoleBlock) wf_roles_kernel(char* __restrict__
     uint64_t* const prefix = reinterpret_cast<uint64_t*>(arena + d.off_prefix);
 
     uint32_t* const error_word = reinterpret_cast<uint32_t*>(arena + d.off_error);
-    // tasks of the envs of this chunk that precede this lane's env (after barrier 3) + the chunk's offset (after barrier 5)
-    auto task_offset = [&]() {
-        uint32_t before = x_task_off[slot];
+    // After barrier 5 either role can place any list of its env: the chunk's offsets (s_prefix), the sums of the chunk's
+    // preceding wavefronts (s_wave_scan) and the env's position inside its wavefront (x_excl) are all in LDS.
+    struct Placement {
+        uint64_t ex[PW];  // packed counts of the chunk's envs that precede this env
+    };
+    auto placement = [&]() {
+        Placement p;
 #pragma unroll
-        for (int j = 0; j < frz::kWaves; ++j) before += j < wave ? (uint32_t)(s_wave_scan[j][0] & 0xFFFFull) : 0u;
-        return (int64_t)s_prefix[0] + (int64_t)before;
+        for (int w = 0; w < PW; ++w) {
+            uint64_t before = x_excl[w][slot];
+#pragma unroll
+            for (int j = 0; j < frz::kWaves; ++j) before += j < wave ? s_wave_scan[j][w] : 0ull;
+            p.ex[w] = before;
+        }
+        return p;
+    };
+    auto channel_offset = [&](const Placement& p, int ch) {
+        uint64_t word = p.ex[0];
+#pragma unroll
+        for (int w = 1; w < PW; ++w) word = (ch >> 2) == w ? p.ex[w] : word;
+        return (int64_t)s_prefix[ch] + (int64_t)((word >> (16 * (ch & 3))) & 0xFFFFull);
+    };
+    // open action list of agent a (and, with show_bad_actions, its listed-but-not-attackable list): wildfire.py:586-717
+    auto emit_agent_lists = [&](int a, mask_t lit1, mask_t ok, int64_t off_f, int64_t off_a, int64_t b) {
+        const int64_t cap = B * HW;
+        int64_t* const act_values = reinterpret_cast<int64_t*>(arena + d.off_act_values);
+        int64_t* const act_offsets = reinterpret_cast<int64_t*>(arena + d.off_act_offsets);
+        int64_t* const bad_values = reinterpret_cast<int64_t*>(arena + d.off_bad_values);
+        int64_t* const bad_offsets = reinterpret_cast<int64_t*>(arena + d.off_bad_offsets);
+        const bool show_bad = (flags_word & kShowBad) != 0;
+        const int F = popc(lit1), fa = popc(ok);
+        act_offsets[a * (B + 1) + b] = off_a;
+        if (b == B - 1) act_offsets[a * (B + 1) + B] = off_a + fa;
+        int64_t* av = act_values + a * cap + off_a;
+        int64_t* bv = bad_values + a * cap + (off_f - off_a);  // bad = listed but not attackable
+        if (show_bad) {
+            bad_offsets[a * (B + 1) + b] = off_f - off_a;
+            if (b == B - 1) bad_offsets[a * (B + 1) + B] = (off_f - off_a) + (F - fa);
+        }
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) {
+            const mask_t below = (mask_t)(((mask_t)1 << c) - 1);
+            const int rk = popc(lit1 & below);
+            if ((ok >> c) & 1)
+                av[popc(ok & below)] = rk;
+            else if (show_bad && ((lit1 >> c) & 1))
+                bv[popc(lit1 & ~ok & below)] = rk;
+        }
     };
 
     // The two roles run the same chunk sequence and meet at five workgroup barriers per chunk; each role's loop is its own
@@ -273,6 +331,10 @@ __global__ void __launch_bounds__(kRoleBlock) wf_roles_kernel(char* __restrict__
             const bool active = b < B;
             const uint32_t bl = (uint32_t)(active ? b : B - 1);
             const int next_chunk = chunk + (int)gridDim.x;
+            // per-iteration opaque copy: keeps the flag tests next to their uses (a launch usually runs ONE iteration per
+            // workgroup; hoisted out of the loop they would all sit in scalar registers from the top of the kernel and spill)
+            uint32_t flags = flags_word;
+            asm volatile("" : "+s"(flags));
             int f[CMAX], in[CMAX], fu[CMAX];
 #pragma unroll
             for (int c = 0; c < CMAX; ++c) f[c] = cells.f[c], in[c] = fld.in[c], fu[c] = fld.fu[c];
@@ -287,22 +349,31 @@ __global__ void __launch_bounds__(kRoleBlock) wf_roles_kernel(char* __restrict__
                         for (int c = 0; c < CMAX; ++c) r_field[e][c] = fdraws.r[e][c];
                 } else if constexpr (kPhilox) {
                     // FRZ_RNG_PHILOX (include/frz.h): draw u = 24-bit field u % 5 of block (u / 5, step, 0, 0); field event e
-                    // of cell c is draw e * HW + c
-                    constexpr int NBF = (3 * CMAX + 4) / 5;
-                    float uni[NBF * 5];
+                    // of cell c is draw e * HW + c, agent event e of agent a is draw 3 * HW + e * A + a.  The field role
+                    // draws for both roles while the crew decodes the actions; agent events 1..4 are only drawn when
+                    // something reads them.
+                    constexpr int U = 3 * CMAX + 5 * AMAX, NB = (U + 4) / 5, NB_EVENT0 = (3 * CMAX + AMAX + 4) / 5;
+                    const bool need_late = (flags & (kStochRepair | kStochDegrade | kCritical | kStochRefill | kStochSwitch)) != 0 || d.K > 1;
+                    const int nb_needed = need_late ? NB : NB_EVENT0;
+                    float uni[NB * 5];
 #pragma unroll
-                    for (int j = 0; j < NBF; ++j) {
-                        const frz::Philox4 w = frz::philox4x32_10((uint32_t)j, (uint32_t)fld.nm, 0u, 0u, fld.seed, 0x46525A00u);
-                        uni[5 * j] = frz::philox_unit24<0>(w);
-                        uni[5 * j + 1] = frz::philox_unit24<1>(w);
-                        uni[5 * j + 2] = frz::philox_unit24<2>(w);
-                        uni[5 * j + 3] = frz::philox_unit24<3>(w);
-                        uni[5 * j + 4] = frz::philox_unit24<4>(w);
+                    for (int j = 0; j < NB; ++j) {
+                        uni[5 * j] = uni[5 * j + 1] = uni[5 * j + 2] = uni[5 * j + 3] = uni[5 * j + 4] = 0.0f;
+                        if (j < nb_needed) {
+                            const frz::Philox4 w = frz::philox4x32_10((uint32_t)j, (uint32_t)fld.nm, 0u, 0u, fld.seed, 0x46525A00u);
+                            uni[5 * j] = frz::philox_unit24<0>(w);
+                            uni[5 * j + 1] = frz::philox_unit24<1>(w);
+                            uni[5 * j + 2] = frz::philox_unit24<2>(w);
+                            uni[5 * j + 3] = frz::philox_unit24<3>(w);
+                            uni[5 * j + 4] = frz::philox_unit24<4>(w);
+                        }
                     }
 #pragma unroll
                     for (int e = 0; e < 3; ++e)
 #pragma unroll
                         for (int c = 0; c < CMAX; ++c) r_field[e][c] = uni[e * CMAX + c];
+#pragma unroll
+                    for (int i = 0; i < 5 * AMAX; ++i) x_draw[i][slot] = uni[3 * CMAX + i];
                 }
             }
             FRZ_RSTAMP(3);
@@ -404,6 +475,36 @@ __global__ void __launch_bounds__(kRoleBlock) wf_roles_kernel(char* __restrict__
                         at32(rows, (uint32_t)(r_fuel + c) * Bu + bl) = fu[c];
                     }
             }
+            {  // agent observations (wildfire.py:677-681, 704-716): the suppressants arrive from the crew
+                float supp[AMAX];
+#pragma unroll
+                for (int a = 0; a < AMAX; ++a) supp[a] = a < A ? x_supp[a][slot] : 0.0f;
+                const int k = d.others_k, width = (A - 1) * k;  // k = 2 + power column + suppressant column
+                const bool op = (flags & kObsPower) != 0;
+#pragma unroll
+                for (int a = 0; a < AMAX; ++a)
+                    if (a < A) {
+                        reinterpret_cast<float4*>(obs_self)[a * B + bl] = make_float4((float)d.ay[a], (float)d.ax[a], d.power[a], supp[a]);
+                        float* const others = obs_others + (a * B + bl) * (int64_t)width;
+                        int j = 0;  // record index: the other agents in agent order
+#pragma unroll
+                        for (int o = 0; o < AMAX; ++o)
+                            if (o < A && o != a) {
+                                float* const rec = others + j * k;
+                                const float y = (float)d.ay[o], x = (float)d.ax[o];
+                                if (k == 4) {
+                                    *reinterpret_cast<float4*>(rec) = make_float4(y, x, d.power[o], supp[o]);
+                                } else if (k == 3) {
+                                    rec[0] = y;
+                                    rec[1] = x;
+                                    rec[2] = op ? d.power[o] : supp[o];
+                                } else {
+                                    *reinterpret_cast<float2*>(rec) = make_float2(y, x);
+                                }
+                                ++j;
+                            }
+                    }
+            }
             FRZ_RSTAMP(7);
             __syncthreads();  // (3) wavefront sums visible
 
@@ -422,7 +523,12 @@ __global__ void __launch_bounds__(kRoleBlock) wf_roles_kernel(char* __restrict__
 
             // ---- phase 6: task list (wildfire.py:586-717)
             if (active) {
-                const int64_t off_f = task_offset();
+                const Placement place = placement();
+                const int64_t off_f = channel_offset(place, 0);
+                const uint32_t oks = x_ok[slot];
+#pragma unroll
+                for (int a = 1; a < AMAX; a += 2)  // odd agents' lists (the crew writes the even ones)
+                    if (a < A) emit_agent_lists(a, lit1, (mask_t)((oks >> (8 * a)) & 0xFFu), off_f, channel_offset(place, a + 1), b);
                 int64_t* const task_values = reinterpret_cast<int64_t*>(arena + d.off_task_values);
                 int64_t* const task_offsets = reinterpret_cast<int64_t*>(arena + d.off_task_offsets);
                 int64_t* const obs_map = reinterpret_cast<int64_t*>(arena + d.off_obs_map);
@@ -444,6 +550,7 @@ __global__ void __launch_bounds__(kRoleBlock) wf_roles_kernel(char* __restrict__
                 }
             }
             FRZ_RSTAMP(10);
+            FRZ_RWALL(1);
             // The workgroup owning the last chunk finished its look-back only after every other chunk published, i.e.
             // after every workgroup of this launch read the epoch: it can advance it for the next launch.
             if (chunk == nchunks - 1 && tid == 0) __hip_atomic_store(epoch_ptr, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -458,6 +565,10 @@ __global__ void __launch_bounds__(kRoleBlock) wf_roles_kernel(char* __restrict__
             const bool active = b < B;
             const uint32_t bl = (uint32_t)(active ? b : B - 1);
             const int next_chunk = chunk + (int)gridDim.x;
+            // per-iteration opaque copy: keeps the flag tests next to their uses (a launch usually runs ONE iteration per
+            // workgroup; hoisted out of the loop they would all sit in scalar registers from the top of the kernel and spill)
+            uint32_t flags = flags_word;
+            asm volatile("" : "+s"(flags));
             uint32_t err = 0;
             float supp[AMAX], capa[AMAX], rew[AMAX];
             int eqs[AMAX], hit[AMAX];
@@ -485,17 +596,30 @@ __global__ void __launch_bounds__(kRoleBlock) wf_roles_kernel(char* __restrict__
                 for (int a = 0; a < AMAX; ++a) {
                     if (a < A) {
                         const mask_t ok = supp[a] > 0.0f ? (lit0 & (mask_t)s_cfg.range_mask[a][eqs[a]]) : (mask_t)0;
-                        refill[a] = crw.act_id[a] == -1;
+                        const mask_t sel = show_bad ? lit0 : ok;  // the tasks the agent's action space lists
+                        int act_idx = crw.act_idx[a], act_id = crw.act_id[a];
+                        if (launch.policy) {
+                            // uniform random policy over OneOf([task] * n + [noop]) (spaces/actions.py:23-41,
+                            // baselines/random.py:20), the stream of frz_wildfire_random_policy: member j ~ U{0..n};
+                            // j < n -> [j, 0] (fight task j), j == n -> [n, -1] (noop / refill)
+                            const int n = popc(sel);
+                            const frz::Philox4 w = frz::philox4x32_10((uint32_t)a, 0u, launch.policy_step_lo, launch.policy_step_hi,
+                                                                      launch.policy_seed_lo ^ crw.seed, launch.policy_seed_hi);
+                            const int j = (int)(((uint64_t)w.w[0] * (uint64_t)(n + 1)) >> 32);
+                            act_idx = j < n ? j : n;
+                            act_id = j < n ? 0 : -1;
+                            reinterpret_cast<int2*>(launch.actions_out)[a * B + bl] = make_int2(act_idx, act_id);
+                        }
+                        refill[a] = act_id == -1;
                         // quirk wildfire.py:434-435: an agent with no attackable task in ANY env of the batch is skipped
                         const bool skipped = prev[1 + a] == 0u;
                         const bool fight = !refill[a] && !skipped;
-                        const mask_t sel = show_bad ? lit0 : ok;
-                        const bool valid = crw.act_idx[a] >= 0 && crw.act_idx[a] < popc(sel);
+                        const bool valid = act_idx >= 0 && act_idx < popc(sel);
                         int target = 0, seen = 0;
 #pragma unroll
                         for (int c = 0; c < CMAX; ++c) {
                             const int bit = (int)((sel >> c) & 1);
-                            target = (bit && seen == crw.act_idx[a]) ? c : target;
+                            target = (bit && seen == act_idx) ? c : target;
                             seen += bit;
                         }
                         const bool attackable = ((ok >> target) & 1) != 0;
@@ -526,28 +650,10 @@ __global__ void __launch_bounds__(kRoleBlock) wf_roles_kernel(char* __restrict__
 #pragma unroll
                         for (int a = 0; a < AMAX; ++a) r_agent[e][a] = cdraws.r[e][a];
                 } else if constexpr (kPhilox) {
-                    // agent event e of agent a is draw 3 * HW + e * A + a; events 1..4 are only drawn when something reads them
-                    constexpr int U = 3 * CMAX + 5 * AMAX, J0 = (3 * CMAX) / 5, NB = (U + 4) / 5, NB_EVENT0 = (3 * CMAX + AMAX + 4) / 5;
-                    const bool need_late = (flags & (kStochRepair | kStochDegrade | kCritical | kStochRefill | kStochSwitch)) != 0 || d.K > 1;
-                    const int nb_needed = need_late ? NB : NB_EVENT0;
-                    float uni[(NB - J0) * 5];
-#pragma unroll
-                    for (int j = J0; j < NB; ++j) {
-                        const int o = 5 * (j - J0);
-                        uni[o] = uni[o + 1] = uni[o + 2] = uni[o + 3] = uni[o + 4] = 0.0f;
-                        if (j < nb_needed) {
-                            const frz::Philox4 w = frz::philox4x32_10((uint32_t)j, (uint32_t)crw.nm, 0u, 0u, crw.seed, 0x46525A00u);
-                            uni[o] = frz::philox_unit24<0>(w);
-                            uni[o + 1] = frz::philox_unit24<1>(w);
-                            uni[o + 2] = frz::philox_unit24<2>(w);
-                            uni[o + 3] = frz::philox_unit24<3>(w);
-                            uni[o + 4] = frz::philox_unit24<4>(w);
-                        }
-                    }
 #pragma unroll
                     for (int e = 0; e < 5; ++e)
 #pragma unroll
-                        for (int a = 0; a < AMAX; ++a) r_agent[e][a] = uni[3 * CMAX + e * AMAX + a - 5 * J0];
+                        for (int a = 0; a < AMAX; ++a) r_agent[e][a] = x_draw[e * AMAX + a][slot];  // drawn by the field role
                 }
 #pragma unroll
                 for (int a = 0; a < AMAX; ++a) {
@@ -589,33 +695,9 @@ __global__ void __launch_bounds__(kRoleBlock) wf_roles_kernel(char* __restrict__
                     }
                 }
             }
-            {  // agent observations (wildfire.py:677-681, 704-716)
-                const int k = d.others_k, width = (A - 1) * k;  // k = 2 + power column + suppressant column
-                const bool op = (flags & kObsPower) != 0;
 #pragma unroll
-                for (int a = 0; a < AMAX; ++a)
-                    if (a < A) {
-                        reinterpret_cast<float4*>(obs_self)[a * B + bl] = make_float4((float)d.ay[a], (float)d.ax[a], d.power[a], supp[a]);
-                        float* const others = obs_others + (a * B + bl) * (int64_t)width;
-                        int j = 0;  // record index: the other agents in agent order
-#pragma unroll
-                        for (int o = 0; o < AMAX; ++o)
-                            if (o < A && o != a) {
-                                float* const rec = others + j * k;
-                                const float y = (float)d.ay[o], x = (float)d.ax[o];
-                                if (k == 4) {
-                                    *reinterpret_cast<float4*>(rec) = make_float4(y, x, d.power[o], supp[o]);
-                                } else if (k == 3) {
-                                    rec[0] = y;
-                                    rec[1] = x;
-                                    rec[2] = op ? d.power[o] : supp[o];
-                                } else {
-                                    *reinterpret_cast<float2*>(rec) = make_float2(y, x);
-                                }
-                                ++j;
-                            }
-                    }
-            }
+            for (int a = 0; a < AMAX; ++a)
+                if (a < A) x_supp[a][slot] = supp[a];  // the field role stores the agent observations
             FRZ_RSTAMP(5);
             __syncthreads();  // (2) lit mask and fates visible
             FRZ_RSTAMP(6);
@@ -656,7 +738,14 @@ __global__ void __launch_bounds__(kRoleBlock) wf_roles_kernel(char* __restrict__
                 s_wave_live[wave][0] = live_nt;
                 s_wave_live[wave][1] = live_ntr;
             }
-            x_task_off[slot] = (uint32_t)((incl[0] - packed[0]) & 0xFFFFull);
+#pragma unroll
+            for (int w = 0; w < PW; ++w) x_excl[w][slot] = incl[w] - packed[w];
+            {
+                uint32_t oks = 0;
+#pragma unroll
+                for (int a = 0; a < AMAX; ++a) oks |= ok1[a] << (8 * a);
+                x_ok[slot] = oks;
+            }
             FRZ_RSTAMP(7);
             __syncthreads();  // (3) wavefront sums visible
 
@@ -801,44 +890,16 @@ __global__ void __launch_bounds__(kRoleBlock) wf_roles_kernel(char* __restrict__
             FRZ_RSTAMP(9);
             if (timed_out) err |= FRZ_ERR_SCAN_TIMEOUT;
 
-            // ---- phase 6: action lists (wildfire.py:586-717)
+            // ---- phase 6: the even agents' action lists (the field role writes the odd ones and the task list)
             if (active) {
-                const int64_t cap = B * HW;
-                const int64_t off_f = task_offset();
-                int64_t* const act_values = reinterpret_cast<int64_t*>(arena + d.off_act_values);
-                int64_t* const act_offsets = reinterpret_cast<int64_t*>(arena + d.off_act_offsets);
-                int64_t* const bad_values = reinterpret_cast<int64_t*>(arena + d.off_bad_values);
-                int64_t* const bad_offsets = reinterpret_cast<int64_t*>(arena + d.off_bad_offsets);
-                const bool show_bad = (flags & kShowBad) != 0;
+                const Placement place = placement();
+                const int64_t off_f = channel_offset(place, 0);
 #pragma unroll
-                for (int a = 0; a < AMAX; ++a)
-                    if (a < A) {
-                        const int w = (a + 1) >> 2, sh = 16 * ((a + 1) & 3);
-                        uint64_t excl = base[0] + incl[0] - packed[0];
-#pragma unroll
-                        for (int ww = 1; ww < PW; ++ww) excl = w == ww ? base[ww] + incl[ww] - packed[ww] : excl;
-                        const int64_t off_a = (int64_t)s_prefix[a + 1] + (int64_t)((excl >> sh) & 0xFFFFull);
-                        const int fa = popc(ok1[a]);
-                        act_offsets[a * (B + 1) + b] = off_a;
-                        if (b == B - 1) act_offsets[a * (B + 1) + B] = off_a + fa;
-                        int64_t* av = act_values + a * cap + off_a;
-                        int64_t* bv = bad_values + a * cap + (off_f - off_a);  // bad = listed but not attackable
-                        if (show_bad) {
-                            bad_offsets[a * (B + 1) + b] = off_f - off_a;
-                            if (b == B - 1) bad_offsets[a * (B + 1) + B] = (off_f - off_a) + (F - fa);
-                        }
-#pragma unroll
-                        for (int c = 0; c < CMAX; ++c) {
-                            const mask_t below = (mask_t)(((mask_t)1 << c) - 1);
-                            const int rk = popc(lit1 & below);
-                            if ((ok1[a] >> c) & 1)
-                                av[popc(ok1[a] & below)] = rk;
-                            else if (show_bad && ((lit1 >> c) & 1))
-                                bv[popc(lit1 & ~ok1[a] & below)] = rk;
-                        }
-                    }
+                for (int a = 0; a < AMAX; a += 2)
+                    if (a < A) emit_agent_lists(a, lit1, ok1[a], off_f, channel_offset(place, a + 1), b);
             }
             FRZ_RSTAMP(10);
+            FRZ_RWALL(1);
             if (err) atomicOr(error_word, err);
             cells = next_cells;
             crw = next_crw;
@@ -849,17 +910,17 @@ __global__ void __launch_bounds__(kRoleBlock) wf_roles_kernel(char* __restrict__
 
 template <int CMAX, int AMAX, bool EXACT>
 void launch_roles_variant(const WfArgs& a, const WfDev* dev, int grid, int rng, int mode, hipStream_t stream) {
-    const WfLaunch batch = make_launch(a.host_dev);
+    const WfLaunch batch = make_launch(a);
     if (mode == kRebuild) {
-        hipLaunchKernelGGL((wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kRebuild>), dim3(grid), dim3(kRoleBlock), 0, stream, a.arena,
-                           dev, a.actions, a.field_rand, a.agent_rand, batch);
+        launch_step_kernel(a, wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kRebuild>, grid, kRoleBlock, stream, a.arena, dev, a.actions,
+                           a.field_rand, a.agent_rand, batch);
     } else if (rng == FRZ_RNG_PHILOX) {
         if constexpr (EXACT)
-            hipLaunchKernelGGL((wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_PHILOX, kStep>), dim3(grid), dim3(kRoleBlock), 0, stream, a.arena,
-                               dev, a.actions, a.field_rand, a.agent_rand, batch);
+            launch_step_kernel(a, wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_PHILOX, kStep>, grid, kRoleBlock, stream, a.arena, dev, a.actions,
+                               a.field_rand, a.agent_rand, batch);
     } else {
-        hipLaunchKernelGGL((wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kStep>), dim3(grid), dim3(kRoleBlock), 0, stream, a.arena,
-                           dev, a.actions, a.field_rand, a.agent_rand, batch);
+        launch_step_kernel(a, wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kStep>, grid, kRoleBlock, stream, a.arena, dev, a.actions,
+                           a.field_rand, a.agent_rand, batch);
     }
 }
 

@@ -301,7 +301,8 @@ class raw_env(BatchedParallelEnv):
     @torch.no_grad()
     def capture_random_rollout(self, steps: int, policy_seed: int = 0, include_reset: bool = True) -> 'torch.cuda.CUDAGraph':
         """
-        Capture ``[reset] + steps x (device random policy -> fused step)`` into a HIP graph and return it.
+        Capture ``[reset] + steps x (random policy + step, one launch where the grid shape has a fused kernel)`` into a HIP
+        graph and return it.
 
         Launch-bound rollouts (one ~20 us kernel per step) are replayed with ``graph.replay()`` without per-step host
         work; results land in the same persistent buffers ``step()`` fills.  The env seeds are read at replay time
@@ -325,9 +326,26 @@ class raw_env(BatchedParallelEnv):
                                                      self.parallel_envs, stream), 'frz_mt19937_seed')
                 _capi.check(lib.frz_wildfire_reset(handle, stream), 'frz_wildfire_reset')
             for t in range(steps):
-                _capi.check(lib.frz_wildfire_random_policy(handle, policy_seed, t, actions, stream), 'frz_wildfire_random_policy')
-                _capi.check(lib.frz_wildfire_step(handle, actions, mode, None, None, stream), 'frz_wildfire_step')
+                _capi.check(lib.frz_wildfire_step_random_policy(handle, policy_seed, t, actions, mode, None, None, stream),
+                            'frz_wildfire_step_random_policy')
         return graph
+
+    @torch.no_grad()
+    def step_random_policy(self, policy_seed: int, policy_step: int):
+        """``random_policy_actions`` + ``step`` as one launch (same results as the two calls); actions are left in ``last_actions``."""
+        if not self._has_reset:
+            raise RuntimeError('reset() must be called before step_random_policy()')
+        mt = self.rng == 'mt19937'
+        if mt:
+            self.generator._ensure_streams()
+        mode = _capi.FRZ_RNG_MT19937 if mt else _capi.FRZ_RNG_PHILOX
+        _capi.check(self._lib.frz_wildfire_step_random_policy(self._handle, policy_seed, policy_step, self._actions.data_ptr(), mode, None, None,
+                                                              stream_ptr(self.device)), 'frz_wildfire_step_random_policy')
+        self._publish()
+        self.infos = {agent: {} for agent in self.agents}
+        self.infos['burnouts'] = self._burnouts
+        self.infos['putouts'] = self._putouts
+        return ({agent: self.observations[agent] for agent in self.agents}, self.rewards, self.terminations, self.truncations, self.infos)
 
     # ------------------------------------------------------------------------------------------------ spaces
     @torch.no_grad()

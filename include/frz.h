@@ -207,6 +207,18 @@ int frz_wildfire_step(frz_wildfire_env* env, const int32_t* actions, int rng_mod
  * the stream of an env depends on its seed only, so a sharded batch draws what the unsharded one draws */
 int frz_wildfire_random_policy(frz_wildfire_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out,
                                void* stream);
+/* frz_wildfire_random_policy + frz_wildfire_step as ONE launch (the random-policy rollout of baselines/random.py): the
+ * actions are sampled inside the step kernel from the same stream and left in actions_out (int32 [A][B][2]); results are
+ * identical to the two calls in sequence (once every env is terminated or truncated the step ignores its actions and
+ * actions_out is left as it is).  Grid shapes without a fused kernel run the two launches. */
+int frz_wildfire_step_random_policy(frz_wildfire_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out,
+                                    int rng_mode, const float* field_randomness, const float* agent_randomness, void* stream);
+/* Measurement aid: the same launch with the step dispatch's own begin / end timestamps taken by two HIP events on `stream`
+ * (what a profiler's kernel trace reports); synchronises on the stop event and returns the duration in milliseconds.  With
+ * a grid shape that has no fused kernel the duration is the step launch's (the policy launch is outside the bracket). */
+int frz_wildfire_step_random_policy_timed(frz_wildfire_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out,
+                                          int rng_mode, const float* field_randomness, const float* agent_randomness, void* stream,
+                                          float* kernel_ms);
 
 /* ------------------------------------------------------------------------------------------------
  * Cybersecurity  (reference: free_range_zoo/envs/cybersecurity/env/cybersecurity.py, transitions/,

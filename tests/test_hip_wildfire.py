@@ -167,6 +167,44 @@ def test_device_random_policy_matches_oracle(oracle):
     run_against_oracle(oracle, configs.wildfire_openness, dict(show_bad_actions=True), 513, 20, 10, seed=13, policy='device')
 
 
+@pytest.mark.parametrize('rng', ['philox', 'mt19937'])
+@pytest.mark.parametrize('kwargs', [{}, dict(show_bad_actions=True)])
+def test_fused_random_policy_step_equals_policy_then_step(rng, kwargs):
+    """frz_wildfire_step_random_policy (one launch) leaves exactly what random_policy + step (two launches) leave."""
+    B, steps = 3001, 25  # partial last chunk
+    two, one = [make_env(configs.wildfire_openness, B, 20, rng=rng, exact_shapes=False, **kwargs) for _ in range(2)]
+    for env in (two, one):
+        env.reset(seed=torch.arange(B, dtype=torch.int32) * 3 + 1)
+    names = ('_fires', '_intensity', '_fuel', '_suppressants', '_capacity', '_equipment', '_rewards', '_task_offsets', '_task_values',
+             '_act_map_offsets', '_act_map_values', '_obs_map_values', '_burnouts', '_putouts')
+    for t in range(steps):
+        if rng == 'mt19937':  # device-side MT19937 streams on both paths
+            acts = two.random_policy_actions(policy_seed=5, policy_step=t)
+            from free_range_zoo_amd import _capi
+            from free_range_zoo_amd.utils.env import stream_ptr
+            two.generator._ensure_streams()
+            _capi.check(two._lib.frz_wildfire_step(two._handle, acts.data_ptr(), _capi.FRZ_RNG_MT19937, None, None, stream_ptr(two.device)), 'step')
+        else:
+            two.step(two.random_policy_actions(policy_seed=5, policy_step=t))
+        live = not bool(one.finished.all())  # a frozen batch ignores its actions: the fused launch leaves the buffer untouched
+        one.step_random_policy(policy_seed=5, policy_step=t)
+        if live:
+            assert torch.equal(two._actions, one._actions), f'actions at step {t}'
+        for name in names:
+            assert torch.equal(getattr(two, name), getattr(one, name)), f'{name} at step {t}'
+        assert torch.equal(two.finished, one.finished)
+    one.check()
+
+
+@pytest.mark.parametrize('kernel', ['lane', 'roles'])
+def test_both_small_grid_kernels_match_the_oracle(oracle, kernel, monkeypatch):
+    """Grids of <= 8 cells have two kernels (FRZ_WF_KERNEL): the lane-per-env one and the field/crew wavefront pairs."""
+    monkeypatch.setenv('FRZ_WF_KERNEL', kernel)
+    run_against_oracle(oracle, configs.wildfire_openness, {}, 1500, 20, 14, seed=21, rng='philox')
+    run_against_oracle(oracle, configs.wildfire_openness, dict(show_bad_actions=True), 700, 20, 12, seed=22)
+    run_against_oracle(oracle, configs.wildfire_rich, dict(observe_other_suppressant=True), 300, 20, 10, seed=23, rng='philox')
+
+
 # ------------------------------------------------------------------------------------------------------------
 # 3. full-size properties (BASELINE.json config 2: B = 65 536)
 # ------------------------------------------------------------------------------------------------------------

@@ -23,5 +23,17 @@ for B in [int(x) for x in sys.argv[1:]] or [256, 4096, 16384, 65536, 131072, 262
             e[2].record(); ev.append(e)
         torch.cuda.synchronize()
         ts = [a[1].elapsed_time(a[2]) * 1e3 for a in ev]; tp = [a[0].elapsed_time(a[1]) * 1e3 for a in ev]
-    print(f'B={B:7d} step us median={np.median(ts):6.1f} min={np.min(ts):6.1f}  policy us median={np.median(tp):5.1f}', flush=True)
+    tf = []
+    for rep in range(3):
+        lib.frz_wildfire_reset(h, s)
+        torch.cuda.synchronize(); torch.cuda._sleep(int(2.0e9 * 0.02))
+        ev = []
+        for t in range(45):
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            e[0].record(); lib.frz_wildfire_step_random_policy(h, 1, t, env._actions.data_ptr(), _capi.FRZ_RNG_PHILOX, None, None, s)
+            e[1].record(); ev.append(e)
+        torch.cuda.synchronize()
+        tf = [a[0].elapsed_time(a[1]) * 1e3 for a in ev]
+    print(f'B={B:7d} step us median={np.median(ts):6.1f} min={np.min(ts):6.1f}  policy us median={np.median(tp):5.1f}  '
+          f'fused policy+step us median={np.median(tf):6.1f} min={np.min(tf):6.1f}', flush=True)
     del env

@@ -30,6 +30,18 @@ for B in [int(x) for x in sys.argv[1:]] or [256, 65536]:
         off = bufs.mt_state - env._arena.data_ptr() - ((5 * B * 3 * 4 + 255) // 256) * 256
         st = env._arena[off:off + 32 * 8].view(torch.int64).cpu().numpy().astype(np.int64)
         rows.append(st.copy())
+        if roles and t == 29 and B >= 65536:
+            offf = off - ((3 * B * 6 * 4 + 255) // 256) * 256  # field-randomness staging region precedes the agent one
+            n = (B + 255) // 256
+            wall = env._arena[offf:offf + n * 32].view(torch.int64).cpu().numpy().astype(np.int64).reshape(n, 4)
+            t00 = wall[:, [0, 2]].min()
+            start = wall[:, [0, 2]].min(axis=1) - t00
+            end = wall[:, [1, 3]].max(axis=1) - t00
+            q = lambda v: ' '.join(f'{x * 10:7.0f}' for x in np.percentile(v, [0, 10, 50, 90, 100]))
+            print(f'--- B={B}: per-workgroup wall clock, ns since the first workgroup started (min p10 p50 p90 max)')
+            print(f'  start {q(start)}')
+            print(f'  end   {q(end)}')
+            print(f'  life  {q(end - start)}')
     st = np.array(rows[5:])
     if roles:
         t0 = st[:, 0:1]
