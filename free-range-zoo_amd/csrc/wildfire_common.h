@@ -7,6 +7,7 @@
 
 #include "../../include/frz.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace frz_wf {
@@ -78,6 +79,7 @@ struct WfLaunch {
     int64_t off_rows1, off_epoch, off_totals;
     uint32_t policy_seed_lo, policy_seed_hi, policy_step_lo, policy_step_hi;
     int32_t* actions_out;  // where the sampled actions are left (policy == 1), int32 [A][B][2]
+    uint32_t skip;         // diagnostic builds only (-DFRZ_WF_EXPERIMENT): store groups to leave out when timing; 0 in the product
 };
 
 struct WfArgs {
@@ -102,10 +104,24 @@ inline void launch_step_kernel(const WfArgs& a, K kernel, int grid, int block, h
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, args...);
 }
 
+inline uint32_t experiment_skip() {
+#ifdef FRZ_WF_EXPERIMENT
+    const char* v = std::getenv("FRZ_WF_SKIP");
+    return v ? (uint32_t)std::atoi(v) : 0u;
+#else
+    return 0u;
+#endif
+}
+#ifdef FRZ_WF_EXPERIMENT
+#define FRZ_SKIP(bit) ((launch.skip >> (bit)) & 1u)
+#else
+#define FRZ_SKIP(bit) false
+#endif
+
 inline WfLaunch make_launch(const WfArgs& a) {
     const WfDev* host = a.host_dev;
     return WfLaunch{host->B, a.policy ? 1u : 0u, host->off_rows1, host->off_epoch, host->off_totals, (uint32_t)a.policy_seed,
-                    (uint32_t)(a.policy_seed >> 32), (uint32_t)a.policy_step, (uint32_t)(a.policy_step >> 32), a.actions_out};
+                    (uint32_t)(a.policy_seed >> 32), (uint32_t)a.policy_step, (uint32_t)(a.policy_step >> 32), a.actions_out, experiment_skip()};
 }
 
 // Staging the configuration: the 16-byte piece is requested by the kernel's FIRST vector-memory instruction (before the

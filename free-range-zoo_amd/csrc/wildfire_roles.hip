@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(kRoleBlock) wf_roles_kernel(char* __restrict__
             const int next_chunk = chunk + (int)gridDim.x;
             // per-iteration opaque copy: keeps the flag tests next to their uses (a launch usually runs ONE iteration per
             // workgroup; hoisted out of the loop they would all sit in scalar registers from the top of the kernel and spill)
-            uint32_t flags = flags_word;
+            uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)flags_word);
             asm volatile("" : "+s"(flags));
             int f[CMAX], in[CMAX], fu[CMAX];
 #pragma unroll
@@ -466,7 +466,7 @@ __global__ void __launch_bounds__(kRoleBlock) wf_roles_kernel(char* __restrict__
             FRZ_RSTAMP(6);
 
             // ---- phase 3: cell rows (the crew scans meanwhile)
-            if (MODE == kStep) {
+            if (MODE == kStep && !FRZ_SKIP(2)) {
 #pragma unroll
                 for (int c = 0; c < CMAX; ++c)
                     if (c < HW) {
@@ -475,31 +475,42 @@ __global__ void __launch_bounds__(kRoleBlock) wf_roles_kernel(char* __restrict__
                         at32(rows, (uint32_t)(r_fuel + c) * Bu + bl) = fu[c];
                     }
             }
-            {  // agent observations (wildfire.py:677-681, 704-716): the suppressants arrive from the crew
+            if (!FRZ_SKIP(1)) {  // agent observations (wildfire.py:677-681, 704-716): the suppressants arrive from the crew
+                // Agents do not move and their base power is configuration: of an observation record only the suppressant
+                // column changes from step to step.  reset / rebuild write whole records; a step rewrites only that column
+                // (the records stay what the reference would rebuild; nothing is written twice with the same bytes).
                 float supp[AMAX];
 #pragma unroll
                 for (int a = 0; a < AMAX; ++a) supp[a] = a < A ? x_supp[a][slot] : 0.0f;
                 const int k = d.others_k, width = (A - 1) * k;  // k = 2 + power column + suppressant column
-                const bool op = (flags & kObsPower) != 0;
+                const bool op = (flags & kObsPower) != 0, os = (flags & kObsSupp) != 0;
+                const bool whole = MODE != kStep || FRZ_SKIP(6);
 #pragma unroll
                 for (int a = 0; a < AMAX; ++a)
                     if (a < A) {
-                        reinterpret_cast<float4*>(obs_self)[a * B + bl] = make_float4((float)d.ay[a], (float)d.ax[a], d.power[a], supp[a]);
+                        if (whole)
+                            reinterpret_cast<float4*>(obs_self)[a * B + bl] = make_float4((float)d.ay[a], (float)d.ax[a], d.power[a], supp[a]);
+                        else
+                            obs_self[(a * B + bl) * 4 + 3] = supp[a];
                         float* const others = obs_others + (a * B + bl) * (int64_t)width;
                         int j = 0;  // record index: the other agents in agent order
 #pragma unroll
                         for (int o = 0; o < AMAX; ++o)
                             if (o < A && o != a) {
                                 float* const rec = others + j * k;
-                                const float y = (float)d.ay[o], x = (float)d.ax[o];
-                                if (k == 4) {
-                                    *reinterpret_cast<float4*>(rec) = make_float4(y, x, d.power[o], supp[o]);
-                                } else if (k == 3) {
-                                    rec[0] = y;
-                                    rec[1] = x;
-                                    rec[2] = op ? d.power[o] : supp[o];
-                                } else {
-                                    *reinterpret_cast<float2*>(rec) = make_float2(y, x);
+                                if (whole) {
+                                    const float y = (float)d.ay[o], x = (float)d.ax[o];
+                                    if (k == 4) {
+                                        *reinterpret_cast<float4*>(rec) = make_float4(y, x, d.power[o], supp[o]);
+                                    } else if (k == 3) {
+                                        rec[0] = y;
+                                        rec[1] = x;
+                                        rec[2] = op ? d.power[o] : supp[o];
+                                    } else {
+                                        *reinterpret_cast<float2*>(rec) = make_float2(y, x);
+                                    }
+                                } else if (os) {
+                                    rec[k - 1] = supp[o];  // the suppressant column is the last one
                                 }
                                 ++j;
                             }
@@ -567,7 +578,7 @@ __global__ void __launch_bounds__(kRoleBlock) wf_roles_kernel(char* __restrict__
             const int next_chunk = chunk + (int)gridDim.x;
             // per-iteration opaque copy: keeps the flag tests next to their uses (a launch usually runs ONE iteration per
             // workgroup; hoisted out of the loop they would all sit in scalar registers from the top of the kernel and spill)
-            uint32_t flags = flags_word;
+            uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)flags_word);
             asm volatile("" : "+s"(flags));
             uint32_t err = 0;
             float supp[AMAX], capa[AMAX], rew[AMAX];

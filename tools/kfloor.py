@@ -1,5 +1,7 @@
 """Latency floor probe: fused wildfire step launch timed through the C-ABI only (no Python work between the events)."""
 import os, sys
+if os.environ.get('FRZ_WF_SKIP'):  # timing experiments need the diagnostic build
+    os.environ.setdefault('FRZ_HIP_LIB', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'free-range-zoo_amd', 'csrc', 'libfrz_hip_stamps.so'))
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, torch, configs
