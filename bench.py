@@ -184,16 +184,27 @@ def main():
     env.reset(seed=base_seed + 17)
     stream = stream_ptr(device)
     torch.cuda.synchronize(device)
+    done = 0
+    while done < n_probe:  # one episode at a time: reset, then the episode's steps back to back, each with its own event pair
+        n = min(EPISODE, n_probe - done)
+        if done > 0:
+            env.seeds.add_(seed_stride)
+            if args.rng == 'mt19937':
+                env.generator._seed_streams(None)
+            lib.frz_wildfire_reset(handle, stream)
+        out = (ctypes.c_float * n)()
+        _capi.check(lib.frz_wildfire_timed_rollout(handle, 20260104 + rank, 0, n, env._actions.data_ptr(), mode, stream, out), 'frz_wildfire_timed_rollout')
+        kernel_ms.extend(out[i] for i in range(n))
+        done += n
+    # mean task counts for the algorithmic bytes: the same episodes again, step by step (not timed)
+    env.reset(seed=base_seed + 17)
     for i in range(n_probe):
         if i % EPISODE == 0 and i > 0:
             env.seeds.add_(seed_stride)
             if args.rng == 'mt19937':
                 env.generator._seed_streams(None)
             lib.frz_wildfire_reset(handle, stream)
-        ms = ctypes.c_float(0.0)
-        _capi.check(lib.frz_wildfire_step_random_policy_timed(handle, 20260104 + rank, i % EPISODE, env._actions.data_ptr(), mode, None, None, stream,
-                                                              ctypes.byref(ms)), 'frz_wildfire_step_random_policy_timed')
-        kernel_ms.append(ms.value)
+        lib.frz_wildfire_step_random_policy(handle, 20260104 + rank, i % EPISODE, env._actions.data_ptr(), mode, None, None, stream)
         task_sum[0] += env.environment_task_count.sum()
         task_sum[1:] += env.agent_task_count.sum(dim=1)
     torch.cuda.synchronize(device)

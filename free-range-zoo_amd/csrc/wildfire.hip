@@ -22,6 +22,7 @@
 #include <cstring>
 #include <new>
 #include <type_traits>
+#include <vector>
 
 #include "wildfire_common.h"
 
@@ -833,8 +834,10 @@ struct frz_wildfire_env {
     bool fused_policy = false;
     uint64_t policy_seed = 0, policy_step = 0;
     int32_t* actions_out = nullptr;
-    hipEvent_t start_event = nullptr, stop_event = nullptr;  // created on the first timed step
+    hipEvent_t start_event = nullptr, stop_event = nullptr;  // the pair the next timed launch records into
+    std::vector<hipEvent_t> timing_events;                   // pool of frz_wildfire_timed_rollout
     bool timed = false;
+    bool ticketed = false;  // field/crew kernels: more chunks than resident workgroups
 };
 
 namespace {
@@ -910,7 +913,8 @@ int launch(frz_wildfire_env* env, const WfArgs& args, int rng, int mode, hipStre
     if (env->dev.roles) {
         WfArgs a = args;
         if (!kVariants[env->variant].exact && mode == kStep && rng == FRZ_RNG_PHILOX) stage_philox(a, rng, stream);
-        return launch_roles(a, env->variant, env->grid, rng, mode, stream);
+        a.ticketed = env->ticketed;
+        return launch_roles(a, env->variant, env->dev.nchunks, rng, mode, stream);  // one workgroup per chunk
     }
     switch (env->variant) {
         case 0: launch_variant<6, 3, true>(args, env->grid, rng, mode, stream); break;   // BASELINE.json cfg1/cfg2 shape
@@ -1135,14 +1139,14 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
     const int64_t capacity = (int64_t)cus * per_cu;
     const int64_t rounds = (p.nchunks + capacity - 1) / capacity;
     env->grid = (int)((p.nchunks + rounds - 1) / rounds);
+    env->ticketed = p.roles && p.nchunks > cus;  // one 512-thread workgroup per CU is always resident
     *out = env;
     return FRZ_OK;
 }
 
 void frz_wildfire_destroy(frz_wildfire_env* env) {
     if (!env) return;
-    if (env->start_event) (void)hipEventDestroy(env->start_event);
-    if (env->stop_event) (void)hipEventDestroy(env->stop_event);
+    for (hipEvent_t e : env->timing_events) (void)hipEventDestroy(e);
     delete env;
 }
 
@@ -1282,17 +1286,26 @@ int frz_wildfire_step_random_policy(frz_wildfire_env* env, uint64_t policy_seed,
     return rc;
 }
 
-int frz_wildfire_step_random_policy_timed(frz_wildfire_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out, int rng_mode,
-                                          const float* field_randomness, const float* agent_randomness, void* stream, float* kernel_ms) {
-    if (!env || !kernel_ms) return FRZ_E_INVALID;
-    if (!env->start_event && (hipEventCreate(&env->start_event) != hipSuccess || hipEventCreate(&env->stop_event) != hipSuccess))
-        return FRZ_E_LAUNCH;
-    env->timed = true;
-    const int rc = frz_wildfire_step_random_policy(env, policy_seed, policy_step, actions_out, rng_mode, field_randomness, agent_randomness, stream);
-    env->timed = false;
+int frz_wildfire_timed_rollout(frz_wildfire_env* env, uint64_t policy_seed, uint64_t first_step, int32_t n_steps, int32_t* actions_out,
+                               int rng_mode, void* stream, float* kernel_ms) {
+    if (!env || !kernel_ms || n_steps <= 0) return FRZ_E_INVALID;
+    while ((int)env->timing_events.size() < 2 * n_steps) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return FRZ_E_LAUNCH;
+        env->timing_events.push_back(e);
+    }
+    int rc = FRZ_OK;
+    for (int i = 0; i < n_steps && rc == FRZ_OK; ++i) {  // back to back: no host synchronisation between the launches
+        env->start_event = env->timing_events[2 * i];
+        env->stop_event = env->timing_events[2 * i + 1];
+        env->timed = true;
+        rc = frz_wildfire_step_random_policy(env, policy_seed, first_step + (uint64_t)i, actions_out, rng_mode, nullptr, nullptr, stream);
+        env->timed = false;
+    }
     if (rc != FRZ_OK) return rc;
-    if (hipEventSynchronize(env->stop_event) != hipSuccess || hipEventElapsedTime(kernel_ms, env->start_event, env->stop_event) != hipSuccess)
-        return FRZ_E_LAUNCH;
+    if (hipStreamSynchronize(static_cast<hipStream_t>(stream)) != hipSuccess) return FRZ_E_LAUNCH;
+    for (int i = 0; i < n_steps; ++i)
+        if (hipEventElapsedTime(&kernel_ms[i], env->timing_events[2 * i], env->timing_events[2 * i + 1]) != hipSuccess) return FRZ_E_LAUNCH;
     return FRZ_OK;
 }
 

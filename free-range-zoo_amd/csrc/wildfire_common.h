@@ -79,6 +79,7 @@ struct WfLaunch {
     int64_t off_rows1, off_epoch, off_totals;
     uint32_t policy_seed_lo, policy_seed_hi, policy_step_lo, policy_step_hi;
     int32_t* actions_out;  // where the sampled actions are left (policy == 1), int32 [A][B][2]
+    uint32_t ticketed;     // 1: chunks are handed out in arrival order (more chunks than resident workgroups)
     uint32_t skip;         // diagnostic builds only (-DFRZ_WF_EXPERIMENT): store groups to leave out when timing; 0 in the product
 };
 
@@ -93,6 +94,7 @@ struct WfArgs {
     int32_t* actions_out = nullptr;
     // optional: events that receive the step dispatch's own begin / end timestamps (frz_wildfire_step_random_policy_timed)
     hipEvent_t start_event = nullptr, stop_event = nullptr;
+    bool ticketed = false;  // field/crew kernels: one workgroup per chunk, chunks handed out in arrival order
 };
 
 // launch a step kernel; with timing events the dispatch itself is bracketed (what a profiler's kernel trace reports)
@@ -121,7 +123,7 @@ inline uint32_t experiment_skip() {
 inline WfLaunch make_launch(const WfArgs& a) {
     const WfDev* host = a.host_dev;
     return WfLaunch{host->B, a.policy ? 1u : 0u, host->off_rows1, host->off_epoch, host->off_totals, (uint32_t)a.policy_seed,
-                    (uint32_t)(a.policy_seed >> 32), (uint32_t)a.policy_step, (uint32_t)(a.policy_step >> 32), a.actions_out, experiment_skip()};
+                    (uint32_t)(a.policy_seed >> 32), (uint32_t)a.policy_step, (uint32_t)(a.policy_step >> 32), a.actions_out, a.ticketed ? 1u : 0u, experiment_skip()};
 }
 
 // Staging the configuration: the 16-byte piece is requested by the kernel's FIRST vector-memory instruction (before the

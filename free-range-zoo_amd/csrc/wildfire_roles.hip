@@ -25,6 +25,7 @@ namespace frz_wf {
 namespace {
 
 constexpr int kRoleBlock = 2 * kBlock;  // 4 field + 4 crew wavefronts per 256-env chunk
+constexpr int kRound = 256;             // look-back window: a chunk sums at most kRound - 1 predecessors' granules + one prefix granule
 
 // Diagnostic build only (-DFRZ_WF_STAMPS, tools/stamps.py): the first thread of each role of workgroup 0 records the
 // shader clock at phase boundaries into a buffer nothing else reads.  No stamp executes in the production library.
@@ -53,7 +54,7 @@ constexpr int kRoleBlock = 2 * kBlock;  // 4 field + 4 crew wavefronts per 256-e
 #endif
 
 template <int CMAX, int AMAX, bool EXACT, int RNG, int MODE>
-__global__ void __launch_bounds__(kRoleBlock) wf_roles_kernel(char* __restrict__ arena, const WfDev* __restrict__ dev,
+__global__ void __launch_bounds__(kRoleBlock, 4) wf_roles_kernel(char* __restrict__ arena, const WfDev* __restrict__ dev,
                                                                const int32_t* __restrict__ actions, const float* __restrict__ field_rand,
                                                                const float* __restrict__ agent_rand, const WfLaunch launch) {
     const int32_t batch = launch.batch;
@@ -213,14 +214,31 @@ __global__ void __launch_bounds__(kRoleBlock) wf_roles_kernel(char* __restrict__
 
     FRZ_RSTAMP(0);
     FRZ_RWALL(0);
-    // first chunk's loads: in flight while the configuration is staged
+    // One chunk per workgroup.  A launch with no more chunks than resident workgroups maps chunk = blockIdx.x; a larger one
+    // hands chunks out in arrival order (a ticket): every chunk a workgroup waits on in the hand-off then belongs to a
+    // workgroup that has already started, so the launch cannot stall on a workgroup that is not resident yet.  No loop
+    // over chunks: the kernel body is straight-line code per role (a chunk loop made the compiler hoist every
+    // loop-invariant scalar in front of it: +~700 instructions and ~60 spilled scalar registers per wavefront).
+    __shared__ int s_ticket;
+    int chunk = blockIdx.x;
+    if (launch.ticketed) {
+        uint32_t* const counter = reinterpret_cast<uint32_t*>(arena + launch.off_epoch) + 32;
+        if (tid == 0) {
+            const uint32_t t = atomicAdd(counter, 1u);
+            if (t == (uint32_t)nchunks - 1u) atomicExch(counter, 0u);  // every ticket of this launch is out: ready for the next launch
+            s_ticket = (int)t;
+        }
+        __syncthreads();
+        chunk = s_ticket;
+    }
+    // the chunk's loads: in flight while the configuration is staged
     FDraws fdraws;
     CDraws cdraws;
-    Cells cells = load_cells(blockIdx.x);
+    Cells cells = load_cells(chunk);
     FieldRegs fld;
     CrewRegs crw;
-    if (!crew) fld = load_field(blockIdx.x, fdraws);
-    else crw = load_crew(blockIdx.x, cdraws);
+    if (!crew) fld = load_field(chunk, fdraws);
+    else crw = load_crew(chunk, cdraws);
 
     const WfHot d = stage_commit(s_cfg, cfg_piece);  // configuration block at arena offset 0; never written by a kernel
     FRZ_RSTAMP(1);
@@ -249,7 +267,7 @@ __global__ void __launch_bounds__(kRoleBlock) wf_roles_kernel(char* __restrict__
         if (nt == 0u || ntr == 0u) {
             // The parallel adapter (utils/conversions.py:87-90) then adds the stale aec rewards once per agent call.
             if (!crew)
-                for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+                {
                     const int64_t b = (int64_t)chunk * kBlock + slot;
                     if (b < B && !at32(rows1, u_frozen * Bu + (uint32_t)b)) {
                         for (int a = 0; a < A; ++a) {
@@ -326,11 +344,10 @@ __global__ void __launch_bounds__(kRoleBlock) wf_roles_kernel(char* __restrict__
     // region of the program so that its registers are allocated for that role alone.
     if (!crew) {
         // ============================================================================================ FIELD ROLE
-        for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        {
             const int64_t b = (int64_t)chunk * kBlock + slot;
             const bool active = b < B;
             const uint32_t bl = (uint32_t)(active ? b : B - 1);
-            const int next_chunk = chunk + (int)gridDim.x;
             // per-iteration opaque copy: keeps the flag tests next to their uses (a launch usually runs ONE iteration per
             // workgroup; hoisted out of the loop they would all sit in scalar registers from the top of the kernel and spill)
             uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)flags_word);
@@ -519,14 +536,7 @@ __global__ void __launch_bounds__(kRoleBlock) wf_roles_kernel(char* __restrict__
             FRZ_RSTAMP(7);
             __syncthreads();  // (3) wavefront sums visible
 
-            // ---- phase 4: next chunk's loads
-            Cells next_cells = cells;
-            FieldRegs next_fld = fld;
-            FDraws next_fdraws = fdraws;
-            if (next_chunk < nchunks) {
-                next_cells = load_cells(next_chunk);
-                next_fld = load_field(next_chunk, next_fdraws);
-            }
+            // ---- phase 4 belongs to the crew (hand-off)
             FRZ_RSTAMP(8);
             __syncthreads();  // (4)
             __syncthreads();  // (5) chunk prefix visible
@@ -565,17 +575,13 @@ __global__ void __launch_bounds__(kRoleBlock) wf_roles_kernel(char* __restrict__
             // The workgroup owning the last chunk finished its look-back only after every other chunk published, i.e.
             // after every workgroup of this launch read the epoch: it can advance it for the next launch.
             if (chunk == nchunks - 1 && tid == 0) __hip_atomic_store(epoch_ptr, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            cells = next_cells;
-            fld = next_fld;
-            fdraws = next_fdraws;
         }
     } else {
         // ============================================================================================= CREW ROLE
-        for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        {
             const int64_t b = (int64_t)chunk * kBlock + slot;
             const bool active = b < B;
             const uint32_t bl = (uint32_t)(active ? b : B - 1);
-            const int next_chunk = chunk + (int)gridDim.x;
             // per-iteration opaque copy: keeps the flag tests next to their uses (a launch usually runs ONE iteration per
             // workgroup; hoisted out of the loop they would all sit in scalar registers from the top of the kernel and spill)
             uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)flags_word);
@@ -761,7 +767,7 @@ __global__ void __launch_bounds__(kRoleBlock) wf_roles_kernel(char* __restrict__
             __syncthreads();  // (3) wavefront sums visible
 
             // ---- phase 4: chunk sums published; rewards / bookkeeping hide the hand-off; look-back
-            const int round_first = chunk - blockIdx.x;  // first chunk of this round
+            const int round_first = chunk & ~(kRound - 1);  // chunks are handed off in windows of kRound
             uint64_t block_total[PW];
 #pragma unroll
             for (int w = 0; w < PW; ++w) {
@@ -840,14 +846,6 @@ __global__ void __launch_bounds__(kRoleBlock) wf_roles_kernel(char* __restrict__
                     if (a < A) at32(rows, (uint32_t)(r_atc + a) * Bu + bl) = popc(ok1[a]);
                 at32(rows8, q_etc * Bu + bl) = F;
             }
-            Cells next_cells = cells;
-            CrewRegs next_crw = crw;
-            CDraws next_cdraws = cdraws;
-            if (next_chunk < nchunks) {
-                next_cells = load_cells(next_chunk);
-                next_crw = load_crew(next_chunk, next_cdraws);
-            }
-
             // inter-workgroup exclusive prefix (single pass), as in wildfire.hip: crew thread t sums channel (t % NCHP) over
             // predecessors t / NCHP, t / NCHP + PP, ...; the window's loads are unconditional so they are in flight together
             bool timed_out = false;
@@ -891,7 +889,7 @@ __global__ void __launch_bounds__(kRoleBlock) wf_roles_kernel(char* __restrict__
 #pragma unroll
                 for (int j = 0; j < frz::kWaves; ++j) s += s_reduce[j][slot];
                 s_prefix[slot] = s;
-                const bool round_last = blockIdx.x == gridDim.x - 1 || chunk == nchunks - 1;
+                const bool round_last = (chunk & (kRound - 1)) == kRound - 1 || chunk == nchunks - 1;
                 if (round_last) {
                     frz::granule_store(prefix + (int64_t)chunk * nch + slot, tag, s + my_total);
                     if (chunk == nchunks - 1) cur_totals[slot] = s + my_total;  // batch totals, read by the next launch
@@ -912,9 +910,6 @@ __global__ void __launch_bounds__(kRoleBlock) wf_roles_kernel(char* __restrict__
             FRZ_RSTAMP(10);
             FRZ_RWALL(1);
             if (err) atomicOr(error_word, err);
-            cells = next_cells;
-            crw = next_crw;
-            cdraws = next_cdraws;
         }
     }
 }

@@ -213,12 +213,12 @@ int frz_wildfire_random_policy(frz_wildfire_env* env, uint64_t policy_seed, uint
  * actions_out is left as it is).  Grid shapes without a fused kernel run the two launches. */
 int frz_wildfire_step_random_policy(frz_wildfire_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out,
                                     int rng_mode, const float* field_randomness, const float* agent_randomness, void* stream);
-/* Measurement aid: the same launch with the step dispatch's own begin / end timestamps taken by two HIP events on `stream`
- * (what a profiler's kernel trace reports); synchronises on the stop event and returns the duration in milliseconds.  With
- * a grid shape that has no fused kernel the duration is the step launch's (the policy launch is outside the bracket). */
-int frz_wildfire_step_random_policy_timed(frz_wildfire_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out,
-                                          int rng_mode, const float* field_randomness, const float* agent_randomness, void* stream,
-                                          float* kernel_ms);
+/* Measurement aid: n_steps launches of frz_wildfire_step_random_policy (policy steps first_step ...), back to back with no
+ * host synchronisation in between, each bracketed by its own pair of HIP events that take the step dispatch's begin / end
+ * timestamps on `stream` (what a profiler's kernel trace reports); synchronises once at the end and returns the durations
+ * in milliseconds.  Randomness is drawn in-kernel or from the env's MT19937 streams (rng_mode != FRZ_RNG_INJECTED). */
+int frz_wildfire_timed_rollout(frz_wildfire_env* env, uint64_t policy_seed, uint64_t first_step, int32_t n_steps, int32_t* actions_out,
+                               int rng_mode, void* stream, float* kernel_ms);
 
 /* ------------------------------------------------------------------------------------------------
  * Cybersecurity  (reference: free_range_zoo/envs/cybersecurity/env/cybersecurity.py, transitions/,
