@@ -81,8 +81,9 @@ __global__ void __launch_bounds__(kBlock) cy_fill_kernel(char* arena) {
 template <int NMAX, int AMAX, int RNG, int MODE>
 __global__ void __launch_bounds__(kBlock) cy_step_kernel(char* __restrict__ arena, const CyDev* __restrict__ dev,
                                                           const int32_t* __restrict__ actions, const float* __restrict__ net_rand,
-                                                          const float* __restrict__ agent_rand) {
+                                                          const float* __restrict__ agent_rand, uint32_t ticketed) {
     __shared__ frz::ScanShared<AMAX> s_scan;
+    __shared__ int s_ticket;
     __shared__ float s_lut[kLdsLutEntries];
     __shared__ float s_state_rewards[FRZ_MAX_NETWORK_STATES];
 
@@ -113,7 +114,8 @@ __global__ void __launch_bounds__(kBlock) cy_step_kernel(char* __restrict__ aren
     if (MODE == kStep) frozen = launch.prev[A] == 0u || launch.prev[A + 1] == 0u;
     __syncthreads();
 
-    for (int chunk = blockIdx.x; chunk < d.nchunks; chunk += gridDim.x) {
+    {  // one chunk per workgroup (no chunk loop: see wildfire_roles.hip)
+        const int chunk = frz::scan_take_chunk(ws, d.nchunks, ticketed != 0, &s_ticket);
         const int64_t b = (int64_t)chunk * kBlock + tid;
         const bool active = b < B;
         const uint32_t bl = (uint32_t)(active ? b : B - 1);
@@ -128,7 +130,7 @@ __global__ void __launch_bounds__(kBlock) cy_step_kernel(char* __restrict__ aren
                 }
                 at32(rows1, (uint32_t)d.u_frozen * Bu + bl) = 1;
             }
-            continue;
+            return;
         }
 
         // ------------------------------------------------------------------------------------------ load state
@@ -417,7 +419,7 @@ struct frz_cybersecurity_env {
     std::vector<float> lut;
     char* arena = nullptr;
     bool was_reset = false;
-    int grid = 0;
+    bool ticketed = false;  // more chunks than CUs: chunks are handed out in arrival order (frz_scan.h)
     int variant = 0;
 };
 
@@ -429,13 +431,13 @@ template <int NMAX, int AMAX>
 void launch_variant(frz_cybersecurity_env* env, const int32_t* actions, const float* nr, const float* ar, int rng, int mode,
                     hipStream_t stream) {
     const CyDev* dev = reinterpret_cast<const CyDev*>(env->arena);
-    const dim3 grid(env->grid), block(kBlock);
+    const dim3 grid(env->dev.nchunks), block(kBlock);
     if (mode == kRebuild)
-        hipLaunchKernelGGL((cy_step_kernel<NMAX, AMAX, FRZ_RNG_INJECTED, kRebuild>), grid, block, 0, stream, env->arena, dev, actions, nr, ar);
+        hipLaunchKernelGGL((cy_step_kernel<NMAX, AMAX, FRZ_RNG_INJECTED, kRebuild>), grid, block, 0, stream, env->arena, dev, actions, nr, ar, env->ticketed ? 1u : 0u);
     else if (rng == FRZ_RNG_PHILOX)
-        hipLaunchKernelGGL((cy_step_kernel<NMAX, AMAX, FRZ_RNG_PHILOX, kStep>), grid, block, 0, stream, env->arena, dev, actions, nr, ar);
+        hipLaunchKernelGGL((cy_step_kernel<NMAX, AMAX, FRZ_RNG_PHILOX, kStep>), grid, block, 0, stream, env->arena, dev, actions, nr, ar, env->ticketed ? 1u : 0u);
     else
-        hipLaunchKernelGGL((cy_step_kernel<NMAX, AMAX, FRZ_RNG_INJECTED, kStep>), grid, block, 0, stream, env->arena, dev, actions, nr, ar);
+        hipLaunchKernelGGL((cy_step_kernel<NMAX, AMAX, FRZ_RNG_INJECTED, kStep>), grid, block, 0, stream, env->arena, dev, actions, nr, ar, env->ticketed ? 1u : 0u);
 }
 
 int launch(frz_cybersecurity_env* env, const int32_t* actions, const float* nr, const float* ar, int rng, int mode, hipStream_t stream) {
@@ -559,10 +561,7 @@ int frz_cybersecurity_create(const frz_cybersecurity_cfg* cfg, frz_cybersecurity
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     }
-    const int per_cu = p.nchunks >= 4 * cus ? 2 : 1;  // co-resident persistent grid (see wildfire.hip)
-    const int64_t capacity = (int64_t)cus * per_cu;
-    const int64_t rounds = (p.nchunks + capacity - 1) / capacity;
-    env->grid = (int)((p.nchunks + rounds - 1) / rounds);
+    env->ticketed = p.nchunks > cus;  // one workgroup per chunk; one 256-thread workgroup per CU is always resident
     *out = env;
     return FRZ_OK;
 }

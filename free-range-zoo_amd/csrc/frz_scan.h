@@ -3,9 +3,11 @@
 // The open action / observation lists of the reference are jagged tensors in env-major order: env b's segment starts at
 // the sum of the counts of all envs < b.  Each workgroup (256 envs = one chunk) scans its envs with wavefront shuffles
 // (counts packed four 16-bit channels per 64-bit word), combines its four waves through LDS, publishes the chunk sums
-// as epoch-tagged 8-byte granules and reads the sums of the preceding chunks of its round (co-resident persistent grid)
-// plus the inclusive prefix the previous round's last chunk published.  The batch totals of every channel are left
-// for the next launch (freeze detection, batch-global quirks).  See wildfire.hip for the same scheme written inline.
+// as epoch-tagged 8-byte granules and reads the sums of the preceding chunks of its window (kRound chunks) plus the
+// inclusive prefix the previous window's last chunk published.  The batch totals of every channel are left for the next
+// launch (freeze detection, batch-global quirks).  One chunk per workgroup: chunk = blockIdx.x while the grid is
+// co-resident (at most one workgroup per CU), otherwise chunks are handed out in arrival order (scan_take_chunk), so a
+// chunk only waits on chunks whose workgroups have started.  See wildfire_roles.hip for the same scheme written inline.
 #pragma once
 
 #include "frz_device.h"
@@ -13,10 +15,11 @@
 namespace frz {
 
 constexpr int kTotalsStride = 32;  // uint32 words per totals slot (channels 0..31)
+constexpr int kRound = 256;        // look-back window: a chunk sums at most kRound - 1 granules per channel + one prefix granule
 
 // workspace words shared by every launch of one env object (zero-filled once by the caller)
 struct ScanWorkspace {
-    uint32_t* epoch;   // [1]
+    uint32_t* epoch;   // [1]; word 32 of the same 256-byte block is the chunk ticket counter
     uint32_t* totals;  // [2][kTotalsStride]
     uint64_t* agg;     // [nchunks][nch_total]
     uint64_t* prefix;  // [nchunks][nch_total]
@@ -45,6 +48,20 @@ __device__ __forceinline__ ScanLaunch scan_begin(const ScanWorkspace& ws) {
     return l;
 }
 
+// The chunk this workgroup processes.  ticketed: arrival order (one atomic per workgroup; the holder of the last ticket
+// re-arms the counter for the next launch: every ticket of this launch is out by then).
+__device__ __forceinline__ int scan_take_chunk(const ScanWorkspace& ws, int nchunks, bool ticketed, int* lds_word) {
+    if (!ticketed) return (int)blockIdx.x;
+    if (threadIdx.x == 0) {
+        uint32_t* const counter = ws.epoch + 32;
+        const uint32_t t = atomicAdd(counter, 1u);
+        if (t == (uint32_t)nchunks - 1u) atomicExch(counter, 0u);
+        *lds_word = (int)t;
+    }
+    __syncthreads();
+    return *lds_word;
+}
+
 // cnt[ch] < 65536 / 256 per env (counts are packed in 16-bit fields over a 256-env chunk).
 // On return excl[ch] = sum of cnt[ch] over all envs of the launch that precede this lane's env.
 // Channels nch and nch + 1 of the granules / totals carry the number of envs with live0 / live1 set.
@@ -66,7 +83,7 @@ __device__ __forceinline__ void scan_chunk(ScanShared<NCH>& sh, const ScanWorksp
 #pragma unroll
     for (int w = 0; w < PW; ++w) incl[w] = wave_inclusive_scan(packed[w]);
     const uint32_t n0 = (uint32_t)__popcll(__ballot(live0)), n1 = (uint32_t)__popcll(__ballot(live1));
-    __syncthreads();  // LDS reuse across chunks of a persistent workgroup
+    __syncthreads();
     if (lane == 63) {
 #pragma unroll
         for (int w = 0; w < PW; ++w) sh.wave_scan[wave][w] = incl[w];
@@ -103,7 +120,7 @@ __device__ __forceinline__ void scan_chunk(ScanShared<NCH>& sh, const ScanWorksp
     }
 
     // sums of the preceding chunks of this round + inclusive prefix of the previous round's last chunk
-    const int round_first = chunk - (int)blockIdx.x;
+    const int round_first = chunk & ~(kRound - 1);
     bool timed_out = false;
     uint32_t acc = 0;
     {
@@ -116,12 +133,12 @@ __device__ __forceinline__ void scan_chunk(ScanShared<NCH>& sh, const ScanWorksp
                 part = 0;
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
+                    // unconditional loads (lanes without a predecessor read granule 0 and ignore it): in flight together
                     const int pred = first + u * PP + slot;
-                    if (pred < chunk && ch < nch_total) {
-                        const uint64_t g = granule_load(ws.agg + (int64_t)pred * nch_total + ch);
-                        all = all && (uint32_t)(g >> 32) == l.tag;
-                        part += (uint32_t)g;
-                    }
+                    const bool valid = pred < chunk && ch < nch_total;
+                    const uint64_t g = granule_load(ws.agg + (valid ? (int64_t)pred * nch_total + ch : (int64_t)0));
+                    all = all && (!valid || (uint32_t)(g >> 32) == l.tag);
+                    part += valid ? (uint32_t)g : 0u;
                 }
                 if (all) break;
                 if (spin >= (1 << 22)) {
@@ -143,7 +160,7 @@ __device__ __forceinline__ void scan_chunk(ScanShared<NCH>& sh, const ScanWorksp
 #pragma unroll
         for (int j = 0; j < kWaves; ++j) s += sh.reduce[j][tid];
         sh.prefix[tid] = s;
-        const bool round_last = blockIdx.x == gridDim.x - 1 || chunk == nchunks - 1;
+        const bool round_last = (chunk & (kRound - 1)) == kRound - 1 || chunk == nchunks - 1;
         if (round_last) {
             granule_store(ws.prefix + (int64_t)chunk * nch_total + tid, l.tag, s + mine);
             if (chunk == nchunks - 1) l.cur[tid] = s + mine;  // batch totals, read by the next launch

@@ -119,8 +119,9 @@ __global__ void __launch_bounds__(kBlock) rs_fill_kernel(char* arena) {
 
 template <int AMAX, int MODE>
 __global__ void __launch_bounds__(kBlock) rs_step_kernel(char* __restrict__ arena, const RsDev* __restrict__ dev,
-                                                          const int32_t* __restrict__ actions) {
+                                                          const int32_t* __restrict__ actions, uint32_t ticketed) {
     __shared__ frz::ScanShared<AMAX + 1> s_scan;
+    __shared__ int s_ticket;
 
     const RsDev& d = *dev;
     const int tid = threadIdx.x;
@@ -144,7 +145,8 @@ __global__ void __launch_bounds__(kBlock) rs_step_kernel(char* __restrict__ aren
     bool frozen = false;
     if (MODE == kStep) frozen = launch.prev[A + 1] == 0u || launch.prev[A + 2] == 0u;
 
-    for (int chunk = blockIdx.x; chunk < d.nchunks; chunk += gridDim.x) {
+    {  // one chunk per workgroup (no chunk loop: see wildfire_roles.hip)
+        const int chunk = frz::scan_take_chunk(ws, d.nchunks, ticketed != 0, &s_ticket);
         const int64_t b = (int64_t)chunk * kBlock + tid;
         const bool active = b < B;
         const uint32_t bl = (uint32_t)(active ? b : B - 1);
@@ -159,7 +161,7 @@ __global__ void __launch_bounds__(kBlock) rs_step_kernel(char* __restrict__ aren
                 }
                 at32(rows1, (uint32_t)d.u_frozen * Bu + bl) = 1;
             }
-            continue;
+            return;
         }
 
         int count = at32(rows, (uint32_t)d.r_count * Bu + bl);
@@ -295,9 +297,9 @@ __global__ void __launch_bounds__(kBlock) rs_step_kernel(char* __restrict__ aren
 #pragma unroll
             for (int a = 0; a < AMAX; ++a) owned[a] = 0;
             for (int s = 0; s < count; ++s) {
-                int v[PCOLS];
+                int v[PCOLS], was[PCOLS];
 #pragma unroll
-                for (int c = 0; c < PCOLS; ++c) v[c] = pcol(c, s, bl);
+                for (int c = 0; c < PCOLS; ++c) was[c] = v[c] = pcol(c, s, bl);
                 if (v[PSTATE] == 2) {  // best_moves[env, driver]; driver -1 wraps to the last agent like Python's index
                     const int drv = v[PDRIVER] < 0 ? A + v[PDRIVER] : v[PDRIVER];
 #pragma unroll
@@ -327,8 +329,12 @@ __global__ void __launch_bounds__(kBlock) rs_step_kernel(char* __restrict__ aren
                 }
                 if (!removed) {
                     if (active) {
+                        // a slot is rewritten only where it changes: every column once a removal has shifted the table
+                        // (kept < s), otherwise just the columns this step touched (most slots: none)
+                        const bool shifted = kept != s;
 #pragma unroll
-                        for (int c = 0; c < PCOLS; ++c) pcol(c, kept, bl) = v[c];
+                        for (int c = 0; c < PCOLS; ++c)
+                            if (shifted || v[c] != was[c]) pcol(c, kept, bl) = v[c];
                     }
                     const int st = v[PSTATE];
                     const int since = st == 0 ? v[PENTERED] : (st == 1 ? v[PACCEPTED] : v[PPICKED]);
@@ -511,7 +517,7 @@ struct frz_rideshare_env {
     std::vector<int32_t> schedule_index;  // [max_time + 2]
     char* arena = nullptr;
     bool was_reset = false;
-    int grid = 0;
+    bool ticketed = false;  // more chunks than CUs: chunks are handed out in arrival order (frz_scan.h)
     int variant = 0;
 };
 
@@ -523,9 +529,9 @@ template <int AMAX>
 void launch_variant(frz_rideshare_env* env, const int32_t* actions, int mode, hipStream_t stream) {
     const RsDev* dev = reinterpret_cast<const RsDev*>(env->arena);
     if (mode == kRebuild)
-        hipLaunchKernelGGL((rs_step_kernel<AMAX, kRebuild>), dim3(env->grid), dim3(kBlock), 0, stream, env->arena, dev, actions);
+        hipLaunchKernelGGL((rs_step_kernel<AMAX, kRebuild>), dim3(env->dev.nchunks), dim3(kBlock), 0, stream, env->arena, dev, actions, env->ticketed ? 1u : 0u);
     else
-        hipLaunchKernelGGL((rs_step_kernel<AMAX, kStep>), dim3(env->grid), dim3(kBlock), 0, stream, env->arena, dev, actions);
+        hipLaunchKernelGGL((rs_step_kernel<AMAX, kStep>), dim3(env->dev.nchunks), dim3(kBlock), 0, stream, env->arena, dev, actions, env->ticketed ? 1u : 0u);
 }
 
 int launch(frz_rideshare_env* env, const int32_t* actions, int mode, hipStream_t stream) {
@@ -642,9 +648,7 @@ int frz_rideshare_create(const frz_rideshare_cfg* cfg, const int32_t* schedule, 
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     }
-    const int64_t capacity = cus;  // one resident workgroup per CU: co-resident persistent grid (see wildfire.hip)
-    const int64_t rounds = (p.nchunks + capacity - 1) / capacity;
-    env->grid = (int)((p.nchunks + rounds - 1) / rounds);
+    env->ticketed = p.nchunks > cus;  // one workgroup per chunk; one 256-thread workgroup per CU is always resident
     *out = env;
     return FRZ_OK;
 }
