@@ -24,6 +24,7 @@
 #include <type_traits>
 #include <vector>
 
+#include "frz_scan.h"
 #include "wildfire_common.h"
 
 namespace {
@@ -201,8 +202,23 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ aren
         return e;
     };
 
+    // One chunk per workgroup (no chunk loop: wildfire_roles.hip explains what the loop cost); chunk = blockIdx.x while
+    // the grid is co-resident, otherwise chunks are handed out in arrival order so that the hand-off never waits on a
+    // workgroup that has not started.
+    __shared__ int s_ticket;
+    int chunk = blockIdx.x;
+    if (launch.ticketed) {
+        uint32_t* const counter = reinterpret_cast<uint32_t*>(arena + launch.off_epoch) + 32;
+        if (tid == 0) {
+            const uint32_t t = atomicAdd(counter, 1u);
+            if (t == (uint32_t)nchunks - 1u) atomicExch(counter, 0u);  // every ticket of this launch is out
+            s_ticket = (int)t;
+        }
+        __syncthreads();
+        chunk = s_ticket;
+    }
     Draws cur_draws;
-    Env cur = load_env(blockIdx.x, cur_draws);  // in flight while the configuration is staged
+    Env cur = load_env(chunk, cur_draws);  // in flight while the configuration is staged
 
     const WfHot d = stage_commit(s_cfg, cfg_piece);  // configuration block at arena offset 0; never written by a kernel
     FRZ_STAMP(0);
@@ -230,7 +246,7 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ aren
         }
         if (nt == 0u || ntr == 0u) {
             // The parallel adapter (utils/conversions.py:87-90) then adds the stale aec rewards once per agent call.
-            for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+            {
                 const int64_t b = (int64_t)chunk * kBlock + tid;
                 if (b < B && !at32(rows1, u_frozen * Bu + (uint32_t)b)) {
                     for (int a = 0; a < A; ++a) {
@@ -252,7 +268,7 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ aren
     uint64_t* const prefix = reinterpret_cast<uint64_t*>(arena + d.off_prefix);
 
     FRZ_STAMP(1);
-    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    {
         const int64_t b = (int64_t)chunk * kBlock + tid;
         const bool active = b < B;
         const uint32_t bl = (uint32_t)(active ? b : B - 1);  // lanes past the end shadow the last env
@@ -572,7 +588,7 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ aren
 
         FRZ_STAMP(7);
         // publish this chunk's channel sums; the bookkeeping below runs while the hand-off is in flight
-        const int round_first = chunk - blockIdx.x;  // first chunk of this round
+        const int round_first = chunk & ~(frz::kRound - 1);  // chunks are handed off in windows of kRound
         uint32_t my_total = 0;                         // this chunk's sum of channel `tid` (tid < nch)
         if (tid < nch) {
             if (tid <= A) {
@@ -643,12 +659,6 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ aren
             at32(rows8, q_etc * Bu + bl) = F;
         }
 
-        // the next chunk's loads are issued before the hand-off wait and the list stores (multi-round launches)
-        const int next_chunk = chunk + (int)gridDim.x;
-        Env nxt = cur;
-        Draws nxt_draws = cur_draws;
-        if (next_chunk < nchunks) nxt = load_env(next_chunk, nxt_draws);
-
         FRZ_STAMP(8);
         // -------------------------------------------------- inter-workgroup exclusive prefix (single pass)
         // chunk j needs the channel sums of all chunks < j: those of this round that precede it (their workgroups
@@ -694,7 +704,7 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ aren
 #pragma unroll
             for (int j = 0; j < frz::kWaves; ++j) s += s_reduce[j][tid];
             s_prefix[tid] = s;
-            const bool round_last = blockIdx.x == gridDim.x - 1 || chunk == nchunks - 1;
+            const bool round_last = (chunk & (frz::kRound - 1)) == frz::kRound - 1 || chunk == nchunks - 1;
             if (round_last) {
                 frz::granule_store(prefix + (int64_t)chunk * nch + tid, tag, s + my_total);
                 if (chunk == nchunks - 1) cur_totals[tid] = s + my_total;  // batch totals, read by the next launch
@@ -767,8 +777,6 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ aren
         // The workgroup owning the last chunk finished its look-back only after every other chunk published, i.e.
         // after every workgroup of this launch read the epoch: it can advance it for the next launch.
         if (chunk == nchunks - 1 && tid == 0) __hip_atomic_store(epoch_ptr, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        cur = nxt;
-        cur_draws = nxt_draws;
     }
 }
 
@@ -828,7 +836,6 @@ struct frz_wildfire_env {
     WfDev dev;
     char* arena = nullptr;
     bool was_reset = false;
-    int grid = 0;
     int variant = 0;  // index into the (CMAX, AMAX) instantiation table
     // set for the duration of one frz_wildfire_step_random_policy call
     bool fused_policy = false;
@@ -884,46 +891,30 @@ void launch_variant(const WfArgs& args, int grid, int rng, int mode, hipStream_t
     }
 }
 
-// Resident 256-thread workgroups per CU the runtime reports for every kernel a variant may launch (register bound).
-template <int CMAX, int AMAX, bool EXACT>
-int variant_occupancy() {
-    int lo = 8, n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_step_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kRebuild>, kBlock, 0) != hipSuccess) return 1;
-    lo = n < lo ? n : lo;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_step_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kStep>, kBlock, 0) != hipSuccess) return 1;
-    lo = n < lo ? n : lo;
-    if constexpr (EXACT) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_step_kernel<CMAX, AMAX, EXACT, FRZ_RNG_PHILOX, kStep>, kBlock, 0) != hipSuccess) return 1;
-        lo = n < lo ? n : lo;
+int launch_lane(frz_wildfire_env* env, const WfArgs& args, int rng, int mode, hipStream_t stream) {
+    const int grid = env->dev.nchunks;  // one workgroup per chunk
+    switch (env->variant) {
+        case 0: launch_variant<6, 3, true>(args, grid, rng, mode, stream); break;   // BASELINE.json cfg1/cfg2 shape
+        case 1: launch_variant<6, 2, true>(args, grid, rng, mode, stream); break;   // AAAI-2025 openness configs
+        case 2: launch_variant<8, 4, false>(args, grid, rng, mode, stream); break;
+        case 3: launch_variant<24, 8, false>(args, grid, rng, mode, stream); break;
+        default: launch_variant<64, 16, false>(args, grid, rng, mode, stream); break;
     }
-    return lo < 1 ? 1 : lo;
-}
-
-int lane_blocks_per_cu(int variant) {
-    switch (variant) {
-        case 0: return variant_occupancy<6, 3, true>();
-        case 1: return variant_occupancy<6, 2, true>();
-        case 2: return variant_occupancy<8, 4, false>();
-        case 3: return variant_occupancy<24, 8, false>();
-        default: return variant_occupancy<64, 16, false>();
-    }
+    return hipGetLastError() == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;
 }
 
 int launch(frz_wildfire_env* env, const WfArgs& args, int rng, int mode, hipStream_t stream) {
-    if (env->dev.roles) {
+    if (!env->dev.roles) {
+        WfArgs a = args;
+        a.ticketed = env->ticketed;
+        return launch_lane(env, a, rng, mode, stream);
+    }
+    {
         WfArgs a = args;
         if (!kVariants[env->variant].exact && mode == kStep && rng == FRZ_RNG_PHILOX) stage_philox(a, rng, stream);
         a.ticketed = env->ticketed;
         return launch_roles(a, env->variant, env->dev.nchunks, rng, mode, stream);  // one workgroup per chunk
     }
-    switch (env->variant) {
-        case 0: launch_variant<6, 3, true>(args, env->grid, rng, mode, stream); break;   // BASELINE.json cfg1/cfg2 shape
-        case 1: launch_variant<6, 2, true>(args, env->grid, rng, mode, stream); break;   // AAAI-2025 openness configs
-        case 2: launch_variant<8, 4, false>(args, env->grid, rng, mode, stream); break;
-        case 3: launch_variant<24, 8, false>(args, env->grid, rng, mode, stream); break;
-        default: launch_variant<64, 16, false>(args, env->grid, rng, mode, stream); break;
-    }
-    return hipGetLastError() == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;
 }
 
 template <typename T>
@@ -1118,28 +1109,15 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
     p.off_mt_state = take(624 * B * 4);
     p.total_bytes = off;
 
-    // Co-resident persistent grid: every workgroup of a launch must be resident for the single-pass prefix hand-off
-    // (a chunk waits on chunks owned by other workgroups).  One workgroup per CU is always resident (256 threads at <= 512
-    // registers, or 512 threads at <= 256); rounds are balanced.
+    // One workgroup per chunk.  With no more chunks than CUs the whole grid is resident (one 256- or 512-thread workgroup
+    // per CU always fits) and chunk = blockIdx.x; otherwise chunks are handed out in arrival order (ticket), which needs no
+    // residency assumption: a chunk only waits on chunks whose workgroups have started.
     int device = 0, cus = 256;
     if (hipGetDevice(&device) == hipSuccess) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     }
-    int per_cu = 1;
-    // a second resident workgroup per CU hides latency once there are several rounds; never ask for more than the
-    // register budget of the variant's kernels allows (a non-resident workgroup would stall the hand-off).  The
-    // field/crew kernel already runs two wavefronts per SIMD with one 512-thread workgroup per CU.
-    if (!p.roles) per_cu = (p.nchunks >= 4 * cus && lane_blocks_per_cu(env->variant) >= 2) ? 2 : 1;
-    if (const char* forced = std::getenv("FRZ_WF_BLOCKS_PER_CU")) {  // diagnostics only; clamped to what is resident
-        const int v = std::atoi(forced);
-        const int resident = p.roles ? 1 : lane_blocks_per_cu(env->variant);
-        if (v >= 1 && v <= 8) per_cu = v < resident ? v : (resident < 1 ? 1 : resident);
-    }
-    const int64_t capacity = (int64_t)cus * per_cu;
-    const int64_t rounds = (p.nchunks + capacity - 1) / capacity;
-    env->grid = (int)((p.nchunks + rounds - 1) / rounds);
-    env->ticketed = p.roles && p.nchunks > cus;  // one 512-thread workgroup per CU is always resident
+    env->ticketed = p.nchunks > cus;
     *out = env;
     return FRZ_OK;
 }

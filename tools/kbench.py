@@ -1,7 +1,7 @@
 """Kernel micro-benchmark: time the fused step launch alone (HIP events on the launch stream), for tuning sweeps.
 
 usage: python tools/kbench.py [domain] [B] [steps] [rng]
-       domain in {wildfire, cybersecurity, rideshare}; env: FRZ_WF_GROUP_KERNEL, FRZ_WF_BLOCKS_PER_CU"""
+       domain in {wildfire, cybersecurity, rideshare}; env: FRZ_WF_KERNEL=lane|roles"""
 import os
 import sys
 
