@@ -196,6 +196,25 @@ def test_fused_random_policy_step_equals_policy_then_step(rng, kwargs):
     one.check()
 
 
+def test_timed_rollout_runs_the_same_steps():
+    """frz_wildfire_timed_rollout (measurement aid): same state as the untimed launches, one positive duration per step."""
+    import ctypes
+    from free_range_zoo_amd import _capi
+    from free_range_zoo_amd.utils.env import stream_ptr
+    B, n = 5000, 12
+    plain, timed = [make_env(configs.wildfire_openness, B, 50, rng='philox', exact_shapes=False) for _ in range(2)]
+    for env in (plain, timed):
+        env.reset(seed=torch.arange(B, dtype=torch.int32) + 5)
+    for t in range(n):
+        plain.step_random_policy(policy_seed=3, policy_step=t)
+    out = (ctypes.c_float * n)()
+    _capi.check(timed._lib.frz_wildfire_timed_rollout(timed._handle, 3, 0, n, timed._actions.data_ptr(), _capi.FRZ_RNG_PHILOX,
+                                                      stream_ptr(timed.device), out), 'frz_wildfire_timed_rollout')
+    assert all(0.0 < out[i] < 5.0 for i in range(n)), list(out)
+    for name in ('_fires', '_intensity', '_fuel', '_suppressants', '_rewards', '_task_offsets', '_act_map_offsets'):
+        assert torch.equal(getattr(plain, name), getattr(timed, name)), name
+
+
 @pytest.mark.parametrize('kernel', ['lane', 'roles'])
 def test_both_small_grid_kernels_match_the_oracle(oracle, kernel, monkeypatch):
     """Grids of <= 8 cells have two kernels (FRZ_WF_KERNEL): the lane-per-env one and the field/crew wavefront pairs."""
