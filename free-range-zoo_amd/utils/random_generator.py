@@ -4,6 +4,12 @@ The reference keeps one torch CPU generator state per env and loops over envs in
 same streams — MT19937 ``init_genrand(seed)``, float32 = (u32 & 0xFFFFFF) * 2**-24, env ``b`` drawing
 ``events * prod(shape)`` consecutive floats per call — live in HBM (``[624, B]`` words, env innermost) and are advanced
 by the hand-written kernels of ``csrc/mt19937.hip``: the same seeds give bit-identical tensors to the reference's CPU path.
+
+``single_seeding=True`` is the reference's one-shared-stream mode (random_generator.py:59-65, 103-106): ONE torch CPU
+generator serves all envs, ``torch.rand((parallel_envs, events, *shape))`` per call.  A single sequential stream has no
+batch axis to put on the GPU: it is drawn with torch's own CPU generator and uploaded (randomness as an input, the same
+path as ``step(..., randomness=...)``).  As in the reference, the stream starts from a freshly constructed generator's
+state: the seed value passed to ``seed()`` is stored in ``seeds`` but does not reach the stream.
 """
 from typing import Optional, Tuple
 
@@ -24,8 +30,8 @@ class RandomGenerator:
         device = torch.device(device)
         if device.type != 'cuda':
             raise ValueError(f'Device {device} not supported: the HIP kernels need a GPU device (no CPU fallback)')
-        if single_seeding:
-            raise NotImplementedError('single_seeding (one shared stream for all envs) is not implemented yet')
+        self._single = torch.Generator(device='cpu') if single_seeding else None
+        self._single_state = None
         self.parallel_envs = parallel_envs
         self.buffer_size = buffer_size
         self.single_seeding = single_seeding
@@ -52,6 +58,11 @@ class RandomGenerator:
             shape = self.seeds.shape if partial_seeding is None else torch.as_tensor(partial_seeding).shape
             seed = torch.randint(100000000, shape, device=self.device)
         seed = torch.as_tensor(seed, device=self.device).to(torch.int32)
+        if self.single_seeding:  # random_generator.py:59-65: a fresh generator's state, whatever the seed
+            self.seeds[:] = seed.reshape(-1)[0] if seed.numel() >= 1 else seed
+            self._single_state = torch.Generator(device='cpu').get_state()
+            self.has_been_seeded = True
+            return
         if partial_seeding is None:
             self.seeds[:] = seed
             self._streams_valid = False  # all streams restart: expanded to MT19937 states when first drawn from
@@ -71,6 +82,9 @@ class RandomGenerator:
                                                  indices_ptr, n, self.parallel_envs, _stream_ptr(self.device)), 'frz_mt19937_seed')
 
     def _ensure_streams(self) -> None:
+        if self.single_seeding:
+            raise NotImplementedError('single_seeding draws from one host-side stream: use step() (randomness is uploaded per call); '
+                                      'the device-side MT19937 streams of graph-captured / fused rollouts are per env')
         if not self._streams_valid:
             self._seed_streams(None)
             self._streams_valid = True
@@ -90,6 +104,8 @@ class RandomGenerator:
             raise ValueError('The environment must be seeded before generating randomness')
         if parallel_envs != self.parallel_envs:
             raise ValueError('parallel_envs does not match the generator')
+        if self.single_seeding:
+            return self._generate_single(parallel_envs, events, tuple(int(v) for v in shape), key)
         count = 1
         for s in shape:
             count *= int(s)
@@ -100,6 +116,25 @@ class RandomGenerator:
             # each env draws buffer_size*events*count consecutive floats (random_generator.py:133-138)
             block = self._draw(self.buffer_size * events, count)
             self.buffers[buffer_key] = block.reshape(self.buffer_size, events, parallel_envs, *shape)
+            self.buffer_count[buffer_key] = 0
+        out = self.buffers[buffer_key][self.buffer_count[buffer_key]]
+        self.buffer_count[buffer_key] += 1
+        return out
+
+    def _generate_single(self, parallel_envs: int, events: int, shape: Tuple[int], key: Optional[str]) -> torch.Tensor:
+        """One shared host stream (random_generator.py:103-106, 124-131); returns ``[events, parallel_envs, *shape]`` on the device."""
+        g = self._single
+        if key is None or self.buffer_size == 0:
+            g.set_state(self._single_state)
+            out = torch.rand((parallel_envs, events, *shape), generator=g)
+            self._single_state = g.get_state()
+            return out.transpose(1, 0).contiguous().to(self.device)
+        buffer_key = (key, (parallel_envs, events, *shape))
+        if buffer_key not in self.buffers or self.buffer_count[buffer_key] >= self.buffer_size:
+            g.set_state(self._single_state)
+            block = torch.rand((self.buffer_size, parallel_envs, events, *shape), generator=g)
+            self._single_state = g.get_state()
+            self.buffers[buffer_key] = block.transpose(1, 2).contiguous().to(self.device)
             self.buffer_count[buffer_key] = 0
         out = self.buffers[buffer_key][self.buffer_count[buffer_key]]
         self.buffer_count[buffer_key] += 1
@@ -118,6 +153,7 @@ class RandomGenerator:
             'buffer_count': dict(self.buffer_count),
             'buffers': {k: v.clone() for k, v in self.buffers.items()},
             'has_been_seeded': self.has_been_seeded,
+            'single_state': None if self._single_state is None else self._single_state.clone(),
         }
 
     def load_state_dict(self, state: dict) -> None:
@@ -134,3 +170,7 @@ class RandomGenerator:
         self.buffer_count = dict(state['buffer_count'])
         self.buffers = {k: v.clone() for k, v in state['buffers'].items()}
         self.has_been_seeded = state['has_been_seeded']
+        single = state.get('single_state')
+        self._single_state = None if single is None else single.clone()
+        if self.single_seeding and self._single is None:
+            self._single = torch.Generator(device='cpu')

@@ -196,6 +196,28 @@ def test_fused_random_policy_step_equals_policy_then_step(rng, kwargs):
     one.check()
 
 
+def test_single_seeding_shares_one_host_stream():
+    """single_seeding=True (random_generator.py:59-65, 103-106): one torch CPU generator for all envs, started from a fresh
+    generator's state; the env consumes its draws like injected randomness."""
+    B = 33
+    env = make_env(configs.wildfire_openness, B, 20, rng='mt19937', single_seeding=True)
+    env.reset(seed=torch.full((B, ), 5, dtype=torch.int32))
+    want = torch.Generator(device='cpu')
+    field = torch.rand((B, 3, 2, 3), generator=want).transpose(1, 0)
+    agent = torch.rand((B, 5, 3), generator=want).transpose(1, 0)
+    twin = make_env(configs.wildfire_openness, B, 20, rng='mt19937')
+    twin.reset(seed=torch.full((B, ), 5, dtype=torch.int32))
+    acts = env.random_policy_actions(policy_seed=1, policy_step=0).clone()
+    env.step(acts)
+    twin.step(acts, randomness=(field, agent))
+    for name in ('_fires', '_intensity', '_fuel', '_suppressants', '_rewards'):
+        assert torch.equal(getattr(env, name), getattr(twin, name)), name
+    got = env.generator.generate(B, 2, (4, ))
+    assert torch.equal(got.cpu(), torch.rand((B, 2, 4), generator=want).transpose(1, 0))
+    with pytest.raises(NotImplementedError):
+        env.step_random_policy(policy_seed=1, policy_step=1)
+
+
 def test_timed_rollout_runs_the_same_steps():
     """frz_wildfire_timed_rollout (measurement aid): same state as the untimed launches, one positive duration per step."""
     import ctypes
