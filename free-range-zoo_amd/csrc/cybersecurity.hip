@@ -48,6 +48,16 @@ struct CyDev {
 };
 constexpr int64_t kDevBlockBytes = 4096;
 static_assert(sizeof(CyDev) <= kDevBlockBytes, "configuration block too large");
+constexpr int kCfgPieces = (int)((sizeof(CyDev) + 15) / 16);  // 16-byte pieces staged through LDS, one per thread
+static_assert(kCfgPieces <= kBlock && kCfgPieces * 16 <= kDevBlockBytes, "configuration staged with one 16-byte load per thread");
+
+// What the step kernel needs before the configuration block is staged (by value: kernel arguments are there at wave start,
+// so the state loads and the epoch / totals words are in flight from the first instruction; see wildfire_roles.hip)
+struct CyLaunch {
+    int32_t B, N, Att, D, A;
+    uint32_t ticketed;
+    int64_t off_rows1, off_epoch, off_totals;
+};
 
 template <typename T>
 __device__ __forceinline__ T& at32(T* base, uint32_t index) {
@@ -81,32 +91,77 @@ __global__ void __launch_bounds__(kBlock) cy_fill_kernel(char* arena) {
 template <int NMAX, int AMAX, int RNG, int MODE>
 __global__ void __launch_bounds__(kBlock) cy_step_kernel(char* __restrict__ arena, const CyDev* __restrict__ dev,
                                                           const int32_t* __restrict__ actions, const float* __restrict__ net_rand,
-                                                          const float* __restrict__ agent_rand, uint32_t ticketed) {
+                                                          const float* __restrict__ agent_rand, const CyLaunch L) {
     __shared__ frz::ScanShared<AMAX> s_scan;
     __shared__ int s_ticket;
     __shared__ float s_lut[kLdsLutEntries];
-    __shared__ float s_state_rewards[FRZ_MAX_NETWORK_STATES];
+    __shared__ uint4 s_cfg[kCfgPieces];  // the configuration block; per-lane-indexed tables (state rewards) are read from here
 
-    const CyDev& d = *dev;
     const int tid = threadIdx.x;
-    const int64_t B = d.B;
-    const uint32_t Bu = (uint32_t)d.B;
-    const int N = d.N, Att = d.Att, D = d.D, A = d.A;
+    // the configuration piece is the kernel's first vector-memory instruction (waiting for it must not wait for the state loads)
+    const uint4 cfg_piece = tid < kCfgPieces ? reinterpret_cast<const uint4*>(dev)[tid] : make_uint4(0, 0, 0, 0);
+    const int64_t B = L.B;
+    const uint32_t Bu = (uint32_t)L.B;
+    const int N = L.N, Att = L.Att, D = L.D, A = L.A;
+    const int nchunks = (int)((B + kBlock - 1) / kBlock);
+    // rows of the [rows][B] block: a fixed function of (N, D, A) (frz_cybersecurity_create lays them out in this order)
+    const int r_state = 0, r_loc = N, r_last = N + D, r_moves = N + 2 * D, r_seeds = r_moves + 3 * A + 2;
+    const uint32_t u_presence = 0, u_trunc = 2u * (uint32_t)A;
+    int32_t* const rows = reinterpret_cast<int32_t*>(arena + kDevBlockBytes);
+    float* const rowsf = reinterpret_cast<float*>(arena + kDevBlockBytes);
+    uint8_t* const rows1 = reinterpret_cast<uint8_t*>(arena + L.off_rows1);
+
+    frz::ScanWorkspace ws{reinterpret_cast<uint32_t*>(arena + L.off_epoch), reinterpret_cast<uint32_t*>(arena + L.off_totals), nullptr, nullptr};
+    const int chunk = frz::scan_take_chunk(ws, nchunks, L.ticketed != 0, &s_ticket);
+    const frz::ScanLaunch launch = frz::scan_begin(ws);
+    const int64_t b = (int64_t)chunk * kBlock + tid;
+    const bool active = b < B;
+    const uint32_t bl = (uint32_t)(active ? b : B - 1);
+
+    // ---------------------------------------------------------------------------------------------- load state
+    // (issued before the configuration is staged; lanes past the end shadow the last env and store nothing)
+    int state[NMAX], loc[AMAX], last[AMAX];
+    uint32_t pres_raw[AMAX];
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) state[n] = n < N ? at32(rows, (uint32_t)(r_state + n) * Bu + bl) : 0;
+#pragma unroll
+    for (int k = 0; k < AMAX; ++k) {
+        loc[k] = k < D ? at32(rows, (uint32_t)(r_loc + k) * Bu + bl) : -1;
+        last[k] = k < D ? at32(rows, (uint32_t)(r_last + k) * Bu + bl) : -2;
+    }
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) pres_raw[a] = a < A ? at32(rows1, (u_presence + (uint32_t)a) * Bu + bl) : 0u;
+    const uint32_t trunc_raw = at32(rows1, u_trunc * Bu + bl);
+    int nm = 0;
+    uint32_t seed = 0;
+    int2 act_in[AMAX];
+    float r_net_in[NMAX], r_agent_in[AMAX];
+    if (MODE == kStep) {
+        nm = at32(rows, (uint32_t)r_moves * Bu + bl);
+        if (RNG == FRZ_RNG_PHILOX) seed = (uint32_t)at32(rows, (uint32_t)r_seeds * Bu + bl);
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a) act_in[a] = a < A ? reinterpret_cast<const int2*>(actions)[a * B + bl] : make_int2(0, -1);
+        if (RNG == FRZ_RNG_INJECTED) {
+#pragma unroll
+            for (int n = 0; n < NMAX; ++n) r_net_in[n] = n < N ? net_rand[(int64_t)bl * N + n] : 0.0f;
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a) r_agent_in[a] = a < A ? agent_rand[(int64_t)bl * A + a] : 0.0f;
+        }
+    }
+
+    if (tid < kCfgPieces) s_cfg[tid] = cfg_piece;
+    __syncthreads();
+    const CyDev* const cfg_lds = reinterpret_cast<const CyDev*>(s_cfg);
+    const CyDev d = *cfg_lds;  // hot scalars end up in registers
     const uint32_t flags = d.flags;
     const float* lut = reinterpret_cast<const float*>(arena + d.off_lut);
     const bool lut_in_lds = d.lut_entries <= kLdsLutEntries;
     if (MODE == kStep) {
         if (lut_in_lds)
             for (int i = tid; i < d.lut_entries; i += kBlock) s_lut[i] = lut[i];
-        if (tid < FRZ_MAX_NETWORK_STATES) s_state_rewards[tid] = d.state_rewards[tid];
     }
-
-    frz::ScanWorkspace ws{reinterpret_cast<uint32_t*>(arena + d.off_epoch), reinterpret_cast<uint32_t*>(arena + d.off_totals),
-                          reinterpret_cast<uint64_t*>(arena + d.off_agg), reinterpret_cast<uint64_t*>(arena + d.off_prefix)};
-    const frz::ScanLaunch launch = frz::scan_begin(ws);
-    int32_t* const rows = reinterpret_cast<int32_t*>(arena + d.off_rows4);
-    float* const rowsf = reinterpret_cast<float*>(arena + d.off_rows4);
-    uint8_t* const rows1 = reinterpret_cast<uint8_t*>(arena + d.off_rows1);
+    ws.agg = reinterpret_cast<uint64_t*>(arena + d.off_agg);
+    ws.prefix = reinterpret_cast<uint64_t*>(arena + d.off_prefix);
 
     // utils/env.py:211-213: no-op once ALL envs are terminated (never, cybersecurity.py:298) or ALL are truncated;
     // totals channels A / A + 1 = number of envs not terminated / not truncated after the previous launch
@@ -115,10 +170,6 @@ __global__ void __launch_bounds__(kBlock) cy_step_kernel(char* __restrict__ aren
     __syncthreads();
 
     {  // one chunk per workgroup (no chunk loop: see wildfire_roles.hip)
-        const int chunk = frz::scan_take_chunk(ws, d.nchunks, ticketed != 0, &s_ticket);
-        const int64_t b = (int64_t)chunk * kBlock + tid;
-        const bool active = b < B;
-        const uint32_t bl = (uint32_t)(active ? b : B - 1);
 
         if (frozen) {  // the parallel adapter sums the stale rewards once per agent call (utils/conversions.py:87-90)
             if (active && !at32(rows1, (uint32_t)d.u_frozen * Bu + bl)) {
@@ -133,32 +184,21 @@ __global__ void __launch_bounds__(kBlock) cy_step_kernel(char* __restrict__ aren
             return;
         }
 
-        // ------------------------------------------------------------------------------------------ load state
-        int state[NMAX], loc[AMAX], last[AMAX];
         bool pres[AMAX];
 #pragma unroll
-        for (int n = 0; n < NMAX; ++n) state[n] = n < N ? at32(rows, (uint32_t)(d.r_state + n) * Bu + bl) : 0;
-#pragma unroll
-        for (int k = 0; k < AMAX; ++k) {
-            loc[k] = k < D ? at32(rows, (uint32_t)(d.r_loc + k) * Bu + bl) : -1;
-            last[k] = k < D ? at32(rows, (uint32_t)(d.r_last + k) * Bu + bl) : -2;
-        }
-#pragma unroll
-        for (int a = 0; a < AMAX; ++a) pres[a] = a < A ? at32(rows1, (uint32_t)(d.u_presence + a) * Bu + bl) != 0 : false;
-        bool trunc = at32(rows1, (uint32_t)d.u_trunc * Bu + bl) != 0;
+        for (int a = 0; a < AMAX; ++a) pres[a] = pres_raw[a] != 0;
+        bool trunc = trunc_raw != 0;
         uint32_t err = 0;
 
         if (MODE == kStep) {
-            int nm = at32(rows, (uint32_t)d.r_moves * Bu + bl);
             // ---------------------------------------------------------------------------------- randomness
             float r_net[NMAX], r_agent[AMAX];
             if (RNG == FRZ_RNG_INJECTED) {
 #pragma unroll
-                for (int n = 0; n < NMAX; ++n) r_net[n] = n < N ? net_rand[(int64_t)bl * N + n] : 0.0f;
+                for (int n = 0; n < NMAX; ++n) r_net[n] = r_net_in[n];
 #pragma unroll
-                for (int a = 0; a < AMAX; ++a) r_agent[a] = a < A ? agent_rand[(int64_t)bl * A + a] : 0.0f;
+                for (int a = 0; a < AMAX; ++a) r_agent[a] = r_agent_in[a];
             } else {  // FRZ_RNG_PHILOX stream of include/frz.h
-                const uint32_t seed = (uint32_t)at32(rows, (uint32_t)d.r_seeds * Bu + bl);
 #pragma unroll
                 for (int q = 0; q < (NMAX + 3) / 4; ++q) {
 #pragma unroll
@@ -194,7 +234,7 @@ __global__ void __launch_bounds__(kBlock) cy_step_kernel(char* __restrict__ aren
             for (int a = 0; a < AMAX; ++a) {
                 rew[a] = 0.0f;
                 if (a < A) {
-                    const int2 v = reinterpret_cast<const int2*>(actions)[a * B + bl];
+                    const int2 v = act_in[a];
                     const int idx = v.x, act = v.y;
                     const bool bad_target = act == 0 && (idx < 0 || idx >= N);  // reference raises ValueError (:341-346, :358-363)
                     if (bad_target && active) err |= FRZ_ERR_INVALID_TARGET;
@@ -210,7 +250,9 @@ __global__ void __launch_bounds__(kBlock) cy_step_kernel(char* __restrict__ aren
 #pragma unroll
             for (int k = 0; k < AMAX; ++k) {
                 if (k < D) {
-                    const int2 v = reinterpret_cast<const int2*>(actions)[(Att + k) * B + bl];
+                    int2 v = make_int2(0, -1);
+#pragma unroll
+                    for (int a = 0; a < AMAX; ++a) v = (a == Att + k) ? act_in[a] : v;
                     const int idx = v.x, act = v.y;
                     const bool bad_target = act == 0 && (idx < 0 || idx >= N);
                     const bool move = act == 0 && !bad_target;
@@ -253,7 +295,7 @@ __global__ void __launch_bounds__(kBlock) cy_step_kernel(char* __restrict__ aren
                     s = s < 0 ? 0 : (s > d.S - 1 ? d.S - 1 : s);
                     state[n] = s;
                     // :396-399 criticality-weighted state rewards, sequential float32 dot product
-                    net_reward = __fadd_rn(net_reward, __fmul_rn(s_state_rewards[s], (float)d.criticality[n]));
+                    net_reward = __fadd_rn(net_reward, __fmul_rn(cfg_lds->state_rewards[s], (float)d.criticality[n]));
                 }
             }
             nm += 1;
@@ -291,7 +333,7 @@ __global__ void __launch_bounds__(kBlock) cy_step_kernel(char* __restrict__ aren
         uint32_t cnt[AMAX], excl[AMAX];
 #pragma unroll
         for (int a = 0; a < AMAX; ++a) cnt[a] = (active && a < A && pres[a]) ? 1u : 0u;
-        frz::scan_chunk<AMAX>(s_scan, ws, launch, cnt, active, active && !trunc, A, chunk, d.nchunks, excl, &err);
+        frz::scan_chunk<AMAX>(s_scan, ws, launch, cnt, active, active && !trunc, A, chunk, nchunks, excl, &err);
 
         if (active) {
             float* const self_att = reinterpret_cast<float*>(arena + d.off_self_att);
@@ -379,7 +421,7 @@ __global__ void __launch_bounds__(kBlock) cy_step_kernel(char* __restrict__ aren
             }
         }
         if (err) atomicOr(reinterpret_cast<uint32_t*>(arena + d.off_error), err);
-        frz::scan_end(ws, launch, chunk, d.nchunks);
+        frz::scan_end(ws, launch, chunk, nchunks);
     }
 }
 
@@ -432,12 +474,14 @@ void launch_variant(frz_cybersecurity_env* env, const int32_t* actions, const fl
                     hipStream_t stream) {
     const CyDev* dev = reinterpret_cast<const CyDev*>(env->arena);
     const dim3 grid(env->dev.nchunks), block(kBlock);
+    const CyDev& p = env->dev;
+    const CyLaunch L{p.B, p.N, p.Att, p.D, p.A, env->ticketed ? 1u : 0u, p.off_rows1, p.off_epoch, p.off_totals};
     if (mode == kRebuild)
-        hipLaunchKernelGGL((cy_step_kernel<NMAX, AMAX, FRZ_RNG_INJECTED, kRebuild>), grid, block, 0, stream, env->arena, dev, actions, nr, ar, env->ticketed ? 1u : 0u);
+        hipLaunchKernelGGL((cy_step_kernel<NMAX, AMAX, FRZ_RNG_INJECTED, kRebuild>), grid, block, 0, stream, env->arena, dev, actions, nr, ar, L);
     else if (rng == FRZ_RNG_PHILOX)
-        hipLaunchKernelGGL((cy_step_kernel<NMAX, AMAX, FRZ_RNG_PHILOX, kStep>), grid, block, 0, stream, env->arena, dev, actions, nr, ar, env->ticketed ? 1u : 0u);
+        hipLaunchKernelGGL((cy_step_kernel<NMAX, AMAX, FRZ_RNG_PHILOX, kStep>), grid, block, 0, stream, env->arena, dev, actions, nr, ar, L);
     else
-        hipLaunchKernelGGL((cy_step_kernel<NMAX, AMAX, FRZ_RNG_INJECTED, kStep>), grid, block, 0, stream, env->arena, dev, actions, nr, ar, env->ticketed ? 1u : 0u);
+        hipLaunchKernelGGL((cy_step_kernel<NMAX, AMAX, FRZ_RNG_INJECTED, kStep>), grid, block, 0, stream, env->arena, dev, actions, nr, ar, L);
 }
 
 int launch(frz_cybersecurity_env* env, const int32_t* actions, const float* nr, const float* ar, int rng, int mode, hipStream_t stream) {
@@ -535,6 +579,12 @@ int frz_cybersecurity_create(const frz_cybersecurity_cfg* cfg, frz_cybersecurity
     };
     p.off_rows4 = take((int64_t)p.n_rows4 * B * 4);
     p.off_rows1 = take((int64_t)p.n_rows1 * B);
+    // the step kernel derives these from (N, D, A) alone (its loads start before the configuration block is staged)
+    if (p.off_rows4 != kDevBlockBytes || p.r_state != 0 || p.r_loc != N || p.r_last != N + D || p.r_moves != N + 2 * D ||
+        p.r_seeds != p.r_moves + 3 * A + 2 || p.u_presence != 0 || p.u_trunc != 2 * A) {
+        delete env;
+        return FRZ_E_INVALID;
+    }
     p.off_self_att = take((int64_t)Att * B * 8);
     p.off_self_def = take((int64_t)D * B * 12);
     p.off_others_att = take((int64_t)Att * B * (Att > 0 ? Att - 1 : 0) * ka * 4);

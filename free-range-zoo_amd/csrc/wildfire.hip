@@ -1102,7 +1102,6 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
     p.off_epoch = take(256);
     p.off_totals = take(2 * kTotalsStride * 4);
     p.off_agg = take((int64_t)p.nchunks * p.nch * 8);
-    p.off_gtot = take((int64_t)p.nchunks * p.nch * 8);
     p.off_prefix = take((int64_t)p.nchunks * p.nch * 8);
     p.off_rand_field = take(3 * B * HW * 4);
     p.off_rand_agent = take(5 * B * A * 4);
