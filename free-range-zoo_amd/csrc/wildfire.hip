@@ -1081,7 +1081,7 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
     // block is staged): keep both sides in step
     if (p.off_rows4 != kDevBlockBytes || p.r_fires != 0 || p.r_intensity != HW || p.r_fuel != 2 * HW || p.r_supp != 3 * HW ||
         p.r_cap != p.r_supp + A || p.r_equip != p.r_cap + A || p.r_moves != p.r_equip + A || p.r_burnouts != p.r_moves + 1 ||
-        p.r_rewards != p.r_moves + 2 || p.r_cum != p.r_rewards + A || p.r_atc != p.r_cum + A || p.r_seeds != p.r_atc + A ||
+        p.r_rewards != p.r_moves + 2 || p.r_cum != p.r_rewards + A || p.r_atc != p.r_cum + A || p.r_seeds != p.r_atc + A || p.r_mti != p.r_seeds + 1 ||
         p.u_term != 0 || p.u_trunc != A || p.u_frozen != 2 * A || p.q_burnouts != 0 || p.q_putouts != 1 || p.q_etc != 2) {
         delete env;
         return FRZ_E_INVALID;
@@ -1226,6 +1226,8 @@ int frz_wildfire_step(frz_wildfire_env* env, const int32_t* actions, int rng_mod
         if (!field_randomness || !agent_randomness) return FRZ_E_INVALID;
         args.field_rand = field_randomness;
         args.agent_rand = agent_randomness;
+    } else if (rng_mode == FRZ_RNG_MT19937 && env->dev.roles && kVariants[env->variant].exact) {
+        // the field/crew kernel advances the per-env MT19937 streams itself (wildfire_roles.hip)
     } else if (rng_mode == FRZ_RNG_MT19937) {
         // per-env MT19937 streams: field draws first, then agent draws (wildfire.py:409-410), staged in the arena
         const int64_t B = c.parallel_envs;

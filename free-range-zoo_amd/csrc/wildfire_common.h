@@ -76,7 +76,7 @@ constexpr int64_t kDevBlockBytes = 8192;
 struct WfLaunch {
     int32_t batch;
     uint32_t policy;  // 1: sample the actions in-kernel (uniform random policy, frz_wildfire_step_random_policy)
-    int64_t off_rows1, off_epoch, off_totals;
+    int64_t off_rows1, off_epoch, off_totals, off_mt_state;
     uint32_t policy_seed_lo, policy_seed_hi, policy_step_lo, policy_step_hi;
     int32_t* actions_out;  // where the sampled actions are left (policy == 1), int32 [A][B][2]
     uint32_t ticketed;     // 1: chunks are handed out in arrival order (more chunks than resident workgroups)
@@ -122,7 +122,7 @@ inline uint32_t experiment_skip() {
 
 inline WfLaunch make_launch(const WfArgs& a) {
     const WfDev* host = a.host_dev;
-    return WfLaunch{host->B, a.policy ? 1u : 0u, host->off_rows1, host->off_epoch, host->off_totals, (uint32_t)a.policy_seed,
+    return WfLaunch{host->B, a.policy ? 1u : 0u, host->off_rows1, host->off_epoch, host->off_totals, host->off_mt_state, (uint32_t)a.policy_seed,
                     (uint32_t)(a.policy_seed >> 32), (uint32_t)a.policy_step, (uint32_t)(a.policy_step >> 32), a.actions_out, a.ticketed ? 1u : 0u, experiment_skip()};
 }
 

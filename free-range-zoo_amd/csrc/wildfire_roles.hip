@@ -54,7 +54,7 @@ constexpr int kRound = 256;             // look-back window: a chunk sums at mos
 #endif
 
 template <int CMAX, int AMAX, bool EXACT, int RNG, int MODE>
-__global__ void __launch_bounds__(kRoleBlock, 4) wf_roles_kernel(char* __restrict__ arena, const WfDev* __restrict__ dev,
+__global__ void __launch_bounds__(kRoleBlock, (RNG == FRZ_RNG_MT19937 ? 2 : 4)) wf_roles_kernel(char* __restrict__ arena, const WfDev* __restrict__ dev,
                                                                const int32_t* __restrict__ actions, const float* __restrict__ field_rand,
                                                                const float* __restrict__ agent_rand, const WfLaunch launch) {
     const int32_t batch = launch.batch;
@@ -63,8 +63,9 @@ __global__ void __launch_bounds__(kRoleBlock, 4) wf_roles_kernel(char* __restric
     constexpr int PW = (AMAX + 1 + 3) / 4;                                // packed scan words (four 16-bit channels each)
     constexpr int NCHP = AMAX + 3 <= 8 ? 8 : (AMAX + 3 <= 16 ? 16 : 32);  // scan channels padded to a power of two
     constexpr bool kPhilox = RNG == FRZ_RNG_PHILOX && MODE == kStep;
+    constexpr bool kMt = RNG == FRZ_RNG_MT19937 && MODE == kStep;  // per-env MT19937 streams advanced inside the step
     constexpr bool kInjected = RNG == FRZ_RNG_INJECTED && MODE == kStep;
-    static_assert(EXACT || !kPhilox, "runtime shapes stage their draws (wf_philox_fill_kernel)");
+    static_assert(EXACT || !(kPhilox || kMt), "runtime shapes stage their draws (wf_philox_fill_kernel / frz_mt19937_generate)");
 
     __shared__ uint64_t s_wave_scan[frz::kWaves][PW];
     __shared__ uint32_t s_wave_live[frz::kWaves][2];
@@ -77,7 +78,7 @@ __global__ void __launch_bounds__(kRoleBlock, 4) wf_roles_kernel(char* __restric
     __shared__ uint64_t x_excl[PW][kBlock];  // crew -> both: packed per-env counts of the preceding envs of the same wavefront
     __shared__ uint32_t x_ok[kBlock];        // crew -> both: attackable cells of agent a in byte a (AMAX <= 4)
     __shared__ float x_supp[AMAX][kBlock];   // crew -> field: suppressant after the agent transitions (agent observations)
-    __shared__ float x_draw[kPhilox ? 5 * AMAX : 1][kBlock];  // field -> crew: the step's agent draws (FRZ_RNG_PHILOX)
+    __shared__ float x_draw[(kPhilox || kMt) ? 5 * AMAX : 1][kBlock];  // field -> crew: the step's agent draws (in-kernel RNG)
 
     const int tid = threadIdx.x;
     const uint4 cfg_piece = stage_request(dev);  // first vector-memory instruction of the kernel
@@ -112,7 +113,7 @@ __global__ void __launch_bounds__(kRoleBlock, 4) wf_roles_kernel(char* __restric
         int f[CMAX];
     };
     struct FieldRegs {
-        int in[CMAX], fu[CMAX], nm;
+        int in[CMAX], fu[CMAX], nm, mti;
         uint32_t seed;
     };
     struct CrewRegs {
@@ -154,11 +155,12 @@ __global__ void __launch_bounds__(kRoleBlock, 4) wf_roles_kernel(char* __restric
             e.in[c] = c < HW ? at32(rows, (uint32_t)(r_intensity + c) * Bu + bl) : 0;
             e.fu[c] = c < HW ? at32(rows, (uint32_t)(r_fuel + c) * Bu + bl) : 0;
         }
-        e.nm = 0;
+        e.nm = e.mti = 0;
         e.seed = 0;
         if (MODE == kStep) {
             e.nm = at32(rows, (uint32_t)r_moves * Bu + bl);
             if (kPhilox) e.seed = (uint32_t)at32(rows, (uint32_t)r_seeds * Bu + bl);
+            if (kMt) e.mti = at32(rows, (uint32_t)(r_seeds + 1) * Bu + bl);  // position of the env's MT19937 stream
         }
         if constexpr (kInjected) {
 #pragma unroll
@@ -384,6 +386,54 @@ __global__ void __launch_bounds__(kRoleBlock, 4) wf_roles_kernel(char* __restric
                             uni[5 * j + 3] = frz::philox_unit24<3>(w);
                             uni[5 * j + 4] = frz::philox_unit24<4>(w);
                         }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 3; ++e)
+#pragma unroll
+                        for (int c = 0; c < CMAX; ++c) r_field[e][c] = uni[e * CMAX + c];
+#pragma unroll
+                    for (int i = 0; i < 5 * AMAX; ++i) x_draw[i][slot] = uni[3 * CMAX + i];
+                } else if constexpr (kMt) {
+                    // FRZ_RNG_MT19937: the env's own MT19937 stream (mt19937.hip: state word j of env b at [j][b], twisted
+                    // lazily, one word per draw), bit-identical to the reference's per-env torch CPU generator.  The step
+                    // draws U consecutive floats: generate(B, 3, (H, W)) then generate(B, 5, (A,)) (wildfire.py:409-410), i.e.
+                    // field event e of cell c is draw e * HW + c, agent event e of agent a is draw 3 * HW + e * A + a.
+                    // U <= 227, so no word read here is rewritten by this batch: every load is issued before the first use.
+                    constexpr int U = 3 * CMAX + 5 * AMAX, kN = 624, kM = 397;
+                    static_assert(U <= kN - kM, "a batch must not read a word it rewrites");
+                    uint32_t* const mt = reinterpret_cast<uint32_t*>(arena + launch.off_mt_state);
+                    const int i0 = fld.mti;
+                    uint32_t w[U + 1], far[U];
+#pragma unroll
+                    for (int k = 0; k <= U; ++k) {
+                        int j = i0 + k;
+                        j -= j >= kN ? kN : 0;
+                        w[k] = at32(mt, (uint32_t)j * Bu + bl);
+                    }
+#pragma unroll
+                    for (int k = 0; k < U; ++k) {
+                        int j = i0 + k + kM;
+                        j -= j >= kN ? kN : 0;
+                        far[k] = at32(mt, (uint32_t)j * Bu + bl);
+                    }
+                    float uni[U];
+#pragma unroll
+                    for (int k = 0; k < U; ++k) {
+                        const uint32_t y = (w[k] & 0x80000000u) | (w[k + 1] & 0x7fffffffu);
+                        uint32_t v = far[k] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                        int j = i0 + k;
+                        j -= j >= kN ? kN : 0;
+                        at32(mt, (uint32_t)j * Bu + bl) = v;
+                        v ^= v >> 11;
+                        v ^= (v << 7) & 0x9d2c5680u;
+                        v ^= (v << 15) & 0xefc60000u;
+                        v ^= v >> 18;
+                        uni[k] = (float)(v & 0xFFFFFFu) * (1.0f / 16777216.0f);
+                    }
+                    {
+                        int j = i0 + U;
+                        j -= j >= kN ? kN : 0;
+                        at32(rows, (uint32_t)(r_seeds + 1) * Bu + bl) = j;
                     }
 #pragma unroll
                     for (int e = 0; e < 3; ++e)
@@ -666,7 +716,7 @@ __global__ void __launch_bounds__(kRoleBlock, 4) wf_roles_kernel(char* __restric
                     for (int e = 0; e < 5; ++e)
 #pragma unroll
                         for (int a = 0; a < AMAX; ++a) r_agent[e][a] = cdraws.r[e][a];
-                } else if constexpr (kPhilox) {
+                } else if constexpr (kPhilox || kMt) {
 #pragma unroll
                     for (int e = 0; e < 5; ++e)
 #pragma unroll
@@ -923,6 +973,10 @@ void launch_roles_variant(const WfArgs& a, const WfDev* dev, int grid, int rng, 
     } else if (rng == FRZ_RNG_PHILOX) {
         if constexpr (EXACT)
             launch_step_kernel(a, wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_PHILOX, kStep>, grid, kRoleBlock, stream, a.arena, dev, a.actions,
+                               a.field_rand, a.agent_rand, batch);
+    } else if (rng == FRZ_RNG_MT19937) {
+        if constexpr (EXACT)
+            launch_step_kernel(a, wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_MT19937, kStep>, grid, kRoleBlock, stream, a.arena, dev, a.actions,
                                a.field_rand, a.agent_rand, batch);
     } else {
         launch_step_kernel(a, wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kStep>, grid, kRoleBlock, stream, a.arena, dev, a.actions,

@@ -269,7 +269,13 @@ class raw_env(BatchedParallelEnv):
             actions_ptr = actions.data_ptr()
         stream = stream_ptr(self.device)
         B, H, W, A = self.parallel_envs, self.max_y, self.max_x, len(self.agents)
-        if randomness is not None or self.rng == 'mt19937':
+        fused_mt = (randomness is None and self.rng == 'mt19937' and not self.single_seeding and self.generator.buffer_size == 0)
+        if fused_mt:
+            # unbuffered per-env streams: the step kernel advances the env's own MT19937 stream (same draws, same order as
+            # generator.generate(B, 3, (H, W)) followed by generate(B, 5, (A,)), wildfire.py:409-410)
+            self.generator._ensure_streams()
+            rc = self._lib.frz_wildfire_step(self._handle, actions_ptr, _capi.FRZ_RNG_MT19937, None, None, stream)
+        elif randomness is not None or self.rng == 'mt19937':
             if randomness is None:  # wildfire.py:409-410
                 field = self.generator.generate(B, 3, (H, W), key='field')
                 agent = self.generator.generate(B, 5, (A, ), key='agent')

@@ -196,6 +196,33 @@ def test_fused_random_policy_step_equals_policy_then_step(rng, kwargs):
     one.check()
 
 
+@pytest.mark.parametrize('kernel', ['roles', 'lane'])
+def test_mt19937_streams_advanced_in_the_step_equal_generated_tensors(kernel, monkeypatch):
+    """FRZ_RNG_MT19937 through frz_wildfire_step (field/crew kernel: the stream is advanced inside the step; lane kernel:
+    two frz_mt19937_generate launches) draws exactly what RandomGenerator.generate() hands to an injected step — across
+    the 624-word wrap of the streams (33 draws per step: wraps at steps 19 and 38) and after a partial re-seed."""
+    monkeypatch.setenv('FRZ_WF_KERNEL', kernel)
+    B = 777
+    a, b = [make_env(configs.wildfire_openness, B, 50, rng='mt19937', exact_shapes=False) for _ in range(2)]
+    seeds = torch.arange(B, dtype=torch.int32) * 11 + 3
+    a.reset(seed=seeds)
+    b.reset(seed=seeds)
+    for t in range(45):
+        if t == 7:  # streams at different positions inside one wavefront
+            idx = torch.arange(0, B, 3, dtype=torch.int32)
+            for env in (a, b):
+                env.generator.seed(torch.arange(idx.numel(), dtype=torch.int32) + 1000, partial_seeding=idx)
+        acts = a.random_policy_actions(policy_seed=9, policy_step=t).clone()
+        field = b.generator.generate(B, 3, (2, 3), key='field')
+        agent = b.generator.generate(B, 5, (3, ), key='agent')
+        a.step(acts)                              # in-kernel / staged MT19937 through the C-ABI
+        b.step(acts, randomness=(field, agent))   # the same streams drawn by the generator API
+        for name in ('_fires', '_intensity', '_fuel', '_suppressants', '_capacity', '_equipment', '_rewards', '_task_offsets'):
+            assert torch.equal(getattr(a, name), getattr(b, name)), f'{name} at step {t}'
+    assert torch.equal(a.generator.generator_index, b.generator.generator_index)
+    assert torch.equal(a.generator.generator_states, b.generator.generator_states)
+
+
 def test_single_seeding_shares_one_host_stream():
     """single_seeding=True (random_generator.py:59-65, 103-106): one torch CPU generator for all envs, started from a fresh
     generator's state; the env consumes its draws like injected randomness."""
