@@ -41,34 +41,52 @@ def algorithmic_bytes_per_env_step(HW, A, k, mean_tasks, mean_agent_tasks_sum, i
     return state + io + obs + tasks + obs_map + act_maps + counts + rnd
 
 
-def cpu_baseline(budget_s=12.0):
-    """The CPU oracle (scalar C restatement, 1 thread) on a bounded sample of the same workload: same policy, same
-    Philox randomness, same step — reported beside the GPU number, never the thing measured above."""
+def cpu_baseline(budget_s=12.0, cores=None):
+    """The CPU oracle (scalar C restatement) on a bounded sample of the same workload: same policy, same Philox randomness,
+    same step — reported beside the GPU number, never the thing measured above.  The env-batch axis shards on the host
+    exactly as it does across GPUs: `cores` threads each step their own shard of envs with their own oracle instance
+    (ctypes releases the GIL inside the C calls; no process is forked or exec'd after the GPU was initialised)."""
     import configs
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle
     from free_range_zoo_amd.envs.wildfire.env.structures.configuration import to_cstruct
-    B = 16384
-    cfg = to_cstruct(configs.wildfire_openness(), B, EPISODE)
-    ref = oracle.WildfireOracle(cfg)
-    seeds = np.arange(B, dtype=np.int32)
+    try:
+        available = len(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover
+        available = os.cpu_count() or 1
+    cores = max(1, min(cores or 16, available))
+    shard = 16384
     oracle.lib()
-    steps, t_total = 0, 0.0
-    while t_total < budget_s:
-        ref.reset()
-        t0 = time.perf_counter()
-        for t in range(EPISODE):
-            actions = oracle.wildfire_random_policy(cfg, ref.agent_task_count, ref.env_task_count, seeds, 7, steps + t)
-            field, agent = oracle.wildfire_philox_randomness(cfg, seeds, ref.num_moves)
-            ref.step(actions, field, agent)
-        t_total += time.perf_counter() - t0
-        steps += EPISODE
+
+    def worker(index):
+        cfg = to_cstruct(configs.wildfire_openness(), shard, EPISODE)
+        ref = oracle.WildfireOracle(cfg)
+        seeds = np.arange(shard, dtype=np.int32) + index * shard
+        steps, t_busy = 0, 0.0
+        t_start = time.perf_counter()
+        while time.perf_counter() - t_start < budget_s:
+            ref.reset()
+            t0 = time.perf_counter()
+            for t in range(EPISODE):
+                actions = oracle.wildfire_random_policy(cfg, ref.agent_task_count, ref.env_task_count, seeds, 7, steps + t)
+                field, agent = oracle.wildfire_philox_randomness(cfg, seeds, ref.num_moves)
+                ref.step(actions, field, agent)
+            t_busy += time.perf_counter() - t0
+            steps += EPISODE
+        return steps, t_busy
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as pool:
+        results = list(pool.map(worker, range(cores)))
+    wall = time.perf_counter() - t0
+    total_steps = sum(r[0] for r in results)
     return {
-        'value': B * steps / t_total,
+        'value': shard * total_steps / wall,
         'unit': 'env-steps/s',
-        'cores': 1,
+        'cores': cores,
         'kind': 'port',
-        'sample': f'oracle (scalar C restatement): wildfire cfg2 B={B}, {steps // EPISODE} episodes x {EPISODE} steps incl. policy + Philox randomness, '
-                  f'{t_total:.1f} s on 1 of {os.cpu_count()} host cores',
+        'sample': f'oracle (scalar C restatement): wildfire cfg2, {cores} threads x {shard} envs each, {total_steps // EPISODE} episodes x {EPISODE} '
+                  f'steps in total incl. policy + Philox randomness, {wall:.1f} s wall on {cores} of {os.cpu_count()} host cores',
     }
 
 
