@@ -83,6 +83,35 @@ def wildfire_rich_plain() -> W.WildfireConfiguration:
     return cfg
 
 
+def wildfire_grid(H: int, Wd: int, A: int, seed: int = 11) -> W.WildfireConfiguration:
+    """A fully stochastic H x Wd grid with A agents (kernel-variant coverage beyond the reference's own test shapes)."""
+    g = torch.Generator().manual_seed(seed)
+    types = torch.randint(0, 4, (H, Wd), generator=g, dtype=torch.int32)
+    lit = (torch.rand((H, Wd), generator=g) < 0.4) & (types > 0)
+    fire = W.FireConfiguration(
+        fire_types=types, num_fire_states=5, lit=lit, intensity_increase_probability=0.6, intensity_decrease_probability=0.7,
+        extra_power_decrease_bonus=0.1, burnout_probability=0.4, base_spread_rate=30.0, max_spread_rate=67.0,
+        random_ignition_probability=0.01, cell_size=200.0, wind_direction=0.7,
+        ignition_temp=torch.randint(1, 3, (H, Wd), generator=g, dtype=torch.int32), initial_fuel=2)
+    agents = torch.stack([torch.randint(0, H, (A, ), generator=g), torch.randint(0, Wd, (A, ), generator=g)], dim=1).to(torch.int32)
+    agent = W.AgentConfiguration(
+        agents=agents, fire_reduction_power=torch.rand((A, ), generator=g) + 0.5,
+        attack_range=torch.randint(1, 3, (A, ), generator=g, dtype=torch.int32), suppressant_states=4, initial_suppressant=2,
+        suppressant_decrease_probability=0.7, suppressant_refill_probability=0.6, initial_equipment_state=1,
+        equipment_states=torch.tensor([[-1.0, -0.5, -1.0], [0.0, 0.0, 0.0], [1.0, 0.25, 1.0]], dtype=torch.float32),
+        repair_probability=0.5, degrade_probability=0.2, critical_error_probability=0.05, initial_capacity=2,
+        tank_switch_probability=0.5, possible_capacities=torch.tensor([1, 2, 3], dtype=torch.float32),
+        capacity_probabilities=torch.tensor([0.3, 0.4, 0.3], dtype=torch.float32))
+    reward = W.RewardConfiguration(fire_rewards=torch.rand((H, Wd), generator=g) * 30 + 5, bad_attack_penalty=-2.0, burnout_penalty=-1.5,
+                                   burnout_penalty_scaled=False, termination_reward=10.0, termination_kappa=2.0, localize_putouts=False)
+    stoch = W.StochasticConfiguration(special_burnout_probability=True, suppressant_refill=True, suppressant_decrease=True,
+                                      tank_switch=True, critical_error=True, degrade=True, repair=True, fire_increase=True,
+                                      fire_decrease=True, fire_spread=True, realistic_fire_spread=True, random_fire_ignition=True,
+                                      fire_fuel=False)
+    return W.WildfireConfiguration(grid_width=Wd, grid_height=H, fire_config=fire, agent_config=agent, reward_config=reward,
+                                   stochastic_config=stoch)
+
+
 # golden trajectory name -> (configuration builder, env kwargs)
 WILDFIRE_GOLDEN = {
     'cfg1_nonstochastic': (wildfire_non_stochastic, {}),

@@ -264,6 +264,17 @@ def test_timed_rollout_runs_the_same_steps():
         assert torch.equal(getattr(plain, name), getattr(timed, name)), name
 
 
+@pytest.mark.parametrize('shape,kernel', [((2, 4, 4), 'roles'), ((2, 4, 4), 'lane'), ((1, 7, 3), 'roles'), ((8, 8, 12), 'lane'), ((5, 9, 16), 'lane')])
+def test_every_kernel_variant_matches_the_oracle(oracle, shape, kernel, monkeypatch):
+    """Grid shapes that select the runtime-shape variants: <8,4> (field/crew with staged draws, and lane) and <64,16> (lane)."""
+    monkeypatch.setenv('FRZ_WF_KERNEL', kernel)
+    H, Wd, A = shape
+    build = lambda: configs.wildfire_grid(H, Wd, A)
+    run_against_oracle(oracle, build, {}, 700, 20, 12, seed=31)
+    run_against_oracle(oracle, build, dict(show_bad_actions=True, observe_other_power=True), 300, 20, 10, seed=32, rng='philox')
+    run_against_oracle(oracle, build, dict(observe_other_suppressant=True), 300, 20, 10, seed=33, policy='device')
+
+
 @pytest.mark.parametrize('kernel', ['lane', 'roles'])
 def test_both_small_grid_kernels_match_the_oracle(oracle, kernel, monkeypatch):
     """Grids of <= 8 cells have two kernels (FRZ_WF_KERNEL): the lane-per-env one and the field/crew wavefront pairs."""
