@@ -121,6 +121,15 @@ def test_vs_oracle_multi_round_and_rng_modes(oracle):
     run_against_oracle(oracle, configs.cyber_openness, {}, 1200, 30, 10, seed=9, rng='mt19937')
 
 
+@pytest.mark.parametrize('shape', [(12, 5, 7), (16, 3, 6), (7, 8, 8)])
+def test_large_variants_match_the_oracle(oracle, shape):
+    """<16,16> kernel variant: more than 8 nodes or agents; 2^(Att+D) danger entries beyond the LDS-staged 1024 read from HBM."""
+    build = lambda: configs.cyber_grid(*shape)
+    run_against_oracle(oracle, build, {}, 600, 20, 12, seed=41)
+    run_against_oracle(oracle, build, dict(show_bad_actions=False, observe_other_presence=True, observe_other_location=True), 300, 20, 10,
+                       seed=42, rng='philox')
+
+
 def test_full_size_properties():
     """BASELINE.json config 4: B = 65 536, 2 attackers + 2 defenders, agent openness on."""
     B = 65536

@@ -107,6 +107,12 @@ def test_vs_oracle_variants(oracle, name):
     run_against_oracle(oracle, configs.RIDESHARE_GOLDEN[name], 1500, 40, 42, seed=3)
 
 
+@pytest.mark.parametrize('A', [2, 12, 16])
+def test_agent_count_variants_match_the_oracle(oracle, A):
+    """<4> and <16> kernel variants (the golden configurations all use the <8> one)."""
+    run_against_oracle(oracle, lambda: configs.rideshare_busy(A=A, steps=12, per_step=3, seed=20 + A), 500, 20, 16, seed=7, contest=0.3)
+
+
 def test_vs_oracle_multi_round(oracle):
     run_against_oracle(oracle, lambda: configs.rideshare_busy(A=3, steps=6, per_step=1, seed=4), 140000, 8, 5, seed=5, contest=0.2)
 
