@@ -142,6 +142,12 @@ int frz_oracle_rideshare_reset(const frz_rideshare_cfg* cfg, frz_oracle_rideshar
 int frz_oracle_rideshare_rebuild(const frz_rideshare_cfg* cfg, frz_oracle_rideshare_bufs* s);
 int frz_oracle_rideshare_step(const frz_rideshare_cfg* cfg, frz_oracle_rideshare_bufs* s, const int32_t* schedule, const int32_t* actions);
 void frz_oracle_rs_move(const frz_rideshare_cfg* cfg, const int32_t vec[4], int32_t move[2], float* cost);
+/* single transitions on the slot table (known-answer vectors of the reference's transition tests) */
+int frz_oracle_rs_passenger_state(const frz_rideshare_cfg* cfg, frz_oracle_rideshare_bufs* s, const uint8_t* accepts, const uint8_t* picks,
+                                  const int32_t* targets, const int32_t* vectors, const int32_t* timesteps);
+int frz_oracle_rs_passenger_exit(const frz_rideshare_cfg* cfg, frz_oracle_rideshare_bufs* s, const uint8_t* drops, const int32_t* targets,
+                                 const int32_t* vectors, int32_t* fares_out);
+int frz_oracle_rs_passenger_entry(const frz_rideshare_cfg* cfg, frz_oracle_rideshare_bufs* s, const int32_t* schedule, const int32_t* timesteps);
 void frz_oracle_rideshare_random_policy(const frz_rideshare_cfg* cfg, const frz_oracle_rideshare_bufs* s, uint64_t seed, uint64_t step,
                                         int32_t* actions);
 

@@ -135,6 +135,114 @@ void frz_oracle_rs_move(const frz_rideshare_cfg* cfg, const int32_t vec[4], int3
     *cost = ndirs == 9 ? sqrtf(my * my + mx * mx) : fabsf(my) + fabsf(mx);
 }
 
+/* squared pre-move distance between the two points of a task vector (sqrt is monotonic, zero iff zero); returns 0 when the
+ * vector is all -100, i.e. the reference's distance is +inf (passenger_state.py:48-49, passenger_exit.py:43-44) */
+static int vec_dist2(const int32_t v[4], int64_t* d2) {
+    const int64_t dy = (int64_t)v[0] - v[2], dx = (int64_t)v[1] - v[3];
+    *d2 = dy * dy + dx * dx;
+    return !(v[0] == NONE && v[1] == NONE && v[2] == NONE && v[3] == NONE);
+}
+
+/* transitions/passenger_state.py:48-98 for env b.  target[a] = slot of agent a's passenger inside the env (or NONE).  Distances
+ * come from the PRE-move vectors.  Accept conflicts: while any passenger is claimed by more than one accepting agent, per env
+ * only the closest of ALL contested agents keeps its claim (first index on ties) and every other contested agent loses;
+ * uncontested accepts survive (:54-74). */
+static void rs_passenger_state(const frz_rideshare_cfg* cfg, frz_oracle_rideshare_bufs* s, int64_t b, int32_t nm, const int* accept,
+                               const int* pick, const int* target, int32_t vec[][4]) {
+    const int A = cfg->num_agents;
+    int64_t dist2[FRZ_MAX_AGENTS];
+    int has_vec[FRZ_MAX_AGENTS];
+    for (int a = 0; a < A; ++a) has_vec[a] = vec_dist2(vec[a], &dist2[a]);
+    int accept_target[FRZ_MAX_AGENTS];
+    for (int a = 0; a < A; ++a) accept_target[a] = accept[a] ? target[a] : NONE;
+    for (;;) {
+        int contested[FRZ_MAX_AGENTS], any = 0, winner = 0;
+        for (int a = 0; a < A; ++a) {
+            contested[a] = 0;
+            if (accept_target[a] == NONE) continue;
+            for (int o = 0; o < A; ++o) contested[a] |= o != a && accept_target[o] == accept_target[a];
+            any |= contested[a];
+        }
+        if (!any) break;
+        int found = 0;
+        for (int a = 0; a < A; ++a) /* argmin over the row with non-contested entries at +inf; row of all inf -> index 0 */
+            if (contested[a] && has_vec[a] && (!found || dist2[a] < dist2[winner])) winner = a, found = 1;
+        for (int a = 0; a < A; ++a)
+            if (contested[a] && !(found && a == winner) && !(!found && a == 0)) accept_target[a] = NONE;
+    }
+    for (int a = 0; a < A; ++a)
+        if (accept_target[a] != NONE) {
+            int32_t* p = prow(s, cfg, b, accept_target[a]);
+            p[PSTATE] = 1, p[PACCEPTED] = nm, p[PDRIVER] = a;
+        }
+    for (int a = 0; a < A; ++a)
+        if (pick[a] && target[a] != NONE && has_vec[a] && dist2[a] == 0) { /* distance < 1e-6: the agent already stood on the passenger */
+            int32_t* p = prow(s, cfg, b, target[a]);
+            p[PSTATE] = 2, p[PPICKED] = nm;
+        }
+}
+
+/* transitions/passenger_exit.py:22-56 for env b: drops succeed at distance 0; fares paid; rows removed in order */
+static void rs_passenger_exit(const frz_rideshare_cfg* cfg, frz_oracle_rideshare_bufs* s, int64_t b, const int* drop, const int* target,
+                              int32_t vec[][4], int32_t* fares) {
+    const int A = cfg->num_agents;
+    uint8_t removed[FRZ_MAX_PASSENGERS];
+    memset(removed, 0, sizeof(removed));
+    for (int a = 0; a < A; ++a) {
+        int64_t d2;
+        const int has = vec_dist2(vec[a], &d2);
+        fares[a] = 0;
+        if (drop[a] && target[a] != NONE && has && d2 == 0) {
+            fares[a] = prow(s, cfg, b, target[a])[PFARE];
+            removed[target[a]] = 1;
+        }
+    }
+    int kept = 0;
+    for (int k = 0; k < s->passenger_count[b]; ++k)
+        if (!removed[k]) {
+            if (kept != k) memcpy(prow(s, cfg, b, kept), prow(s, cfg, b, k), PCOLS * sizeof(int32_t));
+            ++kept;
+        }
+    s->passenger_count[b] = kept;
+}
+
+/* Single transitions on the slot table, for the known-answer vectors recorded from the reference's own transition tests
+ * (tests/golden/ka_rideshare.npz): masks uint8 [B][A], targets int32 [B][A] = slot inside the env or -100, vectors int32 [B][A][4] */
+int frz_oracle_rs_passenger_state(const frz_rideshare_cfg* cfg, frz_oracle_rideshare_bufs* s, const uint8_t* accepts, const uint8_t* picks,
+                                  const int32_t* targets, const int32_t* vectors, const int32_t* timesteps) {
+    const int A = cfg->num_agents;
+    for (int64_t b = 0; b < cfg->parallel_envs; ++b) {
+        int accept[FRZ_MAX_AGENTS], pick[FRZ_MAX_AGENTS], target[FRZ_MAX_AGENTS];
+        int32_t vec[FRZ_MAX_AGENTS][4];
+        for (int a = 0; a < A; ++a) {
+            accept[a] = accepts[b * A + a], pick[a] = picks[b * A + a], target[a] = targets[b * A + a];
+            memcpy(vec[a], vectors + (b * A + a) * 4, sizeof(vec[a]));
+        }
+        rs_passenger_state(cfg, s, b, timesteps[b], accept, pick, target, vec);
+    }
+    return FRZ_OK;
+}
+
+int frz_oracle_rs_passenger_exit(const frz_rideshare_cfg* cfg, frz_oracle_rideshare_bufs* s, const uint8_t* drops, const int32_t* targets,
+                                 const int32_t* vectors, int32_t* fares_out) {
+    const int A = cfg->num_agents;
+    for (int64_t b = 0; b < cfg->parallel_envs; ++b) {
+        int drop[FRZ_MAX_AGENTS], target[FRZ_MAX_AGENTS];
+        int32_t vec[FRZ_MAX_AGENTS][4];
+        for (int a = 0; a < A; ++a) {
+            drop[a] = drops[b * A + a], target[a] = targets[b * A + a];
+            memcpy(vec[a], vectors + (b * A + a) * 4, sizeof(vec[a]));
+        }
+        rs_passenger_exit(cfg, s, b, drop, target, vec, fares_out + b * A);
+    }
+    return FRZ_OK;
+}
+
+int frz_oracle_rs_passenger_entry(const frz_rideshare_cfg* cfg, frz_oracle_rideshare_bufs* s, const int32_t* schedule, const int32_t* timesteps) {
+    for (int64_t b = 0; b < cfg->parallel_envs; ++b) passenger_entry(cfg, s, schedule, b, timesteps[b]);
+    return FRZ_OK;
+}
+
 /* One ParallelEnv.step(): utils/conversions.py:59-99 -> utils/env.py:203-242 -> rideshare.py:248-365 -> rebuild */
 int frz_oracle_rideshare_step(const frz_rideshare_cfg* cfg, frz_oracle_rideshare_bufs* s, const int32_t* schedule, const int32_t* actions) {
     const int64_t B = cfg->parallel_envs, cap = B * cfg->max_passengers;
@@ -201,60 +309,9 @@ int frz_oracle_rideshare_step(const frz_rideshare_cfg* cfg, frz_oracle_rideshare
                 p[PX] += move[driver][1];
             }
         }
-        /* (3) transitions/passenger_state.py:48-98.  Distances come from the PRE-move vectors.  Accept conflicts: while any
-         * passenger is claimed by more than one accepting agent, per env only the closest of ALL contested agents keeps
-         * its claim (first index on ties) and every other contested agent loses; uncontested accepts survive (:54-74). */
-        int64_t dist2[FRZ_MAX_AGENTS]; /* squared Euclidean distance; sqrt is monotonic, zero iff zero */
-        int has_vec[FRZ_MAX_AGENTS];
-        for (int a = 0; a < A; ++a) {
-            has_vec[a] = !(vec[a][0] == NONE && vec[a][1] == NONE && vec[a][2] == NONE && vec[a][3] == NONE);
-            const int64_t dy = vec[a][0] - vec[a][2], dx = vec[a][1] - vec[a][3];
-            dist2[a] = dy * dy + dx * dx;
-        }
-        int accept_target[FRZ_MAX_AGENTS];
-        for (int a = 0; a < A; ++a) accept_target[a] = accept[a] ? target[a] : NONE;
-        for (;;) {
-            int contested[FRZ_MAX_AGENTS], any = 0, winner = 0;
-            for (int a = 0; a < A; ++a) {
-                contested[a] = 0;
-                if (accept_target[a] == NONE) continue;
-                for (int o = 0; o < A; ++o) contested[a] |= o != a && accept_target[o] == accept_target[a];
-                any |= contested[a];
-            }
-            if (!any) break;
-            int found = 0;
-            for (int a = 0; a < A; ++a) /* argmin over the row with non-contested entries at +inf; row of all inf -> index 0 */
-                if (contested[a] && has_vec[a] && (!found || dist2[a] < dist2[winner])) winner = a, found = 1;
-            for (int a = 0; a < A; ++a)
-                if (contested[a] && !(found && a == winner) && !(!found && a == 0)) accept_target[a] = NONE;
-        }
-        for (int a = 0; a < A; ++a)
-            if (accept_target[a] != NONE) {
-                int32_t* p = prow(s, cfg, b, accept_target[a]);
-                p[PSTATE] = 1, p[PACCEPTED] = nm, p[PDRIVER] = a;
-            }
-        for (int a = 0; a < A; ++a)
-            if (pick[a] && has_vec[a] && dist2[a] == 0) { /* distance < 1e-6: the agent already stood on the passenger */
-                int32_t* p = prow(s, cfg, b, target[a]);
-                p[PSTATE] = 2, p[PPICKED] = nm;
-            }
-        /* (4) transitions/passenger_exit.py:22-56: drops succeed at distance 0; fares paid; rows removed in order */
-        uint8_t removed[FRZ_MAX_PASSENGERS];
-        memset(removed, 0, sizeof(removed));
-        for (int a = 0; a < A; ++a) {
-            fares[a] = 0;
-            if (drop[a] && has_vec[a] && dist2[a] == 0) {
-                fares[a] = prow(s, cfg, b, target[a])[PFARE];
-                removed[target[a]] = 1;
-            }
-        }
-        int kept = 0;
-        for (int k = 0; k < s->passenger_count[b]; ++k)
-            if (!removed[k]) {
-                if (kept != k) memcpy(prow(s, cfg, b, kept), prow(s, cfg, b, k), PCOLS * sizeof(int32_t));
-                ++kept;
-            }
-        s->passenger_count[b] = kept;
+        /* (3) transitions/passenger_state.py:48-98 on the PRE-move vectors, then (4) transitions/passenger_exit.py:22-56 */
+        rs_passenger_state(cfg, s, b, nm, accept, pick, target, vec);
+        rs_passenger_exit(cfg, s, b, drop, target, vec, fares);
         /* (5) entry of the passengers scheduled for the NEXT timestep (rideshare.py:308) */
         passenger_entry(cfg, s, schedule, b, nm + 1);
 

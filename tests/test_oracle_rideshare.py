@@ -83,3 +83,79 @@ def test_known_answer_movement(oracle):
                 assert [agents_in[b, a, 0] + move[0], agents_in[b, a, 1] + move[1]] == agents_out[b, a].tolist(), what
                 assert np.float32(cost.value) == dist[b, a], what
     assert seen >= 3
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the other three transitions of the reference's own transition tests (tests/golden/ka_rideshare.npz), one call each
+# ------------------------------------------------------------------------------------------------------------
+def _oracle_from_table(oracle, case, schedule=None):
+    """An oracle whose per-env slot tables hold the reference's global passenger table of a recorded call."""
+    agents = np.asarray(case['in_agents'], np.int32)
+    B, A = agents.shape[:2]
+    table = np.asarray(case.get('in_passengers', np.zeros((0, 11))), np.int64).reshape(-1, 11)
+    schedule = np.zeros((0, 7), np.int32) if schedule is None else np.asarray(schedule, np.int32).reshape(-1, 7)
+    cfg = _capi.frz_rideshare_cfg()
+    cfg.parallel_envs, cfg.num_agents, cfg.max_passengers, cfg.schedule_rows = B, A, 32, schedule.shape[0]
+    o = oracle.RideshareOracle(cfg, schedule if schedule.shape[0] else np.zeros((1, 7), np.int32))
+    o.agents[:] = agents
+    slot_of_row = np.full(table.shape[0], -100, np.int32)
+    for r, row in enumerate(table):
+        b = int(row[0])
+        slot_of_row[r] = o.passenger_count[b]
+        o.passengers[b, o.passenger_count[b]] = row[1:]
+        o.passenger_count[b] += 1
+    return o, cfg, slot_of_row
+
+
+def _slots(targets, slot_of_row):
+    targets = np.asarray(targets, np.int64)
+    return np.where(targets == -100, -100, slot_of_row[np.clip(targets, 0, max(len(slot_of_row) - 1, 0))] if len(slot_of_row) else -100).astype(np.int32)
+
+
+def _cases(cls):
+    cases = [c for c in G.known_answers('rideshare') if c['cls'] == cls]
+    assert cases, cls
+    return cases
+
+
+def test_known_answer_passenger_entry(oracle):
+    """PassengerEntryTransition.forward calls of the reference's test_passenger_entry.py."""
+    lib = oracle.lib()
+    for case in _cases('PassengerEntryTransition'):
+        o, cfg, _ = _oracle_from_table(oracle, case, case['buf_schedule'])
+        timesteps = np.ascontiguousarray(case['arg_timesteps'], np.int32)
+        assert lib.frz_oracle_rs_passenger_entry(ctypes.byref(cfg), ctypes.byref(o.bufs), o.schedule.ctypes.data_as(ctypes.c_void_p),
+                                                 timesteps.ctypes.data_as(ctypes.c_void_p)) == 0
+        G.assert_same(o.table(), np.asarray(case['out_passengers'], np.int32).reshape(-1, 11), case['test'])
+        assert int(o.error_flags[0]) == 0
+
+
+def test_known_answer_passenger_state(oracle):
+    """PassengerStateTransition.forward calls of the reference's test_passenger_state.py (accept conflicts, picks on the spot)."""
+    lib = oracle.lib()
+    for case in _cases('PassengerStateTransition'):
+        o, cfg, slot_of_row = _oracle_from_table(oracle, case)
+        accepts = np.ascontiguousarray(case['arg_accepts'], np.uint8)
+        picks = np.ascontiguousarray(case['arg_picks'], np.uint8)
+        targets = np.ascontiguousarray(_slots(case['arg_targets'], slot_of_row))
+        vectors = np.ascontiguousarray(case['arg_vectors'], np.int32)
+        timesteps = np.ascontiguousarray(case['arg_timesteps'], np.int32)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        assert lib.frz_oracle_rs_passenger_state(ctypes.byref(cfg), ctypes.byref(o.bufs), p(accepts), p(picks), p(targets), p(vectors),
+                                                 p(timesteps)) == 0
+        G.assert_same(o.table(), np.asarray(case['out_passengers'], np.int32).reshape(-1, 11), case['test'])
+
+
+def test_known_answer_passenger_exit(oracle):
+    """PassengerExitTransition.forward calls of the reference's test_passenger_exit.py: rows removed in order, fares returned."""
+    lib = oracle.lib()
+    for case in _cases('PassengerExitTransition'):
+        o, cfg, slot_of_row = _oracle_from_table(oracle, case)
+        drops = np.ascontiguousarray(case['arg_drops'], np.uint8)
+        targets = np.ascontiguousarray(_slots(case['arg_targets'], slot_of_row))
+        vectors = np.ascontiguousarray(case['arg_vectors'], np.int32)
+        fares = np.zeros(drops.shape, np.int32)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        assert lib.frz_oracle_rs_passenger_exit(ctypes.byref(cfg), ctypes.byref(o.bufs), p(drops), p(targets), p(vectors), p(fares)) == 0
+        G.assert_same(o.table(), np.asarray(case['out_passengers'], np.int32).reshape(-1, 11), case['test'])
+        G.assert_same(fares, np.asarray(case['ret_0'], np.int32), case['test'] + ' fares')
