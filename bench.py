@@ -135,7 +135,7 @@ def main():
     def episode_metrics():
         # episode end: the rank's own metrics are accumulated on the device; nothing crosses GPUs on the step path.  The
         # job's single collective (one RCCL all-reduce of A + 2 doubles over xGMI) runs once, at the end of the timed region.
-        metrics.add_(sharding.episode_metrics(env._cumulative, env.finished, B * EPISODE))
+        env.accumulate_episode_metrics(metrics)  # one launch: cumulative rewards per agent, env-steps, finished envs
 
     def one_step():
         """Eager path: the same launches the graphs replay, issued one by one through the Python boundary."""

@@ -826,6 +826,63 @@ __global__ void __launch_bounds__(kBlock) wf_policy_kernel(const char* arena, ui
     reinterpret_cast<int2*>(actions)[i] = j < n ? make_int2(j, 0) : make_int2(n, -1);
 }
 
+// Episode metrics in one launch (the reductions a rollout loop takes after each episode): out[a] += sum_b cumulative
+// reward of agent a, out[A] += sum_b num_moves (env-steps taken), out[A + 1] += envs whose agents are all terminated or all
+// truncated.  Deterministic: each of kMetricBlocks workgroups reduces a fixed slice in a fixed order into its own partial
+// row; the workgroup that arrives last (atomic ticket) adds the rows up in index order.
+constexpr int kMetricBlocks = 64;
+
+__global__ void __launch_bounds__(kBlock) wf_metrics_kernel(char* __restrict__ arena, double* __restrict__ out) {
+    const WfDev& d = *reinterpret_cast<const WfDev*>(arena);
+    const int64_t B = d.B;
+    const int A = d.A, nrow = A + 2;
+    __shared__ double s_part[frz::kWaves][FRZ_MAX_AGENTS + 2];
+    __shared__ int s_last;
+    const float* rowsf = reinterpret_cast<const float*>(arena + d.off_rows4);
+    const int32_t* rows = reinterpret_cast<const int32_t*>(arena + d.off_rows4);
+    const uint8_t* rows1 = reinterpret_cast<const uint8_t*>(arena + d.off_rows1);
+    double* const partial = reinterpret_cast<double*>(arena + d.off_metrics);
+    uint32_t* const counter = reinterpret_cast<uint32_t*>(arena + d.off_epoch) + 48;
+    double acc[FRZ_MAX_AGENTS + 2];
+    for (int i = 0; i < nrow; ++i) acc[i] = 0.0;
+    for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < B; b += (int64_t)kMetricBlocks * kBlock) {
+        bool all_term = true, all_trunc = true;
+        for (int a = 0; a < A; ++a) {
+            acc[a] += (double)rowsf[(int64_t)(d.r_cum + a) * B + b];
+            all_term = all_term && rows1[(int64_t)(d.u_term + a) * B + b] != 0;
+            all_trunc = all_trunc && rows1[(int64_t)(d.u_trunc + a) * B + b] != 0;
+        }
+        acc[A] += (double)rows[(int64_t)d.r_moves * B + b];
+        acc[A + 1] += (all_term || all_trunc) ? 1.0 : 0.0;
+    }
+    const int lane = frz::lane_id(), wave = frz::wave_id();
+    for (int i = 0; i < nrow; ++i) {
+        double v = acc[i];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);  // fixed tree: deterministic
+        if (lane == 0) s_part[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < nrow) {
+        double v = 0.0;
+        for (int w = 0; w < frz::kWaves; ++w) v += s_part[w][threadIdx.x];
+        partial[(int64_t)blockIdx.x * nrow + threadIdx.x] = v;
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = atomicAdd(counter, 1u);
+        s_last = t == kMetricBlocks - 1;
+        if (s_last) atomicExch(counter, 0u);
+    }
+    __syncthreads();
+    if (s_last && threadIdx.x < nrow) {
+        __threadfence();
+        double v = 0.0;
+        for (int k = 0; k < kMetricBlocks; ++k) v += __hip_atomic_load(&partial[(int64_t)k * nrow + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        out[threadIdx.x] += v;
+    }
+}
+
 }  // namespace
 
 // ================================================================================================================
@@ -1100,6 +1157,7 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
     p.off_actions = take((int64_t)A * B * 8);
     p.off_error = take(256);
     p.off_epoch = take(256);
+    p.off_metrics = take((int64_t)64 * (FRZ_MAX_AGENTS + 2) * 8);  // partial rows of frz_wildfire_episode_metrics
     p.off_totals = take(2 * kTotalsStride * 4);
     p.off_agg = take((int64_t)p.nchunks * p.nch * 8);
     p.off_prefix = take((int64_t)p.nchunks * p.nch * 8);
@@ -1286,6 +1344,13 @@ int frz_wildfire_timed_rollout(frz_wildfire_env* env, uint64_t policy_seed, uint
     for (int i = 0; i < n_steps; ++i)
         if (hipEventElapsedTime(&kernel_ms[i], env->timing_events[2 * i], env->timing_events[2 * i + 1]) != hipSuccess) return FRZ_E_LAUNCH;
     return FRZ_OK;
+}
+
+int frz_wildfire_episode_metrics(frz_wildfire_env* env, double* metrics, void* stream) {
+    if (!env || !metrics) return FRZ_E_INVALID;
+    if (!env->arena) return FRZ_E_UNBOUND;
+    hipLaunchKernelGGL(wf_metrics_kernel, dim3(kMetricBlocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), env->arena, metrics);
+    return hipGetLastError() == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;
 }
 
 int frz_wildfire_random_policy(frz_wildfire_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out, void* stream) {

@@ -48,7 +48,7 @@ struct WfHot {
     // byte offsets from the arena base
     int64_t off_rows4, off_rows8, off_rows1, off_obs_self, off_obs_others, off_task_values, off_task_offsets, off_obs_map,
         off_act_values, off_act_offsets, off_bad_values, off_bad_offsets, off_mt_state, off_actions, off_error, off_epoch, off_totals,
-        off_agg, off_prefix, off_rand_field, off_rand_agent, total_bytes, pad8_;
+        off_agg, off_prefix, off_rand_field, off_rand_agent, total_bytes, off_metrics;
     float fire_rewards[FRZ_MAX_CELLS];
     int32_t ignition[FRZ_MAX_CELLS];
     int32_t cell_yx[FRZ_MAX_CELLS];  // (y << 16) | x

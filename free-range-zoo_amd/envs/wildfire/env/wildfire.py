@@ -353,6 +353,14 @@ class raw_env(BatchedParallelEnv):
         self.infos['putouts'] = self._putouts
         return ({agent: self.observations[agent] for agent in self.agents}, self.rewards, self.terminations, self.truncations, self.infos)
 
+    @torch.no_grad()
+    def accumulate_episode_metrics(self, metrics: torch.Tensor) -> torch.Tensor:
+        """``metrics`` (float64 ``[A + 2]`` on the device) += (cumulative reward per agent ..., env-steps taken, finished envs): one launch."""
+        if metrics.dtype != torch.float64 or metrics.numel() != len(self.agents) + 2 or not metrics.is_contiguous() or not metrics.is_cuda:
+            raise ValueError('metrics must be a contiguous float64 [A + 2] tensor on the env device')
+        _capi.check(self._lib.frz_wildfire_episode_metrics(self._handle, metrics.data_ptr(), stream_ptr(self.device)), 'frz_wildfire_episode_metrics')
+        return metrics
+
     # ------------------------------------------------------------------------------------------------ spaces
     @torch.no_grad()
     def action_space(self, agent: str) -> BatchedOneOfSpace:

@@ -213,6 +213,12 @@ int frz_wildfire_random_policy(frz_wildfire_env* env, uint64_t policy_seed, uint
  * actions_out is left as it is).  Grid shapes without a fused kernel run the two launches. */
 int frz_wildfire_step_random_policy(frz_wildfire_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out,
                                     int rng_mode, const float* field_randomness, const float* agent_randomness, void* stream);
+/* Episode metrics in one launch (what a rollout loop reduces after an episode; utils/env.py:137-160 bookkeeping arrays):
+ * metrics[a] += sum over envs of agent a's cumulative reward, metrics[A] += sum of num_moves, metrics[A + 1] += number of
+ * envs whose agents are all terminated or all truncated.  metrics: float64 [A + 2] on the device, accumulated in place;
+ * deterministic summation order. */
+int frz_wildfire_episode_metrics(frz_wildfire_env* env, double* metrics, void* stream);
+
 /* Measurement aid: n_steps launches of frz_wildfire_step_random_policy (policy steps first_step ...), back to back with no
  * host synchronisation in between, each bracketed by its own pair of HIP events that take the step dispatch's begin / end
  * timestamps on `stream` (what a profiler's kernel trace reports); synchronises once at the end and returns the durations

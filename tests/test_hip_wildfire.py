@@ -245,6 +245,23 @@ def test_single_seeding_shares_one_host_stream():
         env.step_random_policy(policy_seed=1, policy_step=1)
 
 
+def test_episode_metrics_in_one_launch():
+    """frz_wildfire_episode_metrics accumulates what the torch reductions of utils/sharding.py give."""
+    from free_range_zoo_amd.utils import sharding
+    B = 20011
+    env = make_env(configs.wildfire_openness, B, 20, rng='philox', exact_shapes=False)
+    env.reset(seed=torch.arange(B, dtype=torch.int32))
+    metrics = torch.zeros(5, dtype=torch.float64, device='cuda')
+    for episode in range(2):
+        for t in range(13 + 9 * episode):  # the second episode runs into truncation
+            env.step_random_policy(policy_seed=2, policy_step=t)
+        before = metrics.clone()
+        env.accumulate_episode_metrics(metrics)
+        want = sharding.episode_metrics(env._cumulative, env.finished, int(env.num_moves.sum()))
+        torch.testing.assert_close(metrics - before, want, rtol=1e-12, atol=1e-9)
+    assert float(metrics[4] - before[4]) == B  # every env is truncated at max_steps = 20 by the end of the second block
+
+
 def test_timed_rollout_runs_the_same_steps():
     """frz_wildfire_timed_rollout (measurement aid): same state as the untimed launches, one positive duration per step."""
     import ctypes
