@@ -331,9 +331,8 @@ class raw_env(BatchedParallelEnv):
                     _capi.check(lib.frz_mt19937_seed(self._bufs.mt_state, self._bufs.mt_index, self._bufs.seeds, None, 0,
                                                      self.parallel_envs, stream), 'frz_mt19937_seed')
                 _capi.check(lib.frz_wildfire_reset(handle, stream), 'frz_wildfire_reset')
-            for t in range(steps):
-                _capi.check(lib.frz_wildfire_step_random_policy(handle, policy_seed, t, actions, mode, None, None, stream),
-                            'frz_wildfire_step_random_policy')
+            _capi.check(lib.frz_wildfire_rollout_random_policy(handle, policy_seed, 0, steps, actions, mode, stream),
+                        'frz_wildfire_rollout_random_policy')
         return graph
 
     @torch.no_grad()
@@ -347,6 +346,23 @@ class raw_env(BatchedParallelEnv):
         mode = _capi.FRZ_RNG_MT19937 if mt else _capi.FRZ_RNG_PHILOX
         _capi.check(self._lib.frz_wildfire_step_random_policy(self._handle, policy_seed, policy_step, self._actions.data_ptr(), mode, None, None,
                                                               stream_ptr(self.device)), 'frz_wildfire_step_random_policy')
+        self._publish()
+        self.infos = {agent: {} for agent in self.agents}
+        self.infos['burnouts'] = self._burnouts
+        self.infos['putouts'] = self._putouts
+        return ({agent: self.observations[agent] for agent in self.agents}, self.rewards, self.terminations, self.truncations, self.infos)
+
+    @torch.no_grad()
+    def rollout_random_policy(self, steps: int, policy_seed: int = 0, first_step: int = 0):
+        """``steps`` x ``step_random_policy`` (same results), enqueued by one call through the C boundary."""
+        if not self._has_reset:
+            raise RuntimeError('reset() must be called before rollout_random_policy()')
+        mt = self.rng == 'mt19937'
+        if mt:
+            self.generator._ensure_streams()
+        mode = _capi.FRZ_RNG_MT19937 if mt else _capi.FRZ_RNG_PHILOX
+        _capi.check(self._lib.frz_wildfire_rollout_random_policy(self._handle, policy_seed, first_step, steps, self._actions.data_ptr(), mode,
+                                                                 stream_ptr(self.device)), 'frz_wildfire_rollout_random_policy')
         self._publish()
         self.infos = {agent: {} for agent in self.agents}
         self.infos['burnouts'] = self._burnouts

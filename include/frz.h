@@ -213,6 +213,11 @@ int frz_wildfire_random_policy(frz_wildfire_env* env, uint64_t policy_seed, uint
  * actions_out is left as it is).  Grid shapes without a fused kernel run the two launches. */
 int frz_wildfire_step_random_policy(frz_wildfire_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out,
                                     int rng_mode, const float* field_randomness, const float* agent_randomness, void* stream);
+/* n_steps random-policy steps (policy steps first_step, first_step + 1, ...) = n_steps calls of frz_wildfire_step_random_policy,
+ * stream-ordered, one launch per step; rng_mode FRZ_RNG_PHILOX or FRZ_RNG_MT19937 (capture it into a HIP graph for rollouts). */
+int frz_wildfire_rollout_random_policy(frz_wildfire_env* env, uint64_t policy_seed, uint64_t first_step, int32_t n_steps,
+                                       int32_t* actions_out, int rng_mode, void* stream);
+
 /* Episode metrics in one launch (what a rollout loop reduces after an episode; utils/env.py:137-160 bookkeeping arrays):
  * metrics[a] += sum over envs of agent a's cumulative reward, metrics[A] += sum of num_moves, metrics[A + 1] += number of
  * envs whose agents are all terminated or all truncated.  metrics: float64 [A + 2] on the device, accumulated in place;
