@@ -443,6 +443,14 @@ __global__ void __launch_bounds__(kRoleBlock, (RNG == FRZ_RNG_MT19937 ? 2 : 4)) 
                     for (int i = 0; i < 5 * AMAX; ++i) x_draw[i][slot] = uni[3 * CMAX + i];
                 }
             }
+            if (MODE == kStep) {
+                // the draws are final BEFORE the barrier: the field role reaches it early (the crew's decode is longer) and
+                // the compiler would otherwise sink the generator arithmetic behind it, into the transitions on the critical path
+#pragma unroll
+                for (int e = 0; e < 3; ++e)
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c) asm volatile("" : "+v"(r_field[e][c]));
+            }
             FRZ_RSTAMP(3);
             __syncthreads();  // (1) applied power visible
             FRZ_RSTAMP(4);
