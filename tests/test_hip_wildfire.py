@@ -286,6 +286,25 @@ def test_episode_metrics_in_one_launch():
     assert float(metrics[4] - before[4]) == B  # every env is truncated at max_steps = 20 by the end of the second block
 
 
+def test_reference_evaluation_protocol_runs_unchanged():
+    """The rollout loop of the reference's evaluation script (docs/source/events/moasei-2026/evaluation: 3 firefighters,
+    max_steps=50, buffer_size=50, single_seeding=True, show_bad_actions=False, reset(seed=0), loop until finished)."""
+    from free_range_zoo_amd.envs import wildfire_v0
+    env = wildfire_v0.parallel_env(parallel_envs=64, max_steps=50, configuration=configs.wildfire_openness(), device=torch.device('cuda'),
+                                   buffer_size=50, single_seeding=True, show_bad_actions=False)
+    observations, infos = env.reset(seed=0)
+    assert set(observations) == set(env.agents) and len(env.agents) == 3
+    steps = 0
+    while not torch.all(env.finished):
+        actions = {agent: env.action_space(agent).sample_nested() for agent in env.agents}  # int32 [B, 2] on the device
+        observations, rewards, terminations, truncations, infos = env.step(actions)
+        steps += 1
+        assert steps <= 50
+    assert steps == 50 or bool(env.terminated.all())
+    assert all(rewards[a].shape == (64, ) for a in env.agents)
+    env.check()
+
+
 def test_timed_rollout_runs_the_same_steps():
     """frz_wildfire_timed_rollout (measurement aid): same state as the untimed launches, one positive duration per step."""
     import ctypes
