@@ -1252,6 +1252,12 @@ int frz_wildfire_rebuild(frz_wildfire_env* env, void* stream) {
 int frz_wildfire_reset(frz_wildfire_env* env, void* stream) {
     if (!env) return FRZ_E_INVALID;
     if (!env->arena) return FRZ_E_UNBOUND;
+    if (env->dev.roles) {  // one launch: the configured initial state is produced inside the rebuild kernel
+        WfArgs args{env->arena, nullptr, nullptr, nullptr, &env->dev};
+        const int rc = launch(env, args, FRZ_RNG_INJECTED, kReset, static_cast<hipStream_t>(stream));
+        if (rc == FRZ_OK) env->was_reset = true;
+        return rc;
+    }
     const int blocks = (env->cfg.parallel_envs + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(wf_fill_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), env->arena);
     if (hipGetLastError() != hipSuccess) return FRZ_E_LAUNCH;

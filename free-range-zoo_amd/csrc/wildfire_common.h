@@ -16,7 +16,7 @@ using frz::kBlock;
 
 constexpr int kTotalsStride = 32;  // uint32 words per totals slot (128 B)
 
-enum Mode { kStep = 0, kRebuild = 1 };
+enum Mode { kStep = 0, kRebuild = 1, kReset = 2 };  // kReset (field/crew kernel): the configured initial state instead of loads, then rebuild
 
 enum Flag : uint32_t {
     kStochIncrease = 1u << 0, kStochBurnouts = 1u << 1, kStochDecrease = 1u << 2, kUseFuel = 1u << 3, kStochSuppDecrease = 1u << 4,

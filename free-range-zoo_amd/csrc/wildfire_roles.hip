@@ -144,7 +144,12 @@ __global__ void __launch_bounds__(kRoleBlock, (RNG == FRZ_RNG_MT19937 ? 2 : 4)) 
         Cells e;
         const uint32_t bl = env_index(chunk);
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c) e.f[c] = c < HW ? at32(rows, (uint32_t)(r_fires + c) * Bu + bl) : 0;
+        for (int c = 0; c < CMAX; ++c) {
+            if (MODE == kReset)  // wildfire.py:347-349: +type on the configured lit cells, -type elsewhere
+                e.f[c] = c < HW ? (dev->lit[c] ? dev->fire_types[c] : -dev->fire_types[c]) : 0;
+            else
+                e.f[c] = c < HW ? at32(rows, (uint32_t)(r_fires + c) * Bu + bl) : 0;
+        }
         return e;
     };
     auto load_field = [&](int chunk, FDraws& draws) {
@@ -152,8 +157,13 @@ __global__ void __launch_bounds__(kRoleBlock, (RNG == FRZ_RNG_MT19937 ? 2 : 4)) 
         const uint32_t bl = env_index(chunk);
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) {
-            e.in[c] = c < HW ? at32(rows, (uint32_t)(r_intensity + c) * Bu + bl) : 0;
-            e.fu[c] = c < HW ? at32(rows, (uint32_t)(r_fuel + c) * Bu + bl) : 0;
+            if (MODE == kReset) {  // wildfire.py:350-351
+                e.in[c] = (c < HW && dev->lit[c]) ? dev->ignition[c] : 0;
+                e.fu[c] = (c < HW && dev->fire_types[c] != 0) ? dev->initial_fuel : 0;
+            } else {
+                e.in[c] = c < HW ? at32(rows, (uint32_t)(r_intensity + c) * Bu + bl) : 0;
+                e.fu[c] = c < HW ? at32(rows, (uint32_t)(r_fuel + c) * Bu + bl) : 0;
+            }
         }
         e.nm = e.mti = 0;
         e.seed = 0;
@@ -179,7 +189,11 @@ __global__ void __launch_bounds__(kRoleBlock, (RNG == FRZ_RNG_MT19937 ? 2 : 4)) 
             e.supp[a] = e.capa[a] = e.cum[a] = 0.0f;
             e.eqs[a] = e.act_idx[a] = 0;
             e.act_id[a] = -1;
-            if (a < A) {
+            if (a < A && MODE == kReset) {  // wildfire.py:352-354
+                e.supp[a] = dev->initial_suppressant;
+                e.capa[a] = dev->initial_capacity;
+                e.eqs[a] = dev->initial_equipment;
+            } else if (a < A) {
                 e.supp[a] = at32(rowsf, (uint32_t)(r_supp + a) * Bu + bl);
                 e.capa[a] = at32(rowsf, (uint32_t)(r_cap + a) * Bu + bl);
                 e.eqs[a] = at32(rows, (uint32_t)(r_equip + a) * Bu + bl);
@@ -195,8 +209,8 @@ __global__ void __launch_bounds__(kRoleBlock, (RNG == FRZ_RNG_MT19937 ? 2 : 4)) 
         }
         // agents share one termination / truncation value (wildfire.py:579, utils/env.py:231-233): row 0 is read,
         // all A rows are written
-        e.term = at32(rows1, u_term * Bu + bl);
-        e.trunc = at32(rows1, u_trunc * Bu + bl);
+        e.term = MODE == kReset ? 0u : at32(rows1, u_term * Bu + bl);
+        e.trunc = MODE == kReset ? 0u : at32(rows1, u_trunc * Bu + bl);
         e.nm = e.nb = 0;
         e.seed = 0;
         if (MODE == kStep) {
@@ -541,7 +555,7 @@ __global__ void __launch_bounds__(kRoleBlock, (RNG == FRZ_RNG_MT19937 ? 2 : 4)) 
             FRZ_RSTAMP(6);
 
             // ---- phase 3: cell rows (the crew scans meanwhile)
-            if (MODE == kStep && !FRZ_SKIP(2)) {
+            if ((MODE == kStep || MODE == kReset) && !FRZ_SKIP(2)) {
 #pragma unroll
                 for (int c = 0; c < CMAX; ++c)
                     if (c < HW) {
@@ -770,6 +784,24 @@ __global__ void __launch_bounds__(kRoleBlock, (RNG == FRZ_RNG_MT19937 ? 2 : 4)) 
                     }
                 }
             }
+            if (MODE == kReset) {  // the configured agent state + zeroed bookkeeping (utils/env.py:137-160)
+#pragma unroll
+                for (int a = 0; a < AMAX; ++a)
+                    if (a < A) {
+                        at32(rowsf, (uint32_t)(r_supp + a) * Bu + bl) = supp[a];
+                        at32(rowsf, (uint32_t)(r_cap + a) * Bu + bl) = capa[a];
+                        at32(rows, (uint32_t)(r_equip + a) * Bu + bl) = eqs[a];
+                        at32(rowsf, (uint32_t)(r_rewards + a) * Bu + bl) = 0.0f;
+                        at32(rowsf, (uint32_t)(r_cum + a) * Bu + bl) = 0.0f;
+                        at32(rows1, (u_term + (uint32_t)a) * Bu + bl) = (uint8_t)0;
+                        at32(rows1, (u_trunc + (uint32_t)a) * Bu + bl) = (uint8_t)0;
+                    }
+                at32(rows, (uint32_t)r_moves * Bu + bl) = 0;
+                at32(rows, (uint32_t)r_burnouts * Bu + bl) = 0;
+                at32(rows8, q_burnouts * Bu + bl) = 0;
+                at32(rows8, q_putouts * Bu + bl) = 0;
+                at32(rows1, u_frozen * Bu + bl) = (uint8_t)0;
+            }
 #pragma unroll
             for (int a = 0; a < AMAX; ++a)
                 if (a < A) x_supp[a][slot] = supp[a];  // the field role stores the agent observations
@@ -975,7 +1007,10 @@ __global__ void __launch_bounds__(kRoleBlock, (RNG == FRZ_RNG_MT19937 ? 2 : 4)) 
 template <int CMAX, int AMAX, bool EXACT>
 void launch_roles_variant(const WfArgs& a, const WfDev* dev, int grid, int rng, int mode, hipStream_t stream) {
     const WfLaunch batch = make_launch(a);
-    if (mode == kRebuild) {
+    if (mode == kReset) {
+        launch_step_kernel(a, wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kReset>, grid, kRoleBlock, stream, a.arena, dev, a.actions,
+                           a.field_rand, a.agent_rand, batch);
+    } else if (mode == kRebuild) {
         launch_step_kernel(a, wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kRebuild>, grid, kRoleBlock, stream, a.arena, dev, a.actions,
                            a.field_rand, a.agent_rand, batch);
     } else if (rng == FRZ_RNG_PHILOX) {
