@@ -578,6 +578,10 @@ int frz_cybersecurity_create(const frz_cybersecurity_cfg* cfg, frz_cybersecurity
         return here;
     };
     p.off_rows4 = take((int64_t)p.n_rows4 * B * 4);
+    if ((int64_t)p.n_rows4 * B * 4 >= (int64_t)1 << 32) {  // the row blocks are addressed with 32-bit byte offsets
+        delete env;
+        return FRZ_E_INVALID;
+    }
     p.off_rows1 = take((int64_t)p.n_rows1 * B);
     // the step kernel derives these from (N, D, A) alone (its loads start before the configuration block is staged)
     if (p.off_rows4 != kDevBlockBytes || p.r_state != 0 || p.r_loc != N || p.r_last != N + D || p.r_moves != N + 2 * D ||

@@ -622,8 +622,16 @@ int frz_rideshare_create(const frz_rideshare_cfg* cfg, const int32_t* schedule, 
         return here;
     };
     p.off_rows4 = take((int64_t)p.n_rows4 * B * 4);
+    if ((int64_t)p.n_rows4 * B * 4 >= (int64_t)1 << 32) {  // the row blocks are addressed with 32-bit byte offsets
+        delete env;
+        return FRZ_E_INVALID;
+    }
     p.off_rows1 = take((int64_t)p.n_rows1 * B);
     p.off_passengers = take((int64_t)PCOLS * P * B * 4);
+    if ((int64_t)PCOLS * P * B * 4 >= (int64_t)1 << 32) {  // the passenger slots are addressed with 32-bit byte offsets
+        delete env;
+        return FRZ_E_INVALID;
+    }
     p.off_etc = take(B * 8);
     p.off_obs_self = take((int64_t)A * B * 16);
     p.off_obs_others = take((int64_t)A * B * (A - 1) * 16);

@@ -1134,6 +1134,10 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
         return here;
     };
     p.off_rows4 = take((int64_t)p.n_rows4 * B * 4);
+    if ((int64_t)p.n_rows4 * B * 4 >= (int64_t)1 << 32) {  // the row blocks are addressed with 32-bit byte offsets
+        delete env;
+        return FRZ_E_INVALID;
+    }
     // the step kernels derive these from (HW, A) and the batch size alone (their loads start before the configuration
     // block is staged): keep both sides in step
     if (p.off_rows4 != kDevBlockBytes || p.r_fires != 0 || p.r_intensity != HW || p.r_fuel != 2 * HW || p.r_supp != 3 * HW ||

@@ -422,13 +422,13 @@ __global__ void __launch_bounds__(kRoleBlock, (RNG == FRZ_RNG_MT19937 ? 2 : 4)) 
                     for (int k = 0; k <= U; ++k) {
                         int j = i0 + k;
                         j -= j >= kN ? kN : 0;
-                        w[k] = at32(mt, (uint32_t)j * Bu + bl);
+                        w[k] = mt[(int64_t)j * B + bl];
                     }
 #pragma unroll
                     for (int k = 0; k < U; ++k) {
                         int j = i0 + k + kM;
                         j -= j >= kN ? kN : 0;
-                        far[k] = at32(mt, (uint32_t)j * Bu + bl);
+                        far[k] = mt[(int64_t)j * B + bl];
                     }
                     float uni[U];
 #pragma unroll
@@ -437,7 +437,7 @@ __global__ void __launch_bounds__(kRoleBlock, (RNG == FRZ_RNG_MT19937 ? 2 : 4)) 
                         uint32_t v = far[k] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
                         int j = i0 + k;
                         j -= j >= kN ? kN : 0;
-                        at32(mt, (uint32_t)j * Bu + bl) = v;
+                        mt[(int64_t)j * B + bl] = v;
                         v ^= v >> 11;
                         v ^= (v << 7) & 0x9d2c5680u;
                         v ^= (v << 15) & 0xefc60000u;
