@@ -108,7 +108,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or 'RANK' in os.environ:  # launched by torch.distributed.run (also with one rank: same code path as N > 1)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend='nccl', device_id=device)  # RCCL over xGMI

@@ -265,7 +265,7 @@ class raw_env(BatchedParallelEnv):
         mode = _capi.FRZ_RNG_MT19937 if mt else _capi.FRZ_RNG_PHILOX
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode='thread_local'):
             stream = stream_ptr(self.device)
             if include_reset:
                 if mt:

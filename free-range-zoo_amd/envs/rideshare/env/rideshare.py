@@ -253,7 +253,7 @@ class raw_env(BatchedParallelEnv):
         lib, handle, actions = self._lib, self._handle, self._actions.data_ptr()
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode='thread_local'):
             stream = stream_ptr(self.device)
             if include_reset:
                 _capi.check(lib.frz_rideshare_reset(handle, stream), 'frz_rideshare_reset')

@@ -324,7 +324,9 @@ class raw_env(BatchedParallelEnv):
         mode = _capi.FRZ_RNG_MT19937 if mt else _capi.FRZ_RNG_PHILOX
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread-local capture: other threads of the process (e.g. the RCCL watchdog of torch.distributed) may touch the HIP
+        # runtime while this thread records the launches
+        with torch.cuda.graph(graph, capture_error_mode='thread_local'):
             stream = stream_ptr(self.device)
             if include_reset:
                 if mt:
