@@ -821,8 +821,14 @@ __global__ void __launch_bounds__(kBlock) wf_policy_kernel(const char* arena, ui
     const int64_t* rows8 = reinterpret_cast<const int64_t*>(arena + d.off_rows8);
     const int n = (d.flags & kShowBad) ? (int)rows8[d.q_etc * B + b] : rows[d.r_atc * B + i];
     const uint32_t env_seed = (uint32_t)rows[d.r_seeds * B + b];
-    const frz::Philox4 w = frz::philox4x32_10((uint32_t)(i / B), 0u, step_lo, step_hi, seed_lo ^ env_seed, seed_hi);  // (agent, step) keyed by the env seed
-    const int j = (int)(((uint64_t)w.w[0] * (uint64_t)(n + 1)) >> 32);
+    // one block serves four agents: agent a draws word a % 4 of block (a / 4, step), keyed by the env seed
+    const uint32_t agent = (uint32_t)(i / B);
+    const frz::Philox4 w = frz::philox4x32_10(agent >> 2, 0u, step_lo, step_hi, seed_lo ^ env_seed, seed_hi);
+    uint32_t word = w.w[0];
+    word = (agent & 3u) == 1u ? w.w[1] : word;
+    word = (agent & 3u) == 2u ? w.w[2] : word;
+    word = (agent & 3u) == 3u ? w.w[3] : word;
+    const int j = (int)(((uint64_t)word * (uint64_t)(n + 1)) >> 32);
     reinterpret_cast<int2*>(actions)[i] = j < n ? make_int2(j, 0) : make_int2(n, -1);
 }
 

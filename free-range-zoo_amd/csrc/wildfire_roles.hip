@@ -681,6 +681,11 @@ __global__ void __launch_bounds__(kRoleBlock, (RNG == FRZ_RNG_MT19937 ? 2 : 4)) 
 #pragma unroll
                 for (int c = 0; c < CMAX; ++c) ap[c] = 0.0f;
                 const bool show_bad = (flags & kShowBad) != 0;
+                // stream of frz_wildfire_random_policy: agent a draws word a % 4 of block (a / 4, policy step), keyed by the env seed
+                frz::Philox4 policy_block{};
+                if (launch.policy)
+                    policy_block = frz::philox4x32_10(0u, 0u, launch.policy_step_lo, launch.policy_step_hi, launch.policy_seed_lo ^ crw.seed,
+                                                      launch.policy_seed_hi);
 #pragma unroll
                 for (int a = 0; a < AMAX; ++a) {
                     if (a < A) {
@@ -692,9 +697,7 @@ __global__ void __launch_bounds__(kRoleBlock, (RNG == FRZ_RNG_MT19937 ? 2 : 4)) 
                             // baselines/random.py:20), the stream of frz_wildfire_random_policy: member j ~ U{0..n};
                             // j < n -> [j, 0] (fight task j), j == n -> [n, -1] (noop / refill)
                             const int n = popc(sel);
-                            const frz::Philox4 w = frz::philox4x32_10((uint32_t)a, 0u, launch.policy_step_lo, launch.policy_step_hi,
-                                                                      launch.policy_seed_lo ^ crw.seed, launch.policy_seed_hi);
-                            const int j = (int)(((uint64_t)w.w[0] * (uint64_t)(n + 1)) >> 32);
+                            const int j = (int)(((uint64_t)policy_block.w[a] * (uint64_t)(n + 1)) >> 32);  // AMAX <= 4: one block
                             act_idx = j < n ? j : n;
                             act_id = j < n ? 0 : -1;
                             reinterpret_cast<int2*>(launch.actions_out)[a * B + bl] = make_int2(act_idx, act_id);

@@ -203,7 +203,7 @@ int frz_wildfire_rebuild(frz_wildfire_env* env, void* stream);
 int frz_wildfire_step(frz_wildfire_env* env, const int32_t* actions, int rng_mode, const float* field_randomness,
                       const float* agent_randomness, void* stream);
 /* uniform random policy over OneOf([task]*n + [noop]) (spaces/actions.py:23-41): writes int32 [A][B][2];
- * member j = (word 0 of Philox(counter (agent, 0, step, step >> 32), key (seed ^ seeds[b], seed >> 32)) * (n + 1)) >> 32:
+ * member j = (word agent % 4 of Philox(counter (agent / 4, 0, step, step >> 32), key (seed ^ seeds[b], seed >> 32)) * (n + 1)) >> 32:
  * the stream of an env depends on its seed only, so a sharded batch draws what the unsharded one draws */
 int frz_wildfire_random_policy(frz_wildfire_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out,
                                void* stream);
@@ -312,7 +312,8 @@ int frz_cybersecurity_rebuild(frz_cybersecurity_env* env, void* stream);
  *   node n draw  = word n & 3 of counter (n >> 2, step, 0, 0);  agent a draw = word a & 3 of counter (a >> 2, step, 1, 0) */
 int frz_cybersecurity_step(frz_cybersecurity_env* env, const int32_t* actions, int rng_mode, const float* network_randomness,
                            const float* agent_randomness, void* stream);
-/* uniform random policy over each agent's OneOf action space (spaces/actions.py:11-99), Philox keyed like wildfire's */
+/* uniform random policy over each agent's OneOf action space (spaces/actions.py:11-99): member from word 0 of
+ * Philox(counter (agent, 0, step, step >> 32), key (seed ^ seeds[b], seed >> 32)) */
 int frz_cybersecurity_random_policy(frz_cybersecurity_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out,
                                     void* stream);
 

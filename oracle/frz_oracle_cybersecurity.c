@@ -248,7 +248,7 @@ void frz_oracle_cybersecurity_philox_randomness(const frz_cybersecurity_cfg* cfg
 
 /* Uniform member of each agent's OneOf action space (spaces/actions.py:11-99): n task members then the tail
  * attacker [noop]; defender [noop, patch, monitor] (patch dropped at the home node unless show_bad_actions; noop only
- * when the agent has no task).  Philox keyed like the wildfire policy. */
+ * when the agent has no task).  word 0 of Philox(counter (agent, 0, step lo, step hi), key (seed lo ^ env seed, seed hi)). */
 void frz_oracle_cybersecurity_random_policy(const frz_cybersecurity_cfg* cfg, const int32_t* agent_task_count, const int32_t* location,
                                             const int32_t* env_seeds, uint64_t seed, uint64_t step, int32_t* actions) {
     const int64_t B = cfg->parallel_envs;

@@ -113,17 +113,18 @@ void frz_oracle_wildfire_philox_randomness(const frz_wildfire_cfg* cfg, const in
 }
 
 /* Uniform random policy over OneOf([task]*n + [noop]) (spaces/actions.py:23-41): member j = floor(u32 * (n+1) / 2^32)
- * with u32 = word 0 of Philox(counter = (agent, 0, step lo, step hi), key = (seed lo ^ env seed, seed hi)). */
+ * with u32 = word agent % 4 of Philox(counter = (agent / 4, 0, step lo, step hi), key = (seed lo ^ env seed, seed hi)). */
 void frz_oracle_wildfire_random_policy(const frz_wildfire_cfg* cfg, const int32_t* agent_task_count, const int64_t* env_task_count,
                                        const int32_t* env_seeds, uint64_t seed, uint64_t step, int32_t* actions) {
     const int64_t B = cfg->parallel_envs;
     for (int64_t i = 0; i < (int64_t)cfg->num_agents * B; ++i) {
         const int32_t n = cfg->show_bad_actions ? (int32_t)env_task_count[i % B] : agent_task_count[i];
-        const uint32_t ctr[4] = {(uint32_t)(i / B), 0u, (uint32_t)step, (uint32_t)(step >> 32)};
+        const uint32_t agent = (uint32_t)(i / B); /* one block serves four agents: agent a draws word a % 4 of block a / 4 */
+        const uint32_t ctr[4] = {agent >> 2, 0u, (uint32_t)step, (uint32_t)(step >> 32)};
         const uint32_t key[2] = {(uint32_t)seed ^ (uint32_t)env_seeds[i % B], (uint32_t)(seed >> 32)};
         uint32_t out[4];
         frz_oracle_philox4x32_10(ctr, key, out);
-        const int32_t j = (int32_t)(((uint64_t)out[0] * (uint64_t)(n + 1)) >> 32);
+        const int32_t j = (int32_t)(((uint64_t)out[agent & 3u] * (uint64_t)(n + 1)) >> 32);
         actions[i * 2 + 0] = j < n ? j : n;
         actions[i * 2 + 1] = j < n ? 0 : -1;
     }
