@@ -1,0 +1,56 @@
+"""State API surface + behaviour on CPU tensors (mirrors the reference's structures/test_state.py for the three domains and
+exercises what those tests only name: clone / save_initial / restore_initial / checkpoint round trips, partial restores)."""
+import pytest
+import torch
+
+from free_range_zoo_amd.envs.cybersecurity.env.structures.state import CybersecurityState
+from free_range_zoo_amd.envs.rideshare.env.structures.state import RideshareState
+from free_range_zoo_amd.envs.wildfire.env.structures.state import WildfireState
+
+METHODS = ('to', 'save_initial', 'restore_initial', 'save_checkpoint', 'restore_from_checkpoint', 'clone')
+
+
+@pytest.mark.parametrize('cls', [WildfireState, CybersecurityState, RideshareState])
+@pytest.mark.parametrize('method', METHODS)
+def test_state_includes_method(cls, method):
+    assert hasattr(cls, method) and callable(getattr(cls, method)), f'{cls.__name__} does not include {method}'
+
+
+def _wildfire_state(B=5):
+    g = torch.Generator().manual_seed(0)
+    return WildfireState(fires=torch.randint(-2, 3, (B, 2, 3), generator=g, dtype=torch.int32),
+                         intensity=torch.randint(0, 4, (B, 2, 3), generator=g, dtype=torch.int32),
+                         fuel=torch.randint(0, 3, (B, 2, 3), generator=g, dtype=torch.int32),
+                         agents=torch.tensor([[0, 0], [0, 1], [0, 2]], dtype=torch.int32),
+                         suppressants=torch.rand((B, 3), generator=g), capacity=torch.rand((B, 3), generator=g),
+                         equipment=torch.randint(0, 3, (B, 3), generator=g, dtype=torch.int32))
+
+
+def test_clone_is_deep_and_partial_restores_touch_only_their_envs():
+    s = _wildfire_state()
+    c = s.clone()
+    s.fires += 7
+    assert not torch.equal(s.fires, c.fires)  # clone does not alias
+    s.save_initial()
+    before = s.clone()
+    s.fires.zero_()
+    s.suppressants.fill_(9.0)
+    idx = torch.tensor([1, 3])
+    s.restore_initial(idx)
+    assert torch.equal(s.fires[idx], before.fires[idx]) and torch.equal(s.suppressants[idx], before.suppressants[idx])
+    keep = torch.tensor([0, 2, 4])
+    assert bool((s.fires[keep] == 0).all()) and bool((s.suppressants[keep] == 9.0).all())
+    s.restore_initial()
+    assert torch.equal(s.fires, before.fires) and torch.equal(s.suppressants, before.suppressants)
+
+
+def test_checkpoint_round_trip():
+    s = _wildfire_state()
+    s.save_checkpoint()
+    snapshot = s.clone()
+    s.intensity += 3
+    s.equipment.zero_()
+    s.restore_from_checkpoint(torch.tensor([0]))
+    assert torch.equal(s.intensity[0], snapshot.intensity[0]) and not torch.equal(s.intensity[1:], snapshot.intensity[1:])
+    s.restore_from_checkpoint()
+    assert torch.equal(s.intensity, snapshot.intensity) and torch.equal(s.equipment, snapshot.equipment)
