@@ -218,6 +218,15 @@ int frz_wildfire_step_random_policy(frz_wildfire_env* env, uint64_t policy_seed,
 int frz_wildfire_rollout_random_policy(frz_wildfire_env* env, uint64_t policy_seed, uint64_t first_step, int32_t n_steps,
                                        int32_t* actions_out, int rng_mode, void* stream);
 
+/* Scripted baselines "always fight the strongest / weakest fire" (envs/wildfire/baselines/strongest.py:32-62, weakest.py) as a
+ * device-side policy on the observation buffers: task_values int64 [*][4] + task_offsets int64 [B+1] (the `tasks` observation),
+ * map_offsets int64 [B+1] / map_lengths int64 [B] (the agent's action mapping), obs_self float32 [B][4].  Candidates are
+ * the intensities of the env's first map_lengths[b] task rows (indexed by position, as the reference does); ties are broken
+ * by word 0 of Philox(counter (first_env_index + b, 0, step, step >> 32), key (seed, seed >> 32)); actions_out int32 [B][2]. */
+int frz_wildfire_extreme_fire_policy(const int64_t* task_values, const int64_t* task_offsets, const int64_t* map_offsets,
+                                     const int64_t* map_lengths, const float* obs_self, int64_t parallel_envs, int weakest,
+                                     uint64_t seed, uint64_t step, int64_t first_env_index, int32_t* actions_out, void* stream);
+
 /* Episode metrics in one launch (what a rollout loop reduces after an episode; utils/env.py:137-160 bookkeeping arrays):
  * metrics[a] += sum over envs of agent a's cumulative reward, metrics[A] += sum of num_moves, metrics[A + 1] += number of
  * envs whose agents are all terminated or all truncated.  metrics: float64 [A + 2] on the device, accumulated in place;

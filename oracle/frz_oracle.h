@@ -158,6 +158,10 @@ void frz_oracle_mt19937_generate(uint32_t* mt_state, int32_t* mt_index, float* o
 void frz_oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 /* the float stream FRZ_RNG_PHILOX defines: draw d of env with seed s at step t */
 float frz_oracle_philox_uniform(int32_t seed, uint32_t step, uint32_t draw, uint32_t stream);
+/* the scripted strongest / weakest fire baselines (envs/wildfire/baselines/strongest.py, weakest.py) on the jagged observation */
+void frz_oracle_wildfire_extreme_policy(const int64_t* task_values, const int64_t* task_offsets, const int64_t* map_offsets,
+                                        const int64_t* map_lengths, const float* obs_self, int64_t B, int weakest, uint64_t seed, uint64_t step,
+                                        int64_t first_env, int32_t* actions);
 void frz_oracle_wildfire_philox_randomness(const frz_wildfire_cfg* cfg, const int32_t* seeds, const int32_t* num_moves, float* field,
                                            float* agent);
 void frz_oracle_wildfire_random_policy(const frz_wildfire_cfg* cfg, const int32_t* agent_task_count, const int64_t* env_task_count,

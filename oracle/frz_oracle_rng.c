@@ -129,3 +129,44 @@ void frz_oracle_wildfire_random_policy(const frz_wildfire_cfg* cfg, const int32_
         actions[i * 2 + 1] = j < n ? 0 : -1;
     }
 }
+
+/* envs/wildfire/baselines/strongest.py:32-62 / weakest.py: the scripted "always fight the strongest (weakest) fire" agents.
+ * observation = (obs, {'agent_action_mapping': mapping}); candidates = intensity (task column 3) of the env's FIRST len(mapping[b])
+ * task rows (:47-48 index the padded task tensor by position); empty mapping everywhere -> all [-1, -1] (:41-43); empty in
+ * this env -> [-1, -1] (:50-52); ties broken uniformly (:54-57; the reference uses torch's global generator, the build's
+ * stream is word 0 of Philox(counter (first_env + b, 0, step lo, step hi), key (seed lo, seed hi)), member
+ * floor(u32 * ties / 2^32)); no suppressant (self[:, 3] == 0) -> second component -1 (:62). */
+void frz_oracle_wildfire_extreme_policy(const int64_t* task_values, const int64_t* task_offsets, const int64_t* map_offsets,
+                                        const int64_t* map_lengths, const float* obs_self, int64_t B, int weakest, uint64_t seed, uint64_t step,
+                                        int64_t first_env, int32_t* actions) {
+    const int any_mapping = map_offsets[B] - map_offsets[0] > 0;
+    for (int64_t b = 0; b < B; ++b) {
+        int32_t idx = -1, act = -1;
+        const int64_t n = map_lengths[b];
+        if (any_mapping && n > 0) {
+            const int64_t* rows = task_values + task_offsets[b] * 4;
+            int64_t best = rows[3];
+            for (int64_t k = 1; k < n; ++k) {
+                const int64_t v = rows[k * 4 + 3];
+                if (weakest ? v < best : v > best) best = v;
+            }
+            int64_t ties = 0;
+            for (int64_t k = 0; k < n; ++k) ties += rows[k * 4 + 3] == best;
+            const uint32_t ctr[4] = {(uint32_t)(b + first_env), 0u, (uint32_t)step, (uint32_t)(step >> 32)};
+            const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+            uint32_t out[4];
+            frz_oracle_philox4x32_10(ctr, key, out);
+            int64_t pick = (int64_t)(((uint64_t)out[0] * (uint64_t)ties) >> 32);
+            for (int64_t k = 0; k < n; ++k)
+                if (rows[k * 4 + 3] == best && pick-- == 0) {
+                    idx = (int32_t)k;
+                    break;
+                }
+            act = 0;
+        }
+        if (any_mapping && obs_self[b * 4 + 3] == 0.0f) act = -1;
+        actions[b * 2 + 0] = idx;
+        actions[b * 2 + 1] = act;
+    }
+}
+

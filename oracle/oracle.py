@@ -163,6 +163,21 @@ def wildfire_random_policy(cfg, agent_task_count: np.ndarray, env_task_count: np
     return actions
 
 
+def wildfire_extreme_policy(task_values, task_offsets, map_offsets, map_lengths, obs_self, weakest: bool, seed: int, step: int,
+                            first_env: int = 0) -> np.ndarray:
+    """envs/wildfire/baselines/strongest.py / weakest.py on the jagged observation -> int32 [B, 2]."""
+    tv = np.ascontiguousarray(task_values, np.int64).reshape(-1, 4)
+    to, mo = np.ascontiguousarray(task_offsets, np.int64), np.ascontiguousarray(map_offsets, np.int64)
+    ml, ob = np.ascontiguousarray(map_lengths, np.int64), np.ascontiguousarray(obs_self, np.float32)
+    B = ml.shape[0]
+    if tv.shape[0] == 0:
+        tv = np.zeros((1, 4), np.int64)
+    actions = np.zeros((B, 2), np.int32)
+    lib().frz_oracle_wildfire_extreme_policy(_ptr(tv), _ptr(to), _ptr(mo), _ptr(ml), _ptr(ob), ctypes.c_int64(B), ctypes.c_int(int(weakest)),
+                                             ctypes.c_uint64(seed), ctypes.c_uint64(step), ctypes.c_int64(first_env), _ptr(actions))
+    return actions
+
+
 class _ArrayOracle:
     """Common plumbing: named numpy arrays bound to a ctypes bufs struct."""
 

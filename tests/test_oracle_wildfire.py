@@ -190,3 +190,49 @@ def test_in_range_truth_table(oracle):
     f.argtypes = [ctypes.c_int32] * 4 + [ctypes.c_float]
     assert f(0, 0, 1, 1, 1.0) == 1 and f(0, 0, 2, 1, 1.0) == 0 and f(0, 0, 0, 0, 0.0) == 1
     assert f(3, 3, 1, 2, 2.0) == 1 and f(3, 3, 0, 3, 2.0) == 0 and f(0, 0, 1, 0, 0.5) == 0
+
+
+def _baseline_cases():
+    data = np.load(G.golden_path('baselines_wildfire.npz'))
+    for i in range(int(data['cases'])):
+        p = f'c{i}_'
+        yield i, {k[len(p):]: data[k] for k in data.files if k.startswith(p)}
+
+
+def check_extreme_answer(got, case, kind, what):
+    """Exact where the extreme intensity is unique; where the reference broke a tie with torch's global generator, any tied index."""
+    want = case[kind]
+    counts, lengths, values = case['task_counts'], case['map_lengths'], case['task_values']
+    offsets = np.concatenate([[0], np.cumsum(counts)])
+    assert np.array_equal(got[:, 1], want[:, 1]), f'{what}: action column'
+    for b in range(len(lengths)):
+        n = int(lengths[b])
+        if lengths.sum() == 0 or n == 0:
+            assert got[b, 0] == want[b, 0] == -1, f'{what}: env {b} has no mapped task'
+            continue
+        intensity = values[offsets[b]:offsets[b] + n, 3]
+        best = intensity.min() if kind == 'weakest' else intensity.max()
+        assert intensity[want[b, 0]] == best, f'{what}: the recorded answer is not an extreme?!'
+        if (intensity == best).sum() == 1:
+            assert got[b, 0] == want[b, 0], f'{what}: env {b}'
+        else:
+            assert 0 <= got[b, 0] < n and intensity[got[b, 0]] == best, f'{what}: env {b} (tie)'
+
+
+def test_scripted_baselines_match_reference_answers(oracle):
+    """Strongest / Weakest baselines of the reference (envs/wildfire/baselines) on 154 recorded (observation, mapping) pairs."""
+    seen_tie = seen_empty = 0
+    for i, case in _baseline_cases():
+        counts, lengths = case['task_counts'], case['map_lengths']
+        task_offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        map_offsets = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+        for kind in ('strongest', 'weakest'):
+            got = oracle.wildfire_extreme_policy(case['task_values'], task_offsets, map_offsets, lengths, case['obs_self'], kind == 'weakest',
+                                                 seed=5, step=i)
+            check_extreme_answer(got, case, kind, f'case {i} {kind}')
+        seen_empty += int((lengths == 0).any())
+        for b in range(len(lengths)):
+            v = case['task_values'][task_offsets[b]:task_offsets[b] + lengths[b], 3]
+            seen_tie += int(len(v) > 1 and (v == v.max()).sum() > 1)
+    assert seen_tie > 0 and seen_empty > 0  # the fixtures exercise ties and empty mappings
+

@@ -594,7 +594,52 @@ def record_misc():
     print('misc vectors written')
 
 
-PARTS = {'ka': record_known_answers, 'traj_wildfire': record_wildfire_trajectories, 'traj_cybersecurity': record_cyber_trajectories,
+# ----------------------------------------------------------------------------------------------------------
+# scripted wildfire baselines: the reference's agents on observations of the reference env
+# ----------------------------------------------------------------------------------------------------------
+def record_wildfire_baselines():
+    """Runs free_range_zoo.envs.wildfire.baselines.{Strongest,Weakest}Baseline.observe() on (observation, action mapping) pairs of
+    the unmodified reference env (the pair is what wrappers/action_task.py:45 hands to an agent) and records inputs and answers."""
+    from free_range_zoo.envs import wildfire_v0
+    from free_range_zoo.envs.wildfire.baselines.strongest import StrongestBaseline
+    from free_range_zoo.envs.wildfire.baselines.weakest import WeakestBaseline
+
+    variants = {v[0]: v for v in wildfire_variants()}
+    out, cases = {}, 0
+    for name in ('rich_localized', 'rich_plain_bad_actions', 'cfg2_openness'):
+        _, configuration, kwargs, B, max_steps, steps, seed = variants[name]
+        flags = dict(show_bad_actions=False, observe_other_power=False, observe_other_suppressant=False)
+        flags.update(kwargs)
+        env = wildfire_v0.parallel_env(parallel_envs=B, max_steps=max_steps, configuration=configuration, device=torch.device('cpu'), **flags)
+        observations, _ = env.reset(seed=torch.arange(B, dtype=torch.int32))
+        env.aec_env.generator.generate = InjectedRandomness(seed + 100)
+        rng = np.random.default_rng(seed + 100)
+        agents = list(env.aec_env.agents)
+        bots = {agent: (StrongestBaseline(agent, B), WeakestBaseline(agent, B)) for agent in agents}
+        for t in range(min(steps, 14)):
+            for agent in agents:
+                mapping = env.aec_env.agent_action_mapping[agent]
+                pair = (observations[agent], {'agent_action_mapping': mapping})
+                tasks = observations[agent]['tasks']
+                rows = [r for r in tasks.unbind()]
+                p = f'c{cases}_'
+                out[p + 'task_values'] = np.concatenate([_np(r).reshape(-1, 4) for r in rows]).astype(np.int64) if rows else np.zeros((0, 4), np.int64)
+                out[p + 'task_counts'] = np.asarray([r.shape[0] for r in rows], np.int64)
+                out[p + 'map_lengths'] = np.asarray([m.shape[0] for m in mapping.unbind()], np.int64)
+                out[p + 'obs_self'] = _np(observations[agent]['self']).astype(np.float32)
+                for kind, bot in zip(('strongest', 'weakest'), bots[agent]):
+                    bot.observe(pair)
+                    out[p + kind] = _np(bot.act(None)).astype(np.int32).copy()
+                cases += 1
+            actions = wildfire_policy(env.aec_env, rng)
+            observations, *_ = env.step({agent: torch.from_numpy(actions[a]) for a, agent in enumerate(agents)})
+    out['cases'] = np.asarray(cases)
+    path = os.path.join(GOLDEN, 'baselines_wildfire.npz')
+    np.savez_compressed(path, **out)
+    print(f'{path}: {cases} observe() calls')
+
+
+PARTS = {'ka': record_known_answers, 'baselines_wildfire': record_wildfire_baselines, 'traj_wildfire': record_wildfire_trajectories, 'traj_cybersecurity': record_cyber_trajectories,
          'traj_rideshare': record_rideshare_trajectories,
          'misc': record_misc}
 
