@@ -66,6 +66,7 @@ SIGNATURES = {
     'frz_rideshare_random_policy': (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_uint64, _P, _P]),
     'frz_mt19937_seed': (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int64, ctypes.c_int64, _P]),
     'frz_mt19937_generate': (ctypes.c_int, [_P, _P, _P, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _P]),
+    'frz_mt19937_generate_pair': (ctypes.c_int, [_P, _P, _P, ctypes.c_int64, ctypes.c_int64, _P, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _P]),
 }
 
 

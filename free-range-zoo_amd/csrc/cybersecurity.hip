@@ -688,7 +688,8 @@ int frz_cybersecurity_reset(frz_cybersecurity_env* env, void* stream) {
     return frz_cybersecurity_rebuild(env, stream);
 }
 
-int frz_mt19937_generate(uint32_t* mt_state, int32_t* mt_index, float* out, int64_t events, int64_t count, int64_t B, void* stream);
+int frz_mt19937_generate_pair(uint32_t* mt_state, int32_t* mt_index, float* out, int64_t events, int64_t count, float* out2, int64_t events2,
+                              int64_t count2, int64_t B, void* stream);
 
 int frz_cybersecurity_step(frz_cybersecurity_env* env, const int32_t* actions, int rng_mode, const float* network_randomness,
                            const float* agent_randomness, void* stream) {
@@ -704,9 +705,7 @@ int frz_cybersecurity_step(frz_cybersecurity_env* env, const int32_t* actions, i
         int32_t* mt_index = at<int32_t>(env->arena, p.off_rows4 + (int64_t)p.r_mti * B * 4);
         float* rn = at<float>(env->arena, p.off_rand_net);
         float* ra = at<float>(env->arena, p.off_rand_agent);
-        int rc = frz_mt19937_generate(mt_state, mt_index, rn, 1, p.N, B, stream);
-        if (rc != FRZ_OK) return rc;
-        rc = frz_mt19937_generate(mt_state, mt_index, ra, 1, p.A, B, stream);
+        const int rc = frz_mt19937_generate_pair(mt_state, mt_index, rn, 1, p.N, ra, 1, p.A, B, stream);
         if (rc != FRZ_OK) return rc;
         network_randomness = rn;
         agent_randomness = ra;

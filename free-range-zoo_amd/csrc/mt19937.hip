@@ -30,32 +30,51 @@ __global__ void __launch_bounds__(frz::kBlock) mt_seed_kernel(uint32_t* mt_state
 }
 
 // RandomGenerator.generate(), unbuffered per-env branch (random_generator.py:106-114): env b draws events*count
-// consecutive floats; output [events][B][count].
+// consecutive floats; output [events][B][count].  A second tensor (events2 x count2, may be empty) continues the same
+// streams in the same launch: the step kernels draw field randomness then agent randomness (wildfire.py:409-410,
+// cybersecurity.py:304-315) and one launch serves both.
+//
+// The 624-word block twist is done lazily, one word per draw.  Word i's twist reads words i, i+1 and i+397 (mod 624); a
+// batch of kBatch <= 227 consecutive draws reads no word it rewrites, so all of its 2*kBatch+1 loads are issued before the
+// first use (one memory round trip per batch instead of one per draw).
+constexpr int kBatch = 16;
+
+__device__ __forceinline__ int wrap(int j) { return j >= kN ? j - kN : j; }
+
 __global__ void __launch_bounds__(frz::kBlock) mt_generate_kernel(uint32_t* mt_state, int32_t* mt_index, float* out, int64_t events,
-                                                                    int64_t count, int64_t B) {
+                                                                    int64_t count, float* out2, int64_t events2, int64_t count2, int64_t B) {
     const int64_t b = (int64_t)blockIdx.x * frz::kBlock + threadIdx.x;
     if (b >= B) return;
     int i = mt_index[b];
-    uint32_t cur = mt_state[(int64_t)i * B + b];
-    for (int64_t e = 0; e < events; ++e) {
-        for (int64_t k = 0; k < count; ++k) {
-            const int i1 = i + 1 == kN ? 0 : i + 1;
-            const int im = i + kM >= kN ? i + kM - kN : i + kM;
-            const uint32_t next = mt_state[(int64_t)i1 * B + b];
-            const uint32_t far = mt_state[(int64_t)im * B + b];
-            const uint32_t y = (cur & 0x80000000u) | (next & 0x7fffffffu);
-            uint32_t v = far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-            mt_state[(int64_t)i * B + b] = v;
-            v ^= v >> 11;
-            v ^= (v << 7) & 0x9d2c5680u;
-            v ^= (v << 15) & 0xefc60000u;
-            v ^= v >> 18;
-            out[(e * B + b) * count + k] = (float)(v & 0xFFFFFFu) * (1.0f / 16777216.0f);
-            // word i1 is re-read from memory next iteration unless it is the word just written (i1 == i only if kN == 1)
-            cur = next;
-            i = i1;
-            if (i == 0) cur = mt_state[b];  // wrapped: word 0 was rewritten earlier in this generation
+    const int64_t n1 = events * count, total = n1 + events2 * count2;
+    for (int64_t u0 = 0; u0 < total; u0 += kBatch) {
+        const int n = (int)(total - u0 < kBatch ? total - u0 : kBatch);
+        uint32_t w[kBatch + 1], far[kBatch];
+#pragma unroll
+        for (int k = 0; k <= kBatch; ++k) w[k] = k <= n ? mt_state[(int64_t)wrap(i + k) * B + b] : 0u;
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) far[k] = k < n ? mt_state[(int64_t)wrap(wrap(i + k) + kM) * B + b] : 0u;
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) {
+            if (k < n) {
+                const uint32_t y = (w[k] & 0x80000000u) | (w[k + 1] & 0x7fffffffu);
+                uint32_t v = far[k] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                mt_state[(int64_t)wrap(i + k) * B + b] = v;
+                v ^= v >> 11;
+                v ^= (v << 7) & 0x9d2c5680u;
+                v ^= (v << 15) & 0xefc60000u;
+                v ^= v >> 18;
+                const float r = (float)(v & 0xFFFFFFu) * (1.0f / 16777216.0f);
+                const int64_t u = u0 + k;
+                if (u < n1) {
+                    out[((u / count) * B + b) * count + u % count] = r;
+                } else {
+                    const int64_t u2 = u - n1;
+                    out2[((u2 / count2) * B + b) * count2 + u2 % count2] = r;
+                }
+            }
         }
+        i = wrap(i + n);
     }
     mt_index[b] = i;
 }
@@ -80,7 +99,16 @@ int frz_mt19937_generate(uint32_t* mt_state, int32_t* mt_index, float* out, int6
     if (events == 0 || count == 0) return FRZ_OK;
     const int blocks = (int)((B + frz::kBlock - 1) / frz::kBlock);
     hipLaunchKernelGGL(mt_generate_kernel, dim3(blocks), dim3(frz::kBlock), 0, static_cast<hipStream_t>(stream), mt_state, mt_index, out,
-                       events, count, B);
+                       events, count, static_cast<float*>(nullptr), (int64_t)0, (int64_t)1, B);
+    return hipGetLastError() == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;
+}
+
+int frz_mt19937_generate_pair(uint32_t* mt_state, int32_t* mt_index, float* out, int64_t events, int64_t count, float* out2, int64_t events2,
+                              int64_t count2, int64_t B, void* stream) {
+    if (!mt_state || !mt_index || !out || !out2 || B <= 0 || events <= 0 || count <= 0 || events2 <= 0 || count2 <= 0) return FRZ_E_INVALID;
+    const int blocks = (int)((B + frz::kBlock - 1) / frz::kBlock);
+    hipLaunchKernelGGL(mt_generate_kernel, dim3(blocks), dim3(frz::kBlock), 0, static_cast<hipStream_t>(stream), mt_state, mt_index, out,
+                       events, count, out2, events2, count2, B);
     return hipGetLastError() == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;
 }
 

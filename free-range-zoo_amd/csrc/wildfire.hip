@@ -1274,7 +1274,8 @@ int frz_wildfire_reset(frz_wildfire_env* env, void* stream) {
     return frz_wildfire_rebuild(env, stream);
 }
 
-int frz_mt19937_generate(uint32_t* mt_state, int32_t* mt_index, float* out, int64_t events, int64_t count, int64_t B, void* stream);
+int frz_mt19937_generate_pair(uint32_t* mt_state, int32_t* mt_index, float* out, int64_t events, int64_t count, float* out2, int64_t events2,
+                              int64_t count2, int64_t B, void* stream);
 
 int frz_wildfire_random_policy(frz_wildfire_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out, void* stream);
 
@@ -1309,9 +1310,7 @@ int frz_wildfire_step(frz_wildfire_env* env, const int32_t* actions, int rng_mod
         int32_t* mt_index = at<int32_t>(env->arena, p.off_rows4 + (int64_t)p.r_mti * B * 4);
         float* rf = at<float>(env->arena, p.off_rand_field);
         float* ra = at<float>(env->arena, p.off_rand_agent);
-        int rc = frz_mt19937_generate(mt_state, mt_index, rf, 3, (int64_t)c.grid_height * c.grid_width, B, stream);
-        if (rc != FRZ_OK) return rc;
-        rc = frz_mt19937_generate(mt_state, mt_index, ra, 5, c.num_agents, B, stream);
+        const int rc = frz_mt19937_generate_pair(mt_state, mt_index, rf, 3, (int64_t)c.grid_height * c.grid_width, ra, 5, c.num_agents, B, stream);
         if (rc != FRZ_OK) return rc;
         args.field_rand = rf;
         args.agent_rand = ra;

@@ -404,6 +404,10 @@ int frz_mt19937_seed(uint32_t* mt_state /*[624][B]*/, int32_t* mt_index /*[B]*/,
 /* out float32 [events][B][count]: env b draws events*count consecutive floats (generate(), unbuffered) */
 int frz_mt19937_generate(uint32_t* mt_state, int32_t* mt_index, float* out, int64_t events, int64_t count, int64_t B,
                          void* stream);
+/* two consecutive generate() calls on the same streams in one launch: `out` (events x count) first, then `out2`
+ * (the randomness of one step: wildfire.py:409-410, cybersecurity.py:304-315) */
+int frz_mt19937_generate_pair(uint32_t* mt_state, int32_t* mt_index, float* out, int64_t events, int64_t count, float* out2, int64_t events2,
+                              int64_t count2, int64_t parallel_envs, void* stream);
 
 #ifdef __cplusplus
 }
