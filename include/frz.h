@@ -227,6 +227,19 @@ int frz_wildfire_extreme_fire_policy(const int64_t* task_values, const int64_t* 
                                      const int64_t* map_lengths, const float* obs_self, int64_t parallel_envs, int weakest,
                                      uint64_t seed, uint64_t step, int64_t first_env_index, int32_t* actions_out, void* stream);
 
+/* Scripted rideshare baselines (envs/rideshare/baselines/greedy_Tfocus.py:48-115, greedy_Tglobal.py:48-99, fifo_Tfocus.py:36-80,
+ * fifo_Tglobal.py:36-74) as one device-side policy on the observation buffers.  kind: 0 greedy_Tfocus, 1 greedy_Tglobal,
+ * 2 fifo_Tfocus, 3 fifo_Tglobal.  task_values int32 [*][8] (16-byte aligned; rows y, x, y_dest, x_dest, accepted_by, riding_by,
+ * fare, entered_step), task_offsets int64 [B] first row of each env, task_lengths int64 [B] rows per env (the `tasks`
+ * observation), map_lengths int64 [B] (the agent's action mapping), obs_self int32 [B][4], diagonal = the agent configuration's
+ * use_diagonal_travel.  The answer is drawn among the rows holding the minimal key: member tie_draws[b] (int64 [B]) when
+ * tie_draws is given — e.g. replayed torch.randint draws — else floor(u32 * ties / 2^32) of word 0 of
+ * Philox(counter (first_env_index + b, 0, step, step >> 32), key (seed, seed >> 32)).  actions_out int32 [B][2]. */
+int frz_rideshare_task_policy(const int32_t* task_values, const int64_t* task_offsets, const int64_t* task_lengths,
+                              const int64_t* map_lengths, const int32_t* obs_self, int64_t parallel_envs, int kind, int diagonal,
+                              uint64_t seed, uint64_t step, int64_t first_env_index, const int64_t* tie_draws, int32_t* actions_out,
+                              void* stream);
+
 /* Episode metrics in one launch (what a rollout loop reduces after an episode; utils/env.py:137-160 bookkeeping arrays):
  * metrics[a] += sum over envs of agent a's cumulative reward, metrics[A] += sum of num_moves, metrics[A + 1] += number of
  * envs whose agents are all terminated or all truncated.  metrics: float64 [A + 2] on the device, accumulated in place;

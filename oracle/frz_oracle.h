@@ -162,6 +162,11 @@ float frz_oracle_philox_uniform(int32_t seed, uint32_t step, uint32_t draw, uint
 void frz_oracle_wildfire_extreme_policy(const int64_t* task_values, const int64_t* task_offsets, const int64_t* map_offsets,
                                         const int64_t* map_lengths, const float* obs_self, int64_t B, int weakest, uint64_t seed, uint64_t step,
                                         int64_t first_env, int32_t* actions);
+/* the scripted greedy / FIFO rideshare baselines (envs/rideshare/baselines/{greedy,fifo}_T{focus,global}.py); kind 0 greedy_Tfocus,
+ * 1 greedy_Tglobal, 2 fifo_Tfocus, 3 fifo_Tglobal; forced_pick (nullable) replays recorded tie-break draws, ties_out is nullable */
+void frz_oracle_rideshare_task_policy(const int32_t* task_values, const int64_t* task_offsets, const int64_t* task_lengths,
+                                      const int64_t* map_lengths, const int32_t* obs_self, int64_t B, int kind, int diagonal, uint64_t seed,
+                                      uint64_t step, int64_t first_env, const int64_t* forced_pick, int64_t* ties_out, int32_t* actions);
 void frz_oracle_wildfire_philox_randomness(const frz_wildfire_cfg* cfg, const int32_t* seeds, const int32_t* num_moves, float* field,
                                            float* agent);
 void frz_oracle_wildfire_random_policy(const frz_wildfire_cfg* cfg, const int32_t* agent_task_count, const int64_t* env_task_count,

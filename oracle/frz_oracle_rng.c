@@ -12,6 +12,10 @@
  */
 #include "frz_oracle.h"
 
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+
 #define MT_N 624
 #define MT_M 397
 
@@ -170,3 +174,87 @@ void frz_oracle_wildfire_extreme_policy(const int64_t* task_values, const int64_
     }
 }
 
+
+/* envs/rideshare/baselines/{greedy_Tfocus,greedy_Tglobal,fifo_Tfocus,fifo_Tglobal}.py, observe(), reproduced as written.
+ * kind 0 greedy_Tfocus (:48-115), 1 greedy_Tglobal (:48-99), 2 fifo_Tfocus (:36-80), 3 fifo_Tglobal (:36-74).
+ * Task rows are the observation's (y, x, y_dest, x_dest, accepted_by, riding_by, fare, entered_step) (rideshare.py:397-467).
+ *   - no task in any env -> [-1, -1] everywhere; no mapped task in this env -> [-1, -1];
+ *   - candidates are the env's FIRST n task rows, n = len(agent_action_mapping[b]);
+ *   - greedy key: trip length + my distance to the passenger, float32; the agents build MovementTransition with fast_travel=True,
+ *     so distance() (transitions/movement.py:56-86) is |dy| + |dx| on a 4-connected grid and sqrt(dy^2 + dx^2) with diagonals;
+ *     greedy_Tglobal stores the key into an int64 buffer (empty_like of the mapping): truncated toward zero;
+ *   - fifo key: entered_step as float32;
+ *   - the Tfocus agents overwrite the key of every row that is not accepted, when the env shows an accepted row, and then of
+ *     every row that is not riding, when it shows a riding row, with FLT_MAX (greedy) / +inf (fifo): an observation holding both
+ *     kinds ends with every key equal (greedy_Tfocus asserts on such observations and on two accepted rows; this restatement
+ *     carries on with the arithmetic);
+ *   - the answer is drawn uniformly among the rows whose key equals the minimum (torch.randint on the global generator in the
+ *     reference; here word 0 of Philox(counter (first_env + b, 0, step lo, step hi), key (seed lo, seed hi)), member
+ *     floor(u32 * ties / 2^32), or forced_pick[b] when given, which is how the recorded reference draws are replayed);
+ *   - second component by the chosen row: riding 2, accepted 1, otherwise 0. */
+void frz_oracle_rideshare_task_policy(const int32_t* task_values, const int64_t* task_offsets, const int64_t* task_lengths,
+                                      const int64_t* map_lengths, const int32_t* obs_self, int64_t B, int kind, int diagonal, uint64_t seed,
+                                      uint64_t step, int64_t first_env, const int64_t* forced_pick, int64_t* ties_out, int32_t* actions) {
+    int64_t total = 0;
+    for (int64_t b = 0; b < B; ++b) total += task_lengths[b];
+    const int greedy = kind < 2, focus = (kind & 1) == 0;
+    const float masked = greedy ? FLT_MAX : INFINITY;
+    for (int64_t b = 0; b < B; ++b) {
+        int32_t idx = -1, act = -1;
+        int64_t ties = 0;
+        const int64_t count = task_lengths[b];
+        const int64_t n = map_lengths[b] < count ? map_lengths[b] : count;
+        if (total > 0 && n > 0) {
+            const int32_t* rows = task_values + task_offsets[b] * 8;
+            int any_accepted = 0, any_riding = 0;
+            for (int64_t k = 0; k < count; ++k) {
+                any_accepted |= rows[k * 8 + 4] >= 0;
+                any_riding |= rows[k * 8 + 5] >= 0;
+            }
+            float* keys = (float*)malloc((size_t)n * sizeof(float));
+            for (int64_t k = 0; k < n; ++k) {
+                const int32_t* r = rows + k * 8;
+                float key;
+                if (greedy) {
+                    const float ty = (float)(r[2] - r[0]), tx = (float)(r[3] - r[1]);
+                    const float my = (float)(r[0] - obs_self[b * 4 + 0]), mx = (float)(r[1] - obs_self[b * 4 + 1]);
+                    const float trip = diagonal ? sqrtf(ty * ty + tx * tx) : fabsf(ty) + fabsf(tx);
+                    const float mine = diagonal ? sqrtf(my * my + mx * mx) : fabsf(my) + fabsf(mx);
+                    key = trip + mine;
+                } else {
+                    key = (float)r[7];
+                }
+                if (focus) {
+                    if (any_accepted && !(r[4] >= 0)) key = masked;
+                    if (any_riding && !(r[5] >= 0)) key = masked;
+                }
+                if (kind == 1) key = (float)(int64_t)key;
+                keys[k] = key;
+            }
+            float best = keys[0];
+            for (int64_t k = 1; k < n; ++k)
+                if (keys[k] < best) best = keys[k];
+            for (int64_t k = 0; k < n; ++k) ties += keys[k] == best;
+            int64_t pick;
+            if (forced_pick) {
+                pick = forced_pick[b];
+            } else {
+                const uint32_t ctr[4] = {(uint32_t)(b + first_env), 0u, (uint32_t)step, (uint32_t)(step >> 32)};
+                const uint32_t key2[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+                uint32_t out[4];
+                frz_oracle_philox4x32_10(ctr, key2, out);
+                pick = (int64_t)(((uint64_t)out[0] * (uint64_t)ties) >> 32);
+            }
+            for (int64_t k = 0; k < n; ++k)
+                if (keys[k] == best && pick-- == 0) {
+                    idx = (int32_t)k;
+                    break;
+                }
+            free(keys);
+            if (idx >= 0) act = rows[idx * 8 + 5] >= 0 ? 2 : (rows[idx * 8 + 4] >= 0 ? 1 : 0);
+        }
+        if (ties_out) ties_out[b] = ties;
+        actions[b * 2 + 0] = idx;
+        actions[b * 2 + 1] = act;
+    }
+}

@@ -178,6 +178,27 @@ def wildfire_extreme_policy(task_values, task_offsets, map_offsets, map_lengths,
     return actions
 
 
+RIDESHARE_TASK_POLICIES = ('greedy_focus', 'greedy_global', 'fifo_focus', 'fifo_global')
+
+
+def rideshare_task_policy(task_values, task_offsets, task_lengths, map_lengths, obs_self, kind: str, diagonal: bool, seed: int = 0, step: int = 0,
+                          first_env: int = 0, forced_pick=None, return_ties: bool = False):
+    """envs/rideshare/baselines/{greedy,fifo}_T{focus,global}.py on the jagged observation -> int32 [B, 2] (and the tie counts)."""
+    tv = np.ascontiguousarray(task_values, np.int32).reshape(-1, 8)
+    to, tl = np.ascontiguousarray(task_offsets, np.int64), np.ascontiguousarray(task_lengths, np.int64)
+    ml, ob = np.ascontiguousarray(map_lengths, np.int64), np.ascontiguousarray(obs_self, np.int32)
+    B = ml.shape[0]
+    if tv.shape[0] == 0:
+        tv = np.zeros((1, 8), np.int32)
+    actions, ties = np.zeros((B, 2), np.int32), np.zeros(B, np.int64)
+    forced = None if forced_pick is None else np.ascontiguousarray(forced_pick, np.int64)
+    lib().frz_oracle_rideshare_task_policy(_ptr(tv), _ptr(to), _ptr(tl), _ptr(ml), _ptr(ob), ctypes.c_int64(B),
+                                           ctypes.c_int(RIDESHARE_TASK_POLICIES.index(kind)), ctypes.c_int(int(diagonal)), ctypes.c_uint64(seed),
+                                           ctypes.c_uint64(step), ctypes.c_int64(first_env), None if forced is None else _ptr(forced), _ptr(ties),
+                                           _ptr(actions))
+    return (actions, ties) if return_ties else actions
+
+
 class _ArrayOracle:
     """Common plumbing: named numpy arrays bound to a ctypes bufs struct."""
 

@@ -87,3 +87,118 @@ def test_baselines_drive_a_rollout_through_the_action_task_wrapper(oracle, kwarg
                 assert np.array_equal(actions[name].cpu().numpy(), want), f'{name} step {t}'
         observations, rewards, terminations, truncations, infos = env.step(actions)
     env.check()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# rideshare: greedy / FIFO, task-focused / task-global (frz_rideshare_task_policy)
+# ------------------------------------------------------------------------------------------------------------------
+from test_oracle_rideshare import RIDESHARE_BOTS, check_task_policy_answer  # noqa: E402
+from test_oracle_rideshare import _baseline_cases as _rideshare_cases  # noqa: E402
+
+
+def hip_task_policy(task_values, task_offsets, task_lengths, map_lengths, obs_self, kind, diagonal, seed=0, step=0, first_env=0, tie_draws=None):
+    from free_range_zoo_amd import _capi
+    dev = torch.device('cuda')
+    tv = torch.as_tensor(np.ascontiguousarray(task_values, np.int32).reshape(-1, 8), device=dev)
+    if tv.shape[0] == 0:
+        tv = torch.zeros((1, 8), dtype=torch.int32, device=dev)
+    to, tl = torch.as_tensor(np.ascontiguousarray(task_offsets, np.int64), device=dev), torch.as_tensor(np.ascontiguousarray(task_lengths, np.int64), device=dev)
+    ml, ob = torch.as_tensor(np.ascontiguousarray(map_lengths, np.int64), device=dev), torch.as_tensor(np.ascontiguousarray(obs_self, np.int32), device=dev)
+    draws = None if tie_draws is None else torch.as_tensor(np.ascontiguousarray(tie_draws, np.int64), device=dev)
+    B = ml.shape[0]
+    out = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+    _capi.check(_capi.lib().frz_rideshare_task_policy(tv.data_ptr(), to.data_ptr(), tl.data_ptr(), ml.data_ptr(), ob.data_ptr(), B,
+                                                      RIDESHARE_BOTS.index(kind), int(diagonal), seed, step, first_env,
+                                                      None if draws is None else draws.data_ptr(), out.data_ptr(),
+                                                      torch.cuda.current_stream().cuda_stream), 'frz_rideshare_task_policy')
+    return out.cpu().numpy()
+
+
+def test_rideshare_recorded_reference_answers_and_oracle(oracle):
+    """The reference's four agents on 420 recorded observations: with the recorded torch.randint draws replayed the HIP answers are
+    the reference's (tied or not); with the build's own Philox tie stream they are the oracle's."""
+    for i, case in _rideshare_cases():
+        args = (case['task_values'], case['task_offsets'], case['task_counts'], case['map_lengths'], case['obs_self'])
+        diagonal = bool(case['diagonal'])
+        for kind in RIDESHARE_BOTS:
+            if int(case[kind + '_valid']):
+                def policy(forced, kind=kind):
+                    return hip_task_policy(*args, kind, diagonal, tie_draws=forced), case[kind + '_ties']  # tie counts: oracle-side check
+                check_task_policy_answer(policy, case, kind, f'case {i} {kind}')
+            got = hip_task_policy(*args, kind, diagonal, seed=5, step=i, first_env=3)
+            want = oracle.rideshare_task_policy(*args, kind, diagonal, seed=5, step=i, first_env=3)
+            assert np.array_equal(got, want), f'case {i} {kind}: HIP vs oracle'
+
+
+@pytest.mark.parametrize('diagonal', [False, True])
+def test_rideshare_task_policy_large_batch_vs_oracle(oracle, diagonal):
+    rng = np.random.default_rng(8 + int(diagonal))
+    B = 50021
+    counts = rng.integers(0, 9, B).astype(np.int64)
+    counts[rng.random(B) < 0.1] = 0
+    total = int(counts.sum())
+    values = np.zeros((total, 8), np.int32)
+    values[:, :4] = rng.integers(0, 6, (total, 4))  # small grid: many equal distances
+    state = rng.integers(0, 3, total)
+    values[:, 4] = np.where(state == 1, rng.integers(0, 4, total), -100)
+    values[:, 5] = np.where(state == 2, rng.integers(0, 4, total), -100)
+    values[:, 6] = rng.integers(1, 11, total)
+    values[:, 7] = rng.integers(0, 5, total)
+    obs_self = rng.integers(0, 6, (B, 4)).astype(np.int32)
+    starts = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    # rows of an env need not be packed back to back (the env's persistent buffers reserve max_passengers rows per env)
+    for offsets, vals in ((starts, values), (None, None)):
+        if offsets is None:
+            stride = 9
+            vals = np.full((B * stride, 8), 77, np.int32)
+            offsets = np.arange(B + 1, dtype=np.int64) * stride
+            for b in np.flatnonzero(counts):
+                vals[offsets[b]:offsets[b] + counts[b]] = values[starts[b]:starts[b + 1]]
+        for kind in RIDESHARE_BOTS:
+            got = hip_task_policy(vals, offsets, counts, counts, obs_self, kind, diagonal, seed=(1 << 40) + 17, step=(1 << 33) + 2, first_env=1000)
+            want, ties = oracle.rideshare_task_policy(vals, offsets, counts, counts, obs_self, kind, diagonal, seed=(1 << 40) + 17,
+                                                      step=(1 << 33) + 2, first_env=1000, return_ties=True)
+            assert np.array_equal(got, want), kind
+            assert (ties > 1).sum() > B // 20 and ((got[:, 0] == -1) == (counts == 0)).all()
+    shorter = np.maximum(counts - 1, 0)  # a mapping shorter than the task list: only its first rows are candidates
+    got = hip_task_policy(values, starts, counts, shorter, obs_self, 'fifo_focus', diagonal, seed=3, step=4)
+    assert np.array_equal(got, oracle.rideshare_task_policy(values, starts, counts, shorter, obs_self, 'fifo_focus', diagonal, seed=3, step=4))
+    assert (got[:, 0] < np.maximum(shorter, 1)).all()
+
+
+@pytest.mark.parametrize('diagonal', [False, True])
+def test_rideshare_baselines_drive_a_rollout_through_the_action_task_wrapper(oracle, diagonal):
+    """The reference's usage on the rideshare env: agents observe() the wrapped observation and act(); every decision is checked
+    against the oracle on the tensors the agent saw, the env accepts every action, and the focused agents deliver passengers."""
+    from free_range_zoo_amd.envs import rideshare_v0
+    from free_range_zoo_amd.envs.rideshare.baselines import (FirstInFirstOutTfocusBaseline, FirstInFirstOutTglobalBaseline, GreedyTaskFocus,
+                                                             GreedyTaskGlobal, NoopBaseline, RandomBaseline)
+    from free_range_zoo_amd.envs.rideshare.baselines._task_policy import jagged_parts
+    from free_range_zoo_amd.wrappers import action_mapping_wrapper_v0
+    B = 2000
+    configuration = configs.rideshare_small(diagonal, False) if diagonal else configs.rideshare_busy(A=6, steps=24, per_step=2, grid=8, seed=2)
+    env = rideshare_v0.parallel_env(configuration=configuration, parallel_envs=B, max_steps=30, device=torch.device('cuda'))
+    env = action_mapping_wrapper_v0(env)
+    observations, _ = env.reset(seed=torch.arange(B, dtype=torch.int32))
+    makers = [GreedyTaskFocus, FirstInFirstOutTfocusBaseline, GreedyTaskGlobal, FirstInFirstOutTglobalBaseline, RandomBaseline, NoopBaseline]
+    agents = {}
+    for i, name in enumerate(env.agents):
+        cls = makers[i % len(makers)]
+        kwargs = dict(agent_configuration=configuration.agent_config, seed=i) if cls.__name__.startswith('Greedy') else {}
+        agents[name] = cls(name, B, **kwargs)
+    first, delivered = list(agents)[0], 0
+    for t in range(20):
+        actions = {}
+        for name, agent in agents.items():
+            agent.observe(observations[name])
+            actions[name] = agent.act(env.action_space(name))
+            if hasattr(agent, 'kind'):
+                obs, mapping = observations[name]
+                tv, to, tl = (x.cpu().numpy() for x in jagged_parts(obs['tasks']))
+                _, _, ml = (x.cpu().numpy() for x in jagged_parts(mapping['agent_action_mapping']))
+                want = oracle.rideshare_task_policy(tv, to, tl, ml, obs['self'].cpu().numpy(), agent.kind, diagonal, seed=agent.seed, step=t)
+                assert np.array_equal(actions[name].cpu().numpy(), want), f'{name} step {t}'
+        observations, rewards, terminations, truncations, infos = env.step(actions)
+        delivered += int((rewards[first] > 0).sum())
+    env.check()
+    assert delivered > 0  # the focused greedy agent completes trips (a fare is the only positive reward)

@@ -159,3 +159,64 @@ def test_known_answer_passenger_exit(oracle):
         assert lib.frz_oracle_rs_passenger_exit(ctypes.byref(cfg), ctypes.byref(o.bufs), p(drops), p(targets), p(vectors), p(fares)) == 0
         G.assert_same(o.table(), np.asarray(case['out_passengers'], np.int32).reshape(-1, 11), case['test'])
         G.assert_same(fares, np.asarray(case['ret_0'], np.int32), case['test'] + ' fares')
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# scripted baselines: the reference's greedy / FIFO agents, answers and tie-break draws recorded
+# ------------------------------------------------------------------------------------------------------------------
+RIDESHARE_BOTS = ('greedy_focus', 'greedy_global', 'fifo_focus', 'fifo_global')
+
+
+def _baseline_cases():
+    data = np.load(G.golden_path('baselines_rideshare.npz'))
+    for i in range(int(data['cases'])):
+        p = f'c{i}_'
+        case = {k[len(p):]: data[k] for k in data.files if k.startswith(p)}
+        counts = case['task_counts']
+        case['task_offsets'] = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        yield i, case
+
+
+def check_task_policy_answer(policy, case, kind, what):
+    """`policy(forced_pick)` -> (actions, ties).  With the reference's recorded draw replayed, the answer is the reference's,
+    tied or not; the number of tied candidates is the bound the reference passed to torch.randint."""
+    got, ties = policy(case[kind + '_picks'])
+    assert np.array_equal(ties, case[kind + '_ties']), f'{what}: tied candidates'
+    assert np.array_equal(got, case[kind]), f'{what}: answers'
+
+
+def test_scripted_baselines_match_reference_answers(oracle):
+    seen = dict(tied=0, empty_env=0, empty_all=0, skipped=0, both_kinds=0)
+    for i, case in _baseline_cases():
+        for kind in RIDESHARE_BOTS:
+            if not int(case[kind + '_valid']):
+                seen['skipped'] += 1  # greedy_Tfocus asserted on this observation in the reference
+                continue
+
+            def policy(forced, kind=kind):
+                return oracle.rideshare_task_policy(case['task_values'], case['task_offsets'], case['task_counts'], case['map_lengths'],
+                                                    case['obs_self'], kind, bool(case['diagonal']), forced_pick=forced, return_ties=True)
+
+            check_task_policy_answer(policy, case, kind, f'case {i} {kind}')
+            seen['tied'] += int((case[kind + '_ties'] > 1).sum())
+        seen['empty_all'] += int(case['task_counts'].sum() == 0)
+        seen['empty_env'] += int((case['task_counts'] == 0).any() and case['task_counts'].sum() > 0)
+        values, offsets = case['task_values'], case['task_offsets']
+        for b in range(len(case['task_counts'])):
+            rows = values[offsets[b]:offsets[b + 1]]
+            seen['both_kinds'] += int((rows[:, 4] >= 0).any() and (rows[:, 5] >= 0).any())
+    assert all(v > 0 for v in seen.values()), seen
+
+
+def test_task_policy_tie_stream(oracle):
+    """Without a forced draw the tie-break is word 0 of Philox(counter (first_env + b, 0, step, 0), key (seed, 0))."""
+    B = 64
+    values = np.zeros((B * 3, 8), np.int32)
+    values[:, 4:6] = -100
+    offsets = np.arange(B + 1, dtype=np.int64) * 3
+    lengths = np.full(B, 3, np.int64)
+    obs_self = np.zeros((B, 4), np.int32)
+    got = oracle.rideshare_task_policy(values, offsets, lengths, lengths, obs_self, 'fifo_global', False, seed=11, step=5, first_env=7)
+    want = [(int(oracle.philox4x32_10((7 + b, 0, 5, 0), (11, 0))[0]) * 3) >> 32 for b in range(B)]
+    assert got[:, 0].tolist() == want and (got[:, 1] == 0).all()
+    assert len(set(want)) == 3

@@ -639,7 +639,105 @@ def record_wildfire_baselines():
     print(f'{path}: {cases} observe() calls')
 
 
-PARTS = {'ka': record_known_answers, 'baselines_wildfire': record_wildfire_baselines, 'traj_wildfire': record_wildfire_trajectories, 'traj_cybersecurity': record_cyber_trajectories,
+
+# ----------------------------------------------------------------------------------------------------------
+# scripted rideshare baselines: greedy / FIFO, task-focused / task-global
+# ----------------------------------------------------------------------------------------------------------
+RIDESHARE_BOTS = ('greedy_focus', 'greedy_global', 'fifo_focus', 'fifo_global')
+
+
+def record_rideshare_baselines():
+    """Runs the reference's four scripted rideshare agents (envs/rideshare/baselines/{greedy,fifo}_T{focus,global}.py) on
+    (observation, action mapping) pairs of the unmodified reference env.  Their tie-breaks come from torch.randint on the global
+    generator; the call is wrapped so that each decision's number of tied candidates and the member drawn are recorded next to
+    the answer, which makes the tied answers checkable too.  States come from two drivers: the recorded random policy (agents
+    hold several passengers at once) and the focused agents driving every car themselves (one passenger at a time)."""
+    from free_range_zoo.envs import rideshare_v0
+    from free_range_zoo.envs.rideshare.baselines.greedy_Tfocus import GreedyTaskFocus
+    from free_range_zoo.envs.rideshare.baselines.greedy_Tglobal import GreedyTaskGlobal
+    from free_range_zoo.envs.rideshare.baselines.fifo_Tfocus import FirstInFirstOutTfocusBaseline
+    from free_range_zoo.envs.rideshare.baselines.fifo_Tglobal import FirstInFirstOutTglobalBaseline
+
+    classes = dict(zip(RIDESHARE_BOTS, (GreedyTaskFocus, GreedyTaskGlobal, FirstInFirstOutTfocusBaseline, FirstInFirstOutTglobalBaseline)))
+    variants = {v[0]: v for v in rideshare_variants()}
+    draws = []
+    original_randint = torch.randint
+
+    def recording_randint(low, high, size, **kwargs):
+        value = original_randint(low, high, size, **kwargs)
+        draws.append((int(high), int(value)))
+        return value
+
+    def make(kind, agent, B, configuration):
+        kwargs = dict(agent_configuration=configuration.agent_config) if kind.startswith('greedy') else {}
+        return classes[kind](agent, B, **kwargs)
+
+    out, cases = {}, 0
+    for name in ('nonstochastic', 'cfg3_busy', 'busy_waiting_costs', 'small_diagonal', 'small_fast_travel'):
+        _, configuration, B, max_steps, steps, seed = variants[name]
+        diagonal = int(bool(configuration.agent_config.use_diagonal_travel))
+        for driver in ('random', 'focused'):
+            env = rideshare_v0.parallel_env(parallel_envs=B, max_steps=max_steps, configuration=configuration, device=torch.device('cpu'))
+            observations, _ = env.reset(seed=torch.arange(B, dtype=torch.int32))
+            aec = env.aec_env
+            agents = list(aec.agents)
+            rng = np.random.default_rng(seed + 200)
+            torch.manual_seed(seed)
+            drivers = {agent: make(RIDESHARE_BOTS[(2 * i) % 4], agent, B, configuration) for i, agent in enumerate(agents)}
+            for t in range(min(steps, 14)):
+                driven = np.zeros((len(agents), B, 2), np.int32)
+                for a, agent in enumerate(agents):
+                    mapping = aec.agent_action_mapping[agent]
+                    pair = (observations[agent], {'agent_action_mapping': mapping})
+                    rows = list(observations[agent]['tasks'].unbind())
+                    counts = np.asarray([r.shape[0] for r in rows], np.int64)
+                    if a < 3:
+                        p = f'c{cases}_'
+                        out[p + 'task_values'] = (np.concatenate([_np(r).reshape(-1, 8) for r in rows]).astype(np.int32)
+                                                  if counts.sum() else np.zeros((0, 8), np.int32))
+                        out[p + 'task_counts'] = counts
+                        out[p + 'map_lengths'] = np.asarray([m.shape[0] for m in mapping.unbind()], np.int64)
+                        out[p + 'obs_self'] = _np(observations[agent]['self']).astype(np.int32)
+                        out[p + 'diagonal'] = np.asarray(diagonal)
+                        for kind in RIDESHARE_BOTS:
+                            bot = make(kind, agent, B, configuration)
+                            del draws[:]
+                            torch.randint = recording_randint
+                            try:
+                                bot.observe(pair)
+                                valid = 1
+                            except AssertionError:  # greedy_Tfocus refuses observations holding several accepted / riding passengers
+                                valid = 0
+                            finally:
+                                torch.randint = original_randint
+                            out[p + kind + '_valid'] = np.asarray(valid)
+                            if valid:
+                                answer = _np(bot.act(None)).astype(np.int32).copy()
+                                decided = np.flatnonzero(answer[:, 0] >= 0)
+                                assert len(decided) == len(draws), (kind, len(decided), len(draws))
+                                ties, picks = np.zeros(B, np.int64), np.zeros(B, np.int64)
+                                ties[decided] = [d[0] for d in draws]
+                                picks[decided] = [d[1] for d in draws]
+                                out[p + kind], out[p + kind + '_ties'], out[p + kind + '_picks'] = answer, ties, picks
+                        cases += 1
+                    if driver == 'focused':
+                        try:
+                            drivers[agent].observe(pair)
+                            answer = _np(drivers[agent].act(None)).astype(np.int32).copy()
+                        except AssertionError:
+                            answer = np.full((B, 2), -1, np.int32)
+                        noop = answer[:, 1] < 0
+                        answer[noop, 0] = counts[noop]
+                        driven[a] = answer
+                actions = rideshare_policy(aec, rng) if driver == 'random' else driven
+                observations, *_ = env.step({agent: torch.from_numpy(actions[a]) for a, agent in enumerate(agents)})
+    out['cases'] = np.asarray(cases)
+    path = os.path.join(GOLDEN, 'baselines_rideshare.npz')
+    np.savez_compressed(path, **out)
+    print(f'{path}: {cases} observe() calls x {len(RIDESHARE_BOTS)} agents')
+
+
+PARTS = {'ka': record_known_answers, 'baselines_wildfire': record_wildfire_baselines, 'baselines_rideshare': record_rideshare_baselines, 'traj_wildfire': record_wildfire_trajectories, 'traj_cybersecurity': record_cyber_trajectories,
          'traj_rideshare': record_rideshare_trajectories,
          'misc': record_misc}
 
