@@ -45,6 +45,9 @@ SIGNATURES = {
                                                        ctypes.c_int64, _P, _P]),
     'frz_rideshare_task_policy': (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64,
                                                 ctypes.c_int64, _P, _P, _P]),
+    'frz_cybersecurity_focus_policy': (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, _P, ctypes.c_int32, ctypes.c_int64,
+                                                     ctypes.c_int, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64,
+                                                     ctypes.c_uint64, ctypes.c_int64, _P, _P, _P, _P, _P]),
     'frz_wildfire_episode_metrics': (ctypes.c_int, [_P, _P, _P]),
     'frz_wildfire_timed_rollout': (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int32, _P, ctypes.c_int, _P,
                                                  ctypes.POINTER(ctypes.c_float)]),

@@ -240,6 +240,21 @@ int frz_rideshare_task_policy(const int32_t* task_values, const int64_t* task_of
                               uint64_t seed, uint64_t step, int64_t first_env_index, const int64_t* tie_draws, int32_t* actions_out,
                               void* stream);
 
+/* Stateful scripted cybersecurity baselines (envs/cybersecurity/baselines/patched.py:33-71,96-152, exploited.py:39-88,120-167,
+ * camp.py:32-60) as one device-side policy.  kind: 0 patched attacker, 1 exploited attacker, 2 patched defender, 3 exploited
+ * defender, 4 camp defender.  The candidates of env b are the row_len values tasks[b * env_stride + k * elem_stride] (int64) —
+ * the reference reads observation['tasks'][:, 0], i.e. (N * F, 1, F) on the [B][N][F] task observation.  obs_self float32
+ * [B][self_width] (attackers: threat, presence; defenders: mitigation, presence, location).  subnetwork_states is used by kind 1,
+ * camp_target (agent index % nodes) by kind 4; mapping_numel == 0 (agent absent everywhere) answers [-100, -1] and keeps the
+ * state.  One uniform draw per env among the positions holding the extreme key: member tie_draws[b] (int64 [B], nullable) or
+ * floor(u32 * ties / 2^32) of word 0 of Philox(counter (first_env_index + b, 0, step, step >> 32), key (seed, seed >> 32)).
+ * target_node int32 [B] (-1 = none), time_focused int32 [B] and actions int32 [B][2] are the agent's persistent state, updated
+ * in place; actions is the answer. */
+int frz_cybersecurity_focus_policy(const int64_t* tasks, int64_t env_stride, int64_t elem_stride, int32_t row_len, const float* obs_self,
+                                   int32_t self_width, int64_t parallel_envs, int kind, int32_t subnetwork_states, int32_t camp_target,
+                                   int64_t mapping_numel, uint64_t seed, uint64_t step, int64_t first_env_index, const int64_t* tie_draws,
+                                   int32_t* target_node, int32_t* time_focused, int32_t* actions, void* stream);
+
 /* Episode metrics in one launch (what a rollout loop reduces after an episode; utils/env.py:137-160 bookkeeping arrays):
  * metrics[a] += sum over envs of agent a's cumulative reward, metrics[A] += sum of num_moves, metrics[A + 1] += number of
  * envs whose agents are all terminated or all truncated.  metrics: float64 [A + 2] on the device, accumulated in place;

@@ -167,6 +167,13 @@ void frz_oracle_wildfire_extreme_policy(const int64_t* task_values, const int64_
 void frz_oracle_rideshare_task_policy(const int32_t* task_values, const int64_t* task_offsets, const int64_t* task_lengths,
                                       const int64_t* map_lengths, const int32_t* obs_self, int64_t B, int kind, int diagonal, uint64_t seed,
                                       uint64_t step, int64_t first_env, const int64_t* forced_pick, int64_t* ties_out, int32_t* actions);
+/* the stateful patched / exploited / camp cybersecurity baselines (envs/cybersecurity/baselines/{patched,exploited,camp}.py);
+ * kind 0 patched attacker, 1 exploited attacker, 2 patched defender, 3 exploited defender, 4 camp defender; target_node,
+ * time_focused and actions are the agent's persistent state, updated in place */
+void frz_oracle_cyber_focus_policy(const int64_t* tasks, int64_t env_stride, int64_t elem_stride, int32_t row_len, const float* obs_self,
+                                   int32_t self_width, int64_t B, int kind, int32_t subnetwork_states, int32_t camp_target,
+                                   int64_t mapping_numel, uint64_t seed, uint64_t step, int64_t first_env, const int64_t* forced_pick,
+                                   int64_t* ties_out, int32_t* target_node, int32_t* time_focused, int32_t* actions);
 void frz_oracle_wildfire_philox_randomness(const frz_wildfire_cfg* cfg, const int32_t* seeds, const int32_t* num_moves, float* field,
                                            float* agent);
 void frz_oracle_wildfire_random_policy(const frz_wildfire_cfg* cfg, const int32_t* agent_task_count, const int64_t* env_task_count,

@@ -258,3 +258,101 @@ void frz_oracle_rideshare_task_policy(const int32_t* task_values, const int64_t*
         actions[b * 2 + 1] = act;
     }
 }
+
+/* envs/cybersecurity/baselines/patched.py:33-71 (kind 0 PatchedAttackerBaseline), exploited.py:39-88 (1 ExploitedAttackerBaseline),
+ * patched.py:96-152 (2 PatchedDefenderBaseline), exploited.py:120-167 (3 ExploitedDefenderBaseline), camp.py:32-60
+ * (4 CampDefenderBaseline), observe(), reproduced as written.  The agents are stateful: target_node / time_focused / actions
+ * persist between calls (int32 [B], [B], [B][2]).
+ *   - an action mapping without any element (the agent is absent everywhere) answers [-100, -1] and leaves the state alone;
+ *   - the candidates are `observation['tasks'][:, 0]`: for env b the row_len values tasks[b * env_stride + k * elem_stride].
+ *     On the env's [B, N, F] task observation that is the F features of node 0 (env_stride N * F, elem_stride 1, row_len F),
+ *     which is what the reference computes; (env_stride N * F, elem_stride F, row_len N) is feature 0 of every node;
+ *   - key: 0 the value, minimum; 1 the value with (subnetwork_states - 1) replaced by -100, maximum; 2 the value with -100
+ *     and 0 replaced by 1000, minimum; 3 the value, maximum.  One uniform draw per env among the positions holding the
+ *     extreme (torch.randint in the reference; forced_pick[b] replays it, else word 0 of Philox(counter (first_env + b, 0,
+ *     step lo, step hi), key (seed lo, seed hi)) -> floor(u32 * ties / 2^32));
+ *   - attackers take the new target when they have none (-1); defenders take it whenever the row holds no -100 ("the last
+ *     action was a monitor");
+ *   - absent = self[:, 1] == 0; attackers: present with a target -> [target, 0] and time_focused + 1; absent -> -1.
+ *     defenders: present with a target -> 0 (move) when self[:, 2] != target else -2 (patch) and time_focused + 1;
+ *     absent -> -1; present without a target and without a monitored row -> -3 (monitor);
+ *   - time_focused reaching 3 clears the target and the counter;
+ *   - camp: target = camp_target (agent index % nodes); not there -> 0, absent -> -1, there -> -2 (also when absent: the
+ *     fills are applied in that order). */
+void frz_oracle_cyber_focus_policy(const int64_t* tasks, int64_t env_stride, int64_t elem_stride, int32_t row_len, const float* obs_self,
+                                   int32_t self_width, int64_t B, int kind, int32_t subnetwork_states, int32_t camp_target,
+                                   int64_t mapping_numel, uint64_t seed, uint64_t step, int64_t first_env, const int64_t* forced_pick,
+                                   int64_t* ties_out, int32_t* target_node, int32_t* time_focused, int32_t* actions) {
+    for (int64_t b = 0; b < B; ++b) {
+        if (ties_out) ties_out[b] = 0;
+        if (mapping_numel == 0) {
+            actions[b * 2 + 0] = -100;
+            actions[b * 2 + 1] = -1;
+            continue;
+        }
+        const float* me = obs_self + b * self_width;
+        const int absent = me[1] == 0.0f;
+        int32_t a1 = actions[b * 2 + 1];
+        if (kind == 4) {
+            const int at = me[2] == (float)camp_target;
+            if (!at) a1 = 0;
+            if (absent) a1 = -1;
+            if (at) a1 = -2;
+            actions[b * 2 + 0] = camp_target;
+            actions[b * 2 + 1] = a1;
+            continue;
+        }
+        const int64_t* row = tasks + b * env_stride;
+        const int want_max = kind == 1 || kind == 3;
+        int64_t best = 0, ties = 0;
+        int monitored = 1;
+        for (int32_t k = 0; k < row_len; ++k) {
+            const int64_t x = row[k * elem_stride];
+            monitored &= x != -100;
+            const int64_t key = kind == 1 ? (x == subnetwork_states - 1 ? -100 : x) : (kind == 2 ? ((x == -100 || x == 0) ? 1000 : x) : x);
+            if (k == 0 || (want_max ? key > best : key < best)) best = key, ties = 1;
+            else if (key == best) ++ties;
+        }
+        int64_t pick;
+        if (forced_pick) {
+            pick = forced_pick[b];
+        } else {
+            const uint32_t ctr[4] = {(uint32_t)(b + first_env), 0u, (uint32_t)step, (uint32_t)(step >> 32)};
+            const uint32_t key2[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+            uint32_t out[4];
+            frz_oracle_philox4x32_10(ctr, key2, out);
+            pick = (int64_t)(((uint64_t)out[0] * (uint64_t)ties) >> 32);
+        }
+        int32_t fresh = 0;
+        for (int32_t k = 0; k < row_len; ++k) {
+            const int64_t x = row[k * elem_stride];
+            const int64_t key = kind == 1 ? (x == subnetwork_states - 1 ? -100 : x) : (kind == 2 ? ((x == -100 || x == 0) ? 1000 : x) : x);
+            if (key == best && pick-- == 0) {
+                fresh = k;
+                break;
+            }
+        }
+        if (ties_out) ties_out[b] = ties;
+        int32_t target = target_node[b], focused = time_focused[b];
+        const int defender = kind >= 2;
+        if (defender ? monitored : target == -1) target = fresh;
+        const int targeted = target != -1 && !absent, targetless = target == -1 && !absent;
+        if (!defender) {
+            if (targeted) a1 = 0;
+            if (absent) a1 = -1;
+            if (targeted) ++focused;
+        } else {
+            const int at = me[2] == (float)target;
+            if (targeted && !at) a1 = 0;
+            if (absent) a1 = -1;
+            if (targeted && at) a1 = -2;
+            if (targetless && !monitored) a1 = -3;
+            if (targeted && at) ++focused;
+        }
+        actions[b * 2 + 0] = target;
+        actions[b * 2 + 1] = a1;
+        if (focused >= 3) target = -1, focused = 0;
+        target_node[b] = target;
+        time_focused[b] = focused;
+    }
+}

@@ -199,6 +199,30 @@ def rideshare_task_policy(task_values, task_offsets, task_lengths, map_lengths, 
     return (actions, ties) if return_ties else actions
 
 
+CYBER_FOCUS_POLICIES = ('patched_attacker', 'exploited_attacker', 'patched_defender', 'exploited_defender', 'camp_defender')
+
+
+def cyber_focus_policy(tasks, obs_self, kind: str, target_node, time_focused, actions, subnetwork_states: int = 0, camp_target: int = 0,
+                       mapping_numel: int = 1, seed: int = 0, step: int = 0, first_env: int = 0, forced_pick=None, across_nodes: bool = False):
+    """envs/cybersecurity/baselines/{patched,exploited,camp}.py observe() on the [B, N, F] task observation; the state arrays
+    (int32 target_node [B], time_focused [B], actions [B, 2]) are updated in place; returns the tie counts."""
+    tasks = np.ascontiguousarray(tasks, np.int64)
+    B, N, F = tasks.shape
+    ob = np.ascontiguousarray(obs_self, np.float32)
+    for arr in (target_node, time_focused, actions):
+        assert arr.dtype == np.int32 and arr.flags['C_CONTIGUOUS']
+    ties = np.zeros(B, np.int64)
+    forced = None if forced_pick is None else np.ascontiguousarray(forced_pick, np.int64)
+    row = (N * F, F, N) if across_nodes else (N * F, 1, F)
+    lib().frz_oracle_cyber_focus_policy(_ptr(tasks), ctypes.c_int64(row[0]), ctypes.c_int64(row[1]), ctypes.c_int32(row[2]), _ptr(ob),
+                                        ctypes.c_int32(ob.shape[1]), ctypes.c_int64(B), ctypes.c_int(CYBER_FOCUS_POLICIES.index(kind)),
+                                        ctypes.c_int32(subnetwork_states), ctypes.c_int32(camp_target), ctypes.c_int64(mapping_numel),
+                                        ctypes.c_uint64(seed), ctypes.c_uint64(step), ctypes.c_int64(first_env),
+                                        None if forced is None else _ptr(forced), _ptr(ties), _ptr(target_node), _ptr(time_focused),
+                                        _ptr(actions))
+    return ties
+
+
 class _ArrayOracle:
     """Common plumbing: named numpy arrays bound to a ctypes bufs struct."""
 

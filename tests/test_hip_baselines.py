@@ -202,3 +202,110 @@ def test_rideshare_baselines_drive_a_rollout_through_the_action_task_wrapper(ora
         delivered += int((rewards[first] > 0).sum())
     env.check()
     assert delivered > 0  # the focused greedy agent completes trips (a fare is the only positive reward)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# cybersecurity: stateful patched / exploited / camp agents (frz_cybersecurity_focus_policy)
+# ------------------------------------------------------------------------------------------------------------------
+from test_oracle_cybersecurity import CYBER_BOTS, check_focus_policy  # noqa: E402
+from test_oracle_cybersecurity import _baseline_cases as _cyber_cases  # noqa: E402
+
+CYBER_KINDS = ('patched_attacker', 'exploited_attacker', 'patched_defender', 'exploited_defender', 'camp_defender')
+
+
+def hip_focus_policy(tasks, obs_self, kind, target, focused, actions, subnetwork_states=0, camp_target=0, mapping_numel=1, seed=0, step=0,
+                     first_env=0, tie_draws=None, across_nodes=False):
+    """Same contract as oracle.cyber_focus_policy: the three numpy state arrays are updated in place."""
+    from free_range_zoo_amd import _capi
+    dev = torch.device('cuda')
+    tk = torch.as_tensor(np.ascontiguousarray(tasks, np.int64), device=dev)
+    ob = torch.as_tensor(np.ascontiguousarray(obs_self, np.float32), device=dev)
+    B, N, F = tk.shape
+    row = (N * F, F, N) if across_nodes else (N * F, 1, F)
+    state = [torch.as_tensor(x.copy(), device=dev) for x in (target, focused, actions)]
+    draws = None if tie_draws is None else torch.as_tensor(np.ascontiguousarray(tie_draws, np.int64), device=dev)
+    _capi.check(_capi.lib().frz_cybersecurity_focus_policy(tk.data_ptr(), row[0], row[1], row[2], ob.data_ptr(), ob.shape[1], B,
+                                                           CYBER_KINDS.index(kind), subnetwork_states, camp_target, mapping_numel, seed, step,
+                                                           first_env, None if draws is None else draws.data_ptr(), state[0].data_ptr(),
+                                                           state[1].data_ptr(), state[2].data_ptr(), torch.cuda.current_stream().cuda_stream),
+                'frz_cybersecurity_focus_policy')
+    for dst, src in zip((target, focused, actions), state):
+        dst[...] = src.cpu().numpy()
+
+
+def test_cyber_recorded_reference_answers(oracle):
+    """528 recorded observe() calls of the reference's agents: from the recorded agent state, with the recorded draws replayed, the
+    HIP policy lands on the reference's answer and state."""
+    for i, case in _cyber_cases():
+        for kind in CYBER_BOTS[str(case['role'])]:
+            def policy(kind, target, focused, actions, forced):
+                hip_focus_policy(case['tasks'], case['obs_self'], kind, target, focused, actions, subnetwork_states=int(case['subnetwork_states']),
+                                 camp_target=int(case.get('camp_target', 0)), mapping_numel=int(case['mapping_numel']), tie_draws=forced)
+
+            check_focus_policy(policy, case, kind, f'case {i} {kind}')
+
+
+@pytest.mark.parametrize('across_nodes', [False, True])
+def test_cyber_focus_policy_trajectory_vs_oracle(oracle, across_nodes):
+    """Large batch, eight consecutive decisions per kind with the build's own tie stream: state and answers bit-equal to the oracle."""
+    rng = np.random.default_rng(12 + int(across_nodes))
+    B, N, F, S = 40003, 5, 2, 6
+    for kind in CYBER_KINDS:
+        width = 2 if 'attacker' in kind else 3
+        state_h = [np.full(B, -1, np.int32), np.zeros(B, np.int32), np.zeros((B, 2), np.int32)]
+        state_o = [x.copy() for x in state_h]
+        for step in range(8):
+            tasks = rng.integers(0, S, (B, N, F)).astype(np.int64)
+            tasks[rng.random((B, N)) < 0.3] = -100  # unobserved nodes
+            tasks[rng.random(B) < 0.3] = rng.integers(0, S, (N, F))  # fully monitored envs
+            obs_self = rng.random((B, width)).astype(np.float32)
+            obs_self[:, 1] = rng.random(B) < 0.8
+            if width == 3:
+                obs_self[:, 2] = rng.integers(-1, N, B)
+            kwargs = dict(subnetwork_states=S, camp_target=3, seed=(7 << 32) + 5, step=(1 << 32) + step, first_env=17, across_nodes=across_nodes)
+            hip_focus_policy(tasks, obs_self, kind, *state_h, **kwargs)
+            oracle.cyber_focus_policy(tasks, obs_self, kind, *state_o, **kwargs)
+            for h, o in zip(state_h, state_o):
+                assert np.array_equal(h, o), f'{kind} step {step}'
+        if kind != 'camp_defender':
+            assert (state_h[1] > 0).any() and (state_h[0] >= 0).any()
+        before = [x.copy() for x in state_h]
+        hip_focus_policy(tasks, obs_self, kind, *state_h, mapping_numel=0)
+        assert (state_h[2] == np.array([-100, -1])).all() and np.array_equal(state_h[0], before[0]) and np.array_equal(state_h[1], before[1])
+
+
+def test_cyber_baselines_drive_a_rollout_through_the_action_task_wrapper(oracle):
+    from free_range_zoo_amd.envs import cybersecurity_v0
+    from free_range_zoo_amd.envs.cybersecurity.baselines import (CampDefenderBaseline, ExploitedAttackerBaseline, ExploitedDefenderBaseline,
+                                                                 NoopBaseline, PatchedAttackerBaseline, PatchedDefenderBaseline, RandomBaseline)
+    from free_range_zoo_amd.wrappers import action_mapping_wrapper_v0
+    B = 3000
+    configuration = configs.cyber_rich()
+    S = int(configuration.network_config.num_states)
+    env = cybersecurity_v0.parallel_env(configuration=configuration, parallel_envs=B, max_steps=30, device=torch.device('cuda'),
+                                        show_bad_actions=True)
+    env = action_mapping_wrapper_v0(env)
+    observations, _ = env.reset(seed=torch.arange(B, dtype=torch.int32))
+    attackers = [lambda n: PatchedAttackerBaseline(n, B, seed=1), lambda n: ExploitedAttackerBaseline(S, n, B, seed=2), lambda n: RandomBaseline(n, B)]
+    defenders = [lambda n: PatchedDefenderBaseline(n, B, seed=3), lambda n: ExploitedDefenderBaseline(S, n, B, seed=4),
+                 lambda n: CampDefenderBaseline(n, B), lambda n: NoopBaseline(n, B)]
+    agents, shadow = {}, {}
+    for name in env.agents:
+        pool = attackers if name.startswith('attacker') else defenders
+        agents[name] = pool[(int(name.split('_')[-1]) - 1) % len(pool)](name)
+        shadow[name] = [np.full(B, -1, np.int32), np.zeros(B, np.int32), np.zeros((B, 2), np.int32)]
+    for t in range(15):
+        actions = {}
+        for name, agent in agents.items():
+            agent.observe(observations[name])
+            actions[name] = agent.act(env.action_space(name))
+            if hasattr(agent, 'kind'):
+                obs, mapping = observations[name]
+                nodes = obs['tasks'].shape[1]
+                oracle.cyber_focus_policy(obs['tasks'].cpu().numpy(), obs['self'].cpu().numpy(), agent.kind, *shadow[name], subnetwork_states=S,
+                                          camp_target=getattr(agent, 'agent_index', 0) % nodes,
+                                          mapping_numel=int(mapping['agent_action_mapping'].numel()), seed=agent.seed, step=t)
+                assert np.array_equal(actions[name].cpu().numpy(), shadow[name][2]), f'{name} step {t}'
+                assert np.array_equal(agent.target_node.cpu().numpy(), shadow[name][0]), f'{name} step {t}: target'
+        observations, rewards, terminations, truncations, infos = env.step(actions)
+    env.check()

@@ -111,3 +111,57 @@ def test_known_answer_transitions(oracle):
         G.assert_same(loc, case['out_location'], what + ' location')
         G.assert_same(pres.astype(bool), case['out_presence'], what + ' presence')
     assert seen == {'MovementTransition', 'PresenceTransition', 'SubnetworkTransition'}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# scripted baselines: the reference's stateful patched / exploited / camp agents along recorded trajectories
+# ------------------------------------------------------------------------------------------------------------------
+CYBER_BOTS = {'attacker': ('patched_attacker', 'exploited_attacker'), 'defender': ('patched_defender', 'exploited_defender', 'camp_defender')}
+
+
+def _baseline_cases():
+    data = np.load(G.golden_path('baselines_cybersecurity.npz'))
+    for i in range(int(data['cases'])):
+        p = f'c{i}_'
+        yield i, {k[len(p):]: data[k] for k in data.files if k.startswith(p)}
+
+
+def check_focus_policy(policy, case, kind, what):
+    """`policy(kind, target, focused, actions, forced_pick)` updates the three state arrays in place (returns tie counts or None).
+    Starting from the reference agent's recorded state and replaying its recorded torch.randint draws, state and answer after
+    observe() are the reference's."""
+    B = case['tasks'].shape[0]
+    if kind == 'camp_defender':
+        target, focused = np.zeros(B, np.int32), np.zeros(B, np.int32)
+        actions = np.ascontiguousarray(case['camp_defender_pre'], np.int32).copy()
+        policy(kind, target, focused, actions, None)
+        assert np.array_equal(actions, case['camp_defender_post']), f'{what}: answers'
+        return
+    pre, post, draws = case[kind + '_pre'], case[kind + '_post'], case[kind + '_draws']
+    target, focused = pre[0].copy(), pre[1].copy()
+    actions = np.ascontiguousarray(pre[2:].T).copy()
+    ties = policy(kind, target, focused, actions, draws[:, 1].copy() if len(draws) else None)
+    if ties is not None and len(draws):
+        assert np.array_equal(ties, draws[:, 0]), f'{what}: tied candidates'
+    assert np.array_equal(actions, post[2:].T), f'{what}: answers'
+    assert np.array_equal(target, post[0]) and np.array_equal(focused, post[1]), f'{what}: agent state'
+
+
+def test_scripted_baselines_match_reference_answers(oracle):
+    seen = dict(tied=0, early=0, patch=0, monitor=0, reset=0)
+    for i, case in _baseline_cases():
+        for kind in CYBER_BOTS[str(case['role'])]:
+            def policy(kind, target, focused, actions, forced):
+                return oracle.cyber_focus_policy(case['tasks'], case['obs_self'], kind, target, focused, actions,
+                                                 subnetwork_states=int(case['subnetwork_states']), camp_target=int(case.get('camp_target', 0)),
+                                                 mapping_numel=int(case['mapping_numel']), forced_pick=forced)
+
+            check_focus_policy(policy, case, kind, f'case {i} {kind}')
+            if kind != 'camp_defender':
+                draws, pre, post = case[kind + '_draws'], case[kind + '_pre'], case[kind + '_post']
+                seen['tied'] += int(len(draws) and (draws[:, 0] > 1).sum())
+                seen['early'] += int(len(draws) == 0)
+                seen['patch'] += int((post[3] == -2).sum())
+                seen['monitor'] += int((post[3] == -3).sum())
+                seen['reset'] += int(((pre[1] == 2) & (post[1] == 0)).sum())
+    assert all(v > 0 for v in seen.values()), seen

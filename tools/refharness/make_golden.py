@@ -737,7 +737,97 @@ def record_rideshare_baselines():
     print(f'{path}: {cases} observe() calls x {len(RIDESHARE_BOTS)} agents')
 
 
-PARTS = {'ka': record_known_answers, 'baselines_wildfire': record_wildfire_baselines, 'baselines_rideshare': record_rideshare_baselines, 'traj_wildfire': record_wildfire_trajectories, 'traj_cybersecurity': record_cyber_trajectories,
+
+# ----------------------------------------------------------------------------------------------------------
+# scripted cybersecurity baselines: patched / exploited attackers and defenders
+# ----------------------------------------------------------------------------------------------------------
+CYBER_BOTS = {'attacker': ('patched_attacker', 'exploited_attacker'), 'defender': ('patched_defender', 'exploited_defender')}
+
+
+def record_cyber_baselines():
+    """Runs the reference's stateful agents (envs/cybersecurity/baselines/{patched,exploited}.py) along trajectories of the
+    unmodified reference env and records, per observe() call, the observation, the agent's state before (target_node,
+    time_focused, actions), the torch.randint tie-break draws, and state + answer after.  Two drivers: the recorded random
+    policy and the agents driving the env themselves."""
+    from free_range_zoo.envs import cybersecurity_v0
+    from free_range_zoo.envs.cybersecurity.baselines.patched import PatchedAttackerBaseline, PatchedDefenderBaseline
+    from free_range_zoo.envs.cybersecurity.baselines.exploited import ExploitedAttackerBaseline, ExploitedDefenderBaseline
+    from free_range_zoo.envs.cybersecurity.baselines.camp import CampDefenderBaseline
+
+    variants = {v[0]: v for v in cyber_variants()}
+    draws = []
+    original_randint = torch.randint
+
+    def recording_randint(low, high, size, **kwargs):
+        value = original_randint(low, high, size, **kwargs)
+        draws.append((int(high), int(value)))
+        return value
+
+    out, cases = {}, 0
+    for name in ('nonstochastic', 'cfg4_openness', 'rich', 'rich_fully_observable'):
+        _, configuration, kwargs, B, max_steps, steps, seed = variants[name]
+        flags = dict(observe_other_location=False, observe_other_presence=False, observe_other_power=True, partially_observable=True,
+                     show_bad_actions=True)
+        flags.update(kwargs)
+        states = int(configuration.network_config.num_states) if hasattr(configuration.network_config, 'num_states') else None
+        for driver in ('random', 'bots'):
+            env = cybersecurity_v0.parallel_env(parallel_envs=B, max_steps=max_steps, configuration=configuration, device=torch.device('cpu'),
+                                                **flags)
+            observations, _ = env.reset(seed=torch.arange(B, dtype=torch.int32))
+            aec = env.aec_env
+            aec.generator.generate = InjectedRandomness(seed + 300)
+            rng = np.random.default_rng(seed + 300)
+            torch.manual_seed(seed)
+            agents = list(aec.agents)
+            S = states if states is not None else int(aec.network_config.num_states)
+            bots = {}
+            camps = {agent: CampDefenderBaseline(agent, B) for agent in agents if agent.startswith('defender')}
+            for agent in agents:
+                if agent.startswith('attacker'):
+                    bots[agent] = (PatchedAttackerBaseline(agent, B), ExploitedAttackerBaseline(S, agent, B))
+                else:
+                    bots[agent] = (PatchedDefenderBaseline(agent, B), ExploitedDefenderBaseline(S, agent, B))
+            for t in range(min(steps, 12)):
+                driven = np.zeros((len(agents), B, 2), np.int32)
+                for a, agent in enumerate(agents):
+                    mapping = aec.agent_action_mapping[agent]
+                    pair = (observations[agent], {'agent_action_mapping': mapping})
+                    p = f'c{cases}_'
+                    out[p + 'tasks'] = _np(observations[agent]['tasks']).astype(np.int64)
+                    out[p + 'obs_self'] = _np(observations[agent]['self']).astype(np.float32)
+                    out[p + 'mapping_numel'] = np.asarray(int(mapping.numel()))
+                    out[p + 'subnetwork_states'] = np.asarray(S)
+                    role = 'attacker' if agent.startswith('attacker') else 'defender'
+                    out[p + 'role'] = np.asarray(role)
+                    for kind, bot in zip(CYBER_BOTS[role], bots[agent]):
+                        out[p + kind + '_pre'] = np.stack([_np(bot.target_node), _np(bot.time_focused), *_np(bot.actions).T]).astype(np.int32)
+                        del draws[:]
+                        torch.randint = recording_randint
+                        try:
+                            bot.observe(pair)
+                        finally:
+                            torch.randint = original_randint
+                        out[p + kind + '_post'] = np.stack([_np(bot.target_node), _np(bot.time_focused), *_np(bot.actions).T]).astype(np.int32)
+                        assert len(draws) in (0, B)
+                        out[p + kind + '_draws'] = np.asarray(draws, np.int64).reshape(-1, 2)
+                    if role == 'defender':  # camp.py reads the mapping under another key than the wrapper's; hand it that key
+                        bot = camps[agent]
+                        out[p + 'camp_defender_pre'] = _np(bot.actions).astype(np.int32).copy()
+                        bot.observe((observations[agent], {'action_task_mappings': mapping}))
+                        out[p + 'camp_defender_post'] = _np(bot.actions).astype(np.int32).copy()
+                        out[p + 'camp_target'] = np.asarray(int(bot.agent_index % observations[agent]['tasks'].size(1)))
+                    which = (a + t // 4) % 2
+                    driven[a] = _np(bots[agent][which].actions)
+                    cases += 1
+                actions = cyber_policy(aec, rng) if driver == 'random' else driven
+                observations, *_ = env.step({agent: torch.from_numpy(actions[a]) for a, agent in enumerate(agents)})
+    out['cases'] = np.asarray(cases)
+    path = os.path.join(GOLDEN, 'baselines_cybersecurity.npz')
+    np.savez_compressed(path, **out)
+    print(f'{path}: {cases} observe() calls x 2 agents')
+
+
+PARTS = {'ka': record_known_answers, 'baselines_wildfire': record_wildfire_baselines, 'baselines_rideshare': record_rideshare_baselines, 'baselines_cybersecurity': record_cyber_baselines, 'traj_wildfire': record_wildfire_trajectories, 'traj_cybersecurity': record_cyber_trajectories,
          'traj_rideshare': record_rideshare_trajectories,
          'misc': record_misc}
 
