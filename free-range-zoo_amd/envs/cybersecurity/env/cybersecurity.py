@@ -186,6 +186,8 @@ class raw_env(BatchedParallelEnv):
         self._has_reset = True
         self._publish()
         self._publish_dense()
+        if self.logger is not None:  # _post_reset_hook (utils/env.py:191-195)
+            self._log_environment(reset=True)
         return {agent: self.observations[agent] for agent in self.agents}, self.infos
 
     @torch.no_grad()
@@ -216,6 +218,7 @@ class raw_env(BatchedParallelEnv):
         """
         if not self._has_reset:
             raise RuntimeError('reset() must be called before step()')
+        logged = self._logs_this_step()
         if isinstance(actions, dict):
             for a, agent in enumerate(self.agents):
                 self._actions[a].copy_(actions[agent])
@@ -225,6 +228,8 @@ class raw_env(BatchedParallelEnv):
                 raise ValueError('stacked actions must be a contiguous int32 [A, B, 2] tensor')
             self._action_keepalive = actions
             actions_ptr = actions.data_ptr()
+            if self.logger is not None:
+                self._actions.copy_(actions)
         stream = stream_ptr(self.device)
         B, N, A = self.parallel_envs, self._N, len(self.agents)
         if randomness is not None or self.rng == 'mt19937':
@@ -244,7 +249,13 @@ class raw_env(BatchedParallelEnv):
         _capi.check(rc, 'frz_cybersecurity_step')
         self._publish()
         self.infos = {agent: {} for agent in self.agents}
+        if logged:
+            self._log_environment()
         return ({agent: self.observations[agent] for agent in self.agents}, self.rewards, self.terminations, self.truncations, self.infos)
+
+    def _log_extra(self, reset: bool):
+        """cybersecurity.py:580-584: the adjacency matrix in every row."""
+        return {'adj_matrix': [str(self.network_config.adj_matrix.int().tolist())] * self.parallel_envs}
 
     @torch.no_grad()
     def random_policy_actions(self, policy_seed: int, policy_step: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:

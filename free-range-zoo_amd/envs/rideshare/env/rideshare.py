@@ -194,6 +194,8 @@ class raw_env(BatchedParallelEnv):
         self._has_reset = True
         self._publish()
         self._publish_dense()
+        if self.logger is not None:  # _post_reset_hook (utils/env.py:191-195)
+            self._log_environment(reset=True)
         return {agent: self.observations[agent] for agent in self.agents}, self.infos
 
     def _enter_step_zero(self) -> None:
@@ -224,6 +226,7 @@ class raw_env(BatchedParallelEnv):
         """
         if not self._has_reset:
             raise RuntimeError('reset() must be called before step()')
+        logged = self._logs_this_step()
         if isinstance(actions, dict):
             for a, agent in enumerate(self.agents):
                 self._actions[a].copy_(actions[agent])
@@ -233,9 +236,13 @@ class raw_env(BatchedParallelEnv):
                 raise ValueError('stacked actions must be a contiguous int32 [A, B, 2] tensor')
             self._action_keepalive = actions
             actions_ptr = actions.data_ptr()
+            if self.logger is not None:
+                self._actions.copy_(actions)
         _capi.check(self._lib.frz_rideshare_step(self._handle, actions_ptr, stream_ptr(self.device)), 'frz_rideshare_step')
         self._publish()
         self.infos = {agent: {} for agent in self.agents}
+        if logged:
+            self._log_environment()
         return ({agent: self.observations[agent] for agent in self.agents}, self.rewards, self.terminations, self.truncations, self.infos)
 
     @torch.no_grad()

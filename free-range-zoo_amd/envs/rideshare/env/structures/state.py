@@ -7,6 +7,17 @@ import torch
 from free_range_zoo_amd.utils.state import State
 
 
+class _RowsByEnv:
+    """Iterates ``table[table[:, 0] == env]`` for env = 0 .. B-1; evaluated by the consumer (the table may be a pending host copy)."""
+
+    def __init__(self, table: torch.Tensor, parallel_envs: int):
+        self.table, self.parallel_envs = table, parallel_envs
+
+    def __iter__(self):
+        for env in range(self.parallel_envs):
+            yield self.table[self.table[:, 0] == env]
+
+
 @dataclass
 class RideshareState(State):
     """
@@ -25,6 +36,10 @@ class RideshareState(State):
         indices = torch.as_tensor(indices, device=self.agents.device).reshape(-1)
         rows = torch.isin(self.passengers[:, 0], indices.to(self.passengers.dtype))
         return RideshareState(agents=self.agents[indices], passengers=self.passengers[rows])
+
+    def to_dataframe_parts(self, copy=lambda tensor: tensor):
+        """The passenger table is logged per env as the rows whose env column matches (structures/state.py:50-66)."""
+        return [('agents', copy(self.agents)), ('passengers', _RowsByEnv(copy(self.passengers), self.agents.shape[0]))], []
 
     def __hash__(self) -> int:
         parts = (self.agents, self.passengers)

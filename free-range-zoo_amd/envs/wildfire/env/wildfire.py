@@ -224,6 +224,8 @@ class raw_env(BatchedParallelEnv):
         self._has_reset = True
         self._publish()
         self._publish_dense()
+        if self.logger is not None:  # _post_reset_hook (utils/env.py:191-195)
+            self._log_environment(reset=True)
         return {agent: self.observations[agent] for agent in self.agents}, self.infos
 
     @torch.no_grad()
@@ -258,6 +260,7 @@ class raw_env(BatchedParallelEnv):
         """
         if not self._has_reset:
             raise RuntimeError('reset() must be called before step()')
+        logged = self._logs_this_step()
         if isinstance(actions, dict):
             for a, agent in enumerate(self.agents):
                 self._actions[a].copy_(actions[agent])
@@ -267,6 +270,8 @@ class raw_env(BatchedParallelEnv):
                 raise ValueError('stacked actions must be a contiguous int32 [A, B, 2] tensor')
             self._action_keepalive = actions
             actions_ptr = actions.data_ptr()
+            if self.logger is not None:
+                self._actions.copy_(actions)
         stream = stream_ptr(self.device)
         B, H, W, A = self.parallel_envs, self.max_y, self.max_x, len(self.agents)
         fused_mt = (randomness is None and self.rng == 'mt19937' and not self.single_seeding and self.generator.buffer_size == 0)
@@ -294,7 +299,15 @@ class raw_env(BatchedParallelEnv):
         self.infos = {agent: {} for agent in self.agents}
         self.infos['burnouts'] = self._burnouts
         self.infos['putouts'] = self._putouts
+        if logged:
+            self._log_environment()
         return ({agent: self.observations[agent] for agent in self.agents}, self.rewards, self.terminations, self.truncations, self.infos)
+
+    def _log_extra(self, reset: bool):
+        """wildfire.py:755-762: the step's burnouts / putouts (NULL in the reset row)."""
+        if reset:
+            return {'burnouts': [None] * self.parallel_envs, 'putouts': [None] * self.parallel_envs}
+        return {'burnouts': self._burnouts, 'putouts': self._putouts}
 
     @torch.no_grad()
     def random_policy_actions(self, policy_seed: int, policy_step: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -109,6 +109,23 @@ class State(ABC):
                 fields[name] = torch.cat([getattr(s, name) for s in states], *args, **kwargs)
         return first.__class__(**fields)
 
+    # -- logging (state.py:180-191) --------------------------------------------------------------------------
+    def to_dataframe_parts(self, copy=lambda tensor: tensor):
+        """``(per-env columns, shared columns)`` as ``(name, tensor)`` lists in the reference's column order; ``copy`` is applied to
+        every tensor (the logging tap passes a stream-ordered device-to-host copy)."""
+        shared = self._shared()
+        columns = [(name, copy(value)) for name, value in self._tensor_fields() if name not in shared]
+        return columns, [(name, copy(getattr(self, name))) for name in shared]
+
+    def to_dataframe(self):
+        """Convert the state into a dataframe: one row per env, cells are ``str(tensor.tolist())``."""
+        import pandas as pd
+        columns, shared = self.to_dataframe_parts(lambda tensor: tensor.cpu())
+        df = pd.DataFrame({name: [str(row.tolist()) for row in value] for name, value in columns})
+        for name, value in shared:
+            df[name] = str(value.tolist())
+        return df
+
     def __len__(self) -> int:
         for name, value in self._tensor_fields():
             if name not in self._shared() and hasattr(value, 'shape'):

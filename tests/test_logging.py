@@ -1,0 +1,164 @@
+"""Logging tap: the CSV files written along the golden trajectories are the reference's.
+
+tests/golden/logs_csv.npz holds the text of the per-env CSV files the unmodified reference wrote (utils/logging_handlers.py:36-114)
+along one golden trajectory per domain (tools/refharness/make_golden.py logs).  The GPU tests replay the same actions and injected
+randomness through the HIP envs with ``log_directory`` set and compare the files cell by cell; the CPU tests cover the logger itself
+(row format, reset semantics, asynchronous hand-off, failure reporting) on host tensors.
+"""
+import csv
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import configs
+import golden_util as G
+
+
+def parse(text):
+    return list(csv.reader(io.StringIO(text)))
+
+
+def assert_csv_equal(got: str, want: str, what: str):
+    """Identical text, or — cell by cell — identical strings / floats within 1e-5 (rewards may differ in the last ulp)."""
+    if got == want:
+        return
+    g, w = parse(got), parse(want)
+    assert len(g) == len(w), f'{what}: {len(g)} rows, reference wrote {len(w)}'
+    assert g[0] == w[0], f'{what}: header'
+    for r, (gr, wr) in enumerate(zip(g[1:], w[1:])):
+        assert len(gr) == len(wr), f'{what} row {r}'
+        for name, gc, wc in zip(g[0], gr, wr):
+            if gc == wc:
+                continue
+            try:
+                ok = name.endswith('_rewards') and abs(float(gc) - float(wc)) <= 1e-5 * max(1.0, abs(float(wc)))
+            except ValueError:
+                ok = False
+            assert ok, f'{what} row {r} column {name}: {gc!r} != {wc!r}'
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the logger on host tensors
+# ------------------------------------------------------------------------------------------------------------------
+def _toy_state(B, value):
+    from free_range_zoo_amd.envs.cybersecurity.env.structures.state import CybersecurityState
+    return CybersecurityState(network_state=torch.full((B, 3), value, dtype=torch.int32), location=torch.zeros((B, 1), dtype=torch.int32),
+                              presence=torch.ones((B, 2), dtype=torch.bool))
+
+
+@pytest.mark.parametrize('asynchronous', [False, True])
+def test_csv_logger_rows_and_reset(tmp_path, asynchronous):
+    from free_range_zoo_amd.utils.logging_handlers import CSVLogger
+    B, agents = 2, ['attacker_1', 'defender_1']
+    log = CSVLogger(str(tmp_path / 'logs'), B, asynchronous=asynchronous)
+    maps = {a: torch.nested.nested_tensor([torch.tensor([0, 2]), torch.tensor([], dtype=torch.int64)], layout=torch.jagged) for a in agents}
+    obs_maps = {a: torch.arange(3).repeat(B, 1, 1) for a in agents}
+    log.log_environment(_toy_state(B, 1), None, None, maps, obs_maps, None, None, 'demo', agents, reset=True)
+    actions = {a: torch.tensor([[1, 0], [2, -1]], dtype=torch.int32) for a in agents}
+    rewards = {a: torch.tensor([0.5, -1.25]) for a in agents}
+    log.log_environment(_toy_state(B, 2), actions, rewards, maps, obs_maps, torch.tensor([1, 1]), torch.tensor([False, True]), 'demo', agents,
+                        extra={'adj': ['x', 'y']})
+    log.flush()
+    rows = parse(open(tmp_path / 'logs' / '1.csv').read())
+    assert rows[0][:3] == ['network_state', 'location', 'presence'] and rows[0][-1] == 'description'
+    assert rows[1][rows[0].index('step')] == '-1' and rows[1][rows[0].index('attacker_1_action')] == 'NULL'
+    assert rows[2][rows[0].index('attacker_1_action')] == '[2, -1]' and rows[2][rows[0].index('defender_1_rewards')] == '-1.25'
+    assert rows[2][rows[0].index('complete')] == 'True' and rows[2][rows[0].index('attacker_1_action_map')] == '[]'
+    assert rows[2][rows[0].index('attacker_1_observation_map')] == '[[0, 1, 2]]' and rows[2][0] == '[2, 2, 2]'
+    # a reset starts the files again (utils/env.py:140-143 + logging_handlers.py:74-75)
+    log.reset()
+    log.log_environment(_toy_state(B, 3), None, None, maps, obs_maps, None, None, None, agents, reset=True)
+    log.close()
+    rows = parse(open(tmp_path / 'logs' / '0.csv').read())
+    assert len(rows) == 2 and rows[1][0] == '[3, 3, 3]' and rows[1][-1] == 'NULL'
+    with pytest.raises(RuntimeError):  # agents must not change between resets (logging_handlers.py:66-72)
+        log.log_environment(_toy_state(B, 3), actions, rewards, maps, obs_maps, torch.tensor([1, 1]), torch.tensor([False, True]), None,
+                            agents[:1])
+
+
+def test_csv_logger_refuses_a_used_directory_and_reports_writer_failures(tmp_path):
+    from free_range_zoo_amd.utils.logging_handlers import CSVLogger
+    used = tmp_path / 'used'
+    used.mkdir()
+    (used / 'x').write_text('x')
+    with pytest.raises(FileExistsError):
+        CSVLogger(str(used), 1)
+    CSVLogger(str(used), 1, override_initialization_check=True)
+    log = CSVLogger(str(tmp_path / 'gone'), 1)
+    os.rmdir(tmp_path / 'gone')  # the writer thread cannot create its files any more
+    maps = {'a_1': torch.zeros((1, 1), dtype=torch.int64)}
+    log.log_environment(_toy_state(1, 1), None, None, maps, maps, None, None, None, ['a_1'], reset=True)
+    with pytest.raises(RuntimeError):
+        log.flush()
+
+
+def test_sql_connection_strings_are_refused_before_anything_else():
+    from free_range_zoo_amd.envs import wildfire_v0
+    if torch.cuda.is_available():
+        with pytest.raises(NotImplementedError):
+            wildfire_v0.parallel_env(configuration=configs.wildfire_openness(), parallel_envs=2, max_steps=3, log_directory='sqlite:///x.db')
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the envs' files against the reference's
+# ------------------------------------------------------------------------------------------------------------------
+def _replay(domain, tmp_path, stacked=False):
+    logs = np.load(G.golden_path('logs_csv.npz'))
+    name = str(logs[f'{domain}_name'])
+    data = np.load(G.golden_path(f'traj_{domain}_{name}.npz'))
+    directory = str(tmp_path / domain)
+    if domain == 'wildfire':
+        from test_hip_wildfire import make_env
+        from free_range_zoo_amd import _capi
+        build, kwargs = configs.WILDFIRE_GOLDEN[name]
+        cfg = G.load_cfg(data, _capi.frz_wildfire_cfg)
+        shapes = [(3, cfg.parallel_envs, cfg.grid_height * cfg.grid_width), (5, cfg.parallel_envs, cfg.num_agents)]
+        keys = ('field_randomness', 'agent_randomness')
+    elif domain == 'cybersecurity':
+        from test_hip_cybersecurity import make_env
+        from free_range_zoo_amd import _capi
+        build, kwargs = configs.CYBER_GOLDEN[name]
+        cfg = G.load_cfg(data, _capi.frz_cybersecurity_cfg)
+        shapes = [(1, cfg.parallel_envs, cfg.num_nodes), (1, cfg.parallel_envs, cfg.num_attackers + cfg.num_defenders)]
+        keys = ('network_randomness', 'agent_randomness')
+    else:
+        from test_hip_rideshare import make_env
+        from free_range_zoo_amd import _capi
+        build, kwargs = configs.RIDESHARE_GOLDEN[name], {}
+        cfg = G.load_cfg(data, _capi.frz_rideshare_cfg)
+        shapes = keys = None
+    B = cfg.parallel_envs
+    env = make_env(build, B, None if cfg.max_steps < 0 else cfg.max_steps, log_directory=directory, **kwargs)
+    env.reset(seed=torch.arange(B, dtype=torch.int32), options={'log_description': f'golden {name}'})
+    for t in range(int(data['steps'])):
+        p = f's{t}_'
+        actions = {agent: torch.from_numpy(data[p + 'actions'][a]).cuda() for a, agent in enumerate(env.agents)}
+        if stacked:
+            actions = torch.stack([actions[agent] for agent in env.agents]).contiguous()
+        if keys is None:
+            env.step(actions)
+        else:
+            stepped = bool(data[p + 'stepped'])
+            rnd = tuple(torch.from_numpy(data[p + k]) if stepped else torch.zeros(s) for k, s in zip(keys, shapes))
+            env.step(actions, randomness=rnd)
+    env.check()
+    env.close()
+    want = logs[domain]
+    assert sorted(os.listdir(directory)) == sorted(f'{i}.csv' for i in range(B))
+    for i in range(B):
+        assert_csv_equal(open(os.path.join(directory, f'{i}.csv')).read(), str(want[i]), f'{domain} {name} env {i}')
+    return directory
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('domain', ['wildfire', 'cybersecurity', 'rideshare'])
+def test_env_logs_equal_the_reference_files(domain, tmp_path):
+    _replay(domain, tmp_path)
+
+
+@pytest.mark.gpu
+def test_stacked_actions_are_logged_too(tmp_path):
+    _replay('cybersecurity', tmp_path, stacked=True)

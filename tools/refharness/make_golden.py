@@ -827,7 +827,55 @@ def record_cyber_baselines():
     print(f'{path}: {cases} observe() calls x 2 agents')
 
 
-PARTS = {'ka': record_known_answers, 'baselines_wildfire': record_wildfire_baselines, 'baselines_rideshare': record_rideshare_baselines, 'baselines_cybersecurity': record_cyber_baselines, 'traj_wildfire': record_wildfire_trajectories, 'traj_cybersecurity': record_cyber_trajectories,
+
+# ----------------------------------------------------------------------------------------------------------
+# CSV logs (logging tap): what utils/logging_handlers.py:CSVLogger writes along the golden trajectories
+# ----------------------------------------------------------------------------------------------------------
+def record_logs():
+    """Re-runs one golden trajectory per domain (same seeds, hence same actions and injected randomness as traj_<domain>_<name>.npz)
+    with log_directory set and stores the text of the per-env CSV files the reference wrote — output data of the reference."""
+    import shutil
+    import tempfile
+    from free_range_zoo.envs import wildfire_v0, rideshare_v0, cybersecurity_v0
+
+    def run(module, name, B, max_steps, steps, seed, configuration, flags, policy, inject):
+        directory = tempfile.mkdtemp(prefix='frz_reflog_')
+        shutil.rmtree(directory)
+        env = module.parallel_env(parallel_envs=B, max_steps=max_steps, configuration=configuration, device=torch.device('cpu'),
+                                  log_directory=directory, **flags)
+        env.reset(seed=torch.arange(B, dtype=torch.int32), options={'log_description': f'golden {name}'})
+        if inject:
+            env.aec_env.generator.generate = InjectedRandomness(seed)
+        rng = np.random.default_rng(seed)
+        agents = list(env.aec_env.agents)
+        for t in range(steps):
+            actions = policy(env.aec_env, rng)
+            env.step({agent: torch.from_numpy(actions[a]) for a, agent in enumerate(agents)})
+        texts = [open(os.path.join(directory, f'{i}.csv')).read() for i in range(B)]
+        shutil.rmtree(directory)
+        return np.asarray(texts)
+
+    out = {}
+    v = {x[0]: x for x in wildfire_variants()}['rich_localized']
+    flags = dict(show_bad_actions=False, observe_other_power=False, observe_other_suppressant=False)
+    flags.update(v[2])
+    out['wildfire_name'] = np.asarray(v[0])
+    out['wildfire'] = run(wildfire_v0, v[0], v[3], v[4], v[5], v[6], v[1], flags, wildfire_policy, True)
+    v = {x[0]: x for x in cyber_variants()}['rich']
+    flags = dict(observe_other_location=False, observe_other_presence=False, observe_other_power=True, partially_observable=True,
+                 show_bad_actions=True)
+    flags.update(v[2])
+    out['cybersecurity_name'] = np.asarray(v[0])
+    out['cybersecurity'] = run(cybersecurity_v0, v[0], v[3], v[4], v[5], v[6], v[1], flags, cyber_policy, True)
+    v = {x[0]: x for x in rideshare_variants()}['busy_waiting_costs']
+    out['rideshare_name'] = np.asarray(v[0])
+    out['rideshare'] = run(rideshare_v0, v[0], v[2], v[3], v[4], v[5], v[1], {}, rideshare_policy, False)
+    path = os.path.join(GOLDEN, 'logs_csv.npz')
+    np.savez_compressed(path, **out)
+    print(path, {k: (len(out[k]), sum(len(t) for t in out[k])) for k in ('wildfire', 'cybersecurity', 'rideshare')})
+
+
+PARTS = {'ka': record_known_answers, 'baselines_wildfire': record_wildfire_baselines, 'baselines_rideshare': record_rideshare_baselines, 'baselines_cybersecurity': record_cyber_baselines, 'logs': record_logs, 'traj_wildfire': record_wildfire_trajectories, 'traj_cybersecurity': record_cyber_trajectories,
          'traj_rideshare': record_rideshare_trajectories,
          'misc': record_misc}
 
