@@ -209,7 +209,6 @@ class raw_env(BatchedParallelEnv):
             self.generator.seed(seed, partial_seeding=None)
         self.agents = self.possible_agents
         self.rewards = None
-        self._static_views = None
         stream = stream_ptr(self.device)
         _capi.check(self._lib.frz_wildfire_reset(self._handle, stream), 'frz_wildfire_reset')
         if options is not None and options.get('initial_state') is not None:
@@ -262,8 +261,7 @@ class raw_env(BatchedParallelEnv):
             raise RuntimeError('reset() must be called before step()')
         logged = self._logs_this_step()
         if isinstance(actions, dict):
-            for a, agent in enumerate(self.agents):
-                self._actions[a].copy_(actions[agent])
+            self._stage_actions(actions)
             actions_ptr = self._actions.data_ptr()
         else:
             if actions.dtype != torch.int32 or not actions.is_contiguous() or tuple(actions.shape) != tuple(self._actions.shape):

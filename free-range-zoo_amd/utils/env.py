@@ -134,6 +134,16 @@ class BatchedParallelEnv:
         if self.logger is not None:  # env.py:140-143: the logger starts new files on every reset
             self.logger.reset(log_label=self._log_label, log_description=self.log_description)
 
+    def _stage_actions(self, actions: Dict[str, torch.Tensor]) -> None:
+        """``{agent: [B, 2]}`` -> the stacked int32 ``[A, B, 2]`` buffer the kernels read: one launch when the tensors already are
+        int32 on the env's device, a converting copy per agent otherwise."""
+        parts = [actions[agent] for agent in self.agents]
+        if all(p.dtype == torch.int32 and p.device == self.device and tuple(p.shape) == (self.parallel_envs, 2) for p in parts):
+            torch.stack(parts, out=self._actions)
+        else:
+            for a, part in enumerate(parts):
+                self._actions[a].copy_(part)
+
     # -- logging tap (env.py:191-195, 239-240, 256-271) ---------------------------------------------------------------
     def _log_extra(self, reset: bool):
         """Per-domain extra columns (dict of per-env columns), None when the domain adds none."""
