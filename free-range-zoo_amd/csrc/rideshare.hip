@@ -27,6 +27,7 @@ using frz::kBlock;
 
 enum Mode { kStep = 0, kRebuild = 1 };
 enum Flag : uint32_t { kFast = 1u << 0, kDiagonal = 1u << 1, kVariableMove = 1u << 2, kWaiting = 1u << 3, kTrackCumulative = 1u << 4, kTruncate = 1u << 5 };
+constexpr int kBatch = 4;  // slots whose loads are in flight together in the three walks over an env's passenger slots
 enum Col { PY = 0, PX, PYD, PXD, PFARE, PSTATE, PDRIVER, PENTERED, PACCEPTED, PPICKED, PCOLS };
 constexpr int kNone = -100;
 
@@ -117,13 +118,21 @@ __global__ void __launch_bounds__(kBlock) rs_fill_kernel(char* arena) {
     if (err) atomicOr(reinterpret_cast<uint32_t*>(arena + d.off_error), err);
 }
 
+// diagnostic builds only (tools/exp_skip.sh): -DFRZ_RS_SKIP_MASK=<bits> leaves store groups of the emission pass out
+#ifdef FRZ_RS_SKIP_MASK
+#define FRZ_RS_SKIP(bit) ((FRZ_RS_SKIP_MASK & (bit)) != 0)
+#else
+#define FRZ_RS_SKIP(bit) false
+#endif
+
 template <int AMAX, int MODE>
-__global__ void __launch_bounds__(kBlock) rs_step_kernel(char* __restrict__ arena, const RsDev* __restrict__ dev,
-                                                          const int32_t* __restrict__ actions, uint32_t ticketed) {
+__global__ void __launch_bounds__(kBlock) rs_step_kernel(char* __restrict__ arena, const RsDev d, const int32_t* __restrict__ actions,
+                                                          uint32_t ticketed) {
+    // the configuration block arrives BY VALUE (424 bytes of kernel arguments): read through a pointer into the arena, every field
+    // had to be re-read after each store that might alias it — a scalar-memory round trip per use, hundreds per env slot walked
     __shared__ frz::ScanShared<AMAX + 1> s_scan;
     __shared__ int s_ticket;
 
-    const RsDev& d = *dev;
     const int tid = threadIdx.x;
     const int64_t B = d.B;
     const uint32_t Bu = (uint32_t)d.B, P = (uint32_t)d.P;
@@ -191,13 +200,26 @@ __global__ void __launch_bounds__(kBlock) rs_step_kernel(char* __restrict__ aren
             }
             // the agent's action mapping lists, in table order, the passengers that are unaccepted or its own
             // (rideshare.py:378-392): walk the slots and pick the act_idx-th visible one
-            for (int s = 0; s < count; ++s) {
-                const int st = pcol(PSTATE, s, bl), drv = pcol(PDRIVER, s, bl);
+            // (slots are walked kBatch at a time with every load of a batch issued before its first use: a lane-per-env walk is a
+            // chain of dependent memory round trips otherwise; slots past `count` are read from slot P - 1 and ignored)
+            for (int s0 = 0; s0 < count; s0 += kBatch) {
+                int st[kBatch], drv[kBatch];
 #pragma unroll
-                for (int a = 0; a < AMAX; ++a) {
-                    const bool vis = st == 0 || drv == a;
-                    target[a] = (vis && seen[a] == act_idx[a]) ? s : target[a];
-                    seen[a] += vis ? 1 : 0;
+                for (int u = 0; u < kBatch; ++u) {
+                    const int s = min(s0 + u, (int)P - 1);
+                    st[u] = pcol(PSTATE, s, bl);
+                    drv[u] = pcol(PDRIVER, s, bl);
+                }
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) {
+                    const int s = s0 + u;
+                    const bool live = s < count;
+#pragma unroll
+                    for (int a = 0; a < AMAX; ++a) {
+                        const bool vis = live && (st[u] == 0 || drv[u] == a);
+                        target[a] = (vis && seen[a] == act_idx[a]) ? s : target[a];
+                        seen[a] += vis ? 1 : 0;
+                    }
                 }
             }
             bool accept[AMAX], pick[AMAX], drop[AMAX], has_vec[AMAX];
@@ -296,10 +318,10 @@ __global__ void __launch_bounds__(kBlock) rs_step_kernel(char* __restrict__ aren
             int owned[AMAX];  // passengers whose driver is agent a, any state (rideshare.py:343-344)
 #pragma unroll
             for (int a = 0; a < AMAX; ++a) owned[a] = 0;
-            for (int s = 0; s < count; ++s) {
-                int v[PCOLS], was[PCOLS];
+            auto settle_slot = [&](const int s, const int (&was)[PCOLS]) {
+                int v[PCOLS];
 #pragma unroll
-                for (int c = 0; c < PCOLS; ++c) was[c] = v[c] = pcol(c, s, bl);
+                for (int c = 0; c < PCOLS; ++c) v[c] = was[c];
                 if (v[PSTATE] == 2) {  // best_moves[env, driver]; driver -1 wraps to the last agent like Python's index
                     const int drv = v[PDRIVER] < 0 ? A + v[PDRIVER] : v[PDRIVER];
 #pragma unroll
@@ -353,6 +375,19 @@ __global__ void __launch_bounds__(kBlock) rs_step_kernel(char* __restrict__ aren
                     }
                     ++kept;
                 }
+            };
+            for (int s0 = 0; s0 < count; s0 += kBatch) {
+                int was[kBatch][PCOLS];
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) {
+                    const int s = min(s0 + u, (int)P - 1);
+#pragma unroll
+                    for (int c = 0; c < PCOLS; ++c) was[u][c] = pcol(c, s, bl);
+                }
+                // a slot is only ever written at or below its own index (kept <= s), so the batch's loads see the old table
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u)
+                    if (s0 + u < count) settle_slot(s0 + u, was[u]);
             }
             count = kept;
             // ---------------------------------------------------------------- (5) entry of the next timestep (rideshare.py:308)
@@ -458,16 +493,15 @@ __global__ void __launch_bounds__(kBlock) rs_step_kernel(char* __restrict__ aren
             int next[AMAX];
 #pragma unroll
             for (int a = 0; a < AMAX; ++a) next[a] = 0;
-            for (int s = 0; s < count; ++s) {
-                const int st = pcol(PSTATE, s, bl), drv = pcol(PDRIVER, s, bl);
-                const int4 lo = make_int4(pcol(PY, s, bl), pcol(PX, s, bl), pcol(PYD, s, bl), pcol(PXD, s, bl));
-                const int4 hi = make_int4(st == 1 ? drv : kNone, st == 2 ? drv : kNone, pcol(PFARE, s, bl), pcol(PENTERED, s, bl));
+            auto emit_slot = [&](const int s, const int st, const int drv, const int4 lo, const int4 hi) {
                 int4* row = reinterpret_cast<int4*>(task_values) + ((int64_t)excl[0] + s) * 2;
-                row[0] = lo;
-                row[1] = hi;
+                if (!FRZ_RS_SKIP(2)) {
+                    row[0] = lo;
+                    row[1] = hi;
+                }
 #pragma unroll
                 for (int a = 0; a < AMAX; ++a) {
-                    if (a < A && (st == 0 || drv == a)) {  // general or exclusive task of agent a (:378-380)
+                    if (!FRZ_RS_SKIP(1) && a < A && (st == 0 || drv == a)) {  // general or exclusive task of agent a (:378-380)
                         const int64_t at = a * cap + (int64_t)excl[a + 1] + next[a];
                         int4* arow = reinterpret_cast<int4*>(agent_tasks) + at * 2;
                         arow[0] = lo;
@@ -476,6 +510,24 @@ __global__ void __launch_bounds__(kBlock) rs_step_kernel(char* __restrict__ aren
                         agent_states[at] = st;
                         ++next[a];
                     }
+                }
+            };
+            for (int s0 = 0; s0 < (FRZ_RS_SKIP(4) ? 0 : count); s0 += kBatch) {
+                int st[kBatch], drv[kBatch];
+                int4 lo[kBatch], hi[kBatch];
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) {
+                    const int s = min(s0 + u, (int)P - 1);
+                    st[u] = pcol(PSTATE, s, bl);
+                    drv[u] = pcol(PDRIVER, s, bl);
+                    lo[u] = make_int4(pcol(PY, s, bl), pcol(PX, s, bl), pcol(PYD, s, bl), pcol(PXD, s, bl));
+                    hi[u] = make_int4(0, 0, pcol(PFARE, s, bl), pcol(PENTERED, s, bl));
+                }
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) {
+                    hi[u].x = st[u] == 1 ? drv[u] : kNone;
+                    hi[u].y = st[u] == 2 ? drv[u] : kNone;
+                    if (s0 + u < count) emit_slot(s0 + u, st[u], drv[u], lo[u], hi[u]);
                 }
             }
         }
@@ -527,11 +579,10 @@ int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
 template <int AMAX>
 void launch_variant(frz_rideshare_env* env, const int32_t* actions, int mode, hipStream_t stream) {
-    const RsDev* dev = reinterpret_cast<const RsDev*>(env->arena);
     if (mode == kRebuild)
-        hipLaunchKernelGGL((rs_step_kernel<AMAX, kRebuild>), dim3(env->dev.nchunks), dim3(kBlock), 0, stream, env->arena, dev, actions, env->ticketed ? 1u : 0u);
+        hipLaunchKernelGGL((rs_step_kernel<AMAX, kRebuild>), dim3(env->dev.nchunks), dim3(kBlock), 0, stream, env->arena, env->dev, actions, env->ticketed ? 1u : 0u);
     else
-        hipLaunchKernelGGL((rs_step_kernel<AMAX, kStep>), dim3(env->dev.nchunks), dim3(kBlock), 0, stream, env->arena, dev, actions, env->ticketed ? 1u : 0u);
+        hipLaunchKernelGGL((rs_step_kernel<AMAX, kStep>), dim3(env->dev.nchunks), dim3(kBlock), 0, stream, env->arena, env->dev, actions, env->ticketed ? 1u : 0u);
 }
 
 int launch(frz_rideshare_env* env, const int32_t* actions, int mode, hipStream_t stream) {
