@@ -82,7 +82,9 @@ __global__ void __launch_bounds__(kRoleBlock, (RNG == FRZ_RNG_MT19937 ? 2 : 4)) 
 
     const int tid = threadIdx.x;
     const uint4 cfg_piece = stage_request(dev);  // first vector-memory instruction of the kernel
-    const bool crew = __builtin_amdgcn_readfirstlane(tid >> 8) != 0;  // wave-uniform role
+    // wave-uniform role.  A workgroup's wavefronts are started one after the other (the last ≈1 000 cycles after the first); the crew is
+    // the role the first barrier waits for, so it gets the wavefronts that start first
+    const bool crew = __builtin_amdgcn_readfirstlane(tid >> 8) == 0;
     const int slot = tid & (kBlock - 1);                                // env slot inside the chunk; the role's thread index
     const int lane = frz::lane_id(), wave = (tid >> 6) & 3;
     const int64_t B = batch;
@@ -646,7 +648,7 @@ __global__ void __launch_bounds__(kRoleBlock, (RNG == FRZ_RNG_MT19937 ? 2 : 4)) 
             FRZ_RWALL(1);
             // The workgroup owning the last chunk finished its look-back only after every other chunk published, i.e.
             // after every workgroup of this launch read the epoch: it can advance it for the next launch.
-            if (chunk == nchunks - 1 && tid == 0) __hip_atomic_store(epoch_ptr, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (chunk == nchunks - 1 && slot == 0) __hip_atomic_store(epoch_ptr, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     } else {
         // ============================================================================================= CREW ROLE
