@@ -199,14 +199,7 @@ __global__ void __launch_bounds__(kRoleBlock, (RNG == FRZ_RNG_MT19937 ? 2 : 4)) 
                 e.supp[a] = at32(rowsf, (uint32_t)(r_supp + a) * Bu + bl);
                 e.capa[a] = at32(rowsf, (uint32_t)(r_cap + a) * Bu + bl);
                 e.eqs[a] = at32(rows, (uint32_t)(r_equip + a) * Bu + bl);
-                if (MODE == kStep) {
-                    if (!launch.policy) {
-                        const int2 v = reinterpret_cast<const int2*>(actions)[a * B + bl];
-                        e.act_idx[a] = v.x;
-                        e.act_id[a] = v.y;
-                    }
-                    e.cum[a] = at32(rowsf, (uint32_t)(r_cum + a) * Bu + bl);
-                }
+                if (MODE == kStep) e.cum[a] = at32(rowsf, (uint32_t)(r_cum + a) * Bu + bl);
             }
         }
         // agents share one termination / truncation value (wildfire.py:579, utils/env.py:231-233): row 0 is read,
@@ -219,6 +212,16 @@ __global__ void __launch_bounds__(kRoleBlock, (RNG == FRZ_RNG_MT19937 ? 2 : 4)) 
             e.nm = at32(rows, (uint32_t)r_moves * Bu + bl);
             e.nb = at32(rows, (uint32_t)r_burnouts * Bu + bl);
             if (kPhilox || launch.policy) e.seed = (uint32_t)at32(rows, (uint32_t)r_seeds * Bu + bl);
+        }
+        if (MODE == kStep && !launch.policy) {  // last, in one block: the pairs are in flight together, behind every other load of the role
+            int2 v[AMAX];
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a) v[a] = a < A ? reinterpret_cast<const int2*>(actions)[a * B + bl] : make_int2(0, -1);
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a) {
+                e.act_idx[a] = v[a].x;
+                e.act_id[a] = v[a].y;
+            }
         }
         if constexpr (kInjected) {
 #pragma unroll
@@ -258,7 +261,16 @@ __global__ void __launch_bounds__(kRoleBlock, (RNG == FRZ_RNG_MT19937 ? 2 : 4)) 
     if (!crew) fld = load_field(chunk, fdraws);
     else crw = load_crew(chunk, cdraws);
 
+#ifdef FRZ_WF_STAMPS  // the same staging with a stamp after each step (diagnostic build only)
+    FRZ_RSTAMP(11);
+    if (threadIdx.x < sizeof(WfStaged) / 16) reinterpret_cast<uint4*>(&s_cfg)[threadIdx.x] = cfg_piece;
+    FRZ_RSTAMP(12);
+    __syncthreads();
+    FRZ_RSTAMP(13);
+    const WfHot d = s_cfg;
+#else
     const WfHot d = stage_commit(s_cfg, cfg_piece);  // configuration block at arena offset 0; never written by a kernel
+#endif
     FRZ_RSTAMP(1);
     const int W = d.W;
     const int nch = d.nch;  // A + 3

@@ -12,7 +12,7 @@ from free_range_zoo_amd.envs import wildfire_v0
 from free_range_zoo_amd.utils.env import stream_ptr
 lane_names = ['loads+config/LDS init', 'epoch+totals+frozen test', 'loop top', 'randomness (philox)', 'decode', 'agent transitions+agent/obs stores',
               'fire inc/dec+spread+cell stores', 'rebuild masks+scan', 'publish+rewards+reward stores+prefetch', 'look-back', 'jagged stores']
-role_points = ['kernel entry', 'config staged', 'epoch/totals read', 'phase 1 done', 'past barrier 1', 'phase 2 done', 'past barrier 2', 'phase 3 done',
+role_points = ['kernel entry (config requested)', 'config staged', 'epoch/totals read', 'phase 1 done', 'past barrier 1', 'phase 2 done', 'past barrier 2', 'phase 3 done',
                'phase 4 done', 'past barrier 5', 'phase 6 done']
 roles = os.environ.get('FRZ_WF_KERNEL', 'roles') != 'lane'
 for B in [int(x) for x in sys.argv[1:]] or [256, 65536]:
@@ -51,6 +51,9 @@ for B in [int(x) for x in sys.argv[1:]] or [256, 65536]:
         print(f'  {"point":22s} {"field":>8s} {"crew":>8s}')
         for n, a, c in zip(role_points, field, crew):
             print(f'  {n:22s} {int(a):8d} {int(c):8d}')
+        extra = ['state loads issued', 'config piece arrived (LDS written)', 'past staging barrier']  # stamps 11..13
+        for k, n in enumerate(extra):
+            print(f'  staging: {n:36s} {int(np.median(st[:, 11 + k] - t0[:, 0])):8d} {int(np.median(st[:, 27 + k] - t0[:, 0])):8d}')
     else:
         dd = np.median(np.diff(st[:, :len(lane_names)], axis=1), axis=0)
         total = dd.sum()
