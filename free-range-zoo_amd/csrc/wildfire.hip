@@ -916,8 +916,10 @@ struct Variant {
     int cmax, amax;
     bool exact;
 };
-constexpr Variant kVariants[] = {{6, 3, true}, {6, 2, true}, {8, 4, false}, {24, 8, false}, {64, 16, false}};
-constexpr int kNumVariants = 5;
+// the lane-per-env kernel unrolls its cell and agent loops to (CMAX, AMAX): a shape runs the smallest instantiation that holds it
+// (3x3 / 3x4 / 4x4 grids do not pay for the 24-cell one)
+constexpr Variant kVariants[] = {{6, 3, true}, {6, 2, true}, {8, 4, false}, {12, 4, false}, {16, 8, false}, {24, 8, false}, {64, 16, false}};
+constexpr int kNumVariants = 7;
 
 int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
@@ -960,7 +962,9 @@ int launch_lane(frz_wildfire_env* env, const WfArgs& args, int rng, int mode, hi
         case 0: launch_variant<6, 3, true>(args, grid, rng, mode, stream); break;   // BASELINE.json cfg1/cfg2 shape
         case 1: launch_variant<6, 2, true>(args, grid, rng, mode, stream); break;   // AAAI-2025 openness configs
         case 2: launch_variant<8, 4, false>(args, grid, rng, mode, stream); break;
-        case 3: launch_variant<24, 8, false>(args, grid, rng, mode, stream); break;
+        case 3: launch_variant<12, 4, false>(args, grid, rng, mode, stream); break;
+        case 4: launch_variant<16, 8, false>(args, grid, rng, mode, stream); break;
+        case 5: launch_variant<24, 8, false>(args, grid, rng, mode, stream); break;
         default: launch_variant<64, 16, false>(args, grid, rng, mode, stream); break;
     }
     return hipGetLastError() == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;
