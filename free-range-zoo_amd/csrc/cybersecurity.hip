@@ -120,17 +120,21 @@ __global__ void __launch_bounds__(kBlock) cy_step_kernel(char* __restrict__ aren
 
     // ---------------------------------------------------------------------------------------------- load state
     // (issued before the configuration is staged; lanes past the end shadow the last env and store nothing)
+    // Every load below is UNCONDITIONAL: rows past the env's node / defender / agent count are read from the last valid row and
+    // replaced afterwards.  A load under `if (a < A)` becomes its own basic block that ends in a wait for everything issued so far:
+    // one memory round trip per agent instead of one for the whole prologue.
     int state[NMAX], loc[AMAX], last[AMAX];
     uint32_t pres_raw[AMAX];
+    float cum_in[AMAX];
 #pragma unroll
-    for (int n = 0; n < NMAX; ++n) state[n] = n < N ? at32(rows, (uint32_t)(r_state + n) * Bu + bl) : 0;
+    for (int n = 0; n < NMAX; ++n) state[n] = at32(rows, (uint32_t)(r_state + min(n, N - 1)) * Bu + bl);
 #pragma unroll
     for (int k = 0; k < AMAX; ++k) {
-        loc[k] = k < D ? at32(rows, (uint32_t)(r_loc + k) * Bu + bl) : -1;
-        last[k] = k < D ? at32(rows, (uint32_t)(r_last + k) * Bu + bl) : -2;
+        loc[k] = at32(rows, (uint32_t)(r_loc + min(k, D - 1)) * Bu + bl);
+        last[k] = at32(rows, (uint32_t)(r_last + min(k, D - 1)) * Bu + bl);
     }
 #pragma unroll
-    for (int a = 0; a < AMAX; ++a) pres_raw[a] = a < A ? at32(rows1, (u_presence + (uint32_t)a) * Bu + bl) : 0u;
+    for (int a = 0; a < AMAX; ++a) pres_raw[a] = at32(rows1, (u_presence + (uint32_t)min(a, A - 1)) * Bu + bl);
     const uint32_t trunc_raw = at32(rows1, u_trunc * Bu + bl);
     int nm = 0;
     uint32_t seed = 0;
@@ -140,13 +144,29 @@ __global__ void __launch_bounds__(kBlock) cy_step_kernel(char* __restrict__ aren
         nm = at32(rows, (uint32_t)r_moves * Bu + bl);
         if (RNG == FRZ_RNG_PHILOX) seed = (uint32_t)at32(rows, (uint32_t)r_seeds * Bu + bl);
 #pragma unroll
-        for (int a = 0; a < AMAX; ++a) act_in[a] = a < A ? reinterpret_cast<const int2*>(actions)[a * B + bl] : make_int2(0, -1);
+        for (int a = 0; a < AMAX; ++a) act_in[a] = reinterpret_cast<const int2*>(actions)[(int64_t)min(a, A - 1) * B + bl];
+        // cumulative rewards (row block r_cum = r_moves + 1 + A, frz_cybersecurity_create): read here, added and stored at the end
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a) cum_in[a] = at32(rowsf, (uint32_t)(r_moves + 1 + A + min(a, A - 1)) * Bu + bl);
         if (RNG == FRZ_RNG_INJECTED) {
 #pragma unroll
-            for (int n = 0; n < NMAX; ++n) r_net_in[n] = n < N ? net_rand[(int64_t)bl * N + n] : 0.0f;
+            for (int n = 0; n < NMAX; ++n) r_net_in[n] = net_rand[(int64_t)bl * N + min(n, N - 1)];
 #pragma unroll
-            for (int a = 0; a < AMAX; ++a) r_agent_in[a] = a < A ? agent_rand[(int64_t)bl * A + a] : 0.0f;
+            for (int a = 0; a < AMAX; ++a) r_agent_in[a] = agent_rand[(int64_t)bl * A + min(a, A - 1)];
         }
+    }
+
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) state[n] = n < N ? state[n] : 0;
+#pragma unroll
+    for (int k = 0; k < AMAX; ++k) {
+        loc[k] = k < D ? loc[k] : -1;
+        last[k] = k < D ? last[k] : -2;
+    }
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) {
+        pres_raw[a] = a < A ? pres_raw[a] : 0u;
+        if (MODE == kStep) act_in[a] = a < A ? act_in[a] : make_int2(0, -1);
     }
 
     if (tid < kCfgPieces) s_cfg[tid] = cfg_piece;
@@ -318,10 +338,7 @@ __global__ void __launch_bounds__(kBlock) cy_step_kernel(char* __restrict__ aren
                         at32(rows1, (uint32_t)(d.u_presence + a) * Bu + bl) = (uint8_t)pres[a];
                         at32(rowsf, (uint32_t)(d.r_rewards + a) * Bu + bl) = r;
                         if (flags & kTruncate) at32(rows1, (uint32_t)(d.u_trunc + a) * Bu + bl) = (uint8_t)trunc;
-                        if (flags & kTrackCumulative) {
-                            float& cum = at32(rowsf, (uint32_t)(d.r_cum + a) * Bu + bl);
-                            cum = __fadd_rn(cum, r);
-                        }
+                        if (flags & kTrackCumulative) at32(rowsf, (uint32_t)(d.r_cum + a) * Bu + bl) = __fadd_rn(cum_in[a], r);
                     }
                 at32(rows, (uint32_t)d.r_moves * Bu + bl) = nm;
             }
