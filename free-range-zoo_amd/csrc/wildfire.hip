@@ -149,31 +149,41 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ aren
         Env e;
         const int64_t b = (int64_t)chunk * kBlock + tid;
         const uint32_t bl = (uint32_t)(b < B ? b : B - 1);
+        // Unconditional loads (rows past the env's cell / agent count are read from the last valid row and replaced below): a load
+        // under `if (a < A)` with a runtime A is a basic block of its own that ends in a wait for every load issued so far.
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) {
-            e.f[c] = e.in[c] = e.fu[c] = 0;
-            if (c < HW) {
-                e.f[c] = at32(rows, (uint32_t)(r_fires + c) * Bu + bl);
-                e.in[c] = at32(rows, (uint32_t)(r_intensity + c) * Bu + bl);
-                e.fu[c] = at32(rows, (uint32_t)(r_fuel + c) * Bu + bl);
+            const int cc = EXACT ? c : min(c, HW - 1);
+            e.f[c] = at32(rows, (uint32_t)(r_fires + cc) * Bu + bl);
+            e.in[c] = at32(rows, (uint32_t)(r_intensity + cc) * Bu + bl);
+            e.fu[c] = at32(rows, (uint32_t)(r_fuel + cc) * Bu + bl);
+        }
+        int2 pair[AMAX];
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a) {
+            const int aa = EXACT ? a : min(a, A - 1);
+            e.supp[a] = at32(rowsf, (uint32_t)(r_supp + aa) * Bu + bl);
+            e.capa[a] = at32(rowsf, (uint32_t)(r_cap + aa) * Bu + bl);
+            e.eqs[a] = at32(rows, (uint32_t)(r_equip + aa) * Bu + bl);
+            e.cum[a] = 0.0f;
+            pair[a] = make_int2(0, -1);
+            if (MODE == kStep) {
+                pair[a] = reinterpret_cast<const int2*>(actions)[(int64_t)aa * B + bl];
+                e.cum[a] = at32(rowsf, (uint32_t)(r_cum + aa) * Bu + bl);
             }
         }
 #pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+            if (c >= HW) e.f[c] = e.in[c] = e.fu[c] = 0;
+#pragma unroll
         for (int a = 0; a < AMAX; ++a) {
-            e.supp[a] = e.capa[a] = e.cum[a] = 0.0f;
-            e.eqs[a] = e.act_idx[a] = 0;
-            e.act_id[a] = -1;
-            if (a < A) {
-                e.supp[a] = at32(rowsf, (uint32_t)(r_supp + a) * Bu + bl);
-                e.capa[a] = at32(rowsf, (uint32_t)(r_cap + a) * Bu + bl);
-                e.eqs[a] = at32(rows, (uint32_t)(r_equip + a) * Bu + bl);
-                if (MODE == kStep) {
-                    const int2 v = reinterpret_cast<const int2*>(actions)[a * B + bl];
-                    e.act_idx[a] = v.x;
-                    e.act_id[a] = v.y;
-                    e.cum[a] = at32(rowsf, (uint32_t)(r_cum + a) * Bu + bl);
-                }
-            }
+            const bool real = a < A;
+            e.supp[a] = real ? e.supp[a] : 0.0f;
+            e.capa[a] = real ? e.capa[a] : 0.0f;
+            e.cum[a] = real ? e.cum[a] : 0.0f;
+            e.eqs[a] = real ? e.eqs[a] : 0;
+            e.act_idx[a] = real ? pair[a].x : 0;
+            e.act_id[a] = real ? pair[a].y : -1;
         }
         // agents share one termination / truncation value (wildfire.py:579, utils/env.py:231-233): row 0 is read,
         // all A rows are written
