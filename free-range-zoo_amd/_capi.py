@@ -60,6 +60,7 @@ SIGNATURES = {
     'frz_cybersecurity_rebuild': (ctypes.c_int, [_P, _P]),
     'frz_cybersecurity_step': (ctypes.c_int, [_P, _P, ctypes.c_int, _P, _P, _P]),
     'frz_cybersecurity_random_policy': (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_uint64, _P, _P]),
+    'frz_cybersecurity_step_random_policy': (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_uint64, _P, ctypes.c_int, _P, _P, _P]),
     'frz_rideshare_create': (ctypes.c_int, [_P, _P, ctypes.POINTER(_P)]),
     'frz_rideshare_destroy': (None, [_P]),
     'frz_rideshare_arena_bytes': (ctypes.c_int64, [_P]),

@@ -57,6 +57,9 @@ struct CyLaunch {
     int32_t B, N, Att, D, A;
     uint32_t ticketed;
     int64_t off_rows1, off_epoch, off_totals;
+    // fused uniform random policy (frz_cybersecurity_step_random_policy): the actions are sampled in the step launch itself
+    uint32_t policy, policy_seed_lo, policy_seed_hi, policy_step_lo, policy_step_hi;
+    int32_t* actions_out;
 };
 
 template <typename T>
@@ -142,9 +145,14 @@ __global__ void __launch_bounds__(kBlock) cy_step_kernel(char* __restrict__ aren
     float r_net_in[NMAX], r_agent_in[AMAX];
     if (MODE == kStep) {
         nm = at32(rows, (uint32_t)r_moves * Bu + bl);
-        if (RNG == FRZ_RNG_PHILOX) seed = (uint32_t)at32(rows, (uint32_t)r_seeds * Bu + bl);
+        if (RNG == FRZ_RNG_PHILOX || L.policy) seed = (uint32_t)at32(rows, (uint32_t)r_seeds * Bu + bl);
+        if (!L.policy) {
 #pragma unroll
-        for (int a = 0; a < AMAX; ++a) act_in[a] = reinterpret_cast<const int2*>(actions)[(int64_t)min(a, A - 1) * B + bl];
+            for (int a = 0; a < AMAX; ++a) act_in[a] = reinterpret_cast<const int2*>(actions)[(int64_t)min(a, A - 1) * B + bl];
+        } else {
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a) act_in[a] = make_int2(0, -1);
+        }
         // cumulative rewards (row block r_cum = r_moves + 1 + A, frz_cybersecurity_create): read here, added and stored at the end
 #pragma unroll
         for (int a = 0; a < AMAX; ++a) cum_in[a] = at32(rowsf, (uint32_t)(r_moves + 1 + A + min(a, A - 1)) * Bu + bl);
@@ -211,6 +219,32 @@ __global__ void __launch_bounds__(kBlock) cy_step_kernel(char* __restrict__ aren
         uint32_t err = 0;
 
         if (MODE == kStep) {
+            if (L.policy) {
+                // uniform member of each agent's OneOf action space, the stream of cy_policy_kernel / frz_cybersecurity_random_policy:
+                // word 0 of Philox(counter (agent, 0, step lo, step hi), key (seed lo ^ env seed, seed hi)); the agent's task count is
+                // what the previous launch published (N while present, everything with show_bad_actions)
+#pragma unroll
+                for (int a = 0; a < AMAX; ++a) {
+                    if (a < A) {
+                        const int n = (flags & kShowBad) ? N : (pres[a] ? N : 0);
+                        int tail1 = -3, nt = 1;
+                        if (a >= Att && n > 0) {
+                            int home_loc = 0;
+#pragma unroll
+                            for (int k = 0; k < AMAX; ++k) home_loc = (a == Att + k) ? loc[k] : home_loc;
+                            const bool patchable = (flags & kShowBad) || home_loc != -1;
+                            tail1 = patchable ? -2 : -3;
+                            nt = patchable ? 3 : 2;
+                        }
+                        const frz::Philox4 w = frz::philox4x32_10((uint32_t)a, 0u, L.policy_step_lo, L.policy_step_hi, L.policy_seed_lo ^ seed,
+                                                                   L.policy_seed_hi);
+                        const int j = (int)(((uint64_t)w.w[0] * (uint64_t)(n + nt)) >> 32);
+                        const int value = j < n ? 0 : (j - n == 0 ? -1 : (j - n == 1 ? tail1 : -3));
+                        act_in[a] = make_int2(j, value);
+                        if (active) reinterpret_cast<int2*>(L.actions_out)[(int64_t)a * B + b] = act_in[a];
+                    }
+                }
+            }
             // ---------------------------------------------------------------------------------- randomness
             float r_net[NMAX], r_agent[AMAX];
             if (RNG == FRZ_RNG_INJECTED) {
@@ -486,13 +520,20 @@ namespace {
 
 int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
+struct Policy {  // fused uniform random policy of a step launch
+    bool on = false;
+    uint64_t seed = 0, step = 0;
+    int32_t* actions_out = nullptr;
+};
+
 template <int NMAX, int AMAX>
 void launch_variant(frz_cybersecurity_env* env, const int32_t* actions, const float* nr, const float* ar, int rng, int mode,
-                    hipStream_t stream) {
+                    hipStream_t stream, const Policy& policy) {
     const CyDev* dev = reinterpret_cast<const CyDev*>(env->arena);
     const dim3 grid(env->dev.nchunks), block(kBlock);
     const CyDev& p = env->dev;
-    const CyLaunch L{p.B, p.N, p.Att, p.D, p.A, env->ticketed ? 1u : 0u, p.off_rows1, p.off_epoch, p.off_totals};
+    const CyLaunch L{p.B, p.N, p.Att, p.D, p.A, env->ticketed ? 1u : 0u, p.off_rows1, p.off_epoch, p.off_totals, policy.on ? 1u : 0u,
+                     (uint32_t)policy.seed, (uint32_t)(policy.seed >> 32), (uint32_t)policy.step, (uint32_t)(policy.step >> 32), policy.actions_out};
     if (mode == kRebuild)
         hipLaunchKernelGGL((cy_step_kernel<NMAX, AMAX, FRZ_RNG_INJECTED, kRebuild>), grid, block, 0, stream, env->arena, dev, actions, nr, ar, L);
     else if (rng == FRZ_RNG_PHILOX)
@@ -501,11 +542,12 @@ void launch_variant(frz_cybersecurity_env* env, const int32_t* actions, const fl
         hipLaunchKernelGGL((cy_step_kernel<NMAX, AMAX, FRZ_RNG_INJECTED, kStep>), grid, block, 0, stream, env->arena, dev, actions, nr, ar, L);
 }
 
-int launch(frz_cybersecurity_env* env, const int32_t* actions, const float* nr, const float* ar, int rng, int mode, hipStream_t stream) {
+int launch(frz_cybersecurity_env* env, const int32_t* actions, const float* nr, const float* ar, int rng, int mode, hipStream_t stream,
+           const Policy& policy = Policy()) {
     switch (env->variant) {
-        case 0: launch_variant<4, 4>(env, actions, nr, ar, rng, mode, stream); break;
-        case 1: launch_variant<8, 8>(env, actions, nr, ar, rng, mode, stream); break;
-        default: launch_variant<16, 16>(env, actions, nr, ar, rng, mode, stream); break;
+        case 0: launch_variant<4, 4>(env, actions, nr, ar, rng, mode, stream, policy); break;
+        case 1: launch_variant<8, 8>(env, actions, nr, ar, rng, mode, stream, policy); break;
+        default: launch_variant<16, 16>(env, actions, nr, ar, rng, mode, stream, policy); break;
     }
     return hipGetLastError() == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;
 }
@@ -708,8 +750,24 @@ int frz_cybersecurity_reset(frz_cybersecurity_env* env, void* stream) {
 int frz_mt19937_generate_pair(uint32_t* mt_state, int32_t* mt_index, float* out, int64_t events, int64_t count, float* out2, int64_t events2,
                               int64_t count2, int64_t B, void* stream);
 
+static int step_impl(frz_cybersecurity_env* env, const int32_t* actions, int rng_mode, const float* network_randomness,
+                     const float* agent_randomness, void* stream, const Policy& policy);
+
 int frz_cybersecurity_step(frz_cybersecurity_env* env, const int32_t* actions, int rng_mode, const float* network_randomness,
                            const float* agent_randomness, void* stream) {
+    return step_impl(env, actions, rng_mode, network_randomness, agent_randomness, stream, Policy());
+}
+
+int frz_cybersecurity_step_random_policy(frz_cybersecurity_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out,
+                                         int rng_mode, const float* network_randomness, const float* agent_randomness, void* stream) {
+    if (!actions_out) return FRZ_E_INVALID;
+    Policy policy;
+    policy.on = true, policy.seed = policy_seed, policy.step = policy_step, policy.actions_out = actions_out;
+    return step_impl(env, actions_out, rng_mode, network_randomness, agent_randomness, stream, policy);
+}
+
+static int step_impl(frz_cybersecurity_env* env, const int32_t* actions, int rng_mode, const float* network_randomness,
+                     const float* agent_randomness, void* stream, const Policy& policy) {
     if (!env || !actions) return FRZ_E_INVALID;
     if (!env->arena) return FRZ_E_UNBOUND;
     if (!env->was_reset) return FRZ_E_INVALID;
@@ -730,7 +788,7 @@ int frz_cybersecurity_step(frz_cybersecurity_env* env, const int32_t* actions, i
     } else if (rng_mode != FRZ_RNG_PHILOX) {
         return FRZ_E_INVALID;
     }
-    return launch(env, actions, network_randomness, agent_randomness, rng_mode, kStep, static_cast<hipStream_t>(stream));
+    return launch(env, actions, network_randomness, agent_randomness, rng_mode, kStep, static_cast<hipStream_t>(stream), policy);
 }
 
 int frz_cybersecurity_random_policy(frz_cybersecurity_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out,

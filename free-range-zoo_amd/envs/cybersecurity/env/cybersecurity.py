@@ -263,8 +263,31 @@ class raw_env(BatchedParallelEnv):
         return out
 
     @torch.no_grad()
+    def step_random_policy(self, policy_seed: int, policy_step: int):
+        """``random_policy_actions`` + ``step`` as one launch (same results as the two calls); the sampled actions are left in
+        ``self.actions`` (not on a step taken after every env has finished, which is a no-op)."""
+        if not self._has_reset:
+            raise RuntimeError('reset() must be called before step_random_policy()')
+        logged = self._logs_this_step()
+        stream = stream_ptr(self.device)
+        if self.rng == 'mt19937':
+            if self.single_seeding or self.generator.buffer_size:
+                raise NotImplementedError('fused rollouts need the per-env device streams (no single_seeding / buffer_size)')
+            self.generator._ensure_streams()
+            mode = _capi.FRZ_RNG_MT19937
+        else:
+            mode = _capi.FRZ_RNG_PHILOX
+        _capi.check(self._lib.frz_cybersecurity_step_random_policy(self._handle, policy_seed, policy_step, self._actions.data_ptr(), mode, None,
+                                                                   None, stream), 'frz_cybersecurity_step_random_policy')
+        self._publish()
+        self.infos = {agent: {} for agent in self.agents}
+        if logged:
+            self._log_environment()
+        return ({agent: self.observations[agent] for agent in self.agents}, self.rewards, self.terminations, self.truncations, self.infos)
+
+    @torch.no_grad()
     def capture_random_rollout(self, steps: int, policy_seed: int = 0, include_reset: bool = True) -> 'torch.cuda.CUDAGraph':
-        """``[reset] + steps x (device random policy -> fused step)`` as one HIP graph (see the wildfire env)."""
+        """``[reset] + steps x (step with the random policy sampled in the launch)`` as one HIP graph (see the wildfire env)."""
         if not self._has_reset:
             raise RuntimeError('reset() must be called once before capturing a rollout')
         lib, handle, actions = self._lib, self._handle, self._actions.data_ptr()
@@ -282,8 +305,8 @@ class raw_env(BatchedParallelEnv):
                                                      stream), 'frz_mt19937_seed')
                 _capi.check(lib.frz_cybersecurity_reset(handle, stream), 'frz_cybersecurity_reset')
             for t in range(steps):
-                _capi.check(lib.frz_cybersecurity_random_policy(handle, policy_seed, t, actions, stream), 'frz_cybersecurity_random_policy')
-                _capi.check(lib.frz_cybersecurity_step(handle, actions, mode, None, None, stream), 'frz_cybersecurity_step')
+                _capi.check(lib.frz_cybersecurity_step_random_policy(handle, policy_seed, t, actions, mode, None, None, stream),
+                            'frz_cybersecurity_step_random_policy')
         return graph
 
     # ------------------------------------------------------------------------------------------------ spaces

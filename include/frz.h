@@ -353,6 +353,12 @@ int frz_cybersecurity_step(frz_cybersecurity_env* env, const int32_t* actions, i
  * Philox(counter (agent, 0, step, step >> 32), key (seed ^ seeds[b], seed >> 32)) */
 int frz_cybersecurity_random_policy(frz_cybersecurity_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out,
                                     void* stream);
+/* frz_cybersecurity_random_policy + frz_cybersecurity_step as ONE launch (same results as the two calls): the actions are sampled
+ * inside the step kernel from the state the launch starts with and left in actions_out (int32 [A][B][2]; not written once every env
+ * is finished, when the step is a no-op).  A random rollout = the reference's `env.step({a: action_space(a).sample_nested()})` loop
+ * (baselines/random.py:20) without a second launch per step. */
+int frz_cybersecurity_step_random_policy(frz_cybersecurity_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out,
+                                         int rng_mode, const float* network_randomness, const float* agent_randomness, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Rideshare  (reference: free_range_zoo/envs/rideshare/env/rideshare.py, transitions/,

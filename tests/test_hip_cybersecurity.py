@@ -184,3 +184,48 @@ def test_action_space_members():
             actions[agent] = sample
         env.step(actions)
     env.check()
+
+
+@pytest.mark.parametrize('rng', ['philox', 'mt19937'])
+@pytest.mark.parametrize('build,kwargs', [(configs.cyber_openness, {}), (configs.cyber_rich, dict(show_bad_actions=False)),
+                                          (lambda: configs.cyber_grid(12, 5, 7), dict(partially_observable=False))])
+def test_fused_random_policy_step_equals_policy_then_step(rng, build, kwargs):
+    """frz_cybersecurity_step_random_policy (policy sampled inside the step launch) == random_policy_actions() + step(): same
+    actions, state, rewards and observations, every step of an episode that runs into the all-finished early-out."""
+    B = 1500
+    two, one = (make_env(build, B, 9, rng=rng, **kwargs) for _ in range(2))
+    for env in (two, one):
+        env.reset(seed=torch.arange(B, dtype=torch.int32) + 3)
+    for t in range(12):
+        live = not bool(two.finished.all())
+        acts = two.random_policy_actions(policy_seed=77, policy_step=t).clone()
+        two.step(acts)
+        one.step_random_policy(policy_seed=77, policy_step=t)
+        if live:  # a frozen step does not write the sampled actions
+            assert torch.equal(one._actions, acts), f'step {t}: actions'
+        a, b = hip_snapshot(two), hip_snapshot(one)
+        for key in a:
+            G.assert_same(b[key], a[key], f'step {t} {key}')
+        for agent in two.agents:
+            assert torch.equal(two.rewards[agent], one.rewards[agent]) and torch.equal(two.truncations[agent], one.truncations[agent])
+            assert torch.equal(two.observations[agent]['tasks'], one.observations[agent]['tasks'])
+            assert torch.equal(two.observations[agent]['self'], one.observations[agent]['self'])
+    two.check(), one.check()
+
+
+def test_graph_replayed_rollout_equals_eager_rollout():
+    B = 2000
+    eager, replay = (make_env(configs.cyber_openness, B, 15, rng='philox') for _ in range(2))
+    seed = torch.arange(B, dtype=torch.int32) + 11
+    eager.reset(seed=seed), replay.reset(seed=seed)
+    graph = replay.capture_random_rollout(15, policy_seed=5, include_reset=True)
+    graph.replay()
+    eager.reset(seed=seed)
+    for t in range(15):
+        eager.step_random_policy(policy_seed=5, policy_step=t)
+    torch.cuda.synchronize()
+    replay._publish()  # the replay wrote the persistent buffers behind Python's back: refresh the exact-shape views
+    a, b = hip_snapshot(eager), hip_snapshot(replay)
+    for key in a:
+        G.assert_same(b[key], a[key], key)
+    assert torch.equal(eager._cumulative, replay._cumulative) and torch.equal(eager._actions, replay._actions)

@@ -33,5 +33,18 @@ for B in [int(x) for x in sys.argv[1:]] or [65536]:
             torch.cuda.synchronize()
             ts = [a[1].elapsed_time(a[2]) * 1e3 for a in ev]
         env.check()
-        print(f'{name:14s} B={B:7d} step us: first={ts[0]:6.1f} median={np.median(ts):6.1f} last={ts[-1]:6.1f} min={np.min(ts):6.1f}', flush=True)
+        tp = [a[0].elapsed_time(a[1]) * 1e3 for a in ev]
+        line = f'{name:14s} B={B:7d} step us: first={ts[0]:6.1f} median={np.median(ts):6.1f} last={ts[-1]:6.1f} min={np.min(ts):6.1f}  policy us median={np.median(tp):5.1f}'
+        if name == 'cybersecurity':  # the step with the policy sampled in the launch
+            env.reset(seed=torch.arange(B, dtype=torch.int32))
+            torch.cuda.synchronize(); torch.cuda._sleep(int(2.0e9 * 0.02))
+            ev = []
+            for t in range(45):
+                e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                e[0].record(); lib.frz_cybersecurity_step_random_policy(h, 1, t, acts, _capi.FRZ_RNG_PHILOX, None, None, s)
+                e[1].record(); ev.append(e)
+            torch.cuda.synchronize()
+            tf = [a[0].elapsed_time(a[1]) * 1e3 for a in ev]
+            line += f'  fused policy+step us median={np.median(tf):6.1f}'
+        print(line, flush=True)
         del env
