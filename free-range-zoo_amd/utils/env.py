@@ -186,3 +186,7 @@ class BatchedParallelEnv:
         """Drain the logging tap (every row handed over so far reaches its file)."""
         if self.logger is not None:
             self.logger.close()
+
+
+# The reference's base class name (utils/env.py:18): one class plays the AEC env and the parallel adapter here.
+BatchedAECEnv = BatchedParallelEnv

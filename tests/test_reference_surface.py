@@ -1,0 +1,118 @@
+"""Drop-in surface check against the reference's SOURCE TEXT (no import): configuration dataclasses carry the same field names,
+the env base class takes the same constructor keywords, the baselines / wrappers packages export the same class names.
+
+Runs only where /root/reference exists (the build container); parses the files with ``ast`` — nothing of the reference is executed
+or copied.  Skipped elsewhere (the GPU box has no reference tree)."""
+import ast
+import importlib
+import inspect
+import os
+
+import pytest
+
+REF = '/root/reference/free_range_zoo'
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason='reference tree not present')
+
+
+def _tree(relative):
+    with open(os.path.join(REF, relative)) as handle:
+        return ast.parse(handle.read())
+
+
+def _dataclass_fields(tree):
+    """{class name: [annotated field names]} for every class of a module (dataclass fields are the annotated assignments)."""
+    out = {}
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef):
+            out[node.name] = [stmt.target.id for stmt in node.body if isinstance(stmt, ast.AnnAssign) and isinstance(stmt.target, ast.Name)]
+    return out
+
+
+def _function_args(tree, class_name, function_name):
+    for node in ast.walk(tree):
+        if isinstance(node, ast.ClassDef) and node.name == class_name:
+            for stmt in node.body:
+                if isinstance(stmt, ast.FunctionDef) and stmt.name == function_name:
+                    names = [a.arg for a in stmt.args.args + stmt.args.kwonlyargs]
+                    return [n for n in names if n != 'self']
+    raise AssertionError(f'{class_name}.{function_name} not found')
+
+
+@pytest.mark.parametrize('domain', ['wildfire', 'rideshare', 'cybersecurity'])
+def test_configuration_dataclasses_have_the_reference_fields(domain):
+    reference = _dataclass_fields(_tree(f'envs/{domain}/env/structures/configuration.py'))
+    mine = importlib.import_module(f'free_range_zoo_amd.envs.{domain}.env.structures.configuration')
+    checked = 0
+    for name, fields in reference.items():
+        if not name.endswith('Configuration') or not fields:
+            continue
+        cls = getattr(mine, name, None)
+        assert cls is not None, f'{domain}: {name} is missing'
+        own = list(getattr(cls, '__dataclass_fields__', {}))
+        assert own == fields, f'{domain}.{name}: fields {own} != reference {fields}'
+        checked += 1
+    assert checked >= 4
+
+
+@pytest.mark.parametrize('domain', ['wildfire', 'rideshare', 'cybersecurity'])
+def test_state_dataclasses_have_the_reference_fields(domain):
+    reference = _dataclass_fields(_tree(f'envs/{domain}/env/structures/state.py'))
+    mine = importlib.import_module(f'free_range_zoo_amd.envs.{domain}.env.structures.state')
+    for name, fields in reference.items():
+        if name.endswith('State') and fields:
+            own = list(getattr(getattr(mine, name), '__dataclass_fields__', {}))
+            assert own == fields, f'{domain}.{name}: fields {own} != reference {fields}'
+
+
+def test_env_constructor_keywords_cover_the_reference():
+    reference = _function_args(_tree('utils/env.py'), 'BatchedAECEnv', '__init__')
+    from free_range_zoo_amd.utils.env import BatchedAECEnv as BatchedEnv
+    own = list(inspect.signature(BatchedEnv.__init__).parameters)
+    for name in reference:
+        assert name in own, f'constructor keyword {name} of the reference env is not accepted'
+    for domain, extra in (('wildfire', ['observe_other_suppressant', 'observe_other_power', 'show_bad_actions']),
+                          ('cybersecurity', ['observe_other_location', 'observe_other_presence', 'observe_other_power', 'partially_observable',
+                                             'show_bad_actions'])):
+        args = _function_args(_tree(f'envs/{domain}/env/{domain}.py'), 'raw_env', '__init__')
+        for name in extra:
+            assert name in args, f'{domain}: the reference constructor no longer takes {name}?'
+        module = importlib.import_module(f'free_range_zoo_amd.envs.{domain}.env.{domain}')
+        mine = list(inspect.signature(module.raw_env.__init__).parameters)
+        for name in args:
+            assert name in mine or 'kwargs' in mine, f'{domain}: constructor keyword {name} is not accepted'
+
+
+def test_env_methods_of_the_reference_exist():
+    from free_range_zoo_amd.envs import cybersecurity_v0, rideshare_v0, wildfire_v0
+    for module in (wildfire_v0, rideshare_v0, cybersecurity_v0):
+        for name in ('reset', 'reset_batches', 'step', 'observe', 'state', 'action_space', 'observation_space', 'close'):
+            assert callable(getattr(module.raw_env, name, None)), f'{module.__name__}.raw_env.{name}'
+        for name in ('finished', 'terminated', 'truncated', 'num_agents', 'max_num_agents'):
+            assert isinstance(getattr(module.raw_env, name, None), property), f'{module.__name__}.raw_env.{name}'
+        assert callable(module.parallel_env) and callable(module.env)
+
+
+@pytest.mark.parametrize('domain', ['wildfire', 'rideshare', 'cybersecurity'])
+def test_baseline_packages_export_the_reference_classes(domain):
+    tree = _tree(f'envs/{domain}/baselines/__init__.py')
+    names = [alias.asname or alias.name for node in tree.body if isinstance(node, ast.ImportFrom) for alias in node.names]
+    mine = importlib.import_module(f'free_range_zoo_amd.envs.{domain}.baselines')
+    assert names, domain
+    for name in names:
+        cls = getattr(mine, name, None)
+        assert inspect.isclass(cls), f'{domain}.baselines.{name} is missing'
+        assert callable(getattr(cls, 'act', None)) and callable(getattr(cls, 'observe', None))
+
+
+def test_random_generator_and_agent_interfaces():
+    reference = _tree('utils/random_generator.py')
+    from free_range_zoo_amd.utils.random_generator import RandomGenerator
+    for method in ('seed', 'generate'):
+        args = _function_args(reference, 'RandomGenerator', method)
+        own = list(inspect.signature(getattr(RandomGenerator, method)).parameters)
+        for name in args:
+            assert name in own, f'RandomGenerator.{method}({name}) missing'
+    assert _function_args(reference, 'RandomGenerator', '__init__') == [p for p in inspect.signature(RandomGenerator.__init__).parameters if p != 'self']
+    agent = _function_args(_tree('utils/agent.py'), 'Agent', '__init__')
+    from free_range_zoo_amd.utils.agent import Agent
+    assert agent == [p for p in inspect.signature(Agent.__init__).parameters if p != 'self']
