@@ -100,3 +100,52 @@ class BatchedOneOfSpace:
             tail_value = tail_values[k.clamp(max=len(self.tail) - 1)]
         value = torch.where(is_task, task_value, tail_value)
         return torch.stack([member, value], dim=1).to(torch.int32)
+
+    @torch.no_grad()
+    def invalid_actions(self, actions: torch.Tensor, allow_flexible_task_tags: bool = True) -> torch.Tensor:
+        """Which envs' ``[task_channel, action_channel]`` pairs the reference's validator rejects
+        (wrappers/space_validator.py:47-83), as a bool ``[B]`` tensor computed on the actions' device.  As written there:
+        a negative action channel, with ``allow_flexible_task_tags``, only has to equal the start of SOME member of the env's
+        space; otherwise the task channel indexes the member list like a Python list (negative indices count from the end,
+        out of range is invalid) and the action channel must lie in ``[start, start + n]`` of that member (inclusive upper end)."""
+        actions = actions.to(torch.int64)
+        device = actions.device
+        counts = self.task_counts.to(device=device, dtype=torch.int64)
+        B = counts.shape[0]
+        task, act = actions[:, 0], actions[:, 1]
+        tail_values = torch.tensor(self.tail, dtype=torch.int64, device=device)
+        T = len(self.tail)
+        mask = self.tail_mask.to(device) if self.tail_mask is not None else torch.ones((B, T), dtype=torch.bool, device=device)
+        n_tail = mask.sum(dim=1).to(torch.int64)
+        total = counts + n_tail
+        starts = None
+        if self.task_starts is not None and self.task_starts.shape[1] > 0:
+            starts = self.task_starts.to(device=device, dtype=torch.int64)
+
+        # member lookup: index like a Python list
+        index = torch.where(task < 0, task + total, task)
+        in_range = (task >= -total) & (task < total)
+        safe = index.clamp(min=0)
+        is_task = safe < counts
+        if starts is not None:
+            task_start = starts.gather(1, safe.clamp(max=starts.shape[1] - 1).unsqueeze(1)).squeeze(1)
+        else:
+            task_start = torch.zeros_like(safe)
+        k = (safe - counts).clamp(min=0)
+        order = torch.cumsum(mask.to(torch.int64), dim=1) - 1
+        pick = ((order == k.unsqueeze(1)) & mask).to(torch.int64).argmax(dim=1) if T > 0 else torch.zeros_like(k)
+        tail_start = tail_values[pick] if T > 0 else torch.zeros_like(k)
+        start = torch.where(is_task, task_start, tail_start)
+        by_member = ~in_range | (act < start) | (act > start + 1)
+
+        if not allow_flexible_task_tags:
+            return by_member
+        # flexible: a negative action channel matches any member's start (task starts included)
+        matches_tail = ((act.unsqueeze(1) == tail_values.unsqueeze(0)) & mask).any(dim=1) if T > 0 else torch.zeros(B, dtype=torch.bool, device=device)
+        if starts is not None:
+            live = torch.arange(starts.shape[1], device=device).unsqueeze(0) < counts.unsqueeze(1)
+            matches_task = ((act.unsqueeze(1) == starts) & live).any(dim=1)
+        else:
+            matches_task = (act == 0) & (counts > 0)
+        flexible = act < 0
+        return torch.where(flexible, ~(matches_tail | matches_task), by_member)

@@ -309,3 +309,29 @@ def test_cyber_baselines_drive_a_rollout_through_the_action_task_wrapper(oracle)
                 assert np.array_equal(agent.target_node.cpu().numpy(), shadow[name][0]), f'{name} step {t}: target'
         observations, rewards, terminations, truncations, infos = env.step(actions)
     env.check()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# action space validator wrapper (wrappers/space_validator.py)
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('domain', ['wildfire', 'rideshare', 'cybersecurity'])
+def test_space_validator_wrapper_accepts_members_and_rejects_the_rest(domain):
+    from free_range_zoo_amd.envs import cybersecurity_v0, rideshare_v0, wildfire_v0
+    from free_range_zoo_amd.wrappers import space_validator_wrapper_v0
+    module, configuration = {'wildfire': (wildfire_v0, configs.wildfire_rich()), 'rideshare': (rideshare_v0, configs.rideshare_busy(A=4, steps=12)),
+                             'cybersecurity': (cybersecurity_v0, configs.cyber_rich())}[domain]
+    B = 500
+    env = space_validator_wrapper_v0(module.parallel_env(configuration=configuration, parallel_envs=B, max_steps=20, device=torch.device('cuda')))
+    env.reset(seed=torch.arange(B, dtype=torch.int32))
+    for t in range(6):  # members of the spaces always pass, and the env agrees (no error flags)
+        env.step({agent: env.action_space(agent).sample_nested() for agent in env.agents})
+    env.check()
+    actions = {agent: env.action_space(agent).sample_nested() for agent in env.agents}
+    victim = env.agents[-1]
+    actions[victim] = actions[victim].clone()
+    actions[victim][B // 2] = torch.tensor([0, 7], dtype=torch.int32)  # no member has the value 7
+    with pytest.raises(IndexError, match=f'{victim} in batch {B // 2}'):
+        env.step(actions)
+    actions[victim][B // 2] = torch.tensor([10 ** 6, 0], dtype=torch.int32)  # no such member
+    with pytest.raises(IndexError):
+        env.step(actions)

@@ -54,3 +54,43 @@ def test_checkpoint_round_trip():
     assert torch.equal(s.intensity[0], snapshot.intensity[0]) and not torch.equal(s.intensity[1:], snapshot.intensity[1:])
     s.restore_from_checkpoint()
     assert torch.equal(s.intensity, snapshot.intensity) and torch.equal(s.equipment, snapshot.equipment)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# action space validator (wrappers/space_validator.py): the vectorised verdict equals the reference's per-env rule
+# ------------------------------------------------------------------------------------------------------------------
+def _reference_rule(space, task_channel, action_channel, allow_flexible):
+    """wrappers/space_validator.py:52-81 restated on a materialised OneOf: True = the validator raises IndexError."""
+    if action_channel < 0 and allow_flexible:
+        return not any(action_channel == sub.start for sub in reversed(space.spaces))
+    try:
+        discrete = space.spaces[task_channel]
+    except IndexError:
+        return True
+    return action_channel < discrete.start or action_channel > discrete.start + discrete.n
+
+
+@pytest.mark.parametrize('kind', ['wildfire', 'rideshare', 'cyber_defender'])
+@pytest.mark.parametrize('allow_flexible', [True, False])
+def test_invalid_actions_matches_the_reference_validator_rule(kind, allow_flexible):
+    import numpy as np
+    from free_range_zoo_amd.utils.spaces import BatchedOneOfSpace
+    rng = np.random.default_rng(3)
+    B = 400
+    counts = torch.from_numpy(rng.integers(0, 5, B))
+    if kind == 'wildfire':
+        space = BatchedOneOfSpace(counts, tail=[-1])
+    elif kind == 'rideshare':
+        space = BatchedOneOfSpace(counts, tail=[-1], task_starts=torch.from_numpy(rng.integers(0, 3, (B, 4))))
+    else:
+        mask = torch.from_numpy(rng.random((B, 3)) < 0.7)
+        mask[:, 0] = True  # noop always exists
+        space = BatchedOneOfSpace(counts, tail=[-1, -2, -3], tail_mask=mask)
+    actions = torch.from_numpy(np.stack([rng.integers(-7, 7, B), rng.integers(-4, 4, B)], axis=1)).to(torch.int32)
+    got = space.invalid_actions(actions, allow_flexible).tolist()
+    spaces = space.spaces
+    want = [_reference_rule(spaces[b], int(actions[b, 0]), int(actions[b, 1]), allow_flexible) for b in range(B)]
+    assert got == want
+    assert 0.1 < sum(want) / B < 0.95  # both verdicts occur
+    sampled = space.sample_nested()
+    assert not space.invalid_actions(sampled, allow_flexible).any()  # members of the space always pass
