@@ -60,6 +60,7 @@ struct CyLaunch {
     // fused uniform random policy (frz_cybersecurity_step_random_policy): the actions are sampled in the step launch itself
     uint32_t policy, policy_seed_lo, policy_seed_hi, policy_step_lo, policy_step_hi;
     int32_t* actions_out;
+    int64_t off_mt_state;  // FRZ_RNG_MT19937 inside the step: the per-env generator states, word j of env b at [j][b]
 };
 
 template <typename T>
@@ -139,13 +140,14 @@ __global__ void __launch_bounds__(kBlock) cy_step_kernel(char* __restrict__ aren
 #pragma unroll
     for (int a = 0; a < AMAX; ++a) pres_raw[a] = at32(rows1, (u_presence + (uint32_t)min(a, A - 1)) * Bu + bl);
     const uint32_t trunc_raw = at32(rows1, u_trunc * Bu + bl);
-    int nm = 0;
+    int nm = 0, mti = 0;
     uint32_t seed = 0;
     int2 act_in[AMAX];
     float r_net_in[NMAX], r_agent_in[AMAX];
     if (MODE == kStep) {
         nm = at32(rows, (uint32_t)r_moves * Bu + bl);
         if (RNG == FRZ_RNG_PHILOX || L.policy) seed = (uint32_t)at32(rows, (uint32_t)r_seeds * Bu + bl);
+        if (RNG == FRZ_RNG_MT19937) mti = at32(rows, (uint32_t)(r_seeds + 1) * Bu + bl);  // position of the env's MT19937 stream
         if (!L.policy) {
 #pragma unroll
             for (int a = 0; a < AMAX; ++a) act_in[a] = reinterpret_cast<const int2*>(actions)[(int64_t)min(a, A - 1) * B + bl];
@@ -252,6 +254,58 @@ __global__ void __launch_bounds__(kBlock) cy_step_kernel(char* __restrict__ aren
                 for (int n = 0; n < NMAX; ++n) r_net[n] = r_net_in[n];
 #pragma unroll
                 for (int a = 0; a < AMAX; ++a) r_agent[a] = r_agent_in[a];
+            } else if constexpr (RNG == FRZ_RNG_MT19937) {
+                // The env's own MT19937 stream (mt19937.hip: state word j of env b at [j][b], twisted lazily, one word per draw),
+                // bit-identical to the reference's per-env torch CPU generator: generate(B, 1, (N,)) then generate(B, 1, (A,))
+                // (cybersecurity.py:304-315), i.e. node n is draw n and agent a is draw N + a of the step's N + A consecutive floats.
+                // N + A <= 227, so no word read here is rewritten by this batch: every load is issued before the first use
+                // (wildfire_roles.hip has the same generator; a frozen step returns above and leaves the stream alone).
+                constexpr int U = NMAX + AMAX, kN = 624, kM = 397;
+                static_assert(U <= kN - kM, "a batch must not read a word it rewrites");
+                uint32_t* const mt = reinterpret_cast<uint32_t*>(arena + L.off_mt_state);
+                const int used = N + A;
+                uint32_t w[U + 1], far[U];
+#pragma unroll
+                for (int k = 0; k <= U; ++k) {
+                    int j = mti + k;
+                    j -= j >= kN ? kN : 0;
+                    w[k] = mt[(int64_t)j * B + bl];
+                }
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    int j = mti + k + kM;
+                    j -= j >= kN ? kN : 0;
+                    j -= j >= kN ? kN : 0;
+                    far[k] = mt[(int64_t)j * B + bl];
+                }
+                float uni[U];
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    const uint32_t y = (w[k] & 0x80000000u) | (w[k + 1] & 0x7fffffffu);
+                    uint32_t v = far[k] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                    int j = mti + k;
+                    j -= j >= kN ? kN : 0;
+                    if (active && k < used) mt[(int64_t)j * B + bl] = v;
+                    v ^= v >> 11;
+                    v ^= (v << 7) & 0x9d2c5680u;
+                    v ^= (v << 15) & 0xefc60000u;
+                    v ^= v >> 18;
+                    uni[k] = (float)(v & 0xFFFFFFu) * (1.0f / 16777216.0f);
+                }
+                if (active) {
+                    int j = mti + used;
+                    j -= j >= kN ? kN : 0;
+                    at32(rows, (uint32_t)(r_seeds + 1) * Bu + bl) = j;
+                }
+#pragma unroll
+                for (int n = 0; n < NMAX; ++n) r_net[n] = uni[n];
+#pragma unroll
+                for (int a = 0; a < AMAX; ++a) {
+                    float u = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < U; ++k) u = (k == N + a) ? uni[k] : u;
+                    r_agent[a] = u;
+                }
             } else {  // FRZ_RNG_PHILOX stream of include/frz.h
 #pragma unroll
                 for (int q = 0; q < (NMAX + 3) / 4; ++q) {
@@ -520,6 +574,10 @@ namespace {
 
 int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
+// variants whose step kernel advances the per-env MT19937 streams itself (the 16-node / 16-agent one stages its draws)
+template <int NMAX, int AMAX>
+constexpr bool kMtInKernel = NMAX + AMAX <= 16;
+
 struct Policy {  // fused uniform random policy of a step launch
     bool on = false;
     uint64_t seed = 0, step = 0;
@@ -533,11 +591,16 @@ void launch_variant(frz_cybersecurity_env* env, const int32_t* actions, const fl
     const dim3 grid(env->dev.nchunks), block(kBlock);
     const CyDev& p = env->dev;
     const CyLaunch L{p.B, p.N, p.Att, p.D, p.A, env->ticketed ? 1u : 0u, p.off_rows1, p.off_epoch, p.off_totals, policy.on ? 1u : 0u,
-                     (uint32_t)policy.seed, (uint32_t)(policy.seed >> 32), (uint32_t)policy.step, (uint32_t)(policy.step >> 32), policy.actions_out};
+                     (uint32_t)policy.seed, (uint32_t)(policy.seed >> 32), (uint32_t)policy.step, (uint32_t)(policy.step >> 32), policy.actions_out,
+                     p.off_mt_state};
     if (mode == kRebuild)
         hipLaunchKernelGGL((cy_step_kernel<NMAX, AMAX, FRZ_RNG_INJECTED, kRebuild>), grid, block, 0, stream, env->arena, dev, actions, nr, ar, L);
     else if (rng == FRZ_RNG_PHILOX)
         hipLaunchKernelGGL((cy_step_kernel<NMAX, AMAX, FRZ_RNG_PHILOX, kStep>), grid, block, 0, stream, env->arena, dev, actions, nr, ar, L);
+    else if (rng == FRZ_RNG_MT19937) {
+        if constexpr (kMtInKernel<NMAX, AMAX>)
+            hipLaunchKernelGGL((cy_step_kernel<NMAX, AMAX, FRZ_RNG_MT19937, kStep>), grid, block, 0, stream, env->arena, dev, actions, nr, ar, L);
+    }
     else
         hipLaunchKernelGGL((cy_step_kernel<NMAX, AMAX, FRZ_RNG_INJECTED, kStep>), grid, block, 0, stream, env->arena, dev, actions, nr, ar, L);
 }
@@ -774,7 +837,9 @@ static int step_impl(frz_cybersecurity_env* env, const int32_t* actions, int rng
     const CyDev& p = env->dev;
     if (rng_mode == FRZ_RNG_INJECTED) {
         if (!network_randomness || !agent_randomness) return FRZ_E_INVALID;
-    } else if (rng_mode == FRZ_RNG_MT19937) {  // network draws first, then agent draws (cybersecurity.py:304-315)
+    } else if (rng_mode == FRZ_RNG_MT19937 && env->variant < 2) {
+        // the step kernel advances the env's own stream (network draws first, then agent draws, cybersecurity.py:304-315)
+    } else if (rng_mode == FRZ_RNG_MT19937) {  // 16-node / 16-agent variant: the same draws staged in the arena by a generator launch
         const int64_t B = p.B;
         uint32_t* mt_state = at<uint32_t>(env->arena, p.off_mt_state);
         int32_t* mt_index = at<int32_t>(env->arena, p.off_rows4 + (int64_t)p.r_mti * B * 4);

@@ -230,7 +230,13 @@ class raw_env(BatchedParallelEnv):
                 self._actions.copy_(actions)
         stream = stream_ptr(self.device)
         B, N, A = self.parallel_envs, self._N, len(self.agents)
-        if randomness is not None or self.rng == 'mt19937':
+        fused_mt = (randomness is None and self.rng == 'mt19937' and not self.single_seeding and self.generator.buffer_size == 0)
+        if fused_mt:
+            # unbuffered per-env streams: the step launch advances the env's own MT19937 stream (same draws, same order as
+            # generator.generate(B, 1, (N,)) followed by generate(B, 1, (A,)), cybersecurity.py:304-315)
+            self.generator._ensure_streams()
+            rc = self._lib.frz_cybersecurity_step(self._handle, actions_ptr, _capi.FRZ_RNG_MT19937, None, None, stream)
+        elif randomness is not None or self.rng == 'mt19937':
             if randomness is None:  # cybersecurity.py:304-315
                 network = self.generator.generate(B, 1, (N, ), key='network')
                 agent = self.generator.generate(B, 1, (A, ), key='agent')

@@ -229,3 +229,26 @@ def test_graph_replayed_rollout_equals_eager_rollout():
     for key in a:
         G.assert_same(b[key], a[key], key)
     assert torch.equal(eager._cumulative, replay._cumulative) and torch.equal(eager._actions, replay._actions)
+
+
+@pytest.mark.parametrize('build,steps', [(configs.cyber_openness, 100), (configs.cyber_rich, 60), (lambda: configs.cyber_grid(12, 5, 7), 12)])
+def test_mt19937_streams_advanced_in_the_step_match_the_generator(oracle, build, steps):
+    """Default rng: the <4,4> and <8,8> step kernels advance the per-env MT19937 streams themselves (the 16-node one stages the
+    draws with a generator launch); same trajectory as the oracle fed from the oracle's MT19937, across the 624-word wrap."""
+    run_against_oracle(oracle, build, {}, 300, 200, steps, seed=51, rng='mt19937')
+
+
+def test_mt19937_stream_is_left_alone_by_frozen_steps(oracle):
+    """Once every env is truncated the reference returns before drawing (utils/env.py:211-213): the in-kernel streams agree with a
+    generator that stopped drawing at the last real step."""
+    B = 500
+    env = make_env(configs.cyber_openness, B, 5, rng='mt19937')
+    env.reset(seed=torch.arange(B, dtype=torch.int32))
+    for t in range(9):
+        env.step(env.random_policy_actions(policy_seed=1, policy_step=t))
+    N, A = env._N, len(env.agents)
+    mt_state, mt_index = oracle.mt19937_seed(np.arange(B, dtype=np.int32))
+    for t in range(5):
+        oracle.mt19937_generate(mt_state, mt_index, 1, N)
+        oracle.mt19937_generate(mt_state, mt_index, 1, A)
+    assert np.array_equal(np_(env._view(env._bufs.mt_index, (B, ), torch.int32)), mt_index)
