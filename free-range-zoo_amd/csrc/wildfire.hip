@@ -927,8 +927,8 @@ struct Variant {
     bool exact;
 };
 // the lane-per-env kernel unrolls its cell and agent loops to (CMAX, AMAX): a shape runs the smallest instantiation that holds it
-// (3x3 / 3x4 / 4x4 grids do not pay for the 24-cell one)
-constexpr Variant kVariants[] = {{6, 3, true}, {6, 2, true}, {8, 4, false}, {12, 4, false}, {16, 8, false}, {24, 8, false}, {64, 16, false}};
+// (3x3 / 3x4 / 4x4 grids do not pay for the 24-cell one); grids of <= 16 cells with <= 4 agents run the field/crew kernel by default
+constexpr Variant kVariants[] = {{6, 3, true}, {6, 2, true}, {8, 4, false}, {16, 4, false}, {16, 8, false}, {24, 8, false}, {64, 16, false}};
 constexpr int kNumVariants = 7;
 
 int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
@@ -972,7 +972,7 @@ int launch_lane(frz_wildfire_env* env, const WfArgs& args, int rng, int mode, hi
         case 0: launch_variant<6, 3, true>(args, grid, rng, mode, stream); break;   // BASELINE.json cfg1/cfg2 shape
         case 1: launch_variant<6, 2, true>(args, grid, rng, mode, stream); break;   // AAAI-2025 openness configs
         case 2: launch_variant<8, 4, false>(args, grid, rng, mode, stream); break;
-        case 3: launch_variant<12, 4, false>(args, grid, rng, mode, stream); break;
+        case 3: launch_variant<16, 4, false>(args, grid, rng, mode, stream); break;
         case 4: launch_variant<16, 8, false>(args, grid, rng, mode, stream); break;
         case 5: launch_variant<24, 8, false>(args, grid, rng, mode, stream); break;
         default: launch_variant<64, 16, false>(args, grid, rng, mode, stream); break;
@@ -1044,7 +1044,7 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
     // Kernel choice for grids of <= 8 cells: the field/crew wavefront-pair kernel (wildfire_roles.hip, two wavefronts per
     // 64 envs) or the lane-per-env kernel below; FRZ_WF_KERNEL=lane|roles overrides the default.
     const char* want = std::getenv("FRZ_WF_KERNEL");
-    const bool small = HW <= 8 && A <= 4;
+    const bool small = HW <= 16 && A <= 4;
     p.roles = small ? 1 : 0;
     if (want && std::strcmp(want, "lane") == 0) p.roles = 0;
     if (want && std::strcmp(want, "roles") == 0 && small) p.roles = 1;

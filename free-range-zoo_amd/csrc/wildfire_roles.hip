@@ -54,12 +54,14 @@ constexpr int kRound = 256;             // look-back window: a chunk sums at mos
 #endif
 
 template <int CMAX, int AMAX, bool EXACT, int RNG, int MODE>
-__global__ void __launch_bounds__(kRoleBlock, (RNG == FRZ_RNG_MT19937 ? 2 : 4)) wf_roles_kernel(char* __restrict__ arena, const WfDev* __restrict__ dev,
+__global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX > 8 || !EXACT) ? 2 : 4)) wf_roles_kernel(char* __restrict__ arena, const WfDev* __restrict__ dev,
                                                                const int32_t* __restrict__ actions, const float* __restrict__ field_rand,
                                                                const float* __restrict__ agent_rand, const WfLaunch launch) {
     const int32_t batch = launch.batch;
-    static_assert(CMAX <= 8 && AMAX <= 4, "cell masks travel between the roles as bytes");
+    static_assert(CMAX <= 16 && AMAX <= 4, "cell masks travel between the roles as 8- or 16-bit fields of one word");
     using mask_t = uint32_t;
+    constexpr int MB = CMAX <= 8 ? 8 : 16;                                  // bits of a cell mask in the exchange words
+    using pack_t = std::conditional_t<(CMAX <= 8), uint32_t, uint64_t>;     // burned | put_out | dead, and one mask per agent
     constexpr int PW = (AMAX + 1 + 3) / 4;                                // packed scan words (four 16-bit channels each)
     constexpr int NCHP = AMAX + 3 <= 8 ? 8 : (AMAX + 3 <= 16 ? 16 : 32);  // scan channels padded to a power of two
     constexpr bool kPhilox = RNG == FRZ_RNG_PHILOX && MODE == kStep;
@@ -74,9 +76,9 @@ __global__ void __launch_bounds__(kRoleBlock, (RNG == FRZ_RNG_MT19937 ? 2 : 4)) 
     __shared__ WfStaged s_cfg;  // hot scalars (copied to registers below) + the per-lane lookup tables (range sets, equipment, capacities)
     __shared__ float x_power[CMAX][kBlock];  // crew -> field: fire-fighting power applied to each cell
     __shared__ uint32_t x_lit[kBlock];       // field -> crew: lit cells after the transitions
-    __shared__ uint32_t x_fate[kBlock];      // field -> crew: burned | put_out << 8 | dead << 16
+    __shared__ pack_t x_fate[kBlock];        // field -> crew: burned | put_out << MB | dead << 2 MB
     __shared__ uint64_t x_excl[PW][kBlock];  // crew -> both: packed per-env counts of the preceding envs of the same wavefront
-    __shared__ uint32_t x_ok[kBlock];        // crew -> both: attackable cells of agent a in byte a (AMAX <= 4)
+    __shared__ pack_t x_ok[kBlock];          // crew -> both: attackable cells of agent a in field a (MB bits each, AMAX <= 4)
     __shared__ float x_supp[AMAX][kBlock];   // crew -> field: suppressant after the agent transitions (agent observations)
     __shared__ float x_draw[(kPhilox || kMt) ? 5 * AMAX : 1][kBlock];  // field -> crew: the step's agent draws (in-kernel RNG)
 
@@ -563,7 +565,7 @@ __global__ void __launch_bounds__(kRoleBlock, (RNG == FRZ_RNG_MT19937 ? 2 : 4)) 
             for (int c = 0; c < CMAX; ++c) lit1 |= (mask_t)(f[c] > 0) << c;
             lit1 = active ? lit1 : (mask_t)0;
             x_lit[slot] = lit1;
-            x_fate[slot] = burned | (put_out << 8) | ((uint32_t)dead << 16);
+            x_fate[slot] = (pack_t)burned | ((pack_t)put_out << MB) | ((pack_t)dead << (2 * MB));
             FRZ_RSTAMP(5);
             __syncthreads();  // (2) lit mask and fates visible to the crew
             FRZ_RSTAMP(6);
@@ -632,10 +634,10 @@ __global__ void __launch_bounds__(kRoleBlock, (RNG == FRZ_RNG_MT19937 ? 2 : 4)) 
             if (active) {
                 const Placement place = placement();
                 const int64_t off_f = channel_offset(place, 0);
-                const uint32_t oks = x_ok[slot];
+                const pack_t oks = x_ok[slot];
 #pragma unroll
                 for (int a = 1; a < AMAX; a += 2)  // odd agents' lists (the crew writes the even ones)
-                    if (a < A) emit_agent_lists(a, lit1, (mask_t)((oks >> (8 * a)) & 0xFFu), off_f, channel_offset(place, a + 1), b);
+                    if (a < A) emit_agent_lists(a, lit1, (mask_t)((oks >> (MB * a)) & (pack_t)((1u << MB) - 1u)), off_f, channel_offset(place, a + 1), b);
                 int64_t* const task_values = reinterpret_cast<int64_t*>(arena + d.off_task_values);
                 int64_t* const task_offsets = reinterpret_cast<int64_t*>(arena + d.off_task_offsets);
                 int64_t* const obs_map = reinterpret_cast<int64_t*>(arena + d.off_obs_map);
@@ -828,9 +830,9 @@ __global__ void __launch_bounds__(kRoleBlock, (RNG == FRZ_RNG_MT19937 ? 2 : 4)) 
 
             // ---- phase 3: open-task sets, per-env counts, wavefront scan
             const mask_t lit1 = x_lit[slot];
-            const uint32_t fate = x_fate[slot];
-            const mask_t burned = fate & 0xFFu, put_out = (fate >> 8) & 0xFFu;
-            const bool dead = ((fate >> 16) & 1u) != 0;
+            const pack_t fate = x_fate[slot];
+            const mask_t burned = (mask_t)(fate & (pack_t)((1u << MB) - 1u)), put_out = (mask_t)((fate >> MB) & (pack_t)((1u << MB) - 1u));
+            const bool dead = ((fate >> (2 * MB)) & 1u) != 0;
             bool term = term0, trunc = trunc0;
             if (MODE == kStep) {
                 const int nm = crw.nm + 1;
@@ -865,9 +867,9 @@ __global__ void __launch_bounds__(kRoleBlock, (RNG == FRZ_RNG_MT19937 ? 2 : 4)) 
 #pragma unroll
             for (int w = 0; w < PW; ++w) x_excl[w][slot] = incl[w] - packed[w];
             {
-                uint32_t oks = 0;
+                pack_t oks = 0;
 #pragma unroll
-                for (int a = 0; a < AMAX; ++a) oks |= ok1[a] << (8 * a);
+                for (int a = 0; a < AMAX; ++a) oks |= (pack_t)ok1[a] << (MB * a);
                 x_ok[slot] = oks;
             }
             FRZ_RSTAMP(7);
@@ -1046,7 +1048,7 @@ void launch_roles_variant(const WfArgs& a, const WfDev* dev, int grid, int rng, 
 
 }  // namespace
 
-// variant: 0 = (6 cells, 3 agents, exact), 1 = (6, 2, exact), 2 = (<= 8, <= 4); the caller has already staged the Philox
+// variant: 0 = (6 cells, 3 agents, exact), 1 = (6, 2, exact), 2 = (<= 8, <= 4), 3 = (<= 16, <= 4); the caller has already staged the Philox
 // draws for variant 2 (rng arrives as FRZ_RNG_INJECTED)
 int launch_roles(const WfArgs& args, int variant, int grid, int rng, int mode, hipStream_t stream) {
     const WfDev* dev = reinterpret_cast<const WfDev*>(args.arena);
@@ -1054,6 +1056,7 @@ int launch_roles(const WfArgs& args, int variant, int grid, int rng, int mode, h
         case 0: launch_roles_variant<6, 3, true>(args, dev, grid, rng, mode, stream); break;
         case 1: launch_roles_variant<6, 2, true>(args, dev, grid, rng, mode, stream); break;
         case 2: launch_roles_variant<8, 4, false>(args, dev, grid, rng, mode, stream); break;
+        case 3: launch_roles_variant<16, 4, false>(args, dev, grid, rng, mode, stream); break;
         default: return FRZ_E_INVALID;
     }
     return hipGetLastError() == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;

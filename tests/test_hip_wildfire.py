@@ -324,11 +324,12 @@ def test_timed_rollout_runs_the_same_steps():
         assert torch.equal(getattr(plain, name), getattr(timed, name)), name
 
 
-@pytest.mark.parametrize('shape,kernel', [((2, 4, 4), 'roles'), ((2, 4, 4), 'lane'), ((1, 7, 3), 'roles'), ((3, 3, 3), 'lane'), ((3, 4, 4), 'lane'),
+@pytest.mark.parametrize('shape,kernel', [((2, 4, 4), 'roles'), ((2, 4, 4), 'lane'), ((1, 7, 3), 'roles'), ((3, 3, 3), 'roles'), ((3, 3, 3), 'lane'),
+                                          ((3, 4, 4), 'roles'), ((4, 4, 4), 'roles'), ((4, 4, 2), 'lane'), ((2, 7, 1), 'roles'),
                                           ((4, 4, 6), 'lane'), ((2, 5, 7), 'lane'), ((8, 8, 12), 'lane'), ((5, 9, 16), 'lane')])
 def test_every_kernel_variant_matches_the_oracle(oracle, shape, kernel, monkeypatch):
-    """Grid shapes that select the runtime-shape variants: <8,4> (field/crew with staged draws, and lane), and the lane kernel's
-    <12,4>, <16,8>, <24,8> (wildfire_rich, 4x5, is the other user of it) and <64,16>."""
+    """Grid shapes that select the runtime-shape variants: <8,4> and <16,4> (field/crew with staged draws, and lane), and the lane
+    kernel's <16,8>, <24,8> (wildfire_rich, 4x5, is the other user of it) and <64,16>."""
     monkeypatch.setenv('FRZ_WF_KERNEL', kernel)
     H, Wd, A = shape
     build = lambda: configs.wildfire_grid(H, Wd, A)
