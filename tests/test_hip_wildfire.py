@@ -476,3 +476,23 @@ def test_graph_replayed_rollout_equals_eager_rollout(rng):
     total = int(eager._task_offsets[-1])
     assert torch.equal(eager._task_values[:total], graphed._task_values[:total])
     graphed.check()
+
+
+def test_env_from_a_configuration_pickled_by_the_reference():
+    """The reference distributes its competition configurations as pickles of its Configuration classes: such a file loads through
+    utils/compat.py and drives the env like the configuration built by hand."""
+    import os
+    from free_range_zoo_amd.utils.compat import load_reference_pickle
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_configuration_wildfire.pkl')
+    build, kwargs = configs.WILDFIRE_GOLDEN['rich_localized']
+    B = 500
+    loaded = make_env(lambda: load_reference_pickle(path), B, 20, rng='philox', **kwargs)
+    built = make_env(build, B, 20, rng='philox', **kwargs)
+    for env in (loaded, built):
+        env.reset(seed=torch.arange(B, dtype=torch.int32))
+        for t in range(10):
+            env.step_random_policy(policy_seed=4, policy_step=t) if hasattr(env, 'step_random_policy') else None
+    a, b = hip_snapshot(loaded), hip_snapshot(built)
+    for key in a:
+        G.assert_same(a[key], b[key], key)
+    loaded.check()

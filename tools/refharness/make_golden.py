@@ -875,7 +875,26 @@ def record_logs():
     print(path, {k: (len(out[k]), sum(len(t) for t in out[k])) for k in ('wildfire', 'cybersecurity', 'rideshare')})
 
 
-PARTS = {'ka': record_known_answers, 'baselines_wildfire': record_wildfire_baselines, 'baselines_rideshare': record_rideshare_baselines, 'baselines_cybersecurity': record_cyber_baselines, 'logs': record_logs, 'traj_wildfire': record_wildfire_trajectories, 'traj_cybersecurity': record_cyber_trajectories,
+
+# ----------------------------------------------------------------------------------------------------------
+# configurations pickled by the reference (how the reference distributes its competition configurations)
+# ----------------------------------------------------------------------------------------------------------
+def record_pickles():
+    """pickle.dumps of reference Configuration objects (one per domain): the bytes a user's `<configuration>.pkl` holds."""
+    import pickle
+    out = {
+        'wildfire': {x[0]: x for x in wildfire_variants()}['rich_localized'][1],
+        'cybersecurity': {x[0]: x for x in cyber_variants()}['rich'][1],
+        'rideshare': {x[0]: x for x in rideshare_variants()}['busy_waiting_costs'][1],
+    }
+    for domain, configuration in out.items():
+        path = os.path.join(GOLDEN, f'reference_configuration_{domain}.pkl')
+        with open(path, 'wb') as handle:
+            pickle.dump(configuration.to(torch.device('cpu')), handle)
+        print(path, os.path.getsize(path), 'bytes', type(configuration).__module__)
+
+
+PARTS = {'ka': record_known_answers, 'baselines_wildfire': record_wildfire_baselines, 'baselines_rideshare': record_rideshare_baselines, 'baselines_cybersecurity': record_cyber_baselines, 'logs': record_logs, 'pickles': record_pickles, 'traj_wildfire': record_wildfire_trajectories, 'traj_cybersecurity': record_cyber_trajectories,
          'traj_rideshare': record_rideshare_trajectories,
          'misc': record_misc}
 
