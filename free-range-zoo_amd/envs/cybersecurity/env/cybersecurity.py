@@ -31,6 +31,7 @@ def env(wrappers: List[Callable] = [], **kwargs) -> 'raw_env':
 
 class raw_env(BatchedParallelEnv):
     """Environment definition for the cybersecurity environment."""
+    _rebuild_symbol = 'frz_cybersecurity_rebuild'
 
     metadata = {'render.modes': ['human', 'rgb_array'], 'name': 'cybersecurity_v0', 'is_parallelizable': True, 'render_fps': 2,
                 'null_value': -100}

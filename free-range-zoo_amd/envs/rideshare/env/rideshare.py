@@ -31,6 +31,7 @@ def env(wrappers: List[Callable] = [], **kwargs) -> 'raw_env':
 
 class raw_env(BatchedParallelEnv):
     """Implementation of the dynamic rideshare environment."""
+    _rebuild_symbol = 'frz_rideshare_rebuild'
 
     metadata = {'render.modes': ['human', 'rgb_array'], 'name': 'rideshare_v0', 'is_parallelizable': True, 'render_fps': 2}
 

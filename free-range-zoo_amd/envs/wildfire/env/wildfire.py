@@ -33,6 +33,7 @@ def env(wrappers: List[Callable] = [], **kwargs) -> 'raw_env':
 
 class raw_env(BatchedParallelEnv):
     """Environment definition for the wildfire environment."""
+    _rebuild_symbol = 'frz_wildfire_rebuild'
 
     metadata = {'render.modes': ['human', 'rgb_array'], 'name': 'wildfire_v0', 'is_parallelizable': True, 'render_fps': 2}
 

@@ -161,6 +161,23 @@ class BatchedParallelEnv:
                                     finished=None if reset else self.finished, log_description=self.log_description,
                                     agents=self.possible_agents, extra=self._log_extra(reset), reset=reset)
 
+    # -- refreshing the published outputs after the state was edited in place (planning / search code) -----------------------------
+    _rebuild_symbol: Optional[str] = None  # set by the domain envs: the C-ABI entry that rebuilds task lists, observations, spaces
+
+    @torch.no_grad()
+    def update_observations(self) -> None:
+        """Rebuild observations, task lists and action mappings from the CURRENT state (the reference's hooks of the same names,
+        e.g. wildfire.py:584-700, called by code that edits ``env.state()`` between steps): one launch, then re-publish."""
+        if not self._has_reset:
+            raise RuntimeError('reset() must be called before update_observations()')
+        rebuild = getattr(self._lib, self._rebuild_symbol)
+        _capi.check(rebuild(self._handle, stream_ptr(self.device)), self._rebuild_symbol)
+        self._publish()
+
+    def update_actions(self) -> None:
+        """The same launch rebuilds both (update_observations + update_actions of the reference are one kernel here)."""
+        self.update_observations()
+
     def observe(self, agent: Optional[str] = None):
         """``observe(agent)`` (AEC, env.py:274-284) or ``observe()`` -> dict of all agents (adapter, conversions.py:101-108)."""
         if agent is None:

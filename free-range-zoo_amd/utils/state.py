@@ -126,6 +126,10 @@ class State(ABC):
             df[name] = str(value.tolist())
         return df
 
+    def unwrap(self) -> List['State']:
+        """Unwrap a set of batched states into one state per env (state.py:193-206)."""
+        return [self[index] for index in range(len(self))]
+
     def __len__(self) -> int:
         for name, value in self._tensor_fields():
             if name not in self._shared() and hasattr(value, 'shape'):

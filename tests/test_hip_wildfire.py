@@ -496,3 +496,27 @@ def test_env_from_a_configuration_pickled_by_the_reference():
     for key in a:
         G.assert_same(a[key], b[key], key)
     loaded.check()
+
+
+def test_update_observations_after_editing_the_state_in_place():
+    """Planning-style use: edit env.state() between steps, call update_observations() / update_actions() (the reference's hooks),
+    and the published task lists / observations / mappings are those of an env reset to that very state."""
+    B = 600
+    edited = make_env(configs.wildfire_rich, B, 30, rng='philox')
+    edited.reset(seed=torch.arange(B, dtype=torch.int32))
+    for t in range(4):
+        edited.step_random_policy(policy_seed=2, policy_step=t)
+    state = edited.state()
+    state.fires[::3] = state.fires[::3].abs()          # light every fire cell of every third env
+    state.intensity[::3] = torch.where(state.fires[::3] > 0, torch.ones_like(state.intensity[::3]), state.intensity[::3])
+    state.suppressants[1::4] = 0.0                      # empty tanks: no attackable task for those agents
+    edited.update_observations()
+    edited.update_actions()
+    fresh = make_env(configs.wildfire_rich, B, 30, rng='philox')
+    fresh.reset(seed=torch.arange(B, dtype=torch.int32), options={'initial_state': edited.state().clone()})
+    a, b = hip_snapshot(edited), hip_snapshot(fresh)
+    for key in ('fires', 'intensity', 'fuel', 'suppressants', 'env_task_count', 'agent_task_count', 'task_values', 'task_offsets'):
+        G.assert_same(a[key], b[key], key)
+    for k in [k for k in a if k.startswith(('act_map', 'obs_'))]:
+        G.assert_same(a[k], b[k], k)
+    assert int(a['env_task_count'][0]) > int(a['env_task_count'][1]) or int(a['env_task_count'][::3].sum()) > 0

@@ -94,3 +94,11 @@ def test_invalid_actions_matches_the_reference_validator_rule(kind, allow_flexib
     assert 0.1 < sum(want) / B < 0.95  # both verdicts occur
     sampled = space.sample_nested()
     assert not space.invalid_actions(sampled, allow_flexible).any()  # members of the space always pass
+
+
+def test_unwrap_gives_one_state_per_env():
+    state = CybersecurityState(network_state=torch.arange(6, dtype=torch.int32).reshape(3, 2), location=torch.zeros((3, 1), dtype=torch.int32),
+                               presence=torch.ones((3, 2), dtype=torch.bool))
+    parts = state.unwrap()
+    assert len(parts) == 3 and all(isinstance(p, CybersecurityState) for p in parts)
+    assert parts[2].network_state.reshape(-1).tolist() == [4, 5]
