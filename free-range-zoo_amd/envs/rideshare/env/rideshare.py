@@ -25,8 +25,11 @@ def parallel_env(wrappers: List[Callable] = [], **kwargs) -> 'raw_env':
     return env
 
 
-def env(wrappers: List[Callable] = [], **kwargs) -> 'raw_env':
-    return parallel_env(wrappers, **kwargs)
+def env(wrappers: List[Callable] = [], **kwargs) -> 'BatchedAECView':
+    """AEC constructor of the reference (rideshare.py): agents act one after the other (``agent_selection`` / ``step`` / ``last``), the
+    simulation steps — one launch — when the last one has acted (utils/aec.py)."""
+    from free_range_zoo_amd.utils.aec import BatchedAECView
+    return BatchedAECView(parallel_env(wrappers, **kwargs))
 
 
 class raw_env(BatchedParallelEnv):
