@@ -1048,15 +1048,17 @@ void launch_roles_variant(const WfArgs& a, const WfDev* dev, int grid, int rng, 
 
 }  // namespace
 
-// variant: 0 = (6 cells, 3 agents, exact), 1 = (6, 2, exact), 2 = (<= 8, <= 4), 3 = (<= 16, <= 4); the caller has already staged the Philox
-// draws for variant 2 (rng arrives as FRZ_RNG_INJECTED)
+// variant (index into wildfire.hip's table): 0..3 = exact (6 cells, 3 agents), (6, 2), (9, 3), (9, 4); 4 = (<= 8, <= 4), 5 = (<= 16, <= 4);
+// the caller has already staged the Philox draws for the runtime-shape variants (rng arrives as FRZ_RNG_INJECTED)
 int launch_roles(const WfArgs& args, int variant, int grid, int rng, int mode, hipStream_t stream) {
     const WfDev* dev = reinterpret_cast<const WfDev*>(args.arena);
     switch (variant) {
         case 0: launch_roles_variant<6, 3, true>(args, dev, grid, rng, mode, stream); break;
         case 1: launch_roles_variant<6, 2, true>(args, dev, grid, rng, mode, stream); break;
-        case 2: launch_roles_variant<8, 4, false>(args, dev, grid, rng, mode, stream); break;
-        case 3: launch_roles_variant<16, 4, false>(args, dev, grid, rng, mode, stream); break;
+        case 2: launch_roles_variant<9, 3, true>(args, dev, grid, rng, mode, stream); break;
+        case 3: launch_roles_variant<9, 4, true>(args, dev, grid, rng, mode, stream); break;
+        case 4: launch_roles_variant<8, 4, false>(args, dev, grid, rng, mode, stream); break;
+        case 5: launch_roles_variant<16, 4, false>(args, dev, grid, rng, mode, stream); break;
         default: return FRZ_E_INVALID;
     }
     return hipGetLastError() == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;

@@ -520,3 +520,15 @@ def test_update_observations_after_editing_the_state_in_place():
     for k in [k for k in a if k.startswith(('act_map', 'obs_'))]:
         G.assert_same(a[k], b[k], k)
     assert int(a['env_task_count'][0]) > int(a['env_task_count'][1]) or int(a['env_task_count'][::3].sum()) > 0
+
+
+@pytest.mark.parametrize('kernel', ['roles', 'lane'])
+@pytest.mark.parametrize('agents', [3, 4])
+def test_exact_3x3_variants_match_the_oracle_in_every_rng_mode(oracle, agents, kernel, monkeypatch):
+    """3x3 grids with 3 or 4 agents run exact instantiations (<9,3>, <9,4>): loops of their own size, Philox and MT19937 inside the
+    step launch (no staging launch), the fused random policy."""
+    monkeypatch.setenv('FRZ_WF_KERNEL', kernel)
+    build = lambda: configs.wildfire_grid(3, 3, agents)
+    run_against_oracle(oracle, build, {}, 700, 20, 12, seed=61)
+    run_against_oracle(oracle, build, dict(show_bad_actions=True, observe_other_power=True), 600, 20, 12, seed=62, rng='philox')
+    run_against_oracle(oracle, build, dict(observe_other_suppressant=True), 500, 60, 30, seed=63, rng='mt19937', policy='device')
