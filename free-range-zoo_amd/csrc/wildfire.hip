@@ -928,10 +928,10 @@ struct Variant {
 };
 // the lane-per-env kernel unrolls its cell and agent loops to (CMAX, AMAX): a shape runs the smallest instantiation that holds it
 // (3x3 / 3x4 / 4x4 grids do not pay for the 24-cell one); grids of <= 16 cells with <= 4 agents run the field/crew kernel by default
-// exact entries first: a 2x3 or 3x3 grid with the listed agent counts gets loops of exactly its size and the in-kernel generators
-constexpr Variant kVariants[] = {{6, 3, true}, {6, 2, true}, {9, 3, true}, {9, 4, true},    {8, 4, false},
-                                 {16, 4, false}, {16, 8, false}, {24, 8, false}, {64, 16, false}};
-constexpr int kNumVariants = 9;
+#define FRZ_X(i, c, a, e) {c, a, e},
+constexpr Variant kVariants[] = {FRZ_WF_VARIANT_LIST(FRZ_X)};
+#undef FRZ_X
+constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
@@ -971,15 +971,11 @@ void launch_variant(const WfArgs& args, int grid, int rng, int mode, hipStream_t
 int launch_lane(frz_wildfire_env* env, const WfArgs& args, int rng, int mode, hipStream_t stream) {
     const int grid = env->dev.nchunks;  // one workgroup per chunk
     switch (env->variant) {
-        case 0: launch_variant<6, 3, true>(args, grid, rng, mode, stream); break;   // BASELINE.json cfg1/cfg2 shape
-        case 1: launch_variant<6, 2, true>(args, grid, rng, mode, stream); break;   // AAAI-2025 openness configs
-        case 2: launch_variant<9, 3, true>(args, grid, rng, mode, stream); break;
-        case 3: launch_variant<9, 4, true>(args, grid, rng, mode, stream); break;
-        case 4: launch_variant<8, 4, false>(args, grid, rng, mode, stream); break;
-        case 5: launch_variant<16, 4, false>(args, grid, rng, mode, stream); break;
-        case 6: launch_variant<16, 8, false>(args, grid, rng, mode, stream); break;
-        case 7: launch_variant<24, 8, false>(args, grid, rng, mode, stream); break;
-        default: launch_variant<64, 16, false>(args, grid, rng, mode, stream); break;
+#define FRZ_X(i, c, a, e) \
+    case i: launch_variant<c, a, e>(args, grid, rng, mode, stream); break;
+        FRZ_WF_VARIANT_LIST(FRZ_X)
+#undef FRZ_X
+        default: return FRZ_E_INVALID;
     }
     return hipGetLastError() == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;
 }

@@ -97,6 +97,14 @@ struct WfArgs {
     bool ticketed = false;  // field/crew kernels: one workgroup per chunk, chunks handed out in arrival order
 };
 
+// The (CMAX, AMAX) instantiations of the step kernels: X(index, CMAX, AMAX, exact).  An env runs the first entry that holds its shape;
+// exact entries (listed first) match only their own (cells, agents) pair: loops of exactly the shape's size and the random streams
+// generated inside the step launch.  Both kernels (wildfire.hip, wildfire_roles.hip) are instantiated from this one list.
+#define FRZ_WF_VARIANT_LIST(X)                                                                                                      \
+    X(0, 6, 3, true) X(1, 6, 2, true) X(2, 9, 3, true) X(3, 9, 4, true) X(4, 8, 3, true) X(5, 8, 4, true) X(6, 12, 3, true)           \
+    X(7, 12, 4, true) X(8, 16, 3, true) X(9, 16, 4, true)                                                                           \
+    X(10, 8, 4, false) X(11, 16, 4, false) X(12, 16, 8, false) X(13, 24, 8, false) X(14, 64, 16, false)
+
 // launch a step kernel; with timing events the dispatch itself is bracketed (what a profiler's kernel trace reports)
 template <typename K, typename... Args>
 inline void launch_step_kernel(const WfArgs& a, K kernel, int grid, int block, hipStream_t stream, Args... args) {

@@ -1048,17 +1048,18 @@ void launch_roles_variant(const WfArgs& a, const WfDev* dev, int grid, int rng, 
 
 }  // namespace
 
-// variant (index into wildfire.hip's table): 0..3 = exact (6 cells, 3 agents), (6, 2), (9, 3), (9, 4); 4 = (<= 8, <= 4), 5 = (<= 16, <= 4);
-// the caller has already staged the Philox draws for the runtime-shape variants (rng arrives as FRZ_RNG_INJECTED)
+// variant = index into FRZ_WF_VARIANT_LIST (wildfire_common.h); only entries of <= 16 cells and <= 4 agents have a field/crew kernel.
+// The caller has already staged the Philox draws for the runtime-shape variants (rng arrives as FRZ_RNG_INJECTED)
 int launch_roles(const WfArgs& args, int variant, int grid, int rng, int mode, hipStream_t stream) {
     const WfDev* dev = reinterpret_cast<const WfDev*>(args.arena);
     switch (variant) {
-        case 0: launch_roles_variant<6, 3, true>(args, dev, grid, rng, mode, stream); break;
-        case 1: launch_roles_variant<6, 2, true>(args, dev, grid, rng, mode, stream); break;
-        case 2: launch_roles_variant<9, 3, true>(args, dev, grid, rng, mode, stream); break;
-        case 3: launch_roles_variant<9, 4, true>(args, dev, grid, rng, mode, stream); break;
-        case 4: launch_roles_variant<8, 4, false>(args, dev, grid, rng, mode, stream); break;
-        case 5: launch_roles_variant<16, 4, false>(args, dev, grid, rng, mode, stream); break;
+#define FRZ_X(i, c, a, e)                                                                                  \
+    case i:                                                                                                \
+        if constexpr (c <= 16 && a <= 4) launch_roles_variant<c, a, e>(args, dev, grid, rng, mode, stream); \
+        else return FRZ_E_INVALID;                                                                         \
+        break;
+        FRZ_WF_VARIANT_LIST(FRZ_X)
+#undef FRZ_X
         default: return FRZ_E_INVALID;
     }
     return hipGetLastError() == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;

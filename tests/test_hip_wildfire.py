@@ -523,12 +523,12 @@ def test_update_observations_after_editing_the_state_in_place():
 
 
 @pytest.mark.parametrize('kernel', ['roles', 'lane'])
-@pytest.mark.parametrize('agents', [3, 4])
-def test_exact_3x3_variants_match_the_oracle_in_every_rng_mode(oracle, agents, kernel, monkeypatch):
-    """3x3 grids with 3 or 4 agents run exact instantiations (<9,3>, <9,4>): loops of their own size, Philox and MT19937 inside the
-    step launch (no staging launch), the fused random policy."""
+@pytest.mark.parametrize('shape', [(3, 3, 3), (3, 3, 4), (2, 4, 3), (4, 2, 4), (3, 4, 3), (4, 3, 4), (4, 4, 3), (2, 8, 4)])
+def test_exact_variants_match_the_oracle_in_every_rng_mode(oracle, shape, kernel, monkeypatch):
+    """Grids of 8, 9, 12 and 16 cells with 3 or 4 agents run exact instantiations (FRZ_WF_VARIANT_LIST): loops of their own size,
+    Philox and MT19937 inside the step launch (no staging launch), the fused random policy."""
     monkeypatch.setenv('FRZ_WF_KERNEL', kernel)
-    build = lambda: configs.wildfire_grid(3, 3, agents)
+    build = lambda: configs.wildfire_grid(*shape)
     run_against_oracle(oracle, build, {}, 700, 20, 12, seed=61)
     run_against_oracle(oracle, build, dict(show_bad_actions=True, observe_other_power=True), 600, 20, 12, seed=62, rng='philox')
     run_against_oracle(oracle, build, dict(observe_other_suppressant=True), 500, 60, 30, seed=63, rng='mt19937', policy='device')
