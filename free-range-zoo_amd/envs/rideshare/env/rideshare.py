@@ -255,6 +255,12 @@ class raw_env(BatchedParallelEnv):
         return out
 
     @torch.no_grad()
+    def step_random_policy(self, policy_seed: int, policy_step: int):
+        """``random_policy_actions`` + ``step`` (the same entry the other domains offer; here the two launches are not fused: the
+        policy launch is ≈3 % of a rideshare step)."""
+        return self.step(self.random_policy_actions(policy_seed, policy_step))
+
+    @torch.no_grad()
     def capture_random_rollout(self, steps: int, policy_seed: int = 0, include_reset: bool = True) -> 'torch.cuda.CUDAGraph':
         """``[reset] + steps x (device random policy -> fused step)`` as one HIP graph (see the wildfire env)."""
         if not self._has_reset:
