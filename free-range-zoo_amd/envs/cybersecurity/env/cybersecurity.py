@@ -133,6 +133,7 @@ class raw_env(BatchedParallelEnv):
 
     # ---------------------------------------------------------------------------------------- output plumbing
     def _publish(self) -> None:
+        self._bump_space_epoch()
         B, A, N, Att = self.parallel_envs, len(self.agents), self._N, self._Att
         if self.exact_shapes:
             totals = self._act_map_offsets[:, -1].tolist()  # one small device->host read per step
@@ -326,11 +327,15 @@ class raw_env(BatchedParallelEnv):
         index = self.possible_agents.index(agent)
         counts = self.environment_task_count if self.show_bad_actions else self.agent_task_count[index]
         if index < self._Att:
-            return BatchedOneOfSpace(counts, tail=[-1])
-        has_tasks = counts > 0
-        can_patch = has_tasks & (torch.full_like(has_tasks, self.show_bad_actions) | (self._location[index - self._Att] != -1))
-        tail_mask = torch.stack([torch.ones_like(has_tasks), can_patch, has_tasks], dim=1)
-        return BatchedOneOfSpace(counts, tail=[-1, -2, -3], tail_mask=tail_mask)
+            return BatchedOneOfSpace(counts, tail=[-1], sampler=self._space_sampler(index))
+        location = self._location[index - self._Att]
+
+        def tail_mask() -> torch.Tensor:  # which of (noop, patch, monitor) exist per env; resolved by code that inspects the members
+            has_tasks = counts > 0
+            can_patch = has_tasks & (torch.full_like(has_tasks, self.show_bad_actions) | (location != -1))
+            return torch.stack([torch.ones_like(has_tasks), can_patch, has_tasks], dim=1)
+
+        return BatchedOneOfSpace(counts, tail=[-1, -2, -3], tail_mask=tail_mask, sampler=self._space_sampler(index))
 
     def observation_space(self, agent: str):
         kind = agent.split('_')[0]

@@ -144,6 +144,7 @@ class raw_env(BatchedParallelEnv):
 
     # ---------------------------------------------------------------------------------------- output plumbing
     def _publish(self) -> None:
+        self._bump_space_epoch()
         B, A, P = self.parallel_envs, len(self.agents), self._P
         if self.exact_shapes:
             stats = torch.cat([self._task_offsets[-1:], self._agent_offsets[:, -1], self.environment_task_count.max().reshape(1),
@@ -283,10 +284,15 @@ class raw_env(BatchedParallelEnv):
         """Per-env ``OneOf([Discrete(1, start=state_t) for visible task t] + [noop])`` (rideshare.py:469-487, spaces/actions.py:10-50)."""
         a = self.possible_agents.index(agent)
         counts = self.agent_task_count[a]
-        total = int(self._agent_offsets[a, -1])
-        states = jagged(self._agent_task_states[a, :total], self._agent_offsets[a], max_seqlen=max(int(counts.max()), 1))
-        padded = states.to_padded_tensor(0) if total > 0 else torch.zeros((self.parallel_envs, 0), dtype=torch.int32, device=self.device)
-        return BatchedOneOfSpace(counts, tail=[-1], task_starts=padded)
+
+        def starts() -> torch.Tensor:  # padded member values; resolved only by code that inspects the members (two host reads)
+            total = int(self._agent_offsets[a, -1])
+            if total == 0:
+                return torch.zeros((self.parallel_envs, 0), dtype=torch.int32, device=self.device)
+            states = jagged(self._agent_task_states[a, :total].clone(), self._agent_offsets[a].clone(), max_seqlen=max(int(counts.max()), 1))
+            return states.to_padded_tensor(0)
+
+        return BatchedOneOfSpace(counts, tail=[-1], task_starts=starts, sampler=self._space_sampler(a))
 
     def observation_space(self, agent: str):
         return {'self_high': self.agent_observation_bounds, 'others_high': self.agent_observation_bounds,

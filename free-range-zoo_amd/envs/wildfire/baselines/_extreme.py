@@ -47,6 +47,8 @@ class ExtremeFireBaseline(Agent):
         if self.actions is None or self.actions.device != device:
             self.actions = torch.zeros((self.parallel_envs, 2), dtype=torch.int32, device=device)
         task_values = task_values.to(torch.int64).contiguous()
+        if task_values.numel() == 0:  # no lit cell in any env: an empty tensor has no address to hand over
+            task_values = torch.zeros((1, 4), dtype=torch.int64, device=device)
         obs_self = obs_self.to(torch.float32).contiguous()
         self._keepalive = (task_values, task_offsets, map_offsets, map_lengths, obs_self)
         _capi.check(_capi.lib().frz_wildfire_extreme_fire_policy(task_values.data_ptr(), task_offsets.data_ptr(), map_offsets.data_ptr(),

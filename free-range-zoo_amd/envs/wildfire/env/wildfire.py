@@ -145,6 +145,7 @@ class raw_env(BatchedParallelEnv):
     # ---------------------------------------------------------------------------------------- output plumbing
     def _publish(self) -> None:
         """Wrap the persistent output buffers in the reference's dict / TensorDict / nested-tensor structure."""
+        self._bump_space_epoch()
         B, A = self.parallel_envs, len(self.agents)
         HW = self.max_y * self.max_x
         if self.exact_shapes:
@@ -401,7 +402,7 @@ class raw_env(BatchedParallelEnv):
             counts = self.environment_task_count
         else:
             counts = self.agent_task_count[self.possible_agents.index(agent)]
-        return BatchedOneOfSpace(counts, tail=[-1])
+        return BatchedOneOfSpace(counts, tail=[-1], sampler=self._space_sampler(self.possible_agents.index(agent)))
 
     def observation_space(self, agent: str):
         """Observation bounds per env (wildfire.py:736-753): dict of the static highs + the per-env task counts."""

@@ -161,6 +161,34 @@ class BatchedParallelEnv:
                                     finished=None if reset else self.finished, log_description=self.log_description,
                                     agents=self.possible_agents, extra=self._log_extra(reset), reset=reset)
 
+    # -- action_space(agent).sample_nested() through the policy kernel -----------------------------------------------------------
+    policy_seed: int = 0x5EED  # stream of the spaces' device-side sampler; set it for reproducible `sample_nested()` rollouts
+
+    def _space_sampler(self, agent_index: int):
+        """``() -> int32 [B, 2]`` for ``BatchedOneOfSpace.sample_nested``: the first call after a step / reset launches the domain's
+        uniform random policy for ALL agents into a buffer of its own, the other agents' calls return their slice of it."""
+
+        def sample() -> torch.Tensor:
+            stamp = (self._space_epoch, )
+            if getattr(self, '_sampled_epoch', None) != stamp:
+                if getattr(self, '_sampled_actions', None) is None:
+                    self._sampled_actions = torch.zeros_like(self._actions)
+                    self._sampled_draws = 0
+                self.random_policy_actions(self.policy_seed, self._sampled_draws, out=self._sampled_actions)
+                self._sampled_draws += 1
+                self._sampled_epoch = stamp
+            return self._sampled_actions[agent_index]
+
+        return sample
+
+    @property
+    def _space_epoch(self) -> int:
+        return getattr(self, '_epoch_counter', 0)
+
+    def _bump_space_epoch(self) -> None:
+        """Called by reset / step / rebuild: the task counts changed, samples drawn before are stale."""
+        self._epoch_counter = getattr(self, '_epoch_counter', 0) + 1
+
     # -- refreshing the published outputs after the state was edited in place (planning / search code) -----------------------------
     _rebuild_symbol: Optional[str] = None  # set by the domain envs: the C-ABI entry that rebuilds task lists, observations, spaces
 

@@ -38,10 +38,14 @@ class OneOf:
 
 
 class BatchedOneOfSpace:
-    """Vector of per-env ``OneOf`` spaces described by (task member starts, task-agnostic tail)."""
+    """Vector of per-env ``OneOf`` spaces described by (task member starts, task-agnostic tail).
+
+    A space handed out by ``env.action_space(agent)`` describes the env's CURRENT step: its counts are views of the env's buffers and
+    its lazily built parts are resolved on first use, so it is valid until the next ``step()`` / ``reset()`` (take a new one then,
+    as rollout code does)."""
 
     def __init__(self, task_counts: torch.Tensor, tail: Sequence[int], task_starts: torch.Tensor = None,
-                 tail_mask: torch.Tensor = None):
+                 tail_mask: torch.Tensor = None, sampler=None):
         """
         task_counts: int tensor [B] — number of task members (Discrete(1, start=task_starts or 0)) per env
         tail:        values of the task-agnostic members appended after the tasks (e.g. [-1] = noop)
@@ -50,11 +54,24 @@ class BatchedOneOfSpace:
         """
         self.task_counts = task_counts
         self.tail = list(tail)
-        self.task_starts = task_starts
-        self.tail_mask = tail_mask
+        self._task_starts = task_starts  # tensor, None, or a zero-argument callable resolved on first use (it may cost a host read)
+        self._tail_mask = tail_mask  # tensor, None, or a zero-argument callable resolved on first use
+        self.sampler = sampler  # optional () -> int32 [B, 2]: the env's device-side policy kernel (one launch for all agents)
 
     def __len__(self):
         return int(self.task_counts.shape[0])
+
+    @property
+    def tail_mask(self):
+        if callable(self._tail_mask):
+            self._tail_mask = self._tail_mask()
+        return self._tail_mask
+
+    @property
+    def task_starts(self):
+        if callable(self._task_starts):
+            self._task_starts = self._task_starts()
+        return self._task_starts
 
     @property
     def spaces(self) -> List[OneOf]:
@@ -73,7 +90,11 @@ class BatchedOneOfSpace:
 
     @torch.no_grad()
     def sample_nested(self, generator: torch.Generator = None) -> torch.Tensor:
-        """Uniform member per env -> int32 ``[B, 2]`` = (member index, member value), on the counts' device."""
+        """Uniform member per env -> int32 ``[B, 2]`` = (member index, member value), on the counts' device.  Spaces handed out by an
+        env sample through its policy kernel (one launch serves every agent of the step); an explicit ``generator`` selects the
+        torch path below."""
+        if self.sampler is not None and generator is None:
+            return self.sampler()
         counts = self.task_counts.to(torch.int64)
         device = counts.device
         B = counts.shape[0]
