@@ -374,3 +374,27 @@ def test_aec_cycle_equals_the_parallel_step(domain):
     aec.step(actions[aec.agent_selection])  # finished: a no-op that leaves the selection where it is
     assert aec.agent_selection == aec.agents[0] and torch.equal(aec.num_moves, par.num_moves)
     aec.check()
+
+
+def test_wildfire_baselines_survive_an_observation_without_any_task():
+    """When no env has a lit cell the jagged task observation is an EMPTY tensor (no address to hand to the kernel): the agents
+    answer [-1, -1] like the reference's (strongest.py:41-43)."""
+    from free_range_zoo_amd.envs import wildfire_v0
+    from free_range_zoo_amd.envs.wildfire.baselines import StrongestBaseline, WeakestBaseline
+    from free_range_zoo_amd.wrappers import action_mapping_wrapper_v0
+    B = 3
+    env = action_mapping_wrapper_v0(wildfire_v0.parallel_env(configuration=configs.wildfire_rich(), parallel_envs=B, max_steps=12,
+                                                             device=torch.device('cuda')))
+    env.reset(seed=torch.arange(B, dtype=torch.int32))
+    state = env.state()
+    state.fires.copy_(-state.fires.abs())  # every fire out
+    env.update_observations()
+    for agent_cls in (StrongestBaseline, WeakestBaseline):
+        for name in env.agents:
+            agent = agent_cls(name, B)
+            observation = env.observe(name)
+            assert observation[0]['tasks'].values().numel() == 0
+            agent.observe(observation)
+            assert (agent.act(None) == -1).all()
+    env.step({name: torch.tensor([[0, -1]] * B, dtype=torch.int32, device='cuda') for name in env.agents})
+    env.check()
