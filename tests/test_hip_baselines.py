@@ -398,3 +398,32 @@ def test_wildfire_baselines_survive_an_observation_without_any_task():
             assert (agent.act(None) == -1).all()
     env.step({name: torch.tensor([[0, -1]] * B, dtype=torch.int32, device='cuda') for name in env.agents})
     env.check()
+
+
+@pytest.mark.parametrize('domain', ['wildfire', 'rideshare', 'cybersecurity'])
+@pytest.mark.parametrize('B', [1, 2])
+def test_tiny_batches_run_whole_episodes_through_every_wrapper(domain, B, tmp_path):
+    """B = 1 and 2 with exact shapes: empty task lists, empty jagged tensors and zero-length mappings all occur; the validator and
+    action-task wrappers, the logging tap and the materialised per-env spaces keep working for a whole episode."""
+    from free_range_zoo_amd.envs import cybersecurity_v0, rideshare_v0, wildfire_v0
+    from free_range_zoo_amd.wrappers import action_mapping_wrapper_v0, space_validator_wrapper_v0
+    module, configuration = {'wildfire': (wildfire_v0, configs.wildfire_non_stochastic()), 'rideshare': (rideshare_v0, configs.rideshare_non_stochastic()),
+                             'cybersecurity': (cybersecurity_v0, configs.cyber_openness())}[domain]
+    env = module.parallel_env(configuration=configuration, parallel_envs=B, max_steps=25, device=torch.device('cuda'),
+                              log_directory=str(tmp_path / 'logs'))
+    env = action_mapping_wrapper_v0(space_validator_wrapper_v0(env))
+    observations, infos = env.reset(seed=torch.arange(B, dtype=torch.int32))
+    steps = 0
+    while not torch.all(env.finished):
+        for name in env.agents:
+            space = env.action_space(name)
+            assert len(space.spaces) == B  # materialise the per-env OneOf objects
+            observation, mapping = observations[name]
+            assert mapping['agent_action_mapping'].size(0) == B
+        observations, rewards, terminations, truncations, infos = env.step({name: env.action_space(name).sample_nested() for name in env.agents})
+        steps += 1
+    env.check()
+    env.close()
+    assert 0 < steps <= 25
+    rows = open(tmp_path / 'logs' / '0.csv').read().strip().splitlines()
+    assert len(rows) == 1 + 1 + steps
