@@ -962,7 +962,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
             {
                 const int ch = slot & (NCHP - 1), pslot = slot / NCHP;
                 constexpr int PP = kBlock / NCHP, UNR = 8;
-                for (int first = round_first; first < chunk; first += PP * UNR) {
+                for (int first = round_first; first < (FRZ_SKIP(7) ? round_first : chunk); first += PP * UNR) {  // (bit 7: timing experiments)
                     uint32_t part = 0;
                     for (int spin = 0;; ++spin) {  // bounded: every granule of the window must carry this launch's tag
                         bool all = true;
