@@ -90,6 +90,32 @@ def cpu_baseline(budget_s=12.0, cores=None):
     }
 
 
+def secondary_workloads(device, B):
+    """BASELINE.json configs 2 and 3 (parity-test cases, not the bench line): random-policy rollouts of the other two domains at the same
+    batch, whole episodes replayed as HIP graphs, reported beside the headline (never part of `value`)."""
+    import configs
+    from free_range_zoo_amd.envs import cybersecurity_v0, rideshare_v0
+    out = {}
+    for name, module, configuration, reps in (('cybersecurity_v0 cfg4 (3 nodes, 2+2 agents, agent openness on)', cybersecurity_v0, configs.cyber_openness(), 20),
+                                              ('rideshare_v0 cfg3 (10x10 grid, 8 agents, 2 passengers entering per step)', rideshare_v0,
+                                               configs.rideshare_busy(), 5)):
+        env = module.parallel_env(configuration=configuration, parallel_envs=B, max_steps=EPISODE, device=device, rng='philox', exact_shapes=False)
+        env.reset(seed=torch.arange(B, dtype=torch.int32))
+        graph = env.capture_random_rollout(EPISODE, policy_seed=20260104, include_reset=True)
+        graph.replay()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            graph.replay()
+        torch.cuda.synchronize(device)
+        elapsed = time.perf_counter() - t0
+        env.check()
+        out[name] = {'env_steps_per_s': B * EPISODE * reps / elapsed, 'ms_per_step': 1e3 * elapsed / (EPISODE * reps), 'parallel_envs': B,
+                     'steps': EPISODE * reps}
+        del graph, env
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -98,6 +124,7 @@ def main():
     ap.add_argument('--rng', choices=['philox', 'mt19937'], default='philox')
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='parallel_envs per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the cybersecurity / rideshare rollouts reported beside the headline')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -271,6 +298,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
+        if world == 1 and not args.no_secondary:
+            line['secondary_workloads'] = secondary_workloads(device, B)
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()
