@@ -132,6 +132,11 @@ __global__ void __launch_bounds__(kBlock) rs_step_kernel(char* __restrict__ aren
     // had to be re-read after each store that might alias it — a scalar-memory round trip per use, hundreds per env slot walked
     __shared__ frz::ScanShared<AMAX + 1> s_scan;
     __shared__ int s_ticket;
+    // What this step does to each slot of each env, looked up by slot in the ordered pass instead of comparing every agent's target with
+    // every slot: bits 0-4 the (last) agent whose accept won the slot, plus one; bit 5 picked up; bit 6 dropped off.  And the agents' moves,
+    // looked up by a riding passenger's driver.  [slot][lane] / [agent][lane]: a lane only ever reads what it wrote itself.
+    __shared__ uint8_t s_effect[MODE == kStep ? FRZ_MAX_PASSENGERS : 1][kBlock];
+    __shared__ int2 s_move[MODE == kStep ? AMAX : 1][kBlock];
 
     const int tid = threadIdx.x;
     const int64_t B = d.B;
@@ -310,45 +315,59 @@ __global__ void __launch_bounds__(kBlock) rs_step_kernel(char* __restrict__ aren
                 dropped[a] = drop[a] && dist2[a] == 0;   // transitions/passenger_exit.py:43-46
                 fares[a] = dropped[a] ? pcol(PFARE, target[a], bl) : 0;
             }
+            // the slot effects of this step (cleared cooperatively: the table is per launch)
+            {
+                uint4* const table = reinterpret_cast<uint4*>(&s_effect[0][0]);
+                for (uint32_t i = (uint32_t)tid; i < P * (kBlock / 16); i += kBlock) table[i] = make_uint4(0, 0, 0, 0);
+                __syncthreads();
+#pragma unroll
+                for (int a = 0; a < AMAX; ++a) {
+                    const bool any = wins[a] || picked[a] || dropped[a];
+                    if (any) {
+                        uint32_t e = s_effect[target[a]][tid];
+                        e = wins[a] ? ((e & ~31u) | (uint32_t)(a + 1)) : e;
+                        e |= (picked[a] ? 32u : 0u) | (dropped[a] ? 64u : 0u);
+                        s_effect[target[a]][tid] = (uint8_t)e;
+                    }
+                    s_move[a][tid] = make_int2(my[a], mx[a]);
+                }
+            }
             // ---------------------------------------------------------------- (2b/3/4) one ordered pass over the env's slots:
             // riding passengers follow their driver, winners accept, picks ride, drops leave (order-preserving compaction)
             int kept = 0, unaccepted = 0;
             int wait_last[3] = {0, 0, 0};
             bool has_state[3] = {false, false, false};
             int owned[AMAX];  // passengers whose driver is agent a, any state (rideshare.py:343-344)
+            // per-agent counters packed one byte per agent (a count is at most max_passengers <= 128): [0] driver == a, [1] accepted by a,
+            // [2] riding with a, [3] driver == a and not unaccepted (the visible-but-not-general ones)
+            constexpr int KW = (AMAX + 7) / 8;
+            uint64_t tally[4][KW];
 #pragma unroll
-            for (int a = 0; a < AMAX; ++a) owned[a] = 0;
-            auto settle_slot = [&](const int s, const int (&was)[PCOLS]) {
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int w = 0; w < KW; ++w) tally[k][w] = 0;
+            auto settle_slot = [&](const int s, const int (&was)[PCOLS], const uint32_t effect) {
                 int v[PCOLS];
 #pragma unroll
                 for (int c = 0; c < PCOLS; ++c) v[c] = was[c];
                 if (v[PSTATE] == 2) {  // best_moves[env, driver]; driver -1 wraps to the last agent like Python's index
                     const int drv = v[PDRIVER] < 0 ? A + v[PDRIVER] : v[PDRIVER];
-#pragma unroll
-                    for (int a = 0; a < AMAX; ++a) {
-                        v[PY] += drv == a ? my[a] : 0;
-                        v[PX] += drv == a ? mx[a] : 0;
-                    }
+                    const int2 move = s_move[min(max(drv, 0), AMAX - 1)][tid];
+                    const bool real = drv >= 0 && drv < AMAX;
+                    v[PY] += real ? move.x : 0;
+                    v[PX] += real ? move.y : 0;
                 }
-                bool removed = false;
-#pragma unroll
-                for (int a = 0; a < AMAX; ++a) {
-                    const bool mine = target[a] == s;
-                    if (wins[a] && mine) {
-                        v[PSTATE] = 1;
-                        v[PACCEPTED] = nm;
-                        v[PDRIVER] = a;
-                    }
+                const int winner = (int)(effect & 31u) - 1;
+                if (winner >= 0) {
+                    v[PSTATE] = 1;
+                    v[PACCEPTED] = nm;
+                    v[PDRIVER] = winner;
                 }
-#pragma unroll
-                for (int a = 0; a < AMAX; ++a) {
-                    const bool mine = target[a] == s;
-                    if (picked[a] && mine) {
-                        v[PSTATE] = 2;
-                        v[PPICKED] = nm;
-                    }
-                    removed = removed || (dropped[a] && mine);
+                if (effect & 32u) {
+                    v[PSTATE] = 2;
+                    v[PPICKED] = nm;
                 }
+                const bool removed = (effect & 64u) != 0;
                 if (!removed) {
                     if (active) {
                         // a slot is rewritten only where it changes: every column once a removal has shifted the table
@@ -366,30 +385,44 @@ __global__ void __launch_bounds__(kBlock) rs_step_kernel(char* __restrict__ aren
                         has_state[k] = has_state[k] || st == k;
                     }
                     unaccepted += st == 0 ? 1 : 0;
+                    const int drv = v[PDRIVER];
 #pragma unroll
-                    for (int a = 0; a < AMAX; ++a) {
-                        owned[a] += v[PDRIVER] == a ? 1 : 0;
-                        visible[a] += (st == 0 || v[PDRIVER] == a) ? 1 : 0;
-                        n_accepted[a] += (st == 1 && v[PDRIVER] == a) ? 1 : 0;
-                        n_riding[a] += (st == 2 && v[PDRIVER] == a) ? 1 : 0;
+                    for (int w = 0; w < KW; ++w) {
+                        const int local = drv - 8 * w;
+                        const uint64_t one = (local >= 0 && local < 8) ? (uint64_t)1 << (8 * local) : (uint64_t)0;
+                        tally[0][w] += one;
+                        tally[1][w] += st == 1 ? one : (uint64_t)0;
+                        tally[2][w] += st == 2 ? one : (uint64_t)0;
+                        tally[3][w] += st != 0 ? one : (uint64_t)0;
                     }
                     ++kept;
                 }
             };
             for (int s0 = 0; s0 < count; s0 += kBatch) {
                 int was[kBatch][PCOLS];
+                uint32_t effect[kBatch];
 #pragma unroll
                 for (int u = 0; u < kBatch; ++u) {
                     const int s = min(s0 + u, (int)P - 1);
 #pragma unroll
                     for (int c = 0; c < PCOLS; ++c) was[u][c] = pcol(c, s, bl);
+                    effect[u] = s_effect[s][tid];
                 }
                 // a slot is only ever written at or below its own index (kept <= s), so the batch's loads see the old table
 #pragma unroll
                 for (int u = 0; u < kBatch; ++u)
-                    if (s0 + u < count) settle_slot(s0 + u, was[u]);
+                    if (s0 + u < count) settle_slot(s0 + u, was[u], effect[u]);
             }
             count = kept;
+            // unpack the tallies (visible = the unaccepted ones, seen by every agent, plus the agent's own accepted / riding ones)
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a) {
+                const int w = a >> 3, sh = 8 * (a & 7);
+                owned[a] = (int)((tally[0][w] >> sh) & 0xFFu);
+                n_accepted[a] = (int)((tally[1][w] >> sh) & 0xFFu);
+                n_riding[a] = (int)((tally[2][w] >> sh) & 0xFFu);
+                visible[a] = unaccepted + (int)((tally[3][w] >> sh) & 0xFFu);
+            }
             // ---------------------------------------------------------------- (5) entry of the next timestep (rideshare.py:308)
             passenger_entry(d, sch, pas, Bu, bl, b, nm + 1, count, err, active, [&](int t) {
                 wait_last[0] = nm - t;
