@@ -92,7 +92,10 @@ __global__ void __launch_bounds__(kBlock) cy_fill_kernel(char* arena) {
     rows1[d.u_frozen * B + b] = 0;
 }
 
-template <int NMAX, int AMAX, int RNG, int MODE>
+// ATT >= 0: an exact instantiation — the env has exactly NMAX nodes, ATT attackers and AMAX - ATT defenders, so every shape test
+// below folds at compile time (the runtime-shape instantiations, ATT = -1, pay for them with select chains: ~25 % of their
+// instructions)
+template <int NMAX, int AMAX, int ATT, int RNG, int MODE>
 __global__ void __launch_bounds__(kBlock) cy_step_kernel(char* __restrict__ arena, const CyDev* __restrict__ dev,
                                                           const int32_t* __restrict__ actions, const float* __restrict__ net_rand,
                                                           const float* __restrict__ agent_rand, const CyLaunch L) {
@@ -106,7 +109,7 @@ __global__ void __launch_bounds__(kBlock) cy_step_kernel(char* __restrict__ aren
     const uint4 cfg_piece = tid < kCfgPieces ? reinterpret_cast<const uint4*>(dev)[tid] : make_uint4(0, 0, 0, 0);
     const int64_t B = L.B;
     const uint32_t Bu = (uint32_t)L.B;
-    const int N = L.N, Att = L.Att, D = L.D, A = L.A;
+    const int N = ATT >= 0 ? NMAX : L.N, Att = ATT >= 0 ? ATT : L.Att, D = ATT >= 0 ? AMAX - ATT : L.D, A = ATT >= 0 ? AMAX : L.A;
     const int nchunks = (int)((B + kBlock - 1) / kBlock);
     // rows of the [rows][B] block: a fixed function of (N, D, A) (frz_cybersecurity_create lays them out in this order)
     const int r_state = 0, r_loc = N, r_last = N + D, r_moves = N + 2 * D, r_seeds = r_moves + 3 * A + 2;
@@ -584,7 +587,7 @@ struct Policy {  // fused uniform random policy of a step launch
     int32_t* actions_out = nullptr;
 };
 
-template <int NMAX, int AMAX>
+template <int NMAX, int AMAX, int ATT = -1>
 void launch_variant(frz_cybersecurity_env* env, const int32_t* actions, const float* nr, const float* ar, int rng, int mode,
                     hipStream_t stream, const Policy& policy) {
     const CyDev* dev = reinterpret_cast<const CyDev*>(env->arena);
@@ -594,15 +597,15 @@ void launch_variant(frz_cybersecurity_env* env, const int32_t* actions, const fl
                      (uint32_t)policy.seed, (uint32_t)(policy.seed >> 32), (uint32_t)policy.step, (uint32_t)(policy.step >> 32), policy.actions_out,
                      p.off_mt_state};
     if (mode == kRebuild)
-        hipLaunchKernelGGL((cy_step_kernel<NMAX, AMAX, FRZ_RNG_INJECTED, kRebuild>), grid, block, 0, stream, env->arena, dev, actions, nr, ar, L);
+        hipLaunchKernelGGL((cy_step_kernel<NMAX, AMAX, ATT, FRZ_RNG_INJECTED, kRebuild>), grid, block, 0, stream, env->arena, dev, actions, nr, ar, L);
     else if (rng == FRZ_RNG_PHILOX)
-        hipLaunchKernelGGL((cy_step_kernel<NMAX, AMAX, FRZ_RNG_PHILOX, kStep>), grid, block, 0, stream, env->arena, dev, actions, nr, ar, L);
+        hipLaunchKernelGGL((cy_step_kernel<NMAX, AMAX, ATT, FRZ_RNG_PHILOX, kStep>), grid, block, 0, stream, env->arena, dev, actions, nr, ar, L);
     else if (rng == FRZ_RNG_MT19937) {
         if constexpr (kMtInKernel<NMAX, AMAX>)
-            hipLaunchKernelGGL((cy_step_kernel<NMAX, AMAX, FRZ_RNG_MT19937, kStep>), grid, block, 0, stream, env->arena, dev, actions, nr, ar, L);
+            hipLaunchKernelGGL((cy_step_kernel<NMAX, AMAX, ATT, FRZ_RNG_MT19937, kStep>), grid, block, 0, stream, env->arena, dev, actions, nr, ar, L);
     }
     else
-        hipLaunchKernelGGL((cy_step_kernel<NMAX, AMAX, FRZ_RNG_INJECTED, kStep>), grid, block, 0, stream, env->arena, dev, actions, nr, ar, L);
+        hipLaunchKernelGGL((cy_step_kernel<NMAX, AMAX, ATT, FRZ_RNG_INJECTED, kStep>), grid, block, 0, stream, env->arena, dev, actions, nr, ar, L);
 }
 
 int launch(frz_cybersecurity_env* env, const int32_t* actions, const float* nr, const float* ar, int rng, int mode, hipStream_t stream,
@@ -610,6 +613,7 @@ int launch(frz_cybersecurity_env* env, const int32_t* actions, const float* nr, 
     switch (env->variant) {
         case 0: launch_variant<4, 4>(env, actions, nr, ar, rng, mode, stream, policy); break;
         case 1: launch_variant<8, 8>(env, actions, nr, ar, rng, mode, stream, policy); break;
+        case 3: launch_variant<3, 4, 2>(env, actions, nr, ar, rng, mode, stream, policy); break;  // exact: 3 nodes, 2 attackers, 2 defenders
         default: launch_variant<16, 16>(env, actions, nr, ar, rng, mode, stream, policy); break;
     }
     return hipGetLastError() == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;
@@ -634,6 +638,7 @@ int frz_cybersecurity_create(const frz_cybersecurity_cfg* cfg, frz_cybersecurity
     if (!env) return FRZ_E_INVALID;
     env->cfg = *cfg;
     env->variant = (N <= 4 && A <= 4) ? 0 : ((N <= 8 && A <= 8) ? 1 : 2);
+    if (N == 3 && Att == 2 && D == 2) env->variant = 3;  // the reference's own test / competition shape gets an exact instantiation
     CyDev& p = env->dev;
     std::memset(&p, 0, sizeof(p));
     const int64_t B = cfg->parallel_envs;
@@ -837,7 +842,7 @@ static int step_impl(frz_cybersecurity_env* env, const int32_t* actions, int rng
     const CyDev& p = env->dev;
     if (rng_mode == FRZ_RNG_INJECTED) {
         if (!network_randomness || !agent_randomness) return FRZ_E_INVALID;
-    } else if (rng_mode == FRZ_RNG_MT19937 && env->variant < 2) {
+    } else if (rng_mode == FRZ_RNG_MT19937 && env->variant != 2) {
         // the step kernel advances the env's own stream (network draws first, then agent draws, cybersecurity.py:304-315)
     } else if (rng_mode == FRZ_RNG_MT19937) {  // 16-node / 16-agent variant: the same draws staged in the arena by a generator launch
         const int64_t B = p.B;

@@ -252,3 +252,23 @@ def test_mt19937_stream_is_left_alone_by_frozen_steps(oracle):
         oracle.mt19937_generate(mt_state, mt_index, 1, N)
         oracle.mt19937_generate(mt_state, mt_index, 1, A)
     assert np.array_equal(np_(env._view(env._bufs.mt_index, (B, ), torch.int32)), mt_index)
+
+
+@pytest.mark.parametrize('shape', [(4, 2, 2), (3, 1, 3), (2, 1, 1), (3, 3, 1), (6, 2, 2)])
+def test_runtime_shape_small_variants_match_the_oracle(oracle, shape):
+    """The 3-node / 2-attacker / 2-defender shape has an exact instantiation; every other shape of <= 4 (<= 8) nodes and agents runs
+    the runtime-shape <4,4> (<8,8>) kernels: injected, Philox, in-kernel MT19937 and the fused policy on those."""
+    build = lambda: configs.cyber_grid(*shape)
+    run_against_oracle(oracle, build, {}, 500, 20, 12, seed=71)
+    run_against_oracle(oracle, build, dict(show_bad_actions=False, observe_other_location=True), 400, 20, 10, seed=72, rng='philox')
+    run_against_oracle(oracle, build, dict(partially_observable=False), 300, 150, 40, seed=73, rng='mt19937')
+    B = 700
+    two, one = (make_env(build, B, 9, rng='philox') for _ in range(2))
+    for env in (two, one):
+        env.reset(seed=torch.arange(B, dtype=torch.int32) + 9)
+    for t in range(11):
+        two.step(two.random_policy_actions(policy_seed=5, policy_step=t).clone())
+        one.step_random_policy(policy_seed=5, policy_step=t)
+        a, b = hip_snapshot(two), hip_snapshot(one)
+        for key in a:
+            G.assert_same(b[key], a[key], f'{shape} step {t} {key}')
