@@ -523,9 +523,10 @@ def test_update_observations_after_editing_the_state_in_place():
 
 
 @pytest.mark.parametrize('kernel', ['roles', 'lane'])
-@pytest.mark.parametrize('shape', [(3, 3, 3), (3, 3, 4), (2, 4, 3), (4, 2, 4), (3, 4, 3), (4, 3, 4), (4, 4, 3), (2, 8, 4)])
+@pytest.mark.parametrize('shape', [(3, 3, 3), (3, 3, 4), (2, 4, 3), (4, 2, 4), (3, 4, 3), (4, 3, 4), (4, 4, 3), (2, 8, 4), (2, 2, 2), (2, 2, 3), (2, 4, 2),
+                                   (3, 3, 2), (3, 4, 2), (4, 4, 2), (2, 3, 4)])
 def test_exact_variants_match_the_oracle_in_every_rng_mode(oracle, shape, kernel, monkeypatch):
-    """Grids of 8, 9, 12 and 16 cells with 3 or 4 agents run exact instantiations (FRZ_WF_VARIANT_LIST): loops of their own size,
+    """Grids of 4, 6, 8, 9, 12 and 16 cells with 2 to 4 agents run exact instantiations (FRZ_WF_VARIANT_LIST): loops of their own size,
     Philox and MT19937 inside the step launch (no staging launch), the fused random policy."""
     monkeypatch.setenv('FRZ_WF_KERNEL', kernel)
     build = lambda: configs.wildfire_grid(*shape)
