@@ -132,13 +132,21 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus and world > 1:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    # rehearsal on a one-GPU box only (never set by the driver): FRZ_BENCH_SHARE_DEVICE=1 puts every rank on device 0 and swaps RCCL
+    # (which refuses two ranks on one device) for gloo, so that the N > 1 code path — seeds per rank, barriers, the max over ranks, the
+    # metrics reduction, rank 0's JSON line — can be run end to end without an 8-GPU node
+    rehearsal = os.environ.get('FRZ_BENCH_SHARE_DEVICE') == '1'
+    device_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(device_index)
+    device = torch.device('cuda', device_index)
     dist = None
     if world > 1 or 'RANK' in os.environ:  # launched by torch.distributed.run (also with one rank: same code path as N > 1)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', device_id=device)  # RCCL over xGMI
+        if rehearsal:
+            dist.init_process_group(backend='gloo')
+        else:
+            dist.init_process_group(backend='nccl', device_id=device)  # RCCL over xGMI
 
     import configs
     from free_range_zoo_amd.envs import wildfire_v0

@@ -1,0 +1,30 @@
+"""The N > 1 path of bench.py end to end on ONE GPU: two ranks launched exactly as the driver launches them
+(python -m torch.distributed.run ... bench.py --gpus 2 ...), sharing device 0 and using gloo instead of RCCL
+(FRZ_BENCH_SHARE_DEVICE=1, a rehearsal switch the driver never sets).  Checks the contract of the JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_prints_one_contract_line():
+    env = dict(os.environ, FRZ_BENCH_SHARE_DEVICE='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', '29531',
+           os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '150', '--warmup', '50']
+    done = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert done.returncode == 0, done.stderr[-2000:]
+    lines = [line for line in done.stdout.splitlines() if line.startswith('{')]
+    assert len(lines) == 1, done.stdout[-2000:]  # rank 0 only
+    line = json.loads(lines[0])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data',
+                'config', 'roofline'):
+        assert key in line, key
+    assert line['n_gpus'] == 2 and line['steps'] == 150 and line['warmup'] == 50 and line['scaling'] == 'weak' and line['vs_baseline'] is None
+    assert line['value'] > 0 and abs(line['value'] - 2 * 65536 * 150 / (line['ms_per_step'] * 150 / 1e3)) / line['value'] < 1e-6
+    assert 'cpu_baseline' not in line and 'secondary_workloads' not in line  # rank 0 at N = 1 only
+    assert set(line['roofline']) >= {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'}
