@@ -226,8 +226,13 @@ __global__ void __launch_bounds__(kBlock) cy_step_kernel(char* __restrict__ aren
         if (MODE == kStep) {
             if (L.policy) {
                 // uniform member of each agent's OneOf action space, the stream of cy_policy_kernel / frz_cybersecurity_random_policy:
-                // word 0 of Philox(counter (agent, 0, step lo, step hi), key (seed lo ^ env seed, seed hi)); the agent's task count is
-                // what the previous launch published (N while present, everything with show_bad_actions)
+                // agent a draws word a % 4 of Philox(counter (a / 4, 0, step lo, step hi), key (seed lo ^ env seed, seed hi)); the agent's
+                // task count is what the previous launch published (N while present, everything with show_bad_actions)
+                frz::Philox4 policy_words[(AMAX + 3) / 4];
+#pragma unroll
+                for (int q = 0; q < (AMAX + 3) / 4; ++q)
+                    if (q * 4 < A) policy_words[q] = frz::philox4x32_10((uint32_t)q, 0u, L.policy_step_lo, L.policy_step_hi, L.policy_seed_lo ^ seed,
+                                                                       L.policy_seed_hi);
 #pragma unroll
                 for (int a = 0; a < AMAX; ++a) {
                     if (a < A) {
@@ -241,9 +246,7 @@ __global__ void __launch_bounds__(kBlock) cy_step_kernel(char* __restrict__ aren
                             tail1 = patchable ? -2 : -3;
                             nt = patchable ? 3 : 2;
                         }
-                        const frz::Philox4 w = frz::philox4x32_10((uint32_t)a, 0u, L.policy_step_lo, L.policy_step_hi, L.policy_seed_lo ^ seed,
-                                                                   L.policy_seed_hi);
-                        const int j = (int)(((uint64_t)w.w[0] * (uint64_t)(n + nt)) >> 32);
+                        const int j = (int)(((uint64_t)policy_words[a >> 2].w[a & 3] * (uint64_t)(n + nt)) >> 32);
                         const int value = j < n ? 0 : (j - n == 0 ? -1 : (j - n == 1 ? tail1 : -3));
                         act_in[a] = make_int2(j, value);
                         if (active) reinterpret_cast<int2*>(L.actions_out)[(int64_t)a * B + b] = act_in[a];
@@ -552,8 +555,11 @@ __global__ void __launch_bounds__(kBlock) cy_policy_kernel(const char* arena, ui
         tail[nt++] = -3;
     }
     const uint32_t env_seed = (uint32_t)rows[d.r_seeds * B + b];
-    const frz::Philox4 w = frz::philox4x32_10((uint32_t)(i / B), 0u, step_lo, step_hi, seed_lo ^ env_seed, seed_hi);  // (agent, step) keyed by the env seed
-    const int j = (int)(((uint64_t)w.w[0] * (uint64_t)(n + nt)) >> 32);
+    const uint32_t agent = (uint32_t)(i / B);  // agent a draws word a % 4 of block a / 4 of the (env, step) stream
+    const frz::Philox4 w = frz::philox4x32_10(agent >> 2, 0u, step_lo, step_hi, seed_lo ^ env_seed, seed_hi);
+    const uint32_t lane_word = agent & 3u;  // selected with compares: a runtime index into the block would put it in scratch
+    const uint32_t word = lane_word == 0u ? w.w[0] : (lane_word == 1u ? w.w[1] : (lane_word == 2u ? w.w[2] : w.w[3]));
+    const int j = (int)(((uint64_t)word * (uint64_t)(n + nt)) >> 32);
     const int value = j < n ? 0 : (j - n == 0 ? tail[0] : (j - n == 1 ? tail[1] : tail[2]));
     reinterpret_cast<int2*>(actions)[i] = make_int2(j, value);
 }

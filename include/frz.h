@@ -349,8 +349,8 @@ int frz_cybersecurity_rebuild(frz_cybersecurity_env* env, void* stream);
  *   node n draw  = word n & 3 of counter (n >> 2, step, 0, 0);  agent a draw = word a & 3 of counter (a >> 2, step, 1, 0) */
 int frz_cybersecurity_step(frz_cybersecurity_env* env, const int32_t* actions, int rng_mode, const float* network_randomness,
                            const float* agent_randomness, void* stream);
-/* uniform random policy over each agent's OneOf action space (spaces/actions.py:11-99): member from word 0 of
- * Philox(counter (agent, 0, step, step >> 32), key (seed ^ seeds[b], seed >> 32)) */
+/* uniform random policy over each agent's OneOf action space (spaces/actions.py:11-99): agent a draws its member from word a % 4 of
+ * Philox(counter (a / 4, 0, step, step >> 32), key (seed ^ seeds[b], seed >> 32)) — the wildfire policy's stream */
 int frz_cybersecurity_random_policy(frz_cybersecurity_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out,
                                     void* stream);
 /* frz_cybersecurity_random_policy + frz_cybersecurity_step as ONE launch (same results as the two calls): the actions are sampled

@@ -248,7 +248,8 @@ void frz_oracle_cybersecurity_philox_randomness(const frz_cybersecurity_cfg* cfg
 
 /* Uniform member of each agent's OneOf action space (spaces/actions.py:11-99): n task members then the tail
  * attacker [noop]; defender [noop, patch, monitor] (patch dropped at the home node unless show_bad_actions; noop only
- * when the agent has no task).  word 0 of Philox(counter (agent, 0, step lo, step hi), key (seed lo ^ env seed, seed hi)). */
+ * when the agent has no task).  Agent a draws word a % 4 of Philox(counter (a / 4, 0, step lo, step hi), key (seed lo ^ env seed, seed hi)):
+ * the stream the wildfire policy defines (four agents share a block). */
 void frz_oracle_cybersecurity_random_policy(const frz_cybersecurity_cfg* cfg, const int32_t* agent_task_count, const int32_t* location,
                                             const int32_t* env_seeds, uint64_t seed, uint64_t step, int32_t* actions) {
     const int64_t B = cfg->parallel_envs;
@@ -264,11 +265,11 @@ void frz_oracle_cybersecurity_random_policy(const frz_cybersecurity_cfg* cfg, co
             if (cfg->show_bad_actions || !home) tail[nt++] = -2;
             tail[nt++] = -3;
         }
-        const uint32_t ctr[4] = {(uint32_t)a, 0u, (uint32_t)step, (uint32_t)(step >> 32)};
+        const uint32_t ctr[4] = {(uint32_t)(a >> 2), 0u, (uint32_t)step, (uint32_t)(step >> 32)};
         const uint32_t key[2] = {(uint32_t)seed ^ (uint32_t)env_seeds[b], (uint32_t)(seed >> 32)};
         uint32_t out[4];
         frz_oracle_philox4x32_10(ctr, key, out);
-        const int j = (int)(((uint64_t)out[0] * (uint64_t)(n + nt)) >> 32);
+        const int j = (int)(((uint64_t)out[a & 3] * (uint64_t)(n + nt)) >> 32);
         actions[i * 2 + 0] = j;
         actions[i * 2 + 1] = j < n ? 0 : tail[j - n];
     }
