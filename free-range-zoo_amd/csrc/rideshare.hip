@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(kBlock) rs_step_kernel(char* __restrict__ aren
     // every slot: bits 0-4 the (last) agent whose accept won the slot, plus one; bit 5 picked up; bit 6 dropped off.  And the agents' moves,
     // looked up by a riding passenger's driver.  [slot][lane] / [agent][lane]: a lane only ever reads what it wrote itself.
     __shared__ uint8_t s_effect[MODE == kStep ? FRZ_MAX_PASSENGERS : 1][kBlock];
-    __shared__ int2 s_move[MODE == kStep ? AMAX : 1][kBlock];
+    __shared__ short2 s_move[MODE == kStep ? AMAX : 1][kBlock];  // (dy, dx): |move| < grid size < 2^15 (checked by frz_rideshare_create)
 
     const int tid = threadIdx.x;
     const int64_t B = d.B;
@@ -329,7 +329,7 @@ __global__ void __launch_bounds__(kBlock) rs_step_kernel(char* __restrict__ aren
                         e |= (picked[a] ? 32u : 0u) | (dropped[a] ? 64u : 0u);
                         s_effect[target[a]][tid] = (uint8_t)e;
                     }
-                    s_move[a][tid] = make_int2(my[a], mx[a]);
+                    s_move[a][tid] = make_short2((short)my[a], (short)mx[a]);
                 }
             }
             // ---------------------------------------------------------------- (2b/3/4) one ordered pass over the env's slots:
@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(kBlock) rs_step_kernel(char* __restrict__ aren
                 for (int c = 0; c < PCOLS; ++c) v[c] = was[c];
                 if (v[PSTATE] == 2) {  // best_moves[env, driver]; driver -1 wraps to the last agent like Python's index
                     const int drv = v[PDRIVER] < 0 ? A + v[PDRIVER] : v[PDRIVER];
-                    const int2 move = s_move[min(max(drv, 0), AMAX - 1)][tid];
+                    const short2 move = s_move[min(max(drv, 0), AMAX - 1)][tid];
                     const bool real = drv >= 0 && drv < AMAX;
                     v[PY] += real ? move.x : 0;
                     v[PX] += real ? move.y : 0;
@@ -643,6 +643,13 @@ int frz_rideshare_create(const frz_rideshare_cfg* cfg, const int32_t* schedule, 
         return FRZ_E_INVALID;
     if ((int64_t)PCOLS * P * cfg->parallel_envs >= (int64_t)1 << 30 || (int64_t)(4 * A + 8) * cfg->parallel_envs >= (int64_t)1 << 30)
         return FRZ_E_INVALID;  // 32-bit element indices
+    // coordinates stay inside +-16383: an agent's move (a difference of two positions with fast travel) travels through a 16-bit table
+    auto small = [](int32_t v) { return v > -16384 && v < 16384; };
+    for (int a = 0; a < A; ++a)
+        if (!small(cfg->start_y[a]) || !small(cfg->start_x[a])) return FRZ_E_INVALID;
+    for (int64_t r = 0; r < cfg->schedule_rows; ++r)
+        for (int c = 2; c < 6; ++c)
+            if (!small(schedule[r * 7 + c])) return FRZ_E_INVALID;
     frz_rideshare_env* env = new (std::nothrow) frz_rideshare_env();
     if (!env) return FRZ_E_INVALID;
     env->cfg = *cfg;

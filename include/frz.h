@@ -414,7 +414,8 @@ typedef struct frz_rideshare_bufs {
 
 typedef struct frz_rideshare_env frz_rideshare_env;
 
-/* schedule: host pointer to int32 [schedule_rows][7] (PassengerConfiguration.schedule), copied at create */
+/* schedule: host pointer to int32 [schedule_rows][7] (PassengerConfiguration.schedule), copied at create.  Start positions and
+ * schedule coordinates must lie within +-16383 (FRZ_E_INVALID otherwise). */
 int frz_rideshare_create(const frz_rideshare_cfg* cfg, const int32_t* schedule, frz_rideshare_env** out);
 void frz_rideshare_destroy(frz_rideshare_env* env);
 int64_t frz_rideshare_arena_bytes(const frz_rideshare_env* env);
