@@ -1044,7 +1044,7 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
     // Kernel choice for grids of <= 8 cells: the field/crew wavefront-pair kernel (wildfire_roles.hip, two wavefronts per
     // 64 envs) or the lane-per-env kernel below; FRZ_WF_KERNEL=lane|roles overrides the default.
     const char* want = std::getenv("FRZ_WF_KERNEL");
-    const bool small = HW <= 16 && A <= 4;
+    const bool small = HW <= 16 && A * (HW <= 8 ? 8 : 16) <= 64;  // shapes the field/crew kernel has an instantiation for
     p.roles = small ? 1 : 0;
     if (want && std::strcmp(want, "lane") == 0) p.roles = 0;
     if (want && std::strcmp(want, "roles") == 0 && small) p.roles = 1;

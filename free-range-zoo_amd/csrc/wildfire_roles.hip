@@ -58,10 +58,11 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                                                                const int32_t* __restrict__ actions, const float* __restrict__ field_rand,
                                                                const float* __restrict__ agent_rand, const WfLaunch launch) {
     const int32_t batch = launch.batch;
-    static_assert(CMAX <= 16 && AMAX <= 4, "cell masks travel between the roles as 8- or 16-bit fields of one word");
     using mask_t = uint32_t;
     constexpr int MB = CMAX <= 8 ? 8 : 16;                                  // bits of a cell mask in the exchange words
-    using pack_t = std::conditional_t<(CMAX <= 8), uint32_t, uint64_t>;     // burned | put_out | dead, and one mask per agent
+    static_assert(CMAX <= 16 && AMAX * MB <= 64, "cell masks travel between the roles as 8- or 16-bit fields of one word, one per agent");
+    using pack_t = std::conditional_t<(AMAX * MB <= 32), uint32_t, uint64_t>;  // one mask per agent
+    using fate_t = std::conditional_t<(MB == 8), uint32_t, uint64_t>;           // burned | put_out << MB | dead << 2 MB
     constexpr int PW = (AMAX + 1 + 3) / 4;                                // packed scan words (four 16-bit channels each)
     constexpr int NCHP = AMAX + 3 <= 8 ? 8 : (AMAX + 3 <= 16 ? 16 : 32);  // scan channels padded to a power of two
     constexpr bool kPhilox = RNG == FRZ_RNG_PHILOX && MODE == kStep;
@@ -76,9 +77,9 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
     __shared__ WfStaged s_cfg;  // hot scalars (copied to registers below) + the per-lane lookup tables (range sets, equipment, capacities)
     __shared__ float x_power[CMAX][kBlock];  // crew -> field: fire-fighting power applied to each cell
     __shared__ uint32_t x_lit[kBlock];       // field -> crew: lit cells after the transitions
-    __shared__ pack_t x_fate[kBlock];        // field -> crew: burned | put_out << MB | dead << 2 MB
+    __shared__ fate_t x_fate[kBlock];        // field -> crew: burned | put_out << MB | dead << 2 MB
     __shared__ uint64_t x_excl[PW][kBlock];  // crew -> both: packed per-env counts of the preceding envs of the same wavefront
-    __shared__ pack_t x_ok[kBlock];          // crew -> both: attackable cells of agent a in field a (MB bits each, AMAX <= 4)
+    __shared__ pack_t x_ok[kBlock];          // crew -> both: attackable cells of agent a in field a (MB bits each, AMAX * MB <= 64)
     __shared__ float x_supp[AMAX][kBlock];   // crew -> field: suppressant after the agent transitions (agent observations)
     __shared__ float x_draw[(kPhilox || kMt) ? 5 * AMAX : 1][kBlock];  // field -> crew: the step's agent draws (in-kernel RNG)
 
@@ -565,7 +566,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
             for (int c = 0; c < CMAX; ++c) lit1 |= (mask_t)(f[c] > 0) << c;
             lit1 = active ? lit1 : (mask_t)0;
             x_lit[slot] = lit1;
-            x_fate[slot] = (pack_t)burned | ((pack_t)put_out << MB) | ((pack_t)dead << (2 * MB));
+            x_fate[slot] = (fate_t)burned | ((fate_t)put_out << MB) | ((fate_t)dead << (2 * MB));
             FRZ_RSTAMP(5);
             __syncthreads();  // (2) lit mask and fates visible to the crew
             FRZ_RSTAMP(6);
@@ -698,10 +699,13 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                 for (int c = 0; c < CMAX; ++c) ap[c] = 0.0f;
                 const bool show_bad = (flags & kShowBad) != 0;
                 // stream of frz_wildfire_random_policy: agent a draws word a % 4 of block (a / 4, policy step), keyed by the env seed
-                frz::Philox4 policy_block{};
-                if (launch.policy)
-                    policy_block = frz::philox4x32_10(0u, 0u, launch.policy_step_lo, launch.policy_step_hi, launch.policy_seed_lo ^ crw.seed,
-                                                      launch.policy_seed_hi);
+                frz::Philox4 policy_block[(AMAX + 3) / 4]{};  // agent a draws word a % 4 of block a / 4
+                if (launch.policy) {
+#pragma unroll
+                    for (int q = 0; q < (AMAX + 3) / 4; ++q)
+                        if (q * 4 < A) policy_block[q] = frz::philox4x32_10((uint32_t)q, 0u, launch.policy_step_lo, launch.policy_step_hi,
+                                                                           launch.policy_seed_lo ^ crw.seed, launch.policy_seed_hi);
+                }
 #pragma unroll
                 for (int a = 0; a < AMAX; ++a) {
                     if (a < A) {
@@ -713,7 +717,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                             // baselines/random.py:20), the stream of frz_wildfire_random_policy: member j ~ U{0..n};
                             // j < n -> [j, 0] (fight task j), j == n -> [n, -1] (noop / refill)
                             const int n = popc(sel);
-                            const int j = (int)(((uint64_t)policy_block.w[a] * (uint64_t)(n + 1)) >> 32);  // AMAX <= 4: one block
+                            const int j = (int)(((uint64_t)policy_block[a >> 2].w[a & 3] * (uint64_t)(n + 1)) >> 32);
                             act_idx = j < n ? j : n;
                             act_id = j < n ? 0 : -1;
                             reinterpret_cast<int2*>(launch.actions_out)[a * B + bl] = make_int2(act_idx, act_id);
@@ -830,8 +834,8 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
 
             // ---- phase 3: open-task sets, per-env counts, wavefront scan
             const mask_t lit1 = x_lit[slot];
-            const pack_t fate = x_fate[slot];
-            const mask_t burned = (mask_t)(fate & (pack_t)((1u << MB) - 1u)), put_out = (mask_t)((fate >> MB) & (pack_t)((1u << MB) - 1u));
+            const fate_t fate = x_fate[slot];
+            const mask_t burned = (mask_t)(fate & (fate_t)((1u << MB) - 1u)), put_out = (mask_t)((fate >> MB) & (fate_t)((1u << MB) - 1u));
             const bool dead = ((fate >> (2 * MB)) & 1u) != 0;
             bool term = term0, trunc = trunc0;
             if (MODE == kStep) {
@@ -1055,7 +1059,7 @@ int launch_roles(const WfArgs& args, int variant, int grid, int rng, int mode, h
     switch (variant) {
 #define FRZ_X(i, c, a, e)                                                                                  \
     case i:                                                                                                \
-        if constexpr (c <= 16 && a <= 4) launch_roles_variant<c, a, e>(args, dev, grid, rng, mode, stream); \
+        if constexpr (c <= 16 && a * (c <= 8 ? 8 : 16) <= 64) launch_roles_variant<c, a, e>(args, dev, grid, rng, mode, stream); \
         else return FRZ_E_INVALID;                                                                         \
         break;
         FRZ_WF_VARIANT_LIST(FRZ_X)

@@ -326,9 +326,10 @@ def test_timed_rollout_runs_the_same_steps():
 
 @pytest.mark.parametrize('shape,kernel', [((2, 4, 4), 'roles'), ((2, 4, 4), 'lane'), ((1, 7, 3), 'roles'), ((3, 3, 3), 'roles'), ((3, 3, 3), 'lane'),
                                           ((3, 4, 4), 'roles'), ((4, 4, 4), 'roles'), ((4, 4, 2), 'lane'), ((2, 7, 1), 'roles'),
+                                          ((2, 3, 6), 'roles'), ((2, 4, 8), 'roles'), ((1, 5, 5), 'roles'), ((2, 2, 7), 'roles'), ((2, 4, 8), 'lane'),
                                           ((4, 4, 6), 'lane'), ((2, 5, 7), 'lane'), ((8, 8, 12), 'lane'), ((5, 9, 16), 'lane')])
 def test_every_kernel_variant_matches_the_oracle(oracle, shape, kernel, monkeypatch):
-    """Grid shapes that select the runtime-shape variants: <8,4> and <16,4> (field/crew with staged draws, and lane), and the lane
+    """Grid shapes that select the runtime-shape variants: <8,4>, <16,4> and <8,8> (field/crew with staged draws, and lane), and the lane
     kernel's <16,8>, <24,8> (wildfire_rich, 4x5, is the other user of it) and <64,16>."""
     monkeypatch.setenv('FRZ_WF_KERNEL', kernel)
     H, Wd, A = shape
@@ -533,3 +534,23 @@ def test_exact_variants_match_the_oracle_in_every_rng_mode(oracle, shape, kernel
     run_against_oracle(oracle, build, {}, 700, 20, 12, seed=61)
     run_against_oracle(oracle, build, dict(show_bad_actions=True, observe_other_power=True), 600, 20, 12, seed=62, rng='philox')
     run_against_oracle(oracle, build, dict(observe_other_suppressant=True), 500, 60, 30, seed=63, rng='mt19937', policy='device')
+
+
+@pytest.mark.parametrize('shape', [(2, 4, 8), (2, 3, 6), (3, 4, 3), (2, 2, 2)])
+def test_fused_random_policy_on_other_shapes(shape):
+    """The fused policy draws agent a from word a % 4 of block a / 4: more than four agents need a second block; exact and runtime-shape
+    field/crew instantiations alike leave what policy launch + step launch leave."""
+    B = 1200
+    build = lambda: configs.wildfire_grid(*shape)
+    two, one = [make_env(build, B, 15, rng='philox', exact_shapes=False) for _ in range(2)]
+    for env in (two, one):
+        env.reset(seed=torch.arange(B, dtype=torch.int32) + 2)
+    for t in range(18):
+        two.step(two.random_policy_actions(policy_seed=8, policy_step=t))
+        live = not bool(one.finished.all())
+        one.step_random_policy(policy_seed=8, policy_step=t)
+        if live:
+            assert torch.equal(two._actions, one._actions), f'{shape}: actions at step {t}'
+        for name in ('_fires', '_intensity', '_fuel', '_suppressants', '_rewards', '_task_offsets', '_act_map_offsets', '_act_map_values'):
+            assert torch.equal(getattr(two, name), getattr(one, name)), f'{shape}: {name} at step {t}'
+    one.check()
