@@ -28,3 +28,16 @@ def test_two_rank_bench_prints_one_contract_line():
     assert line['value'] > 0 and abs(line['value'] - 2 * 65536 * 150 / (line['ms_per_step'] * 150 / 1e3)) / line['value'] < 1e-6
     assert 'cpu_baseline' not in line and 'secondary_workloads' not in line  # rank 0 at N = 1 only
     assert set(line['roofline']) >= {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'}
+
+
+@pytest.mark.gpu
+def test_examples_run(tmp_path):
+    """examples/ are the reference's documented loops on this package: they must keep running as shipped."""
+    done = subprocess.run([sys.executable, os.path.join(ROOT, 'examples', 'baselines_rollout.py'), '3', str(tmp_path / 'logs')], cwd=ROOT,
+                          capture_output=True, text=True, timeout=300)
+    assert done.returncode == 0, done.stderr[-2000:]
+    assert 'StrongestBaseline' in done.stdout and sorted(os.listdir(tmp_path / 'logs')) == ['0.csv', '1.csv', '2.csv']
+    done = subprocess.run([sys.executable, os.path.join(ROOT, 'examples', 'random_rollout.py'), '2048'], cwd=ROOT, capture_output=True, text=True,
+                          timeout=300)
+    assert done.returncode == 0, done.stderr[-2000:]
+    assert all(name in done.stdout for name in ('wildfire', 'cybersecurity', 'rideshare'))
