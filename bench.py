@@ -3,15 +3,23 @@
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-A "step" is one pass of the hot path over one batch: the device-side random policy writes the actions, then the fused
-HIP kernel performs one ParallelEnv.step() for all parallel_envs (action decode, 7 transitions, rewards/termination,
-open action/observation space rebuild).  Episodes are max_steps = 50 long (BASELINE.md protocol); the reset between
-episodes is inside the timed region.  Inputs are resident in HBM; nothing crosses PCIe inside the timed region.
-Prints ONE JSON line (rank 0).
+A "step" is one pass of the hot path over one batch: ONE launch of the fused HIP kernel that samples the uniform random
+policy and performs one ParallelEnv.step() for all parallel_envs (action decode, 7 transitions, rewards / termination,
+open action / observation space rebuild).  Inputs are resident in HBM; nothing crosses PCIe inside the timed region.
+
+Protocol (timed rollouts, median reported).  The K steps are one BLOCK = a rollout loop captured as ONE HIP
+graph: per episode of max_steps = 50 (the last one shorter when K is not a multiple) fresh env seeds, reset, the episode's
+steps, the episode-metrics reduction.  W warm-up steps are run as whole blocks (graph uploaded and warm before any clock starts).
+Then the block is timed R >= 10 times, each time bracketed by barrier + torch.cuda.synchronize() on both sides (N > 1: the
+closing barrier is the job's one collective, the RCCL all-reduce of the block's metrics, followed by the synchronize); the
+per-block times are max-reduced over the ranks and the MEDIAN block is reported: value = N * B * K / median, ms_per_step =
+median / K.  Prints ONE JSON line (rank 0).
 """
 import argparse
 import ctypes
+import hashlib
 import json
+import math
 import os
 import sys
 import time
@@ -26,9 +34,11 @@ import torch  # noqa: E402
 EPISODE = 50          # max_steps of the benchmark protocol
 BATCH_PER_GPU = 65536  # BASELINE.json configs[1]
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PROBE_EPISODES = 4     # whole episodes behind the kernel-level figures (independent of --steps)
+MIN_BLOCKS, TARGET_TIMED_S = 10, 0.05
 
 
-def algorithmic_bytes_per_env_step(HW, A, k, mean_tasks, mean_agent_tasks_sum, injected_randomness=False):
+def wildfire_bytes_per_env_step(HW, A, k, mean_tasks, mean_agent_tasks_sum, injected_randomness=False):
     """reference-visible dtypes, every array read or written once per env-step."""
     state = 2 * (3 * HW * 4 + 3 * A * 4)
     io = 8 * A + 4 * A + 2 * A + 24
@@ -41,91 +51,167 @@ def algorithmic_bytes_per_env_step(HW, A, k, mean_tasks, mean_agent_tasks_sum, i
     return state + io + obs + tasks + obs_map + act_maps + counts + rnd
 
 
-def cpu_baseline(budget_s=12.0, cores=None):
-    """The CPU oracle (scalar C restatement) on a bounded sample of the same workload: same policy, same Philox randomness,
-    same step — reported beside the GPU number, never the thing measured above.  The env-batch axis shards on the host
-    exactly as it does across GPUs: `cores` threads each step their own shard of envs with their own oracle instance
-    (ctypes releases the GIL inside the C calls; no process is forked or exec'd after the GPU was initialised)."""
+def cybersecurity_bytes_per_env_step(N, Att, D, mean_presence_sum):
+    """2(4N + 4D + A) + 8A + 4A + ~10A + 16NA + 2 x sum_a (4 N presence_a + 8); the action maps hold N entries
+    per PRESENT agent (measured mean presence), the observation map N per env."""
+    A = Att + D
+    maps = 4 * N * mean_presence_sum + 8 * A + 4 * N + 8
+    return 2 * (4 * N + 4 * D + A) + 8 * A + 4 * A + 10 * A + 16 * N * A + maps
+
+
+def rideshare_bytes_per_env_step(A, mean_passengers, mean_visible_sum):
+    """2(8A + 44P) + 8A + 4A + 16A + 16A(A-1) + sum_a (32 P_a + 8) + 2 sum_a (8 P_a + 8), with the measured mean
+    live passengers P and visible tasks P_a."""
+    P = mean_passengers
+    return 2 * (8 * A + 44 * P) + 8 * A + 4 * A + 16 * A + 16 * A * (A - 1) + 32 * mean_visible_sum + 8 * A + 2 * (8 * mean_visible_sum + 8 * A)
+
+
+def source_fingerprint():
+    """sha256 over the kernel sources: profiles/hbm_traffic.json records the fingerprint it was measured on."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, 'free-range-zoo_amd', 'csrc')
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith(('.hip', '.h')):
+            h.update(name.encode())
+            h.update(open(os.path.join(csrc, name), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def recorded_traffic(key):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/hbm_traffic.json): PMC counters cannot be collected from
+    inside this process, so the figure is a RECORDED one and is only reported for the kernel build it was measured on."""
+    path = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
+    try:
+        rec = json.load(open(path))
+    except Exception:  # noqa: BLE001
+        return None, None
+    if rec.get('source_fingerprint') != source_fingerprint():
+        return None, f'profiles/hbm_traffic.json was recorded on another kernel build ({rec.get("source_fingerprint")}); not reported'
+    return rec.get(key), f'recorded: {rec.get("how", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes")} (profiles/hbm_traffic.json)'
+
+
+def cpu_baseline(cores, budget_s=8.0):
+    """The CPU oracle (scalar C restatement) on a bounded sample of the same workload: same policy, same Philox randomness, same
+    step — reported beside the GPU number, never the thing measured above.  The env-batch axis shards on the host exactly as it
+    does across GPUs: `cores` threads each step their own shard of envs with their own oracle instance, one C call per episode
+    (ctypes releases the interpreter lock for its duration; no process is forked or exec'd after the GPU was initialised)."""
     import configs
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle
     from free_range_zoo_amd.envs.wildfire.env.structures.configuration import to_cstruct
-    try:
-        available = len(os.sched_getaffinity(0))
-    except AttributeError:  # pragma: no cover
-        available = os.cpu_count() or 1
-    cores = max(1, min(cores or 16, available))
-    shard = 16384
+    shard = 4096
     oracle.lib()
 
     def worker(index):
         cfg = to_cstruct(configs.wildfire_openness(), shard, EPISODE)
         ref = oracle.WildfireOracle(cfg)
         seeds = np.arange(shard, dtype=np.int32) + index * shard
-        steps, t_busy = 0, 0.0
+        episodes = 0
         t_start = time.perf_counter()
         while time.perf_counter() - t_start < budget_s:
             ref.reset()
-            t0 = time.perf_counter()
-            for t in range(EPISODE):
-                actions = oracle.wildfire_random_policy(cfg, ref.agent_task_count, ref.env_task_count, seeds, 7, steps + t)
-                field, agent = oracle.wildfire_philox_randomness(cfg, seeds, ref.num_moves)
-                ref.step(actions, field, agent)
-            t_busy += time.perf_counter() - t0
-            steps += EPISODE
-        return steps, t_busy
+            ref.rollout(seeds + 1000003 * episodes, 20260104, 0, EPISODE)
+            episodes += 1
+        return episodes
 
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=cores) as pool:
-        results = list(pool.map(worker, range(cores)))
+        episodes = sum(pool.map(worker, range(cores)))
     wall = time.perf_counter() - t0
-    total_steps = sum(r[0] for r in results)
     return {
-        'value': shard * total_steps / wall,
+        'value': shard * episodes * EPISODE / wall,
         'unit': 'env-steps/s',
         'cores': cores,
         'kind': 'port',
-        'sample': f'oracle (scalar C restatement): wildfire cfg2, {cores} threads x {shard} envs each, {total_steps // EPISODE} episodes x {EPISODE} '
-                  f'steps in total incl. policy + Philox randomness, {wall:.1f} s wall on {cores} of {os.cpu_count()} host cores',
+        'sample': f'oracle (scalar C restatement): wildfire cfg2, {cores} threads x {shard} envs each, {episodes} episodes x {EPISODE} steps in '
+                  f'total incl. reset, policy and Philox randomness, {wall:.1f} s wall on {cores} of {os.cpu_count()} host cores',
     }
+
+
+def episode_ms(env, steps, policy_seed, reps, device):
+    """Device time of `steps` random-policy steps (no reset inside), by HIP events on the launch stream around a graph replay."""
+    graph = env.capture_random_rollout(steps, policy_seed=policy_seed, include_reset=False)
+    times = []
+    for _ in range(reps):
+        env.reset(seed=torch.arange(env.parallel_envs, dtype=torch.int32))
+        torch.cuda.synchronize(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        graph.replay()
+        e1.record()
+        torch.cuda.synchronize(device)
+        times.append(e0.elapsed_time(e1))
+    del graph
+    return float(np.median(times))
 
 
 def secondary_workloads(device, B):
     """BASELINE.json configs 2 and 3 (parity-test cases, not the bench line): random-policy rollouts of the other two domains at the same
-    batch, whole episodes replayed as HIP graphs, reported beside the headline (never part of `value`)."""
+    batch, reported beside the headline (never part of `value`), each with its own roofline record: whole episodes replayed as HIP
+    graphs for the rate, HIP events around an episode's steps for the step time, task counts averaged over the same episode."""
     import configs
     from free_range_zoo_amd.envs import cybersecurity_v0, rideshare_v0
     out = {}
-    for name, module, configuration, reps in (('cybersecurity_v0 cfg4 (3 nodes, 2+2 agents, agent openness on)', cybersecurity_v0, configs.cyber_openness(), 20),
-                                              ('rideshare_v0 cfg3 (10x10 grid, 8 agents, 2 passengers entering per step)', rideshare_v0,
-                                               configs.rideshare_busy(), 5)):
+    specs = (('cybersecurity_v0 cfg4 (3 nodes, 2+2 agents, agent openness on)', cybersecurity_v0, configs.cyber_openness(), 20),
+             ('rideshare_v0 cfg3 (10x10 grid, 8 agents, 2 passengers entering per step)', rideshare_v0, configs.rideshare_busy(), 5))
+    for name, module, configuration, reps in specs:
         env = module.parallel_env(configuration=configuration, parallel_envs=B, max_steps=EPISODE, device=device, rng='philox', exact_shapes=False)
         env.reset(seed=torch.arange(B, dtype=torch.int32))
         graph = env.capture_random_rollout(EPISODE, policy_seed=20260104, include_reset=True)
         graph.replay()
         torch.cuda.synchronize(device)
-        t0 = time.perf_counter()
+        times = []
         for _ in range(reps):
+            t0 = time.perf_counter()
             graph.replay()
-        torch.cuda.synchronize(device)
-        elapsed = time.perf_counter() - t0
+            torch.cuda.synchronize(device)
+            times.append(time.perf_counter() - t0)
+        elapsed = float(np.median(times))
         env.check()
-        out[name] = {'env_steps_per_s': B * EPISODE * reps / elapsed, 'ms_per_step': 1e3 * elapsed / (EPISODE * reps), 'parallel_envs': B,
-                     'steps': EPISODE * reps}
-        del graph, env
+        del graph
+        step_ms = episode_ms(env, EPISODE, 20260104, 3, device) / EPISODE
+        # mean task counts over one episode (not timed)
+        env.reset(seed=torch.arange(B, dtype=torch.int32))
+        A = len(env.agents)
+        sums = torch.zeros(2, dtype=torch.float64, device=device)
+        for t in range(EPISODE):
+            env.step_random_policy(policy_seed=20260104, policy_step=t)
+            sums[0] += env.environment_task_count.sum()
+            sums[1] += env.agent_task_count.sum()
+        mean_env, mean_agents = (sums / (EPISODE * B)).tolist()
+        if module is cybersecurity_v0:
+            N = env.network_config.num_nodes
+            Att, D = env.attacker_config.num_attackers, env.defender_config.num_defenders
+            per_env = cybersecurity_bytes_per_env_step(N, Att, D, mean_agents / N)
+            kernels = 'cy_step_kernel (policy sampled in the launch)'
+            counts = {'mean_present_agents_per_env': mean_agents / N}
+        else:
+            per_env = rideshare_bytes_per_env_step(A, mean_env, mean_agents)
+            kernels = getattr(env, 'step_kernels', 'rs_step_kernel + rs_policy_kernel')
+            counts = {'mean_passengers_per_env': mean_env, 'mean_visible_tasks_per_env_summed_over_agents': mean_agents}
+        achieved = per_env * B / (step_ms * 1e-3) / 1e9
+        out[name] = {'env_steps_per_s': B * EPISODE / elapsed, 'ms_per_step': 1e3 * elapsed / EPISODE, 'parallel_envs': B, 'steps': EPISODE,
+                     'episodes_timed': reps,
+                     'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                                  'traffic': None, 'kernel': kernels, 'step_ms_avg': step_ms, 'algorithmic_bytes_per_env_step': per_env,
+                                  'how': 'HIP events on the launch stream around one episode of step launches (graph replay, reset outside), '
+                                         'median of 3, divided by 50', **counts}}
+        del env
     return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=2000)
-    ap.add_argument('--warmup', type=int, default=200)
+    ap.add_argument('--steps', type=int, default=500)
+    ap.add_argument('--warmup', type=int, default=100)
     ap.add_argument('--rng', choices=['philox', 'mt19937'], default='philox')
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='parallel_envs per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the cybersecurity / rideshare rollouts reported beside the headline')
     args = ap.parse_args()
+    if args.steps <= 0:
+        raise SystemExit('--steps must be positive')
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -150,14 +236,15 @@ def main():
 
     import configs
     from free_range_zoo_amd.envs import wildfire_v0
-    B = args.batch
+    from free_range_zoo_amd.utils import sharding
+    B, K = args.batch, args.steps
     env = wildfire_v0.parallel_env(configuration=configs.wildfire_openness(), parallel_envs=B, max_steps=EPISODE, device=device,
                                    rng=args.rng, exact_shapes=False)
     A, HW = len(env.agents), env.max_y * env.max_x
-    from free_range_zoo_amd.utils import sharding
     base_seed = sharding.shard_seeds(rank, B)  # seed = global env index = rank * B + i
     metrics = torch.zeros(A + 2, dtype=torch.float64, device=device)  # (sum reward per agent, env-steps, finished)
-    actions = torch.zeros((A, B, 2), dtype=torch.int32, device=device)
+    job_metrics = torch.zeros_like(metrics)                           # what the collective reduces (copied at the end of the graph)
+    policy_seed = 20260104 + rank
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -165,60 +252,51 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    # ---- the block: K steps as ONE graph = per episode (fresh seeds, reset, <= 50 x fused policy+step, episode metrics), metrics copy
+    env.reset(seed=base_seed)
+    seed_stride = torch.tensor(1000003, dtype=torch.int32, device=device)
+    block = env.capture_random_rollout(K, policy_seed=policy_seed, include_reset=True, episode_length=EPISODE, seed_stride=seed_stride,
+                                       metrics=metrics, metrics_copy=job_metrics)
+
+    def run_block():
+        block.replay()
+        if dist is not None:  # the job's one collective; every rank's result needs every rank's contribution: it closes the block
+            sharding.reduce_metrics(job_metrics)
+        torch.cuda.synchronize(device)
+
+    for _ in range(max(1, math.ceil(args.warmup / K))):  # W warm-up steps, in whole blocks (graph uploaded, caches and clocks warm)
+        run_block()
+    repeats = max(MIN_BLOCKS, min(2000, math.ceil(TARGET_TIMED_S / (K * 12e-6 + 40e-6))))
+    block_s = []
+    metrics.zero_()
+    for _ in range(repeats):
+        barrier()
+        t0 = time.perf_counter()
+        run_block()
+        block_s.append(time.perf_counter() - t0)
+    barrier()
+    block_t = torch.tensor(block_s, dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(block_t, op=dist.ReduceOp.MAX)  # MAX over ranks, block by block
+    block_s = block_t.cpu().numpy()
+    median_s = float(np.median(block_s))
+    value = world * B * K / median_s
+    finished_metrics = job_metrics.clone()
+
+    # ---- the drop-in Python API path (env.step_random_policy per call, host-bound), reported beside the headline
     state = {'step': 0, 'episode': 0}
 
-    def episode_metrics():
-        # episode end: the rank's own metrics are accumulated on the device; nothing crosses GPUs on the step path.  The
-        # job's single collective (one RCCL all-reduce of A + 2 doubles over xGMI) runs once, at the end of the timed region.
-        env.accumulate_episode_metrics(metrics)  # one launch: cumulative rewards per agent, env-steps, finished envs
-
     def one_step():
-        """Eager path: the same launches the graphs replay, issued one by one through the Python boundary."""
         if state['step'] % EPISODE == 0:
-            if state['step'] > 0:
-                episode_metrics()
             env.reset(seed=base_seed + 1000003 * state['episode'])
             state['episode'] += 1
-        env.step_random_policy(policy_seed=20260104 + rank, policy_step=state['step'] % EPISODE)
+        env.step_random_policy(policy_seed=policy_seed, policy_step=state['step'] % EPISODE)
         state['step'] += 1
 
-    # ---- timed region: K steps as HIP-graph replays of whole episodes (reset + 50 x (policy, step) per replay)
-    env.reset(seed=base_seed)
-    full = env.capture_random_rollout(EPISODE, policy_seed=20260104 + rank, include_reset=True)
-    rem_steps = args.steps % EPISODE
-    rem = env.capture_random_rollout(rem_steps, policy_seed=20260104 + rank, include_reset=True) if rem_steps else None
-    seed_stride = torch.tensor(1000003, dtype=torch.int32, device=device)
-
-    def run(steps):
-        done = 0
-        while done < steps:
-            env.seeds.add_(seed_stride)  # fresh env seeds for every episode
-            if steps - done >= EPISODE:
-                full.replay()
-                done += EPISODE
-            else:
-                rem.replay()
-                done += steps - done
-            episode_metrics()
-
-    run(max(EPISODE, (args.warmup // EPISODE) * EPISODE))
-    barrier()
-    t0 = time.perf_counter()
-    metrics.zero_()
-    run(args.steps)
-    sharding.reduce_metrics(metrics)  # inside the timed region
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    value = world * B * args.steps / elapsed
-
-    # ---- the drop-in Python API path (env.step per call, host-bound), reported beside the headline
-    api_steps = min(args.steps, 200)
+    api_steps = 4 * EPISODE
     for _ in range(20):
         one_step()
+    state['step'] = 0
     barrier()
     t1 = time.perf_counter()
     for _ in range(api_steps):
@@ -226,86 +304,82 @@ def main():
     barrier()
     api_value = world * B * api_steps / (time.perf_counter() - t1)
 
-    # ---- kernel-level pass (not part of `value`): two HIP events on the launch stream take the step dispatch's own begin
-    # and end timestamps (hipExtLaunchKernel start/stop events: what rocprofv3's kernel trace reports, profiles/) + mean
-    # task counts for the algorithmic bytes
+    # ---- kernel-level pass (not part of `value`; always PROBE_EPISODES whole episodes, whatever --steps is): two HIP events on the
+    # launch stream take each step dispatch's own begin and end timestamps (hipExtLaunchKernel start/stop events: what rocprofv3's
+    # kernel trace reports, profiles/) + mean task counts over the same episodes for the algorithmic bytes
     from free_range_zoo_amd import _capi
     from free_range_zoo_amd.utils.env import stream_ptr
     lib, handle = env._lib, env._handle
     mode = _capi.FRZ_RNG_MT19937 if args.rng == 'mt19937' else _capi.FRZ_RNG_PHILOX
-    n_probe = min(args.steps, 200)
     kernel_ms = []
     task_sum = torch.zeros(1 + A, dtype=torch.float64, device=device)
-    env.reset(seed=base_seed + 17)
     stream = stream_ptr(device)
+    for episode in range(PROBE_EPISODES):
+        env.reset(seed=base_seed + 17 + 1000003 * episode)
+        torch.cuda.synchronize(device)
+        out = (ctypes.c_float * EPISODE)()
+        _capi.check(lib.frz_wildfire_timed_rollout(handle, policy_seed, 0, EPISODE, env._actions.data_ptr(), mode, stream, out), 'frz_wildfire_timed_rollout')
+        kernel_ms.extend(out[i] for i in range(EPISODE))
+    for episode in range(PROBE_EPISODES):  # the same episodes again, step by step, for the task counts (not timed)
+        env.reset(seed=base_seed + 17 + 1000003 * episode)
+        for t in range(EPISODE):
+            lib.frz_wildfire_step_random_policy(handle, policy_seed, t, env._actions.data_ptr(), mode, None, None, stream)
+            task_sum[0] += env.environment_task_count.sum()
+            task_sum[1:] += env.agent_task_count.sum(dim=1)
     torch.cuda.synchronize(device)
-    done = 0
-    while done < n_probe:  # one episode at a time: reset, then the episode's steps back to back, each with its own event pair
-        n = min(EPISODE, n_probe - done)
-        if done > 0:
-            env.seeds.add_(seed_stride)
-            if args.rng == 'mt19937':
-                env.generator._seed_streams(None)
-            lib.frz_wildfire_reset(handle, stream)
-        out = (ctypes.c_float * n)()
-        _capi.check(lib.frz_wildfire_timed_rollout(handle, 20260104 + rank, 0, n, env._actions.data_ptr(), mode, stream, out), 'frz_wildfire_timed_rollout')
-        kernel_ms.extend(out[i] for i in range(n))
-        done += n
-    # mean task counts for the algorithmic bytes: the same episodes again, step by step (not timed)
-    env.reset(seed=base_seed + 17)
-    for i in range(n_probe):
-        if i % EPISODE == 0 and i > 0:
-            env.seeds.add_(seed_stride)
-            if args.rng == 'mt19937':
-                env.generator._seed_streams(None)
-            lib.frz_wildfire_reset(handle, stream)
-        lib.frz_wildfire_step_random_policy(handle, 20260104 + rank, i % EPISODE, env._actions.data_ptr(), mode, None, None, stream)
-        task_sum[0] += env.environment_task_count.sum()
-        task_sum[1:] += env.agent_task_count.sum(dim=1)
-    torch.cuda.synchronize(device)
+    n_probe = PROBE_EPISODES * EPISODE
     kernel_ms_avg = float(np.mean(kernel_ms))
-    kernel_ms_med = float(np.median(kernel_ms))
     mean_tasks = float(task_sum[0].item()) / (n_probe * B)
     mean_agent_tasks = float(task_sum[1:].sum().item()) / (n_probe * B)
-    per_env = algorithmic_bytes_per_env_step(HW, A, env._k, mean_tasks, mean_agent_tasks, injected_randomness=(args.rng == 'mt19937'))
+    per_env = wildfire_bytes_per_env_step(HW, A, env._k, mean_tasks, mean_agent_tasks, injected_randomness=(args.rng == 'mt19937'))
     achieved = per_env * B / (kernel_ms_avg * 1e-3) / 1e9
-    traffic = None
-    traffic_file = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
-    if os.path.exists(traffic_file):
-        try:
-            traffic = json.load(open(traffic_file)).get('wf_step_kernel_bytes_per_launch')
-        except Exception:  # noqa: BLE001
-            traffic = None
+    traffic, traffic_source = recorded_traffic('wf_step_kernel_bytes_per_launch')
 
     if rank == 0:
         env.check()
+        episodes_per_block = math.ceil(K / EPISODE)
         line = {
             'metric': 'env steps/sec (batch x agents) wildfire random-policy',
             'value': value,
             'unit': 'env-steps/s',
             'n_gpus': world,
-            'steps': args.steps,
+            'steps': K,
             'warmup': args.warmup,
-            'ms_per_step': 1e3 * elapsed / args.steps,
+            'ms_per_step': 1e3 * median_s / K,
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
             'dtype': 'i32/f32',
             'data': 'synthetic',
-            'config': {'workload': f'wildfire_v0 cfg2 (2x3 grid, 3 agents, agent+task openness on), batch={B} per GPU, '
-                                   f'max_steps={EPISODE}, uniform random policy sampled inside the step launch, rng={args.rng}, reset inside timed region, one HIP graph replay per episode',
-                       'parallel_envs_per_gpu': B, 'agents': A, 'sharding': f'env-batch axis x{world}, no step-path collective, one metrics all-reduce per run'},
+            'config': {'workload': f'wildfire_v0 cfg2 (2x3 grid, 3 agents, agent+task openness on), batch={B} per GPU, max_steps={EPISODE}, uniform random '
+                                   f'policy sampled inside the step launch, rng={args.rng}',
+                       'parallel_envs_per_gpu': B, 'agents': A,
+                       'sharding': f'env-batch axis x{world}, no step-path collective, one metrics all-reduce per timed block'},
+            'timing': {'protocol': f'{K}-step block = ONE HIP graph ({episodes_per_block} x [reseed, reset, <= {EPISODE} steps, episode metrics]); timed '
+                                   f'{repeats} times, each bracketed by barrier + synchronize; median block over the max-over-ranks times',
+                       'blocks': repeats, 'block_ms_median': 1e3 * median_s, 'block_ms_min': 1e3 * float(block_s.min()),
+                       'block_ms_max': 1e3 * float(block_s.max()), 'block_ms_mean': 1e3 * float(block_s.mean()),
+                       'steps_timed_in_total': repeats * K,
+                       'job_metrics': {'mean_episode_return_per_agent': (finished_metrics[:A] / max(world * B * episodes_per_block * repeats, 1)).tolist(),
+                                       'env_steps_counted': float(finished_metrics[A].item())}},
             'agent_steps_per_s': value * A,
             'python_api_env_steps_per_s': api_value,
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic, 'kernel': 'wf_roles_kernel<6,3,exact,philox,step>' if args.rng == 'philox' else 'wf_roles_kernel<6,3,exact,injected,step>',
-                         'kernel_ms_avg': kernel_ms_avg,
-                         'kernel_ms_median': kernel_ms_med, 'algorithmic_bytes_per_env_step': per_env,
-                         'mean_tasks_per_env': mean_tasks, 'mean_agent_tasks_per_env': mean_agent_tasks},
+                         'traffic': traffic, 'traffic_source': traffic_source,
+                         'kernel': 'wf_roles_kernel<6,3,exact,philox,step>' if args.rng == 'philox' else 'wf_roles_kernel<6,3,exact,mt19937,step>',
+                         'kernel_ms_avg': kernel_ms_avg, 'kernel_ms_median': float(np.median(kernel_ms)), 'launches_timed': n_probe,
+                         'algorithmic_bytes_per_env_step': per_env, 'mean_tasks_per_env': mean_tasks, 'mean_agent_tasks_per_env': mean_agent_tasks,
+                         'frac_at_driver_ms_per_step': per_env * B / (median_s / K) / 1e9 / HBM_PEAK_GBS},
             'reference_cpu_env_steps_per_s': {'value': 21112, 'source': 'BASELINE.md §2: unmodified reference, 8 vCPU, B=65536 (survey container)'},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline()
+            try:
+                available = len(os.sched_getaffinity(0))
+            except AttributeError:  # pragma: no cover
+                available = os.cpu_count() or 1
+            line['cpu_baseline'] = cpu_baseline(available)        # every host core this process may use
+            if available > 16:
+                line['cpu_baseline_16_cores'] = cpu_baseline(16)  # the figure of round 1, for comparison
         if world == 1 and not args.no_secondary:
             line['secondary_workloads'] = secondary_workloads(device, B)
         print(json.dumps(line))

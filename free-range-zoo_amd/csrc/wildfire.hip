@@ -844,14 +844,17 @@ __global__ void __launch_bounds__(kBlock) wf_policy_kernel(const char* arena, ui
 
 // Episode metrics in one launch (the reductions a rollout loop takes after each episode): out[a] += sum_b cumulative
 // reward of agent a, out[A] += sum_b num_moves (env-steps taken), out[A + 1] += envs whose agents are all terminated or all
-// truncated.  Deterministic: each of kMetricBlocks workgroups reduces a fixed slice in a fixed order into its own partial
-// row; the workgroup that arrives last (atomic ticket) adds the rows up in index order.
-constexpr int kMetricBlocks = 64;
+// truncated.  Deterministic: each of the launch's workgroups reduces a fixed slice in a fixed order into its own partial
+// row; the workgroup that arrives last (atomic ticket) adds the rows up in a fixed tree.  Hand-off between workgroups: the
+// partial rows are written and read with agent-scope (L1-bypassing, write-through) accesses, every storing wavefront drains its
+// stores before the workgroup's barrier, one lane then takes the ticket (MI355X_MICROARCH.md, inter-workgroup visibility).
+constexpr int kMetricBlocks = 256;
 
 __global__ void __launch_bounds__(kBlock) wf_metrics_kernel(char* __restrict__ arena, double* __restrict__ out) {
     const WfDev& d = *reinterpret_cast<const WfDev*>(arena);
     const int64_t B = d.B;
     const int A = d.A, nrow = A + 2;
+    const int nblocks = (int)gridDim.x;
     __shared__ double s_part[frz::kWaves][FRZ_MAX_AGENTS + 2];
     __shared__ int s_last;
     const float* rowsf = reinterpret_cast<const float*>(arena + d.off_rows4);
@@ -861,7 +864,7 @@ __global__ void __launch_bounds__(kBlock) wf_metrics_kernel(char* __restrict__ a
     uint32_t* const counter = reinterpret_cast<uint32_t*>(arena + d.off_epoch) + 48;
     double acc[FRZ_MAX_AGENTS + 2];
     for (int i = 0; i < nrow; ++i) acc[i] = 0.0;
-    for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < B; b += (int64_t)kMetricBlocks * kBlock) {
+    for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < B; b += (int64_t)nblocks * kBlock) {
         bool all_term = true, all_trunc = true;
         for (int a = 0; a < A; ++a) {
             acc[a] += (double)rowsf[(int64_t)(d.r_cum + a) * B + b];
@@ -881,21 +884,30 @@ __global__ void __launch_bounds__(kBlock) wf_metrics_kernel(char* __restrict__ a
     if (threadIdx.x < nrow) {
         double v = 0.0;
         for (int w = 0; w < frz::kWaves; ++w) v += s_part[w][threadIdx.x];
-        partial[(int64_t)blockIdx.x * nrow + threadIdx.x] = v;
+        __hip_atomic_store(&partial[(int64_t)blockIdx.x * nrow + threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __threadfence();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wavefront drains before the barrier the ticket follows
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t t = atomicAdd(counter, 1u);
-        s_last = t == kMetricBlocks - 1;
+        s_last = t == (uint32_t)nblocks - 1u;
         if (s_last) atomicExch(counter, 0u);
     }
     __syncthreads();
-    if (s_last && threadIdx.x < nrow) {
-        __threadfence();
-        double v = 0.0;
-        for (int k = 0; k < kMetricBlocks; ++k) v += __hip_atomic_load(&partial[(int64_t)k * nrow + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        out[threadIdx.x] += v;
+    if (s_last) {  // thread t takes partial row t (nblocks <= kBlock); rows are summed lane-tree, then wave 0..3
+        for (int i = 0; i < nrow; ++i) {
+            double v = (int)threadIdx.x < nblocks
+                           ? __hip_atomic_load(&partial[(int64_t)threadIdx.x * nrow + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                           : 0.0;
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0) s_part[wave][i] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < nrow) {
+            double v = 0.0;
+            for (int w = 0; w < frz::kWaves; ++w) v += s_part[w][threadIdx.x];
+            out[threadIdx.x] += v;
+        }
     }
 }
 
@@ -1181,7 +1193,7 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
     p.off_actions = take((int64_t)A * B * 8);
     p.off_error = take(256);
     p.off_epoch = take(256);
-    p.off_metrics = take((int64_t)64 * (FRZ_MAX_AGENTS + 2) * 8);  // partial rows of frz_wildfire_episode_metrics
+    p.off_metrics = take((int64_t)kMetricBlocks * (FRZ_MAX_AGENTS + 2) * 8);  // partial rows of frz_wildfire_episode_metrics
     p.off_totals = take(2 * kTotalsStride * 4);
     p.off_agg = take((int64_t)p.nchunks * p.nch * 8);
     p.off_prefix = take((int64_t)p.nchunks * p.nch * 8);
@@ -1394,7 +1406,8 @@ int frz_wildfire_rollout_random_policy(frz_wildfire_env* env, uint64_t policy_se
 int frz_wildfire_episode_metrics(frz_wildfire_env* env, double* metrics, void* stream) {
     if (!env || !metrics) return FRZ_E_INVALID;
     if (!env->arena) return FRZ_E_UNBOUND;
-    hipLaunchKernelGGL(wf_metrics_kernel, dim3(kMetricBlocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), env->arena, metrics);
+    const int blocks = env->dev.nchunks < kMetricBlocks ? env->dev.nchunks : kMetricBlocks;
+    hipLaunchKernelGGL(wf_metrics_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), env->arena, metrics);
     return hipGetLastError() == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;
 }
 

@@ -320,71 +320,104 @@ class raw_env(BatchedParallelEnv):
         return out
 
     @torch.no_grad()
-    def capture_random_rollout(self, steps: int, policy_seed: int = 0, include_reset: bool = True) -> 'torch.cuda.CUDAGraph':
+    def capture_random_rollout(self, steps: int, policy_seed: int = 0, include_reset: bool = True, episode_length: Optional[int] = None,
+                               seed_stride: Optional[torch.Tensor] = None, metrics: Optional[torch.Tensor] = None,
+                               metrics_copy: Optional[torch.Tensor] = None) -> 'torch.cuda.CUDAGraph':
         """
         Capture ``[reset] + steps x (random policy + step, one launch where the grid shape has a fused kernel)`` into a HIP
         graph and return it.
 
-        Launch-bound rollouts (one ~20 us kernel per step) are replayed with ``graph.replay()`` without per-step host
+        Launch-bound rollouts (one ~10 us kernel per step) are replayed with ``graph.replay()`` without per-step host
         work; results land in the same persistent buffers ``step()`` fills.  The env seeds are read at replay time
         (``env.seeds`` may be changed between replays); the reset inside the graph restores the configured initial
         state (it does not re-run the Python-side ``save_initial``).
+
+        A whole rollout loop as ONE graph: with ``episode_length`` the ``steps`` are cut into episodes, each starting with a
+        reset (policy steps restart at 0); ``seed_stride`` (int32 scalar tensor on the device) is added to ``env.seeds`` before every
+        reset (fresh seeds per episode); ``metrics`` (float64 ``[A + 2]``) receives ``accumulate_episode_metrics`` after every
+        episode and is copied to ``metrics_copy`` at the end of the graph (the buffer a collective then reduces).
         """
         if not self._has_reset:
             raise RuntimeError('reset() must be called once before capturing a rollout')
+        if metrics is not None and (metrics.dtype != torch.float64 or metrics.numel() != len(self.agents) + 2 or not metrics.is_contiguous()):
+            raise ValueError('metrics must be a contiguous float64 [A + 2] tensor on the env device')
         lib, handle, actions = self._lib, self._handle, self._actions.data_ptr()
-        mt = self.rng == 'mt19937'
-        if mt:
-            self.generator._ensure_streams()
-        mode = _capi.FRZ_RNG_MT19937 if mt else _capi.FRZ_RNG_PHILOX
+        mode = self._fused_rng_mode()
+        mt = mode == _capi.FRZ_RNG_MT19937
+        episode = steps if not episode_length else int(episode_length)
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
         # thread-local capture: other threads of the process (e.g. the RCCL watchdog of torch.distributed) may touch the HIP
         # runtime while this thread records the launches
         with torch.cuda.graph(graph, capture_error_mode='thread_local'):
             stream = stream_ptr(self.device)
-            if include_reset:
-                if mt:
-                    _capi.check(lib.frz_mt19937_seed(self._bufs.mt_state, self._bufs.mt_index, self._bufs.seeds, None, 0,
-                                                     self.parallel_envs, stream), 'frz_mt19937_seed')
-                _capi.check(lib.frz_wildfire_reset(handle, stream), 'frz_wildfire_reset')
-            _capi.check(lib.frz_wildfire_rollout_random_policy(handle, policy_seed, 0, steps, actions, mode, stream),
-                        'frz_wildfire_rollout_random_policy')
+            done = 0
+            while done < steps or (steps == 0 and done == 0):
+                n = min(episode, steps - done) if steps else 0
+                if include_reset:
+                    if seed_stride is not None:
+                        self.seeds.add_(seed_stride)
+                    if mt:
+                        _capi.check(lib.frz_mt19937_seed(self._bufs.mt_state, self._bufs.mt_index, self._bufs.seeds, None, 0,
+                                                         self.parallel_envs, stream), 'frz_mt19937_seed')
+                    _capi.check(lib.frz_wildfire_reset(handle, stream), 'frz_wildfire_reset')
+                _capi.check(lib.frz_wildfire_rollout_random_policy(handle, policy_seed, 0 if include_reset else done, n, actions, mode, stream),
+                            'frz_wildfire_rollout_random_policy')
+                if metrics is not None:
+                    _capi.check(lib.frz_wildfire_episode_metrics(handle, metrics.data_ptr(), stream), 'frz_wildfire_episode_metrics')
+                done += n
+                if n == 0:
+                    break
+            if metrics is not None and metrics_copy is not None:
+                metrics_copy.copy_(metrics)
         return graph
+
+    def _fused_rng_mode(self) -> int:
+        """RNG mode of the fused policy + step entry points: they advance the raw per-env device streams, which is what step() draws
+        from only without single_seeding and without a draw buffer (utils/random_generator.py:116-146 semantics need step())."""
+        if self.rng != 'mt19937':
+            return _capi.FRZ_RNG_PHILOX
+        if self.single_seeding or self.generator.buffer_size:
+            raise NotImplementedError('fused rollouts need the per-env device streams (no single_seeding / buffer_size)')
+        self.generator._ensure_streams()
+        return _capi.FRZ_RNG_MT19937
+
+    def _after_fused(self, logged: bool):
+        self._publish()
+        self.infos = {agent: {} for agent in self.agents}
+        self.infos['burnouts'] = self._burnouts
+        self.infos['putouts'] = self._putouts
+        if logged:
+            self._log_environment()
+        return ({agent: self.observations[agent] for agent in self.agents}, self.rewards, self.terminations, self.truncations, self.infos)
 
     @torch.no_grad()
     def step_random_policy(self, policy_seed: int, policy_step: int):
-        """``random_policy_actions`` + ``step`` as one launch (same results as the two calls); actions are left in ``last_actions``."""
+        """``random_policy_actions`` + ``step`` as one launch (same results as the two calls, CSV log rows included); the sampled actions
+        are left in ``self.actions``."""
         if not self._has_reset:
             raise RuntimeError('reset() must be called before step_random_policy()')
-        mt = self.rng == 'mt19937'
-        if mt:
-            self.generator._ensure_streams()
-        mode = _capi.FRZ_RNG_MT19937 if mt else _capi.FRZ_RNG_PHILOX
+        logged = self._logs_this_step()
+        mode = self._fused_rng_mode()
         _capi.check(self._lib.frz_wildfire_step_random_policy(self._handle, policy_seed, policy_step, self._actions.data_ptr(), mode, None, None,
                                                               stream_ptr(self.device)), 'frz_wildfire_step_random_policy')
-        self._publish()
-        self.infos = {agent: {} for agent in self.agents}
-        self.infos['burnouts'] = self._burnouts
-        self.infos['putouts'] = self._putouts
-        return ({agent: self.observations[agent] for agent in self.agents}, self.rewards, self.terminations, self.truncations, self.infos)
+        return self._after_fused(logged)
 
     @torch.no_grad()
     def rollout_random_policy(self, steps: int, policy_seed: int = 0, first_step: int = 0):
-        """``steps`` x ``step_random_policy`` (same results), enqueued by one call through the C boundary."""
+        """``steps`` x ``step_random_policy`` (same results), enqueued by one call through the C boundary.  With ``log_directory`` set the
+        steps are taken one by one so that every one of them reaches the CSV files."""
         if not self._has_reset:
             raise RuntimeError('reset() must be called before rollout_random_policy()')
-        mt = self.rng == 'mt19937'
-        if mt:
-            self.generator._ensure_streams()
-        mode = _capi.FRZ_RNG_MT19937 if mt else _capi.FRZ_RNG_PHILOX
+        if self.logger is not None:
+            out = None
+            for t in range(steps):
+                out = self.step_random_policy(policy_seed, first_step + t)
+            return out if out is not None else self._after_fused(False)
+        mode = self._fused_rng_mode()
         _capi.check(self._lib.frz_wildfire_rollout_random_policy(self._handle, policy_seed, first_step, steps, self._actions.data_ptr(), mode,
                                                                  stream_ptr(self.device)), 'frz_wildfire_rollout_random_policy')
-        self._publish()
-        self.infos = {agent: {} for agent in self.agents}
-        self.infos['burnouts'] = self._burnouts
-        self.infos['putouts'] = self._putouts
-        return ({agent: self.observations[agent] for agent in self.agents}, self.rewards, self.terminations, self.truncations, self.infos)
+        return self._after_fused(False)
 
     @torch.no_grad()
     def accumulate_episode_metrics(self, metrics: torch.Tensor) -> torch.Tensor:

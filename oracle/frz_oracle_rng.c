@@ -356,3 +356,19 @@ void frz_oracle_cyber_focus_policy(const int64_t* tasks, int64_t env_stride, int
         time_focused[b] = focused;
     }
 }
+
+/* CPU-baseline aid (bench.py): n_steps random-policy steps of one env batch, entirely in C — per step the uniform random policy
+ * (frz_oracle_wildfire_random_policy), the step's Philox randomness (frz_oracle_wildfire_philox_randomness) and
+ * frz_oracle_wildfire_step: the loop tests/ and bench.py otherwise drive from Python, one call per episode so that many host
+ * threads can each step their own shard without meeting on the interpreter lock.  actions int32 [A][B][2], field float32
+ * [3][B][H*W], agent float32 [5][B][A]: caller-provided scratch.  Returns the number of steps taken, or a negative error. */
+int frz_oracle_wildfire_rollout(const frz_wildfire_cfg* cfg, frz_oracle_wildfire_bufs* s, const int32_t* env_seeds, uint64_t policy_seed,
+                                uint64_t first_step, int32_t n_steps, int32_t* actions, float* field, float* agent) {
+    for (int32_t t = 0; t < n_steps; ++t) {
+        frz_oracle_wildfire_random_policy(cfg, s->agent_task_count, s->env_task_count, env_seeds, policy_seed, first_step + (uint64_t)t, actions);
+        frz_oracle_wildfire_philox_randomness(cfg, env_seeds, s->num_moves, field, agent);
+        const int rc = frz_oracle_wildfire_step(cfg, s, actions, field, agent);
+        if (rc != 0) return rc < 0 ? rc : -rc;
+    }
+    return n_steps;
+}

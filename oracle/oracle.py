@@ -99,6 +99,19 @@ class WildfireOracle:
         assert actions.shape == (A, B, 2) and fr.size == 3 * B * HW and ar.size == 5 * B * A
         assert lib().frz_oracle_wildfire_step(ctypes.byref(self.cfg), ctypes.byref(self.bufs), _ptr(actions), _ptr(fr), _ptr(ar)) == 0
 
+    def rollout(self, env_seeds: np.ndarray, policy_seed: int, first_step: int, n_steps: int) -> int:
+        """``n_steps`` x (uniform random policy, the step's Philox randomness, step) in ONE C call (the loop smoke() drives from Python);
+        the interpreter lock is released for its whole duration, so host threads stepping their own shards run in parallel."""
+        B, HW, A = self.cfg.parallel_envs, self.cfg.grid_height * self.cfg.grid_width, self.cfg.num_agents
+        if getattr(self, '_scratch', None) is None:
+            self._scratch = (np.zeros((A, B, 2), np.int32), np.zeros((3, B, HW), np.float32), np.zeros((5, B, A), np.float32))
+        actions, field, agent = self._scratch
+        seeds = np.ascontiguousarray(env_seeds, np.int32)
+        done = lib().frz_oracle_wildfire_rollout(ctypes.byref(self.cfg), ctypes.byref(self.bufs), _ptr(seeds), ctypes.c_uint64(policy_seed),
+                                                 ctypes.c_uint64(first_step), ctypes.c_int32(n_steps), _ptr(actions), _ptr(field), _ptr(agent))
+        assert done == n_steps, done
+        return done
+
     # jagged helpers -------------------------------------------------------------------------------------
     def total_tasks(self) -> int:
         return int(self.task_offsets[-1])

@@ -31,6 +31,26 @@ def test_two_rank_bench_prints_one_contract_line():
 
 
 @pytest.mark.gpu
+def test_one_rank_bench_over_rccl():
+    """bench.py under torch.distributed.run with ONE rank and no rehearsal switch: backend 'nccl' (= RCCL) is initialised on device 0 and the
+    job's collectives (the per-block metrics all-reduce, the barriers, the max over ranks) run on the GPU — the N > 1 code path with RCCL
+    itself, as far as one GPU can take it."""
+    env = {k: v for k, v in os.environ.items() if k != 'FRZ_BENCH_SHARE_DEVICE'}
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port', '29533',
+           os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '20', '--warmup', '5', '--no-cpu-baseline', '--no-secondary']
+    done = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert done.returncode == 0, done.stderr[-2000:]
+    lines = [line for line in done.stdout.splitlines() if line.startswith('{')]
+    assert len(lines) == 1, done.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 1 and line['steps'] == 20 and line['warmup'] == 5
+    assert line['timing']['blocks'] >= 10 and line['timing']['block_ms_min'] <= line['timing']['block_ms_median'] <= line['timing']['block_ms_max']
+    assert abs(line['ms_per_step'] * 20 - line['timing']['block_ms_median']) < 1e-9
+    # every timed block stepped every env 20 times and the all-reduced metrics saw all of them
+    assert line['timing']['job_metrics']['env_steps_counted'] == 65536 * 20 * line['timing']['blocks']
+
+
+@pytest.mark.gpu
 def test_examples_run(tmp_path):
     """examples/ are the reference's documented loops on this package: they must keep running as shipped."""
     done = subprocess.run([sys.executable, os.path.join(ROOT, 'examples', 'baselines_rollout.py'), '3', str(tmp_path / 'logs')], cwd=ROOT,

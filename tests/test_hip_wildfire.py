@@ -392,6 +392,41 @@ def test_full_size_properties():
     envs[0].check()
 
 
+def test_cfg5_batch_on_one_gpu_equals_its_shards():
+    """BASELINE.json config 5 (B = 524 288 = 8 x 65 536) stepped on ONE GPU (ticketed path, more chunks than CUs), and the sharding
+    property the 8-GPU run rests on: the envs [r * 65 536, (r + 1) * 65 536) of the big batch, seeded with their global index, go through
+    exactly what rank r's own 65 536-env batch goes through (state, rewards, task lists), env for env."""
+    from free_range_zoo_amd.utils import sharding
+    per_rank, ranks, steps = 65536, 8, 12
+    B = per_rank * ranks
+    big = make_env(configs.wildfire_openness, B, 50, rng='philox', exact_shapes=False)
+    big.reset(seed=torch.arange(B, dtype=torch.int32))
+    shards = {r: make_env(configs.wildfire_openness, per_rank, 50, rng='philox', exact_shapes=False) for r in (0, 5, 7)}
+    for r, env in shards.items():
+        env.reset(seed=sharding.shard_seeds(r, per_rank))
+    for t in range(steps):
+        big.step_random_policy(policy_seed=31, policy_step=t)
+        for env in shards.values():
+            env.step_random_policy(policy_seed=31, policy_step=t)
+    off = big._task_offsets
+    counts = big.environment_task_count
+    assert int(off[0]) == 0 and torch.equal(off[1:] - off[:-1], counts) and torch.equal(counts, (big._fires > 0).sum(dim=0))
+    assert int(big.num_moves.min()) == steps and int(big.num_moves.max()) == steps
+    for r, env in shards.items():
+        lo, hi = sharding.shard_range(r, per_rank)
+        for name in ('_fires', '_intensity', '_fuel', '_suppressants', '_capacity', '_equipment', '_rewards', '_cumulative', '_terminations',
+                     'agent_task_count', '_actions'):
+            assert torch.equal(getattr(big, name)[:, lo:hi], getattr(env, name)), (r, name)
+        assert torch.equal(counts[lo:hi], env.environment_task_count)
+        first, last = int(off[lo]), int(off[hi])
+        assert last - first == int(env._task_offsets[-1])
+        assert torch.equal(big._task_values[first:last], env._task_values[:last - first])
+        for ag in range(3):
+            a0, a1 = int(big._act_map_offsets[ag, lo]), int(big._act_map_offsets[ag, hi])
+            assert torch.equal(big._act_map_values[ag, a0:a1], env._act_map_values[ag, :a1 - a0])
+    big.check()
+
+
 # ------------------------------------------------------------------------------------------------------------
 # 4. boundary behaviour
 # ------------------------------------------------------------------------------------------------------------

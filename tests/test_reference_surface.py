@@ -169,3 +169,45 @@ def test_reference_pickle_loader_refuses_everything_else():
         with pytest.raises(pickle.UnpicklingError):
             load_reference_pickle(payload)
     assert load_reference_pickle(pickle.dumps({'a': torch.arange(3), 'b': (1, 2.5, 'x')}))['a'].tolist() == [0, 1, 2]
+
+
+class _Run:
+    """A pickle whose load would call ``fn(*args)``."""
+
+    def __init__(self, fn, *args):
+        self.fn, self.args = fn, args
+
+    def __reduce__(self):
+        return self.fn, self.args
+
+
+def test_reference_pickle_loader_refuses_code_under_allowed_packages(tmp_path):
+    """Globals are allowed by exact name, not by package prefix: a callable that lives under torch / numpy / collections is refused,
+    and a tensor's storage bytes are read with weights_only=True (torch.storage._load_from_bytes would run a nested full unpickle)."""
+    import collections
+    import io
+    import numpy
+    import torch.utils.collect_env
+    from free_range_zoo_amd.utils.compat import load_reference_pickle
+    marker = tmp_path / 'ran'
+    payloads = [
+        pickle.dumps(_Run(torch.utils.collect_env.run, f'touch {marker}')),
+        pickle.dumps(_Run(numpy.load, str(marker), None, True)),
+        pickle.dumps(_Run(collections.namedtuple, 'x', 'a b')),
+        pickle.dumps(_Run(torch.load, str(marker))),
+        pickle.dumps(_Run(torch.hub.load, 'x', 'y')),
+    ]
+    # the nested route: bytes handed to the storage loader that are themselves a program
+    inner = io.BytesIO()
+    pickle.dump(_Run(os.system, f'touch {marker}'), inner)
+    payloads.append(pickle.dumps(_Run(torch.storage._load_from_bytes, inner.getvalue())))
+    for payload in payloads:
+        with pytest.raises(Exception) as caught:  # UnpicklingError from find_class, or torch's weights_only refusal for the nested bytes
+            load_reference_pickle(payload)
+        assert isinstance(caught.value, (pickle.UnpicklingError, RuntimeError)), caught.value
+        assert not marker.exists()
+    # what a configuration does hold still loads: tensors of several dtypes, a numpy array and scalar, an OrderedDict
+    ok = {'t': torch.arange(6, dtype=torch.int32).reshape(2, 3), 'b': torch.ones(2, dtype=torch.bool), 'f': torch.zeros(2, dtype=torch.float64),
+          'n': numpy.arange(3), 's': numpy.float32(1.5), 'o': collections.OrderedDict(a=1)}
+    got = load_reference_pickle(pickle.dumps(ok))
+    assert got['t'].tolist() == [[0, 1, 2], [3, 4, 5]] and got['n'].tolist() == [0, 1, 2] and float(got['s']) == 1.5 and got['o']['a'] == 1
