@@ -254,14 +254,18 @@ def main():
 
     # ---- the block: K steps as ONE graph = per episode (fresh seeds, reset, <= 50 x fused policy+step, episode metrics), metrics copy
     env.reset(seed=base_seed)
-    seed_stride = torch.tensor(1000003, dtype=torch.int32, device=device)
+    seed_stride = 1000003
     block = env.capture_random_rollout(K, policy_seed=policy_seed, include_reset=True, episode_length=EPISODE, seed_stride=seed_stride,
-                                       metrics=metrics, metrics_copy=job_metrics)
+                                       metrics=metrics, metrics_copy=job_metrics if dist is not None else None)
+    done_event = torch.cuda.Event()
 
     def run_block():
         block.replay()
         if dist is not None:  # the job's one collective; every rank's result needs every rank's contribution: it closes the block
             sharding.reduce_metrics(job_metrics)
+        done_event.record()
+        while not done_event.query():  # poll instead of sleeping in the driver: the wake-up of a blocking wait costs more than a step
+            pass
         torch.cuda.synchronize(device)
 
     for _ in range(max(1, math.ceil(args.warmup / K))):  # W warm-up steps, in whole blocks (graph uploaded, caches and clocks warm)
@@ -281,7 +285,7 @@ def main():
     block_s = block_t.cpu().numpy()
     median_s = float(np.median(block_s))
     value = world * B * K / median_s
-    finished_metrics = job_metrics.clone()
+    finished_metrics = (job_metrics if dist is not None else metrics).clone()
 
     # ---- the drop-in Python API path (env.step_random_policy per call, host-bound), reported beside the headline
     state = {'step': 0, 'episode': 0}
@@ -377,9 +381,10 @@ def main():
                 available = len(os.sched_getaffinity(0))
             except AttributeError:  # pragma: no cover
                 available = os.cpu_count() or 1
-            line['cpu_baseline'] = cpu_baseline(available)        # every host core this process may use
+            # a one-GPU box grants this process a 16-core share of the host (more threads than that gain nothing: both runs are reported)
+            line['cpu_baseline'] = cpu_baseline(min(16, available))
             if available > 16:
-                line['cpu_baseline_16_cores'] = cpu_baseline(16)  # the figure of round 1, for comparison
+                line['cpu_baseline_all_visible_cores'] = cpu_baseline(available, budget_s=5.0)
         if world == 1 and not args.no_secondary:
             line['secondary_workloads'] = secondary_workloads(device, B)
         print(json.dumps(line))

@@ -36,6 +36,7 @@ SIGNATURES = {
     'frz_wildfire_bind': (ctypes.c_int, [_P, _P, _P]),
     'frz_wildfire_get_bufs': (ctypes.c_int, [_P, _P]),
     'frz_wildfire_reset': (ctypes.c_int, [_P, _P]),
+    'frz_wildfire_reset_reseed': (ctypes.c_int, [_P, ctypes.c_int32, _P]),
     'frz_wildfire_rebuild': (ctypes.c_int, [_P, _P]),
     'frz_wildfire_step': (ctypes.c_int, [_P, _P, ctypes.c_int, _P, _P, _P]),
     'frz_wildfire_random_policy': (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_uint64, _P, _P]),
@@ -70,6 +71,8 @@ SIGNATURES = {
     'frz_rideshare_rebuild': (ctypes.c_int, [_P, _P]),
     'frz_rideshare_step': (ctypes.c_int, [_P, _P, _P]),
     'frz_rideshare_random_policy': (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_uint64, _P, _P]),
+    'frz_rideshare_step_random_policy': (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_uint64, _P, _P]),
+    'frz_rideshare_timed_rollout': (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int32, _P, _P, ctypes.POINTER(ctypes.c_float)]),
     'frz_mt19937_seed': (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int64, ctypes.c_int64, _P]),
     'frz_mt19937_generate': (ctypes.c_int, [_P, _P, _P, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _P]),
     'frz_mt19937_generate_pair': (ctypes.c_int, [_P, _P, _P, ctypes.c_int64, ctypes.c_int64, _P, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _P]),

@@ -1,21 +1,29 @@
-// rideshare.hip — fused rideshare environment step for gfx950 (MI355X), one environment per lane.
+// rideshare.hip — rideshare environment step for gfx950 (MI355X): one environment per WAVEFRONT, passenger slots across its lanes.
 //
-// One launch = one ParallelEnv.step() of the reference (rideshare.py:248-467) for the whole batch:
-//   action decode through the open action mapping -> movement -> passenger state (accept-conflict resolution, picks)
-//   -> passenger exit (drops, fares, ordered compaction) -> passenger entry (schedule) -> rewards -> truncation
-//   -> update_actions / update_observations: per-agent visible-task lists compacted with the launch-wide single-pass
-//      prefix scan of frz_scan.h.
+// One ParallelEnv.step() of the reference (rideshare.py:248-467) = three stream-ordered launches:
+//   rs_env_kernel      (wave per env)  action decode through the open action mapping (optionally the uniform random policy, sampled in
+//                                      the launch) -> movement -> passenger state (accept-conflict resolution, picks) -> passenger exit
+//                                      (drops, fares, ordered in-place compaction by ballot + lane rank) -> passenger entry (schedule)
+//                                      -> rewards -> truncation -> agent observations, per-env task counts
+//   rs_offsets_kernel  (lane per env)  launch-wide exclusive prefix sums of the counts (frz_scan.h) -> the jagged offsets + the
+//                                      batch totals the next step's freeze test reads
+//   rs_emit_kernel     (wave per env)  update_actions / update_observations: the env's task rows staged once in LDS, every list
+//                                      (all passengers, each agent's visible ones) compacted by ballot + lane rank and written as
+//                                      CONTIGUOUS 16-byte pieces (one wave store = up to 1 KiB of consecutive bytes)
 //
-// The reference keeps one global passenger table sorted by env and re-sorts / boolean-compacts it every step; here each
-// env owns max_passengers slots in table order, struct-of-arrays [column][slot][B] in the device arena, so that the 64
-// lanes of a wavefront stream slot s of 64 consecutive envs as one 256-byte segment per column.  A lane walks its env's
-// slots three times per step: decode (2 columns), transform + ordered in-place compaction (10 columns), emission of the
-// observation rows (8 columns, re-read from L2).  Deterministic integer/byte work, HBM-bound: no MFMA, no randomness.
+// The reference keeps one global passenger table sorted by env and re-sorts / boolean-compacts it every step; here each env owns
+// max_passengers slots in table order, env-major [B][column][slot]: lane s of the env's wavefront holds slot s (and s + 64 when an env
+// has more than 64 slots), so a column of one env is one coalesced load, per-agent quantities live in lanes 0..A-1 of the same
+// wavefront, and everything that crosses between "slot lanes" and "agent lanes" is a ballot, a readlane or a ds_bpermute: no
+// workgroup barrier anywhere (a 256-thread workgroup is four independent envs).  Deterministic integer/byte work, HBM-bound: no MFMA.
 #include "frz_scan.h"
 
 #include "../../include/frz.h"
 
+#include <hip/hip_ext.h>
+
 #include <algorithm>
+#include <utility>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -27,9 +35,9 @@ using frz::kBlock;
 
 enum Mode { kStep = 0, kRebuild = 1 };
 enum Flag : uint32_t { kFast = 1u << 0, kDiagonal = 1u << 1, kVariableMove = 1u << 2, kWaiting = 1u << 3, kTrackCumulative = 1u << 4, kTruncate = 1u << 5 };
-constexpr int kBatch = 4;  // slots whose loads are in flight together in the three walks over an env's passenger slots
 enum Col { PY = 0, PX, PYD, PXD, PFARE, PSTATE, PDRIVER, PENTERED, PACCEPTED, PPICKED, PCOLS };
 constexpr int kNone = -100;
+constexpr int kEnvsPerBlock = kBlock / 64;  // one env per wavefront
 
 struct RsDev {
     int32_t B, A, P, nchunks, max_steps, pool_limit, long_wait_time, schedule_rows, max_time, first_env_index;
@@ -37,18 +45,43 @@ struct RsDev {
     uint32_t flags;
     float move_cost, drop_cost, noop_cost, accept_cost, pool_limit_cost, general_wait_cost, long_wait_cost;
     int32_t start_y[FRZ_MAX_AGENTS], start_x[FRZ_MAX_AGENTS];
-    int32_t r_agents, r_count, r_moves, r_rewards, r_cum, r_atc, n_rows4;
+    uint32_t inv_others;  // ceil(2^16 / (A - 1)): q / (A - 1) = (q * inv_others) >> 16 for the q < A * (A - 1) the kernels divide
+    int32_t r_count, r_moves, r_rewards, r_cum, r_atc, n_rows4;
     int32_t u_term, u_trunc, u_frozen, n_rows1;
-    int64_t off_rows4, off_rows1, off_passengers, off_etc, off_obs_self, off_obs_others, off_task_values, off_task_offsets,
+    int64_t off_rows4, off_rows1, off_agents, off_passengers, off_etc, off_obs_self, off_obs_others, off_task_values, off_task_offsets,
         off_agent_task_values, off_agent_map_values, off_agent_offsets, off_agent_task_states, off_schedule, off_schedule_index,
         off_actions, off_error, off_epoch, off_totals, off_agg, off_prefix, total_bytes;
 };
 constexpr int64_t kDevBlockBytes = 4096;
 static_assert(sizeof(RsDev) <= kDevBlockBytes, "configuration block too large");
 
-template <typename T>
-__device__ __forceinline__ T& at32(T* base, uint32_t index) {
-    return *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + (uint64_t)(index * (uint32_t)sizeof(T)));
+// the uniform random policy sampled inside rs_env_kernel (frz_rideshare_step_random_policy)
+struct RsPolicy {
+    uint32_t on, seed_lo, seed_hi, step_lo, step_hi;
+    int32_t* actions_out;
+};
+
+// ---- wavefront helpers: lanes 0..63 of ONE env
+__device__ __forceinline__ int lane_rank(uint64_t m) {  // set bits of m below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ int from_lane(int src_lane, int value) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, value); }
+__device__ __forceinline__ int read_lane(int value, int lane) { return __builtin_amdgcn_readlane(value, lane); }
+__device__ __forceinline__ int last_bit(uint64_t m) { return 63 - __builtin_clzll(m); }
+
+// The env a wavefront owns.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 share one); the mapping below gives every
+// run of 32 consecutive envs (one 128-byte line of each [rows][B] array) to workgroups of ONE XCD, so that its L2 merges their 4-byte
+// pieces into whole lines.  Speed only: any bijection is correct.
+__device__ __forceinline__ int64_t env_of_wave(int64_t B) {
+    const uint32_t nblocks = gridDim.x, blk = blockIdx.x;
+    uint32_t quad = blk;
+    const uint32_t group = blk >> 6;
+    if ((group + 1u) * 64u <= nblocks) {
+        const uint32_t l = blk & 63u;
+        quad = (group << 6) + ((l & 7u) << 3) + (l >> 3);
+    }
+    const int64_t b = (int64_t)quad * kEnvsPerBlock + (threadIdx.x >> 6);
+    return b < B ? (int64_t)__builtin_amdgcn_readfirstlane((int)b) : (int64_t)-1;
 }
 
 // schedule rows of one timestep are contiguous in the time-sorted device copy: [index[t], index[t + 1])
@@ -58,514 +91,636 @@ struct Schedule {
     int max_time;
 };
 
-// transitions/passenger_entry.py:24-72 for one env: append the rows of timestep t (this env or wildcard) in schedule order
-template <typename OnEntry>
-__device__ __forceinline__ void passenger_entry(const RsDev& d, const Schedule& sch, int32_t* pas, uint32_t Bu, uint32_t bl, int64_t b,
-                                                int t, int& count, uint32_t& err, bool active, OnEntry on_entry) {
-    if (t < 0 || t > sch.max_time) return;
+// transitions/passenger_entry.py:24-72 for one env: the rows of timestep t (this env or wildcard) are appended in schedule order behind
+// the `count` passengers of the table; 64 schedule rows per pass, their places by ballot + lane rank.  Returns the number appended.
+__device__ __forceinline__ int passenger_entry(const Schedule& sch, int32_t* pas, int P, int b, int t, int count, uint32_t& err) {
+    if (t < 0 || t > sch.max_time) return 0;
+    const int lane = threadIdx.x & 63;
     const int first = sch.index[t], last = sch.index[t + 1];
-    for (int r = first; r < last; ++r) {
-        const int32_t* row = sch.rows + r * 7;
+    int appended = 0;
+    for (int r0 = first; r0 < last; r0 += 64) {
+        const int r = r0 + lane;
+        const bool in = r < last;
+        const int32_t* row = sch.rows + (int64_t)(in ? r : first) * 7;
         const int env = row[1];
-        if (!(env == -1 || env == (int)b)) continue;
-        if (count >= d.P) {
-            if (active) err |= FRZ_ERR_OVERFLOW;
-            continue;
+        const bool match = in && (env == -1 || env == b);
+        const uint64_t m = __ballot(match);
+        if (m == 0) continue;
+        const int pos = count + appended + lane_rank(m);
+        if (match) {
+            if (pos < P) {
+                pas[PY * P + pos] = row[2];
+                pas[PX * P + pos] = row[3];
+                pas[PYD * P + pos] = row[4];
+                pas[PXD * P + pos] = row[5];
+                pas[PFARE * P + pos] = row[6];
+                pas[PSTATE * P + pos] = 0;
+                pas[PDRIVER * P + pos] = -1;
+                pas[PENTERED * P + pos] = t;
+                pas[PACCEPTED * P + pos] = -1;
+                pas[PPICKED * P + pos] = -1;
+            } else {
+                err |= FRZ_ERR_OVERFLOW;
+            }
         }
-        const uint32_t s = (uint32_t)count;
-        if (active) {
-            at32(pas, ((uint32_t)PY * d.P + s) * Bu + bl) = row[2];
-            at32(pas, ((uint32_t)PX * d.P + s) * Bu + bl) = row[3];
-            at32(pas, ((uint32_t)PYD * d.P + s) * Bu + bl) = row[4];
-            at32(pas, ((uint32_t)PXD * d.P + s) * Bu + bl) = row[5];
-            at32(pas, ((uint32_t)PFARE * d.P + s) * Bu + bl) = row[6];
-            at32(pas, ((uint32_t)PSTATE * d.P + s) * Bu + bl) = 0;
-            at32(pas, ((uint32_t)PDRIVER * d.P + s) * Bu + bl) = -1;
-            at32(pas, ((uint32_t)PENTERED * d.P + s) * Bu + bl) = t;
-            at32(pas, ((uint32_t)PACCEPTED * d.P + s) * Bu + bl) = -1;
-            at32(pas, ((uint32_t)PPICKED * d.P + s) * Bu + bl) = -1;
-        }
-        on_entry(t);
-        ++count;
+        appended = min(appended + (int)__popcll(m), P - count);
     }
+    return appended;
 }
 
 // rideshare.py:185-222 + utils/env.py:137-160: agents at their start positions, bookkeeping zeroed, step-0 passengers enter
-__global__ void __launch_bounds__(kBlock) rs_fill_kernel(char* arena) {
-    const RsDev& d = *reinterpret_cast<const RsDev*>(arena);
-    const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x, B = d.B;
-    if (b >= B) return;
-    int32_t* rows = reinterpret_cast<int32_t*>(arena + d.off_rows4);
-    float* rowsf = reinterpret_cast<float*>(arena + d.off_rows4);
-    uint8_t* rows1 = reinterpret_cast<uint8_t*>(arena + d.off_rows1);
-    int32_t* pas = reinterpret_cast<int32_t*>(arena + d.off_passengers);
-    for (int a = 0; a < d.A; ++a) {
-        rows[(d.r_agents + 2 * a) * B + b] = d.start_y[a];
-        rows[(d.r_agents + 2 * a + 1) * B + b] = d.start_x[a];
-        rowsf[(d.r_rewards + a) * B + b] = 0.0f;
-        rowsf[(d.r_cum + a) * B + b] = 0.0f;
-        rows1[(d.u_term + a) * B + b] = 0;
-        rows1[(d.u_trunc + a) * B + b] = 0;
-    }
-    rows[d.r_moves * B + b] = 0;
-    rows1[d.u_frozen * B + b] = 0;
-    const Schedule sch{reinterpret_cast<const int32_t*>(arena + d.off_schedule), reinterpret_cast<const int32_t*>(arena + d.off_schedule_index),
-                       d.max_time};
-    int count = 0;
-    uint32_t err = 0;
-    passenger_entry(d, sch, pas, (uint32_t)B, (uint32_t)b, b, 0, count, err, true, [](int) {});
-    rows[d.r_count * B + b] = count;
-    if (err) atomicOr(reinterpret_cast<uint32_t*>(arena + d.off_error), err);
-}
-
-// diagnostic builds only (tools/exp_skip.sh): -DFRZ_RS_SKIP_MASK=<bits> leaves store groups of the emission pass out
-#ifdef FRZ_RS_SKIP_MASK
-#define FRZ_RS_SKIP(bit) ((FRZ_RS_SKIP_MASK & (bit)) != 0)
-#else
-#define FRZ_RS_SKIP(bit) false
-#endif
-
-template <int AMAX, int MODE>
-__global__ void __launch_bounds__(kBlock) rs_step_kernel(char* __restrict__ arena, const RsDev d, const int32_t* __restrict__ actions,
-                                                          uint32_t ticketed) {
-    // the configuration block arrives BY VALUE (424 bytes of kernel arguments): read through a pointer into the arena, every field
-    // had to be re-read after each store that might alias it — a scalar-memory round trip per use, hundreds per env slot walked
-    __shared__ frz::ScanShared<AMAX + 1> s_scan;
-    __shared__ int s_ticket;
-    // What this step does to each slot of each env, looked up by slot in the ordered pass instead of comparing every agent's target with
-    // every slot: bits 0-4 the (last) agent whose accept won the slot, plus one; bit 5 picked up; bit 6 dropped off.  And the agents' moves,
-    // looked up by a riding passenger's driver.  [slot][lane] / [agent][lane]: a lane only ever reads what it wrote itself.
-    __shared__ uint8_t s_effect[MODE == kStep ? FRZ_MAX_PASSENGERS : 1][kBlock];
-    __shared__ short2 s_move[MODE == kStep ? AMAX : 1][kBlock];  // (dy, dx): |move| < grid size < 2^15 (checked by frz_rideshare_create)
-
-    const int tid = threadIdx.x;
+__global__ void __launch_bounds__(kBlock) rs_fill_kernel(char* __restrict__ arena, const RsDev d) {
+    const int64_t bw = env_of_wave(d.B);
+    if (bw < 0) return;
+    const int b = (int)bw, lane = threadIdx.x & 63;
     const int64_t B = d.B;
-    const uint32_t Bu = (uint32_t)d.B, P = (uint32_t)d.P;
-    const int A = d.A;
-    const uint32_t flags = d.flags;
-    frz::ScanWorkspace ws{reinterpret_cast<uint32_t*>(arena + d.off_epoch), reinterpret_cast<uint32_t*>(arena + d.off_totals),
-                          reinterpret_cast<uint64_t*>(arena + d.off_agg), reinterpret_cast<uint64_t*>(arena + d.off_prefix)};
-    const frz::ScanLaunch launch = frz::scan_begin(ws);
     int32_t* const rows = reinterpret_cast<int32_t*>(arena + d.off_rows4);
     float* const rowsf = reinterpret_cast<float*>(arena + d.off_rows4);
     uint8_t* const rows1 = reinterpret_cast<uint8_t*>(arena + d.off_rows1);
-    int32_t* const pas = reinterpret_cast<int32_t*>(arena + d.off_passengers);
+    int32_t* const pas = reinterpret_cast<int32_t*>(arena + d.off_passengers) + (int64_t)b * PCOLS * d.P;
+    if (lane < d.A) {
+        reinterpret_cast<int2*>(arena + d.off_agents)[(int64_t)b * d.A + lane] = make_int2(d.start_y[lane], d.start_x[lane]);
+        rowsf[(d.r_rewards + lane) * B + b] = 0.0f;
+        rowsf[(d.r_cum + lane) * B + b] = 0.0f;
+        rows1[(d.u_term + lane) * B + b] = 0;
+        rows1[(d.u_trunc + lane) * B + b] = 0;
+    }
     const Schedule sch{reinterpret_cast<const int32_t*>(arena + d.off_schedule), reinterpret_cast<const int32_t*>(arena + d.off_schedule_index),
                        d.max_time};
-    auto pcol = [&](int col, int slot, uint32_t env) -> int32_t& { return at32(pas, ((uint32_t)col * P + (uint32_t)slot) * Bu + env); };
+    uint32_t err = 0;
+    const int count = passenger_entry(sch, pas, d.P, b, 0, 0, err);
+    if (lane == 0) {
+        rows[d.r_moves * B + b] = 0;
+        rows1[d.u_frozen * B + b] = 0;
+        rows[d.r_count * B + b] = count;
+    }
+    if (err) atomicOr(reinterpret_cast<uint32_t*>(arena + d.off_error), err);
+}
 
-    // utils/env.py:211-213 (terminations never set, rideshare.py:252): frozen once every env is truncated.
-    // totals channels A + 1 / A + 2 = number of envs not terminated / not truncated after the previous launch
-    bool frozen = false;
-    if (MODE == kStep) frozen = launch.prev[A + 1] == 0u || launch.prev[A + 2] == 0u;
+// ------------------------------------------------------------------------------------------------------------------------------------
+// rs_env_kernel: everything of a step that concerns ONE env.  SPL = slots per lane (1: up to 64 passenger slots per env, 2: up to 128).
+// "slot-lane" values: lane s holds slot s + 64 * k in element k.  "agent-lane" values: lane a < A holds agent a's value (lanes >= A carry
+// inert values).  A CU has ONE scalar unit for its four SIMDs, so per-agent work is not a scalar loop over the agents: each agent's
+// "passengers I drive" set is a ballot moved into that agent's lane (v_cmp + v_writelane), and everything per agent — the visible set,
+// the index-th visible passenger, the counts of the rebuilt spaces — is vector arithmetic on those masks, all agents at once.  What
+// agents do to slots (accept / pick / drop) and the accept claims travel through two LDS words per slot.
+// ------------------------------------------------------------------------------------------------------------------------------------
+// gfx950 needs two wait states between a vector instruction that writes a scalar register (a ballot's v_cmp) and a vector instruction
+// that reads it; the compiler inserts them for its own instructions but does not look inside an asm statement, hence the s_nop.
+template <int LANE>
+__device__ __forceinline__ uint32_t write_lane_c(uint32_t vec, uint32_t scalar) {  // vec with lane LANE replaced by a wave-uniform value
+    asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(vec) : "s"(scalar), "n"(LANE));
+    return vec;
+}
+template <int LANE>
+__device__ __forceinline__ void write_lane_c(uint32_t& lo, uint32_t& hi, uint64_t scalar) {  // the two halves of a ballot
+    asm("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+        : "+v"(lo), "+v"(hi)
+        : "s"((uint32_t)scalar), "s"((uint32_t)(scalar >> 32)), "n"(LANE));
+}
+template <typename F, int... Is>
+__device__ __forceinline__ void for_each_index(std::integer_sequence<int, Is...>, F&& f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+__device__ __forceinline__ void wave_lds_sync() {  // LDS traffic of one wavefront is in order; this keeps the compiler from reordering it
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
-    {  // one chunk per workgroup (no chunk loop: see wildfire_roles.hip)
-        const int chunk = frz::scan_take_chunk(ws, d.nchunks, ticketed != 0, &s_ticket);
-        const int64_t b = (int64_t)chunk * kBlock + tid;
-        const bool active = b < B;
-        const uint32_t bl = (uint32_t)(active ? b : B - 1);
+// position of the n-th (0-based) set bit of a mask of W 32-bit words, -1 when the mask has no more than n bits: a descent on population
+// counts, per lane, without divergence
+template <int W>
+__device__ __forceinline__ int select_nth(const uint32_t (&mask)[W], int n) {
+    int word = 0, rem = n;
+#pragma unroll
+    for (int i = 0; i + 1 < W; ++i) {
+        const int c = __popc(mask[i]);
+        const bool up = word == i && rem >= c;
+        rem -= up ? c : 0;
+        word += up ? 1 : 0;
+    }
+    uint32_t w = mask[0];
+#pragma unroll
+    for (int i = 1; i < W; ++i) w = word == i ? mask[i] : w;
+    const bool found = n >= 0 && rem < __popc(w);
+    int pos = 32 * word;
+#pragma unroll
+    for (int width = 16; width >= 1; width >>= 1) {
+        const int c = __popc(w & ((1u << width) - 1u));
+        const bool up = rem >= c;
+        rem -= up ? c : 0;
+        w = up ? w >> width : w;
+        pos += up ? width : 0;
+    }
+    return found ? pos : -1;
+}
+template <int W>
+__device__ __forceinline__ int popc_words(const uint32_t (&mask)[W]) {
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < W; ++i) n += __popc(mask[i]);
+    return n;
+}
 
-        if (frozen) {  // the parallel adapter sums the stale rewards once per agent call (utils/conversions.py:87-90)
-            if (active && !at32(rows1, (uint32_t)d.u_frozen * Bu + bl)) {
-                for (int a = 0; a < A; ++a) {
-                    const float r = at32(rowsf, (uint32_t)(d.r_rewards + a) * Bu + bl);
+template <int AMAX, int SPL, int MODE>
+__global__ void __launch_bounds__(kBlock) rs_env_kernel(char* __restrict__ arena, const RsDev d, const int32_t* __restrict__ actions,
+                                                         const RsPolicy pol) {
+    constexpr int W = 2 * SPL;  // 32-bit words of a slot mask
+    __shared__ uint32_t s_claim[kEnvsPerBlock][SPL * 64];   // accepting agents per slot
+    __shared__ uint32_t s_effect[kEnvsPerBlock][SPL * 64];  // (winning agent + 1) << 8 | picked << 1 | dropped << 2
+    __shared__ int4 s_self[kEnvsPerBlock][AMAX];            // the agents' self observation rows
+    const int64_t bw = env_of_wave(d.B);
+    if (bw < 0) return;  // no workgroup barrier in this kernel: a wavefront without an env just leaves
+    const int b = (int)bw, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t B = d.B;
+    const int A = d.A, P = d.P;
+    const uint32_t flags = d.flags;
+    const bool is_agent = lane < A;
+    const int agent = is_agent ? lane : A - 1;  // clamped: unconditional loads
+    int32_t* const rows = reinterpret_cast<int32_t*>(arena + d.off_rows4);
+    float* const rowsf = reinterpret_cast<float*>(arena + d.off_rows4);
+    uint8_t* const rows1 = reinterpret_cast<uint8_t*>(arena + d.off_rows1);
+    int32_t* const pas = reinterpret_cast<int32_t*>(arena + d.off_passengers) + (int64_t)b * PCOLS * P;  // this env's table [column][slot]
+    int2* const agents = reinterpret_cast<int2*>(arena + d.off_agents) + (int64_t)b * A;
+
+    if (MODE == kStep) {
+        // utils/env.py:211-213 (terminations never set, rideshare.py:252): frozen once every env is truncated.  Channels A + 1 / A + 2 of
+        // the batch totals rs_offsets_kernel left after the previous step = number of envs not terminated / not truncated
+        const uint32_t epoch = *reinterpret_cast<const uint32_t*>(arena + d.off_epoch);
+        const uint32_t* prev = reinterpret_cast<const uint32_t*>(arena + d.off_totals) + ((epoch + 1u) & 1u) * frz::kTotalsStride;
+        if (prev[A + 1] == 0u || prev[A + 2] == 0u) {
+            // the parallel adapter sums the stale rewards once per agent call (utils/conversions.py:87-90)
+            if (!rows1[(int64_t)d.u_frozen * B + b]) {
+                if (is_agent) {
+                    const float r = rowsf[(int64_t)(d.r_rewards + lane) * B + b];
                     float acc = 0.0f;
                     for (int j = 0; j < A; ++j) acc = acc + r;
-                    at32(rowsf, (uint32_t)(d.r_rewards + a) * Bu + bl) = acc;
+                    rowsf[(int64_t)(d.r_rewards + lane) * B + b] = acc;
                 }
-                at32(rows1, (uint32_t)d.u_frozen * Bu + bl) = 1;
+                if (lane == 0) rows1[(int64_t)d.u_frozen * B + b] = 1;
             }
             return;
         }
+    }
 
-        int count = at32(rows, (uint32_t)d.r_count * Bu + bl);
-        bool trunc = at32(rows1, (uint32_t)d.u_trunc * Bu + bl) != 0;
-        int ay[AMAX], ax[AMAX];
+    // ---------------------------------------------------------------- loads: the env's table, its agents, their actions
+    const int count0 = rows[(int64_t)d.r_count * B + b];
+    int v[SPL][PCOLS];
+    bool live[SPL];
 #pragma unroll
-        for (int a = 0; a < AMAX; ++a) {
-            ay[a] = a < A ? at32(rows, (uint32_t)(d.r_agents + 2 * a) * Bu + bl) : 0;
-            ax[a] = a < A ? at32(rows, (uint32_t)(d.r_agents + 2 * a + 1) * Bu + bl) : 0;
+    for (int k = 0; k < SPL; ++k) {
+        const int slot = lane + 64 * k;
+        live[k] = slot < count0;
+        const int s = live[k] ? slot : (count0 > 0 ? count0 - 1 : 0);  // dead lanes re-read a live slot's line: no extra traffic
+#pragma unroll
+        for (int c = 0; c < PCOLS; ++c) v[k][c] = pas[c * P + s];
+    }
+    const int2 pos0 = agents[agent];
+    int ay = pos0.x, ax = pos0.y;
+    int nm = 0;
+    int act_idx = 0, act_id = -1;
+    bool trunc = rows1[(int64_t)d.u_trunc * B + b] != 0;
+    if (MODE == kStep) {
+        nm = rows[(int64_t)d.r_moves * B + b];
+        if (!pol.on) {
+            const int2 a2 = reinterpret_cast<const int2*>(actions)[(int64_t)agent * B + b];
+            act_idx = a2.x;
+            act_id = is_agent ? a2.y : -1;
         }
-        uint32_t err = 0;
-        int visible[AMAX], n_accepted[AMAX], n_riding[AMAX];  // per agent: visible tasks, own accepted / riding passengers
+        // the LDS words of this env's slots start clear
 #pragma unroll
-        for (int a = 0; a < AMAX; ++a) visible[a] = n_accepted[a] = n_riding[a] = 0;
+        for (int k = 0; k < SPL; ++k) s_claim[wave][lane + 64 * k] = 0u, s_effect[wave][lane + 64 * k] = 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {  // dead lanes hold no passenger
+        v[k][PSTATE] = live[k] ? v[k][PSTATE] : -1;
+        v[k][PDRIVER] = live[k] ? v[k][PDRIVER] : -2;
+    }
+    // the passengers each agent drives, as a mask in that agent's lane (slot 64 k + 32 h + i = bit i of word 2 k + h)
+    uint32_t driven[W];
+#pragma unroll
+    for (int i = 0; i < W; ++i) driven[i] = 0u;
+    for_each_index(std::make_integer_sequence<int, AMAX>{}, [&](auto ic) {
+        constexpr int a = decltype(ic)::value;
+#pragma unroll
+        for (int k = 0; k < SPL; ++k) {
+            write_lane_c<a>(driven[2 * k], driven[2 * k + 1], __ballot(v[k][PDRIVER] == a));
+        }
+    });
+    uint64_t st0[SPL], st1[SPL], st2[SPL];  // unaccepted / accepted / riding passengers (wave-uniform masks)
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+        st0[k] = __ballot(v[k][PSTATE] == 0);
+        st1[k] = __ballot(v[k][PSTATE] == 1);
+        st2[k] = __ballot(v[k][PSTATE] == 2);
+    }
 
-        if (MODE == kStep) {
-            const int nm = at32(rows, (uint32_t)d.r_moves * Bu + bl);
-            // ---------------------------------------------------------------- (1) action decode (rideshare.py:256-300)
-            int act_idx[AMAX], act_id[AMAX], target[AMAX], seen[AMAX];
+    uint32_t err = 0;
+    uint64_t kept_mask[SPL];  // the slots that stay in the table
 #pragma unroll
-            for (int a = 0; a < AMAX; ++a) {
-                const int2 v = a < A ? reinterpret_cast<const int2*>(actions)[a * B + bl] : make_int2(0, -1);
-                act_idx[a] = v.x;
-                act_id[a] = v.y;
-                target[a] = kNone;
-                seen[a] = 0;
+    for (int k = 0; k < SPL; ++k) kept_mask[k] = __ballot(live[k]);
+    int count = count0, entered = 0;
+    float reward = 0.0f;
+
+    if (MODE == kStep) {
+        // ------------------------------------------------------------ (1) action decode (rideshare.py:256-300)
+        // the agent's action mapping lists, in table order, the passengers that are unaccepted or its own (rideshare.py:378-392): entry i
+        // of the mapping = the i-th set bit of (unaccepted | driven)
+        uint32_t seen[W];
+#pragma unroll
+        for (int k = 0; k < SPL; ++k) {
+            seen[2 * k] = driven[2 * k] | (uint32_t)st0[k];
+            seen[2 * k + 1] = driven[2 * k + 1] | (uint32_t)(st0[k] >> 32);
+        }
+        const int n_visible = popc_words(seen);
+        if (pol.on) {
+            // uniform member of OneOf([Discrete(1, start=state_t) for visible task t] + [noop]) (spaces/actions.py:10-50), the stream
+            // of frz_rideshare_random_policy: word 0 of Philox(counter (agent, global env, step), key seed), all agents at once
+            const frz::Philox4 w = frz::philox4x32_10((uint32_t)lane, (uint32_t)(b + d.first_env_index), pol.step_lo, pol.step_hi, pol.seed_lo, pol.seed_hi);
+            act_idx = (int)(((uint64_t)w.w[0] * (uint64_t)(n_visible + 1)) >> 32);
+        }
+        const int target = is_agent ? select_nth(seen, act_idx) : -1;  // slot of the chosen passenger, -1 = none
+        // a column of the chosen passenger, read from its slot lane (unconditional: a ds_bpermute reads 0 from switched-off lanes)
+        auto of_target = [&](int col) {
+            const int t = target < 0 ? 0 : target;
+            int got = from_lane(t & 63, v[0][col]);
+            if (SPL > 1) {
+                const int hi = from_lane(t & 63, v[SPL - 1][col]);
+                got = t >= 64 ? hi : got;
             }
-            // the agent's action mapping lists, in table order, the passengers that are unaccepted or its own
-            // (rideshare.py:378-392): walk the slots and pick the act_idx-th visible one
-            // (slots are walked kBatch at a time with every load of a batch issued before its first use: a lane-per-env walk is a
-            // chain of dependent memory round trips otherwise; slots past `count` are read from slot P - 1 and ignored)
-            for (int s0 = 0; s0 < count; s0 += kBatch) {
-                int st[kBatch], drv[kBatch];
+            return got;
+        };
+        const int t_state = of_target(PSTATE);
+        if (pol.on) {
+            act_id = (is_agent && target >= 0) ? t_state : -1;
+            if (is_agent) reinterpret_cast<int2*>(pol.actions_out)[(int64_t)lane * B + b] = make_int2(act_idx, act_id);
+        }
+        const bool noop = act_id == -1;
+        const bool valid = is_agent && !noop && target >= 0;  // act_idx inside the mapping
+        if (is_agent && !noop && !valid) err |= FRZ_ERR_BAD_ACTION_INDEX;  // the reference reads a garbage row
+        const bool accept = valid && act_id == 0, pick = valid && act_id == 1, drop = valid && act_id == 2;
+        const bool has_vec = accept || pick || drop;
+        // goal of the task vector: the passenger's position, or its destination for a drop — from the state BEFORE movement
+        const int t_y = of_target(PY), t_x = of_target(PX), t_yd = of_target(PYD), t_xd = of_target(PXD), t_fare = of_target(PFARE);
+        const int gy = drop ? t_yd : t_y, gx = drop ? t_xd : t_x;
+        // ------------------------------------------------------------ (2) movement (transitions/movement.py:56-116)
+        int my = 0, mx = 0;
+        float cost = 0.0f;
+        uint32_t dist2 = 0;  // squared pre-move distance to the goal (coordinates within +-16383: fits): sqrt is monotonic, zero iff zero
+        {
+            const int dy = ay - gy, dx = ax - gx;
+            uint32_t best = (uint32_t)(dy * dy) + (uint32_t)(dx * dx);
+            dist2 = has_vec ? best : 0u;
+            int by = 0, bx = 0;
+            if (flags & kFast) {
+                by = -dy;
+                bx = -dx;
+            } else {  // first minimum over {stay, N, E, S, W(, NW, NE, SE, SW)}
+                const int cy[9] = {0, -1, 0, 1, 0, -1, -1, 1, 1}, cx[9] = {0, 0, 1, 0, -1, -1, 1, 1, -1};
+                const int ndirs = (flags & kDiagonal) ? 9 : 5;
 #pragma unroll
-                for (int u = 0; u < kBatch; ++u) {
-                    const int s = min(s0 + u, (int)P - 1);
-                    st[u] = pcol(PSTATE, s, bl);
-                    drv[u] = pcol(PDRIVER, s, bl);
-                }
-#pragma unroll
-                for (int u = 0; u < kBatch; ++u) {
-                    const int s = s0 + u;
-                    const bool live = s < count;
-#pragma unroll
-                    for (int a = 0; a < AMAX; ++a) {
-                        const bool vis = live && (st[u] == 0 || drv[u] == a);
-                        target[a] = (vis && seen[a] == act_idx[a]) ? s : target[a];
-                        seen[a] += vis ? 1 : 0;
+                for (int k = 1; k < 9; ++k) {
+                    if (k < ndirs) {
+                        const int ey = dy + cy[k], ex = dx + cx[k];
+                        const uint32_t e = (uint32_t)(ey * ey) + (uint32_t)(ex * ex);
+                        const bool better = e < best;
+                        best = better ? e : best;
+                        by = better ? cy[k] : by;
+                        bx = better ? cx[k] : bx;
                     }
                 }
             }
-            bool accept[AMAX], pick[AMAX], drop[AMAX], has_vec[AMAX];
-            int gy[AMAX], gx[AMAX];  // goal of the task vector (passenger position, or destination for a drop)
+            my = has_vec ? by : 0;
+            mx = has_vec ? bx : 0;
+            const float fy = (float)my, fx = (float)mx;
+            cost = (flags & kDiagonal) ? __fsqrt_rn(__fadd_rn(__fmul_rn(fy, fy), __fmul_rn(fx, fx))) : __fadd_rn(fabsf(fy), fabsf(fx));
+            ay += my;
+            ax += mx;
+        }
+        // ------------------------------------------------------------ (3) accept conflicts (passenger_state.py:54-74)
+        // while a passenger is claimed by several accepting agents, per env only the closest of ALL contested agents keeps its claim
+        // (lowest index on ties); uncontested accepts survive.  One pass settles an env.  Claims are counted per slot in LDS.
+        const int tslot = target < 0 ? 0 : target;
+        wave_lds_sync();
+        if (accept) atomicAdd(&s_claim[wave][tslot], 1u);
+        wave_lds_sync();
+        const bool contested = accept && s_claim[wave][tslot] > 1u;
+        const uint64_t contested_mask = __ballot(contested);
+        int winner = -1;
+        if (contested_mask) {  // rare
+            uint32_t best = 0;
 #pragma unroll
-            for (int a = 0; a < AMAX; ++a) {
-                const bool noop = act_id[a] == -1;
-                const bool valid = a < A && !noop && act_idx[a] >= 0 && act_idx[a] < seen[a];
-                if (a < A && !noop && !valid && active) err |= FRZ_ERR_BAD_ACTION_INDEX;  // the reference reads a garbage row
-                accept[a] = valid && act_id[a] == 0;
-                pick[a] = valid && act_id[a] == 1;
-                drop[a] = valid && act_id[a] == 2;
-                has_vec[a] = accept[a] || pick[a] || drop[a];
-                gy[a] = gx[a] = kNone;
-                if (has_vec[a]) {
-                    gy[a] = pcol(drop[a] ? PYD : PY, target[a], bl);
-                    gx[a] = pcol(drop[a] ? PXD : PX, target[a], bl);
+            for (int o = 0; o < AMAX; ++o)
+                if (o < A && ((contested_mask >> o) & 1)) {
+                    const uint32_t d_o = (uint32_t)read_lane((int)dist2, o);
+                    if (winner < 0 || d_o < best) best = d_o, winner = o;
                 }
+        }
+        const bool wins = accept && (!contested || lane == winner);
+        const bool picked = pick && dist2 == 0;   // distance < 1e-6: the agent already stood on the passenger (:88-90)
+        const bool dropped = drop && dist2 == 0;  // transitions/passenger_exit.py:43-46
+        const int fare = dropped ? t_fare : 0;
+        // ------------------------------------------------------------ what this step does to each slot
+        const uint32_t effect = (wins ? (uint32_t)(lane + 1) << 8 : 0u) | (picked ? 2u : 0u) | (dropped ? 4u : 0u);
+        if (effect) atomicOr(&s_effect[wave][tslot], effect);
+        wave_lds_sync();
+        // ------------------------------------------------------------ (2b/3/4) riding passengers follow their driver, winners accept,
+        // picks ride, drops leave (order-preserving compaction: a kept slot's new place = its rank among the kept ones)
+        const int move_word = is_agent ? ((my & 0xFFFF) | (mx << 16)) : 0;
+        uint64_t taken_mask[SPL], boarded_mask[SPL];
+        int place[SPL];
+        bool keep[SPL], moved[SPL], taken[SPL], boarded[SPL];
+        int kept = 0;
+#pragma unroll
+        for (int k = 0; k < SPL; ++k) {
+            const uint32_t e = s_effect[wave][lane + 64 * k];
+            // best_moves[env, driver]; driver -1 wraps to the last agent like Python's index (movement.py:107-108)
+            const int drv0 = v[k][PDRIVER] < 0 ? A + v[k][PDRIVER] : v[k][PDRIVER];
+            const int word = from_lane(drv0 < 0 ? 0 : (drv0 > 63 ? 63 : drv0), move_word);
+            const bool rides = v[k][PSTATE] == 2 && drv0 >= 0 && drv0 < A;
+            const int sy = (int)(short)(word & 0xFFFF), sx = word >> 16;
+            moved[k] = rides && word != 0;
+            v[k][PY] += rides ? sy : 0;
+            v[k][PX] += rides ? sx : 0;
+            taken[k] = live[k] && (e >> 8) != 0u;
+            if (taken[k]) {
+                v[k][PSTATE] = 1;
+                v[k][PACCEPTED] = nm;
+                v[k][PDRIVER] = (int)(e >> 8) - 1;
             }
-            // ---------------------------------------------------------------- (2) movement (transitions/movement.py:56-116)
-            int my[AMAX], mx[AMAX];
-            float cost[AMAX];
-            int64_t dist2[AMAX];  // squared pre-move distance to the goal: sqrt is monotonic, zero iff zero
-#pragma unroll
-            for (int a = 0; a < AMAX; ++a) {
-                my[a] = mx[a] = 0;
-                cost[a] = 0.0f;
-                dist2[a] = 0;
-                if (has_vec[a]) {
-                    const int dy = ay[a] - gy[a], dx = ax[a] - gx[a];
-                    dist2[a] = (int64_t)dy * dy + (int64_t)dx * dx;
-                    if (flags & kFast) {
-                        my[a] = -dy;
-                        mx[a] = -dx;
-                    } else {  // first minimum over {stay, N, E, S, W(, NW, NE, SE, SW)}
-                        int64_t best = dist2[a];
-                        const int cy[9] = {0, -1, 0, 1, 0, -1, -1, 1, 1}, cx[9] = {0, 0, 1, 0, -1, -1, 1, 1, -1};
-                        const int ndirs = (flags & kDiagonal) ? 9 : 5;
-#pragma unroll
-                        for (int k = 1; k < 9; ++k) {
-                            if (k < ndirs) {
-                                const int64_t ey = dy + cy[k], ex = dx + cx[k];
-                                const int64_t e = ey * ey + ex * ex;
-                                const bool better = e < best;
-                                best = better ? e : best;
-                                my[a] = better ? cy[k] : my[a];
-                                mx[a] = better ? cx[k] : mx[a];
-                            }
-                        }
-                    }
-                    const float fy = (float)my[a], fx = (float)mx[a];
-                    cost[a] = (flags & kDiagonal) ? __fsqrt_rn(__fadd_rn(__fmul_rn(fy, fy), __fmul_rn(fx, fx))) : __fadd_rn(fabsf(fy), fabsf(fx));
-                    ay[a] += my[a];
-                    ax[a] += mx[a];
-                }
+            boarded[k] = live[k] && (e & 2u) != 0u;
+            if (boarded[k]) {
+                v[k][PSTATE] = 2;
+                v[k][PPICKED] = nm;
             }
-            // ---------------------------------------------------------------- (3) accept conflicts (passenger_state.py:54-74)
-            // while a passenger is claimed by several accepting agents, per env only the closest of ALL contested agents keeps
-            // its claim (lowest index on ties); uncontested accepts survive.  One pass settles an env.
-            bool wins[AMAX];
-            {
-                bool contested[AMAX];
-                bool any = false;
+            keep[k] = live[k] && !(e & 4u);
+            kept_mask[k] = __ballot(keep[k]);
+            taken_mask[k] = __ballot(taken[k]);
+            boarded_mask[k] = __ballot(boarded[k]);
+            place[k] = kept + lane_rank(kept_mask[k]);
+            kept += (int)__popcll(kept_mask[k]);
+        }
+        // every load of the table has landed before the first store into it (a slot is only ever written at or below its own index,
+        // i.e. where ANOTHER lane's value was read from)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int a = 0; a < AMAX; ++a) {
-                    contested[a] = false;
-#pragma unroll
-                    for (int o = 0; o < AMAX; ++o) contested[a] = contested[a] || (o != a && accept[a] && accept[o] && target[o] == target[a]);
-                    any = any || contested[a];
+        for (int k = 0; k < SPL; ++k)
+            if (keep[k]) {
+                // a slot is rewritten only where it changes: every column once a removal has shifted it, otherwise the columns this step touched
+                const bool shifted = place[k] != lane + 64 * k;
+                const int at = place[k];
+                if (shifted || moved[k]) {
+                    pas[PY * P + at] = v[k][PY];
+                    pas[PX * P + at] = v[k][PX];
                 }
-                int winner = -1;
-                int64_t best = 0;
-#pragma unroll
-                for (int a = 0; a < AMAX; ++a) {
-                    const bool better = contested[a] && (winner < 0 || dist2[a] < best);
-                    best = better ? dist2[a] : best;
-                    winner = better ? a : winner;
+                if (shifted) {
+                    pas[PYD * P + at] = v[k][PYD];
+                    pas[PXD * P + at] = v[k][PXD];
+                    pas[PFARE * P + at] = v[k][PFARE];
+                    pas[PENTERED * P + at] = v[k][PENTERED];
                 }
-#pragma unroll
-                for (int a = 0; a < AMAX; ++a) wins[a] = accept[a] && (!contested[a] || a == winner);
-                (void)any;
+                if (shifted || taken[k] || boarded[k]) pas[PSTATE * P + at] = v[k][PSTATE];
+                if (shifted || taken[k]) {
+                    pas[PDRIVER * P + at] = v[k][PDRIVER];
+                    pas[PACCEPTED * P + at] = v[k][PACCEPTED];
+                }
+                if (shifted || boarded[k]) pas[PPICKED * P + at] = v[k][PPICKED];
             }
-            bool picked[AMAX], dropped[AMAX];
-            int fares[AMAX];
+        // ------------------------------------------------------------ (5) entry of the next timestep (rideshare.py:308)
+        const Schedule sch{reinterpret_cast<const int32_t*>(arena + d.off_schedule), reinterpret_cast<const int32_t*>(arena + d.off_schedule_index),
+                           d.max_time};
+        entered = passenger_entry(sch, pas, P, b, nm + 1, kept, err);
+        count = kept + entered;
+        // ------------------------------------------------------------ the new table as masks over the OLD slot numbers (counts do not care)
 #pragma unroll
-            for (int a = 0; a < AMAX; ++a) {
-                picked[a] = pick[a] && dist2[a] == 0;    // distance < 1e-6: the agent already stood on the passenger (:88-90)
-                dropped[a] = drop[a] && dist2[a] == 0;   // transitions/passenger_exit.py:43-46
-                fares[a] = dropped[a] ? pcol(PFARE, target[a], bl) : 0;
-            }
-            // the slot effects of this step (cleared cooperatively: the table is per launch)
-            {
-                uint4* const table = reinterpret_cast<uint4*>(&s_effect[0][0]);
-                for (uint32_t i = (uint32_t)tid; i < P * (kBlock / 16); i += kBlock) table[i] = make_uint4(0, 0, 0, 0);
-                __syncthreads();
+        for (int k = 0; k < SPL; ++k) {
+            st0[k] = st0[k] & ~taken_mask[k] & ~boarded_mask[k] & kept_mask[k];
+            st1[k] = ((st1[k] | taken_mask[k]) & ~boarded_mask[k]) & kept_mask[k];
+            st2[k] = (st2[k] | boarded_mask[k]) & kept_mask[k];
+        }
+        // an accepted passenger had no driver or this one (it was visible to the agent): the winner's bit joins its driven set
+        {
+            const uint32_t bit = wins ? 1u << (tslot & 31) : 0u;
+            const int word = tslot >> 5;
 #pragma unroll
-                for (int a = 0; a < AMAX; ++a) {
-                    const bool any = wins[a] || picked[a] || dropped[a];
-                    if (any) {
-                        uint32_t e = s_effect[target[a]][tid];
-                        e = wins[a] ? ((e & ~31u) | (uint32_t)(a + 1)) : e;
-                        e |= (picked[a] ? 32u : 0u) | (dropped[a] ? 64u : 0u);
-                        s_effect[target[a]][tid] = (uint8_t)e;
+            for (int i = 0; i < W; ++i) driven[i] |= word == i ? bit : 0u;
+        }
+        // ------------------------------------------------------------ (6) rewards (rideshare.py:310-363)
+        int unaccepted = entered;
+#pragma unroll
+        for (int k = 0; k < SPL; ++k) unaccepted += (int)__popcll(st0[k]);
+        float global = 0.0f;
+        if (flags & kWaiting) {
+            // `global_rewards[envs] += cost` is an index_put without accumulation: per statement only the LAST passenger (table order) of
+            // the env in that state takes effect (:323-333); the passengers that just entered are the last unaccepted ones
+            auto last_wait = [&](const uint64_t (&mask)[SPL], int since_col, bool& any) {
+                int wait = 0;
+                any = false;
+#pragma unroll
+                for (int k = 0; k < SPL; ++k)
+                    if (mask[k]) {
+                        wait = nm - read_lane(v[k][since_col], last_bit(mask[k]));
+                        any = true;
                     }
-                    s_move[a][tid] = make_short2((short)my[a], (short)mx[a]);
-                }
-            }
-            // ---------------------------------------------------------------- (2b/3/4) one ordered pass over the env's slots:
-            // riding passengers follow their driver, winners accept, picks ride, drops leave (order-preserving compaction)
-            int kept = 0, unaccepted = 0;
-            int wait_last[3] = {0, 0, 0};
-            bool has_state[3] = {false, false, false};
-            int owned[AMAX];  // passengers whose driver is agent a, any state (rideshare.py:343-344)
-            // per-agent counters packed one byte per agent (a count is at most max_passengers <= 128): [0] driver == a, [1] accepted by a,
-            // [2] riding with a, [3] driver == a and not unaccepted (the visible-but-not-general ones)
-            constexpr int KW = (AMAX + 7) / 8;
-            uint64_t tally[4][KW];
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int w = 0; w < KW; ++w) tally[k][w] = 0;
-            auto settle_slot = [&](const int s, const int (&was)[PCOLS], const uint32_t effect) {
-                int v[PCOLS];
-#pragma unroll
-                for (int c = 0; c < PCOLS; ++c) v[c] = was[c];
-                if (v[PSTATE] == 2) {  // best_moves[env, driver]; driver -1 wraps to the last agent like Python's index
-                    const int drv = v[PDRIVER] < 0 ? A + v[PDRIVER] : v[PDRIVER];
-                    const short2 move = s_move[min(max(drv, 0), AMAX - 1)][tid];
-                    const bool real = drv >= 0 && drv < AMAX;
-                    v[PY] += real ? move.x : 0;
-                    v[PX] += real ? move.y : 0;
-                }
-                const int winner = (int)(effect & 31u) - 1;
-                if (winner >= 0) {
-                    v[PSTATE] = 1;
-                    v[PACCEPTED] = nm;
-                    v[PDRIVER] = winner;
-                }
-                if (effect & 32u) {
-                    v[PSTATE] = 2;
-                    v[PPICKED] = nm;
-                }
-                const bool removed = (effect & 64u) != 0;
-                if (!removed) {
-                    if (active) {
-                        // a slot is rewritten only where it changes: every column once a removal has shifted the table
-                        // (kept < s), otherwise just the columns this step touched (most slots: none)
-                        const bool shifted = kept != s;
-#pragma unroll
-                        for (int c = 0; c < PCOLS; ++c)
-                            if (shifted || v[c] != was[c]) pcol(c, kept, bl) = v[c];
-                    }
-                    const int st = v[PSTATE];
-                    const int since = st == 0 ? v[PENTERED] : (st == 1 ? v[PACCEPTED] : v[PPICKED]);
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        wait_last[k] = st == k ? nm - since : wait_last[k];
-                        has_state[k] = has_state[k] || st == k;
-                    }
-                    unaccepted += st == 0 ? 1 : 0;
-                    const int drv = v[PDRIVER];
-#pragma unroll
-                    for (int w = 0; w < KW; ++w) {
-                        const int local = drv - 8 * w;
-                        const uint64_t one = (local >= 0 && local < 8) ? (uint64_t)1 << (8 * local) : (uint64_t)0;
-                        tally[0][w] += one;
-                        tally[1][w] += st == 1 ? one : (uint64_t)0;
-                        tally[2][w] += st == 2 ? one : (uint64_t)0;
-                        tally[3][w] += st != 0 ? one : (uint64_t)0;
-                    }
-                    ++kept;
-                }
+                return wait;
             };
-            for (int s0 = 0; s0 < count; s0 += kBatch) {
-                int was[kBatch][PCOLS];
-                uint32_t effect[kBatch];
-#pragma unroll
-                for (int u = 0; u < kBatch; ++u) {
-                    const int s = min(s0 + u, (int)P - 1);
-#pragma unroll
-                    for (int c = 0; c < PCOLS; ++c) was[u][c] = pcol(c, s, bl);
-                    effect[u] = s_effect[s][tid];
-                }
-                // a slot is only ever written at or below its own index (kept <= s), so the batch's loads see the old table
-#pragma unroll
-                for (int u = 0; u < kBatch; ++u)
-                    if (s0 + u < count) settle_slot(s0 + u, was[u], effect[u]);
-            }
-            count = kept;
-            // unpack the tallies (visible = the unaccepted ones, seen by every agent, plus the agent's own accepted / riding ones)
-#pragma unroll
-            for (int a = 0; a < AMAX; ++a) {
-                const int w = a >> 3, sh = 8 * (a & 7);
-                owned[a] = (int)((tally[0][w] >> sh) & 0xFFu);
-                n_accepted[a] = (int)((tally[1][w] >> sh) & 0xFFu);
-                n_riding[a] = (int)((tally[2][w] >> sh) & 0xFFu);
-                visible[a] = unaccepted + (int)((tally[3][w] >> sh) & 0xFFu);
-            }
-            // ---------------------------------------------------------------- (5) entry of the next timestep (rideshare.py:308)
-            passenger_entry(d, sch, pas, Bu, bl, b, nm + 1, count, err, active, [&](int t) {
-                wait_last[0] = nm - t;
-                has_state[0] = true;
-                ++unaccepted;
-#pragma unroll
-                for (int a = 0; a < AMAX; ++a) visible[a] += 1;
-            });
-            // ---------------------------------------------------------------- (6) rewards (rideshare.py:310-363)
-            float global = 0.0f;
-            if (flags & kWaiting) {
-                // `global_rewards[envs] += cost` is an index_put without accumulation: per statement only the LAST passenger
-                // (table order) of the env in that state takes effect (:323-333)
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    if (has_state[k]) global = __fadd_rn(global, __fmul_rn(wait_last[k] >= d.wait_limit[k] ? 1.0f : 0.0f, d.general_wait_cost));
-                if (has_state[0]) global = __fadd_rn(global, __fmul_rn(wait_last[0] >= d.long_wait_time ? 1.0f : 0.0f, d.long_wait_cost));
-                const int slots = A * d.pool_limit;
-                global = __fadd_rn(global, __fmul_rn(__fmul_rn(unaccepted >= slots - count ? 1.0f : 0.0f, -0.5f), (float)(slots - count)));
-            }
-            const int nm1 = nm + 1;
-            trunc = (flags & kTruncate) ? nm1 >= d.max_steps : trunc;
-            if (active) {
-#pragma unroll
-                for (int a = 0; a < AMAX; ++a) {
-                    if (a < A) {
-                        float r = 0.0f;
-                        r = __fadd_rn(r, owned[a] > d.pool_limit ? d.pool_limit_cost : 0.0f);
-                        r = __fadd_rn(r, __fmul_rn(act_id[a] == -1 ? 1.0f : 0.0f, d.noop_cost));
-                        r = __fadd_rn(r, __fmul_rn(act_id[a] == 0 ? 1.0f : 0.0f, d.accept_cost));  // the accept ACTION, won or not
-                        r = __fadd_rn(r, fares[a] > 0 ? __fsub_rn((float)fares[a], d.drop_cost) : 0.0f);
-                        float dr = __fmul_rn(cost[a], d.move_cost);
-                        if (flags & kVariableMove) dr = __fdiv_rn(dr, (float)(owned[a] + 1));
-                        r = __fadd_rn(r, dr);
-                        r = __fadd_rn(r, global);
-                        at32(rowsf, (uint32_t)(d.r_rewards + a) * Bu + bl) = r;
-                        if (flags & kTrackCumulative) {
-                            float& cum = at32(rowsf, (uint32_t)(d.r_cum + a) * Bu + bl);
-                            cum = __fadd_rn(cum, r);
-                        }
-                        if (flags & kTruncate) at32(rows1, (uint32_t)(d.u_trunc + a) * Bu + bl) = (uint8_t)trunc;
-                        at32(rows, (uint32_t)(d.r_agents + 2 * a) * Bu + bl) = ay[a];
-                        at32(rows, (uint32_t)(d.r_agents + 2 * a + 1) * Bu + bl) = ax[a];
-                    }
-                }
-                at32(rows, (uint32_t)d.r_moves * Bu + bl) = nm1;
-                at32(rows, (uint32_t)d.r_count * Bu + bl) = count;
-            }
-        } else {
-            // rebuild only: statistics of the table as it stands
-            for (int s = 0; s < count; ++s) {
-                const int st = pcol(PSTATE, s, bl), drv = pcol(PDRIVER, s, bl);
-#pragma unroll
-                for (int a = 0; a < AMAX; ++a) {
-                    visible[a] += (st == 0 || drv == a) ? 1 : 0;
-                    n_accepted[a] += (st == 1 && drv == a) ? 1 : 0;
-                    n_riding[a] += (st == 2 && drv == a) ? 1 : 0;
-                }
-            }
+            bool any0, any1, any2;
+            int w0 = last_wait(st0, PENTERED, any0);
+            const int w1 = last_wait(st1, PACCEPTED, any1), w2 = last_wait(st2, PPICKED, any2);
+            if (entered > 0) w0 = nm - (nm + 1), any0 = true;
+            if (any0) global = __fadd_rn(global, __fmul_rn(w0 >= d.wait_limit[0] ? 1.0f : 0.0f, d.general_wait_cost));
+            if (any1) global = __fadd_rn(global, __fmul_rn(w1 >= d.wait_limit[1] ? 1.0f : 0.0f, d.general_wait_cost));
+            if (any2) global = __fadd_rn(global, __fmul_rn(w2 >= d.wait_limit[2] ? 1.0f : 0.0f, d.general_wait_cost));
+            if (any0) global = __fadd_rn(global, __fmul_rn(w0 >= d.long_wait_time ? 1.0f : 0.0f, d.long_wait_cost));
+            const int slots = A * d.pool_limit;
+            global = __fadd_rn(global, __fmul_rn(__fmul_rn(unaccepted >= slots - count ? 1.0f : 0.0f, -0.5f), (float)(slots - count)));
         }
-
-        // ======================================================================================================
-        // update_actions + update_observations (rideshare.py:367-467)
-        // ======================================================================================================
-        uint32_t cnt[AMAX + 1], excl[AMAX + 1];
-        cnt[0] = active ? (uint32_t)count : 0u;
+        int owned = 0;  // passengers whose driver is this agent, any state (rideshare.py:343-344)
 #pragma unroll
-        for (int a = 0; a < AMAX; ++a) cnt[a + 1] = (active && a < A) ? (uint32_t)visible[a] : 0u;
-        frz::scan_chunk<AMAX + 1>(s_scan, ws, launch, cnt, active, active && !trunc, A + 1, chunk, d.nchunks, excl, &err);
-
-        if (active) {
-            const int64_t cap = B * (int64_t)P;
-            int32_t* const obs_self = reinterpret_cast<int32_t*>(arena + d.off_obs_self);
-            int32_t* const obs_others = reinterpret_cast<int32_t*>(arena + d.off_obs_others);
-            int64_t* const etc = reinterpret_cast<int64_t*>(arena + d.off_etc);
-            int32_t* const task_values = reinterpret_cast<int32_t*>(arena + d.off_task_values);
-            int64_t* const task_offsets = reinterpret_cast<int64_t*>(arena + d.off_task_offsets);
-            int32_t* const agent_tasks = reinterpret_cast<int32_t*>(arena + d.off_agent_task_values);
-            int64_t* const agent_maps = reinterpret_cast<int64_t*>(arena + d.off_agent_map_values);
-            int64_t* const agent_offsets = reinterpret_cast<int64_t*>(arena + d.off_agent_offsets);
-            int32_t* const agent_states = reinterpret_cast<int32_t*>(arena + d.off_agent_task_states);
-            // agent observations: self = (y, x, #accepted, #riding); others = the other agents' self rows (:427-463)
-#pragma unroll
-            for (int a = 0; a < AMAX; ++a) {
-                if (a < A) {
-                    reinterpret_cast<int4*>(obs_self)[a * B + b] = make_int4(ay[a], ax[a], n_accepted[a], n_riding[a]);
-                    int4* others = reinterpret_cast<int4*>(obs_others) + (a * B + b) * (int64_t)(A - 1);
-                    int j = 0;
-#pragma unroll
-                    for (int o = 0; o < AMAX; ++o)
-                        if (o < A && o != a) others[j++] = make_int4(ay[o], ax[o], n_accepted[o], n_riding[o]);
-                    at32(rows, (uint32_t)(d.r_atc + a) * Bu + bl) = visible[a];
-                    agent_offsets[a * (B + 1) + b] = excl[a + 1];
-                    if (b == B - 1) agent_offsets[a * (B + 1) + B] = (int64_t)excl[a + 1] + visible[a];
-                }
+        for (int k = 0; k < SPL; ++k)
+            owned += __popc(driven[2 * k] & (uint32_t)kept_mask[k]) + __popc(driven[2 * k + 1] & (uint32_t)(kept_mask[k] >> 32));
+        float r = 0.0f;
+        r = __fadd_rn(r, owned > d.pool_limit ? d.pool_limit_cost : 0.0f);
+        r = __fadd_rn(r, __fmul_rn(act_id == -1 ? 1.0f : 0.0f, d.noop_cost));
+        r = __fadd_rn(r, __fmul_rn(act_id == 0 ? 1.0f : 0.0f, d.accept_cost));  // the accept ACTION, won or not
+        r = __fadd_rn(r, fare > 0 ? __fsub_rn((float)fare, d.drop_cost) : 0.0f);
+        float dr = __fmul_rn(cost, d.move_cost);
+        if (flags & kVariableMove) dr = __fdiv_rn(dr, (float)(owned + 1));
+        r = __fadd_rn(r, dr);
+        reward = __fadd_rn(r, global);
+        const int nm1 = nm + 1;
+        trunc = (flags & kTruncate) ? nm1 >= d.max_steps : trunc;
+        if (is_agent) {
+            rowsf[(int64_t)(d.r_rewards + lane) * B + b] = reward;
+            if (flags & kTrackCumulative) {
+                float* const cum = rowsf + (int64_t)(d.r_cum + lane) * B + b;
+                *cum = __fadd_rn(*cum, reward);
             }
-            etc[b] = count;
-            task_offsets[b] = excl[0];
-            if (b == B - 1) task_offsets[B] = (int64_t)excl[0] + count;
-            // task rows (y, x, y_dest, x_dest, accepted_by | -100, riding_by | -100, fare, entered) (:405-414)
-            int next[AMAX];
-#pragma unroll
-            for (int a = 0; a < AMAX; ++a) next[a] = 0;
-            auto emit_slot = [&](const int s, const int st, const int drv, const int4 lo, const int4 hi) {
-                int4* row = reinterpret_cast<int4*>(task_values) + ((int64_t)excl[0] + s) * 2;
-                if (!FRZ_RS_SKIP(2)) {
-                    row[0] = lo;
-                    row[1] = hi;
-                }
-#pragma unroll
-                for (int a = 0; a < AMAX; ++a) {
-                    if (!FRZ_RS_SKIP(1) && a < A && (st == 0 || drv == a)) {  // general or exclusive task of agent a (:378-380)
-                        const int64_t at = a * cap + (int64_t)excl[a + 1] + next[a];
-                        int4* arow = reinterpret_cast<int4*>(agent_tasks) + at * 2;
-                        arow[0] = lo;
-                        arow[1] = hi;
-                        agent_maps[at] = s;
-                        agent_states[at] = st;
-                        ++next[a];
-                    }
-                }
-            };
-            for (int s0 = 0; s0 < (FRZ_RS_SKIP(4) ? 0 : count); s0 += kBatch) {
-                int st[kBatch], drv[kBatch];
-                int4 lo[kBatch], hi[kBatch];
-#pragma unroll
-                for (int u = 0; u < kBatch; ++u) {
-                    const int s = min(s0 + u, (int)P - 1);
-                    st[u] = pcol(PSTATE, s, bl);
-                    drv[u] = pcol(PDRIVER, s, bl);
-                    lo[u] = make_int4(pcol(PY, s, bl), pcol(PX, s, bl), pcol(PYD, s, bl), pcol(PXD, s, bl));
-                    hi[u] = make_int4(0, 0, pcol(PFARE, s, bl), pcol(PENTERED, s, bl));
-                }
-#pragma unroll
-                for (int u = 0; u < kBatch; ++u) {
-                    hi[u].x = st[u] == 1 ? drv[u] : kNone;
-                    hi[u].y = st[u] == 2 ? drv[u] : kNone;
-                    if (s0 + u < count) emit_slot(s0 + u, st[u], drv[u], lo[u], hi[u]);
-                }
-            }
+            if (flags & kTruncate) rows1[(int64_t)(d.u_trunc + lane) * B + b] = (uint8_t)trunc;
+            agents[lane] = make_int2(ay, ax);
         }
-        if (err) atomicOr(reinterpret_cast<uint32_t*>(arena + d.off_error), err);
-        frz::scan_end(ws, launch, chunk, d.nchunks);
+        if (lane == 0) {
+            rows[(int64_t)d.r_moves * B + b] = nm1;
+            rows[(int64_t)d.r_count * B + b] = count;
+        }
+    }
+
+    // ---------------------------------------------------------------- per-env outputs of update_actions / update_observations that are
+    // not lists (rideshare.py:427-463): counts, self = (y, x, #accepted, #riding), others = the other agents' self rows
+    int n_accepted = 0, n_riding = 0, visible = entered;  // agent-lane
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+        const uint32_t lo = driven[2 * k] & (uint32_t)kept_mask[k], hi = driven[2 * k + 1] & (uint32_t)(kept_mask[k] >> 32);
+        n_accepted += __popc(lo & (uint32_t)st1[k]) + __popc(hi & (uint32_t)(st1[k] >> 32));
+        n_riding += __popc(lo & (uint32_t)st2[k]) + __popc(hi & (uint32_t)(st2[k] >> 32));
+        // visible = unaccepted or driven by the agent
+        visible += __popc(lo | (uint32_t)st0[k]) + __popc(hi | (uint32_t)(st0[k] >> 32));
+    }
+    const int4 self = make_int4(ay, ax, n_accepted, n_riding);
+    if (is_agent) {
+        reinterpret_cast<int4*>(arena + d.off_obs_self)[(int64_t)lane * B + b] = self;
+        rows[(int64_t)(d.r_atc + lane) * B + b] = visible;
+        s_self[wave][lane] = self;
+    }
+    wave_lds_sync();
+    {   // others[a][j] = self of the j-th other agent: one lane per (agent, other) pair
+        int4* const obs_others = reinterpret_cast<int4*>(arena + d.off_obs_others);
+        const int others = A - 1, pairs = A * others;
+        for (int q = lane; q < pairs; q += 64) {
+            const int a = (int)(((uint32_t)q * d.inv_others) >> 16), j = q - a * others;
+            obs_others[((int64_t)a * B + b) * others + j] = s_self[wave][j < a ? j : j + 1];
+        }
+    }
+    if (lane == 0) reinterpret_cast<int64_t*>(arena + d.off_etc)[b] = count;
+    if (err) atomicOr(reinterpret_cast<uint32_t*>(arena + d.off_error), err);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// rs_offsets_kernel: one env per lane.  Exclusive prefix sums over the batch of (passengers, visible tasks of agent 0, 1, ...) = where
+// each env's segment of each jagged list starts; the batch totals (and the number of envs not yet truncated) stay for the next step.
+// ------------------------------------------------------------------------------------------------------------------------------------
+template <int AMAX>
+__global__ void __launch_bounds__(kBlock) rs_offsets_kernel(char* __restrict__ arena, const RsDev d, uint32_t ticketed) {
+    __shared__ frz::ScanShared<AMAX + 1> s_scan;
+    __shared__ int s_ticket;
+    const int tid = threadIdx.x;
+    const int64_t B = d.B;
+    const int A = d.A;
+    frz::ScanWorkspace ws{reinterpret_cast<uint32_t*>(arena + d.off_epoch), reinterpret_cast<uint32_t*>(arena + d.off_totals),
+                          reinterpret_cast<uint64_t*>(arena + d.off_agg), reinterpret_cast<uint64_t*>(arena + d.off_prefix)};
+    const frz::ScanLaunch launch = frz::scan_begin(ws);
+    const int chunk = frz::scan_take_chunk(ws, d.nchunks, ticketed != 0, &s_ticket);
+    const int64_t b = (int64_t)chunk * kBlock + tid;
+    const bool active = b < B;
+    const int64_t bl = active ? b : B - 1;
+    const int32_t* rows = reinterpret_cast<const int32_t*>(arena + d.off_rows4);
+    const uint8_t* rows1 = reinterpret_cast<const uint8_t*>(arena + d.off_rows1);
+    uint32_t cnt[AMAX + 1], excl[AMAX + 1];
+    cnt[0] = active ? (uint32_t)rows[(int64_t)d.r_count * B + bl] : 0u;
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) cnt[a + 1] = (active && a < A) ? (uint32_t)rows[(int64_t)(d.r_atc + (a < A ? a : 0)) * B + bl] : 0u;
+    const bool trunc = rows1[(int64_t)d.u_trunc * B + bl] != 0;
+    uint32_t err = 0;
+    frz::scan_chunk<AMAX + 1>(s_scan, ws, launch, cnt, active, active && !trunc, A + 1, chunk, d.nchunks, excl, &err);
+    if (active) {
+        int64_t* const task_offsets = reinterpret_cast<int64_t*>(arena + d.off_task_offsets);
+        int64_t* const agent_offsets = reinterpret_cast<int64_t*>(arena + d.off_agent_offsets);
+        task_offsets[b] = excl[0];
+        if (b == B - 1) task_offsets[B] = (int64_t)excl[0] + cnt[0];
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a)
+            if (a < A) {
+                agent_offsets[a * (B + 1) + b] = excl[a + 1];
+                if (b == B - 1) agent_offsets[a * (B + 1) + B] = (int64_t)excl[a + 1] + cnt[a + 1];
+            }
+    }
+    if (err) atomicOr(reinterpret_cast<uint32_t*>(arena + d.off_error), err);
+    frz::scan_end(ws, launch, chunk, d.nchunks);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// rs_emit_kernel: the lists of update_actions / update_observations (rideshare.py:367-467) for ONE env per wavefront.  The env's task
+// rows (y, x, y_dest, x_dest, accepted_by | -100, riding_by | -100, fare, entered) are built once and parked in LDS.  The list of all
+// passengers is those rows in order.  The agents' lists (the tasks an agent sees: unaccepted or its own, rideshare.py:378-392, 446-456)
+// are short and many, so they are written as ONE flat sequence: every (agent, visible slot) pair gets a place by ballot + lane rank,
+// the places of all agents are laid end to end in LDS, and the wavefront then streams rows to their destinations, 16 bytes per lane, a
+// whole wave store at a time whatever agent a piece belongs to (its agent's destination comes from a small LDS table).
+// ------------------------------------------------------------------------------------------------------------------------------------
+template <int AMAX, int SPL>
+__global__ void __launch_bounds__(kBlock) rs_emit_kernel(char* __restrict__ arena, const RsDev d) {
+    __shared__ int4 s_rows[kEnvsPerBlock][SPL * 64][2];
+    __shared__ uint16_t s_pick[kEnvsPerBlock][AMAX * SPL * 64];  // flat place -> slot | state << 8 | agent << 12
+    __shared__ int64_t s_dest[kEnvsPerBlock][AMAX];             // agent -> (first row of its segment in the [A][cap] outputs) - (its first flat place)
+    const int64_t bw = env_of_wave(d.B);
+    if (bw < 0) return;  // no workgroup barrier in this kernel
+    const int b = (int)bw, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t B = d.B;
+    const int A = d.A, P = d.P;
+    const int32_t* rows = reinterpret_cast<const int32_t*>(arena + d.off_rows4);
+    const int32_t* pas = reinterpret_cast<const int32_t*>(arena + d.off_passengers) + (int64_t)b * PCOLS * P;
+    const int count = rows[(int64_t)d.r_count * B + b];
+    const int64_t cap = B * (int64_t)P;
+    const int64_t task_base = reinterpret_cast<const int64_t*>(arena + d.off_task_offsets)[b];
+    const int agent = lane < A ? lane : A - 1;
+    const int64_t agent_first = reinterpret_cast<const int64_t*>(arena + d.off_agent_offsets)[(int64_t)agent * (B + 1) + b];  // agent-lane
+    int st[SPL], drv[SPL];
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+        const int slot = lane + 64 * k;
+        const bool live = slot < count;
+        const int s = live ? slot : (count > 0 ? count - 1 : 0);
+        const int st_s = pas[PSTATE * P + s], drv_s = pas[PDRIVER * P + s];
+        const int4 lo = make_int4(pas[PY * P + s], pas[PX * P + s], pas[PYD * P + s], pas[PXD * P + s]);
+        const int4 hi = make_int4(st_s == 1 ? drv_s : kNone, st_s == 2 ? drv_s : kNone, pas[PFARE * P + s], pas[PENTERED * P + s]);
+        s_rows[wave][slot][0] = lo;
+        s_rows[wave][slot][1] = hi;
+        st[k] = live ? st_s : -1;  // dead lanes hold no passenger
+        drv[k] = live ? drv_s : -2;
+    }
+    // flat places: agent 0's visible slots in table order, then agent 1's, ...
+    uint32_t first_place = 0;  // agent-lane: where the agent's places start
+    int total = 0;
+    for_each_index(std::make_integer_sequence<int, AMAX>{}, [&](auto ic) {
+        constexpr int a = decltype(ic)::value;
+        first_place = write_lane_c<a>(first_place, (uint32_t)total);
+#pragma unroll
+        for (int k = 0; k < SPL; ++k) {
+            const bool mine = st[k] == 0 || drv[k] == a;
+            const uint64_t m = __ballot(mine);
+            if (mine) s_pick[wave][total + lane_rank(m)] = (uint16_t)((lane + 64 * k) | (st[k] << 8) | (a << 12));
+            total += (int)__popcll(m);
+        }
+    });
+    if (lane < A) s_dest[wave][lane] = (int64_t)lane * cap + agent_first - (int64_t)first_place;
+    wave_lds_sync();
+    // all passengers, in table order (task_store, rideshare.py:415-425)
+    {
+        int4* const out = reinterpret_cast<int4*>(arena + d.off_task_values) + task_base * 2;
+        const int4* const src = &s_rows[wave][0][0];
+        for (int p = lane; p < 2 * count; p += 64) out[p] = src[p];
+    }
+    // agents >= A of a wider instantiation saw the unaccepted passengers too: their places lie behind those of the real agents and are
+    // not written (the flat sequence is cut at the last real agent's end)
+    const int real_total = A < AMAX ? (int)read_lane((int)first_place, A) : total;
+    // the agents' task rows
+    {
+        int4* const out = reinterpret_cast<int4*>(arena + d.off_agent_task_values);
+        for (int p = lane; p < 2 * real_total; p += 64) {
+            const int r = p >> 1, e = s_pick[wave][r];
+            out[(s_dest[wave][e >> 12] + r) * 2 + (p & 1)] = s_rows[wave][e & 0xFF][p & 1];
+        }
+    }
+    // their positions in the env's passenger list (action = observation mapping) and their states (the action id each OneOf member carries)
+    {
+        int64_t* const map_out = reinterpret_cast<int64_t*>(arena + d.off_agent_map_values);
+        int32_t* const state_out = reinterpret_cast<int32_t*>(arena + d.off_agent_task_states);
+        for (int r = lane; r < real_total; r += 64) {
+            const int e = s_pick[wave][r];
+            const int64_t at = s_dest[wave][e >> 12] + r;
+            map_out[at] = e & 0xFF;
+            state_out[at] = (e >> 8) & 0xF;
+        }
     }
 }
 
@@ -602,27 +757,48 @@ struct frz_rideshare_env {
     std::vector<int32_t> schedule_index;  // [max_time + 2]
     char* arena = nullptr;
     bool was_reset = false;
-    bool ticketed = false;  // more chunks than CUs: chunks are handed out in arrival order (frz_scan.h)
+    bool ticketed = false;  // rs_offsets_kernel: more chunks than CUs, chunks are handed out in arrival order (frz_scan.h)
     int variant = 0;
+    std::vector<hipEvent_t> timing_events;  // pool of frz_rideshare_timed_rollout
 };
 
 namespace {
 
 int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
-template <int AMAX>
-void launch_variant(frz_rideshare_env* env, const int32_t* actions, int mode, hipStream_t stream) {
-    if (mode == kRebuild)
-        hipLaunchKernelGGL((rs_step_kernel<AMAX, kRebuild>), dim3(env->dev.nchunks), dim3(kBlock), 0, stream, env->arena, env->dev, actions, env->ticketed ? 1u : 0u);
+struct Timing {
+    hipEvent_t start = nullptr, stop = nullptr;  // begin of the step's first dispatch / end of its last one
+};
+
+template <typename K, typename... Args>
+void launch_kernel(K kernel, dim3 grid, hipStream_t stream, hipEvent_t start, hipEvent_t stop, Args... args) {
+    if (start || stop)
+        hipExtLaunchKernelGGL(kernel, grid, dim3(kBlock), 0, stream, start, stop, 0, args...);
     else
-        hipLaunchKernelGGL((rs_step_kernel<AMAX, kStep>), dim3(env->dev.nchunks), dim3(kBlock), 0, stream, env->arena, env->dev, actions, env->ticketed ? 1u : 0u);
+        hipLaunchKernelGGL(kernel, grid, dim3(kBlock), 0, stream, args...);
 }
 
-int launch(frz_rideshare_env* env, const int32_t* actions, int mode, hipStream_t stream) {
-    switch (env->variant) {
-        case 0: launch_variant<4>(env, actions, mode, stream); break;
-        case 1: launch_variant<8>(env, actions, mode, stream); break;
-        default: launch_variant<16>(env, actions, mode, stream); break;
+template <int AMAX, int SPL>
+void launch_variant(frz_rideshare_env* env, const int32_t* actions, int mode, const RsPolicy& policy, hipStream_t stream, const Timing& timing) {
+    const RsDev& d = env->dev;
+    const dim3 waves((unsigned)((d.B + kEnvsPerBlock - 1) / kEnvsPerBlock)), lanes((unsigned)d.nchunks);
+    if (mode == kRebuild)
+        launch_kernel(rs_env_kernel<AMAX, SPL, kRebuild>, waves, stream, timing.start, nullptr, env->arena, d, actions, policy);
+    else
+        launch_kernel(rs_env_kernel<AMAX, SPL, kStep>, waves, stream, timing.start, nullptr, env->arena, d, actions, policy);
+    launch_kernel(rs_offsets_kernel<AMAX>, lanes, stream, nullptr, nullptr, env->arena, d, env->ticketed ? 1u : 0u);
+    launch_kernel(rs_emit_kernel<AMAX, SPL>, waves, stream, nullptr, timing.stop, env->arena, d);
+}
+
+int launch(frz_rideshare_env* env, const int32_t* actions, int mode, const RsPolicy& policy, hipStream_t stream, const Timing& timing = Timing()) {
+    const bool wide = env->dev.P > 64;
+    switch (env->variant * 2 + (wide ? 1 : 0)) {
+        case 0: launch_variant<4, 1>(env, actions, mode, policy, stream, timing); break;
+        case 1: launch_variant<4, 2>(env, actions, mode, policy, stream, timing); break;
+        case 2: launch_variant<8, 1>(env, actions, mode, policy, stream, timing); break;
+        case 3: launch_variant<8, 2>(env, actions, mode, policy, stream, timing); break;
+        case 4: launch_variant<16, 1>(env, actions, mode, policy, stream, timing); break;
+        default: launch_variant<16, 2>(env, actions, mode, policy, stream, timing); break;
     }
     return hipGetLastError() == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;
 }
@@ -641,9 +817,10 @@ int frz_rideshare_create(const frz_rideshare_cfg* cfg, const int32_t* schedule, 
     const int A = cfg->num_agents, P = cfg->max_passengers;
     if (cfg->parallel_envs <= 0 || A <= 0 || A > FRZ_MAX_AGENTS || P <= 0 || P > FRZ_MAX_PASSENGERS || cfg->schedule_rows < 0)
         return FRZ_E_INVALID;
-    if ((int64_t)PCOLS * P * cfg->parallel_envs >= (int64_t)1 << 30 || (int64_t)(4 * A + 8) * cfg->parallel_envs >= (int64_t)1 << 30)
-        return FRZ_E_INVALID;  // 32-bit element indices
-    // coordinates stay inside +-16383: an agent's move (a difference of two positions with fast travel) travels through a 16-bit table
+    if ((int64_t)PCOLS * P * cfg->parallel_envs >= (int64_t)1 << 40 || (int64_t)(4 * A + 8) * cfg->parallel_envs >= (int64_t)1 << 30)
+        return FRZ_E_INVALID;
+    // coordinates stay inside +-16383: squared distances fit 32 bits, an agent's move (a difference of two positions with fast
+    // travel) travels between lanes as two 16-bit halves of one word
     auto small = [](int32_t v) { return v > -16384 && v < 16384; };
     for (int a = 0; a < A; ++a)
         if (!small(cfg->start_y[a]) || !small(cfg->start_x[a])) return FRZ_E_INVALID;
@@ -674,6 +851,12 @@ int frz_rideshare_create(const frz_rideshare_cfg* cfg, const int32_t* schedule, 
     flag(cfg->max_steps >= 0, kTruncate);
     p.move_cost = cfg->move_cost, p.drop_cost = cfg->drop_cost, p.noop_cost = cfg->noop_cost, p.accept_cost = cfg->accept_cost;
     p.pool_limit_cost = cfg->pool_limit_cost, p.general_wait_cost = cfg->general_wait_cost, p.long_wait_cost = cfg->long_wait_cost;
+    p.inv_others = A > 1 ? (uint32_t)((65536 + A - 2) / (A - 1)) : 0u;
+    for (int q = 0; q < A * (A - 1); ++q)
+        if ((int)(((uint32_t)q * p.inv_others) >> 16) != q / (A - 1)) {  // cannot happen for A <= FRZ_MAX_AGENTS; checked, not assumed
+            delete env;
+            return FRZ_E_INVALID;
+        }
     std::memcpy(p.start_y, cfg->start_y, sizeof(p.start_y));
     std::memcpy(p.start_x, cfg->start_x, sizeof(p.start_x));
 
@@ -696,7 +879,6 @@ int frz_rideshare_create(const frz_rideshare_cfg* cfg, const int32_t* schedule, 
     }
 
     int r = 0;
-    p.r_agents = r, r += 2 * A;
     p.r_count = r++;
     p.r_moves = r++;
     p.r_rewards = r, r += A;
@@ -713,16 +895,9 @@ int frz_rideshare_create(const frz_rideshare_cfg* cfg, const int32_t* schedule, 
         return here;
     };
     p.off_rows4 = take((int64_t)p.n_rows4 * B * 4);
-    if ((int64_t)p.n_rows4 * B * 4 >= (int64_t)1 << 32) {  // the row blocks are addressed with 32-bit byte offsets
-        delete env;
-        return FRZ_E_INVALID;
-    }
     p.off_rows1 = take((int64_t)p.n_rows1 * B);
+    p.off_agents = take((int64_t)A * B * 8);
     p.off_passengers = take((int64_t)PCOLS * P * B * 4);
-    if ((int64_t)PCOLS * P * B * 4 >= (int64_t)1 << 32) {  // the passenger slots are addressed with 32-bit byte offsets
-        delete env;
-        return FRZ_E_INVALID;
-    }
     p.off_etc = take(B * 8);
     p.off_obs_self = take((int64_t)A * B * 16);
     p.off_obs_others = take((int64_t)A * B * (A - 1) * 16);
@@ -752,7 +927,11 @@ int frz_rideshare_create(const frz_rideshare_cfg* cfg, const int32_t* schedule, 
     return FRZ_OK;
 }
 
-void frz_rideshare_destroy(frz_rideshare_env* env) { delete env; }
+void frz_rideshare_destroy(frz_rideshare_env* env) {
+    if (!env) return;
+    for (hipEvent_t e : env->timing_events) (void)hipEventDestroy(e);
+    delete env;
+}
 
 int64_t frz_rideshare_arena_bytes(const frz_rideshare_env* env) { return env ? env->dev.total_bytes : FRZ_E_INVALID; }
 
@@ -778,7 +957,7 @@ int frz_rideshare_get_bufs(const frz_rideshare_env* env, frz_rideshare_bufs* out
     const int64_t B = p.B;
     auto row4 = [&](int r) { return a + p.off_rows4 + (int64_t)r * B * 4; };
     auto row1 = [&](int r) { return a + p.off_rows1 + (int64_t)r * B; };
-    out->agents = reinterpret_cast<int32_t*>(row4(p.r_agents));
+    out->agents = at<int32_t>(a, p.off_agents);
     out->passenger_count = reinterpret_cast<int32_t*>(row4(p.r_count));
     out->num_moves = reinterpret_cast<int32_t*>(row4(p.r_moves));
     out->rewards = reinterpret_cast<float*>(row4(p.r_rewards));
@@ -807,14 +986,14 @@ int frz_rideshare_rebuild(frz_rideshare_env* env, void* stream) {
     if (!env) return FRZ_E_INVALID;
     if (!env->arena) return FRZ_E_UNBOUND;
     env->was_reset = true;
-    return launch(env, nullptr, kRebuild, static_cast<hipStream_t>(stream));
+    return launch(env, nullptr, kRebuild, RsPolicy{}, static_cast<hipStream_t>(stream));
 }
 
 int frz_rideshare_reset(frz_rideshare_env* env, void* stream) {
     if (!env) return FRZ_E_INVALID;
     if (!env->arena) return FRZ_E_UNBOUND;
-    const int blocks = (env->cfg.parallel_envs + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(rs_fill_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), env->arena);
+    const unsigned blocks = (unsigned)((env->cfg.parallel_envs + kEnvsPerBlock - 1) / kEnvsPerBlock);
+    hipLaunchKernelGGL(rs_fill_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), env->arena, env->dev);
     if (hipGetLastError() != hipSuccess) return FRZ_E_LAUNCH;
     return frz_rideshare_rebuild(env, stream);
 }
@@ -823,7 +1002,40 @@ int frz_rideshare_step(frz_rideshare_env* env, const int32_t* actions, void* str
     if (!env || !actions) return FRZ_E_INVALID;
     if (!env->arena) return FRZ_E_UNBOUND;
     if (!env->was_reset) return FRZ_E_INVALID;
-    return launch(env, actions, kStep, static_cast<hipStream_t>(stream));
+    return launch(env, actions, kStep, RsPolicy{}, static_cast<hipStream_t>(stream));
+}
+
+static RsPolicy make_policy(uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out) {
+    return RsPolicy{1u, (uint32_t)policy_seed, (uint32_t)(policy_seed >> 32), (uint32_t)policy_step, (uint32_t)(policy_step >> 32), actions_out};
+}
+
+int frz_rideshare_step_random_policy(frz_rideshare_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out, void* stream) {
+    if (!env || !actions_out) return FRZ_E_INVALID;
+    if (!env->arena) return FRZ_E_UNBOUND;
+    if (!env->was_reset) return FRZ_E_INVALID;
+    return launch(env, actions_out, kStep, make_policy(policy_seed, policy_step, actions_out), static_cast<hipStream_t>(stream));
+}
+
+int frz_rideshare_timed_rollout(frz_rideshare_env* env, uint64_t policy_seed, uint64_t first_step, int32_t n_steps, int32_t* actions_out,
+                                void* stream, float* step_ms) {
+    if (!env || !actions_out || !step_ms || n_steps <= 0) return FRZ_E_INVALID;
+    if (!env->arena) return FRZ_E_UNBOUND;
+    if (!env->was_reset) return FRZ_E_INVALID;
+    while ((int)env->timing_events.size() < 2 * n_steps) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return FRZ_E_LAUNCH;
+        env->timing_events.push_back(e);
+    }
+    for (int i = 0; i < n_steps; ++i) {  // back to back: no host synchronisation between the steps
+        const Timing timing{env->timing_events[2 * i], env->timing_events[2 * i + 1]};
+        const int rc = launch(env, actions_out, kStep, make_policy(policy_seed, first_step + (uint64_t)i, actions_out),
+                              static_cast<hipStream_t>(stream), timing);
+        if (rc != FRZ_OK) return rc;
+    }
+    if (hipStreamSynchronize(static_cast<hipStream_t>(stream)) != hipSuccess) return FRZ_E_LAUNCH;
+    for (int i = 0; i < n_steps; ++i)
+        if (hipEventElapsedTime(&step_ms[i], env->timing_events[2 * i], env->timing_events[2 * i + 1]) != hipSuccess) return FRZ_E_LAUNCH;
+    return FRZ_OK;
 }
 
 int frz_rideshare_random_policy(frz_rideshare_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out, void* stream) {

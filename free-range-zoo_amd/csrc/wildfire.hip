@@ -32,12 +32,13 @@ namespace {
 using namespace frz_wf;
 
 // wildfire.py:347-354 + utils/env.py:137-160: state from the configuration, bookkeeping zeroed.
-__global__ void __launch_bounds__(kBlock) wf_fill_kernel(char* arena) {
+__global__ void __launch_bounds__(kBlock) wf_fill_kernel(char* arena, int32_t seed_increment) {
     const WfDev& d = *reinterpret_cast<const WfDev*>(arena);
     const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t B = d.B;
     if (b >= B) return;
     int32_t* rows = reinterpret_cast<int32_t*>(arena + d.off_rows4);
+    if (seed_increment != 0) rows[d.r_seeds * B + b] += seed_increment;  // frz_wildfire_reset_reseed: fresh env seeds per episode
     float* rowsf = reinterpret_cast<float*>(arena + d.off_rows4);
     int64_t* rows8 = reinterpret_cast<int64_t*>(arena + d.off_rows8);
     uint8_t* rows1 = reinterpret_cast<uint8_t*>(arena + d.off_rows1);
@@ -1285,17 +1286,20 @@ int frz_wildfire_rebuild(frz_wildfire_env* env, void* stream) {
     return launch(env, args, FRZ_RNG_INJECTED, kRebuild, static_cast<hipStream_t>(stream));
 }
 
-int frz_wildfire_reset(frz_wildfire_env* env, void* stream) {
+int frz_wildfire_reset(frz_wildfire_env* env, void* stream) { return frz_wildfire_reset_reseed(env, 0, stream); }
+
+int frz_wildfire_reset_reseed(frz_wildfire_env* env, int32_t seed_increment, void* stream) {
     if (!env) return FRZ_E_INVALID;
     if (!env->arena) return FRZ_E_UNBOUND;
     if (env->dev.roles) {  // one launch: the configured initial state is produced inside the rebuild kernel
         WfArgs args{env->arena, nullptr, nullptr, nullptr, &env->dev};
+        args.seed_increment = seed_increment;
         const int rc = launch(env, args, FRZ_RNG_INJECTED, kReset, static_cast<hipStream_t>(stream));
         if (rc == FRZ_OK) env->was_reset = true;
         return rc;
     }
     const int blocks = (env->cfg.parallel_envs + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(wf_fill_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), env->arena);
+    hipLaunchKernelGGL(wf_fill_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), env->arena, seed_increment);
     if (hipGetLastError() != hipSuccess) return FRZ_E_LAUNCH;
     return frz_wildfire_rebuild(env, stream);
 }

@@ -81,6 +81,7 @@ struct WfLaunch {
     int32_t* actions_out;  // where the sampled actions are left (policy == 1), int32 [A][B][2]
     uint32_t ticketed;     // 1: chunks are handed out in arrival order (more chunks than resident workgroups)
     uint32_t skip;         // diagnostic builds only (-DFRZ_WF_EXPERIMENT): store groups to leave out when timing; 0 in the product
+    int32_t seed_increment;  // reset only (frz_wildfire_reset_reseed): added to every env seed
 };
 
 struct WfArgs {
@@ -95,6 +96,7 @@ struct WfArgs {
     // optional: events that receive the step dispatch's own begin / end timestamps (frz_wildfire_step_random_policy_timed)
     hipEvent_t start_event = nullptr, stop_event = nullptr;
     bool ticketed = false;  // field/crew kernels: one workgroup per chunk, chunks handed out in arrival order
+    int32_t seed_increment = 0;  // reset launches only
 };
 
 // The (CMAX, AMAX) instantiations of the step kernels: X(index, CMAX, AMAX, exact).  An env runs the first entry that holds its shape;
@@ -132,7 +134,7 @@ inline uint32_t experiment_skip() {
 inline WfLaunch make_launch(const WfArgs& a) {
     const WfDev* host = a.host_dev;
     return WfLaunch{host->B, a.policy ? 1u : 0u, host->off_rows1, host->off_epoch, host->off_totals, host->off_mt_state, (uint32_t)a.policy_seed,
-                    (uint32_t)(a.policy_seed >> 32), (uint32_t)a.policy_step, (uint32_t)(a.policy_step >> 32), a.actions_out, a.ticketed ? 1u : 0u, experiment_skip()};
+                    (uint32_t)(a.policy_seed >> 32), (uint32_t)a.policy_step, (uint32_t)(a.policy_step >> 32), a.actions_out, a.ticketed ? 1u : 0u, experiment_skip(), a.seed_increment};
 }
 
 // Staging the configuration: the 16-byte piece is requested by the kernel's FIRST vector-memory instruction (before the

@@ -821,6 +821,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                     }
                 at32(rows, (uint32_t)r_moves * Bu + bl) = 0;
                 at32(rows, (uint32_t)r_burnouts * Bu + bl) = 0;
+                if (launch.seed_increment != 0 && active) at32(rows, (uint32_t)r_seeds * Bu + bl) += launch.seed_increment;  // fresh seeds per episode
                 at32(rows8, q_burnouts * Bu + bl) = 0;
                 at32(rows8, q_putouts * Bu + bl) = 0;
                 at32(rows1, u_frozen * Bu + bl) = (uint8_t)0;

@@ -3,7 +3,8 @@
 Mirrors free_range_zoo/envs/rideshare/env/rideshare.py (``parallel_env`` :98-114, ``raw_env`` :135-504): same
 constructor keywords, agent names (``driver_i``), observation / mapping attributes, dtypes and shapes.  The arithmetic
 runs in ``csrc/rideshare.hip`` through ``frz_rideshare_*`` (include/frz.h).  The reference's single global passenger
-table is kept as ``max_passengers`` ordered slots per env on the device; ``state().passengers`` rebuilds the table.
+table is kept as ``max_passengers`` ordered slots per env on the device (env-major ``[B][column][slot]``: one env per
+wavefront, its slots across the lanes); ``state().passengers`` rebuilds the table.
 """
 import ctypes
 from typing import Any, Callable, Dict, List, Optional
@@ -76,8 +77,8 @@ class raw_env(BatchedParallelEnv):
         bufs = self._bufs
         f32, i32, i64, u8 = torch.float32, torch.int32, torch.int64, torch.uint8
         v = self._view
-        self._agents = v(bufs.agents, (A, 2, B), i32)
-        self._passengers = v(bufs.passengers, (10, P, B), i32)
+        self._agents = v(bufs.agents, (B, A, 2), i32)
+        self._passengers = v(bufs.passengers, (B, 10, P), i32)
         self._passenger_count = v(bufs.passenger_count, (B, ), i32)
         self.num_moves = v(bufs.num_moves, (B, ), i32)
         self._rewards, self._cumulative = v(bufs.rewards, (A, B), f32), v(bufs.cumulative_rewards, (A, B), f32)
@@ -125,13 +126,13 @@ class raw_env(BatchedParallelEnv):
         B, P = self.parallel_envs, self._P
         live = torch.arange(P, device=self.device).unsqueeze(1) < self._passenger_count.unsqueeze(0)  # [P, B]
         envs, slots = live.t().nonzero(as_tuple=True)  # env-major, slot order = table order
-        columns = self._passengers[:, slots, envs].t()  # [n, 10]
+        columns = self._passengers[envs, :, slots]  # [n, 10]
         table = torch.cat([envs.to(torch.int32).unsqueeze(1), columns], dim=1)
-        return RideshareState(agents=self._agents.permute(2, 0, 1), passengers=table)
+        return RideshareState(agents=self._agents, passengers=table)
 
     def _load_state(self, state: RideshareState) -> None:
         """Write a reference-shaped state (agents + global table sorted by env) into the per-env slots."""
-        self._agents.permute(2, 0, 1).copy_(state.agents.to(self.device))
+        self._agents.copy_(state.agents.to(self.device))
         table = state.passengers.to(self.device)
         envs = table[:, 0].long()
         counts = torch.bincount(envs, minlength=self.parallel_envs)
@@ -139,7 +140,7 @@ class raw_env(BatchedParallelEnv):
             raise ValueError('initial_state holds more passengers in one env than max_passengers slots')
         starts = torch.cumsum(counts, 0) - counts
         slots = torch.arange(table.shape[0], device=self.device) - starts[envs]
-        self._passengers[:, slots, envs] = table[:, 1:].t().to(torch.int32)
+        self._passengers[envs, :, slots] = table[:, 1:].to(torch.int32)
         self._passenger_count.copy_(counts.to(torch.int32))
 
     # ---------------------------------------------------------------------------------------- output plumbing
@@ -255,11 +256,22 @@ class raw_env(BatchedParallelEnv):
                     'frz_rideshare_random_policy')
         return out
 
+    step_kernels = 'rs_env_kernel + rs_offsets_kernel + rs_emit_kernel (policy sampled in the first launch)'
+
     @torch.no_grad()
     def step_random_policy(self, policy_seed: int, policy_step: int):
-        """``random_policy_actions`` + ``step`` (the same entry the other domains offer; here the two launches are not fused: the
-        policy launch is ≈3 % of a rideshare step)."""
-        return self.step(self.random_policy_actions(policy_seed, policy_step))
+        """``random_policy_actions`` + ``step`` with the policy sampled inside the step's first launch (same results as the two calls); the
+        sampled actions are left in ``self.actions``."""
+        if not self._has_reset:
+            raise RuntimeError('reset() must be called before step_random_policy()')
+        logged = self._logs_this_step()
+        _capi.check(self._lib.frz_rideshare_step_random_policy(self._handle, policy_seed, policy_step, self._actions.data_ptr(),
+                                                               stream_ptr(self.device)), 'frz_rideshare_step_random_policy')
+        self._publish()
+        self.infos = {agent: {} for agent in self.agents}
+        if logged:
+            self._log_environment()
+        return ({agent: self.observations[agent] for agent in self.agents}, self.rewards, self.terminations, self.truncations, self.infos)
 
     @torch.no_grad()
     def capture_random_rollout(self, steps: int, policy_seed: int = 0, include_reset: bool = True) -> 'torch.cuda.CUDAGraph':
@@ -274,8 +286,7 @@ class raw_env(BatchedParallelEnv):
             if include_reset:
                 _capi.check(lib.frz_rideshare_reset(handle, stream), 'frz_rideshare_reset')
             for t in range(steps):
-                _capi.check(lib.frz_rideshare_random_policy(handle, policy_seed, t, actions, stream), 'frz_rideshare_random_policy')
-                _capi.check(lib.frz_rideshare_step(handle, actions, stream), 'frz_rideshare_step')
+                _capi.check(lib.frz_rideshare_step_random_policy(handle, policy_seed, t, actions, stream), 'frz_rideshare_step_random_policy')
         return graph
 
     # ------------------------------------------------------------------------------------------------ spaces

@@ -321,7 +321,7 @@ class raw_env(BatchedParallelEnv):
 
     @torch.no_grad()
     def capture_random_rollout(self, steps: int, policy_seed: int = 0, include_reset: bool = True, episode_length: Optional[int] = None,
-                               seed_stride: Optional[torch.Tensor] = None, metrics: Optional[torch.Tensor] = None,
+                               seed_stride: int = 0, metrics: Optional[torch.Tensor] = None,
                                metrics_copy: Optional[torch.Tensor] = None) -> 'torch.cuda.CUDAGraph':
         """
         Capture ``[reset] + steps x (random policy + step, one launch where the grid shape has a fused kernel)`` into a HIP
@@ -333,8 +333,8 @@ class raw_env(BatchedParallelEnv):
         state (it does not re-run the Python-side ``save_initial``).
 
         A whole rollout loop as ONE graph: with ``episode_length`` the ``steps`` are cut into episodes, each starting with a
-        reset (policy steps restart at 0); ``seed_stride`` (int32 scalar tensor on the device) is added to ``env.seeds`` before every
-        reset (fresh seeds per episode); ``metrics`` (float64 ``[A + 2]``) receives ``accumulate_episode_metrics`` after every
+        reset (policy steps restart at 0); ``seed_stride`` (an int) is added to ``env.seeds`` by every reset launch (fresh seeds per
+        episode); ``metrics`` (float64 ``[A + 2]``) receives ``accumulate_episode_metrics`` after every
         episode and is copied to ``metrics_copy`` at the end of the graph (the buffer a collective then reduces).
         """
         if not self._has_reset:
@@ -355,12 +355,10 @@ class raw_env(BatchedParallelEnv):
             while done < steps or (steps == 0 and done == 0):
                 n = min(episode, steps - done) if steps else 0
                 if include_reset:
-                    if seed_stride is not None:
-                        self.seeds.add_(seed_stride)
-                    if mt:
+                    _capi.check(lib.frz_wildfire_reset_reseed(handle, int(seed_stride), stream), 'frz_wildfire_reset_reseed')
+                    if mt:  # the streams restart from the (new) seeds; the reset launch does not touch them
                         _capi.check(lib.frz_mt19937_seed(self._bufs.mt_state, self._bufs.mt_index, self._bufs.seeds, None, 0,
                                                          self.parallel_envs, stream), 'frz_mt19937_seed')
-                    _capi.check(lib.frz_wildfire_reset(handle, stream), 'frz_wildfire_reset')
                 _capi.check(lib.frz_wildfire_rollout_random_policy(handle, policy_seed, 0 if include_reset else done, n, actions, mode, stream),
                             'frz_wildfire_rollout_random_policy')
                 if metrics is not None:

@@ -190,6 +190,10 @@ int frz_wildfire_get_bufs(const frz_wildfire_env* env, frz_wildfire_bufs* out);
 /* replaces raw_env.reset()'s state fill (wildfire.py:347-354) + bookkeeping zeroing (utils/env.py:137-160)
  * followed by update_observations/update_actions */
 int frz_wildfire_reset(frz_wildfire_env* env, void* stream);
+/* frz_wildfire_reset that first adds seed_increment to every env seed (bufs.seeds; the FRZ_RNG_PHILOX key and the value the next
+ * frz_mt19937_seed starts the env's stream from): the "fresh seeds, reset" pair at the top of every episode of a rollout loop
+ * (the reference's `env.reset(seed=...)`, utils/env.py:94-160) as one launch */
+int frz_wildfire_reset_reseed(frz_wildfire_env* env, int32_t seed_increment, void* stream);
 /* replaces update_observations() + update_actions() (wildfire.py:586-717) on the bound state */
 int frz_wildfire_rebuild(frz_wildfire_env* env, void* stream);
 /* replaces one ParallelEnv.step(): BatchedAECEnv.step x A + step_environment + truncation + rebuild.
@@ -364,7 +368,8 @@ int frz_cybersecurity_step_random_policy(frz_cybersecurity_env* env, uint64_t po
  * Rideshare  (reference: free_range_zoo/envs/rideshare/env/rideshare.py, transitions/,
  *             structures/configuration.py).  Deterministic: no randomness is drawn.
  * The reference keeps ONE global passenger table sorted by env (stable: entry order inside an env); here every env owns
- * max_passengers slots in that same order, struct-of-arrays [column][slot][B].
+ * max_passengers slots in that same order, env-major [B][column][slot]: one env is stepped by one wavefront whose lanes hold its slots,
+ * so a column of an env is one coalesced access.
  * ---------------------------------------------------------------------------------------------- */
 #define FRZ_MAX_PASSENGERS 128
 #define FRZ_PASSENGER_COLUMNS 10 /* y, x, y_dest, x_dest, fare, state, driver, entered, accepted, picked */
@@ -388,8 +393,8 @@ typedef struct frz_rideshare_cfg {
 } frz_rideshare_cfg;
 
 typedef struct frz_rideshare_bufs {
-    int32_t* agents;           /* [A][2][B]  (y, x) */
-    int32_t* passengers;       /* [FRZ_PASSENGER_COLUMNS][max_passengers][B] */
+    int32_t* agents;           /* [B][A][2]  (y, x): the reference's own layout (structures/state.py:10-66) */
+    int32_t* passengers;       /* [B][FRZ_PASSENGER_COLUMNS][max_passengers] */
     int32_t* passenger_count;  /* [B] */
     int32_t* num_moves;        /* [B] */
     float* rewards;            /* [A][B] */
@@ -427,8 +432,18 @@ int frz_rideshare_rebuild(frz_rideshare_env* env, void* stream);
 /* one ParallelEnv.step() (rideshare.py:248-467).  actions int32 [A][B][2]: (task index in the agent's mapping, action id)
  * with id -1 noop / 0 accept / 1 pick / 2 drop */
 int frz_rideshare_step(frz_rideshare_env* env, const int32_t* actions, void* stream);
-/* uniform member of OneOf([Discrete(1, start=state_t) for visible task t] + [noop]) (spaces/actions.py:10-50) */
+/* uniform member of OneOf([Discrete(1, start=state_t) for visible task t] + [noop]) (spaces/actions.py:10-50): agent a of env b draws
+ * member floor(u32 * (n + 1) / 2^32) from word 0 of Philox(counter (a, first_env_index + b, step, step >> 32), key (seed, seed >> 32)) */
 int frz_rideshare_random_policy(frz_rideshare_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out, void* stream);
+/* frz_rideshare_random_policy + frz_rideshare_step with the policy sampled inside the step's first launch (same stream, same results as the
+ * two calls; the reference's `env.step({a: action_space(a).sample_nested()})` loop, baselines/random.py:20); the sampled actions are left in
+ * actions_out (int32 [A][B][2]; not written once every env is finished, when the step is a no-op) */
+int frz_rideshare_step_random_policy(frz_rideshare_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out, void* stream);
+/* Measurement aid (bench.py): n_steps x frz_rideshare_step_random_policy back to back with no host synchronisation in between; a pair of
+ * HIP events on `stream` takes the begin timestamp of each step's first dispatch and the end timestamp of its last one; synchronises once
+ * at the end and returns the step durations in milliseconds */
+int frz_rideshare_timed_rollout(frz_rideshare_env* env, uint64_t policy_seed, uint64_t first_step, int32_t n_steps, int32_t* actions_out,
+                                void* stream, float* step_ms);
 
 /* ------------------------------------------------------------------------------------------------
  * Per-env MT19937 streams  (reference: free_range_zoo/utils/random_generator.py:49-146; torch CPU

@@ -113,6 +113,30 @@ def test_agent_count_variants_match_the_oracle(oracle, A):
     run_against_oracle(oracle, lambda: configs.rideshare_busy(A=A, steps=12, per_step=3, seed=20 + A), 500, 20, 16, seed=7, contest=0.3)
 
 
+def test_more_than_64_slots_per_env(oracle):
+    """Envs with up to 120 live passengers: two slots per lane (the <.., 2> kernel variants)."""
+    env, o = run_against_oracle(oracle, lambda: configs.rideshare_busy(A=5, steps=30, per_step=4, seed=31, use_waiting_costs=True), 700, 40, 36, seed=9,
+                                contest=0.25)
+    assert env._P > 64 and int(o.passenger_count.max()) > 64
+
+
+def test_step_random_policy_is_the_two_calls_in_one(oracle):
+    """frz_rideshare_step_random_policy (policy sampled inside the step's first launch) == random_policy_actions + step, actions included."""
+    build = lambda: configs.rideshare_busy(A=8, steps=20, per_step=2, seed=12, use_waiting_costs=True)  # noqa: E731
+    B = 3000
+    fused, split = make_env(build, B, 30), make_env(build, B, 30)
+    for env in (fused, split):
+        env.reset(seed=torch.arange(B, dtype=torch.int32))
+    for t in range(34):  # past the horizon: the frozen steps too
+        fused.step_random_policy(policy_seed=77, policy_step=t)
+        actions = split.random_policy_actions(policy_seed=77, policy_step=t).clone()
+        split.step(actions)
+        if t < 30:
+            assert torch.equal(fused._actions, actions), t
+        compare_snapshots(hip_snapshot(fused), hip_snapshot(split), f'fused vs split step {t}')
+    fused.check()
+
+
 def test_vs_oracle_multi_round(oracle):
     run_against_oracle(oracle, lambda: configs.rideshare_busy(A=3, steps=6, per_step=1, seed=4), 140000, 8, 5, seed=5, contest=0.2)
 
