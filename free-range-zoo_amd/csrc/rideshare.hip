@@ -12,10 +12,11 @@
 //                                      CONTIGUOUS 16-byte pieces (one wave store = up to 1 KiB of consecutive bytes)
 //
 // The reference keeps one global passenger table sorted by env and re-sorts / boolean-compacts it every step; here each env owns
-// max_passengers slots in table order, env-major [B][column][slot]: lane s of the env's wavefront holds slot s (and s + 64 when an env
-// has more than 64 slots), so a column of one env is one coalesced load, per-agent quantities live in lanes 0..A-1 of the same
-// wavefront, and everything that crosses between "slot lanes" and "agent lanes" is a ballot, a readlane or a ds_bpermute: no
-// workgroup barrier anywhere (a 256-thread workgroup is four independent envs).  Deterministic integer/byte work, HBM-bound: no MFMA.
+// max_passengers slots in table order, env-major records [B][slot][10]: lane s of the env's wavefront holds slot s (and s + 64 when an
+// env has more than 64 slots) and moves its 40-byte record with three wide accesses (the columns a step can change come first, so a
+// changed slot is two stores), per-agent quantities live in lanes 0..A-1 of the same wavefront, and everything that crosses between
+// "slot lanes" and "agent lanes" is a ballot, a v_writelane, a ds_bpermute or an LDS word per slot: no workgroup barrier anywhere (a
+// 256-thread workgroup is four independent envs).  Deterministic integer/byte work, HBM-bound: no MFMA.
 #include "frz_scan.h"
 
 #include "../../include/frz.h"
@@ -23,6 +24,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <utility>
 #include <cstdlib>
 #include <cstring>
@@ -35,7 +37,8 @@ using frz::kBlock;
 
 enum Mode { kStep = 0, kRebuild = 1 };
 enum Flag : uint32_t { kFast = 1u << 0, kDiagonal = 1u << 1, kVariableMove = 1u << 2, kWaiting = 1u << 3, kTrackCumulative = 1u << 4, kTruncate = 1u << 5 };
-enum Col { PY = 0, PX, PYD, PXD, PFARE, PSTATE, PDRIVER, PENTERED, PACCEPTED, PPICKED, PCOLS };
+// a passenger record: bytes [0, 16) (y, x, state, driver) and [16, 24) (accepted, picked) are what a step can change, [24, 40) never changes
+enum Col { PY = 0, PX, PSTATE, PDRIVER, PACCEPTED, PPICKED, PYD, PXD, PFARE, PENTERED, PCOLS };
 constexpr int kNone = -100;
 constexpr int kEnvsPerBlock = kBlock / 64;  // one env per wavefront
 
@@ -61,6 +64,32 @@ struct RsPolicy {
     int32_t* actions_out;
 };
 
+// element `index` of an array whose base is wave-uniform, addressed as (scalar base) + (32-bit byte offset): one instruction instead of
+// 64-bit address arithmetic per access (frz_rideshare_create bounds every array addressed this way below 4 GiB)
+template <typename T>
+__device__ __forceinline__ T& at32(T* base, uint32_t index) {
+    using Byte = std::conditional_t<std::is_const_v<T>, const char, char>;
+    return *reinterpret_cast<T*>(reinterpret_cast<Byte*>(base) + (uint64_t)(index * (uint32_t)sizeof(T)));
+}
+
+// one passenger record (40 bytes, 8-byte aligned) of an env's table, as three accesses with immediate offsets
+typedef int int4u __attribute__((ext_vector_type(4), aligned(8)));  // records are 8-byte aligned
+typedef int int2u __attribute__((ext_vector_type(2), aligned(8)));
+__device__ __forceinline__ void load_record(const int32_t* table, uint32_t slot, int (&v)[10]) {
+    const char* r = reinterpret_cast<const char*>(table) + (uint64_t)(slot * 40u);
+    const int4u a = *reinterpret_cast<const int4u*>(r), c = *reinterpret_cast<const int4u*>(r + 24);
+    const int2u m = *reinterpret_cast<const int2u*>(r + 16);
+    v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = m.x, v[5] = m.y, v[6] = c.x, v[7] = c.y, v[8] = c.z, v[9] = c.w;
+}
+__device__ __forceinline__ void store_hot(int32_t* table, uint32_t slot, const int (&v)[10]) {  // what a step can change
+    char* r = reinterpret_cast<char*>(table) + (uint64_t)(slot * 40u);
+    *reinterpret_cast<int4u*>(r) = int4u{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<int2u*>(r + 16) = int2u{v[4], v[5]};
+}
+__device__ __forceinline__ void store_cold(int32_t* table, uint32_t slot, const int (&v)[10]) {
+    *reinterpret_cast<int4u*>(reinterpret_cast<char*>(table) + (uint64_t)(slot * 40u) + 24) = int4u{v[6], v[7], v[8], v[9]};
+}
+
 // ---- wavefront helpers: lanes 0..63 of ONE env
 __device__ __forceinline__ int lane_rank(uint64_t m) {  // set bits of m below this lane
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -72,7 +101,7 @@ __device__ __forceinline__ int last_bit(uint64_t m) { return 63 - __builtin_clzl
 // The env a wavefront owns.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 share one); the mapping below gives every
 // run of 32 consecutive envs (one 128-byte line of each [rows][B] array) to workgroups of ONE XCD, so that its L2 merges their 4-byte
 // pieces into whole lines.  Speed only: any bijection is correct.
-__device__ __forceinline__ int64_t env_of_wave(int64_t B) {
+__device__ __forceinline__ int env_of_wave(int64_t B) {
     const uint32_t nblocks = gridDim.x, blk = blockIdx.x;
     uint32_t quad = blk;
     const uint32_t group = blk >> 6;
@@ -80,8 +109,9 @@ __device__ __forceinline__ int64_t env_of_wave(int64_t B) {
         const uint32_t l = blk & 63u;
         quad = (group << 6) + ((l & 7u) << 3) + (l >> 3);
     }
-    const int64_t b = (int64_t)quad * kEnvsPerBlock + (threadIdx.x >> 6);
-    return b < B ? (int64_t)__builtin_amdgcn_readfirstlane((int)b) : (int64_t)-1;
+    // the same in every lane of a wavefront: said so explicitly, so that everything derived from the env index stays in scalar registers
+    const int b = __builtin_amdgcn_readfirstlane((int)(quad * kEnvsPerBlock + (threadIdx.x >> 6)));
+    return b < B ? b : -1;
 }
 
 // schedule rows of one timestep are contiguous in the time-sorted device copy: [index[t], index[t + 1])
@@ -92,33 +122,49 @@ struct Schedule {
 };
 
 // transitions/passenger_entry.py:24-72 for one env: the rows of timestep t (this env or wildcard) are appended in schedule order behind
-// the `count` passengers of the table; 64 schedule rows per pass, their places by ballot + lane rank.  Returns the number appended.
-__device__ __forceinline__ int passenger_entry(const Schedule& sch, int32_t* pas, int P, int b, int t, int count, uint32_t& err) {
-    if (t < 0 || t > sch.max_time) return 0;
+// the `count` passengers of the table; 64 schedule rows per pass, their places by ballot + lane rank.  The loads of the first pass are
+// issued by entry_prefetch (long before the table is ready for them), the records are written by entry_commit.
+struct EntryPlan {
+    int first, last;  // the timestep's rows [first, last) of the time-sorted schedule
+    int row[7];       // lane's row of the first pass (first + lane)
+};
+__device__ __forceinline__ EntryPlan entry_prefetch(const Schedule& sch, int t) {
+    EntryPlan plan;
+    plan.first = plan.last = 0;
+    if (t >= 0 && t <= sch.max_time) {
+        plan.first = sch.index[t];
+        plan.last = sch.index[t + 1];
+    }
     const int lane = threadIdx.x & 63;
-    const int first = sch.index[t], last = sch.index[t + 1];
+    const int r = plan.first + lane < plan.last ? plan.first + lane : plan.first;
+    const bool any = plan.first < plan.last;
+#pragma unroll
+    for (int c = 0; c < 7; ++c) plan.row[c] = any ? at32(sch.rows, (uint32_t)r * 7u + (uint32_t)c) : 0;
+    return plan;
+}
+// returns the number of passengers appended
+__device__ __forceinline__ int entry_commit(const Schedule& sch, const EntryPlan& plan, int32_t* table, int P, int b, int t, int count, uint32_t& err) {
+    const int lane = threadIdx.x & 63;
     int appended = 0;
-    for (int r0 = first; r0 < last; r0 += 64) {
-        const int r = r0 + lane;
-        const bool in = r < last;
-        const int32_t* row = sch.rows + (int64_t)(in ? r : first) * 7;
-        const int env = row[1];
-        const bool match = in && (env == -1 || env == b);
+    for (int r0 = plan.first; r0 < plan.last; r0 += 64) {
+        int row[7];
+#pragma unroll
+        for (int c = 0; c < 7; ++c) row[c] = plan.row[c];
+        const bool in = r0 + lane < plan.last;
+        if (r0 != plan.first) {
+            const int r = in ? r0 + lane : plan.first;
+#pragma unroll
+            for (int c = 0; c < 7; ++c) row[c] = at32(sch.rows, (uint32_t)r * 7u + (uint32_t)c);
+        }
+        const bool match = in && (row[1] == -1 || row[1] == b);
         const uint64_t m = __ballot(match);
         if (m == 0) continue;
         const int pos = count + appended + lane_rank(m);
         if (match) {
             if (pos < P) {
-                pas[PY * P + pos] = row[2];
-                pas[PX * P + pos] = row[3];
-                pas[PYD * P + pos] = row[4];
-                pas[PXD * P + pos] = row[5];
-                pas[PFARE * P + pos] = row[6];
-                pas[PSTATE * P + pos] = 0;
-                pas[PDRIVER * P + pos] = -1;
-                pas[PENTERED * P + pos] = t;
-                pas[PACCEPTED * P + pos] = -1;
-                pas[PPICKED * P + pos] = -1;
+                const int v[10] = {row[2], row[3], 0, -1, -1, -1, row[4], row[5], row[6], t};  // state 0, no driver, never accepted / picked
+                store_hot(table, (uint32_t)pos, v);
+                store_cold(table, (uint32_t)pos, v);
             } else {
                 err |= FRZ_ERR_OVERFLOW;
             }
@@ -130,9 +176,9 @@ __device__ __forceinline__ int passenger_entry(const Schedule& sch, int32_t* pas
 
 // rideshare.py:185-222 + utils/env.py:137-160: agents at their start positions, bookkeeping zeroed, step-0 passengers enter
 __global__ void __launch_bounds__(kBlock) rs_fill_kernel(char* __restrict__ arena, const RsDev d) {
-    const int64_t bw = env_of_wave(d.B);
-    if (bw < 0) return;
-    const int b = (int)bw, lane = threadIdx.x & 63;
+    const int b = env_of_wave(d.B);
+    if (b < 0) return;
+    const int lane = threadIdx.x & 63;
     const int64_t B = d.B;
     int32_t* const rows = reinterpret_cast<int32_t*>(arena + d.off_rows4);
     float* const rowsf = reinterpret_cast<float*>(arena + d.off_rows4);
@@ -148,7 +194,7 @@ __global__ void __launch_bounds__(kBlock) rs_fill_kernel(char* __restrict__ aren
     const Schedule sch{reinterpret_cast<const int32_t*>(arena + d.off_schedule), reinterpret_cast<const int32_t*>(arena + d.off_schedule_index),
                        d.max_time};
     uint32_t err = 0;
-    const int count = passenger_entry(sch, pas, d.P, b, 0, 0, err);
+    const int count = entry_commit(sch, entry_prefetch(sch, 0), pas, d.P, b, 0, 0, err);
     if (lane == 0) {
         rows[d.r_moves * B + b] = 0;
         rows1[d.u_frozen * B + b] = 0;
@@ -230,9 +276,9 @@ __global__ void __launch_bounds__(kBlock) rs_env_kernel(char* __restrict__ arena
     __shared__ uint32_t s_claim[kEnvsPerBlock][SPL * 64];   // accepting agents per slot
     __shared__ uint32_t s_effect[kEnvsPerBlock][SPL * 64];  // (winning agent + 1) << 8 | picked << 1 | dropped << 2
     __shared__ int4 s_self[kEnvsPerBlock][AMAX];            // the agents' self observation rows
-    const int64_t bw = env_of_wave(d.B);
-    if (bw < 0) return;  // no workgroup barrier in this kernel: a wavefront without an env just leaves
-    const int b = (int)bw, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = env_of_wave(d.B);
+    if (b < 0) return;  // no workgroup barrier in this kernel: a wavefront without an env just leaves
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t B = d.B;
     const int A = d.A, P = d.P;
     const uint32_t flags = d.flags;
@@ -241,61 +287,72 @@ __global__ void __launch_bounds__(kBlock) rs_env_kernel(char* __restrict__ arena
     int32_t* const rows = reinterpret_cast<int32_t*>(arena + d.off_rows4);
     float* const rowsf = reinterpret_cast<float*>(arena + d.off_rows4);
     uint8_t* const rows1 = reinterpret_cast<uint8_t*>(arena + d.off_rows1);
-    int32_t* const pas = reinterpret_cast<int32_t*>(arena + d.off_passengers) + (int64_t)b * PCOLS * P;  // this env's table [column][slot]
+    int32_t* const pas = reinterpret_cast<int32_t*>(arena + d.off_passengers) + (int64_t)b * PCOLS * P;  // this env's table [slot][column]
     int2* const agents = reinterpret_cast<int2*>(arena + d.off_agents) + (int64_t)b * A;
+    const uint32_t Bu = (uint32_t)B, bu = (uint32_t)b;
+
+    // ---------------------------------------------------------------- loads: everything the step reads, requested before anything is
+    // waited for except the passenger count (lanes past it re-read the last live record: the same cache lines, no extra traffic)
+    const uint32_t epoch = *reinterpret_cast<const uint32_t*>(arena + d.off_epoch);
+    const uint32_t* const totals = reinterpret_cast<const uint32_t*>(arena + d.off_totals);
+    const uint32_t left0[2] = {totals[A + 1], totals[A + 2]}, left1[2] = {totals[frz::kTotalsStride + A + 1], totals[frz::kTotalsStride + A + 2]};
+    const int count0 = at32(rows, (uint32_t)d.r_count * Bu + bu);
+    int nm = MODE == kStep ? at32(rows, (uint32_t)d.r_moves * Bu + bu) : 0;
+    bool trunc = at32(rows1, (uint32_t)d.u_trunc * Bu + bu) != 0;
+    int v[SPL][PCOLS];
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+        const int slot = lane + 64 * k;
+        load_record(pas, (uint32_t)(slot < count0 ? slot : (count0 > 0 ? count0 - 1 : 0)), v[k]);
+    }
+    const int2 pos0 = at32(agents, (uint32_t)agent);
+    int act_idx = 0, act_id = -1;
+    float cum0 = 0.0f;
+    if (MODE == kStep) {
+        if (!pol.on) {
+            const int2 a2 = at32(reinterpret_cast<const int2*>(actions), (uint32_t)agent * Bu + bu);
+            act_idx = a2.x;
+            act_id = is_agent ? a2.y : -1;
+        }
+        if (flags & kTrackCumulative) cum0 = at32(rowsf, (uint32_t)(d.r_cum + agent) * Bu + bu);
+    }
+    const Schedule sch{reinterpret_cast<const int32_t*>(arena + d.off_schedule), reinterpret_cast<const int32_t*>(arena + d.off_schedule_index),
+                       d.max_time};
+    EntryPlan plan;
+    if (MODE == kStep) plan = entry_prefetch(sch, nm + 1);  // the next timestep's schedule rows (rideshare.py:308): in flight early
 
     if (MODE == kStep) {
         // utils/env.py:211-213 (terminations never set, rideshare.py:252): frozen once every env is truncated.  Channels A + 1 / A + 2 of
         // the batch totals rs_offsets_kernel left after the previous step = number of envs not terminated / not truncated
-        const uint32_t epoch = *reinterpret_cast<const uint32_t*>(arena + d.off_epoch);
-        const uint32_t* prev = reinterpret_cast<const uint32_t*>(arena + d.off_totals) + ((epoch + 1u) & 1u) * frz::kTotalsStride;
-        if (prev[A + 1] == 0u || prev[A + 2] == 0u) {
+        const bool odd = ((epoch + 1u) & 1u) != 0;
+        const uint32_t left_alive = odd ? left1[0] : left0[0], left_running = odd ? left1[1] : left0[1];
+        if (left_alive == 0u || left_running == 0u) {
             // the parallel adapter sums the stale rewards once per agent call (utils/conversions.py:87-90)
-            if (!rows1[(int64_t)d.u_frozen * B + b]) {
+            if (!at32(rows1, (uint32_t)d.u_frozen * Bu + bu)) {
                 if (is_agent) {
-                    const float r = rowsf[(int64_t)(d.r_rewards + lane) * B + b];
+                    const float r = at32(rowsf, (uint32_t)(d.r_rewards + lane) * Bu + bu);
                     float acc = 0.0f;
                     for (int j = 0; j < A; ++j) acc = acc + r;
-                    rowsf[(int64_t)(d.r_rewards + lane) * B + b] = acc;
+                    at32(rowsf, (uint32_t)(d.r_rewards + lane) * Bu + bu) = acc;
                 }
-                if (lane == 0) rows1[(int64_t)d.u_frozen * B + b] = 1;
+                if (lane == 0) at32(rows1, (uint32_t)d.u_frozen * Bu + bu) = 1;
             }
             return;
         }
     }
 
-    // ---------------------------------------------------------------- loads: the env's table, its agents, their actions
-    const int count0 = rows[(int64_t)d.r_count * B + b];
-    int v[SPL][PCOLS];
+    int ay = pos0.x, ax = pos0.y;
     bool live[SPL];
 #pragma unroll
     for (int k = 0; k < SPL; ++k) {
-        const int slot = lane + 64 * k;
-        live[k] = slot < count0;
-        const int s = live[k] ? slot : (count0 > 0 ? count0 - 1 : 0);  // dead lanes re-read a live slot's line: no extra traffic
-#pragma unroll
-        for (int c = 0; c < PCOLS; ++c) v[k][c] = pas[c * P + s];
+        live[k] = lane + 64 * k < count0;
+        v[k][PSTATE] = live[k] ? v[k][PSTATE] : -1;  // lanes past the count hold no passenger
+        v[k][PDRIVER] = live[k] ? v[k][PDRIVER] : -2;
     }
-    const int2 pos0 = agents[agent];
-    int ay = pos0.x, ax = pos0.y;
-    int nm = 0;
-    int act_idx = 0, act_id = -1;
-    bool trunc = rows1[(int64_t)d.u_trunc * B + b] != 0;
     if (MODE == kStep) {
-        nm = rows[(int64_t)d.r_moves * B + b];
-        if (!pol.on) {
-            const int2 a2 = reinterpret_cast<const int2*>(actions)[(int64_t)agent * B + b];
-            act_idx = a2.x;
-            act_id = is_agent ? a2.y : -1;
-        }
         // the LDS words of this env's slots start clear
 #pragma unroll
         for (int k = 0; k < SPL; ++k) s_claim[wave][lane + 64 * k] = 0u, s_effect[wave][lane + 64 * k] = 0u;
-    }
-#pragma unroll
-    for (int k = 0; k < SPL; ++k) {  // dead lanes hold no passenger
-        v[k][PSTATE] = live[k] ? v[k][PSTATE] : -1;
-        v[k][PDRIVER] = live[k] ? v[k][PDRIVER] : -2;
     }
     // the passengers each agent drives, as a mask in that agent's lane (slot 64 k + 32 h + i = bit i of word 2 k + h)
     uint32_t driven[W];
@@ -354,13 +411,13 @@ __global__ void __launch_bounds__(kBlock) rs_env_kernel(char* __restrict__ arena
         const int t_state = of_target(PSTATE);
         if (pol.on) {
             act_id = (is_agent && target >= 0) ? t_state : -1;
-            if (is_agent) reinterpret_cast<int2*>(pol.actions_out)[(int64_t)lane * B + b] = make_int2(act_idx, act_id);
+            if (is_agent) at32(reinterpret_cast<int2*>(pol.actions_out), (uint32_t)lane * (uint32_t)B + (uint32_t)b) = make_int2(act_idx, act_id);
         }
-        const bool noop = act_id == -1;
-        const bool valid = is_agent && !noop && target >= 0;  // act_idx inside the mapping
-        if (is_agent && !noop && !valid) err |= FRZ_ERR_BAD_ACTION_INDEX;  // the reference reads a garbage row
-        const bool accept = valid && act_id == 0, pick = valid && act_id == 1, drop = valid && act_id == 2;
-        const bool has_vec = accept || pick || drop;
+        // act_idx inside the mapping <=> target >= 0 (lanes that are no agent carry act_id -1 and target -1)
+        if (__ballot(act_id != -1 && target < 0)) err |= FRZ_ERR_BAD_ACTION_INDEX;  // the reference reads a garbage row
+        const int kind = target >= 0 ? act_id : -1;
+        const bool accept = kind == 0, pick = kind == 1, drop = kind == 2;
+        const bool has_vec = (uint32_t)kind <= 2u;
         // goal of the task vector: the passenger's position, or its destination for a drop — from the state BEFORE movement
         const int t_y = of_target(PY), t_x = of_target(PX), t_yd = of_target(PYD), t_xd = of_target(PXD), t_fare = of_target(PFARE);
         const int gy = drop ? t_yd : t_y, gx = drop ? t_xd : t_x;
@@ -465,32 +522,14 @@ __global__ void __launch_bounds__(kBlock) rs_env_kernel(char* __restrict__ arena
         // i.e. where ANOTHER lane's value was read from)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int k = 0; k < SPL; ++k)
-            if (keep[k]) {
-                // a slot is rewritten only where it changes: every column once a removal has shifted it, otherwise the columns this step touched
-                const bool shifted = place[k] != lane + 64 * k;
-                const int at = place[k];
-                if (shifted || moved[k]) {
-                    pas[PY * P + at] = v[k][PY];
-                    pas[PX * P + at] = v[k][PX];
-                }
-                if (shifted) {
-                    pas[PYD * P + at] = v[k][PYD];
-                    pas[PXD * P + at] = v[k][PXD];
-                    pas[PFARE * P + at] = v[k][PFARE];
-                    pas[PENTERED * P + at] = v[k][PENTERED];
-                }
-                if (shifted || taken[k] || boarded[k]) pas[PSTATE * P + at] = v[k][PSTATE];
-                if (shifted || taken[k]) {
-                    pas[PDRIVER * P + at] = v[k][PDRIVER];
-                    pas[PACCEPTED * P + at] = v[k][PACCEPTED];
-                }
-                if (shifted || boarded[k]) pas[PPICKED * P + at] = v[k][PPICKED];
-            }
+        for (int k = 0; k < SPL; ++k) {
+            // a slot is rewritten only where it changes: the whole record once a removal has shifted it, otherwise its changeable part
+            const bool shifted = keep[k] && place[k] != lane + 64 * k;
+            if (shifted) store_cold(pas, (uint32_t)place[k], v[k]);
+            if (shifted || (keep[k] && (moved[k] || taken[k] || boarded[k]))) store_hot(pas, (uint32_t)place[k], v[k]);
+        }
         // ------------------------------------------------------------ (5) entry of the next timestep (rideshare.py:308)
-        const Schedule sch{reinterpret_cast<const int32_t*>(arena + d.off_schedule), reinterpret_cast<const int32_t*>(arena + d.off_schedule_index),
-                           d.max_time};
-        entered = passenger_entry(sch, pas, P, b, nm + 1, kept, err);
+        entered = entry_commit(sch, plan, pas, P, b, nm + 1, kept, err);
         count = kept + entered;
         // ------------------------------------------------------------ the new table as masks over the OLD slot numbers (counts do not care)
 #pragma unroll
@@ -552,17 +591,14 @@ __global__ void __launch_bounds__(kBlock) rs_env_kernel(char* __restrict__ arena
         const int nm1 = nm + 1;
         trunc = (flags & kTruncate) ? nm1 >= d.max_steps : trunc;
         if (is_agent) {
-            rowsf[(int64_t)(d.r_rewards + lane) * B + b] = reward;
-            if (flags & kTrackCumulative) {
-                float* const cum = rowsf + (int64_t)(d.r_cum + lane) * B + b;
-                *cum = __fadd_rn(*cum, reward);
-            }
-            if (flags & kTruncate) rows1[(int64_t)(d.u_trunc + lane) * B + b] = (uint8_t)trunc;
-            agents[lane] = make_int2(ay, ax);
+            at32(rowsf, (uint32_t)(d.r_rewards + lane) * Bu + bu) = reward;
+            if (flags & kTrackCumulative) at32(rowsf, (uint32_t)(d.r_cum + lane) * Bu + bu) = __fadd_rn(cum0, reward);
+            if (flags & kTruncate) at32(rows1, (uint32_t)(d.u_trunc + lane) * Bu + bu) = (uint8_t)trunc;
+            at32(agents, (uint32_t)lane) = make_int2(ay, ax);
         }
         if (lane == 0) {
-            rows[(int64_t)d.r_moves * B + b] = nm1;
-            rows[(int64_t)d.r_count * B + b] = count;
+            at32(rows, (uint32_t)d.r_moves * (uint32_t)B + (uint32_t)b) = nm1;
+            at32(rows, (uint32_t)d.r_count * (uint32_t)B + (uint32_t)b) = count;
         }
     }
 
@@ -579,8 +615,8 @@ __global__ void __launch_bounds__(kBlock) rs_env_kernel(char* __restrict__ arena
     }
     const int4 self = make_int4(ay, ax, n_accepted, n_riding);
     if (is_agent) {
-        reinterpret_cast<int4*>(arena + d.off_obs_self)[(int64_t)lane * B + b] = self;
-        rows[(int64_t)(d.r_atc + lane) * B + b] = visible;
+        at32(reinterpret_cast<int4*>(arena + d.off_obs_self), (uint32_t)lane * (uint32_t)B + (uint32_t)b) = self;
+        at32(rows, (uint32_t)(d.r_atc + lane) * (uint32_t)B + (uint32_t)b) = visible;
         s_self[wave][lane] = self;
     }
     wave_lds_sync();
@@ -589,7 +625,7 @@ __global__ void __launch_bounds__(kBlock) rs_env_kernel(char* __restrict__ arena
         const int others = A - 1, pairs = A * others;
         for (int q = lane; q < pairs; q += 64) {
             const int a = (int)(((uint32_t)q * d.inv_others) >> 16), j = q - a * others;
-            obs_others[((int64_t)a * B + b) * others + j] = s_self[wave][j < a ? j : j + 1];
+            at32(obs_others, ((uint32_t)a * (uint32_t)B + (uint32_t)b) * (uint32_t)others + (uint32_t)j) = s_self[wave][j < a ? j : j + 1];
         }
     }
     if (lane == 0) reinterpret_cast<int64_t*>(arena + d.off_etc)[b] = count;
@@ -652,9 +688,9 @@ __global__ void __launch_bounds__(kBlock) rs_emit_kernel(char* __restrict__ aren
     __shared__ int4 s_rows[kEnvsPerBlock][SPL * 64][2];
     __shared__ uint16_t s_pick[kEnvsPerBlock][AMAX * SPL * 64];  // flat place -> slot | state << 8 | agent << 12
     __shared__ int64_t s_dest[kEnvsPerBlock][AMAX];             // agent -> (first row of its segment in the [A][cap] outputs) - (its first flat place)
-    const int64_t bw = env_of_wave(d.B);
-    if (bw < 0) return;  // no workgroup barrier in this kernel
-    const int b = (int)bw, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = env_of_wave(d.B);
+    if (b < 0) return;  // no workgroup barrier in this kernel
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t B = d.B;
     const int A = d.A, P = d.P;
     const int32_t* rows = reinterpret_cast<const int32_t*>(arena + d.off_rows4);
@@ -668,14 +704,13 @@ __global__ void __launch_bounds__(kBlock) rs_emit_kernel(char* __restrict__ aren
 #pragma unroll
     for (int k = 0; k < SPL; ++k) {
         const int slot = lane + 64 * k;
+        const char* r = reinterpret_cast<const char*>(pas) + (uint64_t)((uint32_t)(slot < count ? slot : (count > 0 ? count - 1 : 0)) * 40u);
+        const int4u hot = *reinterpret_cast<const int4u*>(r), cold = *reinterpret_cast<const int4u*>(r + 24);
         const bool live = slot < count;
-        const int s = live ? slot : (count > 0 ? count - 1 : 0);
-        const int st_s = pas[PSTATE * P + s], drv_s = pas[PDRIVER * P + s];
-        const int4 lo = make_int4(pas[PY * P + s], pas[PX * P + s], pas[PYD * P + s], pas[PXD * P + s]);
-        const int4 hi = make_int4(st_s == 1 ? drv_s : kNone, st_s == 2 ? drv_s : kNone, pas[PFARE * P + s], pas[PENTERED * P + s]);
-        s_rows[wave][slot][0] = lo;
-        s_rows[wave][slot][1] = hi;
-        st[k] = live ? st_s : -1;  // dead lanes hold no passenger
+        const int st_s = hot.z, drv_s = hot.w;
+        s_rows[wave][slot][0] = make_int4(hot.x, hot.y, cold.x, cold.y);
+        s_rows[wave][slot][1] = make_int4(st_s == 1 ? drv_s : kNone, st_s == 2 ? drv_s : kNone, cold.z, cold.w);
+        st[k] = live ? st_s : -1;  // lanes past the count hold no passenger
         drv[k] = live ? drv_s : -2;
     }
     // flat places: agent 0's visible slots in table order, then agent 1's, ...
@@ -817,7 +852,9 @@ int frz_rideshare_create(const frz_rideshare_cfg* cfg, const int32_t* schedule, 
     const int A = cfg->num_agents, P = cfg->max_passengers;
     if (cfg->parallel_envs <= 0 || A <= 0 || A > FRZ_MAX_AGENTS || P <= 0 || P > FRZ_MAX_PASSENGERS || cfg->schedule_rows < 0)
         return FRZ_E_INVALID;
-    if ((int64_t)PCOLS * P * cfg->parallel_envs >= (int64_t)1 << 40 || (int64_t)(4 * A + 8) * cfg->parallel_envs >= (int64_t)1 << 30)
+    // arrays the kernels address with 32-bit byte offsets from a wave-uniform base stay below 4 GiB
+    if ((int64_t)(4 * A + 8) * cfg->parallel_envs >= (int64_t)1 << 28 || (int64_t)A * (A - 1) * cfg->parallel_envs * 16 >= (int64_t)1 << 32 ||
+        (int64_t)cfg->schedule_rows * 28 >= (int64_t)1 << 32)
         return FRZ_E_INVALID;
     // coordinates stay inside +-16383: squared distances fit 32 bits, an agent's move (a difference of two positions with fast
     // travel) travels between lanes as two 16-bit halves of one word

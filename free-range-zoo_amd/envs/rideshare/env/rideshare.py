@@ -3,7 +3,7 @@
 Mirrors free_range_zoo/envs/rideshare/env/rideshare.py (``parallel_env`` :98-114, ``raw_env`` :135-504): same
 constructor keywords, agent names (``driver_i``), observation / mapping attributes, dtypes and shapes.  The arithmetic
 runs in ``csrc/rideshare.hip`` through ``frz_rideshare_*`` (include/frz.h).  The reference's single global passenger
-table is kept as ``max_passengers`` ordered slots per env on the device (env-major ``[B][column][slot]``: one env per
+table is kept as ``max_passengers`` ordered slots per env on the device (env-major records ``[B][slot][10]``: one env per
 wavefront, its slots across the lanes); ``state().passengers`` rebuilds the table.
 """
 import ctypes
@@ -78,7 +78,7 @@ class raw_env(BatchedParallelEnv):
         f32, i32, i64, u8 = torch.float32, torch.int32, torch.int64, torch.uint8
         v = self._view
         self._agents = v(bufs.agents, (B, A, 2), i32)
-        self._passengers = v(bufs.passengers, (B, 10, P), i32)
+        self._passengers = v(bufs.passengers, (B, P, 10), i32)
         self._passenger_count = v(bufs.passenger_count, (B, ), i32)
         self.num_moves = v(bufs.num_moves, (B, ), i32)
         self._rewards, self._cumulative = v(bufs.rewards, (A, B), f32), v(bufs.cumulative_rewards, (A, B), f32)
@@ -121,12 +121,16 @@ class raw_env(BatchedParallelEnv):
             pass
 
     # ----------------------------------------------------------------------------------------------- state views
+    # device record (y, x, state, driver, accepted, picked, y_dest, x_dest, fare, entered: what a step can change comes first, include/frz.h)
+    # -> the reference's columns after the env id (y, x, y_dest, x_dest, fare, state, driver, entered, accepted, picked)
+    _REFERENCE_ORDER = [0, 1, 6, 7, 8, 2, 3, 9, 4, 5]
+
     def state(self) -> RideshareState:
         """Current state in the reference's form: agents ``[B, A, 2]`` (view) and the global passenger table ``[P, 11]``."""
         B, P = self.parallel_envs, self._P
         live = torch.arange(P, device=self.device).unsqueeze(1) < self._passenger_count.unsqueeze(0)  # [P, B]
         envs, slots = live.t().nonzero(as_tuple=True)  # env-major, slot order = table order
-        columns = self._passengers[envs, :, slots]  # [n, 10]
+        columns = self._passengers[envs, slots][:, self._REFERENCE_ORDER]  # [n, 10], the reference's column order
         table = torch.cat([envs.to(torch.int32).unsqueeze(1), columns], dim=1)
         return RideshareState(agents=self._agents, passengers=table)
 
@@ -140,7 +144,9 @@ class raw_env(BatchedParallelEnv):
             raise ValueError('initial_state holds more passengers in one env than max_passengers slots')
         starts = torch.cumsum(counts, 0) - counts
         slots = torch.arange(table.shape[0], device=self.device) - starts[envs]
-        self._passengers[envs, :, slots] = table[:, 1:].to(torch.int32)
+        record = torch.empty((table.shape[0], 10), dtype=torch.int32, device=self.device)
+        record[:, self._REFERENCE_ORDER] = table[:, 1:].to(torch.int32)
+        self._passengers[envs, slots] = record
         self._passenger_count.copy_(counts.to(torch.int32))
 
     # ---------------------------------------------------------------------------------------- output plumbing

@@ -368,11 +368,12 @@ int frz_cybersecurity_step_random_policy(frz_cybersecurity_env* env, uint64_t po
  * Rideshare  (reference: free_range_zoo/envs/rideshare/env/rideshare.py, transitions/,
  *             structures/configuration.py).  Deterministic: no randomness is drawn.
  * The reference keeps ONE global passenger table sorted by env (stable: entry order inside an env); here every env owns
- * max_passengers slots in that same order, env-major [B][column][slot]: one env is stepped by one wavefront whose lanes hold its slots,
- * so a column of an env is one coalesced access.
+ * max_passengers slots in that same order, env-major records [B][slot][FRZ_PASSENGER_COLUMNS]: one env is stepped by one wavefront whose
+ * lanes hold its slots; a record is (y, x, state, driver, accepted, picked, y_dest, x_dest, fare, entered) — the columns a step can change
+ * first, so that a changed slot is rewritten with two wide stores.
  * ---------------------------------------------------------------------------------------------- */
 #define FRZ_MAX_PASSENGERS 128
-#define FRZ_PASSENGER_COLUMNS 10 /* y, x, y_dest, x_dest, fare, state, driver, entered, accepted, picked */
+#define FRZ_PASSENGER_COLUMNS 10 /* y, x, state, driver, accepted, picked, y_dest, x_dest, fare, entered */
 
 typedef struct frz_rideshare_cfg {
     int32_t parallel_envs;
@@ -394,7 +395,7 @@ typedef struct frz_rideshare_cfg {
 
 typedef struct frz_rideshare_bufs {
     int32_t* agents;           /* [B][A][2]  (y, x): the reference's own layout (structures/state.py:10-66) */
-    int32_t* passengers;       /* [B][FRZ_PASSENGER_COLUMNS][max_passengers] */
+    int32_t* passengers;       /* [B][max_passengers][FRZ_PASSENGER_COLUMNS] */
     int32_t* passenger_count;  /* [B] */
     int32_t* num_moves;        /* [B] */
     float* rewards;            /* [A][B] */
