@@ -25,9 +25,9 @@ struct ScanWorkspace {
     uint64_t* prefix;  // [nchunks][nch_total]
 };
 
-template <int NCH>
+template <int NCH, int BITS = 16>
 struct ScanShared {
-    uint64_t wave_scan[kWaves][(NCH + 3) / 4];
+    uint64_t wave_scan[kWaves][(NCH + 64 / BITS - 1) / (64 / BITS)];
     uint32_t wave_live[kWaves][2];
     uint32_t reduce[kWaves][32];
     uint32_t prefix[32];
@@ -62,14 +62,18 @@ __device__ __forceinline__ int scan_take_chunk(const ScanWorkspace& ws, int nchu
     return *lds_word;
 }
 
-// cnt[ch] < 65536 / 256 per env (counts are packed in 16-bit fields over a 256-env chunk).
+// Counts are packed in BITS-wide fields over a 256-env chunk: cnt[ch] < 2^BITS / 256 per env (BITS = 16: up to 255 tasks per env, four
+// channels per 64-bit word; BITS = 32: large wildfire grids, two channels per word).
 // On return excl[ch] = sum of cnt[ch] over all envs of the launch that precede this lane's env.
 // Channels nch and nch + 1 of the granules / totals carry the number of envs with live0 / live1 set.
-template <int NCH>
-__device__ __forceinline__ void scan_chunk(ScanShared<NCH>& sh, const ScanWorkspace& ws, const ScanLaunch& l, const uint32_t (&cnt)[NCH],
+template <int NCH, int BITS = 16>
+__device__ __forceinline__ void scan_chunk(ScanShared<NCH, BITS>& sh, const ScanWorkspace& ws, const ScanLaunch& l, const uint32_t (&cnt)[NCH],
                                            bool live0, bool live1, int nch, int chunk, int nchunks, uint32_t (&excl)[NCH],
                                            uint32_t* err) {
-    constexpr int PW = (NCH + 3) / 4;
+    static_assert(BITS == 16 || BITS == 32, "field width");
+    constexpr int PER = 64 / BITS;  // channels per packed word
+    constexpr uint64_t FIELD = BITS == 16 ? 0xFFFFull : 0xFFFFFFFFull;
+    constexpr int PW = (NCH + PER - 1) / PER;
     constexpr int NCHP = NCH + 2 <= 8 ? 8 : (NCH + 2 <= 16 ? 16 : 32);
     static_assert(NCH + 2 <= 32, "too many scan channels");
     const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
@@ -79,7 +83,7 @@ __device__ __forceinline__ void scan_chunk(ScanShared<NCH>& sh, const ScanWorksp
 #pragma unroll
     for (int w = 0; w < PW; ++w) packed[w] = 0;
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) packed[ch >> 2] |= (uint64_t)(cnt[ch] & 0xFFFFu) << (16 * (ch & 3));
+    for (int ch = 0; ch < NCH; ++ch) packed[ch / PER] |= ((uint64_t)cnt[ch] & FIELD) << (BITS * (ch % PER));
 #pragma unroll
     for (int w = 0; w < PW; ++w) incl[w] = wave_inclusive_scan(packed[w]);
     const uint32_t n0 = (uint32_t)__popcll(__ballot(live0)), n1 = (uint32_t)__popcll(__ballot(live1));
@@ -110,8 +114,8 @@ __device__ __forceinline__ void scan_chunk(ScanShared<NCH>& sh, const ScanWorksp
         if (tid < nch) {
             uint64_t word = total[0];
 #pragma unroll
-            for (int w = 1; w < PW; ++w) word = (tid >> 2) == w ? total[w] : word;
-            mine = (uint32_t)((word >> (16 * (tid & 3))) & 0xFFFFull);
+            for (int w = 1; w < PW; ++w) word = (tid / PER) == w ? total[w] : word;
+            mine = (uint32_t)((word >> (BITS * (tid % PER))) & FIELD);
         } else {
 #pragma unroll
             for (int j = 0; j < kWaves; ++j) mine += sh.wave_live[j][tid - nch];
@@ -171,8 +175,8 @@ __device__ __forceinline__ void scan_chunk(ScanShared<NCH>& sh, const ScanWorksp
 
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-        const int w = ch >> 2, shf = 16 * (ch & 3);
-        excl[ch] = sh.prefix[ch] + (uint32_t)(((base[w] + incl[w] - packed[w]) >> shf) & 0xFFFFull);
+        const int w = ch / PER, shf = BITS * (ch % PER);
+        excl[ch] = sh.prefix[ch] + (uint32_t)(((base[w] + incl[w] - packed[w]) >> shf) & FIELD);
     }
 }
 

@@ -18,6 +18,7 @@
 // "slot lanes" and "agent lanes" is a ballot, a v_writelane, a ds_bpermute or an LDS word per slot: no workgroup barrier anywhere (a
 // 256-thread workgroup is four independent envs).  Deterministic integer/byte work, HBM-bound: no MFMA.
 #include "frz_scan.h"
+#include "frz_wave.h"
 
 #include "../../include/frz.h"
 
@@ -34,6 +35,16 @@
 namespace {
 
 using frz::kBlock;
+using frz::at32;
+using frz::for_each_index;
+using frz::from_lane;
+using frz::lane_rank;
+using frz::last_bit;
+using frz::popc_words;
+using frz::read_lane;
+using frz::select_nth;
+using frz::wave_lds_sync;
+using frz::write_lane_c;
 
 enum Mode { kStep = 0, kRebuild = 1 };
 enum Flag : uint32_t { kFast = 1u << 0, kDiagonal = 1u << 1, kVariableMove = 1u << 2, kWaiting = 1u << 3, kTrackCumulative = 1u << 4, kTruncate = 1u << 5 };
@@ -64,14 +75,6 @@ struct RsPolicy {
     int32_t* actions_out;
 };
 
-// element `index` of an array whose base is wave-uniform, addressed as (scalar base) + (32-bit byte offset): one instruction instead of
-// 64-bit address arithmetic per access (frz_rideshare_create bounds every array addressed this way below 4 GiB)
-template <typename T>
-__device__ __forceinline__ T& at32(T* base, uint32_t index) {
-    using Byte = std::conditional_t<std::is_const_v<T>, const char, char>;
-    return *reinterpret_cast<T*>(reinterpret_cast<Byte*>(base) + (uint64_t)(index * (uint32_t)sizeof(T)));
-}
-
 // one passenger record (40 bytes, 8-byte aligned) of an env's table, as three accesses with immediate offsets
 typedef int int4u __attribute__((ext_vector_type(4), aligned(8)));  // records are 8-byte aligned
 typedef int int2u __attribute__((ext_vector_type(2), aligned(8)));
@@ -88,30 +91,6 @@ __device__ __forceinline__ void store_hot(int32_t* table, uint32_t slot, const i
 }
 __device__ __forceinline__ void store_cold(int32_t* table, uint32_t slot, const int (&v)[10]) {
     *reinterpret_cast<int4u*>(reinterpret_cast<char*>(table) + (uint64_t)(slot * 40u) + 24) = int4u{v[6], v[7], v[8], v[9]};
-}
-
-// ---- wavefront helpers: lanes 0..63 of ONE env
-__device__ __forceinline__ int lane_rank(uint64_t m) {  // set bits of m below this lane
-    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
-__device__ __forceinline__ int from_lane(int src_lane, int value) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, value); }
-__device__ __forceinline__ int read_lane(int value, int lane) { return __builtin_amdgcn_readlane(value, lane); }
-__device__ __forceinline__ int last_bit(uint64_t m) { return 63 - __builtin_clzll(m); }
-
-// The env a wavefront owns.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 share one); the mapping below gives every
-// run of 32 consecutive envs (one 128-byte line of each [rows][B] array) to workgroups of ONE XCD, so that its L2 merges their 4-byte
-// pieces into whole lines.  Speed only: any bijection is correct.
-__device__ __forceinline__ int env_of_wave(int64_t B) {
-    const uint32_t nblocks = gridDim.x, blk = blockIdx.x;
-    uint32_t quad = blk;
-    const uint32_t group = blk >> 6;
-    if ((group + 1u) * 64u <= nblocks) {
-        const uint32_t l = blk & 63u;
-        quad = (group << 6) + ((l & 7u) << 3) + (l >> 3);
-    }
-    // the same in every lane of a wavefront: said so explicitly, so that everything derived from the env index stays in scalar registers
-    const int b = __builtin_amdgcn_readfirstlane((int)(quad * kEnvsPerBlock + (threadIdx.x >> 6)));
-    return b < B ? b : -1;
 }
 
 // schedule rows of one timestep are contiguous in the time-sorted device copy: [index[t], index[t + 1])
@@ -176,7 +155,7 @@ __device__ __forceinline__ int entry_commit(const Schedule& sch, const EntryPlan
 
 // rideshare.py:185-222 + utils/env.py:137-160: agents at their start positions, bookkeeping zeroed, step-0 passengers enter
 __global__ void __launch_bounds__(kBlock) rs_fill_kernel(char* __restrict__ arena, const RsDev d) {
-    const int b = env_of_wave(d.B);
+    const int b = frz::env_of_wave<kEnvsPerBlock>(d.B);
     if (b < 0) return;
     const int lane = threadIdx.x & 63;
     const int64_t B = d.B;
@@ -211,64 +190,6 @@ __global__ void __launch_bounds__(kBlock) rs_fill_kernel(char* __restrict__ aren
 // the index-th visible passenger, the counts of the rebuilt spaces — is vector arithmetic on those masks, all agents at once.  What
 // agents do to slots (accept / pick / drop) and the accept claims travel through two LDS words per slot.
 // ------------------------------------------------------------------------------------------------------------------------------------
-// gfx950 needs two wait states between a vector instruction that writes a scalar register (a ballot's v_cmp) and a vector instruction
-// that reads it; the compiler inserts them for its own instructions but does not look inside an asm statement, hence the s_nop.
-template <int LANE>
-__device__ __forceinline__ uint32_t write_lane_c(uint32_t vec, uint32_t scalar) {  // vec with lane LANE replaced by a wave-uniform value
-    asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(vec) : "s"(scalar), "n"(LANE));
-    return vec;
-}
-template <int LANE>
-__device__ __forceinline__ void write_lane_c(uint32_t& lo, uint32_t& hi, uint64_t scalar) {  // the two halves of a ballot
-    asm("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
-        : "+v"(lo), "+v"(hi)
-        : "s"((uint32_t)scalar), "s"((uint32_t)(scalar >> 32)), "n"(LANE));
-}
-template <typename F, int... Is>
-__device__ __forceinline__ void for_each_index(std::integer_sequence<int, Is...>, F&& f) {
-    (f(std::integral_constant<int, Is>{}), ...);
-}
-__device__ __forceinline__ void wave_lds_sync() {  // LDS traffic of one wavefront is in order; this keeps the compiler from reordering it
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// position of the n-th (0-based) set bit of a mask of W 32-bit words, -1 when the mask has no more than n bits: a descent on population
-// counts, per lane, without divergence
-template <int W>
-__device__ __forceinline__ int select_nth(const uint32_t (&mask)[W], int n) {
-    int word = 0, rem = n;
-#pragma unroll
-    for (int i = 0; i + 1 < W; ++i) {
-        const int c = __popc(mask[i]);
-        const bool up = word == i && rem >= c;
-        rem -= up ? c : 0;
-        word += up ? 1 : 0;
-    }
-    uint32_t w = mask[0];
-#pragma unroll
-    for (int i = 1; i < W; ++i) w = word == i ? mask[i] : w;
-    const bool found = n >= 0 && rem < __popc(w);
-    int pos = 32 * word;
-#pragma unroll
-    for (int width = 16; width >= 1; width >>= 1) {
-        const int c = __popc(w & ((1u << width) - 1u));
-        const bool up = rem >= c;
-        rem -= up ? c : 0;
-        w = up ? w >> width : w;
-        pos += up ? width : 0;
-    }
-    return found ? pos : -1;
-}
-template <int W>
-__device__ __forceinline__ int popc_words(const uint32_t (&mask)[W]) {
-    int n = 0;
-#pragma unroll
-    for (int i = 0; i < W; ++i) n += __popc(mask[i]);
-    return n;
-}
-
 template <int AMAX, int SPL, int MODE>
 __global__ void __launch_bounds__(kBlock) rs_env_kernel(char* __restrict__ arena, const RsDev d, const int32_t* __restrict__ actions,
                                                          const RsPolicy pol) {
@@ -276,7 +197,7 @@ __global__ void __launch_bounds__(kBlock) rs_env_kernel(char* __restrict__ arena
     __shared__ uint32_t s_claim[kEnvsPerBlock][SPL * 64];   // accepting agents per slot
     __shared__ uint32_t s_effect[kEnvsPerBlock][SPL * 64];  // (winning agent + 1) << 8 | picked << 1 | dropped << 2
     __shared__ int4 s_self[kEnvsPerBlock][AMAX];            // the agents' self observation rows
-    const int b = env_of_wave(d.B);
+    const int b = frz::env_of_wave<kEnvsPerBlock>(d.B);
     if (b < 0) return;  // no workgroup barrier in this kernel: a wavefront without an env just leaves
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t B = d.B;
@@ -688,7 +609,7 @@ __global__ void __launch_bounds__(kBlock) rs_emit_kernel(char* __restrict__ aren
     __shared__ int4 s_rows[kEnvsPerBlock][SPL * 64][2];
     __shared__ uint16_t s_pick[kEnvsPerBlock][AMAX * SPL * 64];  // flat place -> slot | state << 8 | agent << 12
     __shared__ int64_t s_dest[kEnvsPerBlock][AMAX];             // agent -> (first row of its segment in the [A][cap] outputs) - (its first flat place)
-    const int b = env_of_wave(d.B);
+    const int b = frz::env_of_wave<kEnvsPerBlock>(d.B);
     if (b < 0) return;  // no workgroup barrier in this kernel
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t B = d.B;

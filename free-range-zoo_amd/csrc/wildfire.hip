@@ -931,6 +931,11 @@ struct frz_wildfire_env {
     std::vector<hipEvent_t> timing_events;                   // pool of frz_wildfire_timed_rollout
     bool timed = false;
     bool ticketed = false;  // field/crew kernels: more chunks than resident workgroups
+    // grids above 16 cells (wildfire_grid.hip): the kernels' configuration and the tables uploaded into the arena at bind
+    WgDev gdev;
+    WgAgentTable agent_table;
+    std::vector<int32_t> cell_tables;    // fire_rewards (float bits), ignition, initial fires / intensity / fuel: HW entries each
+    std::vector<uint64_t> range_words;   // [A][S][chunks]
 };
 
 namespace {
@@ -994,6 +999,7 @@ int launch_lane(frz_wildfire_env* env, const WfArgs& args, int rng, int mode, hi
 }
 
 int launch(frz_wildfire_env* env, const WfArgs& args, int rng, int mode, hipStream_t stream) {
+    if (env->dev.grid) return launch_grid(env->gdev, env->arena, args, rng, mode, env->ticketed, stream);
     if (!env->dev.roles) {
         WfArgs a = args;
         a.ticketed = env->ticketed;
@@ -1012,6 +1018,175 @@ T* at(char* arena, int64_t off) {
     return reinterpret_cast<T*>(arena + off);
 }
 
+// frz_wildfire_create for the grid family (wildfire_grid.hip): cell arrays env-major [B][H*W]; everything per env that is not a cell
+// array keeps the [rows][B] blocks of the other kernels, described by the same WfDev block at arena offset 0, so that the helper kernels
+// (random policy, episode metrics) serve both families unchanged.
+int create_grid(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
+    const int H = cfg->grid_height, W = cfg->grid_width, HW = H * W, A = cfg->num_agents, S = cfg->num_equipment_states;
+    if (S <= 0 || S > FRZ_MAX_EQUIPMENT_STATES || cfg->num_capacities <= 0 || cfg->num_capacities > FRZ_MAX_CAPACITIES) return FRZ_E_INVALID;
+    if (cfg->num_fire_states < 2 || cfg->initial_equipment_state < 0 || cfg->initial_equipment_state >= S) return FRZ_E_INVALID;
+    const int64_t B = cfg->parallel_envs;
+    // arrays addressed with 32-bit byte offsets from a uniform base: the [rows][B] blocks, one env's cells, the observation records
+    if ((int64_t)(6 * A + 8) * B >= (int64_t)1 << 28 || (int64_t)A * (A - 1) * B * 16 >= (int64_t)1 << 32) return FRZ_E_INVALID;
+    frz_wildfire_env* env = new (std::nothrow) frz_wildfire_env();
+    if (!env) return FRZ_E_INVALID;
+    env->cfg = *cfg;
+    WfDev& p = env->dev;
+    WgDev& g = env->gdev;
+    std::memset(&p, 0, sizeof(p));
+    std::memset(&g, 0, sizeof(g));
+    int chunks = 1;
+    while (chunks * 64 < HW) chunks *= 2;  // the kernels are instantiated for 1, 2, 4, 8, 16 cells per lane
+    p.grid = 1;
+    p.B = g.B = cfg->parallel_envs, p.H = g.H = H, p.W = g.W = W, p.HW = g.HW = HW, p.A = g.A = A, p.S = g.S = S;
+    p.K = g.K = cfg->num_capacities;
+    p.nchunks = g.nchunks = (int)((B + kBlock - 1) / kBlock);
+    p.nch = A + 3;
+    p.others_k = g.others_k = 2 + (cfg->observe_other_power ? 1 : 0) + (cfg->observe_other_suppressant ? 1 : 0);
+    p.max_steps = g.max_steps = cfg->max_steps;
+    p.num_fire_states = g.num_fire_states = cfg->num_fire_states;
+    auto flag = [&](int on, uint32_t bit) { p.flags |= on ? bit : 0u; };
+    flag(cfg->stochastic_increase, kStochIncrease);
+    flag(cfg->stochastic_burnouts, kStochBurnouts);
+    flag(cfg->stochastic_decrease, kStochDecrease);
+    flag(cfg->use_fire_fuel, kUseFuel);
+    flag(cfg->stochastic_suppressant_decrease, kStochSuppDecrease);
+    flag(cfg->stochastic_refill, kStochRefill);
+    flag(cfg->stochastic_switch, kStochSwitch);
+    flag(cfg->stochastic_repair, kStochRepair);
+    flag(cfg->stochastic_degrade, kStochDegrade);
+    flag(cfg->critical_error, kCritical);
+    flag(cfg->show_bad_actions, kShowBad);
+    flag(cfg->observe_other_power, kObsPower);
+    flag(cfg->observe_other_suppressant, kObsSupp);
+    flag(cfg->burnout_penalty_scaled, kPenaltyScaled);
+    flag(cfg->localize_putouts, kLocalize);
+    flag(cfg->track_cumulative_rewards, kTrackCumulative);
+    flag(cfg->max_steps >= 0, kTruncate);
+    g.flags = p.flags;
+    g.inv_w = (uint32_t)((65536 + W - 1) / W);
+    for (int c = 0; c < HW; ++c)
+        if ((int)(((uint32_t)c * g.inv_w) >> 16) != c / W) {  // cannot happen for HW <= FRZ_MAX_CELLS; checked, not assumed
+            delete env;
+            return FRZ_E_INVALID;
+        }
+    g.inv_others = A > 1 ? (uint32_t)((65536 + A - 2) / (A - 1)) : 0u;
+    for (int q = 0; q < A * (A - 1); ++q)
+        if ((int)(((uint32_t)q * g.inv_others) >> 16) != q / (A - 1)) {
+            delete env;
+            return FRZ_E_INVALID;
+        }
+    g.p_increase = cfg->intensity_increase_probability, g.p_burnout = cfg->burnout_probability, g.p_decrease = cfg->intensity_decrease_probability;
+    g.decrease_bonus = cfg->extra_power_decrease_bonus, g.p_supp_decrease = cfg->suppressant_decrease_probability;
+    g.p_refill = cfg->suppressant_refill_probability, g.p_switch = cfg->tank_switch_probability, g.p_repair = cfg->repair_probability;
+    g.p_degrade = cfg->degrade_probability, g.p_critical = cfg->critical_error_probability;
+    g.spread_n = cfg->spread_n, g.spread_w = cfg->spread_w, g.spread_e = cfg->spread_e, g.spread_s = cfg->spread_s;
+    g.random_ignition = cfg->random_ignition;
+    g.bad_attack_penalty = cfg->bad_attack_penalty, g.burnout_penalty = cfg->burnout_penalty;
+    g.termination_reward = cfg->termination_reward, g.termination_kappa = cfg->termination_kappa;
+    for (int j = 0; j < FRZ_MAX_CAPACITIES; ++j) g.cum[j] = j < cfg->num_capacities ? cfg->capacity_cumprobs[j] : __builtin_inff();
+    g.initial_fuel = cfg->initial_fuel, g.initial_equipment = cfg->initial_equipment_state;
+    g.initial_suppressant = cfg->initial_suppressant, g.initial_capacity = cfg->initial_capacity;
+
+    // tables a lane indexes by agent / equipment state / cell
+    WgAgentTable& t = env->agent_table;
+    std::memset(&t, 0, sizeof(t));
+    std::memcpy(t.power, cfg->fire_reduction_power, sizeof(t.power));
+    std::memcpy(t.ay, cfg->agent_y, sizeof(t.ay));
+    std::memcpy(t.ax, cfg->agent_x, sizeof(t.ax));
+    std::memcpy(t.caps, cfg->possible_capacities, sizeof(t.caps));
+    for (int s = 0; s < FRZ_MAX_EQUIPMENT_STATES; ++s)
+        for (int j = 0; j < 3; ++j) t.eq[s][j] = cfg->equipment_states[s][j];
+    env->cell_tables.assign((size_t)5 * HW, 0);
+    for (int c = 0; c < HW; ++c) {
+        const int type = cfg->fire_types[c], f0 = cfg->lit[c] ? type : -type;  // wildfire.py:347-351
+        std::memcpy(&env->cell_tables[c], &cfg->fire_rewards[c], 4);
+        env->cell_tables[(size_t)HW + c] = cfg->ignition_temp[c];
+        env->cell_tables[(size_t)2 * HW + c] = f0;
+        env->cell_tables[(size_t)3 * HW + c] = cfg->lit[c] ? cfg->ignition_temp[c] : 0;
+        env->cell_tables[(size_t)4 * HW + c] = f0 != 0 ? cfg->initial_fuel : 0;
+    }
+    // in-range cell sets: chebyshev(agent, cell) <= attack_range + equipment range bonus, float32 compare
+    // (utils/in_range_check.py:5-23, wildfire.py:604-616)
+    env->range_words.assign((size_t)A * S * chunks, 0ull);
+    for (int a = 0; a < A; ++a)
+        for (int s = 0; s < S; ++s) {
+            const float true_range = cfg->attack_range[a] + cfg->equipment_states[s][2];
+            for (int c = 0; c < HW; ++c) {
+                const int dy = std::abs(cfg->agent_y[a] - c / W), dx = std::abs(cfg->agent_x[a] - c % W);
+                if ((float)(dy > dx ? dy : dx) <= true_range) env->range_words[((size_t)a * S + s) * chunks + c / 64] |= 1ull << (c % 64);
+            }
+        }
+
+    // ---- arena layout
+    int r = 0;
+    p.r_supp = r, r += A;
+    p.r_cap = r, r += A;
+    p.r_equip = r, r += A;
+    p.r_moves = r++;
+    p.r_burnouts = r++;
+    p.r_rewards = r, r += A;
+    p.r_cum = r, r += A;
+    p.r_atc = r, r += A;
+    p.r_seeds = r++;
+    p.r_mti = r++;
+    p.n_rows4 = r;
+    p.q_burnouts = 0, p.q_putouts = 1, p.q_etc = 2, p.n_rows8 = 3;
+    p.u_term = 0, p.u_trunc = A, p.u_frozen = 2 * A, p.n_rows1 = 2 * A + 1;
+    const int64_t cap = B * HW, ok = p.others_k;
+    int64_t off = kDevBlockBytes;
+    auto take = [&](int64_t bytes) {
+        const int64_t here = off;
+        off = align_up(off + (bytes > 0 ? bytes : 1), 256);
+        return here;
+    };
+    p.off_rows4 = take((int64_t)p.n_rows4 * B * 4);
+    p.off_rows8 = take((int64_t)p.n_rows8 * B * 8);
+    p.off_rows1 = take((int64_t)p.n_rows1 * B);
+    g.off_cells = take(3 * cap * 4);
+    g.off_agent_table = take(sizeof(WgAgentTable));
+    g.off_cell_tables = take((int64_t)5 * HW * 4);
+    g.off_range = take((int64_t)A * S * chunks * 8);
+    p.off_obs_self = take((int64_t)A * B * 16);
+    p.off_obs_others = take((int64_t)A * B * (A - 1) * ok * 4);
+    p.off_task_offsets = take((B + 1) * 8);
+    p.off_act_offsets = take((int64_t)A * (B + 1) * 8);
+    p.off_bad_offsets = take((int64_t)A * (B + 1) * 8);
+    p.off_task_values = take(cap * 32);
+    p.off_obs_map = take(cap * 8);
+    p.off_act_values = take((int64_t)A * cap * 8);
+    p.off_bad_values = take(cfg->show_bad_actions ? (int64_t)A * cap * 8 : 256);
+    p.off_actions = take((int64_t)A * B * 8);
+    p.off_error = take(256);
+    p.off_epoch = take(256);
+    p.off_metrics = take((int64_t)kMetricBlocks * (FRZ_MAX_AGENTS + 2) * 8);
+    p.off_totals = take(2 * kTotalsStride * 4);
+    p.off_agg = take((int64_t)p.nchunks * p.nch * 8);
+    p.off_prefix = take((int64_t)p.nchunks * p.nch * 8);
+    p.off_rand_field = take(3 * cap * 4);
+    p.off_rand_agent = take(5 * B * A * 4);
+    p.off_mt_state = take(624 * B * 4);
+    p.total_bytes = off;
+    g.r_supp = p.r_supp, g.r_cap = p.r_cap, g.r_equip = p.r_equip, g.r_moves = p.r_moves, g.r_burnouts = p.r_burnouts, g.r_rewards = p.r_rewards;
+    g.r_cum = p.r_cum, g.r_atc = p.r_atc, g.r_seeds = p.r_seeds, g.r_mti = p.r_mti;
+    g.q_burnouts = p.q_burnouts, g.q_putouts = p.q_putouts, g.q_etc = p.q_etc;
+    g.u_term = p.u_term, g.u_trunc = p.u_trunc, g.u_frozen = p.u_frozen;
+    g.off_rows4 = p.off_rows4, g.off_rows8 = p.off_rows8, g.off_rows1 = p.off_rows1;
+    g.off_obs_self = p.off_obs_self, g.off_obs_others = p.off_obs_others, g.off_task_values = p.off_task_values;
+    g.off_task_offsets = p.off_task_offsets, g.off_obs_map = p.off_obs_map, g.off_act_values = p.off_act_values;
+    g.off_act_offsets = p.off_act_offsets, g.off_bad_values = p.off_bad_values, g.off_bad_offsets = p.off_bad_offsets;
+    g.off_error = p.off_error, g.off_epoch = p.off_epoch, g.off_totals = p.off_totals, g.off_agg = p.off_agg, g.off_prefix = p.off_prefix;
+
+    int device = 0, cus = 256;
+    if (hipGetDevice(&device) == hipSuccess) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    }
+    env->ticketed = p.nchunks > cus;  // wg_offsets_kernel: one workgroup per chunk, handed out in arrival order beyond one per CU
+    *out = env;
+    return FRZ_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1022,6 +1197,12 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
     if (!cfg || !out) return FRZ_E_INVALID;
     const int H = cfg->grid_height, W = cfg->grid_width, HW = H * W, A = cfg->num_agents;
     if (cfg->parallel_envs <= 0 || H <= 0 || W <= 0 || HW > FRZ_MAX_CELLS || A <= 0 || A > FRZ_MAX_AGENTS) return FRZ_E_INVALID;
+    // Kernel family.  Grids above 16 cells run one env per wavefront with the cells across its lanes (wildfire_grid.hip); smaller ones
+    // one env per lane (field/crew wavefront pairs, or the lane-per-env kernel below).  FRZ_WF_KERNEL=grid|lane|roles overrides.
+    const char* family = std::getenv("FRZ_WF_KERNEL");
+    const bool force_grid = family && std::strcmp(family, "grid") == 0;
+    const bool force_small = family && (std::strcmp(family, "lane") == 0 || std::strcmp(family, "roles") == 0);
+    if (force_grid || HW > 16 && !(force_small && HW <= kSmallCells)) return create_grid(cfg, out);
     if (cfg->num_equipment_states <= 0 || cfg->num_equipment_states > FRZ_MAX_EQUIPMENT_STATES) return FRZ_E_INVALID;
     if (cfg->num_capacities <= 0 || cfg->num_capacities > FRZ_MAX_CAPACITIES) return FRZ_E_INVALID;
     if (cfg->num_fire_states < 2) return FRZ_E_INVALID;
@@ -1231,6 +1412,14 @@ int frz_wildfire_bind(frz_wildfire_env* env, void* arena, void* stream) {
     env->was_reset = false;
     if (hipMemcpyAsync(arena, &env->dev, sizeof(WfDev), hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)) != hipSuccess)
         return FRZ_E_LAUNCH;
+    if (env->dev.grid) {
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        const WgDev& g = env->gdev;
+        if (hipMemcpyAsync(env->arena + g.off_agent_table, &env->agent_table, sizeof(WgAgentTable), hipMemcpyHostToDevice, s) != hipSuccess ||
+            hipMemcpyAsync(env->arena + g.off_cell_tables, env->cell_tables.data(), env->cell_tables.size() * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
+            hipMemcpyAsync(env->arena + g.off_range, env->range_words.data(), env->range_words.size() * 8, hipMemcpyHostToDevice, s) != hipSuccess)
+            return FRZ_E_LAUNCH;
+    }
     // the handle owns the pageable source for the life of the copy
     return hipStreamSynchronize(static_cast<hipStream_t>(stream)) == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;
 }
@@ -1244,9 +1433,17 @@ int frz_wildfire_get_bufs(const frz_wildfire_env* env, frz_wildfire_bufs* out) {
     auto row4 = [&](int r) { return a + p.off_rows4 + (int64_t)r * B * 4; };
     auto row8 = [&](int r) { return a + p.off_rows8 + (int64_t)r * B * 8; };
     auto row1 = [&](int r) { return a + p.off_rows1 + (int64_t)r * B; };
-    out->fires = reinterpret_cast<int32_t*>(row4(p.r_fires));
-    out->intensity = reinterpret_cast<int32_t*>(row4(p.r_intensity));
-    out->fuel = reinterpret_cast<int32_t*>(row4(p.r_fuel));
+    if (p.grid) {  // env-major cell arrays
+        const int64_t cells = B * p.HW;
+        out->fires = at<int32_t>(a, env->gdev.off_cells);
+        out->intensity = out->fires + cells;
+        out->fuel = out->intensity + cells;
+    } else {
+        out->fires = reinterpret_cast<int32_t*>(row4(p.r_fires));
+        out->intensity = reinterpret_cast<int32_t*>(row4(p.r_intensity));
+        out->fuel = reinterpret_cast<int32_t*>(row4(p.r_fuel));
+    }
+    out->cells_env_major = p.grid;
     out->suppressants = reinterpret_cast<float*>(row4(p.r_supp));
     out->capacity = reinterpret_cast<float*>(row4(p.r_cap));
     out->equipment = reinterpret_cast<int32_t*>(row4(p.r_equip));
@@ -1291,7 +1488,7 @@ int frz_wildfire_reset(frz_wildfire_env* env, void* stream) { return frz_wildfir
 int frz_wildfire_reset_reseed(frz_wildfire_env* env, int32_t seed_increment, void* stream) {
     if (!env) return FRZ_E_INVALID;
     if (!env->arena) return FRZ_E_UNBOUND;
-    if (env->dev.roles) {  // one launch: the configured initial state is produced inside the rebuild kernel
+    if (env->dev.roles || env->dev.grid) {  // the configured initial state is produced inside the rebuild kernel
         WfArgs args{env->arena, nullptr, nullptr, nullptr, &env->dev};
         args.seed_increment = seed_increment;
         const int rc = launch(env, args, FRZ_RNG_INJECTED, kReset, static_cast<hipStream_t>(stream));
@@ -1331,7 +1528,7 @@ int frz_wildfire_step(frz_wildfire_env* env, const int32_t* actions, int rng_mod
         if (!field_randomness || !agent_randomness) return FRZ_E_INVALID;
         args.field_rand = field_randomness;
         args.agent_rand = agent_randomness;
-    } else if (rng_mode == FRZ_RNG_MT19937 && env->dev.roles && kVariants[env->variant].exact) {
+    } else if (rng_mode == FRZ_RNG_MT19937 && env->dev.roles && !env->dev.grid && kVariants[env->variant].exact) {
         // the field/crew kernel advances the per-env MT19937 streams itself (wildfire_roles.hip)
     } else if (rng_mode == FRZ_RNG_MT19937) {
         // per-env MT19937 streams: field draws first, then agent draws (wildfire.py:409-410), staged in the arena
@@ -1355,7 +1552,7 @@ int frz_wildfire_step_random_policy(frz_wildfire_env* env, uint64_t policy_seed,
                                     const float* field_randomness, const float* agent_randomness, void* stream) {
     if (!env || !actions_out) return FRZ_E_INVALID;
     if (!env->arena) return FRZ_E_UNBOUND;
-    if (!env->dev.roles) {  // no fused kernel for this grid shape: policy launch, then step launch
+    if (!env->dev.roles && !env->dev.grid) {  // no fused kernel for this grid shape: policy launch, then step launch
         const int rc = frz_wildfire_random_policy(env, policy_seed, policy_step, actions_out, stream);
         return rc != FRZ_OK ? rc : frz_wildfire_step(env, actions_out, rng_mode, field_randomness, agent_randomness, stream);
     }

@@ -15,6 +15,7 @@ namespace frz_wf {
 using frz::kBlock;
 
 constexpr int kTotalsStride = 32;  // uint32 words per totals slot (128 B)
+constexpr int kSmallCells = 64;    // cells of the env-per-lane kernels' per-cell tables; larger grids run wildfire_grid.hip (cells across lanes)
 
 enum Mode { kStep = 0, kRebuild = 1, kReset = 2 };  // kReset (field/crew kernel): the configured initial state instead of loads, then rebuild
 
@@ -49,9 +50,9 @@ struct WfHot {
     int64_t off_rows4, off_rows8, off_rows1, off_obs_self, off_obs_others, off_task_values, off_task_offsets, off_obs_map,
         off_act_values, off_act_offsets, off_bad_values, off_bad_offsets, off_mt_state, off_actions, off_error, off_epoch, off_totals,
         off_agg, off_prefix, off_rand_field, off_rand_agent, total_bytes, off_metrics;
-    float fire_rewards[FRZ_MAX_CELLS];
-    int32_t ignition[FRZ_MAX_CELLS];
-    int32_t cell_yx[FRZ_MAX_CELLS];  // (y << 16) | x
+    float fire_rewards[kSmallCells];
+    int32_t ignition[kSmallCells];
+    int32_t cell_yx[kSmallCells];  // (y << 16) | x
 };
 static_assert(sizeof(WfHot) % 16 == 0, "WfHot is staged with 16-byte copies");
 
@@ -66,7 +67,8 @@ static_assert(sizeof(WfStaged) % 16 == 0 && sizeof(WfStaged) / 16 <= kBlock, "Wf
 struct WfDev : WfStaged {
     int32_t initial_fuel, initial_equipment;
     float initial_suppressant, initial_capacity;
-    int32_t fire_types[FRZ_MAX_CELLS], lit[FRZ_MAX_CELLS];
+    int32_t fire_types[kSmallCells], lit[kSmallCells];
+    int32_t grid;  // 1: one env per wavefront, cells across lanes (wildfire_grid.hip): the cell arrays are env-major [B][H*W]
 };
 static_assert(sizeof(WfDev) <= 8192, "configuration block too large");
 constexpr int64_t kDevBlockBytes = 8192;
@@ -173,5 +175,40 @@ __device__ __forceinline__ int popc(M m) {
 
 // field/crew wavefront-pair kernels for grids of <= 8 cells (wildfire_roles.hip); variant as in wildfire.hip's table
 int launch_roles(const WfArgs& args, int variant, int grid, int rng, int mode, hipStream_t stream);
+
+// ---- grids above 16 cells: one env per wavefront, cells across its lanes (wildfire_grid.hip) -------------------------------------
+// Configuration of the grid kernels, passed BY VALUE as a kernel argument.  Tables indexed by a lane (per agent, per cell, range sets)
+// live in the arena behind off_agent_table / off_cell_tables / off_range.
+struct WgAgentTable {  // arena block read by the agent lanes
+    float power[FRZ_MAX_AGENTS];
+    int32_t ay[FRZ_MAX_AGENTS], ax[FRZ_MAX_AGENTS];
+    float eq[FRZ_MAX_EQUIPMENT_STATES][4];  // (capacity, power, range, -) bonus per equipment state
+    float caps[FRZ_MAX_CAPACITIES];
+};
+struct WgDev {
+    int32_t B, H, W, HW, A, S, K, nchunks, others_k, max_steps, num_fire_states;
+    uint32_t flags, inv_w;  // inv_w: c / W = (c * inv_w) >> 16 for c < H * W (checked at create)
+    uint32_t inv_others;    // q / (A - 1) = (q * inv_others) >> 16 for q < A * (A - 1)
+    float p_increase, p_burnout, p_decrease, decrease_bonus, p_supp_decrease, p_refill, p_switch, p_repair, p_degrade, p_critical;
+    float spread_n, spread_w, spread_e, spread_s, random_ignition;
+    float bad_attack_penalty, burnout_penalty, termination_reward, termination_kappa;
+    float cum[FRZ_MAX_CAPACITIES];
+    int32_t initial_fuel, initial_equipment;
+    float initial_suppressant, initial_capacity;
+    // rows of the [rows][B] blocks (shared with the helper kernels of wildfire.hip through the WfDev block at arena offset 0)
+    int32_t r_supp, r_cap, r_equip, r_moves, r_burnouts, r_rewards, r_cum, r_atc, r_seeds, r_mti;
+    int32_t q_burnouts, q_putouts, q_etc;
+    int32_t u_term, u_trunc, u_frozen;
+    int64_t off_rows4, off_rows8, off_rows1, off_cells /* fires, intensity, fuel: each int32 [B][HW] */, off_agent_table,
+        off_cell_tables /* float fire_rewards[HW]; int32 ignition[HW], initial fires[HW], initial intensity[HW], initial fuel[HW] */,
+        off_range /* uint64 [A][S][chunks]: cells agent a reaches at equipment state s, bit i of chunk k = cell 64 k + i */,
+        off_obs_self, off_obs_others, off_task_values, off_task_offsets, off_obs_map, off_act_values, off_act_offsets, off_bad_values,
+        off_bad_offsets, off_error, off_epoch, off_totals, off_agg, off_prefix;
+};
+struct WgPolicy {  // the uniform random policy sampled inside the step launch
+    uint32_t on, seed_lo, seed_hi, step_lo, step_hi;
+    int32_t* actions_out;
+};
+int launch_grid(const WgDev& dev, char* arena, const WfArgs& args, int rng, int mode, bool ticketed, hipStream_t stream);
 
 }  // namespace frz_wf

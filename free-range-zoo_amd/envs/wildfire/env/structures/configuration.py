@@ -239,7 +239,7 @@ def to_cstruct(configuration,
     S = int(agent.equipment_states.shape[0])
     K = int(agent.possible_capacities.shape[0])
     if H * W > _capi.DEFINES['FRZ_MAX_CELLS']:
-        raise ValueError(f'grids above {_capi.DEFINES["FRZ_MAX_CELLS"]} cells are not supported by the env-per-lane kernels yet')
+        raise ValueError(f'grids above {_capi.DEFINES["FRZ_MAX_CELLS"]} cells are not supported')
     if A > _capi.DEFINES['FRZ_MAX_AGENTS'] or S > _capi.DEFINES['FRZ_MAX_EQUIPMENT_STATES'] or K > _capi.DEFINES['FRZ_MAX_CAPACITIES']:
         raise ValueError('too many agents / equipment states / capacities for frz_wildfire_cfg')
     if tuple(fire.lit.shape) != (H, W):

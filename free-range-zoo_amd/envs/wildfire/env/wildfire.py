@@ -95,8 +95,11 @@ class raw_env(BatchedParallelEnv):
         self._bufs = bufs
         f32, i32, i64, u8 = torch.float32, torch.int32, torch.int64, torch.uint8
         v = self._view
-        # struct-of-arrays HBM state: env index innermost
-        self._fires, self._intensity, self._fuel = v(bufs.fires, (HW, B), i32), v(bufs.intensity, (HW, B), i32), v(bufs.fuel, (HW, B), i32)
+        # struct-of-arrays HBM state.  Cell arrays: env index innermost for grids of up to 16 cells (one env per lane), env-major — the
+        # reference's own layout — above (one env per wavefront, cells across its lanes); `_cells(name)` is [B, H*W] either way
+        self._cells_env_major = bool(bufs.cells_env_major)
+        cell_shape = (B, HW) if self._cells_env_major else (HW, B)
+        self._fires, self._intensity, self._fuel = v(bufs.fires, cell_shape, i32), v(bufs.intensity, cell_shape, i32), v(bufs.fuel, cell_shape, i32)
         self._suppressants, self._capacity = v(bufs.suppressants, (A, B), f32), v(bufs.capacity, (A, B), f32)
         self._equipment = v(bufs.equipment, (A, B), i32)
         self.num_moves, self.num_burnouts = v(bufs.num_moves, (B, ), i32), v(bufs.num_burnouts, (B, ), i32)
@@ -115,9 +118,9 @@ class raw_env(BatchedParallelEnv):
         self._actions = v(bufs.actions, (A, B, 2), i32)
         self.generator.attach(seeds=v(bufs.seeds, (B, ), i32), states=v(bufs.mt_state, (624, B), i32), index=v(bufs.mt_index, (B, ), i32))
         self.seeds = self.generator.seeds
+        grid = (lambda t: t.view(B, H, W)) if self._cells_env_major else (lambda t: t.view(H, W, B).permute(2, 0, 1))
         self._state = WildfireState(
-            fires=self._fires.view(H, W, B).permute(2, 0, 1), intensity=self._intensity.view(H, W, B).permute(2, 0, 1),
-            fuel=self._fuel.view(H, W, B).permute(2, 0, 1), agents=self.agent_config.agents,
+            fires=grid(self._fires), intensity=grid(self._intensity), fuel=grid(self._fuel), agents=self.agent_config.agents,
             suppressants=self._suppressants.t(), capacity=self._capacity.t(), equipment=self._equipment.t())
 
     def _create_handle(self) -> None:

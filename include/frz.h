@@ -27,10 +27,10 @@
 extern "C" {
 #endif
 
-#define FRZ_ABI_VERSION 1
+#define FRZ_ABI_VERSION 2
 
 #define FRZ_MAX_AGENTS 16
-#define FRZ_MAX_CELLS 64
+#define FRZ_MAX_CELLS 1024 /* 32 x 32; grids above 16 cells run one env per wavefront with the cells across its lanes */
 #define FRZ_MAX_EQUIPMENT_STATES 8
 #define FRZ_MAX_CAPACITIES 8
 #define FRZ_MAX_NODES 16
@@ -135,12 +135,15 @@ typedef struct frz_wildfire_cfg {
 /* Arrays of one wildfire env object.  They all live in ONE contiguous device arena whose layout the library fixes
  * (frz_wildfire_arena_bytes / frz_wildfire_bind); frz_wildfire_get_bufs() reports where each array sits so the caller
  * can wrap it as a typed view.  One base pointer keeps the kernels' scalar-register footprint small: every per-env
- * 4-byte array is a row of one [rows][B] block, addressed as base + (row * B + env) * 4.  "cap" = B*H*W rows. */
+ * 4-byte array is a row of one [rows][B] block, addressed as base + (row * B + env) * 4.  "cap" = B*H*W rows.
+ * The three cell arrays have one of two layouts (cells_env_major): grids of up to 16 cells are stepped one env per lane and keep the
+ * env index innermost, [H*W][B]; larger grids are stepped one env per wavefront with the cells across its lanes and are env-major,
+ * [B][H*W] — the reference's own layout. */
 typedef struct frz_wildfire_bufs {
     /* state (WildfireState, structures/state.py:10-68), SoA */
-    int32_t* fires;      /* [H*W][B] */
-    int32_t* intensity;  /* [H*W][B] */
-    int32_t* fuel;       /* [H*W][B] */
+    int32_t* fires;      /* [H*W][B], or [B][H*W] when cells_env_major */
+    int32_t* intensity;  /* same */
+    int32_t* fuel;       /* same */
     float* suppressants; /* [A][B] */
     float* capacity;     /* [A][B] */
     int32_t* equipment;  /* [A][B] */
@@ -174,6 +177,7 @@ typedef struct frz_wildfire_bufs {
     int32_t* mt_index;    /* [B]       number of draws consumed modulo 624 */
     int32_t* actions;     /* [A][B][2] default action buffer (frz_wildfire_step accepts any device pointer) */
     uint32_t* error_flags; /* [1] sticky FRZ_ERR_* bits */
+    int32_t cells_env_major; /* layout of fires / intensity / fuel, see above */
 } frz_wildfire_bufs;
 
 typedef struct frz_wildfire_env frz_wildfire_env; /* opaque host handle */

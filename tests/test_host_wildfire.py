@@ -24,6 +24,12 @@ def test_configuration_lowers_to_the_reference_struct(name):
     flags.update(kwargs)
     max_steps = None if want['max_steps'] < 0 else want['max_steps']
     got = _capi.struct_to_dict(W.to_cstruct(build(), want['parallel_envs'], max_steps, **flags))
+    # the fixtures were recorded when the struct's per-cell arrays held 64 entries (FRZ_MAX_CELLS has grown since): the recorded prefix
+    # must match and whatever lies beyond it must be unused
+    for key, value in want.items():
+        if isinstance(value, list) and len(got[key]) > len(value):
+            assert not any(got[key][len(value):]), key
+            got[key] = got[key][:len(value)]
     assert got == want
 
 
