@@ -1,0 +1,28 @@
+"""PyTorch custom ops ``torch.ops.frz.*`` over the C-ABI (csrc/torch_ops/frz_torch_ops.cpp -> libfrz_torch_ops.so, linked against libfrz_hip.so).
+
+``load()`` registers the library with the dispatcher (once) and returns ``torch.ops.frz``.  There is no fallback: a missing shared library
+raises.  Environments use it with ``dispatch='torch'`` (or FRZ_DISPATCH=torch); the default path stays the torch-free ctypes binding.
+"""
+import os
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, 'csrc', 'torch_ops', 'libfrz_torch_ops.so')
+_loaded = False
+
+OPS = ('wildfire_reset', 'wildfire_reset_reseed', 'wildfire_rebuild', 'wildfire_step', 'wildfire_random_policy', 'wildfire_step_random_policy',
+       'cybersecurity_reset', 'cybersecurity_rebuild', 'cybersecurity_step', 'cybersecurity_random_policy', 'cybersecurity_step_random_policy',
+       'rideshare_reset', 'rideshare_rebuild', 'rideshare_step', 'rideshare_random_policy', 'rideshare_step_random_policy', 'mt19937_seed',
+       'mt19937_generate')
+
+
+def load():
+    """Register ``frz::*`` with PyTorch's dispatcher; returns the op namespace."""
+    global _loaded
+    import torch
+    if not _loaded:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f'{LIB_PATH} is missing: build it first (python -c "import __graft_entry__ as g; g.build()" or '
+                              f'make -C free-range-zoo_amd/csrc torch_ops)')
+        torch.ops.load_library(LIB_PATH)
+        _loaded = True
+    return torch.ops.frz

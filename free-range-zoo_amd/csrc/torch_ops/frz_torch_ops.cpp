@@ -1,0 +1,228 @@
+// frz_torch_ops.cpp — PyTorch custom ops (namespace `frz`) over the C-ABI of include/frz.h.
+//
+// The product is libfrz_hip.so behind plain C entry points; this shim only registers them with the PyTorch dispatcher
+// (TORCH_LIBRARY schemas with mutable-alias annotations, implementation on the CUDA dispatch key, which is what ROCm builds of
+// PyTorch use for HIP tensors), so that `torch.ops.frz.wildfire_step(...)` etc. exist as BASELINE.json's north star asks.  Every op
+//   * takes the env's device arena (uint8 tensor, declared mutated: `Tensor(a!)`) and the opaque env handle frz_<domain>_create returned,
+//   * launches on the CURRENT HIP stream of the arena's device, never synchronises, never allocates,
+//   * raises (TORCH_CHECK) on shape / dtype / device mismatches and on negative FRZ_E_* codes.
+// No kernel lives here; the ctypes binding (free-range-zoo_amd/_capi.py) remains the torch-free path to the same entry points.
+#include <ATen/core/Tensor.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/library.h>
+
+#include "../../../include/frz.h"
+
+namespace {
+
+void* current_stream(const at::Tensor& on) { return c10::hip::getCurrentHIPStream(on.device().index()).stream(); }
+
+void ok(int code, const char* what) { TORCH_CHECK(code == FRZ_OK, what, " failed with FRZ code ", code); }
+
+void check_arena(const at::Tensor& arena) {
+    TORCH_CHECK(arena.is_cuda() && arena.scalar_type() == at::kByte && arena.is_contiguous(), "arena must be a contiguous uint8 tensor on the GPU");
+}
+void inside(const at::Tensor& arena, const void* p, const char* what) {
+    const char* lo = static_cast<const char*>(arena.data_ptr());
+    TORCH_CHECK(static_cast<const char*>(p) >= lo && static_cast<const char*>(p) < lo + arena.numel(), what, ": the handle is not bound to this arena");
+}
+const int32_t* actions_ptr(const at::Tensor& arena, const at::Tensor& actions, int64_t agents, int64_t envs) {
+    TORCH_CHECK(actions.is_cuda() && actions.device() == arena.device() && actions.scalar_type() == at::kInt && actions.is_contiguous() &&
+                    actions.numel() == agents * envs * 2,
+                "actions must be a contiguous int32 [A, B, 2] tensor on the env's device");
+    return actions.data_ptr<int32_t>();
+}
+const float* floats_or_null(const at::Tensor& arena, const c10::optional<at::Tensor>& t, int64_t numel, const char* what) {
+    if (!t.has_value()) return nullptr;
+    TORCH_CHECK(t->is_cuda() && t->device() == arena.device() && t->scalar_type() == at::kFloat && t->is_contiguous() && t->numel() == numel, what,
+                ": expected a contiguous float32 tensor of ", numel, " elements on the env's device");
+    return t->data_ptr<float>();
+}
+
+// ---------------------------------------------------------------------------------------------------- wildfire
+struct Wf {
+    frz_wildfire_env* env;
+    frz_wildfire_bufs bufs;
+    int64_t A, B, HW;
+};
+Wf wildfire(const at::Tensor& arena, int64_t handle, int64_t agents, int64_t envs, int64_t cells) {
+    check_arena(arena);
+    Wf w{reinterpret_cast<frz_wildfire_env*>(handle), {}, agents, envs, cells};
+    ok(frz_wildfire_get_bufs(w.env, &w.bufs), "frz_wildfire_get_bufs");
+    inside(arena, w.bufs.error_flags, "wildfire");
+    return w;
+}
+void wildfire_reset(at::Tensor arena, int64_t handle) {
+    check_arena(arena);
+    ok(frz_wildfire_reset(reinterpret_cast<frz_wildfire_env*>(handle), current_stream(arena)), "frz_wildfire_reset");
+}
+void wildfire_reset_reseed(at::Tensor arena, int64_t handle, int64_t seed_increment) {
+    check_arena(arena);
+    ok(frz_wildfire_reset_reseed(reinterpret_cast<frz_wildfire_env*>(handle), (int32_t)seed_increment, current_stream(arena)), "frz_wildfire_reset_reseed");
+}
+void wildfire_rebuild(at::Tensor arena, int64_t handle) {
+    check_arena(arena);
+    ok(frz_wildfire_rebuild(reinterpret_cast<frz_wildfire_env*>(handle), current_stream(arena)), "frz_wildfire_rebuild");
+}
+void wildfire_step(at::Tensor arena, int64_t handle, const at::Tensor& actions, int64_t rng_mode, const c10::optional<at::Tensor>& field_randomness,
+                   const c10::optional<at::Tensor>& agent_randomness, int64_t agents, int64_t envs, int64_t cells) {
+    const Wf w = wildfire(arena, handle, agents, envs, cells);
+    ok(frz_wildfire_step(w.env, actions_ptr(arena, actions, agents, envs), (int)rng_mode,
+                         floats_or_null(arena, field_randomness, 3 * envs * cells, "field_randomness"),
+                         floats_or_null(arena, agent_randomness, 5 * envs * agents, "agent_randomness"), current_stream(arena)),
+       "frz_wildfire_step");
+}
+void wildfire_random_policy(const at::Tensor& arena, int64_t handle, int64_t policy_seed, int64_t policy_step, at::Tensor actions_out, int64_t agents,
+                            int64_t envs) {
+    check_arena(arena);
+    ok(frz_wildfire_random_policy(reinterpret_cast<frz_wildfire_env*>(handle), (uint64_t)policy_seed, (uint64_t)policy_step,
+                                  const_cast<int32_t*>(actions_ptr(arena, actions_out, agents, envs)), current_stream(arena)),
+       "frz_wildfire_random_policy");
+}
+void wildfire_step_random_policy(at::Tensor arena, int64_t handle, int64_t policy_seed, int64_t policy_step, at::Tensor actions_out, int64_t rng_mode,
+                                 int64_t agents, int64_t envs) {
+    check_arena(arena);
+    ok(frz_wildfire_step_random_policy(reinterpret_cast<frz_wildfire_env*>(handle), (uint64_t)policy_seed, (uint64_t)policy_step,
+                                       const_cast<int32_t*>(actions_ptr(arena, actions_out, agents, envs)), (int)rng_mode, nullptr, nullptr,
+                                       current_stream(arena)),
+       "frz_wildfire_step_random_policy");
+}
+
+// ---------------------------------------------------------------------------------------------------- cybersecurity
+void cybersecurity_reset(at::Tensor arena, int64_t handle) {
+    check_arena(arena);
+    ok(frz_cybersecurity_reset(reinterpret_cast<frz_cybersecurity_env*>(handle), current_stream(arena)), "frz_cybersecurity_reset");
+}
+void cybersecurity_rebuild(at::Tensor arena, int64_t handle) {
+    check_arena(arena);
+    ok(frz_cybersecurity_rebuild(reinterpret_cast<frz_cybersecurity_env*>(handle), current_stream(arena)), "frz_cybersecurity_rebuild");
+}
+void cybersecurity_step(at::Tensor arena, int64_t handle, const at::Tensor& actions, int64_t rng_mode, const c10::optional<at::Tensor>& network_randomness,
+                        const c10::optional<at::Tensor>& agent_randomness, int64_t agents, int64_t envs, int64_t nodes) {
+    check_arena(arena);
+    ok(frz_cybersecurity_step(reinterpret_cast<frz_cybersecurity_env*>(handle), actions_ptr(arena, actions, agents, envs), (int)rng_mode,
+                              floats_or_null(arena, network_randomness, envs * nodes, "network_randomness"),
+                              floats_or_null(arena, agent_randomness, envs * agents, "agent_randomness"), current_stream(arena)),
+       "frz_cybersecurity_step");
+}
+void cybersecurity_random_policy(const at::Tensor& arena, int64_t handle, int64_t policy_seed, int64_t policy_step, at::Tensor actions_out, int64_t agents,
+                                 int64_t envs) {
+    check_arena(arena);
+    ok(frz_cybersecurity_random_policy(reinterpret_cast<frz_cybersecurity_env*>(handle), (uint64_t)policy_seed, (uint64_t)policy_step,
+                                       const_cast<int32_t*>(actions_ptr(arena, actions_out, agents, envs)), current_stream(arena)),
+       "frz_cybersecurity_random_policy");
+}
+void cybersecurity_step_random_policy(at::Tensor arena, int64_t handle, int64_t policy_seed, int64_t policy_step, at::Tensor actions_out, int64_t rng_mode,
+                                      int64_t agents, int64_t envs) {
+    check_arena(arena);
+    ok(frz_cybersecurity_step_random_policy(reinterpret_cast<frz_cybersecurity_env*>(handle), (uint64_t)policy_seed, (uint64_t)policy_step,
+                                            const_cast<int32_t*>(actions_ptr(arena, actions_out, agents, envs)), (int)rng_mode, nullptr, nullptr,
+                                            current_stream(arena)),
+       "frz_cybersecurity_step_random_policy");
+}
+
+// ---------------------------------------------------------------------------------------------------- rideshare
+void rideshare_reset(at::Tensor arena, int64_t handle) {
+    check_arena(arena);
+    ok(frz_rideshare_reset(reinterpret_cast<frz_rideshare_env*>(handle), current_stream(arena)), "frz_rideshare_reset");
+}
+void rideshare_rebuild(at::Tensor arena, int64_t handle) {
+    check_arena(arena);
+    ok(frz_rideshare_rebuild(reinterpret_cast<frz_rideshare_env*>(handle), current_stream(arena)), "frz_rideshare_rebuild");
+}
+void rideshare_step(at::Tensor arena, int64_t handle, const at::Tensor& actions, int64_t agents, int64_t envs) {
+    check_arena(arena);
+    ok(frz_rideshare_step(reinterpret_cast<frz_rideshare_env*>(handle), actions_ptr(arena, actions, agents, envs), current_stream(arena)), "frz_rideshare_step");
+}
+void rideshare_random_policy(const at::Tensor& arena, int64_t handle, int64_t policy_seed, int64_t policy_step, at::Tensor actions_out, int64_t agents,
+                             int64_t envs) {
+    check_arena(arena);
+    ok(frz_rideshare_random_policy(reinterpret_cast<frz_rideshare_env*>(handle), (uint64_t)policy_seed, (uint64_t)policy_step,
+                                   const_cast<int32_t*>(actions_ptr(arena, actions_out, agents, envs)), current_stream(arena)),
+       "frz_rideshare_random_policy");
+}
+void rideshare_step_random_policy(at::Tensor arena, int64_t handle, int64_t policy_seed, int64_t policy_step, at::Tensor actions_out, int64_t agents,
+                                  int64_t envs) {
+    check_arena(arena);
+    ok(frz_rideshare_step_random_policy(reinterpret_cast<frz_rideshare_env*>(handle), (uint64_t)policy_seed, (uint64_t)policy_step,
+                                        const_cast<int32_t*>(actions_ptr(arena, actions_out, agents, envs)), current_stream(arena)),
+       "frz_rideshare_step_random_policy");
+}
+
+// ---------------------------------------------------------------------------------------------------- per-env MT19937 streams
+void mt19937_seed(at::Tensor state, at::Tensor index, const at::Tensor& seeds, const c10::optional<at::Tensor>& batch_indices) {
+    const int64_t B = index.numel();
+    TORCH_CHECK(state.is_cuda() && state.scalar_type() == at::kInt && state.is_contiguous() && state.numel() == 624 * B, "state must be int32 [624, B]");
+    TORCH_CHECK(index.scalar_type() == at::kInt && index.is_contiguous() && seeds.scalar_type() == at::kInt && seeds.is_contiguous() && seeds.numel() == B,
+                "index / seeds must be contiguous int32 [B]");
+    const int32_t* which = nullptr;
+    int64_t n = 0;
+    if (batch_indices.has_value()) {
+        TORCH_CHECK(batch_indices->scalar_type() == at::kInt && batch_indices->is_contiguous() && batch_indices->device() == state.device(),
+                    "batch_indices must be a contiguous int32 tensor on the same device");
+        which = batch_indices->data_ptr<int32_t>();
+        n = batch_indices->numel();
+    }
+    ok(frz_mt19937_seed(reinterpret_cast<uint32_t*>(state.data_ptr<int32_t>()), index.data_ptr<int32_t>(), seeds.data_ptr<int32_t>(), which, n, B,
+                        current_stream(state)),
+       "frz_mt19937_seed");
+}
+void mt19937_generate(at::Tensor state, at::Tensor index, at::Tensor out, int64_t events, int64_t count) {
+    const int64_t B = index.numel();
+    TORCH_CHECK(state.is_cuda() && state.scalar_type() == at::kInt && state.is_contiguous() && state.numel() == 624 * B, "state must be int32 [624, B]");
+    TORCH_CHECK(out.device() == state.device() && out.scalar_type() == at::kFloat && out.is_contiguous() && out.numel() == events * B * count,
+                "out must be a contiguous float32 [events, B, count] tensor on the same device");
+    ok(frz_mt19937_generate(reinterpret_cast<uint32_t*>(state.data_ptr<int32_t>()), index.data_ptr<int32_t>(), out.data_ptr<float>(), events, count, B,
+                            current_stream(state)),
+       "frz_mt19937_generate");
+}
+
+}  // namespace
+
+TORCH_LIBRARY(frz, m) {
+    // `arena` holds every array of the env (state, outputs, RNG state): the ops mutate it in place and return nothing; the typed views the
+    // Python env hands out alias it.  `handle` = the value frz_<domain>_create returned (an opaque host pointer).
+    m.def("wildfire_reset(Tensor(a!) arena, int handle) -> ()");
+    m.def("wildfire_reset_reseed(Tensor(a!) arena, int handle, int seed_increment) -> ()");
+    m.def("wildfire_rebuild(Tensor(a!) arena, int handle) -> ()");
+    m.def("wildfire_step(Tensor(a!) arena, int handle, Tensor actions, int rng_mode, Tensor? field_randomness, Tensor? agent_randomness, int agents, "
+          "int envs, int cells) -> ()");
+    m.def("wildfire_random_policy(Tensor arena, int handle, int policy_seed, int policy_step, Tensor(b!) actions_out, int agents, int envs) -> ()");
+    m.def("wildfire_step_random_policy(Tensor(a!) arena, int handle, int policy_seed, int policy_step, Tensor(b!) actions_out, int rng_mode, int agents, "
+          "int envs) -> ()");
+    m.def("cybersecurity_reset(Tensor(a!) arena, int handle) -> ()");
+    m.def("cybersecurity_rebuild(Tensor(a!) arena, int handle) -> ()");
+    m.def("cybersecurity_step(Tensor(a!) arena, int handle, Tensor actions, int rng_mode, Tensor? network_randomness, Tensor? agent_randomness, int agents, "
+          "int envs, int nodes) -> ()");
+    m.def("cybersecurity_random_policy(Tensor arena, int handle, int policy_seed, int policy_step, Tensor(b!) actions_out, int agents, int envs) -> ()");
+    m.def("cybersecurity_step_random_policy(Tensor(a!) arena, int handle, int policy_seed, int policy_step, Tensor(b!) actions_out, int rng_mode, int agents, "
+          "int envs) -> ()");
+    m.def("rideshare_reset(Tensor(a!) arena, int handle) -> ()");
+    m.def("rideshare_rebuild(Tensor(a!) arena, int handle) -> ()");
+    m.def("rideshare_step(Tensor(a!) arena, int handle, Tensor actions, int agents, int envs) -> ()");
+    m.def("rideshare_random_policy(Tensor arena, int handle, int policy_seed, int policy_step, Tensor(b!) actions_out, int agents, int envs) -> ()");
+    m.def("rideshare_step_random_policy(Tensor(a!) arena, int handle, int policy_seed, int policy_step, Tensor(b!) actions_out, int agents, int envs) -> ()");
+    m.def("mt19937_seed(Tensor(a!) state, Tensor(b!) index, Tensor seeds, Tensor? batch_indices) -> ()");
+    m.def("mt19937_generate(Tensor(a!) state, Tensor(b!) index, Tensor(c!) out, int events, int count) -> ()");
+}
+
+TORCH_LIBRARY_IMPL(frz, CUDA, m) {  // HIP tensors dispatch on the CUDA key in ROCm builds of PyTorch
+    m.impl("wildfire_reset", &wildfire_reset);
+    m.impl("wildfire_reset_reseed", &wildfire_reset_reseed);
+    m.impl("wildfire_rebuild", &wildfire_rebuild);
+    m.impl("wildfire_step", &wildfire_step);
+    m.impl("wildfire_random_policy", &wildfire_random_policy);
+    m.impl("wildfire_step_random_policy", &wildfire_step_random_policy);
+    m.impl("cybersecurity_reset", &cybersecurity_reset);
+    m.impl("cybersecurity_rebuild", &cybersecurity_rebuild);
+    m.impl("cybersecurity_step", &cybersecurity_step);
+    m.impl("cybersecurity_random_policy", &cybersecurity_random_policy);
+    m.impl("cybersecurity_step_random_policy", &cybersecurity_step_random_policy);
+    m.impl("rideshare_reset", &rideshare_reset);
+    m.impl("rideshare_rebuild", &rideshare_rebuild);
+    m.impl("rideshare_step", &rideshare_step);
+    m.impl("rideshare_random_policy", &rideshare_random_policy);
+    m.impl("rideshare_step_random_policy", &rideshare_step_random_policy);
+    m.impl("mt19937_seed", &mt19937_seed);
+    m.impl("mt19937_generate", &mt19937_generate);
+}

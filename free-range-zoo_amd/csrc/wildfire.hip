@@ -1197,12 +1197,12 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
     if (!cfg || !out) return FRZ_E_INVALID;
     const int H = cfg->grid_height, W = cfg->grid_width, HW = H * W, A = cfg->num_agents;
     if (cfg->parallel_envs <= 0 || H <= 0 || W <= 0 || HW > FRZ_MAX_CELLS || A <= 0 || A > FRZ_MAX_AGENTS) return FRZ_E_INVALID;
-    // Kernel family.  Grids above 16 cells run one env per wavefront with the cells across its lanes (wildfire_grid.hip); smaller ones
-    // one env per lane (field/crew wavefront pairs, or the lane-per-env kernel below).  FRZ_WF_KERNEL=grid|lane|roles overrides.
+    // Kernel family.  Grids above 24 cells, or with more than 8 agents, run one env per wavefront with the cells across its lanes
+    // (wildfire_grid.hip: ~500 instructions per env whatever its size); smaller ones one env per lane (field/crew wavefront pairs, or
+    // the lane-per-env kernel below, whose cost grows with its unrolled cell x agent loops: 68 us per step at 4 x 5 with 4 agents against
+    // 95 us for the wavefront-per-env kernels, 440 us against 121 us at 8 x 8 with 12).  FRZ_WF_KERNEL=grid forces the former.
     const char* family = std::getenv("FRZ_WF_KERNEL");
-    const bool force_grid = family && std::strcmp(family, "grid") == 0;
-    const bool force_small = family && (std::strcmp(family, "lane") == 0 || std::strcmp(family, "roles") == 0);
-    if (force_grid || HW > 16 && !(force_small && HW <= kSmallCells)) return create_grid(cfg, out);
+    if ((family && std::strcmp(family, "grid") == 0) || HW > 24 || A > 8) return create_grid(cfg, out);
     if (cfg->num_equipment_states <= 0 || cfg->num_equipment_states > FRZ_MAX_EQUIPMENT_STATES) return FRZ_E_INVALID;
     if (cfg->num_capacities <= 0 || cfg->num_capacities > FRZ_MAX_CAPACITIES) return FRZ_E_INVALID;
     if (cfg->num_fire_states < 2) return FRZ_E_INVALID;

@@ -108,7 +108,7 @@ struct WfArgs {
     X(0, 6, 3, true) X(1, 6, 2, true) X(2, 9, 3, true) X(3, 9, 4, true) X(4, 8, 3, true) X(5, 8, 4, true) X(6, 12, 3, true)           \
     X(7, 12, 4, true) X(8, 16, 3, true) X(9, 16, 4, true) X(10, 4, 2, true) X(11, 4, 3, true) X(12, 8, 2, true) X(13, 9, 2, true)     \
     X(14, 12, 2, true) X(15, 16, 2, true) X(16, 6, 4, true)                                                                         \
-    X(17, 8, 4, false) X(18, 16, 4, false) X(19, 8, 8, false) X(20, 16, 8, false) X(21, 24, 8, false) X(22, 64, 16, false)
+    X(17, 8, 4, false) X(18, 16, 4, false) X(19, 8, 8, false) X(20, 16, 8, false) X(21, 24, 8, false)
 
 // launch a step kernel; with timing events the dispatch itself is bracketed (what a profiler's kernel trace reports)
 template <typename K, typename... Args>

@@ -34,7 +34,6 @@ using frz::select_nth;
 using frz::wave_lds_sync;
 
 constexpr int kEnvsPerBlock = kBlock / 64;  // one env per wavefront
-constexpr int kChannels = FRZ_MAX_AGENTS + 1;  // scan channels: lit fires, attackable fires of each agent
 
 struct CellTables {  // arena block behind off_cell_tables, HW entries each
     const float* fire_rewards;
@@ -61,6 +60,7 @@ __global__ void __launch_bounds__(kBlock) wg_env_kernel(char* __restrict__ arena
     constexpr bool kPhilox = kStepping && RNG == FRZ_RNG_PHILOX;
     __shared__ float s_draw[kEnvsPerBlock][kPhilox ? 3 * kCells + 5 * FRZ_MAX_AGENTS + 8 : 1];  // the step's draws, by draw number (+ the last block's tail)
     __shared__ float s_power[kEnvsPerBlock][kStepping ? kCells : 1];                         // fire-fighting power applied to each cell
+    __shared__ uint32_t s_hits[kEnvsPerBlock][kStepping ? kCells : 1];                       // agents fighting each cell
     __shared__ uint8_t s_lit[kEnvsPerBlock][kStepping ? kCells : 4];                         // lit map after increase / decrease (spread stencil)
     __shared__ uint8_t s_put[kEnvsPerBlock][kStepping ? kCells : 4];                         // cells put out this step (localized rewards)
     __shared__ float s_supp[kEnvsPerBlock][FRZ_MAX_AGENTS];                                  // suppressants after the agent transitions
@@ -229,12 +229,21 @@ __global__ void __launch_bounds__(kBlock) wg_env_kernel(char* __restrict__ arena
         const float power = base_power + table->eq[eqs][1];
         const int hit = good ? tcell : -1;
         reward = (fight && !good) ? d.bad_attack_penalty : 0.0f;  // assignment, wildfire.py:477
-        // applied power per cell, added in agent order (wildfire.py:455-470): one agent lane at a time into LDS
+        // applied power per cell (wildfire.py:455-470).  The reference adds the agents' powers in agent order; float addition of TWO
+        // terms does not depend on the order, so the agents add theirs with one LDS atomic each unless some cell is hit by three or
+        // more agents — then one agent lane at a time, in order.
 #pragma unroll
-        for (int k = 0; k < CPL; ++k) s_power[wave][lane + 64 * k] = 0.0f;
+        for (int k = 0; k < CPL; ++k) s_power[wave][lane + 64 * k] = 0.0f, s_hits[wave][lane + 64 * k] = 0u;
         wave_lds_sync();
-        for (int a = 0; a < A; ++a) {
-            if (lane == a && good) s_power[wave][tcell] = s_power[wave][tcell] + power;
+        if (good) atomicAdd(&s_hits[wave][tcell], 1u);
+        wave_lds_sync();
+        if (__ballot(good && s_hits[wave][tcell] > 2u)) {
+            for (int a = 0; a < A; ++a) {
+                if (lane == a && good) s_power[wave][tcell] = s_power[wave][tcell] + power;
+                wave_lds_sync();
+            }
+        } else {
+            if (good) atomicAdd(&s_power[wave][tcell], power);
             wave_lds_sync();
         }
         // ------------------------------------------------------------ draws
@@ -483,8 +492,10 @@ __global__ void __launch_bounds__(kBlock) wg_env_kernel(char* __restrict__ arena
 // wg_offsets_kernel: one env per lane.  Exclusive prefix sums over the batch of (lit fires, attackable fires of agent 0, 1, ...) = where
 // each env's segment of each jagged list starts; the batch totals (the skip-agent quirk, the freeze test) stay for the next launch.
 // ------------------------------------------------------------------------------------------------------------------------------------
+template <int AMAX, int BITS>  // BITS = 16: at most 255 cells per env (the scan packs four counts per word), else 32
 __global__ void __launch_bounds__(kBlock) wg_offsets_kernel(char* __restrict__ arena, const WgDev d, uint32_t ticketed) {
-    __shared__ frz::ScanShared<kChannels, 32> s_scan;
+    constexpr int kChannels = AMAX + 1;  // scan channels: lit fires, attackable fires of each agent
+    __shared__ frz::ScanShared<kChannels, BITS> s_scan;
     __shared__ int s_ticket;
     const int tid = threadIdx.x;
     const int64_t B = d.B;
@@ -502,10 +513,10 @@ __global__ void __launch_bounds__(kBlock) wg_offsets_kernel(char* __restrict__ a
     uint32_t cnt[kChannels], excl[kChannels];
     cnt[0] = active ? (uint32_t)rows8[(int64_t)d.q_etc * B + bl] : 0u;
 #pragma unroll
-    for (int a = 0; a < FRZ_MAX_AGENTS; ++a) cnt[a + 1] = (active && a < A) ? (uint32_t)rows[(int64_t)(d.r_atc + (a < A ? a : 0)) * B + bl] : 0u;
+    for (int a = 0; a < AMAX; ++a) cnt[a + 1] = (active && a < A) ? (uint32_t)rows[(int64_t)(d.r_atc + (a < A ? a : 0)) * B + bl] : 0u;
     const bool term = rows1[(int64_t)d.u_term * B + bl] != 0, trunc = rows1[(int64_t)d.u_trunc * B + bl] != 0;
     uint32_t err = 0;
-    frz::scan_chunk<kChannels, 32>(s_scan, ws, launch, cnt, active && !term, active && !trunc, A + 1, chunk, d.nchunks, excl, &err);
+    frz::scan_chunk<kChannels, BITS>(s_scan, ws, launch, cnt, active && !term, active && !trunc, A + 1, chunk, d.nchunks, excl, &err);
     if (active) {
         int64_t* const task_offsets = reinterpret_cast<int64_t*>(arena + d.off_task_offsets);
         int64_t* const act_offsets = reinterpret_cast<int64_t*>(arena + d.off_act_offsets);
@@ -514,7 +525,7 @@ __global__ void __launch_bounds__(kBlock) wg_offsets_kernel(char* __restrict__ a
         task_offsets[b] = excl[0];
         if (b == B - 1) task_offsets[B] = (int64_t)excl[0] + cnt[0];
 #pragma unroll
-        for (int a = 0; a < FRZ_MAX_AGENTS; ++a)
+        for (int a = 0; a < AMAX; ++a)
             if (a < A) {
                 act_offsets[a * (B + 1) + b] = excl[a + 1];
                 if (b == B - 1) act_offsets[a * (B + 1) + B] = (int64_t)excl[a + 1] + cnt[a + 1];
@@ -634,7 +645,15 @@ int launch_cpl(const WgDev& dev, char* arena, const WfArgs& args, int rng, int m
     } else {
         go(wg_env_kernel<CPL, kStep, FRZ_RNG_INJECTED>);
     }
-    hipLaunchKernelGGL(wg_offsets_kernel, lanes, block, 0, stream, arena, dev, ticketed ? 1u : 0u);
+    {
+        const uint32_t tk = ticketed ? 1u : 0u;
+        const bool narrow = dev.HW < 256;
+        if (dev.A <= 4 && narrow) hipLaunchKernelGGL((wg_offsets_kernel<4, 16>), lanes, block, 0, stream, arena, dev, tk);
+        else if (dev.A <= 8 && narrow) hipLaunchKernelGGL((wg_offsets_kernel<8, 16>), lanes, block, 0, stream, arena, dev, tk);
+        else if (narrow) hipLaunchKernelGGL((wg_offsets_kernel<16, 16>), lanes, block, 0, stream, arena, dev, tk);
+        else if (dev.A <= 8) hipLaunchKernelGGL((wg_offsets_kernel<8, 32>), lanes, block, 0, stream, arena, dev, tk);
+        else hipLaunchKernelGGL((wg_offsets_kernel<16, 32>), lanes, block, 0, stream, arena, dev, tk);
+    }
     if (args.stop_event)
         hipExtLaunchKernelGGL(wg_emit_kernel<CPL>, waves, block, 0, stream, nullptr, args.stop_event, 0, arena, dev);
     else

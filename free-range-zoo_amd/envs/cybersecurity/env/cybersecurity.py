@@ -35,6 +35,7 @@ def env(wrappers: List[Callable] = [], **kwargs) -> 'BatchedAECView':
 class raw_env(BatchedParallelEnv):
     """Environment definition for the cybersecurity environment."""
     _rebuild_symbol = 'frz_cybersecurity_rebuild'
+    _domain = 'cybersecurity'
 
     metadata = {'render.modes': ['human', 'rgb_array'], 'name': 'cybersecurity_v0', 'is_parallelizable': True, 'render_fps': 2,
                 'null_value': -100}
@@ -177,14 +178,14 @@ class raw_env(BatchedParallelEnv):
             self.generator.seed(seed, partial_seeding=None)
         self.agents = self.possible_agents
         stream = stream_ptr(self.device)
-        _capi.check(self._lib.frz_cybersecurity_reset(self._handle, stream), 'frz_cybersecurity_reset')
+        self._call('reset')
         self._actions.fill_(-2)  # cybersecurity.py:233-236
         if options is not None and options.get('initial_state') is not None:
             initial_state = options['initial_state']
             if len(initial_state) != self.parallel_envs:
                 raise ValueError('Initial state must have the same number of environments as the parallel environments')
             self._state.load_state(initial_state.to(self.device))
-            _capi.check(self._lib.frz_cybersecurity_rebuild(self._handle, stream), 'frz_cybersecurity_rebuild')
+            self._call('rebuild')
         self._state.save_initial()
         self.infos = {agent: {} for agent in self.agents}
         self._has_reset = True
@@ -208,7 +209,7 @@ class raw_env(BatchedParallelEnv):
         self._last_action[:, batch_indices] = -2
         self._actions[:, batch_indices] = -2
         self._state.restore_initial(batch_indices)
-        _capi.check(self._lib.frz_cybersecurity_rebuild(self._handle, stream_ptr(self.device)), 'frz_cybersecurity_rebuild')
+        self._call('rebuild')
         self._publish()
 
     # -------------------------------------------------------------------------------------------------- step
@@ -225,22 +226,25 @@ class raw_env(BatchedParallelEnv):
         logged = self._logs_this_step()
         if isinstance(actions, dict):
             self._stage_actions(actions)
-            actions_ptr = self._actions.data_ptr()
+            actions = self._actions
         else:
             if actions.dtype != torch.int32 or not actions.is_contiguous() or tuple(actions.shape) != tuple(self._actions.shape):
                 raise ValueError('stacked actions must be a contiguous int32 [A, B, 2] tensor')
             self._action_keepalive = actions
-            actions_ptr = actions.data_ptr()
             if self.logger is not None:
                 self._actions.copy_(actions)
-        stream = stream_ptr(self.device)
         B, N, A = self.parallel_envs, self._N, len(self.agents)
+
+        def launch(mode, network=None, agent=None):
+            self._call('step', (actions.data_ptr(), mode, None if network is None else network.data_ptr(), None if agent is None else agent.data_ptr()),
+                       lambda: (actions, mode, network, agent, A, B, N))
+
         fused_mt = (randomness is None and self.rng == 'mt19937' and not self.single_seeding and self.generator.buffer_size == 0)
         if fused_mt:
             # unbuffered per-env streams: the step launch advances the env's own MT19937 stream (same draws, same order as
             # generator.generate(B, 1, (N,)) followed by generate(B, 1, (A,)), cybersecurity.py:304-315)
             self.generator._ensure_streams()
-            rc = self._lib.frz_cybersecurity_step(self._handle, actions_ptr, _capi.FRZ_RNG_MT19937, None, None, stream)
+            launch(_capi.FRZ_RNG_MT19937)
         elif randomness is not None or self.rng == 'mt19937':
             if randomness is None:  # cybersecurity.py:304-315
                 network = self.generator.generate(B, 1, (N, ), key='network')
@@ -252,10 +256,9 @@ class raw_env(BatchedParallelEnv):
             if network.numel() != B * N or agent.numel() != B * A:
                 raise ValueError('randomness tensors have the wrong size')
             self._randomness_keepalive = (network, agent)
-            rc = self._lib.frz_cybersecurity_step(self._handle, actions_ptr, _capi.FRZ_RNG_INJECTED, network.data_ptr(), agent.data_ptr(), stream)
+            launch(_capi.FRZ_RNG_INJECTED, network, agent)
         else:
-            rc = self._lib.frz_cybersecurity_step(self._handle, actions_ptr, _capi.FRZ_RNG_PHILOX, None, None, stream)
-        _capi.check(rc, 'frz_cybersecurity_step')
+            launch(_capi.FRZ_RNG_PHILOX)
         self._publish()
         self.infos = {agent: {} for agent in self.agents}
         if logged:
@@ -269,8 +272,8 @@ class raw_env(BatchedParallelEnv):
     @torch.no_grad()
     def random_policy_actions(self, policy_seed: int, policy_step: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         out = self._actions if out is None else out
-        _capi.check(self._lib.frz_cybersecurity_random_policy(self._handle, policy_seed, policy_step, out.data_ptr(), stream_ptr(self.device)),
-                    'frz_cybersecurity_random_policy')
+        self._call('random_policy', (policy_seed, policy_step, out.data_ptr()),
+                   lambda: (policy_seed, policy_step, out, len(self.agents), self.parallel_envs))
         return out
 
     @torch.no_grad()
@@ -288,8 +291,8 @@ class raw_env(BatchedParallelEnv):
             mode = _capi.FRZ_RNG_MT19937
         else:
             mode = _capi.FRZ_RNG_PHILOX
-        _capi.check(self._lib.frz_cybersecurity_step_random_policy(self._handle, policy_seed, policy_step, self._actions.data_ptr(), mode, None,
-                                                                   None, stream), 'frz_cybersecurity_step_random_policy')
+        self._call('step_random_policy', (policy_seed, policy_step, self._actions.data_ptr(), mode, None, None),
+                   lambda: (policy_seed, policy_step, self._actions, mode, len(self.agents), self.parallel_envs))
         self._publish()
         self.infos = {agent: {} for agent in self.agents}
         if logged:

@@ -36,6 +36,7 @@ def env(wrappers: List[Callable] = [], **kwargs) -> 'BatchedAECView':
 class raw_env(BatchedParallelEnv):
     """Implementation of the dynamic rideshare environment."""
     _rebuild_symbol = 'frz_rideshare_rebuild'
+    _domain = 'rideshare'
 
     metadata = {'render.modes': ['human', 'rgb_array'], 'name': 'rideshare_v0', 'is_parallelizable': True, 'render_fps': 2}
 
@@ -191,7 +192,7 @@ class raw_env(BatchedParallelEnv):
             self.generator.seed(seed, partial_seeding=None)  # kept for API parity: the domain draws nothing
         self.agents = self.possible_agents
         stream = stream_ptr(self.device)
-        _capi.check(self._lib.frz_rideshare_reset(self._handle, stream), 'frz_rideshare_reset')
+        self._call('reset')
         if options is not None and options.get('initial_state') is not None:
             initial_state = options['initial_state']
             if len(initial_state) != self.parallel_envs:
@@ -199,7 +200,7 @@ class raw_env(BatchedParallelEnv):
             # rideshare.py:206-213: the given state replaces the fresh one, then the passengers scheduled for step 0 enter
             self._load_state(initial_state)
             self._enter_step_zero()
-            _capi.check(self._lib.frz_rideshare_rebuild(self._handle, stream), 'frz_rideshare_rebuild')
+            self._call('rebuild')
         self._initial_state = self.state()
         self.infos = {agent: {} for agent in self.agents}
         self._has_reset = True
@@ -240,15 +241,14 @@ class raw_env(BatchedParallelEnv):
         logged = self._logs_this_step()
         if isinstance(actions, dict):
             self._stage_actions(actions)
-            actions_ptr = self._actions.data_ptr()
+            actions = self._actions
         else:
             if actions.dtype != torch.int32 or not actions.is_contiguous() or tuple(actions.shape) != tuple(self._actions.shape):
                 raise ValueError('stacked actions must be a contiguous int32 [A, B, 2] tensor')
             self._action_keepalive = actions
-            actions_ptr = actions.data_ptr()
             if self.logger is not None:
                 self._actions.copy_(actions)
-        _capi.check(self._lib.frz_rideshare_step(self._handle, actions_ptr, stream_ptr(self.device)), 'frz_rideshare_step')
+        self._call('step', (actions.data_ptr(), ), lambda: (actions, len(self.agents), self.parallel_envs))
         self._publish()
         self.infos = {agent: {} for agent in self.agents}
         if logged:
@@ -258,8 +258,8 @@ class raw_env(BatchedParallelEnv):
     @torch.no_grad()
     def random_policy_actions(self, policy_seed: int, policy_step: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         out = self._actions if out is None else out
-        _capi.check(self._lib.frz_rideshare_random_policy(self._handle, policy_seed, policy_step, out.data_ptr(), stream_ptr(self.device)),
-                    'frz_rideshare_random_policy')
+        self._call('random_policy', (policy_seed, policy_step, out.data_ptr()),
+                   lambda: (policy_seed, policy_step, out, len(self.agents), self.parallel_envs))
         return out
 
     step_kernels = 'rs_env_kernel + rs_offsets_kernel + rs_emit_kernel (policy sampled in the first launch)'
@@ -271,8 +271,8 @@ class raw_env(BatchedParallelEnv):
         if not self._has_reset:
             raise RuntimeError('reset() must be called before step_random_policy()')
         logged = self._logs_this_step()
-        _capi.check(self._lib.frz_rideshare_step_random_policy(self._handle, policy_seed, policy_step, self._actions.data_ptr(),
-                                                               stream_ptr(self.device)), 'frz_rideshare_step_random_policy')
+        self._call('step_random_policy', (policy_seed, policy_step, self._actions.data_ptr()),
+                   lambda: (policy_seed, policy_step, self._actions, len(self.agents), self.parallel_envs))
         self._publish()
         self.infos = {agent: {} for agent in self.agents}
         if logged:

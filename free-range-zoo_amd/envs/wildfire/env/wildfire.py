@@ -36,6 +36,7 @@ def env(wrappers: List[Callable] = [], **kwargs) -> 'BatchedAECView':
 class raw_env(BatchedParallelEnv):
     """Environment definition for the wildfire environment."""
     _rebuild_symbol = 'frz_wildfire_rebuild'
+    _domain = 'wildfire'
 
     metadata = {'render.modes': ['human', 'rgb_array'], 'name': 'wildfire_v0', 'is_parallelizable': True, 'render_fps': 2}
 
@@ -217,13 +218,13 @@ class raw_env(BatchedParallelEnv):
         self.agents = self.possible_agents
         self.rewards = None
         stream = stream_ptr(self.device)
-        _capi.check(self._lib.frz_wildfire_reset(self._handle, stream), 'frz_wildfire_reset')
+        self._call('reset')
         if options is not None and options.get('initial_state') is not None:
             initial_state = options['initial_state']
             if len(initial_state) != self.parallel_envs:
                 raise ValueError('Initial state must have the same number of environments as the parallel environments')
             self._state.load_state(initial_state.to(self.device))
-            _capi.check(self._lib.frz_wildfire_rebuild(self._handle, stream), 'frz_wildfire_rebuild')
+            self._call('rebuild')
         self._state.save_initial()
         self.fire_rewards = self.reward_config.fire_rewards.unsqueeze(0).expand(self.parallel_envs, -1, -1)
         self.infos = {agent: {} for agent in self.agents}
@@ -247,7 +248,7 @@ class raw_env(BatchedParallelEnv):
         self.num_burnouts[batch_indices] = 0
         self._frozen_scaled[batch_indices] = 0
         self._state.restore_initial(batch_indices)
-        _capi.check(self._lib.frz_wildfire_rebuild(self._handle, stream_ptr(self.device)), 'frz_wildfire_rebuild')
+        self._call('rebuild')
         self._publish()
 
     # -------------------------------------------------------------------------------------------------- step
@@ -269,22 +270,25 @@ class raw_env(BatchedParallelEnv):
         logged = self._logs_this_step()
         if isinstance(actions, dict):
             self._stage_actions(actions)
-            actions_ptr = self._actions.data_ptr()
+            actions = self._actions
         else:
             if actions.dtype != torch.int32 or not actions.is_contiguous() or tuple(actions.shape) != tuple(self._actions.shape):
                 raise ValueError('stacked actions must be a contiguous int32 [A, B, 2] tensor')
             self._action_keepalive = actions
-            actions_ptr = actions.data_ptr()
             if self.logger is not None:
                 self._actions.copy_(actions)
-        stream = stream_ptr(self.device)
         B, H, W, A = self.parallel_envs, self.max_y, self.max_x, len(self.agents)
+
+        def launch(mode, field=None, agent=None):
+            self._call('step', (actions.data_ptr(), mode, None if field is None else field.data_ptr(), None if agent is None else agent.data_ptr()),
+                       lambda: (actions, mode, field, agent, A, B, H * W))
+
         fused_mt = (randomness is None and self.rng == 'mt19937' and not self.single_seeding and self.generator.buffer_size == 0)
         if fused_mt:
             # unbuffered per-env streams: the step kernel advances the env's own MT19937 stream (same draws, same order as
             # generator.generate(B, 3, (H, W)) followed by generate(B, 5, (A,)), wildfire.py:409-410)
             self.generator._ensure_streams()
-            rc = self._lib.frz_wildfire_step(self._handle, actions_ptr, _capi.FRZ_RNG_MT19937, None, None, stream)
+            launch(_capi.FRZ_RNG_MT19937)
         elif randomness is not None or self.rng == 'mt19937':
             if randomness is None:  # wildfire.py:409-410
                 field = self.generator.generate(B, 3, (H, W), key='field')
@@ -296,10 +300,9 @@ class raw_env(BatchedParallelEnv):
             if field.numel() != 3 * B * H * W or agent.numel() != 5 * B * A:
                 raise ValueError('randomness tensors have the wrong size')
             self._randomness_keepalive = (field, agent)
-            rc = self._lib.frz_wildfire_step(self._handle, actions_ptr, _capi.FRZ_RNG_INJECTED, field.data_ptr(), agent.data_ptr(), stream)
+            launch(_capi.FRZ_RNG_INJECTED, field, agent)
         else:
-            rc = self._lib.frz_wildfire_step(self._handle, actions_ptr, _capi.FRZ_RNG_PHILOX, None, None, stream)
-        _capi.check(rc, 'frz_wildfire_step')
+            launch(_capi.FRZ_RNG_PHILOX)
         self._publish()
         self.infos = {agent: {} for agent in self.agents}
         self.infos['burnouts'] = self._burnouts
@@ -318,8 +321,8 @@ class raw_env(BatchedParallelEnv):
     def random_policy_actions(self, policy_seed: int, policy_step: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Device-side uniform random policy over each agent's current action space -> int32 ``[A, B, 2]``."""
         out = self._actions if out is None else out
-        _capi.check(self._lib.frz_wildfire_random_policy(self._handle, policy_seed, policy_step, out.data_ptr(), stream_ptr(self.device)),
-                    'frz_wildfire_random_policy')
+        self._call('random_policy', (policy_seed, policy_step, out.data_ptr()),
+                   lambda: (policy_seed, policy_step, out, len(self.agents), self.parallel_envs))
         return out
 
     @torch.no_grad()
@@ -400,8 +403,8 @@ class raw_env(BatchedParallelEnv):
             raise RuntimeError('reset() must be called before step_random_policy()')
         logged = self._logs_this_step()
         mode = self._fused_rng_mode()
-        _capi.check(self._lib.frz_wildfire_step_random_policy(self._handle, policy_seed, policy_step, self._actions.data_ptr(), mode, None, None,
-                                                              stream_ptr(self.device)), 'frz_wildfire_step_random_policy')
+        self._call('step_random_policy', (policy_seed, policy_step, self._actions.data_ptr(), mode, None, None),
+                   lambda: (policy_seed, policy_step, self._actions, mode, len(self.agents), self.parallel_envs))
         return self._after_fused(logged)
 
     @torch.no_grad()

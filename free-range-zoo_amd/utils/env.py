@@ -49,6 +49,7 @@ class BatchedParallelEnv:
                  override_initialization_check: bool = False,
                  rng: str = 'mt19937',
                  exact_shapes: bool = True,
+                 dispatch: Optional[str] = None,
                  **kwargs):
         """
         Same keyword arguments as the reference (utils/env.py:21-34), plus:
@@ -57,6 +58,9 @@ class BatchedParallelEnv:
             exact_shapes: True — jagged outputs are sliced to their exact total length (one small host read per step,
                  objects identical in shape to the reference's); False — sync-free: jagged outputs are persistent
                  views over capacity buffers with explicit lengths.
+            dispatch: how the stream-ordered launches reach libfrz_hip.so: 'ctypes' (default; torch-free C-ABI calls) or 'torch'
+                 (the same entry points as PyTorch custom ops, ``torch.ops.frz.<domain>_<entry>``: csrc/torch_ops).  Same kernels, same
+                 results; the environment variable FRZ_DISPATCH sets the default.
         """
         device = torch.device(device)
         if device.type != 'cuda':
@@ -93,6 +97,14 @@ class BatchedParallelEnv:
         self._lib = _capi.lib()
         self._handle = None
         self._has_reset = False
+        import os
+        self._dispatch = dispatch or os.environ.get('FRZ_DISPATCH', 'ctypes')
+        if self._dispatch not in ('ctypes', 'torch'):
+            raise ValueError("dispatch must be 'ctypes' or 'torch'")
+        self._ops = None
+        if self._dispatch == 'torch':
+            from free_range_zoo_amd import _torch_ops
+            self._ops = _torch_ops.load()
 
     # the reference exposes the AEC env under the parallel wrapper; one object plays both roles here
     @property
@@ -113,6 +125,18 @@ class BatchedParallelEnv:
 
     def _alloc(self, shape, dtype) -> torch.Tensor:
         return torch.zeros(shape, dtype=dtype, device=self.device)
+
+    _domain: str = ''  # 'wildfire' | 'cybersecurity' | 'rideshare': the C entry points are frz_<domain>_<entry>
+
+    def _call(self, entry: str, c_args=(), op_args=None) -> None:
+        """One stream-ordered launch of ``frz_<domain>_<entry>`` on the current stream of the env's device: a ctypes call into
+        libfrz_hip.so (``c_args`` = what follows the handle, the stream is appended), or — ``dispatch='torch'`` — the PyTorch custom op
+        ``torch.ops.frz.<domain>_<entry>(arena, handle, *op_args())``, which takes its stream from the dispatcher's current-stream state."""
+        if self._ops is not None:
+            getattr(self._ops, f'{self._domain}_{entry}')(self._arena, self._handle.value, *(op_args() if op_args else ()))
+        else:
+            symbol = f'frz_{self._domain}_{entry}'
+            _capi.check(getattr(self._lib, symbol)(self._handle, *c_args, stream_ptr(self.device)), symbol)
 
     def _check_errors(self) -> None:
         """Raise the data-dependent errors the kernels flagged (reads one word from the device)."""
@@ -198,8 +222,7 @@ class BatchedParallelEnv:
         e.g. wildfire.py:584-700, called by code that edits ``env.state()`` between steps): one launch, then re-publish."""
         if not self._has_reset:
             raise RuntimeError('reset() must be called before update_observations()')
-        rebuild = getattr(self._lib, self._rebuild_symbol)
-        _capi.check(rebuild(self._handle, stream_ptr(self.device)), self._rebuild_symbol)
+        self._call('rebuild')
         self._publish()
 
     def update_actions(self) -> None:

@@ -1,0 +1,79 @@
+"""The PyTorch custom ops torch.ops.frz.* (csrc/torch_ops): a dispatcher registration of the C entry points of include/frz.h.
+CPU: the library loads and every op carries the schema it should (mutable-alias annotations included).  GPU: environments driven through
+the ops (dispatch='torch') leave bit for bit what the ctypes path leaves."""
+import pytest
+import torch
+
+import configs
+
+
+def test_ops_are_registered_with_their_schemas():
+    from free_range_zoo_amd import _torch_ops
+    ops = _torch_ops.load()
+    for name in _torch_ops.OPS:
+        schema = str(getattr(ops, name).default._schema)
+        assert schema.startswith(f'frz::{name}(') and schema.endswith('-> ()'), schema
+    step = str(ops.wildfire_step.default._schema)
+    assert 'Tensor(a!) arena' in step and 'int handle' in step and 'Tensor? field_randomness' in step
+    assert 'Tensor(b!) actions_out' in str(ops.rideshare_step_random_policy.default._schema)
+    # no CPU implementation: the ops exist for GPU tensors only
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        ops.wildfire_reset(torch.zeros(8, dtype=torch.uint8), 0)
+
+
+def _state_tensors(env):
+    names = [n for n in ('_fires', '_intensity', '_fuel', '_suppressants', '_capacity', '_equipment', '_rewards', '_cumulative', '_terminations',
+                         '_truncations', '_task_values', '_task_offsets', '_act_map_values', '_act_map_offsets', '_network_state', '_location',
+                         '_presence', '_obs_tasks', '_agents', '_passengers', '_passenger_count', '_agent_task_values', '_agent_offsets',
+                         'agent_task_count', 'environment_task_count', '_actions', 'num_moves') if hasattr(env, n)]
+    return {n: getattr(env, n) for n in names}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('domain', ['wildfire', 'wildfire_grid', 'cybersecurity', 'rideshare'])
+def test_envs_driven_through_torch_ops_equal_the_c_abi_path(domain):
+    from free_range_zoo_amd.envs import cybersecurity_v0, rideshare_v0, wildfire_v0
+    B = 2500
+    module, build, kwargs = {
+        'wildfire': (wildfire_v0, configs.wildfire_openness, dict(rng='mt19937')),
+        'wildfire_grid': (wildfire_v0, lambda: configs.wildfire_grid(8, 8, 12), dict(rng='philox')),
+        'cybersecurity': (cybersecurity_v0, configs.cyber_openness, dict(rng='mt19937')),
+        'rideshare': (rideshare_v0, lambda: configs.rideshare_busy(A=4, steps=20, per_step=2, seed=2), {}),
+    }[domain]
+    envs = [module.parallel_env(configuration=build(), parallel_envs=B, max_steps=20, device=torch.device('cuda'), dispatch=how, **kwargs)
+            for how in ('ctypes', 'torch')]
+    assert envs[1]._ops is not None and envs[0]._ops is None
+    for env in envs:
+        env.reset(seed=torch.arange(B, dtype=torch.int32) + 3)
+    for t in range(24):  # past the horizon: frozen steps too
+        for env in envs:
+            if t % 3 == 2:
+                env.step_random_policy(policy_seed=9, policy_step=t)
+            else:
+                env.step(env.random_policy_actions(policy_seed=9, policy_step=t).clone())
+        a, b = (_state_tensors(env) for env in envs)
+        assert a.keys() == b.keys() and len(a) > 6
+        for name in a:
+            assert torch.equal(a[name], b[name]), f'{domain}: {name} at step {t}'
+    for env in envs:
+        env.update_observations()  # the rebuild entry
+        env.check()
+    a, b = (_state_tensors(env) for env in envs)
+    for name in a:
+        assert torch.equal(a[name], b[name]), f'{domain}: {name} after rebuild'
+
+
+@pytest.mark.gpu
+def test_op_argument_checks():
+    from free_range_zoo_amd import _torch_ops
+    from free_range_zoo_amd.envs import wildfire_v0
+    ops = _torch_ops.load()
+    env = wildfire_v0.parallel_env(configuration=configs.wildfire_openness(), parallel_envs=64, max_steps=5, device=torch.device('cuda'), rng='philox')
+    env.reset(seed=torch.arange(64, dtype=torch.int32))
+    good = env._actions.clone()
+    with pytest.raises(RuntimeError):  # wrong dtype
+        ops.wildfire_step(env._arena, env._handle.value, good.long(), 1, None, None, 3, 64, 6)
+    with pytest.raises(RuntimeError):  # an arena the handle is not bound to
+        ops.wildfire_step(torch.zeros_like(env._arena), env._handle.value, good, 1, None, None, 3, 64, 6)
+    ops.wildfire_step(env._arena, env._handle.value, good, 1, None, None, 3, 64, 6)
+    assert int(env.num_moves.max()) == 1

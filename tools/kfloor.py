@@ -9,7 +9,7 @@ from free_range_zoo_amd import _capi
 from free_range_zoo_amd.envs import wildfire_v0
 from free_range_zoo_amd.utils.env import stream_ptr
 for B in [int(x) for x in sys.argv[1:]] or [256, 4096, 16384, 65536, 131072, 262144]:
-    build = {"openness": configs.wildfire_openness, "rich": configs.wildfire_rich, "grid8x8": lambda: configs.wildfire_grid(8, 8, 12), "grid3x3": lambda: configs.wildfire_grid(3, 3, 3), "grid4x4": lambda: configs.wildfire_grid(4, 4, 6), "grid4x4a4": lambda: configs.wildfire_grid(4, 4, 4), "grid3x4a4": lambda: configs.wildfire_grid(3, 4, 4)}[os.environ.get('FRZ_KFLOOR_CONFIG', 'openness')]
+    build = {"openness": configs.wildfire_openness, "rich": configs.wildfire_rich, "grid8x8": lambda: configs.wildfire_grid(8, 8, 12), "grid3x3": lambda: configs.wildfire_grid(3, 3, 3), "grid4x4": lambda: configs.wildfire_grid(4, 4, 6), "grid4x4a4": lambda: configs.wildfire_grid(4, 4, 4), "grid3x4a4": lambda: configs.wildfire_grid(3, 4, 4), "grid5x5": lambda: configs.wildfire_grid(5, 5, 3), "grid16x16": lambda: configs.wildfire_grid(16, 16, 6), "grid32x32": lambda: configs.wildfire_grid(32, 32, 12), "grid4x5": lambda: configs.wildfire_grid(4, 5, 4)}[os.environ.get('FRZ_KFLOOR_CONFIG', 'openness')]
     env = wildfire_v0.parallel_env(configuration=build(), parallel_envs=B, max_steps=50, device=torch.device('cuda'),
                                    rng='philox', exact_shapes=False)
     env.reset(seed=torch.arange(B, dtype=torch.int32))
