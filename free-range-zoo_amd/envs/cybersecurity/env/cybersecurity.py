@@ -327,23 +327,18 @@ class raw_env(BatchedParallelEnv):
     @torch.no_grad()
     def action_space(self, agent: str) -> BatchedOneOfSpace:
         """Per-env OneOf (cybersecurity.py:528-551, spaces/actions.py:11-99)."""
+        from free_range_zoo_amd.envs.cybersecurity.env.spaces import actions
         index = self.possible_agents.index(agent)
         counts = self.environment_task_count if self.show_bad_actions else self.agent_task_count[index]
-        if index < self._Att:
-            return BatchedOneOfSpace(counts, tail=[-1], sampler=self._space_sampler(index))
-        location = self._location[index - self._Att]
-
-        def tail_mask() -> torch.Tensor:  # which of (noop, patch, monitor) exist per env; resolved by code that inspects the members
-            has_tasks = counts > 0
-            can_patch = has_tasks & (torch.full_like(has_tasks, self.show_bad_actions) | (location != -1))
-            return torch.stack([torch.ones_like(has_tasks), can_patch, has_tasks], dim=1)
-
-        return BatchedOneOfSpace(counts, tail=[-1, -2, -3], tail_mask=tail_mask, sampler=self._space_sampler(index))
+        location = self._location[index - self._Att] if index >= self._Att else None
+        return actions.build_action_space(agent.split('_')[0], self.show_bad_actions, counts, location, sampler=self._space_sampler(index))
 
     def observation_space(self, agent: str):
-        kind = agent.split('_')[0]
-        high = self.config.attacker_observation_bounds if kind == 'attacker' else self.config.defender_observation_bounds
-        mask = self.agent_observation_mask(agent).tolist()
-        return {'self_high': tuple(high), 'others_high': tuple(h for h, keep in zip(high, mask) if keep),
-                'tasks_high': tuple(self.config.network_observation_bounds), 'num_tasks': self._N,
-                'num_others': (self._Att if kind == 'attacker' else self._D) - 1}
+        """The same ``Dict{self, others, tasks}`` for every env (it never changes size; cached like the reference's, cybersecurity.py:553-578)."""
+        from free_range_zoo_amd.envs.cybersecurity.env.spaces import observations
+        return observations.build_observation_space(
+            agent_type=agent.split('_')[0], num_nodes=self._N, parallel_envs=self.parallel_envs, num_attackers=self._Att, num_defenders=self._D,
+            attacker_high=tuple(int(v) for v in self.config.attacker_observation_bounds),
+            defender_high=tuple(int(v) for v in self.config.defender_observation_bounds),
+            network_high=tuple(int(v) for v in self.config.network_observation_bounds), include_power=self.observe_other_power,
+            include_presence=self.observe_other_presence, include_location=self.observe_other_location)

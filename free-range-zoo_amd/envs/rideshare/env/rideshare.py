@@ -309,9 +309,12 @@ class raw_env(BatchedParallelEnv):
             states = jagged(self._agent_task_states[a, :total].clone(), self._agent_offsets[a].clone(), max_seqlen=max(int(counts.max()), 1))
             return states.to_padded_tensor(0)
 
-        return BatchedOneOfSpace(counts, tail=[-1], task_starts=starts, sampler=self._space_sampler(a))
+        from free_range_zoo_amd.envs.rideshare.env.spaces import actions
+        return actions.build_action_space(starts, counts, sampler=self._space_sampler(a))
 
     def observation_space(self, agent: str):
-        return {'self_high': self.agent_observation_bounds, 'others_high': self.agent_observation_bounds,
-                'tasks_high': self.passenger_observation_bounds, 'task_counts': self.agent_task_count[self.possible_agents.index(agent)],
-                'num_others': len(self.possible_agents) - 1}
+        """Per-env ``Dict{self, others, tasks}`` sized by the tasks the agent sees (rideshare.py:489-504), count-based."""
+        from free_range_zoo_amd.envs.rideshare.env.spaces import observations
+        return observations.build_observation_space(self.agent_task_count[self.possible_agents.index(agent)], len(self.possible_agents),
+                                                     tuple(int(v) for v in self.agent_observation_bounds),
+                                                     tuple(int(v) if v is not None else 0 for v in self.passenger_observation_bounds))

@@ -1,0 +1,19 @@
+"""Action spaces of the rideshare environment (reference: envs/rideshare/env/spaces/actions.py:10-50).
+
+Per env ``OneOf([Discrete(1, start=state_t) for visible task t] + [Discrete(1, start=-1)])`` where the start of a task member is the
+passenger's state (0 accept / 1 pick / 2 drop); count-based at the batch level, the per-task starts resolved lazily."""
+import functools
+from typing import Tuple
+
+from free_range_zoo_amd.utils.spaces import BatchedOneOfSpace, Space
+
+
+def build_action_space(environment_action_choices, environment_task_counts, sampler=None) -> BatchedOneOfSpace:
+    """``environment_action_choices``: padded int tensor [B, max tasks] of the task members' starts, or a zero-argument callable
+    producing it on first inspection (it costs host reads); ``environment_task_counts``: tasks per env."""
+    return BatchedOneOfSpace(environment_task_counts, tail=[-1], task_starts=environment_action_choices, sampler=sampler)
+
+
+@functools.lru_cache(maxsize=100)
+def build_single_action_space(action_choices: Tuple[int]):
+    return Space.OneOf([Space.Discrete(1, start=choice) for choice in action_choices] + [Space.Discrete(1, start=-1)])

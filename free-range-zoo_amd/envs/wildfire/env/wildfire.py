@@ -439,15 +439,13 @@ class raw_env(BatchedParallelEnv):
             counts = self.environment_task_count
         else:
             counts = self.agent_task_count[self.possible_agents.index(agent)]
-        return BatchedOneOfSpace(counts, tail=[-1], sampler=self._space_sampler(self.possible_agents.index(agent)))
+        from free_range_zoo_amd.envs.wildfire.env.spaces import actions
+        return actions.build_action_space(counts, sampler=self._space_sampler(self.possible_agents.index(agent)))
 
     def observation_space(self, agent: str):
-        """Observation bounds per env (wildfire.py:736-753): dict of the static highs + the per-env task counts."""
-        return {
-            'self_high': self.agent_observation_bounds,
-            'others_high': tuple(b for b, keep in zip(self.agent_observation_bounds,
-                                                      (True, True, self.observe_other_power, self.observe_other_suppressant)) if keep),
-            'tasks_high': self.fire_observation_bounds,
-            'task_counts': self.environment_task_count,
-            'num_others': len(self.possible_agents) - 1,
-        }
+        """Per-env ``Dict{self, others, tasks}`` sized by the env's lit fires (wildfire.py:736-753), count-based."""
+        from free_range_zoo_amd.envs.wildfire.env.spaces import observations
+        return observations.build_observation_space(
+            environment_task_counts=self.environment_task_count, num_agents=len(self.possible_agents),
+            agent_high=tuple(int(v) for v in self.agent_observation_bounds), fire_high=tuple(int(v) for v in self.fire_observation_bounds),
+            include_suppressant=self.observe_other_suppressant, include_power=self.observe_other_power)

@@ -7,7 +7,7 @@ reference tree; this module gives the same *structure* (per-env member lists) co
 kernels maintain, with sampling done on the device.  Sampling distribution: uniform over the OneOf members (parity of
 the Rust sampler's stream is unpinned).
 """
-from typing import List, Sequence
+from typing import Callable, Dict as DictType, List, Sequence
 
 import torch
 
@@ -35,6 +35,134 @@ class OneOf:
 
     def __repr__(self):
         return f'OneOf({self.spaces})'
+
+
+class Box:
+    """Integer box ``[low, high]`` per dimension (``free_range_rust.Space.Box``)."""
+
+    def __init__(self, low: Sequence[int], high: Sequence[int]):
+        self.low, self.high = [int(v) for v in low], [int(v) for v in high]
+        if len(self.low) != len(self.high):
+            raise ValueError('low and high must have the same length')
+
+    def __len__(self):
+        return len(self.high)
+
+    def __eq__(self, other):
+        return isinstance(other, Box) and (self.low, self.high) == (other.low, other.high)
+
+    def __hash__(self):
+        return hash((tuple(self.low), tuple(self.high)))
+
+    def __repr__(self):
+        return f'Box(low={self.low}, high={self.high})'
+
+
+class Tuple:
+    """Fixed sequence of spaces (``free_range_rust.Space.Tuple``)."""
+
+    def __init__(self, spaces: Sequence):
+        self.spaces = list(spaces)
+
+    def __len__(self):
+        return len(self.spaces)
+
+    def __getitem__(self, index):
+        return self.spaces[index]
+
+    def __eq__(self, other):
+        return isinstance(other, Tuple) and self.spaces == other.spaces
+
+    def __repr__(self):
+        return f'Tuple({self.spaces})'
+
+
+class Dict:
+    """Named spaces (``free_range_rust.Space.Dict``)."""
+
+    def __init__(self, spaces: DictType[str, object]):
+        self.spaces = dict(spaces)
+
+    def __getitem__(self, key):
+        return self.spaces[key]
+
+    def keys(self):
+        return self.spaces.keys()
+
+    def __eq__(self, other):
+        return isinstance(other, Dict) and self.spaces == other.spaces
+
+    def __repr__(self):
+        return f'Dict({self.spaces})'
+
+
+class Vector:
+    """A list of per-env spaces (``free_range_rust.Space.Vector``)."""
+
+    def __init__(self, spaces: Sequence):
+        self.spaces = list(spaces)
+
+    def __len__(self):
+        return len(self.spaces)
+
+    def __getitem__(self, index):
+        return self.spaces[index]
+
+    def __eq__(self, other):
+        other_spaces = other.spaces if isinstance(other, (Vector, BatchedOneOfSpace)) else other
+        return self.spaces == other_spaces
+
+    def __repr__(self):
+        return f'Vector({self.spaces})'
+
+
+class Space:
+    """Constructors under the names the reference imports from ``free_range_rust`` (``Space.Box``, ``Space.OneOf``, ...): structure and
+    equality only — the count-based batched objects below carry the per-env structure without materialising B Python objects."""
+    Discrete = Discrete
+    OneOf = OneOf
+    Box = Box
+    Tuple = Tuple
+    Dict = Dict
+    Vector = Vector
+
+
+class BatchedSpace:
+    """Per-env spaces that are a function of one integer per env (the task count): list-like over the env batch, entries built on demand
+    by ``single(count)`` (cached by the builders), so handing one out costs no device read and no O(B) work.  ``observation_space(agent)``
+    of the three domains returns one (wildfire.py:736-753, rideshare.py:489-504, cybersecurity.py:553-578)."""
+
+    def __init__(self, task_counts: torch.Tensor, single: Callable[[int], object]):
+        self.task_counts = task_counts  # a view of the env's buffer: describes the CURRENT step
+        self._single = single
+        self._host_counts = None
+
+    def __len__(self):
+        return int(self.task_counts.shape[0])
+
+    def _counts(self) -> List[int]:
+        if self._host_counts is None:
+            self._host_counts = [int(v) for v in self.task_counts.tolist()]  # one device read, on first inspection
+        return self._host_counts
+
+    def __getitem__(self, index):
+        if isinstance(index, slice):
+            return [self._single(n) for n in self._counts()[index]]
+        return self._single(self._counts()[index])
+
+    def __iter__(self):
+        return (self._single(n) for n in self._counts())
+
+    @property
+    def spaces(self) -> List:
+        return list(self)
+
+    def __eq__(self, other):
+        other_spaces = other.spaces if isinstance(other, (Vector, BatchedSpace)) else other
+        return self.spaces == list(other_spaces)
+
+    def __repr__(self):
+        return f'BatchedSpace({len(self)} envs)'
 
 
 class BatchedOneOfSpace:
