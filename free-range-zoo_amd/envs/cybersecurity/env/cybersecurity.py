@@ -133,8 +133,7 @@ class raw_env(BatchedParallelEnv):
             pass
 
     # ---------------------------------------------------------------------------------------- output plumbing
-    def _publish(self) -> None:
-        self._bump_space_epoch()
+    def _materialize(self) -> None:
         B, A, N, Att = self.parallel_envs, len(self.agents), self._N, self._Att
         if self.exact_shapes:
             totals = self._act_map_offsets[:, -1].tolist()  # one small device->host read per step
@@ -193,7 +192,7 @@ class raw_env(BatchedParallelEnv):
         self._publish_dense()
         if self.logger is not None:  # _post_reset_hook (utils/env.py:191-195)
             self._log_environment(reset=True)
-        return {agent: self.observations[agent] for agent in self.agents}, self.infos
+        return self._observations_out(), self.infos
 
     @torch.no_grad()
     def reset_batches(self, batch_indices: torch.Tensor, seed: Optional[List[int]] = None, options: Optional[Dict[str, Any]] = None) -> None:
@@ -263,7 +262,7 @@ class raw_env(BatchedParallelEnv):
         self.infos = {agent: {} for agent in self.agents}
         if logged:
             self._log_environment()
-        return ({agent: self.observations[agent] for agent in self.agents}, self.rewards, self.terminations, self.truncations, self.infos)
+        return (self._observations_out(), self.rewards, self.terminations, self.truncations, self.infos)
 
     def _log_extra(self, reset: bool):
         """cybersecurity.py:580-584: the adjacency matrix in every row."""
@@ -297,7 +296,7 @@ class raw_env(BatchedParallelEnv):
         self.infos = {agent: {} for agent in self.agents}
         if logged:
             self._log_environment()
-        return ({agent: self.observations[agent] for agent in self.agents}, self.rewards, self.terminations, self.truncations, self.infos)
+        return (self._observations_out(), self.rewards, self.terminations, self.truncations, self.infos)
 
     @torch.no_grad()
     def capture_random_rollout(self, steps: int, policy_seed: int = 0, include_reset: bool = True) -> 'torch.cuda.CUDAGraph':

@@ -151,8 +151,7 @@ class raw_env(BatchedParallelEnv):
         self._passenger_count.copy_(counts.to(torch.int32))
 
     # ---------------------------------------------------------------------------------------- output plumbing
-    def _publish(self) -> None:
-        self._bump_space_epoch()
+    def _materialize(self) -> None:
         B, A, P = self.parallel_envs, len(self.agents), self._P
         if self.exact_shapes:
             stats = torch.cat([self._task_offsets[-1:], self._agent_offsets[:, -1], self.environment_task_count.max().reshape(1),
@@ -208,7 +207,7 @@ class raw_env(BatchedParallelEnv):
         self._publish_dense()
         if self.logger is not None:  # _post_reset_hook (utils/env.py:191-195)
             self._log_environment(reset=True)
-        return {agent: self.observations[agent] for agent in self.agents}, self.infos
+        return self._observations_out(), self.infos
 
     def _enter_step_zero(self) -> None:
         """Append the schedule rows of timestep 0 behind a loaded initial state (host-side; reset-only path)."""
@@ -253,7 +252,7 @@ class raw_env(BatchedParallelEnv):
         self.infos = {agent: {} for agent in self.agents}
         if logged:
             self._log_environment()
-        return ({agent: self.observations[agent] for agent in self.agents}, self.rewards, self.terminations, self.truncations, self.infos)
+        return (self._observations_out(), self.rewards, self.terminations, self.truncations, self.infos)
 
     @torch.no_grad()
     def random_policy_actions(self, policy_seed: int, policy_step: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -277,7 +276,7 @@ class raw_env(BatchedParallelEnv):
         self.infos = {agent: {} for agent in self.agents}
         if logged:
             self._log_environment()
-        return ({agent: self.observations[agent] for agent in self.agents}, self.rewards, self.terminations, self.truncations, self.infos)
+        return (self._observations_out(), self.rewards, self.terminations, self.truncations, self.infos)
 
     @torch.no_grad()
     def capture_random_rollout(self, steps: int, policy_seed: int = 0, include_reset: bool = True) -> 'torch.cuda.CUDAGraph':

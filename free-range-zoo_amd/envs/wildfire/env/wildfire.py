@@ -147,9 +147,8 @@ class raw_env(BatchedParallelEnv):
             pass
 
     # ---------------------------------------------------------------------------------------- output plumbing
-    def _publish(self) -> None:
+    def _materialize(self) -> None:
         """Wrap the persistent output buffers in the reference's dict / TensorDict / nested-tensor structure."""
-        self._bump_space_epoch()
         B, A = self.parallel_envs, len(self.agents)
         HW = self.max_y * self.max_x
         if self.exact_shapes:
@@ -233,7 +232,7 @@ class raw_env(BatchedParallelEnv):
         self._publish_dense()
         if self.logger is not None:  # _post_reset_hook (utils/env.py:191-195)
             self._log_environment(reset=True)
-        return {agent: self.observations[agent] for agent in self.agents}, self.infos
+        return self._observations_out(), self.infos
 
     @torch.no_grad()
     def reset_batches(self, batch_indices: torch.Tensor, seed: Optional[List[int]] = None, options: Optional[Dict[str, Any]] = None) -> None:
@@ -309,7 +308,7 @@ class raw_env(BatchedParallelEnv):
         self.infos['putouts'] = self._putouts
         if logged:
             self._log_environment()
-        return ({agent: self.observations[agent] for agent in self.agents}, self.rewards, self.terminations, self.truncations, self.infos)
+        return (self._observations_out(), self.rewards, self.terminations, self.truncations, self.infos)
 
     def _log_extra(self, reset: bool):
         """wildfire.py:755-762: the step's burnouts / putouts (NULL in the reset row)."""
@@ -393,7 +392,7 @@ class raw_env(BatchedParallelEnv):
         self.infos['putouts'] = self._putouts
         if logged:
             self._log_environment()
-        return ({agent: self.observations[agent] for agent in self.agents}, self.rewards, self.terminations, self.truncations, self.infos)
+        return (self._observations_out(), self.rewards, self.terminations, self.truncations, self.infos)
 
     @torch.no_grad()
     def step_random_policy(self, policy_seed: int, policy_step: int):

@@ -31,6 +31,63 @@ def jagged(values: torch.Tensor, offsets: torch.Tensor, max_seqlen: Optional[int
     return torch.nested.nested_tensor_from_jagged(values, offsets, lengths=lengths, max_seqlen=max_seqlen)
 
 
+class LazyAgentDict(dict):
+    """``{agent: observation}`` as ``step()`` / ``reset()`` return it, filled on first use.  The jagged parts of an observation need the
+    step's list lengths on the host to take their exact shape (``exact_shapes=True``, the default): that one small device read happens when
+    an observation is actually looked at, not on every ``step()`` — rollouts whose policy runs on the device (``step_random_policy``,
+    ``action_space(agent).sample_nested()``, the scripted baselines) never pay it.  Like every tensor the env hands out, the contents are
+    views of the env's buffers, valid until its next ``step()`` / ``reset()``."""
+
+    def __init__(self, env, agents):
+        super().__init__()
+        self._env, self._agents, self._filled = env, tuple(agents), False
+
+    def _fill(self):
+        if not self._filled:
+            self._filled = True
+            observations = self._env.observations
+            dict.update(self, {agent: observations[agent] for agent in self._agents})
+        return self
+
+    def __getitem__(self, key):
+        return dict.__getitem__(self._fill(), key)
+
+    def get(self, key, default=None):
+        return dict.get(self._fill(), key, default)
+
+    def __iter__(self):
+        return iter(self._agents)
+
+    def __len__(self):
+        return len(self._agents)
+
+    def __contains__(self, key):
+        return key in self._agents
+
+    def keys(self):
+        return dict.fromkeys(self._agents).keys()
+
+    def values(self):
+        return dict.values(self._fill())
+
+    def items(self):
+        return dict.items(self._fill())
+
+    def __eq__(self, other):
+        return dict.__eq__(self._fill(), other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = None
+
+    def __repr__(self):
+        return dict.__repr__(self._fill())
+
+    def copy(self):
+        return dict(self._fill())
+
+
 class BatchedParallelEnv:
     """Common constructor / bookkeeping of the three domains."""
 
@@ -127,6 +184,36 @@ class BatchedParallelEnv:
         return torch.zeros(shape, dtype=dtype, device=self.device)
 
     _domain: str = ''  # 'wildfire' | 'cybersecurity' | 'rideshare': the C entry points are frz_<domain>_<entry>
+
+    # -- published outputs ----------------------------------------------------------------------------------------------------------
+    # What a step leaves for the caller besides the dense per-agent dicts: the observations (TensorDicts with jagged `tasks`), the task
+    # store and the jagged action / observation / bad-action mappings.  With exact_shapes (the default) their construction needs the list
+    # lengths on the host, so `_publish()` only marks them stale and the first access builds them (`_materialize()` of the domain, one
+    # small device read); with exact_shapes=False they are persistent views over capacity buffers, built once.
+    _LAZY_OUTPUTS = frozenset(('observations', 'task_store', 'agent_action_mapping', 'agent_observation_mapping', 'agent_bad_actions'))
+
+    def _publish(self) -> None:
+        self._bump_space_epoch()
+        if self.exact_shapes:
+            for name in self._LAZY_OUTPUTS:
+                self.__dict__.pop(name, None)
+        else:
+            self._materialize()
+        if getattr(self, 'rewards', None) is None:
+            self._publish_dense()
+
+    def __getattr__(self, name):
+        # only reached when normal lookup fails: a stale published output is rebuilt on demand
+        if name in BatchedParallelEnv._LAZY_OUTPUTS and self.__dict__.get('_has_reset'):
+            self._materialize()
+            return self.__dict__[name]
+        raise AttributeError(f'{type(self).__name__!r} object has no attribute {name!r}')
+
+    def _observations_out(self):
+        """What step() / reset() return as observations: filled on first use in the exact-shapes mode, the persistent views otherwise."""
+        if self.exact_shapes:
+            return LazyAgentDict(self, self.agents)
+        return {agent: self.observations[agent] for agent in self.agents}
 
     def _call(self, entry: str, c_args=(), op_args=None) -> None:
         """One stream-ordered launch of ``frz_<domain>_<entry>`` on the current stream of the env's device: a ctypes call into

@@ -1,0 +1,73 @@
+"""GPU: with the default exact_shapes=True a step does not read the device — the jagged outputs take their exact shape when they are first
+looked at — and observation_space(agent) describes the env's current step."""
+import pytest
+import torch
+
+import configs
+
+pytestmark = pytest.mark.gpu
+
+
+def _domains():
+    from free_range_zoo_amd.envs import cybersecurity_v0, rideshare_v0, wildfire_v0
+    return {'wildfire': (wildfire_v0, configs.wildfire_openness, dict(rng='philox')),
+            'cybersecurity': (cybersecurity_v0, configs.cyber_openness, dict(rng='philox')),
+            'rideshare': (rideshare_v0, lambda: configs.rideshare_busy(A=4, steps=10, per_step=2, seed=2), {})}
+
+
+@pytest.mark.parametrize('domain', ['wildfire', 'cybersecurity', 'rideshare'])
+def test_default_step_is_sync_free_until_an_output_is_looked_at(domain, monkeypatch):
+    module, build, kwargs = _domains()[domain]
+    B = 512
+    env = module.parallel_env(configuration=build(), parallel_envs=B, max_steps=12, device=torch.device('cuda'), **kwargs)
+    assert env.exact_shapes
+    env.reset(seed=torch.arange(B, dtype=torch.int32))
+    reads = []
+    real = torch.Tensor.tolist
+    monkeypatch.setattr(torch.Tensor, 'tolist', lambda self: (reads.append(1), real(self))[1])
+    real_item = torch.Tensor.item
+    monkeypatch.setattr(torch.Tensor, 'item', lambda self: (reads.append(1), real_item(self))[1])
+    for t in range(5):
+        out = env.step_random_policy(policy_seed=3, policy_step=t)
+    obs, rewards, terminations, truncations, infos = out
+    assert reads == [], 'a device-side-policy rollout read the device'
+    assert set(obs) == set(env.agents) and len(obs) == len(env.agents)  # keys are known without touching the device
+    assert reads == []
+    first = obs[env.agents[0]]  # now the lists take their exact shapes: one read
+    assert len(reads) == 1
+    tasks = first['tasks']
+    total = int(tasks.offsets()[-1]) if tasks.is_nested else tasks.shape[0]
+    if tasks.is_nested:
+        assert tasks.values().shape[0] == total
+    assert obs[env.agents[-1]] is env.observations[env.agents[-1]] and len(reads) <= 2
+    before = len(reads)
+    env.step_random_policy(policy_seed=3, policy_step=5)
+    assert len(reads) == before
+    mapping = env.agent_action_mapping[env.agents[0]]  # stale outputs are rebuilt on demand
+    assert mapping.offsets().shape[0] == B + 1
+    env.check()
+
+
+@pytest.mark.parametrize('domain', ['wildfire', 'cybersecurity', 'rideshare'])
+def test_observation_space_objects(domain):
+    from free_range_zoo_amd.utils.spaces import Box, Dict, Tuple
+    module, build, kwargs = _domains()[domain]
+    B = 64
+    env = module.parallel_env(configuration=build(), parallel_envs=B, max_steps=12, device=torch.device('cuda'), **kwargs)
+    env.reset(seed=torch.arange(B, dtype=torch.int32))
+    for t in range(3):
+        env.step_random_policy(policy_seed=1, policy_step=t)
+    for a, agent in enumerate(env.agents):
+        space = env.observation_space(agent)
+        assert len(space) == B
+        obs = env.observe(agent)
+        counts = {'wildfire': env.environment_task_count, 'rideshare': env.agent_task_count[a],
+                  'cybersecurity': torch.full((B, ), 3)}[domain].tolist()
+        for b in (0, 17, B - 1):
+            single = space[b]
+            assert isinstance(single, Dict) and set(single.keys()) == {'self', 'others', 'tasks'}
+            assert isinstance(single['self'], Box) and len(single['self']) == obs['self'].shape[-1]
+            assert isinstance(single['others'], Tuple) and len(single['others']) == obs['others'].shape[1]
+            assert isinstance(single['tasks'], Tuple) and len(single['tasks']) == counts[b]
+            if len(single['others']) and obs['others'].shape[-1]:
+                assert len(single['others'][0]) == obs['others'].shape[-1]
