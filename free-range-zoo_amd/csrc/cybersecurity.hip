@@ -856,7 +856,9 @@ static int step_impl(frz_cybersecurity_env* env, const int32_t* actions, int rng
         int32_t* mt_index = at<int32_t>(env->arena, p.off_rows4 + (int64_t)p.r_mti * B * 4);
         float* rn = at<float>(env->arena, p.off_rand_net);
         float* ra = at<float>(env->arena, p.off_rand_agent);
-        const int rc = frz_mt19937_generate_pair(mt_state, mt_index, rn, 1, p.N, ra, 1, p.A, B, stream);
+        // (a frozen batch draws nothing: the step launch below will be a no-op, and so is the reference's step then)
+        const int rc = frz::mt19937_generate_pair_gated(mt_state, mt_index, rn, 1, p.N, ra, 1, p.A, B, at<uint32_t>(env->arena, p.off_epoch),
+                                                        at<uint32_t>(env->arena, p.off_totals), p.A, frz::kTotalsStride, stream);
         if (rc != FRZ_OK) return rc;
         network_randomness = rn;
         agent_randomness = ra;

@@ -109,4 +109,8 @@ __device__ __forceinline__ uint32_t granule_wait(const uint64_t* slot, uint32_t 
     return 0;
 }
 
+// mt19937.hip: frz_mt19937_generate_pair gated on an env object's batch totals (host-callable; see the definition)
+int mt19937_generate_pair_gated(uint32_t* mt_state, int32_t* mt_index, float* out, int64_t events, int64_t count, float* out2, int64_t events2,
+                                int64_t count2, int64_t B, const uint32_t* epoch, const uint32_t* totals, int channel, int stride, void* stream);
+
 }  // namespace frz

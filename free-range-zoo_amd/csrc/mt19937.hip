@@ -41,10 +41,24 @@ constexpr int kBatch = 16;
 
 __device__ __forceinline__ int wrap(int j) { return j >= kN ? j - kN : j; }
 
+// gate (optional): the epoch word and the two batch-totals slots of an env object's scan workspace + the channel that counts the envs not
+// yet terminated (the next channel counts those not yet truncated).  When either is zero the step launch that follows is a no-op
+// (utils/env.py:211-213: the reference returns before step_environment draws anything), so the streams are left where they are.
+struct MtGate {
+    const uint32_t* epoch;
+    const uint32_t* totals;
+    int32_t channel, stride;
+};
+
 __global__ void __launch_bounds__(frz::kBlock) mt_generate_kernel(uint32_t* mt_state, int32_t* mt_index, float* out, int64_t events,
-                                                                    int64_t count, float* out2, int64_t events2, int64_t count2, int64_t B) {
+                                                                    int64_t count, float* out2, int64_t events2, int64_t count2, int64_t B,
+                                                                    const MtGate gate) {
     const int64_t b = (int64_t)blockIdx.x * frz::kBlock + threadIdx.x;
     if (b >= B) return;
+    if (gate.epoch) {
+        const uint32_t* left = gate.totals + ((*gate.epoch + 1u) & 1u) * gate.stride + gate.channel;  // what the previous launch left
+        if (left[0] == 0u || left[1] == 0u) return;
+    }
     int i = mt_index[b];
     const int64_t n1 = events * count, total = n1 + events2 * count2;
     for (int64_t u0 = 0; u0 < total; u0 += kBatch) {
@@ -99,7 +113,7 @@ int frz_mt19937_generate(uint32_t* mt_state, int32_t* mt_index, float* out, int6
     if (events == 0 || count == 0) return FRZ_OK;
     const int blocks = (int)((B + frz::kBlock - 1) / frz::kBlock);
     hipLaunchKernelGGL(mt_generate_kernel, dim3(blocks), dim3(frz::kBlock), 0, static_cast<hipStream_t>(stream), mt_state, mt_index, out,
-                       events, count, static_cast<float*>(nullptr), (int64_t)0, (int64_t)1, B);
+                       events, count, static_cast<float*>(nullptr), (int64_t)0, (int64_t)1, B, MtGate{});
     return hipGetLastError() == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;
 }
 
@@ -108,8 +122,23 @@ int frz_mt19937_generate_pair(uint32_t* mt_state, int32_t* mt_index, float* out,
     if (!mt_state || !mt_index || !out || !out2 || B <= 0 || events <= 0 || count <= 0 || events2 <= 0 || count2 <= 0) return FRZ_E_INVALID;
     const int blocks = (int)((B + frz::kBlock - 1) / frz::kBlock);
     hipLaunchKernelGGL(mt_generate_kernel, dim3(blocks), dim3(frz::kBlock), 0, static_cast<hipStream_t>(stream), mt_state, mt_index, out,
-                       events, count, out2, events2, count2, B);
+                       events, count, out2, events2, count2, B, MtGate{});
     return hipGetLastError() == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;
 }
 
 }  // extern "C"
+
+namespace frz {
+
+// frz_mt19937_generate_pair for the step launches that stage their draws (library-internal): nothing is drawn when the env batch is
+// frozen, exactly as the kernels that advance the streams themselves behave
+int mt19937_generate_pair_gated(uint32_t* mt_state, int32_t* mt_index, float* out, int64_t events, int64_t count, float* out2, int64_t events2,
+                                int64_t count2, int64_t B, const uint32_t* epoch, const uint32_t* totals, int channel, int stride, void* stream) {
+    if (!mt_state || !mt_index || !out || !out2 || B <= 0 || events <= 0 || count <= 0 || events2 <= 0 || count2 <= 0) return FRZ_E_INVALID;
+    const int blocks = (int)((B + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(mt_generate_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), mt_state, mt_index, out, events,
+                       count, out2, events2, count2, B, MtGate{epoch, totals, channel, stride});
+    return hipGetLastError() == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;
+}
+
+}  // namespace frz

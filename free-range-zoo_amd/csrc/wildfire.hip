@@ -1537,7 +1537,10 @@ int frz_wildfire_step(frz_wildfire_env* env, const int32_t* actions, int rng_mod
         int32_t* mt_index = at<int32_t>(env->arena, p.off_rows4 + (int64_t)p.r_mti * B * 4);
         float* rf = at<float>(env->arena, p.off_rand_field);
         float* ra = at<float>(env->arena, p.off_rand_agent);
-        const int rc = frz_mt19937_generate_pair(mt_state, mt_index, rf, 3, (int64_t)c.grid_height * c.grid_width, ra, 5, c.num_agents, B, stream);
+        // (a frozen batch draws nothing: the step launch below will be a no-op, and so is the reference's step then)
+        const int rc = frz::mt19937_generate_pair_gated(mt_state, mt_index, rf, 3, (int64_t)c.grid_height * c.grid_width, ra, 5, c.num_agents, B,
+                                                        at<uint32_t>(env->arena, p.off_epoch), at<uint32_t>(env->arena, p.off_totals),
+                                                        c.num_agents + 1, kTotalsStride, stream);
         if (rc != FRZ_OK) return rc;
         args.field_rand = rf;
         args.agent_rand = ra;
