@@ -190,10 +190,11 @@ def secondary_workloads(device, B):
             kernels = getattr(env, 'step_kernels', 'rs_step_kernel + rs_policy_kernel')
             counts = {'mean_passengers_per_env': mean_env, 'mean_visible_tasks_per_env_summed_over_agents': mean_agents}
         achieved = per_env * B / (step_ms * 1e-3) / 1e9
+        traffic, traffic_source = recorded_traffic(('cybersecurity' if module is cybersecurity_v0 else 'rideshare') + '_bytes_per_step')
         out[name] = {'env_steps_per_s': B * EPISODE / elapsed, 'ms_per_step': 1e3 * elapsed / EPISODE, 'parallel_envs': B, 'steps': EPISODE,
                      'episodes_timed': reps,
                      'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                                  'traffic': None, 'kernel': kernels, 'step_ms_avg': step_ms, 'algorithmic_bytes_per_env_step': per_env,
+                                  'traffic': traffic, 'traffic_source': traffic_source, 'kernel': kernels, 'step_ms_avg': step_ms, 'algorithmic_bytes_per_env_step': per_env,
                                   'how': 'HIP events on the launch stream around one episode of step launches (graph replay, reset outside), '
                                          'median of 3, divided by 50', **counts}}
         del env

@@ -604,6 +604,55 @@ __global__ void __launch_bounds__(kBlock) rs_offsets_kernel(char* __restrict__ a
 // the places of all agents are laid end to end in LDS, and the wavefront then streams rows to their destinations, 16 bytes per lane, a
 // whole wave store at a time whatever agent a piece belongs to (its agent's destination comes from a small LDS table).
 // ------------------------------------------------------------------------------------------------------------------------------------
+// list stores: FRZ_RS_STORE = 0 plain, 1 write-through (sc1), 2 non-temporal (nt), 3 sc0 sc1 — experiment switch, see DESIGN.md
+#ifndef FRZ_RS_STORE
+#define FRZ_RS_STORE 0
+#endif
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void list_store(int4* at, const int4& value) {
+    const v4i v = {value.x, value.y, value.z, value.w};
+#if FRZ_RS_STORE == 1
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(at), "v"(v) : "memory");
+#elif FRZ_RS_STORE == 2
+    asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(at), "v"(v) : "memory");
+#elif FRZ_RS_STORE == 3
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(at), "v"(v) : "memory");
+#else
+    *at = value;
+#endif
+}
+__device__ __forceinline__ void list_store(int64_t* at, int64_t value) {
+    const v2i v = {(int)(uint32_t)value, (int)(value >> 32)};
+#if FRZ_RS_STORE == 1
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(at), "v"(v) : "memory");
+#elif FRZ_RS_STORE == 2
+    asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(at), "v"(v) : "memory");
+#elif FRZ_RS_STORE == 3
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(at), "v"(v) : "memory");
+#else
+    *at = value;
+#endif
+}
+__device__ __forceinline__ void list_store(int32_t* at, int32_t value) {
+#if FRZ_RS_STORE == 1
+    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(at), "v"(value) : "memory");
+#elif FRZ_RS_STORE == 2
+    asm volatile("global_store_dword %0, %1, off nt" ::"v"(at), "v"(value) : "memory");
+#elif FRZ_RS_STORE == 3
+    asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(at), "v"(value) : "memory");
+#else
+    *at = value;
+#endif
+}
+
+// diagnostic builds only (timing experiments: -DFRZ_RS_SKIP=<bits> leaves store groups out): 1 task rows, 2 agent rows, 4 maps / states
+#ifdef FRZ_RS_SKIP
+#define FRZ_RS_SKIPPED(bit) ((FRZ_RS_SKIP & (bit)) != 0)
+#else
+#define FRZ_RS_SKIPPED(bit) false
+#endif
+
 template <int AMAX, int SPL>
 __global__ void __launch_bounds__(kBlock) rs_emit_kernel(char* __restrict__ arena, const RsDev d) {
     __shared__ int4 s_rows[kEnvsPerBlock][SPL * 64][2];
@@ -654,7 +703,7 @@ __global__ void __launch_bounds__(kBlock) rs_emit_kernel(char* __restrict__ aren
     {
         int4* const out = reinterpret_cast<int4*>(arena + d.off_task_values) + task_base * 2;
         const int4* const src = &s_rows[wave][0][0];
-        for (int p = lane; p < 2 * count; p += 64) out[p] = src[p];
+        for (int p = lane; p < (FRZ_RS_SKIPPED(1) ? 0 : 2 * count); p += 64) list_store(out + p, src[p]);
     }
     // agents >= A of a wider instantiation saw the unaccepted passengers too: their places lie behind those of the real agents and are
     // not written (the flat sequence is cut at the last real agent's end)
@@ -662,20 +711,20 @@ __global__ void __launch_bounds__(kBlock) rs_emit_kernel(char* __restrict__ aren
     // the agents' task rows
     {
         int4* const out = reinterpret_cast<int4*>(arena + d.off_agent_task_values);
-        for (int p = lane; p < 2 * real_total; p += 64) {
+        for (int p = lane; p < (FRZ_RS_SKIPPED(2) ? 0 : 2 * real_total); p += 64) {
             const int r = p >> 1, e = s_pick[wave][r];
-            out[(s_dest[wave][e >> 12] + r) * 2 + (p & 1)] = s_rows[wave][e & 0xFF][p & 1];
+            list_store(out + (s_dest[wave][e >> 12] + r) * 2 + (p & 1), s_rows[wave][e & 0xFF][p & 1]);
         }
     }
     // their positions in the env's passenger list (action = observation mapping) and their states (the action id each OneOf member carries)
     {
         int64_t* const map_out = reinterpret_cast<int64_t*>(arena + d.off_agent_map_values);
         int32_t* const state_out = reinterpret_cast<int32_t*>(arena + d.off_agent_task_states);
-        for (int r = lane; r < real_total; r += 64) {
+        for (int r = lane; r < (FRZ_RS_SKIPPED(4) ? 0 : real_total); r += 64) {
             const int e = s_pick[wave][r];
             const int64_t at = s_dest[wave][e >> 12] + r;
-            map_out[at] = e & 0xFF;
-            state_out[at] = (e >> 8) & 0xF;
+            list_store(map_out + at, (int64_t)(e & 0xFF));
+            list_store(state_out + at, (int32_t)((e >> 8) & 0xF));
         }
     }
 }
