@@ -61,6 +61,8 @@ struct CyLaunch {
     uint32_t policy, policy_seed_lo, policy_seed_hi, policy_step_lo, policy_step_hi;
     int32_t* actions_out;
     int64_t off_mt_state;  // FRZ_RNG_MT19937 inside the step: the per-env generator states, word j of env b at [j][b]
+    int64_t off_lut;       // the danger table and its size (cy_roles_kernel requests it with its first loads)
+    int32_t lut_entries;
 };
 
 template <typename T>
@@ -536,6 +538,449 @@ __global__ void __launch_bounds__(kBlock) cy_step_kernel(char* __restrict__ aren
     }
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// The step as two roles (the shapes up to 8 nodes / 8 agents).  At 65 536 envs the lane-per-env kernel above is one
+// wavefront per SIMD and what it waits for is itself: ~2 200 dependent instructions between a memory round trip at the
+// start and the stores at the end.  Here a 512-thread workgroup owns the chunk; lane i of wavefront w and of wavefront
+// w + 4 hold the same env:
+//   * wavefronts 0-3 (**state**): loads, fused policy, action decode, presence, subnetwork transition, rewards and
+//     state rows, then the scan of the presence counts and the action mappings;
+//   * wavefronts 4-7 (**view**): the step's random draws (Philox blocks / the env's MT19937 stream / the injected
+//     rows) while the state role decodes, then — from the post-transition state the state role leaves in LDS —
+//     every observation row (self, others, tasks), i.e. two thirds of the step's stores.
+// Three workgroup barriers (configuration staged, draws ready, state ready) + the four of the scan, which the view
+// role passes between its store groups.
+// ----------------------------------------------------------------------------------------------------------------
+constexpr int kRoleBlock = 2 * kBlock;
+
+template <int NMAX, int AMAX, int ATT, int RNG>
+__global__ void __launch_bounds__(kRoleBlock) cy_roles_kernel(char* __restrict__ arena, const CyDev* __restrict__ dev,
+                                                              const int32_t* __restrict__ actions, const float* __restrict__ net_rand,
+                                                              const float* __restrict__ agent_rand, const CyLaunch L) {
+    static_assert(AMAX <= 8, "the danger table is staged with one load per state-role thread");
+    __shared__ frz::ScanShared<AMAX> s_scan;
+    __shared__ int s_ticket;
+    __shared__ float s_lut[1 << AMAX];
+    __shared__ uint4 s_cfg[kCfgPieces];
+    __shared__ float s_draw[NMAX + AMAX][kBlock];     // view -> state: this step's uniforms (nodes, then agents)
+    __shared__ int s_post[NMAX + 2 * AMAX + 1][kBlock];  // state -> view: state, location, last action, presence bits after the step
+
+    const int tid = threadIdx.x & (kBlock - 1);
+    const bool view = threadIdx.x >= kBlock;  // wave-uniform
+    const uint4 cfg_piece = threadIdx.x < kCfgPieces ? reinterpret_cast<const uint4*>(dev)[threadIdx.x] : make_uint4(0, 0, 0, 0);
+    const float lut_piece = (!view && tid < L.lut_entries) ? reinterpret_cast<const float*>(arena + L.off_lut)[tid] : 0.0f;
+    const int64_t B = L.B;
+    const uint32_t Bu = (uint32_t)L.B;
+    const int N = ATT >= 0 ? NMAX : L.N, Att = ATT >= 0 ? ATT : L.Att, D = ATT >= 0 ? AMAX - ATT : L.D, A = ATT >= 0 ? AMAX : L.A;
+    const int nchunks = (int)((B + kBlock - 1) / kBlock);
+    const int r_state = 0, r_loc = N, r_last = N + D, r_moves = N + 2 * D, r_seeds = r_moves + 3 * A + 2;
+    const uint32_t u_presence = 0, u_trunc = 2u * (uint32_t)A;
+    int32_t* const rows = reinterpret_cast<int32_t*>(arena + kDevBlockBytes);
+    float* const rowsf = reinterpret_cast<float*>(arena + kDevBlockBytes);
+    uint8_t* const rows1 = reinterpret_cast<uint8_t*>(arena + L.off_rows1);
+
+    frz::ScanWorkspace ws{reinterpret_cast<uint32_t*>(arena + L.off_epoch), reinterpret_cast<uint32_t*>(arena + L.off_totals), nullptr, nullptr};
+    const int chunk = frz::scan_take_chunk(ws, nchunks, L.ticketed != 0, &s_ticket);
+    const frz::ScanLaunch launch = frz::scan_begin(ws);
+    const int64_t b = (int64_t)chunk * kBlock + tid;
+    const bool active = b < B;
+    const uint32_t bl = (uint32_t)(active ? b : B - 1);
+
+    // ------------------------------------------------------------------------------------ loads of both roles (unconditional, see above)
+    int state[NMAX], loc[AMAX], last[AMAX];
+    uint32_t pres_raw[AMAX];
+    float cum_in[AMAX];
+    uint32_t trunc_raw = 0;
+    int2 act_in[AMAX];
+    float r_in[NMAX + AMAX];
+    const int nm_in = at32(rows, (uint32_t)r_moves * Bu + bl);
+    const uint32_t seed = (RNG == FRZ_RNG_PHILOX || L.policy) ? (uint32_t)at32(rows, (uint32_t)r_seeds * Bu + bl) : 0u;
+    int mti = 0;
+    if (!view) {
+#pragma unroll
+        for (int n = 0; n < NMAX; ++n) state[n] = at32(rows, (uint32_t)(r_state + min(n, N - 1)) * Bu + bl);
+#pragma unroll
+        for (int k = 0; k < AMAX; ++k) {
+            loc[k] = at32(rows, (uint32_t)(r_loc + min(k, D - 1)) * Bu + bl);
+            last[k] = at32(rows, (uint32_t)(r_last + min(k, D - 1)) * Bu + bl);
+        }
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a) pres_raw[a] = at32(rows1, (u_presence + (uint32_t)min(a, A - 1)) * Bu + bl);
+        trunc_raw = at32(rows1, u_trunc * Bu + bl);
+        if (!L.policy) {
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a) act_in[a] = reinterpret_cast<const int2*>(actions)[(int64_t)min(a, A - 1) * B + bl];
+        }
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a) cum_in[a] = at32(rowsf, (uint32_t)(r_moves + 1 + A + min(a, A - 1)) * Bu + bl);
+    } else {
+        if (RNG == FRZ_RNG_MT19937) mti = at32(rows, (uint32_t)(r_seeds + 1) * Bu + bl);
+        if (RNG == FRZ_RNG_INJECTED) {
+#pragma unroll
+            for (int n = 0; n < NMAX; ++n) r_in[n] = net_rand[(int64_t)bl * N + min(n, N - 1)];
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a) r_in[NMAX + a] = agent_rand[(int64_t)bl * A + min(a, A - 1)];
+        }
+    }
+
+    if (threadIdx.x < kCfgPieces) s_cfg[threadIdx.x] = cfg_piece;
+    if (!view && tid < (1 << AMAX)) s_lut[tid] = lut_piece;
+    __syncthreads();  // (1) configuration and danger table staged
+    const CyDev* const cfg_lds = reinterpret_cast<const CyDev*>(s_cfg);
+    const CyDev d = *cfg_lds;
+    const uint32_t flags = d.flags;
+    ws.agg = reinterpret_cast<uint64_t*>(arena + d.off_agg);
+    ws.prefix = reinterpret_cast<uint64_t*>(arena + d.off_prefix);
+
+    if (launch.prev[A] == 0u || launch.prev[A + 1] == 0u) {  // frozen batch (utils/env.py:211-213): see cy_step_kernel
+        if (!view && active && !at32(rows1, (uint32_t)d.u_frozen * Bu + bl)) {
+            for (int a = 0; a < A; ++a) {
+                const float r = at32(rowsf, (uint32_t)(d.r_rewards + a) * Bu + bl);
+                float acc = 0.0f;
+                for (int j = 0; j < A; ++j) acc = acc + r;
+                at32(rowsf, (uint32_t)(d.r_rewards + a) * Bu + bl) = acc;
+            }
+            at32(rows1, (uint32_t)d.u_frozen * Bu + bl) = 1;
+        }
+        return;
+    }
+
+    if (view) {
+        // ================================================================================================ view role
+        // ---------------------------------------------------------------- the step's draws (streams: cy_step_kernel above)
+        if (RNG == FRZ_RNG_INJECTED) {
+#pragma unroll
+            for (int k = 0; k < NMAX + AMAX; ++k) s_draw[k][tid] = r_in[k];
+        } else if constexpr (RNG == FRZ_RNG_MT19937) {
+            constexpr int U = NMAX + AMAX, kN = 624, kM = 397;
+            static_assert(U <= kN - kM, "a batch must not read a word it rewrites");
+            uint32_t* const mt = reinterpret_cast<uint32_t*>(arena + L.off_mt_state);
+            const int used = N + A;
+            uint32_t w[U + 1], far[U];
+#pragma unroll
+            for (int k = 0; k <= U; ++k) {
+                int j = mti + k;
+                j -= j >= kN ? kN : 0;
+                w[k] = mt[(int64_t)j * B + bl];
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                int j = mti + k + kM;
+                j -= j >= kN ? kN : 0;
+                j -= j >= kN ? kN : 0;
+                far[k] = mt[(int64_t)j * B + bl];
+            }
+            float uni[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const uint32_t y = (w[k] & 0x80000000u) | (w[k + 1] & 0x7fffffffu);
+                uint32_t v = far[k] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                int j = mti + k;
+                j -= j >= kN ? kN : 0;
+                if (active && k < used) mt[(int64_t)j * B + bl] = v;
+                v ^= v >> 11;
+                v ^= (v << 7) & 0x9d2c5680u;
+                v ^= (v << 15) & 0xefc60000u;
+                v ^= v >> 18;
+                uni[k] = (float)(v & 0xFFFFFFu) * (1.0f / 16777216.0f);
+            }
+            if (active) {
+                int j = mti + used;
+                j -= j >= kN ? kN : 0;
+                at32(rows, (uint32_t)(r_seeds + 1) * Bu + bl) = j;
+            }
+#pragma unroll
+            for (int n = 0; n < NMAX; ++n) s_draw[n][tid] = uni[n];  // node n is draw n, agent a is draw N + a
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a) {
+                float u = 0.0f;
+#pragma unroll
+                for (int k = 0; k < U; ++k) u = (k == N + a) ? uni[k] : u;
+                s_draw[NMAX + a][tid] = u;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < (NMAX + 3) / 4; ++q) {
+                frz::Philox4 w{{0u, 0u, 0u, 0u}};
+                const bool drawn = q * 4 < N && (flags & kStochState);
+                if (drawn) w = frz::philox4x32_10((uint32_t)q, (uint32_t)nm_in, 0u, 0u, seed, 0x46525A01u);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (q * 4 + j < NMAX) s_draw[q * 4 + j][tid] = drawn ? frz::u32_to_unit_float(w.w[j]) : 0.0f;
+            }
+#pragma unroll
+            for (int q = 0; q < (AMAX + 3) / 4; ++q) {
+                frz::Philox4 w{{0u, 0u, 0u, 0u}};
+                const bool drawn = q * 4 < A;
+                if (drawn) w = frz::philox4x32_10((uint32_t)q, (uint32_t)nm_in, 1u, 0u, seed, 0x46525A01u);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (q * 4 + j < AMAX) s_draw[NMAX + q * 4 + j][tid] = drawn ? frz::u32_to_unit_float(w.w[j]) : 0.0f;
+            }
+        }
+        __syncthreads();  // (2) draws ready
+        // addresses of this env's observation rows, while the state role works
+        float* const self_att = reinterpret_cast<float*>(arena + d.off_self_att);
+        float* const self_def = reinterpret_cast<float*>(arena + d.off_self_def);
+        float* const others_att = reinterpret_cast<float*>(arena + d.off_others_att);
+        float* const others_def = reinterpret_cast<float*>(arena + d.off_others_def);
+        int64_t* const tasks = reinterpret_cast<int64_t*>(arena + d.off_tasks);
+        const bool op = (flags & kObsPower) != 0, opr = (flags & kObsPresence) != 0, ol = (flags & kObsLocation) != 0;
+        const int ka = (op ? 1 : 0) + (opr ? 1 : 0), kd = ka + (ol ? 1 : 0);
+        __syncthreads();  // (3) post-transition state ready
+#pragma unroll
+        for (int n = 0; n < NMAX; ++n) state[n] = s_post[n][tid];
+#pragma unroll
+        for (int k = 0; k < AMAX; ++k) {
+            loc[k] = s_post[NMAX + k][tid];
+            last[k] = s_post[NMAX + AMAX + k][tid];
+        }
+        const uint32_t pres_bits = (uint32_t)s_post[NMAX + 2 * AMAX][tid];
+        bool pres[AMAX];
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a) pres[a] = (pres_bits >> a) & 1u;
+        frz::scan_chunk_passive_front();
+        if (active) {
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a) {
+                if (a < Att) {  // attackers: (threat, presence) (:481-484)
+                    reinterpret_cast<float2*>(self_att)[a * B + b] = make_float2(d.threat[a], pres[a] ? 1.0f : 0.0f);
+                    float* others = others_att + (a * B + b) * (int64_t)((Att - 1) * ka);
+                    int col = 0;
+#pragma unroll
+                    for (int o = 0; o < AMAX; ++o)
+                        if (o < Att && o != a) {
+                            if (op) others[col++] = d.threat[o];
+                            if (opr) others[col++] = pres[o] ? 1.0f : 0.0f;
+                        }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < AMAX; ++k) {
+                if (k < D) {  // defenders: (mitigation, presence, location) (:475-479)
+                    bool present_k = false;
+#pragma unroll
+                    for (int a = 0; a < AMAX; ++a) present_k = (a == Att + k) ? pres[a] : present_k;
+                    float* self = self_def + (k * B + b) * 3;
+                    self[0] = d.mitigation[k];
+                    self[1] = present_k ? 1.0f : 0.0f;
+                    self[2] = (float)loc[k];
+                    float* others = others_def + (k * B + b) * (int64_t)((D - 1) * kd);
+                    int col = 0;
+#pragma unroll
+                    for (int o = 0; o < AMAX; ++o)
+                        if (o < D && o != k) {
+                            bool present_o = false;
+#pragma unroll
+                            for (int a = 0; a < AMAX; ++a) present_o = (a == Att + o) ? pres[a] : present_o;
+                            if (op) others[col++] = d.mitigation[o];
+                            if (opr) others[col++] = present_o ? 1.0f : 0.0f;
+                            if (ol) others[col++] = (float)loc[o];
+                        }
+                }
+            }
+            // tasks (state, criticality) per agent; a defender sees them only right after monitoring (:497, :510-511)
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a) {
+                if (a < A) {
+                    bool hidden = false;
+                    if (flags & kPartial) {
+#pragma unroll
+                        for (int k = 0; k < AMAX; ++k) hidden = (a == Att + k && k < D) ? last[k] != -3 : hidden;
+                    }
+                    int64_t* t = tasks + (a * B + b) * (int64_t)(N * 2);
+#pragma unroll
+                    for (int n = 0; n < NMAX; ++n)
+                        if (n < N)
+                            reinterpret_cast<longlong2*>(t)[n] =
+                                hidden ? make_longlong2(-100, -100) : make_longlong2(state[n], d.criticality[n]);
+                }
+            }
+        }
+        frz::scan_chunk_passive_back();
+        return;
+    }
+
+    // ==================================================================================================== state role
+    bool pres[AMAX];
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) state[n] = n < N ? state[n] : 0;
+#pragma unroll
+    for (int k = 0; k < AMAX; ++k) {
+        loc[k] = k < D ? loc[k] : -1;
+        last[k] = k < D ? last[k] : -2;
+    }
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) {
+        pres[a] = a < A && pres_raw[a] != 0;
+        if (L.policy || a >= A) act_in[a] = make_int2(0, -1);
+    }
+    bool trunc = trunc_raw != 0;
+    uint32_t err = 0;
+    int nm = nm_in;
+
+    if (L.policy) {  // the stream of cy_policy_kernel (see cy_step_kernel)
+        frz::Philox4 policy_words[(AMAX + 3) / 4];
+#pragma unroll
+        for (int q = 0; q < (AMAX + 3) / 4; ++q)
+            if (q * 4 < A) policy_words[q] = frz::philox4x32_10((uint32_t)q, 0u, L.policy_step_lo, L.policy_step_hi, L.policy_seed_lo ^ seed,
+                                                               L.policy_seed_hi);
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a) {
+            if (a < A) {
+                const int n = (flags & kShowBad) ? N : (pres[a] ? N : 0);
+                int tail1 = -3, nt = 1;
+                if (a >= Att && n > 0) {
+                    int home_loc = 0;
+#pragma unroll
+                    for (int k = 0; k < AMAX; ++k) home_loc = (a == Att + k) ? loc[k] : home_loc;
+                    const bool patchable = (flags & kShowBad) || home_loc != -1;
+                    tail1 = patchable ? -2 : -3;
+                    nt = patchable ? 3 : 2;
+                }
+                const int j = (int)(((uint64_t)policy_words[a >> 2].w[a & 3] * (uint64_t)(n + nt)) >> 32);
+                const int value = j < n ? 0 : (j - n == 0 ? -1 : (j - n == 1 ? tail1 : -3));
+                act_in[a] = make_int2(j, value);
+                if (active) reinterpret_cast<int2*>(L.actions_out)[(int64_t)a * B + b] = act_in[a];
+            }
+        }
+    }
+    // --------------------------------------------------- action decode (cybersecurity.py:326-384), agent order
+    uint32_t attack_set[NMAX], patch_set[NMAX];
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) attack_set[n] = patch_set[n] = 0u;
+    float rew[AMAX];
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) {
+        rew[a] = 0.0f;
+        if (a < A) {
+            const int2 v = act_in[a];
+            const int idx = v.x, act = v.y;
+            const bool bad_target = act == 0 && (idx < 0 || idx >= N);
+            if (bad_target && active) err |= FRZ_ERR_INVALID_TARGET;
+            if (!bad_target && !(flags & kShowBad) && !pres[a] && act != -1 && active) err |= FRZ_ERR_ABSENT_ACTION;
+            if (a < Att) {
+                const bool attack = act == 0 && !bad_target;
+#pragma unroll
+                for (int n = 0; n < NMAX; ++n) attack_set[n] |= (attack && idx == n) ? (1u << a) : 0u;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < AMAX; ++k) {
+        if (k < D) {
+            int2 v = make_int2(0, -1);
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a) v = (a == Att + k) ? act_in[a] : v;
+            const int idx = v.x, act = v.y;
+            const bool bad_target = act == 0 && (idx < 0 || idx >= N);
+            const bool move = act == 0 && !bad_target;
+            const bool patch = act == -2 && loc[k] != -1 && !bad_target;
+#pragma unroll
+            for (int n = 0; n < NMAX; ++n) patch_set[n] |= (patch && loc[k] == n) ? (1u << k) : 0u;
+            const float pr = patch ? d.patch_reward : 0.0f;
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a) rew[a] = (a == Att + k) ? rew[a] + pr : rew[a];
+            loc[k] = move ? idx : loc[k];
+            last[k] = bad_target ? last[k] : act;
+        }
+    }
+    __syncthreads();  // (2) draws ready
+    // ------------------------------------------------- presence (transitions/presence.py:46-58), same draw for both tests
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) {
+        if (a < A) {
+            const float u = s_draw[NMAX + a][tid];
+            const bool ret = !pres[a] && u < d.back[a];
+            const bool leave = pres[a] && u >= d.persist[a];
+            pres[a] = ret ? true : (leave ? false : pres[a]);
+#pragma unroll
+            for (int k = 0; k < AMAX; ++k) loc[k] = (ret && a == Att + k) ? -1 : loc[k];
+        }
+    }
+    // ------------------------------------------------- subnetwork transition (transitions/subnetwork.py:53-70)
+    float net_reward = 0.0f;
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) {
+        if (n < N) {
+            const uint32_t index = (patch_set[n] << Att) | attack_set[n];
+            const float danger = s_lut[index];
+            bool better = danger > 0.0f, worse = danger < 0.0f;
+            if (flags & kStochState) {
+                const bool gate = fabsf(danger) <= s_draw[n][tid];
+                better = better && gate;
+                worse = worse && gate;
+            }
+            int s = state[n] - (better ? 1 : 0) + (worse ? 1 : 0);
+            s = s < 0 ? 0 : (s > d.S - 1 ? d.S - 1 : s);
+            state[n] = s;
+            net_reward = __fadd_rn(net_reward, __fmul_rn(cfg_lds->state_rewards[s], (float)d.criticality[n]));
+        }
+    }
+    uint32_t pres_bits = 0;
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) pres_bits |= pres[a] ? (1u << a) : 0u;
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) s_post[n][tid] = state[n];
+#pragma unroll
+    for (int k = 0; k < AMAX; ++k) {
+        s_post[NMAX + k][tid] = loc[k];
+        s_post[NMAX + AMAX + k][tid] = last[k];
+    }
+    s_post[NMAX + 2 * AMAX][tid] = (int)pres_bits;
+    __syncthreads();  // (3) post-transition state ready
+    nm += 1;
+    trunc = (flags & kTruncate) ? nm >= d.max_steps : trunc;
+
+    uint32_t cnt[AMAX], excl[AMAX];
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) cnt[a] = (active && a < A && pres[a]) ? 1u : 0u;
+    if (active) {
+#pragma unroll
+        for (int n = 0; n < NMAX; ++n)
+            if (n < N) at32(rows, (uint32_t)(d.r_state + n) * Bu + bl) = state[n];
+#pragma unroll
+        for (int k = 0; k < AMAX; ++k)
+            if (k < D) {
+                at32(rows, (uint32_t)(d.r_loc + k) * Bu + bl) = loc[k];
+                at32(rows, (uint32_t)(d.r_last + k) * Bu + bl) = last[k];
+            }
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a)
+            if (a < A) {
+                const float r = a < Att ? __fadd_rn(rew[a], __fmul_rn(net_reward, -1.0f)) : __fadd_rn(rew[a], net_reward);
+                at32(rows1, (uint32_t)(d.u_presence + a) * Bu + bl) = (uint8_t)pres[a];
+                at32(rowsf, (uint32_t)(d.r_rewards + a) * Bu + bl) = r;
+                if (flags & kTruncate) at32(rows1, (uint32_t)(d.u_trunc + a) * Bu + bl) = (uint8_t)trunc;
+                if (flags & kTrackCumulative) at32(rowsf, (uint32_t)(d.r_cum + a) * Bu + bl) = __fadd_rn(cum_in[a], r);
+                at32(rows, (uint32_t)(d.r_atc + a) * Bu + bl) = pres[a] ? N : 0;
+            }
+        at32(rows, (uint32_t)d.r_moves * Bu + bl) = nm;
+    }
+    frz::scan_chunk<AMAX>(s_scan, ws, launch, cnt, active, active && !trunc, A, chunk, nchunks, excl, &err);
+    if (active) {  // action mapping: arange(N) while present, empty otherwise (:441-457)
+        int32_t* const act_values = reinterpret_cast<int32_t*>(arena + d.off_act_values);
+        int64_t* const act_offsets = reinterpret_cast<int64_t*>(arena + d.off_act_offsets);
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a) {
+            if (a < A) {
+                const int64_t off = (int64_t)excl[a] * N;
+                act_offsets[a * (B + 1) + b] = off;
+                if (b == B - 1) act_offsets[a * (B + 1) + B] = off + (pres[a] ? N : 0);
+                if (pres[a]) {
+                    int32_t* v = act_values + a * B * N + off;
+#pragma unroll
+                    for (int n = 0; n < NMAX; ++n)
+                        if (n < N) v[n] = n;
+                }
+            }
+        }
+    }
+    if (err) atomicOr(reinterpret_cast<uint32_t*>(arena + d.off_error), err);
+    frz::scan_end(ws, launch, chunk, nchunks);
+}
+
+
 // uniform member of each agent's OneOf action space (spaces/actions.py:11-99), see oracle/frz_oracle_cybersecurity.c
 __global__ void __launch_bounds__(kBlock) cy_policy_kernel(const char* arena, uint32_t seed_lo, uint32_t seed_hi, uint32_t step_lo,
                                                              uint32_t step_hi, int32_t* actions) {
@@ -577,6 +1022,7 @@ struct frz_cybersecurity_env {
     bool was_reset = false;
     bool ticketed = false;  // more chunks than CUs: chunks are handed out in arrival order (frz_scan.h)
     int variant = 0;
+    bool roles = false;  // steps run cy_roles_kernel (shapes up to 8 nodes / 8 agents, unless FRZ_CY_KERNEL=lane)
 };
 
 namespace {
@@ -601,7 +1047,19 @@ void launch_variant(frz_cybersecurity_env* env, const int32_t* actions, const fl
     const CyDev& p = env->dev;
     const CyLaunch L{p.B, p.N, p.Att, p.D, p.A, env->ticketed ? 1u : 0u, p.off_rows1, p.off_epoch, p.off_totals, policy.on ? 1u : 0u,
                      (uint32_t)policy.seed, (uint32_t)(policy.seed >> 32), (uint32_t)policy.step, (uint32_t)(policy.step >> 32), policy.actions_out,
-                     p.off_mt_state};
+                     p.off_mt_state, p.off_lut, p.lut_entries};
+    if constexpr (NMAX <= 8) {
+        if (mode == kStep && env->roles) {  // state / view roles: two wavefronts per 64 envs (cy_roles_kernel)
+            const dim3 wide(kRoleBlock);
+            if (rng == FRZ_RNG_PHILOX)
+                hipLaunchKernelGGL((cy_roles_kernel<NMAX, AMAX, ATT, FRZ_RNG_PHILOX>), grid, wide, 0, stream, env->arena, dev, actions, nr, ar, L);
+            else if (rng == FRZ_RNG_MT19937)
+                hipLaunchKernelGGL((cy_roles_kernel<NMAX, AMAX, ATT, FRZ_RNG_MT19937>), grid, wide, 0, stream, env->arena, dev, actions, nr, ar, L);
+            else
+                hipLaunchKernelGGL((cy_roles_kernel<NMAX, AMAX, ATT, FRZ_RNG_INJECTED>), grid, wide, 0, stream, env->arena, dev, actions, nr, ar, L);
+            return;
+        }
+    }
     if (mode == kRebuild)
         hipLaunchKernelGGL((cy_step_kernel<NMAX, AMAX, ATT, FRZ_RNG_INJECTED, kRebuild>), grid, block, 0, stream, env->arena, dev, actions, nr, ar, L);
     else if (rng == FRZ_RNG_PHILOX)
@@ -645,6 +1103,8 @@ int frz_cybersecurity_create(const frz_cybersecurity_cfg* cfg, frz_cybersecurity
     env->cfg = *cfg;
     env->variant = (N <= 4 && A <= 4) ? 0 : ((N <= 8 && A <= 8) ? 1 : 2);
     if (N == 3 && Att == 2 && D == 2) env->variant = 3;  // the reference's own test / competition shape gets an exact instantiation
+    const char* family = std::getenv("FRZ_CY_KERNEL");
+    env->roles = env->variant != 2 && !(family && std::strcmp(family, "lane") == 0);
     CyDev& p = env->dev;
     std::memset(&p, 0, sizeof(p));
     const int64_t B = cfg->parallel_envs;

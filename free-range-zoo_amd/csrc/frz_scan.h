@@ -76,7 +76,8 @@ __device__ __forceinline__ void scan_chunk(ScanShared<NCH, BITS>& sh, const Scan
     constexpr int PW = (NCH + PER - 1) / PER;
     constexpr int NCHP = NCH + 2 <= 8 ? 8 : (NCH + 2 <= 16 ? 16 : 32);
     static_assert(NCH + 2 <= 32, "too many scan channels");
-    const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+    // (role-split kernels call this from the first kBlock threads of a larger workgroup while the others run scan_chunk_passive)
+    const int tid = threadIdx.x & (kBlock - 1), lane = lane_id(), wave = wave_id() & (kWaves - 1);
     const int nch_total = nch + 2;
 
     uint64_t packed[PW], incl[PW];
@@ -178,6 +179,16 @@ __device__ __forceinline__ void scan_chunk(ScanShared<NCH, BITS>& sh, const Scan
         const int w = ch / PER, shf = BITS * (ch % PER);
         excl[ch] = sh.prefix[ch] + (uint32_t)(((base[w] + incl[w] - packed[w]) >> shf) & FIELD);
     }
+}
+
+// The wavefronts of a role-split workgroup that do not scan: scan_chunk's four workgroup barriers, nothing else
+__device__ __forceinline__ void scan_chunk_passive_front() {
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
+}
+__device__ __forceinline__ void scan_chunk_passive_back() {
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
 }
 
 // The workgroup that owns the last chunk finished its look-back only after every other chunk published, i.e. after
