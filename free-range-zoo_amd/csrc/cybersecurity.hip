@@ -65,6 +65,8 @@ struct CyLaunch {
     int32_t lut_entries;
 };
 
+// (plain stores: written through, frz_device.h, the rows of this kernel gained nothing — 11.4 vs 11.3 us — most of its bytes are
+// record-strided observation rows that need the L2 to merge them)
 template <typename T>
 __device__ __forceinline__ T& at32(T* base, uint32_t index) {
     return *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + (uint64_t)(index * (uint32_t)sizeof(T)));

@@ -109,6 +109,47 @@ __device__ __forceinline__ uint32_t granule_wait(const uint64_t* slot, uint32_t 
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Write-through stores.  A plain store leaves its line dirty in the XCD's L2 and the end-of-kernel release writes all
+// of them back at once: for a step launch that writes ~20 MB in its last microseconds that tail is on the critical path
+// of the next launch.  A store marked sc0 sc1 goes through to memory as it is issued (the line stays valid in L2 for
+// the next step's loads), so the write-back is spread over the kernel: 10.6 -> 9.9 us per launch on the wildfire bench
+// kernel.  Worth it only where a wavefront writes WHOLE lines ([rows][B] rows, offsets arrays): record-strided stores
+// (16-byte pieces of different lines per lane) need the L2 to merge them and get slower (cybersecurity task rows:
+// 11.3 -> 13.7 us when they were written through too).  A relaxed system-scope atomic store is exactly such a store
+// to the compiler (same instruction, sc0 sc1 set, no fence, its vmcnt bookkeeping intact).
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void store_through(T* p, T v) {
+    static_assert(sizeof(T) == 1 || sizeof(T) == 2 || sizeof(T) == 4 || sizeof(T) == 8, "one store instruction");
+    if constexpr (sizeof(T) == 1)
+        __hip_atomic_store(reinterpret_cast<uint8_t*>(p), __builtin_bit_cast(uint8_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else if constexpr (sizeof(T) == 2)
+        __hip_atomic_store(reinterpret_cast<uint16_t*>(p), __builtin_bit_cast(uint16_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else if constexpr (sizeof(T) == 4)
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(p), __builtin_bit_cast(uint32_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else
+        __hip_atomic_store(reinterpret_cast<uint64_t*>(p), __builtin_bit_cast(uint64_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// An element of a [rows][B] row: reads like a T, assignment is a write-through store
+template <typename T>
+struct RowRef {
+    T* p;
+    __device__ __forceinline__ operator T() const { return *p; }
+    __device__ __forceinline__ const RowRef& operator=(T v) const {
+        store_through(p, v);
+        return *this;
+    }
+    __device__ __forceinline__ const RowRef& operator=(const RowRef& o) const { return *this = (T)o; }
+    __device__ __forceinline__ const RowRef& operator+=(T v) const { return *this = (T)(*p + v); }
+};
+template <typename T>
+struct RowRef<const T> {
+    const T* p;
+    __device__ __forceinline__ operator T() const { return *p; }
+};
+
 // mt19937.hip: frz_mt19937_generate_pair gated on an env object's batch totals (host-callable; see the definition)
 int mt19937_generate_pair_gated(uint32_t* mt_state, int32_t* mt_index, float* out, int64_t events, int64_t count, float* out2, int64_t events2,
                                 int64_t count2, int64_t B, const uint32_t* epoch, const uint32_t* totals, int channel, int stride, void* stream);

@@ -152,10 +152,12 @@ __device__ __forceinline__ WfHot stage_commit(WfStaged& lds, const uint4& piece)
     return lds;
 }
 
-// 4-byte row access with a 32-bit element index: lets the compiler address as (uniform base) + (32-bit lane offset)
+// row access with a 32-bit element index: lets the compiler address as (uniform base) + (32-bit lane offset); assignment through the
+// result is a write-through store (frz_device.h: a wavefront writes whole lines of a [rows][B] row)
 template <typename T>
-__device__ __forceinline__ T& at32(T* base, uint32_t index) {
-    return *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + (uint64_t)(index * (uint32_t)sizeof(T)));
+__device__ __forceinline__ frz::RowRef<T> at32(T* base, uint32_t index) {
+    using Byte = std::conditional_t<std::is_const_v<T>, const char, char>;
+    return frz::RowRef<T>{reinterpret_cast<T*>(reinterpret_cast<Byte*>(base) + (uint64_t)(index * (uint32_t)sizeof(T)))};
 }
 
 __device__ __forceinline__ float clamp01(float p) {

@@ -354,12 +354,12 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
         int64_t* const bad_offsets = reinterpret_cast<int64_t*>(arena + d.off_bad_offsets);
         const bool show_bad = (flags_word & kShowBad) != 0;
         const int F = popc(lit1), fa = popc(ok);
-        act_offsets[a * (B + 1) + b] = off_a;
+        frz::store_through(&act_offsets[a * (B + 1) + b], off_a);  // offsets rows are whole lines per wavefront
         if (b == B - 1) act_offsets[a * (B + 1) + B] = off_a + fa;
         int64_t* av = act_values + a * cap + off_a;
         int64_t* bv = bad_values + a * cap + (off_f - off_a);  // bad = listed but not attackable
         if (show_bad) {
-            bad_offsets[a * (B + 1) + b] = off_f - off_a;
+            frz::store_through(&bad_offsets[a * (B + 1) + b], off_f - off_a);
             if (b == B - 1) bad_offsets[a * (B + 1) + B] = (off_f - off_a) + (F - fa);
         }
 #pragma unroll
@@ -597,7 +597,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                         if (whole)
                             reinterpret_cast<float4*>(obs_self)[a * B + bl] = make_float4((float)d.ay[a], (float)d.ax[a], d.power[a], supp[a]);
                         else
-                            obs_self[(a * B + bl) * 4 + 3] = supp[a];
+                            frz::store_through(&obs_self[(a * B + bl) * 4 + 3], supp[a]);
                         float* const others = obs_others + (a * B + bl) * (int64_t)width;
                         int j = 0;  // record index: the other agents in agent order
 #pragma unroll
@@ -616,7 +616,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                                         *reinterpret_cast<float2*>(rec) = make_float2(y, x);
                                     }
                                 } else if (os) {
-                                    rec[k - 1] = supp[o];  // the suppressant column is the last one
+                                    frz::store_through(&rec[k - 1], supp[o]);  // the suppressant column is the last one
                                 }
                                 ++j;
                             }
@@ -642,7 +642,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                 int64_t* const task_values = reinterpret_cast<int64_t*>(arena + d.off_task_values);
                 int64_t* const task_offsets = reinterpret_cast<int64_t*>(arena + d.off_task_offsets);
                 int64_t* const obs_map = reinterpret_cast<int64_t*>(arena + d.off_obs_map);
-                task_offsets[b] = off_f;
+                frz::store_through(&task_offsets[b], off_f);
                 if (b == B - 1) task_offsets[B] = off_f + popc(lit1);
                 // row of cell c's task inside the env's segment = number of lit cells below it
                 int64_t* const trow = task_values + off_f * 4;
@@ -720,7 +720,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                             const int j = (int)(((uint64_t)policy_block[a >> 2].w[a & 3] * (uint64_t)(n + 1)) >> 32);
                             act_idx = j < n ? j : n;
                             act_id = j < n ? 0 : -1;
-                            reinterpret_cast<int2*>(launch.actions_out)[a * B + bl] = make_int2(act_idx, act_id);
+                            frz::store_through(&reinterpret_cast<int2*>(launch.actions_out)[a * B + bl], make_int2(act_idx, act_id));
                         }
                         refill[a] = act_id == -1;
                         // quirk wildfire.py:434-435: an agent with no attackable task in ANY env of the batch is skipped
