@@ -136,7 +136,7 @@ class raw_env(BatchedParallelEnv):
     def _materialize(self) -> None:
         B, A, N, Att = self.parallel_envs, len(self.agents), self._N, self._Att
         if self.exact_shapes:
-            totals = self._act_map_offsets[:, -1].tolist()  # one small device->host read per step
+            totals = self._host_read(self._act_map_offsets[:, -1])  # one small device->host read per step
             act_maps = [jagged(self._act_map_values[a, :totals[a]], self._act_map_offsets[a], max_seqlen=N if totals[a] else 0)
                         for a in range(A)]
         elif getattr(self, '_static_views', None) is None:

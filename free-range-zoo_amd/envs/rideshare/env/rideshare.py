@@ -154,8 +154,8 @@ class raw_env(BatchedParallelEnv):
     def _materialize(self) -> None:
         B, A, P = self.parallel_envs, len(self.agents), self._P
         if self.exact_shapes:
-            stats = torch.cat([self._task_offsets[-1:], self._agent_offsets[:, -1], self.environment_task_count.max().reshape(1),
-                               self.agent_task_count.max(dim=1).values.to(torch.int64)]).tolist()
+            stats = self._host_read(torch.cat([self._task_offsets[-1:], self._agent_offsets[:, -1], self.environment_task_count.max().reshape(1),
+                                               self.agent_task_count.max(dim=1).values.to(torch.int64)]))
             total, totals, most, mosts = stats[0], stats[1:1 + A], stats[1 + A], stats[2 + A:]
             task_store = jagged(self._task_values[:total], self._task_offsets, max_seqlen=most)
             tasks = [jagged(self._agent_task_values[a, :totals[a]], self._agent_offsets[a], max_seqlen=mosts[a]) for a in range(A)]

@@ -158,7 +158,7 @@ class raw_env(BatchedParallelEnv):
             if self.show_bad_actions:
                 bad = self.environment_task_count.unsqueeze(0) - self.agent_task_count
                 stats = torch.cat([stats, self._bad_map_offsets[:, -1], bad.max(dim=1).values])
-            stats = stats.tolist()
+            stats = self._host_read(stats)
             total_f, total_a, max_f, max_a = stats[0], stats[1:1 + A], stats[1 + A], stats[2 + A:2 + 2 * A]
             tasks = jagged(self._task_values[:total_f], self._task_offsets, max_seqlen=max_f)
             obs_map = jagged(self._obs_map_values[:total_f], self._task_offsets, max_seqlen=max_f)

@@ -225,6 +225,17 @@ class BatchedParallelEnv:
             symbol = f'frz_{self._domain}_{entry}'
             _capi.check(getattr(self._lib, symbol)(self._handle, *c_args, stream_ptr(self.device)), symbol)
 
+    def _host_read(self, stats: torch.Tensor) -> list:
+        """The one small device->host read of an exact-shapes publication: ``stats`` (int64 list lengths) and, in the same copy, the
+        device error word — a prefix hand-off that timed out (FRZ_ERR_SCAN_TIMEOUT: another stream or process kept part of a launch
+        from becoming resident) means the jagged offsets about to be used are wrong, so it is raised here rather than left for
+        ``check()``.  Invalid-action bits stay for ``check()`` (sync-free contract of ``step``)."""
+        values = torch.cat([stats.to(torch.int64), self._error_flags.to(torch.int64)]).tolist()
+        if values[-1] & _capi.DEFINES['FRZ_ERR_SCAN_TIMEOUT']:
+            raise RuntimeError('device-side prefix hand-off timed out (FRZ_ERR_SCAN_TIMEOUT): the jagged outputs of this step are invalid; '
+                               'is another stream or process occupying the GPU?')
+        return values[:-1]
+
     def _check_errors(self) -> None:
         """Raise the data-dependent errors the kernels flagged (reads one word from the device)."""
         flags = int(self._error_flags.item())
