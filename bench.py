@@ -188,7 +188,7 @@ def secondary_workloads(device, B):
             N = env.network_config.num_nodes
             Att, D = env.attacker_config.num_attackers, env.defender_config.num_defenders
             per_env = cybersecurity_bytes_per_env_step(N, Att, D, mean_agents / N)
-            kernels = 'cy_step_kernel (policy sampled in the launch)'
+            kernels = 'cy_roles_kernel (state + view roles, policy sampled in the launch)'
             counts = {'mean_present_agents_per_env': mean_agents / N}
         else:
             per_env = rideshare_bytes_per_env_step(A, mean_env, mean_agents)

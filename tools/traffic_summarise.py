@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 from bench import source_fingerprint
 
 src, tag = sys.argv[1], sys.argv[2]
-STEP_KERNELS = {'wildfire': ('wf_roles_kernel', ), 'cybersecurity': ('cy_step_kernel', ), 'rideshare': ('rs_env_kernel', 'rs_offsets_kernel', 'rs_emit_kernel')}
+STEP_KERNELS = {'wildfire': ('wf_roles_kernel', ), 'cybersecurity': ('cy_roles_kernel', ), 'rideshare': ('rs_env_kernel', 'rs_offsets_kernel', 'rs_emit_kernel')}
 
 
 def per_step(domain, counter):
