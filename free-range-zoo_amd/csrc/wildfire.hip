@@ -922,7 +922,8 @@ struct frz_wildfire_env {
     WfDev dev;
     char* arena = nullptr;
     bool was_reset = false;
-    int variant = 0;  // index into the (CMAX, AMAX) instantiation table
+    int variant = 0;       // index into the (CMAX, AMAX) instantiation table
+    int lane_variant = 0;  // the first runtime-shape entry that holds the shape (what the lane-per-env kernel runs)
     // set for the duration of one frz_wildfire_step_random_policy call
     bool fused_policy = false;
     uint64_t policy_seed = 0, policy_step = 0;
@@ -986,11 +987,17 @@ void launch_variant(const WfArgs& args, int grid, int rng, int mode, hipStream_t
     }
 }
 
+// The lane-per-env kernel is instantiated for the runtime-shape entries of the list only: every exact shape has a field/crew kernel
+// (wildfire_roles.hip), and with FRZ_WF_KERNEL=lane such a shape runs the smallest runtime-shape instantiation that holds it
+// (env->lane_variant) — the cross-check the parity tests want, at a third of this file's build time and code size.
 int launch_lane(frz_wildfire_env* env, const WfArgs& args, int rng, int mode, hipStream_t stream) {
     const int grid = env->dev.nchunks;  // one workgroup per chunk
-    switch (env->variant) {
-#define FRZ_X(i, c, a, e) \
-    case i: launch_variant<c, a, e>(args, grid, rng, mode, stream); break;
+    switch (env->lane_variant) {
+#define FRZ_X(i, c, a, e)                                                          \
+    case i:                                                                        \
+        if constexpr (!e) launch_variant<c, a, e>(args, grid, rng, mode, stream); \
+        else return FRZ_E_INVALID;                                                 \
+        break;
         FRZ_WF_VARIANT_LIST(FRZ_X)
 #undef FRZ_X
         default: return FRZ_E_INVALID;
@@ -1217,6 +1224,14 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
         const Variant& v = kVariants[i];
         if (v.exact ? (HW == v.cmax && A == v.amax) : (HW <= v.cmax && A <= v.amax)) {
             env->variant = i;
+            break;
+        }
+    }
+    env->lane_variant = kNumVariants - 1;
+    for (int i = 0; i < kNumVariants; ++i) {
+        const Variant& v = kVariants[i];
+        if (!v.exact && HW <= v.cmax && A <= v.amax) {
+            env->lane_variant = i;
             break;
         }
     }
