@@ -124,9 +124,6 @@ class BatchedParallelEnv:
             raise ValueError('free_range_zoo_amd environments run on a GPU device only (device="cuda"); there is no CPU path')
         if device.index is None:
             device = torch.device('cuda', torch.cuda.current_device())
-        if log_directory is not None and log_directory.startswith(('sqlite://', 'postgresql://')):
-            raise NotImplementedError('the SQL logger of the reference (utils/logging_handlers.py:117-241) is not built; '
-                                      'pass a directory for the CSV logging tap')
         if rng not in ('mt19937', 'philox'):
             raise ValueError("rng must be 'mt19937' or 'philox'")
         self.parallel_envs = parallel_envs
@@ -140,10 +137,13 @@ class BatchedParallelEnv:
         self.exact_shapes = exact_shapes
         self.log_description = None
         self.logger = None
-        if log_directory is not None:  # env.py:65-85 (CSV case); rows are written by a background thread, off the step path
-            from free_range_zoo_amd.utils.logging_handlers import CSVLogger
-            self.logger = CSVLogger(log_directory=log_directory, parallel_envs=parallel_envs,
-                                    override_initialization_check=override_initialization_check)
+        if log_directory is not None:  # env.py:65-85; rows are written by a background thread, off the step path
+            from free_range_zoo_amd.utils.logging_handlers import CSVLogger, SQLLogger
+            if log_directory.startswith(('sqlite://', 'postgresql://')):
+                self.logger = SQLLogger(connection_string=log_directory, domain=f'{self._domain}_v0', parallel_envs=parallel_envs)
+            else:
+                self.logger = CSVLogger(log_directory=log_directory, parallel_envs=parallel_envs,
+                                        override_initialization_check=override_initialization_check)
         if configuration is not None:
             self.config = configuration.to(device)
             for key, value in vars(configuration).items():  # nested configurations become attributes (env.py:58-63)
@@ -254,7 +254,7 @@ class BatchedParallelEnv:
         self._log_label = options.get('log_label') if options else None
         self.log_description = options.get('log_description') if options and options.get('log_description') else None
         if self.logger is not None:  # env.py:140-143: the logger starts new files on every reset
-            self.logger.reset(log_label=self._log_label, log_description=self.log_description)
+            self.logger.reset(log_label=self._log_label, log_description=self.log_description, agents=self.possible_agents)
 
     def _stage_actions(self, actions: Dict[str, torch.Tensor]) -> None:
         """``{agent: [B, 2]}`` -> the stacked int32 ``[A, B, 2]`` buffer the kernels read: one launch when the tensors already are

@@ -95,21 +95,80 @@ def test_csv_logger_refuses_a_used_directory_and_reports_writer_failures(tmp_pat
         log.flush()
 
 
-def test_sql_connection_strings_are_refused_before_anything_else():
-    from free_range_zoo_amd.envs import wildfire_v0
-    if torch.cuda.is_available():
-        with pytest.raises(NotImplementedError):
-            wildfire_v0.parallel_env(configuration=configs.wildfire_openness(), parallel_envs=2, max_steps=3, log_directory='sqlite:///x.db')
+SQL_TABLES = ('simulation', 'environment', 'agent', 'environment_timestep', 'wildfire_environment_log', 'rideshare_environment_log',
+              'cybersecurity_environment_log', 'agent_log')
+
+
+def dump_sqlite(path):
+    """Same dump as tools/refharness/make_golden.py made of the reference's database: every table in id order, without the run date."""
+    import sqlite3
+    con = sqlite3.connect(path)
+    out = {}
+    for table in SQL_TABLES:
+        cur = con.execute(f'SELECT * FROM {table} ORDER BY id')
+        columns = [c[0] for c in cur.description]
+        rows = [list(r) for r in cur.fetchall()]
+        if table == 'simulation':
+            keep = [i for i, c in enumerate(columns) if c != 'timestamp']
+            columns, rows = [columns[i] for i in keep], [[r[i] for i in keep] for r in rows]
+        out[table] = {'columns': columns, 'rows': rows}
+    con.close()
+    return out
+
+
+@pytest.mark.parametrize('asynchronous', [False, True])
+def test_sql_logger_tables(tmp_path, asynchronous):
+    """SQLLogger on host tensors: the schema of the reference (utils/sql_logging.py:12-118) and its per-table row order
+    (logging_handlers.py:132-241)."""
+    from free_range_zoo_amd.utils.logging_handlers import SQLLogger
+    B, agents = 2, ['attacker_1', 'defender_1']
+    path = tmp_path / 'log.db'
+    log = SQLLogger(f'sqlite:///{path}', 'cybersecurity_v0', B, asynchronous=asynchronous)
+    maps = {a: torch.nested.nested_tensor([torch.tensor([0, 2]), torch.tensor([], dtype=torch.int64)], layout=torch.jagged) for a in agents}
+    obs_maps = {a: torch.arange(3).repeat(B, 1, 1) for a in agents}
+    extra = {'adj_matrix': ['[[0, 1], [1, 0]]'] * B}
+    with pytest.raises(RuntimeError):  # logging_handlers.py:175-176
+        log.log_environment(_toy_state(B, 1), None, None, maps, obs_maps, torch.zeros(B, dtype=torch.int32), None, None, agents, extra=extra, reset=True)
+    log.reset(log_label='demo', log_description='two envs', agents=agents)
+    log.log_environment(_toy_state(B, 1), None, None, maps, obs_maps, torch.zeros(B, dtype=torch.int32), None, None, agents, extra=extra, reset=True)
+    later = agents + ['defender_2']
+    maps['defender_2'], obs_maps['defender_2'] = maps['defender_1'], obs_maps['defender_1']
+    actions = {a: torch.tensor([[1, 0], [2, -1]], dtype=torch.int32) for a in later}
+    rewards = {a: torch.tensor([0.5, -1.25]) for a in later}
+    log.log_environment(_toy_state(B, 2), actions, rewards, maps, obs_maps, torch.tensor([1, 1]), torch.tensor([False, True]), None, later,
+                        extra=extra)
+    log.close()
+    t = dump_sqlite(str(path))
+    assert t['simulation'] == {'columns': ['id', 'name', 'description'], 'rows': [[1, 'demo', 'two envs']]}
+    assert t['environment']['rows'] == [[1, 1, 0], [2, 1, 1]]
+    # agent-major at reset; an agent that appears later joins env by env
+    assert t['agent']['rows'] == [[1, 1, 'attacker_1'], [2, 2, 'attacker_1'], [3, 1, 'defender_1'], [4, 2, 'defender_1'], [5, 1, 'defender_2'],
+                                  [6, 2, 'defender_2']]
+    assert t['environment_timestep']['columns'] == ['environment_id', 'id', 'timestep']
+    assert t['environment_timestep']['rows'] == [[1, 1, 0], [2, 2, 0], [1, 3, 1], [2, 4, 1]]
+    assert t['cybersecurity_environment_log']['rows'][2] == [3, 3, '[2, 2, 2]', '[0]', '[True, True]', '[[0, 1], [1, 0]]']
+    assert t['wildfire_environment_log']['rows'] == [] and t['rideshare_environment_log']['rows'] == []
+    # no agent rows for the reset log; rewards are stored truncated (logging_handlers.py:228), env-major then agent
+    assert t['agent_log']['rows'][0] == [1, 3, 1, 0, 0, 1, '[0, 2]', '[[0, 1, 2]]']
+    assert t['agent_log']['rows'][3] == [4, 4, 2, -1, -1, 2, '[]', '[[0, 1, 2]]']
+    assert [r[2] for r in t['agent_log']['rows']] == [1, 3, 5, 2, 4, 6]
+
+
+def test_sql_logger_rejects_unknown_domains(tmp_path):
+    from free_range_zoo_amd.utils.logging_handlers import SQLLogger
+    with pytest.raises(NotImplementedError):
+        SQLLogger(f'sqlite:///{tmp_path / "x.db"}', 'chess_v0', 2)
 
 
 # ------------------------------------------------------------------------------------------------------------------
 # the envs' files against the reference's
 # ------------------------------------------------------------------------------------------------------------------
-def _replay(domain, tmp_path, stacked=False):
+def _replay(domain, tmp_path, stacked=False, sql=False):
     logs = np.load(G.golden_path('logs_csv.npz'))
     name = str(logs[f'{domain}_name'])
     data = np.load(G.golden_path(f'traj_{domain}_{name}.npz'))
     directory = str(tmp_path / domain)
+    target = f'sqlite:///{directory}.db' if sql else directory
     if domain == 'wildfire':
         from test_hip_wildfire import make_env
         from free_range_zoo_amd import _capi
@@ -131,8 +190,8 @@ def _replay(domain, tmp_path, stacked=False):
         cfg = G.load_cfg(data, _capi.frz_rideshare_cfg)
         shapes = keys = None
     B = cfg.parallel_envs
-    env = make_env(build, B, None if cfg.max_steps < 0 else cfg.max_steps, log_directory=directory, **kwargs)
-    env.reset(seed=torch.arange(B, dtype=torch.int32), options={'log_description': f'golden {name}'})
+    env = make_env(build, B, None if cfg.max_steps < 0 else cfg.max_steps, log_directory=target, **kwargs)
+    env.reset(seed=torch.arange(B, dtype=torch.int32), options={'log_description': f'golden {name}', 'log_label': f'run {name}'})
     for t in range(int(data['steps'])):
         p = f's{t}_'
         actions = {agent: torch.from_numpy(data[p + 'actions'][a]).cuda() for a, agent in enumerate(env.agents)}
@@ -146,6 +205,8 @@ def _replay(domain, tmp_path, stacked=False):
             env.step(actions, randomness=rnd)
     env.check()
     env.close()
+    if sql:
+        return f'{directory}.db'
     want = logs[domain]
     assert sorted(os.listdir(directory)) == sorted(f'{i}.csv' for i in range(B))
     for i in range(B):
@@ -157,6 +218,22 @@ def _replay(domain, tmp_path, stacked=False):
 @pytest.mark.parametrize('domain', ['wildfire', 'cybersecurity', 'rideshare'])
 def test_env_logs_equal_the_reference_files(domain, tmp_path):
     _replay(domain, tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('domain', ['wildfire', 'cybersecurity', 'rideshare'])
+def test_env_sql_logs_equal_the_reference_database(domain, tmp_path):
+    """log_directory='sqlite:///...': table by table the database the reference's SQLLogger wrote along the same trajectory
+    (tests/golden/logs_sql.npz, tools/refharness/make_golden.py logs_sql)."""
+    import json
+    path = _replay(domain, tmp_path, sql=True)
+    want = json.loads(str(np.load(G.golden_path('logs_sql.npz'))[domain]))
+    got = dump_sqlite(path)
+    for table in SQL_TABLES:
+        assert got[table]['columns'] == want[table]['columns'], table
+        assert len(got[table]['rows']) == len(want[table]['rows']), f'{domain} {table}: {len(got[table]["rows"])} rows, reference wrote {len(want[table]["rows"])}'
+        for r, (g, w) in enumerate(zip(got[table]['rows'], want[table]['rows'])):
+            assert g == w, f'{domain} {table} row {r}: {g} != {w}'
 
 
 @pytest.mark.gpu

@@ -880,6 +880,80 @@ def record_logs():
 
 
 # ----------------------------------------------------------------------------------------------------------
+# SQL logs: what utils/logging_handlers.py:SQLLogger leaves in a sqlite database along the same trajectories
+# ----------------------------------------------------------------------------------------------------------
+SQL_TABLES = ('simulation', 'environment', 'agent', 'environment_timestep', 'wildfire_environment_log', 'rideshare_environment_log',
+              'cybersecurity_environment_log', 'agent_log')
+
+
+def dump_sqlite(path):
+    """Every table of the logging schema as {'table': {'columns': [...], 'rows': [[...], ...]}} (rows in id order; the simulation
+    table's date column is left out: it is the day of the run)."""
+    import sqlite3
+    con = sqlite3.connect(path)
+    out = {}
+    for table in SQL_TABLES:
+        cur = con.execute(f'SELECT * FROM {table} ORDER BY id')
+        columns = [c[0] for c in cur.description]
+        rows = [list(r) for r in cur.fetchall()]
+        if table == 'simulation':
+            keep = [i for i, c in enumerate(columns) if c != 'timestamp']
+            columns, rows = [columns[i] for i in keep], [[r[i] for i in keep] for r in rows]
+        out[table] = {'columns': columns, 'rows': rows}
+    con.close()
+    return out
+
+
+def record_sql_logs():
+    """The golden trajectories of record_logs() re-run with log_directory='sqlite:///...' (same seeds, hence same actions and injected
+    randomness) and the database the reference's SQLLogger wrote dumped table by table — output data of the reference."""
+    import json
+    import tempfile
+    from free_range_zoo.envs import wildfire_v0, rideshare_v0, cybersecurity_v0
+
+    def run(module, name, B, max_steps, steps, seed, configuration, flags, policy, inject):
+        handle, path = tempfile.mkstemp(prefix='frz_refsql_', suffix='.db')
+        os.close(handle)
+        os.remove(path)
+        env = module.parallel_env(parallel_envs=B, max_steps=max_steps, configuration=configuration, device=torch.device('cpu'),
+                                  log_directory=f'sqlite:///{path}', **flags)
+        env.reset(seed=torch.arange(B, dtype=torch.int32), options={'log_description': f'golden {name}', 'log_label': f'run {name}'})
+        if inject:
+            env.aec_env.generator.generate = InjectedRandomness(seed)
+        rng = np.random.default_rng(seed)
+        agents = list(env.aec_env.agents)
+        for t in range(steps):
+            actions = policy(env.aec_env, rng)
+            env.step({agent: torch.from_numpy(actions[a]) for a, agent in enumerate(agents)})
+        env.aec_env.logger.session.close()
+        tables = dump_sqlite(path)
+        os.remove(path)
+        return np.asarray(json.dumps(tables))
+
+    out = {}
+    v = {x[0]: x for x in wildfire_variants()}['rich_localized']
+    flags = dict(show_bad_actions=False, observe_other_power=False, observe_other_suppressant=False)
+    flags.update(v[2])
+    out['wildfire_name'] = np.asarray(v[0])
+    out['wildfire'] = run(wildfire_v0, v[0], v[3], v[4], v[5], v[6], v[1], flags, wildfire_policy, True)
+    v = {x[0]: x for x in cyber_variants()}['rich']
+    flags = dict(observe_other_location=False, observe_other_presence=False, observe_other_power=True, partially_observable=True,
+                 show_bad_actions=True)
+    flags.update(v[2])
+    out['cybersecurity_name'] = np.asarray(v[0])
+    out['cybersecurity'] = run(cybersecurity_v0, v[0], v[3], v[4], v[5], v[6], v[1], flags, cyber_policy, True)
+    v = {x[0]: x for x in rideshare_variants()}['busy_waiting_costs']
+    out['rideshare_name'] = np.asarray(v[0])
+    try:
+        out['rideshare'] = run(rideshare_v0, v[0], v[2], v[3], v[4], v[5], v[1], {}, rideshare_policy, False)
+    except Exception as failure:  # noqa: BLE001 - recorded: what the reference does with this configuration
+        out['rideshare'] = np.asarray(json.dumps({'raises': type(failure).__name__, 'message': str(failure)[:200]}))
+    path = os.path.join(GOLDEN, 'logs_sql.npz')
+    np.savez_compressed(path, **out)
+    print(path, {k: len(str(out[k])) for k in ('wildfire', 'cybersecurity', 'rideshare')})
+
+
+# ----------------------------------------------------------------------------------------------------------
 # configurations pickled by the reference (how the reference distributes its competition configurations)
 # ----------------------------------------------------------------------------------------------------------
 def record_pickles():
@@ -1024,7 +1098,7 @@ def record_rng():
     np.savez_compressed(os.path.join(GOLDEN, 'rng_modes.npz'), **out)
     print('rng_modes.npz written')
 
-PARTS = {'partial': record_partial_resets, 'rng': record_rng, 'ka': record_known_answers, 'baselines_wildfire': record_wildfire_baselines, 'baselines_rideshare': record_rideshare_baselines, 'baselines_cybersecurity': record_cyber_baselines, 'logs': record_logs, 'pickles': record_pickles, 'traj_wildfire': record_wildfire_trajectories, 'traj_cybersecurity': record_cyber_trajectories,
+PARTS = {'partial': record_partial_resets, 'rng': record_rng, 'ka': record_known_answers, 'baselines_wildfire': record_wildfire_baselines, 'baselines_rideshare': record_rideshare_baselines, 'baselines_cybersecurity': record_cyber_baselines, 'logs': record_logs, 'logs_sql': record_sql_logs, 'pickles': record_pickles, 'traj_wildfire': record_wildfire_trajectories, 'traj_cybersecurity': record_cyber_trajectories,
          'traj_rideshare': record_rideshare_trajectories,
          'misc': record_misc}
 
