@@ -932,6 +932,10 @@ struct frz_wildfire_env {
     std::vector<hipEvent_t> timing_events;                   // pool of frz_wildfire_timed_rollout
     bool timed = false;
     bool ticketed = false;  // field/crew kernels: more chunks than resident workgroups
+    // multi-step launches of frz_wildfire_rollout_random_policy (wf_roles_kernel<..., PERSIST>): byte distance from the packed list
+    // buffers to their second copy (0: not available for this env), and the steps the launch being enqueued performs
+    int64_t list_copy_delta = 0;
+    int32_t rollout_steps = 1;
     // grids above 16 cells (wildfire_grid.hip): the kernels' configuration and the tables uploaded into the arena at bind
     WgDev gdev;
     WgAgentTable agent_table;
@@ -1016,6 +1020,8 @@ int launch(frz_wildfire_env* env, const WfArgs& args, int rng, int mode, hipStre
         WfArgs a = args;
         if (!kVariants[env->variant].exact && mode == kStep && rng == FRZ_RNG_PHILOX) stage_philox(a, rng, stream);
         a.ticketed = env->ticketed;
+        a.n_steps = env->rollout_steps;
+        a.scratch_delta = env->list_copy_delta;
         return launch_roles(a, env->variant, env->dev.nchunks, rng, mode, stream);  // one workgroup per chunk
     }
 }
@@ -1397,6 +1403,10 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
     p.off_rand_field = take(3 * B * HW * 4);
     p.off_rand_agent = take(5 * B * A * 4);
     p.off_mt_state = take(624 * B * 4);
+    // second copy of the packed list buffers (task rows, observation map, action / bad-action maps: contiguous above) for the
+    // multi-step launches of the exact field/crew kernels
+    const bool multi_step = p.roles && kVariants[env->variant].exact && std::getenv("FRZ_WF_MULTISTEP_OFF") == nullptr;
+    if (multi_step) env->list_copy_delta = take(p.off_actions - p.off_task_values) - p.off_task_values;
     p.total_bytes = off;
 
     // One workgroup per chunk.  With no more chunks than CUs the whole grid is resident (one 256- or 512-thread workgroup
@@ -1612,9 +1622,15 @@ int frz_wildfire_rollout_random_policy(frz_wildfire_env* env, uint64_t policy_se
     if (!env->arena) return FRZ_E_UNBOUND;
     if (!env->was_reset) return FRZ_E_INVALID;
     if (n_steps == 0) return FRZ_OK;
-    // One launch per step.  (Keeping the workgroups resident across steps was built and measured: on this multi-XCD part the
-    // per-step outputs of consecutive steps overlap in memory and are written by different XCDs' L2s, so every step boundary
-    // needs an agent-scope release / acquire, i.e. an L2 write-back per workgroup: 47 us per step against 12.7.)
+    // Exact field/crew shapes, Philox draws, the whole grid resident: ONE launch whose workgroups keep their chunk's state in
+    // registers from step to step (wildfire_roles.hip, PERSIST); same results as n_steps single-step launches.  Otherwise one launch
+    // per step.
+    if (n_steps > 1 && env->list_copy_delta != 0 && !env->ticketed && rng_mode == FRZ_RNG_PHILOX && env->dev.roles && !env->dev.grid) {
+        env->rollout_steps = n_steps;
+        const int rc = frz_wildfire_step_random_policy(env, policy_seed, first_step, actions_out, rng_mode, nullptr, nullptr, stream);
+        env->rollout_steps = 1;
+        return rc;
+    }
     for (int32_t t = 0; t < n_steps; ++t) {
         const int rc = frz_wildfire_step_random_policy(env, policy_seed, first_step + (uint64_t)t, actions_out, rng_mode, nullptr, nullptr, stream);
         if (rc != FRZ_OK) return rc;

@@ -84,6 +84,8 @@ struct WfLaunch {
     uint32_t ticketed;     // 1: chunks are handed out in arrival order (more chunks than resident workgroups)
     uint32_t skip;         // diagnostic builds only (-DFRZ_WF_EXPERIMENT): store groups to leave out when timing; 0 in the product
     int32_t seed_increment;  // reset only (frz_wildfire_reset_reseed): added to every env seed
+    int32_t n_steps;         // multi-step launches (wf_roles_kernel<..., PERSIST>): steps of the rollout this launch performs
+    int64_t scratch_delta;   // multi-step launches: byte distance from the packed list buffers to their second copy
 };
 
 struct WfArgs {
@@ -99,6 +101,8 @@ struct WfArgs {
     hipEvent_t start_event = nullptr, stop_event = nullptr;
     bool ticketed = false;  // field/crew kernels: one workgroup per chunk, chunks handed out in arrival order
     int32_t seed_increment = 0;  // reset launches only
+    int32_t n_steps = 1;         // > 1: one multi-step launch (frz_wildfire_rollout_random_policy, field/crew exact Philox kernels)
+    int64_t scratch_delta = 0;
 };
 
 // The (CMAX, AMAX) instantiations of the step kernels: X(index, CMAX, AMAX, exact).  An env runs the first entry that holds its shape;
@@ -136,7 +140,7 @@ inline uint32_t experiment_skip() {
 inline WfLaunch make_launch(const WfArgs& a) {
     const WfDev* host = a.host_dev;
     return WfLaunch{host->B, a.policy ? 1u : 0u, host->off_rows1, host->off_epoch, host->off_totals, host->off_mt_state, (uint32_t)a.policy_seed,
-                    (uint32_t)(a.policy_seed >> 32), (uint32_t)a.policy_step, (uint32_t)(a.policy_step >> 32), a.actions_out, a.ticketed ? 1u : 0u, experiment_skip(), a.seed_increment};
+                    (uint32_t)(a.policy_seed >> 32), (uint32_t)a.policy_step, (uint32_t)(a.policy_step >> 32), a.actions_out, a.ticketed ? 1u : 0u, experiment_skip(), a.seed_increment, a.n_steps, a.scratch_delta};
 }
 
 // Staging the configuration: the 16-byte piece is requested by the kernel's FIRST vector-memory instruction (before the

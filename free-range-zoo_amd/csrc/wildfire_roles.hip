@@ -53,8 +53,17 @@ constexpr int kRound = 256;             // look-back window: a chunk sums at mos
     } while (0)
 #endif
 
-template <int CMAX, int AMAX, bool EXACT, int RNG, int MODE>
-__global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX > 8 || !EXACT) ? 2 : 4)) wf_roles_kernel(char* __restrict__ arena, const WfDev* __restrict__ dev,
+// PERSIST (exact shapes, FRZ_RNG_PHILOX, fused policy): launch.n_steps steps in ONE launch — the workgroup keeps its chunk's state in
+// registers from step to step and only the per-step outputs leave the CU.  What makes that legal on a part whose eight L2s are not
+// coherent with each other: (i) every array a step writes at env-indexed addresses is rewritten by the SAME workgroup at the next
+// step; (ii) the packed lists, whose addresses move between workgroups from step to step, are written THROUGH (no dirty line is
+// left in any L2) into one of two copies alternating with the step parity, the last planned step landing in the copy the caller
+// sees, and a wavefront waits for its own stores of step t-1 before its workgroup publishes anything of step t: two writes to one
+// address are then always separated by a publish -> totals -> wait chain; (iii) what crosses workgroups (chunk sums, batch totals)
+// travels in tagged granules read with agent-scope loads.  The totals of step t — which every workgroup needs before step t + 1:
+// all-done test, skip-agent quirk — are the last chunk's inclusive-prefix granules: waiting for them is the only inter-step barrier.
+template <int CMAX, int AMAX, bool EXACT, int RNG, int MODE, bool PERSIST = false>
+__global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX > 8 || !EXACT || PERSIST) ? 2 : 4)) wf_roles_kernel(char* __restrict__ arena, const WfDev* __restrict__ dev,
                                                                const int32_t* __restrict__ actions, const float* __restrict__ field_rand,
                                                                const float* __restrict__ agent_rand, const WfLaunch launch) {
     const int32_t batch = launch.batch;
@@ -270,18 +279,22 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
     FRZ_RSTAMP(12);
     __syncthreads();
     FRZ_RSTAMP(13);
-    const WfHot d = s_cfg;
+    const WfHot d_launch = s_cfg;
 #else
-    const WfHot d = stage_commit(s_cfg, cfg_piece);  // configuration block at arena offset 0; never written by a kernel
+    const WfHot d_launch = stage_commit(s_cfg, cfg_piece);  // configuration block at arena offset 0; never written by a kernel
 #endif
+    const WfHot& d = d_launch;
     FRZ_RSTAMP(1);
     const int W = d.W;
     const int nch = d.nch;  // A + 3
     const int ch_nt = A + 1, ch_ntr = A + 2;
     const uint32_t flags_word = d.flags;
 
-    const uint32_t tag = epoch + 1u;  // never 0 on a zero-filled arena
-    uint32_t* const cur_totals = totals + (epoch & 1u) * kTotalsStride;
+    static_assert(!PERSIST || (EXACT && RNG == FRZ_RNG_PHILOX && MODE == kStep), "the multi-step launch exists for the exact Philox step kernels");
+    const int n_steps = PERSIST ? launch.n_steps : 1;
+    uint32_t epoch_now = epoch;     // the epoch the current step runs under (advances with every executed step of a multi-step launch)
+    uint32_t tag = epoch + 1u;      // never 0 on a zero-filled arena
+    uint32_t* cur_totals = totals + (epoch & 1u) * kTotalsStride;
     uint32_t prev[AMAX + 3];
 #pragma unroll
     for (int i = 0; i < AMAX + 3; ++i) prev[i] = (epoch & 1u) ? totals0[i] : totals1[i];
@@ -290,28 +303,32 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
     const uint32_t q_burnouts = 0, q_putouts = 1, q_etc = 2;
 
     // utils/env.py:211-213 — every per-agent step() is a no-op once ALL envs are terminated or ALL are truncated.
-    if (MODE == kStep) {
+    auto is_frozen = [&]() {
         uint32_t nt = prev[0], ntr = prev[0];
 #pragma unroll
         for (int i = 0; i < AMAX + 3; ++i) {
             nt = i == ch_nt ? prev[i] : nt;
             ntr = i == ch_ntr ? prev[i] : ntr;
         }
-        if (nt == 0u || ntr == 0u) {
-            // The parallel adapter (utils/conversions.py:87-90) then adds the stale aec rewards once per agent call.
-            if (!crew)
-                {
-                    const int64_t b = (int64_t)chunk * kBlock + slot;
-                    if (b < B && !at32(rows1, u_frozen * Bu + (uint32_t)b)) {
-                        for (int a = 0; a < A; ++a) {
-                            const float r = at32(rowsf, (uint32_t)(r_rewards + a) * Bu + (uint32_t)b);
-                            float acc = 0.0f;
-                            for (int j = 0; j < A; ++j) acc = acc + r;
-                            at32(rowsf, (uint32_t)(r_rewards + a) * Bu + (uint32_t)b) = acc;
-                        }
-                        at32(rows1, u_frozen * Bu + (uint32_t)b) = 1;
-                    }
+        return nt == 0u || ntr == 0u;
+    };
+    auto frozen_step = [&]() {  // The parallel adapter (utils/conversions.py:87-90) then adds the stale aec rewards once per agent call.
+        if (!crew) {
+            const int64_t b = (int64_t)chunk * kBlock + slot;
+            if (b < B && !at32(rows1, u_frozen * Bu + (uint32_t)b)) {
+                for (int a = 0; a < A; ++a) {
+                    const float r = at32(rowsf, (uint32_t)(r_rewards + a) * Bu + (uint32_t)b);
+                    float acc = 0.0f;
+                    for (int j = 0; j < A; ++j) acc = acc + r;
+                    at32(rowsf, (uint32_t)(r_rewards + a) * Bu + (uint32_t)b) = acc;
                 }
+                at32(rows1, u_frozen * Bu + (uint32_t)b) = 1;
+            }
+        }
+    };
+    if (MODE == kStep && !PERSIST) {
+        if (is_frozen()) {
+            frozen_step();
             return;
         }
     }
@@ -323,6 +340,36 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
     uint64_t* const prefix = reinterpret_cast<uint64_t*>(arena + d.off_prefix);
 
     uint32_t* const error_word = reinterpret_cast<uint32_t*>(arena + d.off_error);
+    // Multi-step launch, between two steps: this wavefront's stores of the step that just ended have completed (see PERSIST above), then
+    // the totals that step left — the last chunk's inclusive-prefix granules carry its tag — replace `prev`, and the epoch advances.
+    auto await_totals = [&]() {
+        __builtin_amdgcn_s_waitcnt(0);
+        epoch_now += 1u;
+        const uint32_t ended = tag;
+        tag = epoch_now + 1u;
+        cur_totals = totals + (epoch_now & 1u) * kTotalsStride;
+        const uint64_t* const last = prefix + (int64_t)(nchunks - 1) * nch;
+        bool timed_out = false;
+        for (int spin = 0;; ++spin) {  // bounded
+            bool all = true;
+#pragma unroll
+            for (int i = 0; i < AMAX + 3; ++i) {
+                const uint64_t g = frz::granule_load(last + (i < nch ? i : 0));
+                all = all && (uint32_t)(g >> 32) == ended;
+                prev[i] = (uint32_t)g;
+            }
+            if (all) break;
+            if (spin >= (1 << 22)) {
+                timed_out = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (timed_out && slot == 0) atomicOr(error_word, (uint32_t)FRZ_ERR_SCAN_TIMEOUT);
+    };
+    // which copy of the packed lists step t writes: the last planned step lands in the caller's buffers (byte offset 0)
+    auto list_copy = [&](int t) { return (PERSIST && ((n_steps - 1 - t) & 1)) ? launch.scratch_delta : (int64_t)0; };
+    int executed = 0;
     // After barrier 5 either role can place any list of its env: the chunk's offsets (s_prefix), the sums of the chunk's
     // preceding wavefronts (s_wave_scan) and the env's position inside its wavefront (x_excl) are all in LDS.
     struct Placement {
@@ -346,11 +393,11 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
         return (int64_t)s_prefix[ch] + (int64_t)((word >> (16 * (ch & 3))) & 0xFFFFull);
     };
     // open action list of agent a (and, with show_bad_actions, its listed-but-not-attackable list): wildfire.py:586-717
-    auto emit_agent_lists = [&](int a, mask_t lit1, mask_t ok, int64_t off_f, int64_t off_a, int64_t b) {
+    auto emit_agent_lists = [&](int a, mask_t lit1, mask_t ok, int64_t off_f, int64_t off_a, int64_t b, int64_t copy) {
         const int64_t cap = B * HW;
-        int64_t* const act_values = reinterpret_cast<int64_t*>(arena + d.off_act_values);
+        int64_t* const act_values = reinterpret_cast<int64_t*>(arena + d.off_act_values + copy);
         int64_t* const act_offsets = reinterpret_cast<int64_t*>(arena + d.off_act_offsets);
-        int64_t* const bad_values = reinterpret_cast<int64_t*>(arena + d.off_bad_values);
+        int64_t* const bad_values = reinterpret_cast<int64_t*>(arena + d.off_bad_values + copy);
         int64_t* const bad_offsets = reinterpret_cast<int64_t*>(arena + d.off_bad_offsets);
         const bool show_bad = (flags_word & kShowBad) != 0;
         const int F = popc(lit1), fa = popc(ok);
@@ -366,10 +413,13 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
         for (int c = 0; c < CMAX; ++c) {
             const mask_t below = (mask_t)(((mask_t)1 << c) - 1);
             const int rk = popc(lit1 & below);
-            if ((ok >> c) & 1)
-                av[popc(ok & below)] = rk;
-            else if (show_bad && ((lit1 >> c) & 1))
-                bv[popc(lit1 & ~ok & below)] = rk;
+            if ((ok >> c) & 1) {
+                if constexpr (PERSIST) frz::store_through(&av[popc(ok & below)], (int64_t)rk);
+                else av[popc(ok & below)] = rk;
+            } else if (show_bad && ((lit1 >> c) & 1)) {
+                if constexpr (PERSIST) frz::store_through(&bv[popc(lit1 & ~ok & below)], (int64_t)rk);
+                else bv[popc(lit1 & ~ok & below)] = rk;
+            }
         }
     };
 
@@ -380,15 +430,74 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
         {
             const int64_t b = (int64_t)chunk * kBlock + slot;
             const bool active = b < B;
-            const uint32_t bl = (uint32_t)(active ? b : B - 1);
-            // per-iteration opaque copy: keeps the flag tests next to their uses (a launch usually runs ONE iteration per
-            // workgroup; hoisted out of the loop they would all sit in scalar registers from the top of the kernel and spill)
-            uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)flags_word);
-            asm volatile("" : "+s"(flags));
+            const uint32_t bl_launch = (uint32_t)(active ? b : B - 1), Bu_launch = Bu;
             int f[CMAX], in[CMAX], fu[CMAX];
 #pragma unroll
             for (int c = 0; c < CMAX; ++c) f[c] = cells.f[c], in[c] = fld.in[c], fu[c] = fld.fu[c];
-
+            // phase 6 as a function of (lit cells, copy of the packed lists): a multi-step launch that ends early writes its last lists twice
+            auto emit_field = [&](mask_t lit1, int64_t copy) {
+                if (active) {
+                    const Placement place = placement();
+                    const int64_t off_f = channel_offset(place, 0);
+                    const pack_t oks = x_ok[slot];
+#pragma unroll
+                    for (int a = 1; a < AMAX; a += 2)  // odd agents' lists (the crew writes the even ones)
+                        if (a < A) emit_agent_lists(a, lit1, (mask_t)((oks >> (MB * a)) & (pack_t)((1u << MB) - 1u)), off_f, channel_offset(place, a + 1), b, copy);
+                    int64_t* const task_values = reinterpret_cast<int64_t*>(arena + d.off_task_values + copy);
+                    int64_t* const task_offsets = reinterpret_cast<int64_t*>(arena + d.off_task_offsets);
+                    int64_t* const obs_map = reinterpret_cast<int64_t*>(arena + d.off_obs_map + copy);
+                    frz::store_through(&task_offsets[b], off_f);
+                    if (b == B - 1) task_offsets[B] = off_f + popc(lit1);
+                    // row of cell c's task inside the env's segment = number of lit cells below it
+                    int64_t* const trow = task_values + off_f * 4;
+                    int64_t* const omap = obs_map + off_f;
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c) {
+                        const int rk = popc(lit1 & (mask_t)(((mask_t)1 << c) - 1));
+                        if ((lit1 >> c) & 1) {
+                            const int yx = d.cell_yx[c];
+                            longlong2* const row = reinterpret_cast<longlong2*>(trow + rk * 4);
+                            if constexpr (PERSIST) {  // written through: see PERSIST at the top of the kernel
+                                int64_t* const cell = trow + rk * 4;
+                                frz::store_through(cell, (int64_t)(yx >> 16)), frz::store_through(cell + 1, (int64_t)(yx & 0xFFFF));
+                                frz::store_through(cell + 2, (int64_t)f[c]), frz::store_through(cell + 3, (int64_t)in[c]);
+                                frz::store_through(&omap[rk], (int64_t)rk);
+                            } else {
+                                row[0] = make_longlong2(yx >> 16, yx & 0xFFFF);
+                                row[1] = make_longlong2(f[c], in[c]);
+                                omap[rk] = rk;
+                            }
+                        }
+                    }
+                }
+            };
+            for (int t = 0; t < n_steps; ++t) {
+            if constexpr (PERSIST) {
+                if (t > 0) await_totals();
+                if (is_frozen()) {
+                    frozen_step();
+                    if (t > 0 && list_copy(t - 1) != 0) {  // the last lists went to the other copy: once more, into the caller's buffers
+                        mask_t lit_last = 0;
+#pragma unroll
+                        for (int c = 0; c < CMAX; ++c) lit_last |= (mask_t)(f[c] > 0) << c;
+                        emit_field(active ? lit_last : (mask_t)0, 0);
+                    }
+                    break;
+                }
+            }
+            const int64_t copy = list_copy(t);
+            // per-step opaque copies: the flag tests stay next to their uses, and in a multi-step launch so do the row addresses — hoisted
+            // out of the step loop, the ~100 store addresses and ~40 row bases of a step would all be live from the top of the kernel
+            // (256 VGPRs, >100 spilled scalars)
+            uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)flags_word);
+            asm volatile("" : "+s"(flags));
+            uint32_t bl = bl_launch, Bu = Bu_launch;
+            if constexpr (PERSIST) {
+                asm volatile("" : "+v"(bl));
+                asm volatile("" : "+s"(Bu));
+                asm volatile("" ::: "memory");  // and the configuration is read from LDS where a step uses it, not once above the loop
+            }
+            const WfHot& d = PERSIST ? static_cast<const WfHot&>(s_cfg) : d_launch;
             // ---- phase 1: the step's field draws
             float r_field[3][CMAX];
             if (MODE == kStep) {
@@ -564,8 +673,8 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
             }
 #pragma unroll
             for (int c = 0; c < CMAX; ++c) lit1 |= (mask_t)(f[c] > 0) << c;
+            x_lit[slot] = lit1;  // as it is also for the lanes that shadow the last env: a multi-step launch steps them like their owner
             lit1 = active ? lit1 : (mask_t)0;
-            x_lit[slot] = lit1;
             x_fate[slot] = (fate_t)burned | ((fate_t)put_out << MB) | ((fate_t)dead << (2 * MB));
             FRZ_RSTAMP(5);
             __syncthreads();  // (2) lit mask and fates visible to the crew
@@ -632,58 +741,72 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
             FRZ_RSTAMP(9);
 
             // ---- phase 6: task list (wildfire.py:586-717)
-            if (active) {
-                const Placement place = placement();
-                const int64_t off_f = channel_offset(place, 0);
-                const pack_t oks = x_ok[slot];
-#pragma unroll
-                for (int a = 1; a < AMAX; a += 2)  // odd agents' lists (the crew writes the even ones)
-                    if (a < A) emit_agent_lists(a, lit1, (mask_t)((oks >> (MB * a)) & (pack_t)((1u << MB) - 1u)), off_f, channel_offset(place, a + 1), b);
-                int64_t* const task_values = reinterpret_cast<int64_t*>(arena + d.off_task_values);
-                int64_t* const task_offsets = reinterpret_cast<int64_t*>(arena + d.off_task_offsets);
-                int64_t* const obs_map = reinterpret_cast<int64_t*>(arena + d.off_obs_map);
-                frz::store_through(&task_offsets[b], off_f);
-                if (b == B - 1) task_offsets[B] = off_f + popc(lit1);
-                // row of cell c's task inside the env's segment = number of lit cells below it
-                int64_t* const trow = task_values + off_f * 4;
-                int64_t* const omap = obs_map + off_f;
-#pragma unroll
-                for (int c = 0; c < CMAX; ++c) {
-                    const int rk = popc(lit1 & (mask_t)(((mask_t)1 << c) - 1));
-                    if ((lit1 >> c) & 1) {
-                        const int yx = d.cell_yx[c];
-                        longlong2* const row = reinterpret_cast<longlong2*>(trow + rk * 4);
-                        row[0] = make_longlong2(yx >> 16, yx & 0xFFFF);
-                        row[1] = make_longlong2(f[c], in[c]);
-                        omap[rk] = rk;
-                    }
-                }
-            }
+            emit_field(lit1, copy);
             FRZ_RSTAMP(10);
             FRZ_RWALL(1);
+            if constexpr (PERSIST) fld.nm += 1;
+            executed = t + 1;
+            }  // steps of this launch
             // The workgroup owning the last chunk finished its look-back only after every other chunk published, i.e.
             // after every workgroup of this launch read the epoch: it can advance it for the next launch.
-            if (chunk == nchunks - 1 && slot == 0) __hip_atomic_store(epoch_ptr, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (executed > 0 && chunk == nchunks - 1 && slot == 0)
+                __hip_atomic_store(epoch_ptr, epoch + (uint32_t)executed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     } else {
         // ============================================================================================= CREW ROLE
         {
             const int64_t b = (int64_t)chunk * kBlock + slot;
             const bool active = b < B;
-            const uint32_t bl = (uint32_t)(active ? b : B - 1);
-            // per-iteration opaque copy: keeps the flag tests next to their uses (a launch usually runs ONE iteration per
-            // workgroup; hoisted out of the loop they would all sit in scalar registers from the top of the kernel and spill)
-            uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)flags_word);
-            asm volatile("" : "+s"(flags));
+            const uint32_t bl_launch = (uint32_t)(active ? b : B - 1), Bu_launch = Bu;
             uint32_t err = 0;
             float supp[AMAX], capa[AMAX], rew[AMAX];
             int eqs[AMAX], hit[AMAX];
             bool users[AMAX], refill[AMAX];
 #pragma unroll
-            for (int a = 0; a < AMAX; ++a) {
-                supp[a] = crw.supp[a], capa[a] = crw.capa[a], eqs[a] = crw.eqs[a];
-                rew[a] = 0.0f, hit[a] = -1, users[a] = false, refill[a] = false;
+            for (int a = 0; a < AMAX; ++a) supp[a] = crw.supp[a], capa[a] = crw.capa[a], eqs[a] = crw.eqs[a];
+            mask_t lit_before = 0;  // lit cells of the state the step starts from (later steps of a multi-step launch: the previous step's)
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) lit_before |= (mask_t)(cells.f[c] > 0) << c;
+            // phase 6 as a function of (lit cells, attackable cells per agent, copy of the packed lists)
+            auto emit_crew = [&](mask_t lit1, const mask_t (&ok1)[AMAX], int64_t copy) {
+                if (active) {
+                    const Placement place = placement();
+                    const int64_t off_f = channel_offset(place, 0);
+#pragma unroll
+                    for (int a = 0; a < AMAX; a += 2)
+                        if (a < A) emit_agent_lists(a, lit1, ok1[a], off_f, channel_offset(place, a + 1), b, copy);
+                }
+            };
+            for (int t = 0; t < n_steps; ++t) {
+            if constexpr (PERSIST) {
+                if (t > 0) await_totals();
+                if (is_frozen()) {
+                    frozen_step();
+                    if (t > 0 && list_copy(t - 1) != 0) {  // the last lists went to the other copy: once more, into the caller's buffers
+                        mask_t ok_last[AMAX];
+#pragma unroll
+                        for (int a = 0; a < AMAX; ++a)
+                            ok_last[a] = (a < A && supp[a] > 0.0f) ? (lit_before & (mask_t)s_cfg.range_mask[a][eqs[a]]) : (mask_t)0;
+                        emit_crew(lit_before, ok_last, 0);
+                    }
+                    break;
+                }
             }
+            const int64_t copy = list_copy(t);
+            // per-step opaque copies: the flag tests stay next to their uses, and in a multi-step launch so do the row addresses — hoisted
+            // out of the step loop, the ~100 store addresses and ~40 row bases of a step would all be live from the top of the kernel
+            // (256 VGPRs, >100 spilled scalars)
+            uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)flags_word);
+            asm volatile("" : "+s"(flags));
+            uint32_t bl = bl_launch, Bu = Bu_launch;
+            if constexpr (PERSIST) {
+                asm volatile("" : "+v"(bl));
+                asm volatile("" : "+s"(Bu));
+                asm volatile("" ::: "memory");  // and the configuration is read from LDS where a step uses it, not once above the loop
+            }
+            const WfHot& d = PERSIST ? static_cast<const WfHot&>(s_cfg) : d_launch;
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a) rew[a] = 0.0f, hit[a] = -1, users[a] = false, refill[a] = false;
             const bool term0 = crw.term != 0, trunc0 = crw.trunc != 0;
 
             // ---- phase 1: action decode (wildfire.py:427-483) -> applied power per cell
@@ -691,9 +814,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
             // state just loaded: attackable set of agent a = lit fires within its (equipment-adjusted) range, non-empty
             // only while it has suppressant (wildfire.py:604-623).
             if (MODE == kStep) {
-                mask_t lit0 = 0;
-#pragma unroll
-                for (int c = 0; c < CMAX; ++c) lit0 |= (mask_t)(cells.f[c] > 0) << c;
+                const mask_t lit0 = lit_before;
                 float ap[CMAX];
 #pragma unroll
                 for (int c = 0; c < CMAX; ++c) ap[c] = 0.0f;
@@ -701,9 +822,11 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                 // stream of frz_wildfire_random_policy: agent a draws word a % 4 of block (a / 4, policy step), keyed by the env seed
                 frz::Philox4 policy_block[(AMAX + 3) / 4]{};  // agent a draws word a % 4 of block a / 4
                 if (launch.policy) {
+                    // (a multi-step launch samples step t of its rollout with policy step first + t)
+                    const uint64_t policy_step = (((uint64_t)launch.policy_step_hi << 32) | launch.policy_step_lo) + (uint64_t)(PERSIST ? t : 0);
 #pragma unroll
                     for (int q = 0; q < (AMAX + 3) / 4; ++q)
-                        if (q * 4 < A) policy_block[q] = frz::philox4x32_10((uint32_t)q, 0u, launch.policy_step_lo, launch.policy_step_hi,
+                        if (q * 4 < A) policy_block[q] = frz::philox4x32_10((uint32_t)q, 0u, (uint32_t)policy_step, (uint32_t)(policy_step >> 32),
                                                                            launch.policy_seed_lo ^ crw.seed, launch.policy_seed_hi);
                 }
 #pragma unroll
@@ -834,7 +957,8 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
             FRZ_RSTAMP(6);
 
             // ---- phase 3: open-task sets, per-env counts, wavefront scan
-            const mask_t lit1 = x_lit[slot];
+            const mask_t lit_all = x_lit[slot];
+            const mask_t lit1 = active ? lit_all : (mask_t)0;
             const fate_t fate = x_fate[slot];
             const mask_t burned = (mask_t)(fate & (fate_t)((1u << MB) - 1u)), put_out = (mask_t)((fate >> MB) & (fate_t)((1u << MB) - 1u));
             const bool dead = ((fate >> (2 * MB)) & 1u) != 0;
@@ -947,10 +1071,15 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                         at32(rowsf, (uint32_t)(r_rewards + a) * Bu + bl) = rew[a];
                         at32(rows1, (u_term + (uint32_t)a) * Bu + bl) = (uint8_t)term;
                         if (write_trunc) at32(rows1, (u_trunc + (uint32_t)a) * Bu + bl) = (uint8_t)trunc;
-                        if (track) at32(rowsf, (uint32_t)(r_cum + a) * Bu + bl) = __fadd_rn(crw.cum[a], rew[a]);
+                        if (track) {
+                            const float total = __fadd_rn(crw.cum[a], rew[a]);
+                            at32(rowsf, (uint32_t)(r_cum + a) * Bu + bl) = total;
+                            if constexpr (PERSIST) crw.cum[a] = total;
+                        }
                     }
                 }
                 at32(rows, (uint32_t)r_burnouts * Bu + bl) = crw.nb + n_burn;
+                if constexpr (PERSIST) crw.nb += n_burn;
                 at32(rows8, q_burnouts * Bu + bl) = n_burn;
                 at32(rows8, q_putouts * Bu + bl) = n_put;
             }
@@ -1014,15 +1143,15 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
             if (timed_out) err |= FRZ_ERR_SCAN_TIMEOUT;
 
             // ---- phase 6: the even agents' action lists (the field role writes the odd ones and the task list)
-            if (active) {
-                const Placement place = placement();
-                const int64_t off_f = channel_offset(place, 0);
-#pragma unroll
-                for (int a = 0; a < AMAX; a += 2)
-                    if (a < A) emit_agent_lists(a, lit1, ok1[a], off_f, channel_offset(place, a + 1), b);
-            }
+            emit_crew(lit1, ok1, copy);
             FRZ_RSTAMP(10);
             FRZ_RWALL(1);
+            if constexpr (PERSIST) {  // what the next step of this launch starts from
+                lit_before = lit_all;
+                crw.term = term ? 1u : 0u, crw.trunc = trunc ? 1u : 0u;
+                crw.nm += 1;
+            }
+            }  // steps of this launch
             if (err) atomicOr(error_word, err);
         }
     }
@@ -1038,9 +1167,14 @@ void launch_roles_variant(const WfArgs& a, const WfDev* dev, int grid, int rng, 
         launch_step_kernel(a, wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kRebuild>, grid, kRoleBlock, stream, a.arena, dev, a.actions,
                            a.field_rand, a.agent_rand, batch);
     } else if (rng == FRZ_RNG_PHILOX) {
-        if constexpr (EXACT)
-            launch_step_kernel(a, wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_PHILOX, kStep>, grid, kRoleBlock, stream, a.arena, dev, a.actions,
-                               a.field_rand, a.agent_rand, batch);
+        if constexpr (EXACT) {
+            if (a.n_steps > 1)  // one launch for the whole rollout (the caller has checked policy, residency and the second list copy)
+                launch_step_kernel(a, wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_PHILOX, kStep, true>, grid, kRoleBlock, stream, a.arena, dev,
+                                   a.actions, a.field_rand, a.agent_rand, batch);
+            else
+                launch_step_kernel(a, wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_PHILOX, kStep>, grid, kRoleBlock, stream, a.arena, dev, a.actions,
+                                   a.field_rand, a.agent_rand, batch);
+        }
     } else if (rng == FRZ_RNG_MT19937) {
         if constexpr (EXACT)
             launch_step_kernel(a, wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_MT19937, kStep>, grid, kRoleBlock, stream, a.arena, dev, a.actions,

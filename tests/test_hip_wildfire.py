@@ -589,3 +589,79 @@ def test_fused_random_policy_on_other_shapes(shape):
         for name in ('_fires', '_intensity', '_fuel', '_suppressants', '_rewards', '_task_offsets', '_act_map_offsets', '_act_map_values'):
             assert torch.equal(getattr(two, name), getattr(one, name)), f'{shape}: {name} at step {t}'
     one.check()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# multi-step launches: frz_wildfire_rollout_random_policy as ONE launch (wf_roles_kernel<..., PERSIST>)
+# ------------------------------------------------------------------------------------------------------------------
+ROLLOUT_FIELDS = ('_fires', '_intensity', '_fuel', '_suppressants', '_capacity', '_equipment', '_rewards', '_cumulative', '_terminations',
+                  '_truncations', 'num_moves', 'num_burnouts', '_burnouts', '_putouts', '_obs_self', '_obs_others', '_actions', '_task_offsets',
+                  '_act_map_offsets', '_bad_map_offsets', 'environment_task_count', 'agent_task_count', '_frozen_scaled')
+
+
+def assert_same_env(one, many, what):
+    for name in ROLLOUT_FIELDS:
+        assert torch.equal(getattr(one, name), getattr(many, name)), f'{what}: {name}'
+    total = int(one._task_offsets[-1])
+    assert torch.equal(one._task_values[:total], many._task_values[:total]), f'{what}: task rows'
+    assert torch.equal(one._obs_map_values[:total], many._obs_map_values[:total]), f'{what}: observation map'
+    for a in range(len(one.agents)):
+        n = int(one._act_map_offsets[a, -1])
+        assert torch.equal(one._act_map_values[a, :n], many._act_map_values[a, :n]), f'{what}: action map of agent {a}'
+        if one.show_bad_actions:
+            n = int(one._bad_map_offsets[a, -1])
+            assert torch.equal(one._bad_map_values[a, :n], many._bad_map_values[a, :n]), f'{what}: bad-action map of agent {a}'
+
+
+@pytest.mark.parametrize('case', [
+    dict(build=configs.wildfire_openness, B=65536, max_steps=50, steps=50),           # the bench workload, one launch per episode
+    dict(build=configs.wildfire_openness, B=1000, max_steps=50, steps=7),             # ragged last chunk, odd step count
+    dict(build=configs.wildfire_rich, B=3000, max_steps=40, steps=12, kwargs=dict(show_bad_actions=True, observe_other_suppressant=True)),
+    dict(build=lambda: configs.wildfire_grid(3, 3, 4), B=2048, max_steps=30, steps=9),   # 16-bit cell masks
+    dict(build=lambda: configs.wildfire_grid(4, 4, 2), B=700, max_steps=30, steps=10),
+], ids=['bench', 'ragged', 'rich_bad_actions', '3x3a4', '4x4a2'])
+def test_multi_step_launch_equals_single_step_launches(case):
+    """rollout_random_policy(n) — one launch whose workgroups keep their envs in registers across the n steps — leaves exactly what n
+    step_random_policy launches leave: state, rewards, observations, sampled actions, every list."""
+    kwargs = dict(rng='philox', exact_shapes=False, **case.get('kwargs', {}))
+    one, many = [make_env(case['build'], case['B'], case['max_steps'], **kwargs) for _ in range(2)]
+    for env in (one, many):
+        env.reset(seed=torch.arange(case['B'], dtype=torch.int32) + 3)
+    for t in range(case['steps']):
+        one.step_random_policy(policy_seed=5, policy_step=t)
+    many.rollout_random_policy(case['steps'], policy_seed=5, first_step=0)
+    assert_same_env(one, many, 'first rollout')
+    # and again from where it stands (policy steps continue), to cover a launch that does not start at a reset
+    for t in range(case['steps'], case['steps'] + 3):
+        one.step_random_policy(policy_seed=5, policy_step=t)
+    many.rollout_random_policy(3, policy_seed=5, first_step=case['steps'])
+    assert_same_env(one, many, 'second rollout')
+    one.check()
+    many.check()
+
+
+@pytest.mark.parametrize('steps', [8, 9, 5, 6])
+def test_multi_step_launch_running_into_the_end_of_the_episode(steps):
+    """Every env is truncated after 5 steps: the launch stops stepping there (utils/env.py:211-213), scales the stale rewards once and
+    leaves the lists of the last executed step in the caller's buffers whichever copy that step wrote (both parities of the planned
+    step count; 5 and 6 end exactly at / one past the horizon)."""
+    B = 1500
+    one, many = [make_env(configs.wildfire_openness, B, 5, rng='philox', exact_shapes=False) for _ in range(2)]
+    for env in (one, many):
+        env.reset(seed=torch.arange(B, dtype=torch.int32))
+    for t in range(steps):
+        one.step_random_policy(policy_seed=2, policy_step=t)
+    many.rollout_random_policy(steps, policy_seed=2, first_step=0)
+    assert bool(one.finished.all()) and int(one.num_moves.max()) == 5
+    assert_same_env(one, many, f'{steps} steps planned')
+    # the next launches are no-ops on both
+    one.step_random_policy(policy_seed=2, policy_step=steps)
+    many.rollout_random_policy(4, policy_seed=2, first_step=steps)
+    assert_same_env(one, many, 'after the end')
+    # and a reset starts both again
+    for env in (one, many):
+        env.reset(seed=torch.arange(B, dtype=torch.int32) + 9)
+    for t in range(3):
+        one.step_random_policy(policy_seed=2, policy_step=t)
+    many.rollout_random_policy(3, policy_seed=2, first_step=0)
+    assert_same_env(one, many, 'after a reset')

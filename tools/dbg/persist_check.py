@@ -1,0 +1,47 @@
+"""Multi-step launch (frz_wildfire_rollout_random_policy) against the same steps launched one by one: state, outputs, timing."""
+import os, sys, time
+os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import torch, configs
+from free_range_zoo_amd import _capi
+from free_range_zoo_amd.envs import wildfire_v0
+from free_range_zoo_amd.utils.env import stream_ptr
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+MAXS = int(sys.argv[3]) if len(sys.argv) > 3 else 50
+dev = torch.device('cuda')
+def make():
+    e = wildfire_v0.parallel_env(configuration=configs.wildfire_openness(), parallel_envs=B, max_steps=MAXS, device=dev, rng='philox', exact_shapes=False)
+    e.reset(seed=torch.arange(B, dtype=torch.int32))
+    return e
+one, many = make(), make()
+for t in range(N):
+    one.step_random_policy(7, t)
+many.rollout_random_policy(N, policy_seed=7, first_step=0)
+torch.cuda.synchronize()
+one.check(); many.check()
+bad = []
+for name in ('_fires', '_intensity', '_fuel', '_suppressants', '_capacity', '_equipment', '_rewards', '_cumulative', '_terminations', '_truncations', 'num_moves', 'num_burnouts',
+             '_burnouts', '_putouts', '_obs_self', '_obs_others', '_actions', '_task_offsets', '_act_map_offsets', 'environment_task_count', 'agent_task_count'):
+    if not torch.equal(getattr(one, name), getattr(many, name)):
+        bad.append(name)
+tot = int(one._task_offsets[-1])
+if not torch.equal(one._task_values[:tot], many._task_values[:tot]) or not torch.equal(one._obs_map_values[:tot], many._obs_map_values[:tot]):
+    bad.append('task lists')
+for a in range(len(one.agents)):
+    ta = int(one._act_map_offsets[a, -1])
+    if not torch.equal(one._act_map_values[a, :ta], many._act_map_values[a, :ta]):
+        bad.append(f'act list {a}')
+print('B', B, 'steps', N, 'max_steps', MAXS, 'MISMATCH ' + str(bad) if bad else 'identical', 'moves', int(one.num_moves.max()), 'lit rows', tot)
+lib, h, s, acts = many._lib, many._handle, stream_ptr(dev), many._actions.data_ptr()
+for label, f in (('multi-step launch', lambda: lib.frz_wildfire_rollout_random_policy(h, 7, 0, N, acts, _capi.FRZ_RNG_PHILOX, s)),
+                 ('one launch per step', lambda: [lib.frz_wildfire_step_random_policy(h, 7, t, acts, _capi.FRZ_RNG_PHILOX, None, None, s) for t in range(N)])):
+    best = 1e9
+    for rep in range(5):
+        lib.frz_wildfire_reset(h, s)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); f(); b.record(); torch.cuda.synchronize()
+        best = min(best, a.elapsed_time(b) / N * 1e3)
+    print(f'  {label}: {best:.2f} us per step')
