@@ -3,9 +3,11 @@
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-A "step" is one pass of the hot path over one batch: ONE launch of the fused HIP kernel that samples the uniform random
-policy and performs one ParallelEnv.step() for all parallel_envs (action decode, 7 transitions, rewards / termination,
-open action / observation space rebuild).  Inputs are resident in HBM; nothing crosses PCIe inside the timed region.
+A "step" is one pass of the hot path over one batch: the fused HIP kernel samples the uniform random policy and performs one
+ParallelEnv.step() for all parallel_envs (action decode, 7 transitions, rewards / termination, open action / observation space
+rebuild, every per-step output written).  An episode's steps are ONE launch where the library has a multi-step launch for the shape
+(the bench shape has: the workgroups keep their envs in registers from step to step), otherwise one launch per step.  Inputs are
+resident in HBM; nothing crosses PCIe inside the timed region.
 
 Protocol (timed rollouts, median reported).  The K steps are one BLOCK = a rollout loop captured as ONE HIP
 graph: per episode of max_steps = 50 (the last one shorter when K is not a multiple) fresh env seeds, reset, the episode's
@@ -247,6 +249,9 @@ def main():
     env = wildfire_v0.parallel_env(configuration=configs.wildfire_openness(), parallel_envs=B, max_steps=EPISODE, device=device,
                                    rng=args.rng, exact_shapes=False)
     A, HW = len(env.agents), env.max_y * env.max_x
+    # one process per GPU and one stream: the device is this env's alone, which is what a multi-step launch needs (its workgroups wait
+    # for each other inside the kernel).  Not so in the shared-device rehearsal, where two ranks run on one GPU.
+    env.set_exclusive_device(not rehearsal)
     base_seed = sharding.shard_seeds(rank, B)  # seed = global env index = rank * B + i
     metrics = torch.zeros(A + 2, dtype=torch.float64, device=device)  # (sum reward per agent, env-steps, finished)
     job_metrics = torch.zeros_like(metrics)                           # what the collective reduces (copied at the end of the graph)
@@ -321,15 +326,25 @@ def main():
     from free_range_zoo_amd.utils.env import stream_ptr
     lib, handle = env._lib, env._handle
     mode = _capi.FRZ_RNG_MT19937 if args.rng == 'mt19937' else _capi.FRZ_RNG_PHILOX
-    kernel_ms = []
+    kernel_ms, launch_ms = [], []
     task_sum = torch.zeros(1 + A, dtype=torch.float64, device=device)
     stream = stream_ptr(device)
+    # the launches of the timed region: an episode's steps are ONE multi-step launch where the library has one for the shape
+    # (frz_wildfire_rollout_launches), otherwise one launch per step
+    steps_per_launch = EPISODE if lib.frz_wildfire_rollout_launches(handle, EPISODE, mode) == 1 else 1
     for episode in range(PROBE_EPISODES):
         env.reset(seed=base_seed + 17 + 1000003 * episode)
         torch.cuda.synchronize(device)
         out = (ctypes.c_float * EPISODE)()
         _capi.check(lib.frz_wildfire_timed_rollout(handle, policy_seed, 0, EPISODE, env._actions.data_ptr(), mode, stream, out), 'frz_wildfire_timed_rollout')
         kernel_ms.extend(out[i] for i in range(EPISODE))
+        if steps_per_launch > 1:
+            env.reset(seed=base_seed + 17 + 1000003 * episode)
+            torch.cuda.synchronize(device)
+            one = ctypes.c_float()
+            _capi.check(lib.frz_wildfire_timed_rollout_launch(handle, policy_seed, 0, EPISODE, env._actions.data_ptr(), mode, stream, ctypes.byref(one)),
+                        'frz_wildfire_timed_rollout_launch')
+            launch_ms.append(one.value)
     for episode in range(PROBE_EPISODES):  # the same episodes again, step by step, for the task counts (not timed)
         env.reset(seed=base_seed + 17 + 1000003 * episode)
         for t in range(EPISODE):
@@ -338,12 +353,16 @@ def main():
             task_sum[1:] += env.agent_task_count.sum(dim=1)
     torch.cuda.synchronize(device)
     n_probe = PROBE_EPISODES * EPISODE
-    kernel_ms_avg = float(np.mean(kernel_ms))
+    single_step_ms_avg = float(np.mean(kernel_ms))
+    # duration of the dominant kernel's launch as the timed region runs it (per launch; per step = / steps_per_launch)
+    kernel_ms_avg = float(np.mean(launch_ms)) if launch_ms else single_step_ms_avg
     mean_tasks = float(task_sum[0].item()) / (n_probe * B)
     mean_agent_tasks = float(task_sum[1:].sum().item()) / (n_probe * B)
     per_env = wildfire_bytes_per_env_step(HW, A, env._k, mean_tasks, mean_agent_tasks, injected_randomness=(args.rng == 'mt19937'))
-    achieved = per_env * B / (kernel_ms_avg * 1e-3) / 1e9
-    traffic, traffic_source = recorded_traffic('wf_step_kernel_bytes_per_launch')
+    achieved = per_env * B * steps_per_launch / (kernel_ms_avg * 1e-3) / 1e9  # algorithmic bytes of one launch / its duration
+    traffic, traffic_source = recorded_traffic('wf_step_kernel_bytes_per_step')
+    if traffic is not None:
+        traffic *= steps_per_launch  # per launch, like `achieved`
 
     if rank == 0:
         env.check()
@@ -376,8 +395,14 @@ def main():
             'python_api_env_steps_per_s': api_value,
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'traffic_source': traffic_source,
-                         'kernel': 'wf_roles_kernel<6,3,exact,philox,step>' if args.rng == 'philox' else 'wf_roles_kernel<6,3,exact,mt19937,step>',
-                         'kernel_ms_avg': kernel_ms_avg, 'kernel_ms_median': float(np.median(kernel_ms)), 'launches_timed': n_probe,
+                         'kernel': ('wf_roles_kernel<6,3,exact,philox,step,multi-step>' if steps_per_launch > 1 else
+                                    'wf_roles_kernel<6,3,exact,philox,step>' if args.rng == 'philox' else 'wf_roles_kernel<6,3,exact,mt19937,step>'),
+                         'steps_per_launch': steps_per_launch,
+                         'kernel_ms_avg': kernel_ms_avg, 'kernel_ms_median': float(np.median(launch_ms if launch_ms else kernel_ms)),
+                         'launches_timed': len(launch_ms) if launch_ms else n_probe,
+                         'kernel_ms_per_step': kernel_ms_avg / steps_per_launch,
+                         'single_step_launch_ms_avg': single_step_ms_avg,
+                         'algorithmic_bytes_per_launch': per_env * B * steps_per_launch,
                          'algorithmic_bytes_per_env_step': per_env, 'mean_tasks_per_env': mean_tasks, 'mean_agent_tasks_per_env': mean_agent_tasks,
                          'frac_at_driver_ms_per_step': per_env * B / (median_s / K) / 1e9 / HBM_PEAK_GBS},
             'reference_cpu_env_steps_per_s': {'value': 21112, 'source': 'BASELINE.md §2: unmodified reference, 8 vCPU, B=65536 (survey container)'},

@@ -52,6 +52,10 @@ SIGNATURES = {
     'frz_wildfire_episode_metrics': (ctypes.c_int, [_P, _P, _P]),
     'frz_wildfire_timed_rollout': (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int32, _P, ctypes.c_int, _P,
                                                  ctypes.POINTER(ctypes.c_float)]),
+    'frz_wildfire_set_exclusive_device': (ctypes.c_int, [_P, ctypes.c_int]),
+    'frz_wildfire_rollout_launches': (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int]),
+    'frz_wildfire_timed_rollout_launch': (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int32, _P, ctypes.c_int, _P,
+                                                        ctypes.POINTER(ctypes.c_float)]),
     'frz_cybersecurity_create': (ctypes.c_int, [_P, ctypes.POINTER(_P)]),
     'frz_cybersecurity_destroy': (None, [_P]),
     'frz_cybersecurity_arena_bytes': (ctypes.c_int64, [_P]),

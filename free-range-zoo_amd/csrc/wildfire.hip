@@ -936,6 +936,7 @@ struct frz_wildfire_env {
     // buffers to their second copy (0: not available for this env), and the steps the launch being enqueued performs
     int64_t list_copy_delta = 0;
     int32_t rollout_steps = 1;
+    bool exclusive_device = false;  // frz_wildfire_set_exclusive_device: multi-step launches allowed
     // grids above 16 cells (wildfire_grid.hip): the kernels' configuration and the tables uploaded into the arena at bind
     WgDev gdev;
     WgAgentTable agent_table;
@@ -1405,7 +1406,7 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
     p.off_mt_state = take(624 * B * 4);
     // second copy of the packed list buffers (task rows, observation map, action / bad-action maps: contiguous above) for the
     // multi-step launches of the exact field/crew kernels
-    const bool multi_step = p.roles && kVariants[env->variant].exact && std::getenv("FRZ_WF_MULTISTEP_OFF") == nullptr;
+    const bool multi_step = p.roles && kVariants[env->variant].exact;
     if (multi_step) env->list_copy_delta = take(p.off_actions - p.off_task_values) - p.off_task_values;
     p.total_bytes = off;
 
@@ -1616,6 +1617,37 @@ int frz_wildfire_timed_rollout(frz_wildfire_env* env, uint64_t policy_seed, uint
     return FRZ_OK;
 }
 
+int frz_wildfire_set_exclusive_device(frz_wildfire_env* env, int exclusive) {
+    if (!env) return FRZ_E_INVALID;
+    env->exclusive_device = exclusive != 0;
+    return FRZ_OK;
+}
+
+int frz_wildfire_rollout_launches(const frz_wildfire_env* env, int32_t n_steps, int rng_mode) {
+    if (!env || n_steps < 0) return FRZ_E_INVALID;
+    const bool one = n_steps > 1 && env->exclusive_device && env->list_copy_delta != 0 && !env->ticketed && rng_mode == FRZ_RNG_PHILOX &&
+                     env->dev.roles && !env->dev.grid;
+    return one ? 1 : n_steps;
+}
+
+int frz_wildfire_timed_rollout_launch(frz_wildfire_env* env, uint64_t policy_seed, uint64_t first_step, int32_t n_steps, int32_t* actions_out,
+                                      int rng_mode, void* stream, float* launch_ms) {
+    if (!env || !launch_ms || frz_wildfire_rollout_launches(env, n_steps, rng_mode) != 1) return FRZ_E_INVALID;
+    while ((int)env->timing_events.size() < 2) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return FRZ_E_LAUNCH;
+        env->timing_events.push_back(e);
+    }
+    env->start_event = env->timing_events[0];
+    env->stop_event = env->timing_events[1];
+    env->timed = true;
+    const int rc = frz_wildfire_rollout_random_policy(env, policy_seed, first_step, n_steps, actions_out, rng_mode, stream);
+    env->timed = false;
+    if (rc != FRZ_OK) return rc;
+    if (hipStreamSynchronize(static_cast<hipStream_t>(stream)) != hipSuccess) return FRZ_E_LAUNCH;
+    return hipEventElapsedTime(launch_ms, env->timing_events[0], env->timing_events[1]) == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;
+}
+
 int frz_wildfire_rollout_random_policy(frz_wildfire_env* env, uint64_t policy_seed, uint64_t first_step, int32_t n_steps, int32_t* actions_out,
                                        int rng_mode, void* stream) {
     if (!env || !actions_out || n_steps < 0) return FRZ_E_INVALID;
@@ -1625,7 +1657,7 @@ int frz_wildfire_rollout_random_policy(frz_wildfire_env* env, uint64_t policy_se
     // Exact field/crew shapes, Philox draws, the whole grid resident: ONE launch whose workgroups keep their chunk's state in
     // registers from step to step (wildfire_roles.hip, PERSIST); same results as n_steps single-step launches.  Otherwise one launch
     // per step.
-    if (n_steps > 1 && env->list_copy_delta != 0 && !env->ticketed && rng_mode == FRZ_RNG_PHILOX && env->dev.roles && !env->dev.grid) {
+    if (frz_wildfire_rollout_launches(env, n_steps, rng_mode) == 1 && n_steps > 1) {
         env->rollout_steps = n_steps;
         const int rc = frz_wildfire_step_random_policy(env, policy_seed, first_step, actions_out, rng_mode, nullptr, nullptr, stream);
         env->rollout_steps = 1;

@@ -434,6 +434,36 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
             int f[CMAX], in[CMAX], fu[CMAX];
 #pragma unroll
             for (int c = 0; c < CMAX; ++c) f[c] = cells.f[c], in[c] = fld.in[c], fu[c] = fld.fu[c];
+            // FRZ_RNG_PHILOX (include/frz.h): draw u = 24-bit field u % 5 of block (u / 5, step, 0, 0); field event e of cell c is draw
+            // e * HW + c, agent event e of agent a is draw 3 * HW + e * A + a.  The field role draws for both roles while the crew decodes
+            // the actions; agent events 1..4 are only drawn when something reads them.
+            auto philox_draws = [&](int moves, uint32_t flags, float (&field_out)[3][CMAX], float (&agent_out)[5 * AMAX]) {
+                constexpr int U = 3 * CMAX + 5 * AMAX, NB = (U + 4) / 5, NB_EVENT0 = (3 * CMAX + AMAX + 4) / 5;
+                const bool need_late = (flags & (kStochRepair | kStochDegrade | kCritical | kStochRefill | kStochSwitch)) != 0 || s_cfg.K > 1;
+                const int nb_needed = need_late ? NB : NB_EVENT0;
+                float uni[NB * 5];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    uni[5 * j] = uni[5 * j + 1] = uni[5 * j + 2] = uni[5 * j + 3] = uni[5 * j + 4] = 0.0f;
+                    if (j < nb_needed) {
+                        const frz::Philox4 w = frz::philox4x32_10((uint32_t)j, (uint32_t)moves, 0u, 0u, fld.seed, 0x46525A00u);
+                        uni[5 * j] = frz::philox_unit24<0>(w);
+                        uni[5 * j + 1] = frz::philox_unit24<1>(w);
+                        uni[5 * j + 2] = frz::philox_unit24<2>(w);
+                        uni[5 * j + 3] = frz::philox_unit24<3>(w);
+                        uni[5 * j + 4] = frz::philox_unit24<4>(w);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 3; ++e)
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c) field_out[e][c] = uni[e * CMAX + c];
+#pragma unroll
+                for (int i = 0; i < 5 * AMAX; ++i) agent_out[i] = uni[3 * CMAX + i];
+            };
+            // multi-step launches: the NEXT step's draws (a function of the env seed and the step number only), made while this role
+            // waits for the crew's hand-off — between barriers 3 and 4 it has nothing else to do for about as long as the draws take
+            float next_field[kPhilox && PERSIST ? 3 : 1][kPhilox && PERSIST ? CMAX : 1], next_agent[kPhilox && PERSIST ? 5 * AMAX : 1];
             // phase 6 as a function of (lit cells, copy of the packed lists): a multi-step launch that ends early writes its last lists twice
             auto emit_field = [&](mask_t lit1, int64_t copy) {
                 if (active) {
@@ -472,19 +502,6 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                 }
             };
             for (int t = 0; t < n_steps; ++t) {
-            if constexpr (PERSIST) {
-                if (t > 0) await_totals();
-                if (is_frozen()) {
-                    frozen_step();
-                    if (t > 0 && list_copy(t - 1) != 0) {  // the last lists went to the other copy: once more, into the caller's buffers
-                        mask_t lit_last = 0;
-#pragma unroll
-                        for (int c = 0; c < CMAX; ++c) lit_last |= (mask_t)(f[c] > 0) << c;
-                        emit_field(active ? lit_last : (mask_t)0, 0);
-                    }
-                    break;
-                }
-            }
             const int64_t copy = list_copy(t);
             // per-step opaque copies: the flag tests stay next to their uses, and in a multi-step launch so do the row addresses — hoisted
             // out of the step loop, the ~100 store addresses and ~40 row bases of a step would all be live from the top of the kernel
@@ -507,32 +524,19 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
 #pragma unroll
                         for (int c = 0; c < CMAX; ++c) r_field[e][c] = fdraws.r[e][c];
                 } else if constexpr (kPhilox) {
-                    // FRZ_RNG_PHILOX (include/frz.h): draw u = 24-bit field u % 5 of block (u / 5, step, 0, 0); field event e
-                    // of cell c is draw e * HW + c, agent event e of agent a is draw 3 * HW + e * A + a.  The field role
-                    // draws for both roles while the crew decodes the actions; agent events 1..4 are only drawn when
-                    // something reads them.
-                    constexpr int U = 3 * CMAX + 5 * AMAX, NB = (U + 4) / 5, NB_EVENT0 = (3 * CMAX + AMAX + 4) / 5;
-                    const bool need_late = (flags & (kStochRepair | kStochDegrade | kCritical | kStochRefill | kStochSwitch)) != 0 || d.K > 1;
-                    const int nb_needed = need_late ? NB : NB_EVENT0;
-                    float uni[NB * 5];
+                    if (PERSIST && t > 0) {  // drawn while this role waited for the previous step's hand-off (below)
 #pragma unroll
-                    for (int j = 0; j < NB; ++j) {
-                        uni[5 * j] = uni[5 * j + 1] = uni[5 * j + 2] = uni[5 * j + 3] = uni[5 * j + 4] = 0.0f;
-                        if (j < nb_needed) {
-                            const frz::Philox4 w = frz::philox4x32_10((uint32_t)j, (uint32_t)fld.nm, 0u, 0u, fld.seed, 0x46525A00u);
-                            uni[5 * j] = frz::philox_unit24<0>(w);
-                            uni[5 * j + 1] = frz::philox_unit24<1>(w);
-                            uni[5 * j + 2] = frz::philox_unit24<2>(w);
-                            uni[5 * j + 3] = frz::philox_unit24<3>(w);
-                            uni[5 * j + 4] = frz::philox_unit24<4>(w);
-                        }
+                        for (int e = 0; e < 3; ++e)
+#pragma unroll
+                            for (int c = 0; c < CMAX; ++c) r_field[e][c] = next_field[e][c];
+#pragma unroll
+                        for (int i = 0; i < 5 * AMAX; ++i) x_draw[i][slot] = next_agent[i];
+                    } else {
+                        float agent_draws[5 * AMAX];
+                        philox_draws(fld.nm, flags, r_field, agent_draws);
+#pragma unroll
+                        for (int i = 0; i < 5 * AMAX; ++i) x_draw[i][slot] = agent_draws[i];
                     }
-#pragma unroll
-                    for (int e = 0; e < 3; ++e)
-#pragma unroll
-                        for (int c = 0; c < CMAX; ++c) r_field[e][c] = uni[e * CMAX + c];
-#pragma unroll
-                    for (int i = 0; i < 5 * AMAX; ++i) x_draw[i][slot] = uni[3 * CMAX + i];
                 } else if constexpr (kMt) {
                     // FRZ_RNG_MT19937: the env's own MT19937 stream (mt19937.hip: state word j of env b at [j][b], twisted
                     // lazily, one word per draw), bit-identical to the reference's per-env torch CPU generator.  The step
@@ -590,6 +594,22 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                 for (int e = 0; e < 3; ++e)
 #pragma unroll
                     for (int c = 0; c < CMAX; ++c) asm volatile("" : "+v"(r_field[e][c]));
+            }
+            if constexpr (PERSIST) {
+                // Between two steps of a multi-step launch.  The draws above need nothing from the other workgroups, so the wait for
+                // the totals of the step that just ended (the launch's only inter-step barrier) comes after them: the crew, which needs
+                // the totals for its decode, waits first, and this role's ~700 instructions of Philox cover the same time.
+                if (t > 0) await_totals();
+                if (is_frozen()) {
+                    frozen_step();
+                    if (t > 0 && list_copy(t - 1) != 0) {  // the last lists went to the other copy: once more, into the caller's buffers
+                        mask_t lit_last = 0;
+#pragma unroll
+                        for (int c = 0; c < CMAX; ++c) lit_last |= (mask_t)(f[c] > 0) << c;
+                        emit_field(active ? lit_last : (mask_t)0, 0);
+                    }
+                    break;
+                }
             }
             FRZ_RSTAMP(3);
             __syncthreads();  // (1) applied power visible
@@ -735,6 +755,9 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
             __syncthreads();  // (3) wavefront sums visible
 
             // ---- phase 4 belongs to the crew (hand-off)
+            if constexpr (kPhilox && PERSIST) {
+                if (t + 1 < n_steps) philox_draws(fld.nm + 1, flags, next_field, next_agent);
+            }
             FRZ_RSTAMP(8);
             __syncthreads();  // (4)
             __syncthreads();  // (5) chunk prefix visible
@@ -779,18 +802,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
             };
             for (int t = 0; t < n_steps; ++t) {
             if constexpr (PERSIST) {
-                if (t > 0) await_totals();
-                if (is_frozen()) {
-                    frozen_step();
-                    if (t > 0 && list_copy(t - 1) != 0) {  // the last lists went to the other copy: once more, into the caller's buffers
-                        mask_t ok_last[AMAX];
-#pragma unroll
-                        for (int a = 0; a < AMAX; ++a)
-                            ok_last[a] = (a < A && supp[a] > 0.0f) ? (lit_before & (mask_t)s_cfg.range_mask[a][eqs[a]]) : (mask_t)0;
-                        emit_crew(lit_before, ok_last, 0);
-                    }
-                    break;
-                }
+                if (t == 0 && is_frozen()) break;  // (later steps: tested in phase 1, once the totals of the step before have arrived)
             }
             const int64_t copy = list_copy(t);
             // per-step opaque copies: the flag tests stay next to their uses, and in a multi-step launch so do the row addresses — hoisted
@@ -813,11 +825,10 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
             // The action mapping of the previous rebuild is a pure function of the state it was built from, which is the
             // state just loaded: attackable set of agent a = lit fires within its (equipment-adjusted) range, non-empty
             // only while it has suppressant (wildfire.py:604-623).
+            bool stop = false;  // multi-step launch: the batch turned out to be finished
             if (MODE == kStep) {
                 const mask_t lit0 = lit_before;
                 float ap[CMAX];
-#pragma unroll
-                for (int c = 0; c < CMAX; ++c) ap[c] = 0.0f;
                 const bool show_bad = (flags & kShowBad) != 0;
                 // stream of frz_wildfire_random_policy: agent a draws word a % 4 of block (a / 4, policy step), keyed by the env seed
                 frz::Philox4 policy_block[(AMAX + 3) / 4]{};  // agent a draws word a % 4 of block a / 4
@@ -829,8 +840,20 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                         if (q * 4 < A) policy_block[q] = frz::philox4x32_10((uint32_t)q, 0u, (uint32_t)policy_step, (uint32_t)(policy_step >> 32),
                                                                            launch.policy_seed_lo ^ crw.seed, launch.policy_seed_hi);
                 }
+                // A later step of a multi-step launch decodes BEFORE the totals of the step that just ended are here (they are the launch's
+                // inter-step barrier: a memory round trip after the last chunk has published them), assuming what is true of every
+                // ordinary step — no agent is skipped, the batch is not finished — and only repeats the decode when the totals say
+                // otherwise.  Nothing of this phase leaves the registers before that test.
+                int2 sampled[AMAX];
+                uint32_t err1 = 0;
+                for (int attempt = 0; attempt < (PERSIST ? 2 : 1); ++attempt) {
+                const bool assume_ordinary = PERSIST && t > 0 && attempt == 0;
+                err1 = 0;
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) ap[c] = 0.0f;
 #pragma unroll
                 for (int a = 0; a < AMAX; ++a) {
+                    sampled[a] = make_int2(0, -1);
                     if (a < A) {
                         const mask_t ok = supp[a] > 0.0f ? (lit0 & (mask_t)s_cfg.range_mask[a][eqs[a]]) : (mask_t)0;
                         const mask_t sel = show_bad ? lit0 : ok;  // the tasks the agent's action space lists
@@ -843,11 +866,12 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                             const int j = (int)(((uint64_t)policy_block[a >> 2].w[a & 3] * (uint64_t)(n + 1)) >> 32);
                             act_idx = j < n ? j : n;
                             act_id = j < n ? 0 : -1;
-                            frz::store_through(&reinterpret_cast<int2*>(launch.actions_out)[a * B + bl], make_int2(act_idx, act_id));
+                            sampled[a] = make_int2(act_idx, act_id);
+                            if constexpr (!PERSIST) frz::store_through(&reinterpret_cast<int2*>(launch.actions_out)[a * B + bl], sampled[a]);
                         }
                         refill[a] = act_id == -1;
                         // quirk wildfire.py:434-435: an agent with no attackable task in ANY env of the batch is skipped
-                        const bool skipped = prev[1 + a] == 0u;
+                        const bool skipped = !assume_ordinary && prev[1 + a] == 0u;
                         const bool fight = !refill[a] && !skipped;
                         const bool valid = act_idx >= 0 && act_idx < popc(sel);
                         int target = 0, seen = 0;
@@ -859,7 +883,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                         }
                         const bool attackable = ((ok >> target) & 1) != 0;
                         const bool good = fight && valid && (!show_bad || attackable);
-                        if (fight && !valid && active) err |= FRZ_ERR_BAD_ACTION_INDEX;
+                        if (fight && !valid && active) err1 |= FRZ_ERR_BAD_ACTION_INDEX;
                         const float power = d.power[a] + s_cfg.eq[eqs[a]][1];
 #pragma unroll
                         for (int c = 0; c < CMAX; ++c) ap[c] = ap[c] + ((good && target == c) ? power : 0.0f);  // agent order
@@ -868,9 +892,41 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                         rew[a] = (fight && !good) ? d.bad_attack_penalty : 0.0f;  // assignment, :477
                     }
                 }
+                if constexpr (PERSIST) {
+                    if (!assume_ordinary) break;
+                    await_totals();
+                    stop = is_frozen();
+                    bool someone_skipped = false;
 #pragma unroll
-                for (int c = 0; c < CMAX; ++c)
-                    if (c < HW) x_power[c][slot] = ap[c];
+                    for (int a = 0; a < AMAX; ++a) someone_skipped = someone_skipped || (a < A && prev[1 + a] == 0u);
+                    if (stop || !someone_skipped) break;
+                }
+                }  // attempts
+                if (!stop) {
+                    err |= err1;
+                    if constexpr (PERSIST) {
+                        if (launch.policy) {
+#pragma unroll
+                            for (int a = 0; a < AMAX; ++a)
+                                if (a < A) frz::store_through(&reinterpret_cast<int2*>(launch.actions_out)[a * B + bl], sampled[a]);
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c)
+                        if (c < HW) x_power[c][slot] = ap[c];
+                }
+            }
+            if constexpr (PERSIST) {
+                if (stop) {  // utils/env.py:211-213: nothing more happens in this launch
+                    if (list_copy(t - 1) != 0) {  // the last lists went to the other copy: once more, into the caller's buffers
+                        mask_t ok_last[AMAX];
+#pragma unroll
+                        for (int a = 0; a < AMAX; ++a)
+                            ok_last[a] = (a < A && supp[a] > 0.0f) ? (lit_before & (mask_t)s_cfg.range_mask[a][eqs[a]]) : (mask_t)0;
+                        emit_crew(lit_before, ok_last, 0);
+                    }
+                    break;
+                }
             }
             FRZ_RSTAMP(3);
             __syncthreads();  // (1) applied power visible to the field role

@@ -406,6 +406,13 @@ class raw_env(BatchedParallelEnv):
                    lambda: (policy_seed, policy_step, self._actions, mode, len(self.agents), self.parallel_envs))
         return self._after_fused(logged)
 
+    def set_exclusive_device(self, exclusive: bool = True) -> None:
+        """State that nothing else uses this GPU while the env's rollouts run (no other process, no concurrent stream).  It allows
+        ``rollout_random_policy`` / ``capture_random_rollout`` to run a whole rollout as ONE launch where the library has a multi-step
+        kernel for the shape (include/frz.h: frz_wildfire_set_exclusive_device): its workgroups wait inside the kernel for each other
+        between steps, which is only safe when all of them are resident.  Off by default."""
+        _capi.check(self._lib.frz_wildfire_set_exclusive_device(self._handle, 1 if exclusive else 0), 'frz_wildfire_set_exclusive_device')
+
     @torch.no_grad()
     def rollout_random_policy(self, steps: int, policy_seed: int = 0, first_step: int = 0):
         """``steps`` x ``step_random_policy`` (same results), enqueued by one call through the C boundary.  With ``log_directory`` set the

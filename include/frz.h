@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FRZ_ABI_VERSION 2
+#define FRZ_ABI_VERSION 3
 
 #define FRZ_MAX_AGENTS 16
 #define FRZ_MAX_CELLS 1024 /* 32 x 32; grids above 16 cells run one env per wavefront with the cells across its lanes */
@@ -221,8 +221,12 @@ int frz_wildfire_random_policy(frz_wildfire_env* env, uint64_t policy_seed, uint
  * actions_out is left as it is).  Grid shapes without a fused kernel run the two launches. */
 int frz_wildfire_step_random_policy(frz_wildfire_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out,
                                     int rng_mode, const float* field_randomness, const float* agent_randomness, void* stream);
-/* n_steps random-policy steps (policy steps first_step, first_step + 1, ...) = n_steps calls of frz_wildfire_step_random_policy,
- * stream-ordered, one launch per step; rng_mode FRZ_RNG_PHILOX or FRZ_RNG_MT19937 (capture it into a HIP graph for rollouts). */
+/* n_steps random-policy steps (policy steps first_step, first_step + 1, ...): what n_steps calls of frz_wildfire_step_random_policy
+ * leave — state, rewards, the last step's observations, lists and sampled actions; intermediate steps' outputs are produced and
+ * overwritten, as a loop over step() overwrites them — stream-ordered; rng_mode FRZ_RNG_PHILOX or FRZ_RNG_MT19937 (capture it into a
+ * HIP graph for rollouts).  One launch per step, or — after frz_wildfire_set_exclusive_device(env, 1), for exact field/crew shapes
+ * with FRZ_RNG_PHILOX and parallel_envs <= 256 x CUs — ONE launch whose workgroups keep their envs in registers from step to step
+ * (frz_wildfire_rollout_launches tells which). */
 int frz_wildfire_rollout_random_policy(frz_wildfire_env* env, uint64_t policy_seed, uint64_t first_step, int32_t n_steps,
                                        int32_t* actions_out, int rng_mode, void* stream);
 
@@ -268,6 +272,21 @@ int frz_cybersecurity_focus_policy(const int64_t* tasks, int64_t env_stride, int
  * envs whose agents are all terminated or all truncated.  metrics: float64 [A + 2] on the device, accumulated in place;
  * deterministic summation order. */
 int frz_wildfire_episode_metrics(frz_wildfire_env* env, double* metrics, void* stream);
+
+/* The caller states that nothing else runs on the device while this env's rollouts do (no other process, no concurrent stream): the
+ * precondition of the multi-step launch, whose workgroups wait INSIDE the kernel for the other workgroups of their own grid (the batch
+ * totals of step t gate step t + 1) and therefore must all be resident at once — sharing the CUs with another kernel that also waits
+ * for its own stragglers can stall both until their bounded spins give up (FRZ_ERR_SCAN_TIMEOUT).  Off by default. */
+int frz_wildfire_set_exclusive_device(frz_wildfire_env* env, int exclusive);
+/* How many kernel launches frz_wildfire_rollout_random_policy(n_steps) enqueues for this env and RNG mode: 1 when the whole rollout runs
+ * as one multi-step launch (exact field/crew shapes, FRZ_RNG_PHILOX, every chunk's workgroup resident at once,
+ * frz_wildfire_set_exclusive_device on), n_steps otherwise. */
+int frz_wildfire_rollout_launches(const frz_wildfire_env* env, int32_t n_steps, int rng_mode);
+/* Measurement aid: frz_wildfire_rollout_random_policy(n_steps) when it is ONE launch, bracketed by a pair of HIP events that take that
+ * dispatch's begin / end timestamps on `stream`; synchronises and returns the duration in milliseconds (FRZ_E_INVALID when the rollout
+ * would take several launches). */
+int frz_wildfire_timed_rollout_launch(frz_wildfire_env* env, uint64_t policy_seed, uint64_t first_step, int32_t n_steps, int32_t* actions_out,
+                                      int rng_mode, void* stream, float* launch_ms);
 
 /* Measurement aid: n_steps launches of frz_wildfire_step_random_policy (policy steps first_step ...), back to back with no
  * host synchronisation in between, each bracketed by its own pair of HIP events that take the step dispatch's begin / end

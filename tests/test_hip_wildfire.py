@@ -500,6 +500,7 @@ def test_graph_replayed_rollout_equals_eager_rollout(rng):
     for t in range(steps):
         eager.step(eager.random_policy_actions(policy_seed=77, policy_step=t))
     graphed = make_env(configs.wildfire_openness, B, 50, rng=rng, exact_shapes=False)
+    graphed.set_exclusive_device(True)  # (philox: the graph then holds the rollout as one multi-step launch)
     graphed.reset(seed=seeds)
     graph = graphed.capture_random_rollout(steps, policy_seed=77, include_reset=True)
     for _ in range(2):  # the second replay starts from the in-graph reset again
@@ -616,15 +617,19 @@ def assert_same_env(one, many, what):
 @pytest.mark.parametrize('case', [
     dict(build=configs.wildfire_openness, B=65536, max_steps=50, steps=50),           # the bench workload, one launch per episode
     dict(build=configs.wildfire_openness, B=1000, max_steps=50, steps=7),             # ragged last chunk, odd step count
-    dict(build=configs.wildfire_rich, B=3000, max_steps=40, steps=12, kwargs=dict(show_bad_actions=True, observe_other_suppressant=True)),
+    dict(build=configs.wildfire_openness, B=3000, max_steps=40, steps=12, kwargs=dict(show_bad_actions=True, observe_other_suppressant=True, observe_other_power=True)),
+    dict(build=configs.wildfire_rich, B=3000, max_steps=40, steps=6, kwargs=dict(show_bad_actions=True), launches=6),  # 4 x 5 grid: no multi-step kernel, one launch per step
     dict(build=lambda: configs.wildfire_grid(3, 3, 4), B=2048, max_steps=30, steps=9),   # 16-bit cell masks
     dict(build=lambda: configs.wildfire_grid(4, 4, 2), B=700, max_steps=30, steps=10),
-], ids=['bench', 'ragged', 'rich_bad_actions', '3x3a4', '4x4a2'])
+], ids=['bench', 'ragged', 'bad_actions', 'fallback_4x5', '3x3a4', '4x4a2'])
 def test_multi_step_launch_equals_single_step_launches(case):
     """rollout_random_policy(n) — one launch whose workgroups keep their envs in registers across the n steps — leaves exactly what n
     step_random_policy launches leave: state, rewards, observations, sampled actions, every list."""
     kwargs = dict(rng='philox', exact_shapes=False, **case.get('kwargs', {}))
     one, many = [make_env(case['build'], case['B'], case['max_steps'], **kwargs) for _ in range(2)]
+    many.set_exclusive_device(True)
+    assert many._lib.frz_wildfire_rollout_launches(many._handle, case['steps'], _capi.FRZ_RNG_PHILOX) == case.get('launches', 1)
+    assert one._lib.frz_wildfire_rollout_launches(one._handle, case['steps'], _capi.FRZ_RNG_PHILOX) == case['steps']  # off by default
     for env in (one, many):
         env.reset(seed=torch.arange(case['B'], dtype=torch.int32) + 3)
     for t in range(case['steps']):
@@ -647,6 +652,7 @@ def test_multi_step_launch_running_into_the_end_of_the_episode(steps):
     step count; 5 and 6 end exactly at / one past the horizon)."""
     B = 1500
     one, many = [make_env(configs.wildfire_openness, B, 5, rng='philox', exact_shapes=False) for _ in range(2)]
+    many.set_exclusive_device(True)
     for env in (one, many):
         env.reset(seed=torch.arange(B, dtype=torch.int32))
     for t in range(steps):

@@ -16,6 +16,7 @@ def make():
     e.reset(seed=torch.arange(B, dtype=torch.int32))
     return e
 one, many = make(), make()
+many.set_exclusive_device(True)
 for t in range(N):
     one.step_random_policy(7, t)
 many.rollout_random_policy(N, policy_seed=7, first_step=0)

@@ -22,8 +22,17 @@ def per_step(domain, counter):
         name = r['Kernel_Name']
         if r['Counter_Name'] != counter or not any(k in name for k in STEP_KERNELS[domain]):
             continue
-        if 'rs_env_kernel' in name and ', 1>' in name.split('(')[0]:
+        head = name.split('(')[0]
+        if 'rs_env_kernel' in name and ', 1>' in head:
             continue  # rebuild-mode instantiation (reset), not a step
+        if 'wf_roles_kernel' in name:
+            arguments = [a.strip() for a in head[head.index('<') + 1:head.rindex('>')].split(',')]
+            if arguments[4] != '0':
+                continue  # reset / rebuild mode
+            # <CMAX, AMAX, EXACT, RNG, MODE, PERSIST>: a multi-step launch carries the whole 50-step episode of tools/traffic_run.py
+            total += float(r['Counter_Value'])
+            steps += 50 if (len(arguments) > 5 and arguments[5] in ('true', '1')) else 1
+            continue
         total += float(r['Counter_Value'])
         steps += first in name
     # rideshare: reset's rebuild also runs offsets + emit once: negligible against 50 steps, left in
@@ -41,7 +50,7 @@ for domain in STEP_KERNELS:
         out[f'{domain}_read_bytes_per_env_step'] = 2 * f[0] * 1024 / 65536
         out[f'{domain}_write_bytes_per_env_step'] = w[0] * 1024 / 65536
         out[f'{domain}_steps_counted'] = f[1]
-if 'wildfire_bytes_per_step' in out:
-    out['wf_step_kernel_bytes_per_launch'] = out['wildfire_bytes_per_step']
+if 'wildfire_bytes_per_step' in out:  # bench.py scales it by the steps one launch of its timed region performs
+    out['wf_step_kernel_bytes_per_step'] = out['wildfire_bytes_per_step']
 json.dump(out, open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json'), 'w'), indent=1)
 print(json.dumps(out, indent=1))
