@@ -50,6 +50,7 @@ SIGNATURES = {
                                                      ctypes.c_int, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64,
                                                      ctypes.c_uint64, ctypes.c_int64, _P, _P, _P, _P, _P]),
     'frz_wildfire_episode_metrics': (ctypes.c_int, [_P, _P, _P]),
+    'frz_wildfire_rollout_random_policy_metrics': (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int32, _P, ctypes.c_int, _P, _P]),
     'frz_wildfire_timed_rollout': (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int32, _P, ctypes.c_int, _P,
                                                  ctypes.POINTER(ctypes.c_float)]),
     'frz_wildfire_set_exclusive_device': (ctypes.c_int, [_P, ctypes.c_int]),

@@ -936,6 +936,7 @@ struct frz_wildfire_env {
     // buffers to their second copy (0: not available for this env), and the steps the launch being enqueued performs
     int64_t list_copy_delta = 0;
     int32_t rollout_steps = 1;
+    double* rollout_metrics = nullptr;  // frz_wildfire_rollout_random_policy_metrics: folded into the multi-step launch being enqueued
     bool exclusive_device = false;  // frz_wildfire_set_exclusive_device: multi-step launches allowed
     // grids above 16 cells (wildfire_grid.hip): the kernels' configuration and the tables uploaded into the arena at bind
     WgDev gdev;
@@ -1023,6 +1024,7 @@ int launch(frz_wildfire_env* env, const WfArgs& args, int rng, int mode, hipStre
         a.ticketed = env->ticketed;
         a.n_steps = env->rollout_steps;
         a.scratch_delta = env->list_copy_delta;
+        a.metrics_out = env->rollout_metrics;
         return launch_roles(a, env->variant, env->dev.nchunks, rng, mode, stream);  // one workgroup per chunk
     }
 }
@@ -1668,6 +1670,19 @@ int frz_wildfire_rollout_random_policy(frz_wildfire_env* env, uint64_t policy_se
         if (rc != FRZ_OK) return rc;
     }
     return FRZ_OK;
+}
+
+int frz_wildfire_rollout_random_policy_metrics(frz_wildfire_env* env, uint64_t policy_seed, uint64_t first_step, int32_t n_steps, int32_t* actions_out,
+                                               int rng_mode, double* metrics, void* stream) {
+    if (!env || !metrics) return FRZ_E_INVALID;
+    if (frz_wildfire_rollout_launches(env, n_steps, rng_mode) == 1 && n_steps > 1) {  // the reductions ride in the multi-step launch's tail
+        env->rollout_metrics = metrics;
+        const int rc = frz_wildfire_rollout_random_policy(env, policy_seed, first_step, n_steps, actions_out, rng_mode, stream);
+        env->rollout_metrics = nullptr;
+        return rc;
+    }
+    const int rc = frz_wildfire_rollout_random_policy(env, policy_seed, first_step, n_steps, actions_out, rng_mode, stream);
+    return rc != FRZ_OK ? rc : frz_wildfire_episode_metrics(env, metrics, stream);
 }
 
 int frz_wildfire_episode_metrics(frz_wildfire_env* env, double* metrics, void* stream) {

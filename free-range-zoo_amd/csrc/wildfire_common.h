@@ -86,6 +86,7 @@ struct WfLaunch {
     int32_t seed_increment;  // reset only (frz_wildfire_reset_reseed): added to every env seed
     int32_t n_steps;         // multi-step launches (wf_roles_kernel<..., PERSIST>): steps of the rollout this launch performs
     int64_t scratch_delta;   // multi-step launches: byte distance from the packed list buffers to their second copy
+    double* metrics_out;     // multi-step launches: frz_wildfire_episode_metrics folded into the launch's tail (nullptr: not asked for)
 };
 
 struct WfArgs {
@@ -103,6 +104,7 @@ struct WfArgs {
     int32_t seed_increment = 0;  // reset launches only
     int32_t n_steps = 1;         // > 1: one multi-step launch (frz_wildfire_rollout_random_policy, field/crew exact Philox kernels)
     int64_t scratch_delta = 0;
+    double* metrics_out = nullptr;
 };
 
 // The (CMAX, AMAX) instantiations of the step kernels: X(index, CMAX, AMAX, exact).  An env runs the first entry that holds its shape;
@@ -140,7 +142,7 @@ inline uint32_t experiment_skip() {
 inline WfLaunch make_launch(const WfArgs& a) {
     const WfDev* host = a.host_dev;
     return WfLaunch{host->B, a.policy ? 1u : 0u, host->off_rows1, host->off_epoch, host->off_totals, host->off_mt_state, (uint32_t)a.policy_seed,
-                    (uint32_t)(a.policy_seed >> 32), (uint32_t)a.policy_step, (uint32_t)(a.policy_step >> 32), a.actions_out, a.ticketed ? 1u : 0u, experiment_skip(), a.seed_increment, a.n_steps, a.scratch_delta};
+                    (uint32_t)(a.policy_seed >> 32), (uint32_t)a.policy_step, (uint32_t)(a.policy_step >> 32), a.actions_out, a.ticketed ? 1u : 0u, experiment_skip(), a.seed_increment, a.n_steps, a.scratch_delta, a.metrics_out};
 }
 
 // Staging the configuration: the 16-byte piece is requested by the kernel's FIRST vector-memory instruction (before the

@@ -1211,6 +1211,76 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
             if (err) atomicOr(error_word, err);
         }
     }
+    if constexpr (PERSIST) {
+        // frz_wildfire_rollout_random_policy_metrics: the episode metrics (frz_wildfire_episode_metrics: sum of every agent's cumulative
+        // reward, of num_moves, number of finished envs) from the values the crew role still holds, in the standalone kernel's
+        // summation order (one env per thread, lane tree, wavefronts 0..3, then the chunks' partial rows by the last workgroup to arrive:
+        // lane tree, wavefronts 0..3) — the same float64 results bit for bit, one launch and its gap less per episode.
+        if (launch.metrics_out != nullptr) {
+            __shared__ double s_metric[frz::kWaves][AMAX + 2];
+            __shared__ int s_last_workgroup;
+            const int nrow = A + 2;
+            double* const partial = reinterpret_cast<double*>(arena + d_launch.off_metrics);
+            auto reduce_rows = [&](const double (&mine)[AMAX + 2]) {
+#pragma unroll
+                for (int i = 0; i < AMAX + 2; ++i) {
+                    double v = mine[i];
+                    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);  // fixed tree: deterministic
+                    if (lane == 0) s_metric[wave][i] = v;
+                }
+            };
+            if (crew) {
+                const bool active = (int64_t)chunk * kBlock + slot < B;
+                double mine[AMAX + 2];
+#pragma unroll
+                for (int i = 0; i < AMAX + 2; ++i) mine[i] = 0.0;
+                if (active) {
+#pragma unroll
+                    for (int a = 0; a < AMAX; ++a) mine[a] = a < A ? (double)crw.cum[a] : 0.0;
+#pragma unroll
+                    for (int i = 0; i < AMAX + 2; ++i) {
+                        mine[i] = i == A ? (double)crw.nm : mine[i];
+                        mine[i] = i == A + 1 ? ((crw.term != 0u || crw.trunc != 0u) ? 1.0 : 0.0) : mine[i];
+                    }
+                }
+                reduce_rows(mine);
+            }
+            __syncthreads();
+            if (crew && slot < nrow) {
+                double v = 0.0;
+#pragma unroll
+                for (int w = 0; w < frz::kWaves; ++w) v += s_metric[w][slot];
+                __hip_atomic_store(&partial[(int64_t)chunk * nrow + slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the partial row has left before the ticket is taken
+            __syncthreads();
+            if (crew && slot == 0) {
+                uint32_t* const counter = reinterpret_cast<uint32_t*>(arena + launch.off_epoch) + 48;
+                const uint32_t ticket = atomicAdd(counter, 1u);
+                s_last_workgroup = ticket == (uint32_t)nchunks - 1u;
+                if (s_last_workgroup) atomicExch(counter, 0u);
+            }
+            __syncthreads();
+            if (s_last_workgroup) {
+                if (crew) {
+                    double mine[AMAX + 2];
+#pragma unroll
+                    for (int i = 0; i < AMAX + 2; ++i)
+                        mine[i] = (i < nrow && slot < nchunks)
+                                      ? __hip_atomic_load(&partial[(int64_t)slot * nrow + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                      : 0.0;
+                    reduce_rows(mine);
+                }
+                __syncthreads();
+                if (crew && slot < nrow) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int w = 0; w < frz::kWaves; ++w) v += s_metric[w][slot];
+                    launch.metrics_out[slot] += v;
+                }
+            }
+        }
+    }
 }
 
 template <int CMAX, int AMAX, bool EXACT>

@@ -364,10 +364,14 @@ class raw_env(BatchedParallelEnv):
                     if mt:  # the streams restart from the (new) seeds; the reset launch does not touch them
                         _capi.check(lib.frz_mt19937_seed(self._bufs.mt_state, self._bufs.mt_index, self._bufs.seeds, None, 0,
                                                          self.parallel_envs, stream), 'frz_mt19937_seed')
-                _capi.check(lib.frz_wildfire_rollout_random_policy(handle, policy_seed, 0 if include_reset else done, n, actions, mode, stream),
-                            'frz_wildfire_rollout_random_policy')
-                if metrics is not None:
-                    _capi.check(lib.frz_wildfire_episode_metrics(handle, metrics.data_ptr(), stream), 'frz_wildfire_episode_metrics')
+                if metrics is not None and n > 0:  # the episode and its reductions (one launch where the library has a multi-step kernel)
+                    _capi.check(lib.frz_wildfire_rollout_random_policy_metrics(handle, policy_seed, 0 if include_reset else done, n, actions, mode,
+                                                                               metrics.data_ptr(), stream), 'frz_wildfire_rollout_random_policy_metrics')
+                else:
+                    _capi.check(lib.frz_wildfire_rollout_random_policy(handle, policy_seed, 0 if include_reset else done, n, actions, mode, stream),
+                                'frz_wildfire_rollout_random_policy')
+                    if metrics is not None:
+                        _capi.check(lib.frz_wildfire_episode_metrics(handle, metrics.data_ptr(), stream), 'frz_wildfire_episode_metrics')
                 done += n
                 if n == 0:
                     break

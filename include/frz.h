@@ -272,6 +272,11 @@ int frz_cybersecurity_focus_policy(const int64_t* tasks, int64_t env_stride, int
  * envs whose agents are all terminated or all truncated.  metrics: float64 [A + 2] on the device, accumulated in place;
  * deterministic summation order. */
 int frz_wildfire_episode_metrics(frz_wildfire_env* env, double* metrics, void* stream);
+/* frz_wildfire_rollout_random_policy followed by frz_wildfire_episode_metrics — an episode of a rollout loop and its reductions — with
+ * the same results (the float64 sums bit for bit: same summation order); where the rollout is one multi-step launch the reductions
+ * are made in that launch's tail from the values its workgroups still hold, otherwise it is the two calls. */
+int frz_wildfire_rollout_random_policy_metrics(frz_wildfire_env* env, uint64_t policy_seed, uint64_t first_step, int32_t n_steps,
+                                               int32_t* actions_out, int rng_mode, double* metrics, void* stream);
 
 /* The caller states that nothing else runs on the device while this env's rollouts do (no other process, no concurrent stream): the
  * precondition of the multi-step launch, whose workgroups wait INSIDE the kernel for the other workgroups of their own grid (the batch

@@ -671,3 +671,29 @@ def test_multi_step_launch_running_into_the_end_of_the_episode(steps):
         one.step_random_policy(policy_seed=2, policy_step=t)
     many.rollout_random_policy(3, policy_seed=2, first_step=0)
     assert_same_env(one, many, 'after a reset')
+
+
+@pytest.mark.parametrize('B,steps,max_steps', [(65536, 50, 50), (1500, 7, 50), (1500, 9, 5)])
+def test_rollout_with_metrics_equals_rollout_then_metrics(B, steps, max_steps):
+    """frz_wildfire_rollout_random_policy_metrics: the episode reductions made in the tail of the multi-step launch are, bit for bit, the
+    float64 sums frz_wildfire_episode_metrics makes afterwards (same summation order) — also when the episode ends mid-launch."""
+    from free_range_zoo_amd.utils.env import stream_ptr
+    two, one = [make_env(configs.wildfire_openness, B, max_steps, rng='philox', exact_shapes=False, track_cumulative_rewards=True) for _ in range(2)]
+    one.set_exclusive_device(True)
+    for env in (two, one):
+        env.reset(seed=torch.arange(B, dtype=torch.int32) + 11)
+    m_two = torch.full((len(two.agents) + 2, ), 0.25, dtype=torch.float64, device='cuda')
+    m_one = m_two.clone()
+    for t in range(steps):
+        two.step_random_policy(policy_seed=4, policy_step=t)
+    two.accumulate_episode_metrics(m_two)
+    assert one._lib.frz_wildfire_rollout_launches(one._handle, steps, _capi.FRZ_RNG_PHILOX) == 1
+    _capi.check(one._lib.frz_wildfire_rollout_random_policy_metrics(one._handle, 4, 0, steps, one._actions.data_ptr(), _capi.FRZ_RNG_PHILOX,
+                                                                    m_one.data_ptr(), stream_ptr(one.device)), 'frz_wildfire_rollout_random_policy_metrics')
+    torch.cuda.synchronize()
+    assert torch.equal(m_two, m_one), (m_two, m_one)
+    assert float(m_two[len(two.agents)]) == 0.25 + B * min(steps, max_steps)
+    # a second episode accumulates on top, like the standalone launch
+    two.accumulate_episode_metrics(m_two)
+    one.accumulate_episode_metrics(m_one)
+    assert torch.equal(m_two, m_one)
