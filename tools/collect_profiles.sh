@@ -10,6 +10,8 @@ python3 $GRAFT_REPO_ROOT/bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/bench
 python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $OUT/${TAG}_bench_steps20.json 2> $OUT/bench20.err || echo "bench 20 failed"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_bench -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $OUT/trace_bench.log 2>&1 || echo "trace failed"
 cp $OUT/trace_bench/bench_kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_bench20 -o bench20 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $OUT/trace_bench20.log 2>&1 || echo "trace 20 failed"
+cp $OUT/trace_bench20/bench20_kernel_stats.csv $OUT/${TAG}_bench_steps20_kernel_stats.csv 2>/dev/null
 for domain in wildfire cybersecurity rideshare; do
   for counter in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $counter --output-format csv -d $OUT/pmc_${domain}_${counter} -o pmc -- python3 $GRAFT_REPO_ROOT/tools/traffic_run.py $domain > $OUT/pmc_${domain}_${counter}.log 2>&1 || echo "pmc $domain $counter failed"

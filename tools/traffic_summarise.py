@@ -2,7 +2,7 @@
 HBM bytes per step launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB; FETCH_SIZE reports half the bytes read on gfx950, MI355X_MICROARCH.md §HBM,
 re-checked on this access pattern by tools/ubench/traffic_calib.hip), averaged over the step launches of one 50-step episode.
 usage: python tools/traffic_summarise.py <dir with pmc_<domain>_<COUNTER>/...counter_collection.csv> <round tag>"""
-import csv, glob, json, os, sys
+import csv, glob, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import source_fingerprint
@@ -22,11 +22,11 @@ def per_step(domain, counter):
         name = r['Kernel_Name']
         if r['Counter_Name'] != counter or not any(k in name for k in STEP_KERNELS[domain]):
             continue
-        head = name.split('(')[0]
-        if 'rs_env_kernel' in name and ', 1>' in head:
+        if re.search(r'rs_env_kernel<[^>]*, 1>', name):
             continue  # rebuild-mode instantiation (reset), not a step
-        if 'wf_roles_kernel' in name:
-            arguments = [a.strip() for a in head[head.index('<') + 1:head.rindex('>')].split(',')]
+        roles = re.search(r'wf_roles_kernel<([^>]*)>', name)
+        if roles:
+            arguments = [a.strip() for a in roles.group(1).split(',')]
             if arguments[4] != '0':
                 continue  # reset / rebuild mode
             # <CMAX, AMAX, EXACT, RNG, MODE, PERSIST>: a multi-step launch carries the whole 50-step episode of tools/traffic_run.py
@@ -39,12 +39,36 @@ def per_step(domain, counter):
     return total / max(steps, 1), steps
 
 
+def short_name(name):
+    """`wf_roles_kernel<6, 3, true, 1, 0, true>` out of rocprofv3's full signature."""
+    m = re.search(r'((?:wf|wg|cy|rs)_[a-z_]+kernel)(<[^>]*>)?', name)
+    return (m.group(1) + (m.group(2) or '')) if m else None
+
+
+def write_reduced(domain, counter):
+    """profiles/<tag>_pmc_<COUNTER>_<domain>_step.csv: the per-dispatch counter values of this library's kernels (one row per dispatch)."""
+    files = glob.glob(os.path.join(src, f'pmc_{domain}_{counter}', '**', '*counter_collection.csv'), recursive=True)
+    if not files:
+        return
+    path = os.path.join(ROOT, 'profiles', f'{tag}_pmc_{counter}_{domain}_step.csv')
+    with open(path, 'w', newline='') as handle:
+        w = csv.writer(handle)
+        w.writerow(['Dispatch_Id', 'Kernel', 'Grid_Size', 'Workgroup_Size', 'VGPR_Count', 'SGPR_Count', 'LDS_Block_Size', 'Counter_Name', 'Counter_Value_KiB',
+                    'Duration_ns'])
+        for r in csv.DictReader(open(files[0])):
+            kernel = short_name(r['Kernel_Name'])
+            if kernel and r['Counter_Name'] == counter:
+                w.writerow([r['Dispatch_Id'], kernel, r['Grid_Size'], r['Workgroup_Size'], r['VGPR_Count'], r['SGPR_Count'], r['LDS_Block_Size'], counter,
+                            f"{float(r['Counter_Value']):.6f}", int(r['End_Timestamp']) - int(r['Start_Timestamp'])])
+
+
 out = {'source_fingerprint': source_fingerprint(), 'round': tag,
        'how': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/traffic_run.py (one 50-step episode at B = 65536); '
               'bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB per step, all launches of a step summed',
        'corrections': 'FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md §HBM; calibration: profiles/r01_pmc_*_calibration.csv)'}
 for domain in STEP_KERNELS:
     f, w = per_step(domain, 'FETCH_SIZE'), per_step(domain, 'WRITE_SIZE')
+    write_reduced(domain, 'FETCH_SIZE'), write_reduced(domain, 'WRITE_SIZE')
     if f and w:
         out[f'{domain}_bytes_per_step'] = (2 * f[0] + w[0]) * 1024
         out[f'{domain}_read_bytes_per_env_step'] = 2 * f[0] * 1024 / 65536
