@@ -56,11 +56,11 @@ constexpr int kRound = 256;             // look-back window: a chunk sums at mos
 // PERSIST (exact shapes, FRZ_RNG_PHILOX, fused policy): launch.n_steps steps in ONE launch — the workgroup keeps its chunk's state in
 // registers from step to step and only the per-step outputs leave the CU.  What makes that legal on a part whose eight L2s are not
 // coherent with each other: (i) every array a step writes at env-indexed addresses is rewritten by the SAME workgroup at the next
-// step; (ii) the packed lists, whose addresses move between workgroups from step to step, are written THROUGH (no dirty line is
-// left in any L2) into one of two copies alternating with the step parity, the last planned step landing in the copy the caller
-// sees, and a wavefront waits for its own stores of step t-1 before its workgroup publishes anything of step t: two writes to one
-// address are then always separated by a publish -> totals -> wait chain; (iii) what crosses workgroups (chunk sums, batch totals)
-// travels in tagged granules read with agent-scope loads.  The totals of step t — which every workgroup needs before step t + 1:
+// step; (ii) the packed lists, whose addresses move between workgroups from step to step (two XCDs' L2s could end up holding dirty
+// bytes of one address from different steps, written back in any order), go to the caller's buffers only at the LAST step of the
+// launch — the one whose lists are visible afterwards — and to a second copy of those buffers, which nobody reads, at every step
+// before it (a launch that finds the batch finished early writes its last lists once more, into the caller's buffers); (iii) what
+// crosses workgroups (chunk sums, batch totals) travels in tagged granules read with agent-scope loads.  The totals of step t — which every workgroup needs before step t + 1:
 // all-done test, skip-agent quirk — are the last chunk's inclusive-prefix granules: waiting for them is the only inter-step barrier.
 template <int CMAX, int AMAX, bool EXACT, int RNG, int MODE, bool PERSIST = false>
 __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX > 8 || !EXACT || PERSIST) ? 2 : 4)) wf_roles_kernel(char* __restrict__ arena, const WfDev* __restrict__ dev,
@@ -340,10 +340,9 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
     uint64_t* const prefix = reinterpret_cast<uint64_t*>(arena + d.off_prefix);
 
     uint32_t* const error_word = reinterpret_cast<uint32_t*>(arena + d.off_error);
-    // Multi-step launch, between two steps: this wavefront's stores of the step that just ended have completed (see PERSIST above), then
-    // the totals that step left — the last chunk's inclusive-prefix granules carry its tag — replace `prev`, and the epoch advances.
+    // Multi-step launch, between two steps: the totals the step that just ended left — the last chunk's inclusive-prefix granules carry
+    // its tag — replace `prev`, and the epoch advances.
     auto await_totals = [&]() {
-        __builtin_amdgcn_s_waitcnt(0);
         epoch_now += 1u;
         const uint32_t ended = tag;
         tag = epoch_now + 1u;
@@ -367,8 +366,8 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
         }
         if (timed_out && slot == 0) atomicOr(error_word, (uint32_t)FRZ_ERR_SCAN_TIMEOUT);
     };
-    // which copy of the packed lists step t writes: the last planned step lands in the caller's buffers (byte offset 0)
-    auto list_copy = [&](int t) { return (PERSIST && ((n_steps - 1 - t) & 1)) ? launch.scratch_delta : (int64_t)0; };
+    // which copy of the packed lists step t writes: the caller's buffers (byte offset 0) at the last planned step only
+    auto list_copy = [&](int t) { return (PERSIST && t < n_steps - 1) ? launch.scratch_delta : (int64_t)0; };
     int executed = 0;
     // After barrier 5 either role can place any list of its env: the chunk's offsets (s_prefix), the sums of the chunk's
     // preceding wavefronts (s_wave_scan) and the env's position inside its wavefront (x_excl) are all in LDS.
@@ -413,13 +412,10 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
         for (int c = 0; c < CMAX; ++c) {
             const mask_t below = (mask_t)(((mask_t)1 << c) - 1);
             const int rk = popc(lit1 & below);
-            if ((ok >> c) & 1) {
-                if constexpr (PERSIST) frz::store_through(&av[popc(ok & below)], (int64_t)rk);
-                else av[popc(ok & below)] = rk;
-            } else if (show_bad && ((lit1 >> c) & 1)) {
-                if constexpr (PERSIST) frz::store_through(&bv[popc(lit1 & ~ok & below)], (int64_t)rk);
-                else bv[popc(lit1 & ~ok & below)] = rk;
-            }
+            if ((ok >> c) & 1)
+                av[popc(ok & below)] = rk;
+            else if (show_bad && ((lit1 >> c) & 1))
+                bv[popc(lit1 & ~ok & below)] = rk;
         }
     };
 
@@ -487,16 +483,9 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                         if ((lit1 >> c) & 1) {
                             const int yx = d.cell_yx[c];
                             longlong2* const row = reinterpret_cast<longlong2*>(trow + rk * 4);
-                            if constexpr (PERSIST) {  // written through: see PERSIST at the top of the kernel
-                                int64_t* const cell = trow + rk * 4;
-                                frz::store_through(cell, (int64_t)(yx >> 16)), frz::store_through(cell + 1, (int64_t)(yx & 0xFFFF));
-                                frz::store_through(cell + 2, (int64_t)f[c]), frz::store_through(cell + 3, (int64_t)in[c]);
-                                frz::store_through(&omap[rk], (int64_t)rk);
-                            } else {
-                                row[0] = make_longlong2(yx >> 16, yx & 0xFFFF);
-                                row[1] = make_longlong2(f[c], in[c]);
-                                omap[rk] = rk;
-                            }
+                            row[0] = make_longlong2(yx >> 16, yx & 0xFFFF);
+                            row[1] = make_longlong2(f[c], in[c]);
+                            omap[rk] = rk;
                         }
                     }
                 }
@@ -602,7 +591,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                 if (t > 0) await_totals();
                 if (is_frozen()) {
                     frozen_step();
-                    if (t > 0 && list_copy(t - 1) != 0) {  // the last lists went to the other copy: once more, into the caller's buffers
+                    if (t > 0) {  // the last lists went to the second copy: once more, into the caller's buffers
                         mask_t lit_last = 0;
 #pragma unroll
                         for (int c = 0; c < CMAX; ++c) lit_last |= (mask_t)(f[c] > 0) << c;
@@ -918,7 +907,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
             }
             if constexpr (PERSIST) {
                 if (stop) {  // utils/env.py:211-213: nothing more happens in this launch
-                    if (list_copy(t - 1) != 0) {  // the last lists went to the other copy: once more, into the caller's buffers
+                    {  // (t > 0 here) the last lists went to the second copy: once more, into the caller's buffers
                         mask_t ok_last[AMAX];
 #pragma unroll
                         for (int a = 0; a < AMAX; ++a)
