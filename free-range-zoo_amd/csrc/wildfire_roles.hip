@@ -342,6 +342,14 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
     uint32_t* const error_word = reinterpret_cast<uint32_t*>(arena + d.off_error);
     // Multi-step launch, between two steps: the totals the step that just ended left — the last chunk's inclusive-prefix granules carry
     // its tag — replace `prev`, and the epoch advances.
+    // (the granules are requested at the top of the step — request_totals — and looked at where the step first needs them: the memory
+    // round trip of an agent-scope load passes behind the work in between; only a wavefront that was too early polls)
+    uint64_t requested[AMAX + 3];
+    auto request_totals = [&]() {
+        const uint64_t* const last = prefix + (int64_t)(nchunks - 1) * nch;
+#pragma unroll
+        for (int i = 0; i < AMAX + 3; ++i) requested[i] = frz::granule_load(last + (i < nch ? i : 0));
+    };
     auto await_totals = [&]() {
         epoch_now += 1u;
         const uint32_t ended = tag;
@@ -353,7 +361,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
             bool all = true;
 #pragma unroll
             for (int i = 0; i < AMAX + 3; ++i) {
-                const uint64_t g = frz::granule_load(last + (i < nch ? i : 0));
+                const uint64_t g = spin == 0 ? requested[i] : frz::granule_load(last + (i < nch ? i : 0));
                 all = all && (uint32_t)(g >> 32) == ended;
                 prev[i] = (uint32_t)g;
             }
@@ -504,6 +512,9 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                 asm volatile("" ::: "memory");  // and the configuration is read from LDS where a step uses it, not once above the loop
             }
             const WfHot& d = PERSIST ? static_cast<const WfHot&>(s_cfg) : d_launch;
+            if constexpr (PERSIST) {
+                if (t > 0) request_totals();
+            }
             // ---- phase 1: the step's field draws
             float r_field[3][CMAX];
             if (MODE == kStep) {
@@ -806,6 +817,9 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                 asm volatile("" ::: "memory");  // and the configuration is read from LDS where a step uses it, not once above the loop
             }
             const WfHot& d = PERSIST ? static_cast<const WfHot&>(s_cfg) : d_launch;
+            if constexpr (PERSIST) {
+                if (t > 0) request_totals();
+            }
 #pragma unroll
             for (int a = 0; a < AMAX; ++a) rew[a] = 0.0f, hit[a] = -1, users[a] = false, refill[a] = false;
             const bool term0 = crw.term != 0, trunc0 = crw.trunc != 0;

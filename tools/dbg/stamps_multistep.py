@@ -9,7 +9,7 @@ from free_range_zoo_amd.envs import wildfire_v0
 from free_range_zoo_amd.utils.env import stream_ptr
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 env = wildfire_v0.parallel_env(configuration=configs.wildfire_openness(), parallel_envs=B, max_steps=50, device=torch.device('cuda'), rng='philox', exact_shapes=False)
-env.reset(seed=torch.arange(B, dtype=torch.int32))
+env.reset(seed=torch.arange(B, dtype=torch.int32)); env.set_exclusive_device(True)
 lib, h, s = env._lib, env._handle, stream_ptr(env.device)
 names = ['entry', 'config staged', 'epoch/totals read', 'phase 1 done', 'past barrier 1', 'phase 2 done', 'past barrier 2', 'phase 3 done', 'phase 4 done',
          'past barrier 5', 'phase 6 done']
