@@ -614,14 +614,27 @@ def assert_same_env(one, many, what):
             assert torch.equal(one._bad_map_values[a, :n], many._bad_map_values[a, :n]), f'{what}: bad-action map of agent {a}'
 
 
+def _openness_with_an_agent_out_of_range():
+    """cfg2 with firefighter_1 reaching its own (fire-free) cell only: it has no attackable task in ANY env, the batch-global condition of
+    the skip quirk (wildfire.py:434-435) — with show_bad_actions its attacks on listed fires are then ignored instead of penalised.  A
+    multi-step launch decodes before the batch totals arrive, assuming nobody is skipped: here that assumption fails at every step."""
+    from dataclasses import replace
+    cfg = configs.wildfire_openness()
+    ranges = cfg.agent_config.attack_range.clone()
+    ranges[0] = 0
+    cfg.agent_config = replace(cfg.agent_config, attack_range=ranges)
+    return cfg
+
+
 @pytest.mark.parametrize('case', [
     dict(build=configs.wildfire_openness, B=65536, max_steps=50, steps=50),           # the bench workload, one launch per episode
+    dict(build=_openness_with_an_agent_out_of_range, B=2500, max_steps=40, steps=11, kwargs=dict(show_bad_actions=True), skipped_agent=0),
     dict(build=configs.wildfire_openness, B=1000, max_steps=50, steps=7),             # ragged last chunk, odd step count
     dict(build=configs.wildfire_openness, B=3000, max_steps=40, steps=12, kwargs=dict(show_bad_actions=True, observe_other_suppressant=True, observe_other_power=True)),
     dict(build=configs.wildfire_rich, B=3000, max_steps=40, steps=6, kwargs=dict(show_bad_actions=True), launches=6),  # 4 x 5 grid: no multi-step kernel, one launch per step
     dict(build=lambda: configs.wildfire_grid(3, 3, 4), B=2048, max_steps=30, steps=9),   # 16-bit cell masks
     dict(build=lambda: configs.wildfire_grid(4, 4, 2), B=700, max_steps=30, steps=10),
-], ids=['bench', 'ragged', 'bad_actions', 'fallback_4x5', '3x3a4', '4x4a2'])
+], ids=['bench', 'skip_quirk', 'ragged', 'bad_actions', 'fallback_4x5', '3x3a4', '4x4a2'])
 def test_multi_step_launch_equals_single_step_launches(case):
     """rollout_random_policy(n) — one launch whose workgroups keep their envs in registers across the n steps — leaves exactly what n
     step_random_policy launches leave: state, rewards, observations, sampled actions, every list."""
@@ -636,6 +649,9 @@ def test_multi_step_launch_equals_single_step_launches(case):
         one.step_random_policy(policy_seed=5, policy_step=t)
     many.rollout_random_policy(case['steps'], policy_seed=5, first_step=0)
     assert_same_env(one, many, 'first rollout')
+    if 'skipped_agent' in case:  # the quirk was in force: that agent attacked listed fires it cannot reach and was never penalised
+        a = case['skipped_agent']
+        assert int(one.agent_task_count[a].max()) == 0 and bool((one._actions[a, :, 1] == 0).any())
     # and again from where it stands (policy steps continue), to cover a launch that does not start at a reset
     for t in range(case['steps'], case['steps'] + 3):
         one.step_random_policy(policy_seed=5, policy_step=t)
