@@ -344,6 +344,9 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
     // its tag — replace `prev`, and the epoch advances.
     // (the granules are requested at the top of the step — request_totals — and looked at where the step first needs them: the memory
     // round trip of an agent-scope load passes behind the work in between; only a wavefront that was too early polls)
+    // a wait that hit its bound (workgroups of this launch not resident: the device is shared after all) flags FRZ_ERR_SCAN_TIMEOUT; every
+    // later wait of the launch then gives up at once, so that a launch that cannot work ends in seconds, not minutes
+    bool gave_up = false;
     uint64_t requested[AMAX + 3];
     auto request_totals = [&]() {
         const uint64_t* const last = prefix + (int64_t)(nchunks - 1) * nch;
@@ -366,8 +369,8 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                 prev[i] = (uint32_t)g;
             }
             if (all) break;
-            if (spin >= (1 << 22)) {
-                timed_out = true;
+            if (gave_up || spin >= (1 << 20)) {
+                timed_out = gave_up = true;
                 break;
             }
             __builtin_amdgcn_s_sleep(1);
@@ -1169,8 +1172,8 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                             part += valid ? (uint32_t)g : 0u;
                         }
                         if (all) break;
-                        if (spin >= (1 << 22)) {
-                            timed_out = true;
+                        if (gave_up || spin >= (1 << 22)) {
+                            timed_out = gave_up = true;
                             break;
                         }
                         __builtin_amdgcn_s_sleep(2);
