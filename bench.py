@@ -164,6 +164,8 @@ def secondary_workloads(device, B):
     for name, module, configuration, reps in specs:
         env = module.parallel_env(configuration=configuration, parallel_envs=B, max_steps=EPISODE, device=device, rng='philox', exact_shapes=False)
         env.reset(seed=torch.arange(B, dtype=torch.int32))
+        if hasattr(env, 'set_exclusive_device'):
+            env.set_exclusive_device(True)  # N = 1, one process, one stream: multi-step launches where the library has them
         graph = env.capture_random_rollout(EPISODE, policy_seed=20260104, include_reset=True)
         graph.replay()
         torch.cuda.synchronize(device)
@@ -190,7 +192,7 @@ def secondary_workloads(device, B):
             N = env.network_config.num_nodes
             Att, D = env.attacker_config.num_attackers, env.defender_config.num_defenders
             per_env = cybersecurity_bytes_per_env_step(N, Att, D, mean_agents / N)
-            kernels = 'cy_roles_kernel (state + view roles, policy sampled in the launch)'
+            kernels = 'cy_roles_kernel (state + view roles, policy sampled in the launch; an episode is ONE multi-step launch)'
             counts = {'mean_present_agents_per_env': mean_agents / N}
         else:
             per_env = rideshare_bytes_per_env_step(A, mean_env, mean_agents)

@@ -63,6 +63,8 @@ struct CyLaunch {
     int64_t off_mt_state;  // FRZ_RNG_MT19937 inside the step: the per-env generator states, word j of env b at [j][b]
     int64_t off_lut;       // the danger table and its size (cy_roles_kernel requests it with its first loads)
     int32_t lut_entries;
+    int32_t n_steps;       // multi-step launches (cy_roles_kernel<..., PERSIST>): steps of the rollout this launch performs
+    int64_t copy_delta;    // multi-step launches: byte distance from the packed action-mapping values to their second copy
 };
 
 // (plain stores: written through, frz_device.h, the rows of this kernel gained nothing — 11.4 vs 11.3 us — most of its bytes are
@@ -555,11 +557,17 @@ __global__ void __launch_bounds__(kBlock) cy_step_kernel(char* __restrict__ aren
 // ----------------------------------------------------------------------------------------------------------------
 constexpr int kRoleBlock = 2 * kBlock;
 
-template <int NMAX, int AMAX, int ATT, int RNG>
-__global__ void __launch_bounds__(kRoleBlock) cy_roles_kernel(char* __restrict__ arena, const CyDev* __restrict__ dev,
+// PERSIST (FRZ_RNG_PHILOX, fused policy): L.n_steps steps in ONE launch, the state role keeping its envs in registers from step to step
+// (frz_cybersecurity_rollout_random_policy).  Same scheme as the wildfire field/crew kernel (wildfire_roles.hip, PERSIST): env-indexed
+// outputs are rewritten by the same workgroup every step; the packed action mappings go to the caller's buffers at the last step only
+// and to a second copy, which nobody reads, before it; the batch totals of the step that just ended (all-truncated test) arrive as the
+// last chunk's inclusive-prefix granules — requested at the top of a step, looked at before the step's first store.
+template <int NMAX, int AMAX, int ATT, int RNG, bool PERSIST = false>
+__global__ void __launch_bounds__(kRoleBlock, 2) cy_roles_kernel(char* __restrict__ arena, const CyDev* __restrict__ dev,
                                                               const int32_t* __restrict__ actions, const float* __restrict__ net_rand,
                                                               const float* __restrict__ agent_rand, const CyLaunch L) {
     static_assert(AMAX <= 8, "the danger table is staged with one load per state-role thread");
+    static_assert(!PERSIST || RNG == FRZ_RNG_PHILOX, "multi-step launches draw with Philox");
     __shared__ frz::ScanShared<AMAX> s_scan;
     __shared__ int s_ticket;
     __shared__ float s_lut[1 << AMAX];
@@ -647,8 +655,51 @@ __global__ void __launch_bounds__(kRoleBlock) cy_roles_kernel(char* __restrict__
         return;
     }
 
+    // ---- the steps of this launch (one, or L.n_steps of a multi-step launch)
+    const int n_steps = PERSIST ? L.n_steps : 1;
+    const int nch_total = A + 2;
+    uint32_t epoch_now = launch.epoch;
+    bool gave_up = false, finished = false;
+    uint64_t requested[AMAX + 2];
+    auto request_totals = [&]() {  // granules of the last chunk's inclusive prefix = the batch totals of the step that just ended
+        const uint64_t* const last = ws.prefix + (int64_t)(nchunks - 1) * nch_total;
+#pragma unroll
+        for (int i = 0; i < AMAX + 2; ++i) requested[i] = frz::granule_load(last + (i < nch_total ? i : 0));
+    };
+    auto await_totals = [&]() {  // -> finished: every env truncated (or terminated) after that step: utils/env.py:211-213
+        epoch_now += 1u;
+        const uint32_t ended = epoch_now;  // the tag that step published under
+        const uint64_t* const last = ws.prefix + (int64_t)(nchunks - 1) * nch_total;
+        uint32_t not_terminated = 1, not_truncated = 1;
+        for (int spin = 0;; ++spin) {  // bounded
+            bool all = true;
+#pragma unroll
+            for (int i = 0; i < AMAX + 2; ++i) {
+                const uint64_t g = spin == 0 ? requested[i] : frz::granule_load(last + (i < nch_total ? i : 0));
+                all = all && (uint32_t)(g >> 32) == ended;
+                not_terminated = i == A ? (uint32_t)g : not_terminated;
+                not_truncated = i == A + 1 ? (uint32_t)g : not_truncated;
+            }
+            if (all) break;
+            if (gave_up || spin >= (1 << 20)) {
+                if (!gave_up && tid == 0) atomicOr(reinterpret_cast<uint32_t*>(arena + d.off_error), (uint32_t)FRZ_ERR_SCAN_TIMEOUT);
+                gave_up = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        finished = not_terminated == 0u || not_truncated == 0u;
+    };
+
     if (view) {
         // ================================================================================================ view role
+        for (int t = 0; t < n_steps; ++t) {
+        // (no per-step opaque copies here, unlike wildfire_roles.hip: with them this kernel needs 160 instead of 219 VGPRs and is slower,
+        // 7.7 against 7.4 us per step — its row addresses are better computed once, above the step loop)
+        if constexpr (PERSIST) {
+            if (t > 0) request_totals();
+        }
+        const int nm_step = nm_in + t;
         // ---------------------------------------------------------------- the step's draws (streams: cy_step_kernel above)
         if (RNG == FRZ_RNG_INJECTED) {
 #pragma unroll
@@ -705,7 +756,7 @@ __global__ void __launch_bounds__(kRoleBlock) cy_roles_kernel(char* __restrict__
             for (int q = 0; q < (NMAX + 3) / 4; ++q) {
                 frz::Philox4 w{{0u, 0u, 0u, 0u}};
                 const bool drawn = q * 4 < N && (flags & kStochState);
-                if (drawn) w = frz::philox4x32_10((uint32_t)q, (uint32_t)nm_in, 0u, 0u, seed, 0x46525A01u);
+                if (drawn) w = frz::philox4x32_10((uint32_t)q, (uint32_t)nm_step, 0u, 0u, seed, 0x46525A01u);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (q * 4 + j < NMAX) s_draw[q * 4 + j][tid] = drawn ? frz::u32_to_unit_float(w.w[j]) : 0.0f;
@@ -714,10 +765,16 @@ __global__ void __launch_bounds__(kRoleBlock) cy_roles_kernel(char* __restrict__
             for (int q = 0; q < (AMAX + 3) / 4; ++q) {
                 frz::Philox4 w{{0u, 0u, 0u, 0u}};
                 const bool drawn = q * 4 < A;
-                if (drawn) w = frz::philox4x32_10((uint32_t)q, (uint32_t)nm_in, 1u, 0u, seed, 0x46525A01u);
+                if (drawn) w = frz::philox4x32_10((uint32_t)q, (uint32_t)nm_step, 1u, 0u, seed, 0x46525A01u);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (q * 4 + j < AMAX) s_draw[NMAX + q * 4 + j][tid] = drawn ? frz::u32_to_unit_float(w.w[j]) : 0.0f;
+            }
+        }
+        if constexpr (PERSIST) {
+            if (t > 0) {
+                await_totals();
+                if (finished) break;  // (the state role leaves at the same barrier)
             }
         }
         __syncthreads();  // (2) draws ready
@@ -800,6 +857,7 @@ __global__ void __launch_bounds__(kRoleBlock) cy_roles_kernel(char* __restrict__
             }
         }
         frz::scan_chunk_passive_back();
+        }  // steps of this launch
         return;
     }
 
@@ -819,14 +877,50 @@ __global__ void __launch_bounds__(kRoleBlock) cy_roles_kernel(char* __restrict__
     }
     bool trunc = trunc_raw != 0;
     uint32_t err = 0;
-    int nm = nm_in;
+    int nm = nm_in, executed = 0;
+    uint32_t excl[AMAX];
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) excl[a] = 0;
+    // action mapping: arange(N) while present, empty otherwise (:441-457); `copy`: byte distance to the copy of the packed values to write
+    auto emit_mappings = [&](int64_t copy) {
+        if (active) {
+            int32_t* const act_values = reinterpret_cast<int32_t*>(arena + d.off_act_values + copy);
+            int64_t* const act_offsets = reinterpret_cast<int64_t*>(arena + d.off_act_offsets);
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a) {
+                if (a < A) {
+                    const int64_t off = (int64_t)excl[a] * N;
+                    act_offsets[a * (B + 1) + b] = off;
+                    if (b == B - 1) act_offsets[a * (B + 1) + B] = off + (pres[a] ? N : 0);
+                    if (pres[a]) {
+                        int32_t* v = act_values + a * B * N + off;
+#pragma unroll
+                        for (int n = 0; n < NMAX; ++n)
+                            if (n < N) v[n] = n;
+                    }
+                }
+            }
+        }
+    };
+    for (int t = 0; t < n_steps; ++t) {
+    const int64_t copy = (PERSIST && t < n_steps - 1) ? L.copy_delta : (int64_t)0;  // the caller's buffers at the last step only
+    if constexpr (PERSIST) {
+        if (t > 0) {
+            request_totals();
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a) act_in[a] = make_int2(0, -1);
+        }
+    }
 
     if (L.policy) {  // the stream of cy_policy_kernel (see cy_step_kernel)
         frz::Philox4 policy_words[(AMAX + 3) / 4];
 #pragma unroll
         for (int q = 0; q < (AMAX + 3) / 4; ++q)
-            if (q * 4 < A) policy_words[q] = frz::philox4x32_10((uint32_t)q, 0u, L.policy_step_lo, L.policy_step_hi, L.policy_seed_lo ^ seed,
-                                                               L.policy_seed_hi);
+            if (q * 4 < A) {
+                const uint64_t policy_step = (((uint64_t)L.policy_step_hi << 32) | L.policy_step_lo) + (uint64_t)(PERSIST ? t : 0);
+                policy_words[q] = frz::philox4x32_10((uint32_t)q, 0u, (uint32_t)policy_step, (uint32_t)(policy_step >> 32), L.policy_seed_lo ^ seed,
+                                                     L.policy_seed_hi);
+            }
 #pragma unroll
         for (int a = 0; a < AMAX; ++a) {
             if (a < A) {
@@ -843,7 +937,9 @@ __global__ void __launch_bounds__(kRoleBlock) cy_roles_kernel(char* __restrict__
                 const int j = (int)(((uint64_t)policy_words[a >> 2].w[a & 3] * (uint64_t)(n + nt)) >> 32);
                 const int value = j < n ? 0 : (j - n == 0 ? -1 : (j - n == 1 ? tail1 : -3));
                 act_in[a] = make_int2(j, value);
-                if (active) reinterpret_cast<int2*>(L.actions_out)[(int64_t)a * B + b] = act_in[a];
+                if constexpr (!PERSIST) {
+                    if (active) reinterpret_cast<int2*>(L.actions_out)[(int64_t)a * B + b] = act_in[a];
+                }
             }
         }
     }
@@ -885,6 +981,30 @@ __global__ void __launch_bounds__(kRoleBlock) cy_roles_kernel(char* __restrict__
             for (int a = 0; a < AMAX; ++a) rew[a] = (a == Att + k) ? rew[a] + pr : rew[a];
             loc[k] = move ? idx : loc[k];
             last[k] = bad_target ? last[k] : act;
+        }
+    }
+    if constexpr (PERSIST) {
+        // nothing of this step has left the registers yet: now the totals of the step before it (requested above) must be here
+        if (t > 0) {
+            await_totals();
+            if (finished) {  // utils/env.py:211-213: nothing more happens in this launch
+                if (active && !at32(rows1, (uint32_t)d.u_frozen * Bu + bl)) {  // stale rewards, once (utils/conversions.py:87-90)
+                    for (int a = 0; a < A; ++a) {
+                        const float r = at32(rowsf, (uint32_t)(d.r_rewards + a) * Bu + bl);
+                        float acc = 0.0f;
+                        for (int j = 0; j < A; ++j) acc = acc + r;
+                        at32(rowsf, (uint32_t)(d.r_rewards + a) * Bu + bl) = acc;
+                    }
+                    at32(rows1, (uint32_t)d.u_frozen * Bu + bl) = 1;
+                }
+                emit_mappings(0);  // the last mappings went to the second copy: once more, into the caller's buffers
+                break;
+            }
+        }
+        if (L.policy && active) {
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a)
+                if (a < A) reinterpret_cast<int2*>(L.actions_out)[(int64_t)a * B + b] = act_in[a];
         }
     }
     __syncthreads();  // (2) draws ready
@@ -934,7 +1054,7 @@ __global__ void __launch_bounds__(kRoleBlock) cy_roles_kernel(char* __restrict__
     nm += 1;
     trunc = (flags & kTruncate) ? nm >= d.max_steps : trunc;
 
-    uint32_t cnt[AMAX], excl[AMAX];
+    uint32_t cnt[AMAX];
 #pragma unroll
     for (int a = 0; a < AMAX; ++a) cnt[a] = (active && a < A && pres[a]) ? 1u : 0u;
     if (active) {
@@ -954,32 +1074,26 @@ __global__ void __launch_bounds__(kRoleBlock) cy_roles_kernel(char* __restrict__
                 at32(rows1, (uint32_t)(d.u_presence + a) * Bu + bl) = (uint8_t)pres[a];
                 at32(rowsf, (uint32_t)(d.r_rewards + a) * Bu + bl) = r;
                 if (flags & kTruncate) at32(rows1, (uint32_t)(d.u_trunc + a) * Bu + bl) = (uint8_t)trunc;
-                if (flags & kTrackCumulative) at32(rowsf, (uint32_t)(d.r_cum + a) * Bu + bl) = __fadd_rn(cum_in[a], r);
+                if (flags & kTrackCumulative) {
+                    const float total = __fadd_rn(cum_in[a], r);
+                    at32(rowsf, (uint32_t)(d.r_cum + a) * Bu + bl) = total;
+                    if constexpr (PERSIST) cum_in[a] = total;
+                }
                 at32(rows, (uint32_t)(d.r_atc + a) * Bu + bl) = pres[a] ? N : 0;
             }
         at32(rows, (uint32_t)d.r_moves * Bu + bl) = nm;
     }
-    frz::scan_chunk<AMAX>(s_scan, ws, launch, cnt, active, active && !trunc, A, chunk, nchunks, excl, &err);
-    if (active) {  // action mapping: arange(N) while present, empty otherwise (:441-457)
-        int32_t* const act_values = reinterpret_cast<int32_t*>(arena + d.off_act_values);
-        int64_t* const act_offsets = reinterpret_cast<int64_t*>(arena + d.off_act_offsets);
-#pragma unroll
-        for (int a = 0; a < AMAX; ++a) {
-            if (a < A) {
-                const int64_t off = (int64_t)excl[a] * N;
-                act_offsets[a * (B + 1) + b] = off;
-                if (b == B - 1) act_offsets[a * (B + 1) + B] = off + (pres[a] ? N : 0);
-                if (pres[a]) {
-                    int32_t* v = act_values + a * B * N + off;
-#pragma unroll
-                    for (int n = 0; n < NMAX; ++n)
-                        if (n < N) v[n] = n;
-                }
-            }
-        }
+    {
+        const frz::ScanLaunch step{epoch_now, epoch_now + 1u, nullptr, ws.totals + (epoch_now & 1u) * frz::kTotalsStride};
+        frz::scan_chunk<AMAX>(s_scan, ws, step, cnt, active, active && !trunc, A, chunk, nchunks, excl, &err);
     }
+    emit_mappings(copy);
+    executed = t + 1;
+    }  // steps of this launch
     if (err) atomicOr(reinterpret_cast<uint32_t*>(arena + d.off_error), err);
-    frz::scan_end(ws, launch, chunk, nchunks);
+    // The workgroup that owns the last chunk finished its last look-back only after every other chunk published, i.e. after every
+    // workgroup of the launch read the epoch: it advances it, by the steps the launch executed.
+    if (executed > 0 && chunk == nchunks - 1 && threadIdx.x == 0) *ws.epoch = launch.epoch + (uint32_t)executed;
 }
 
 
@@ -1025,6 +1139,11 @@ struct frz_cybersecurity_env {
     bool ticketed = false;  // more chunks than CUs: chunks are handed out in arrival order (frz_scan.h)
     int variant = 0;
     bool roles = false;  // steps run cy_roles_kernel (shapes up to 8 nodes / 8 agents, unless FRZ_CY_KERNEL=lane)
+    // multi-step launches (frz_cybersecurity_rollout_random_policy): allowed by frz_cybersecurity_set_exclusive_device; byte distance from
+    // the packed action-mapping values to their second copy; steps of the launch being enqueued
+    bool exclusive_device = false;
+    int64_t copy_delta = 0;
+    int32_t rollout_steps = 1;
 };
 
 namespace {
@@ -1049,11 +1168,13 @@ void launch_variant(frz_cybersecurity_env* env, const int32_t* actions, const fl
     const CyDev& p = env->dev;
     const CyLaunch L{p.B, p.N, p.Att, p.D, p.A, env->ticketed ? 1u : 0u, p.off_rows1, p.off_epoch, p.off_totals, policy.on ? 1u : 0u,
                      (uint32_t)policy.seed, (uint32_t)(policy.seed >> 32), (uint32_t)policy.step, (uint32_t)(policy.step >> 32), policy.actions_out,
-                     p.off_mt_state, p.off_lut, p.lut_entries};
+                     p.off_mt_state, p.off_lut, p.lut_entries, env->rollout_steps, env->copy_delta};
     if constexpr (NMAX <= 8) {
         if (mode == kStep && env->roles) {  // state / view roles: two wavefronts per 64 envs (cy_roles_kernel)
             const dim3 wide(kRoleBlock);
-            if (rng == FRZ_RNG_PHILOX)
+            if (rng == FRZ_RNG_PHILOX && env->rollout_steps > 1)
+                hipLaunchKernelGGL((cy_roles_kernel<NMAX, AMAX, ATT, FRZ_RNG_PHILOX, true>), grid, wide, 0, stream, env->arena, dev, actions, nr, ar, L);
+            else if (rng == FRZ_RNG_PHILOX)
                 hipLaunchKernelGGL((cy_roles_kernel<NMAX, AMAX, ATT, FRZ_RNG_PHILOX>), grid, wide, 0, stream, env->arena, dev, actions, nr, ar, L);
             else if (rng == FRZ_RNG_MT19937)
                 hipLaunchKernelGGL((cy_roles_kernel<NMAX, AMAX, ATT, FRZ_RNG_MT19937>), grid, wide, 0, stream, env->arena, dev, actions, nr, ar, L);
@@ -1203,6 +1324,7 @@ int frz_cybersecurity_create(const frz_cybersecurity_cfg* cfg, frz_cybersecurity
     p.off_rand_net = take(B * N * 4);
     p.off_rand_agent = take(B * A * 4);
     p.off_mt_state = take(624 * B * 4);
+    if (env->roles) env->copy_delta = take((int64_t)A * B * N * 4) - p.off_act_values;  // second copy of the packed action-mapping values
     p.total_bytes = off;
 
     int device = 0, cus = 256;
@@ -1329,6 +1451,37 @@ static int step_impl(frz_cybersecurity_env* env, const int32_t* actions, int rng
         return FRZ_E_INVALID;
     }
     return launch(env, actions, network_randomness, agent_randomness, rng_mode, kStep, static_cast<hipStream_t>(stream), policy);
+}
+
+int frz_cybersecurity_set_exclusive_device(frz_cybersecurity_env* env, int exclusive) {
+    if (!env) return FRZ_E_INVALID;
+    env->exclusive_device = exclusive != 0;
+    return FRZ_OK;
+}
+
+int frz_cybersecurity_rollout_launches(const frz_cybersecurity_env* env, int32_t n_steps, int rng_mode) {
+    if (!env || n_steps < 0) return FRZ_E_INVALID;
+    const bool one = n_steps > 1 && env->exclusive_device && env->roles && env->copy_delta != 0 && !env->ticketed && rng_mode == FRZ_RNG_PHILOX;
+    return one ? 1 : n_steps;
+}
+
+int frz_cybersecurity_rollout_random_policy(frz_cybersecurity_env* env, uint64_t policy_seed, uint64_t first_step, int32_t n_steps,
+                                            int32_t* actions_out, int rng_mode, void* stream) {
+    if (!env || !actions_out || n_steps < 0) return FRZ_E_INVALID;
+    if (!env->arena) return FRZ_E_UNBOUND;
+    if (!env->was_reset) return FRZ_E_INVALID;
+    if (n_steps == 0) return FRZ_OK;
+    if (n_steps > 1 && frz_cybersecurity_rollout_launches(env, n_steps, rng_mode) == 1) {  // one launch, the envs in registers across its steps
+        env->rollout_steps = n_steps;
+        const int rc = frz_cybersecurity_step_random_policy(env, policy_seed, first_step, actions_out, rng_mode, nullptr, nullptr, stream);
+        env->rollout_steps = 1;
+        return rc;
+    }
+    for (int32_t t = 0; t < n_steps; ++t) {
+        const int rc = frz_cybersecurity_step_random_policy(env, policy_seed, first_step + (uint64_t)t, actions_out, rng_mode, nullptr, nullptr, stream);
+        if (rc != FRZ_OK) return rc;
+    }
+    return FRZ_OK;
 }
 
 int frz_cybersecurity_random_policy(frz_cybersecurity_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out,

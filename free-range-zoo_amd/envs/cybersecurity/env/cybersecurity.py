@@ -317,10 +317,35 @@ class raw_env(BatchedParallelEnv):
                     _capi.check(lib.frz_mt19937_seed(self._bufs.mt_state, self._bufs.mt_index, self._bufs.seeds, None, 0, self.parallel_envs,
                                                      stream), 'frz_mt19937_seed')
                 _capi.check(lib.frz_cybersecurity_reset(handle, stream), 'frz_cybersecurity_reset')
-            for t in range(steps):
-                _capi.check(lib.frz_cybersecurity_step_random_policy(handle, policy_seed, t, actions, mode, None, None, stream),
-                            'frz_cybersecurity_step_random_policy')
+            # (one multi-step launch where the library has one and the device is this env's alone: set_exclusive_device)
+            _capi.check(lib.frz_cybersecurity_rollout_random_policy(handle, policy_seed, 0, steps, actions, mode, stream),
+                        'frz_cybersecurity_rollout_random_policy')
         return graph
+
+    def set_exclusive_device(self, exclusive: bool = True) -> None:
+        """State that nothing else uses this GPU while the env's rollouts run: allows ``rollout_random_policy`` / ``capture_random_rollout`` to
+        run a rollout as ONE launch (include/frz.h: frz_cybersecurity_set_exclusive_device; see the wildfire env).  Off by default."""
+        _capi.check(self._lib.frz_cybersecurity_set_exclusive_device(self._handle, 1 if exclusive else 0), 'frz_cybersecurity_set_exclusive_device')
+
+    @torch.no_grad()
+    def rollout_random_policy(self, steps: int, policy_seed: int = 0, first_step: int = 0):
+        """``steps`` x ``step_random_policy`` (same results), enqueued by one call through the C boundary (no CSV / SQL rows: with a logger
+        the steps are taken one by one)."""
+        if not self._has_reset:
+            raise RuntimeError('reset() must be called before rollout_random_policy()')
+        if self.logger is not None or self.rng == 'mt19937' and (self.single_seeding or self.generator.buffer_size):
+            out = None
+            for t in range(steps):
+                out = self.step_random_policy(policy_seed, first_step + t)
+            return out
+        if self.rng == 'mt19937':
+            self.generator._ensure_streams()
+        mode = _capi.FRZ_RNG_MT19937 if self.rng == 'mt19937' else _capi.FRZ_RNG_PHILOX
+        _capi.check(self._lib.frz_cybersecurity_rollout_random_policy(self._handle, policy_seed, first_step, steps, self._actions.data_ptr(), mode,
+                                                                     stream_ptr(self.device)), 'frz_cybersecurity_rollout_random_policy')
+        self._publish()
+        self.infos = {agent: {} for agent in self.agents}
+        return (self._observations_out(), self.rewards, self.terminations, self.truncations, self.infos)
 
     # ------------------------------------------------------------------------------------------------ spaces
     @torch.no_grad()

@@ -391,6 +391,14 @@ int frz_cybersecurity_random_policy(frz_cybersecurity_env* env, uint64_t policy_
  * (baselines/random.py:20) without a second launch per step. */
 int frz_cybersecurity_step_random_policy(frz_cybersecurity_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out,
                                          int rng_mode, const float* network_randomness, const float* agent_randomness, void* stream);
+/* n_steps random-policy steps (policy steps first_step, first_step + 1, ...): what n_steps calls of frz_cybersecurity_step_random_policy
+ * leave; one launch per step, or — after frz_cybersecurity_set_exclusive_device(env, 1), shapes up to 8 nodes / 8 agents, FRZ_RNG_PHILOX,
+ * parallel_envs <= 256 x CUs — ONE launch whose workgroups keep their envs in registers from step to step (see
+ * frz_wildfire_rollout_random_policy / frz_wildfire_set_exclusive_device: same scheme, same precondition). */
+int frz_cybersecurity_rollout_random_policy(frz_cybersecurity_env* env, uint64_t policy_seed, uint64_t first_step, int32_t n_steps,
+                                            int32_t* actions_out, int rng_mode, void* stream);
+int frz_cybersecurity_set_exclusive_device(frz_cybersecurity_env* env, int exclusive);
+int frz_cybersecurity_rollout_launches(const frz_cybersecurity_env* env, int32_t n_steps, int rng_mode);
 
 /* ------------------------------------------------------------------------------------------------
  * Rideshare  (reference: free_range_zoo/envs/rideshare/env/rideshare.py, transitions/,

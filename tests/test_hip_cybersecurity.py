@@ -216,6 +216,7 @@ def test_fused_random_policy_step_equals_policy_then_step(rng, build, kwargs):
 def test_graph_replayed_rollout_equals_eager_rollout():
     B = 2000
     eager, replay = (make_env(configs.cyber_openness, B, 15, rng='philox') for _ in range(2))
+    replay.set_exclusive_device(True)  # the graph then holds the rollout as one multi-step launch
     seed = torch.arange(B, dtype=torch.int32) + 11
     eager.reset(seed=seed), replay.reset(seed=seed)
     graph = replay.capture_random_rollout(15, policy_seed=5, include_reset=True)
@@ -272,3 +273,50 @@ def test_runtime_shape_small_variants_match_the_oracle(oracle, shape):
         a, b = hip_snapshot(two), hip_snapshot(one)
         for key in a:
             G.assert_same(b[key], a[key], f'{shape} step {t} {key}')
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# multi-step launches: frz_cybersecurity_rollout_random_policy as ONE launch (cy_roles_kernel<..., PERSIST>)
+# ------------------------------------------------------------------------------------------------------------------
+def assert_same_rollout(one, many, what):
+    a, b = hip_snapshot(one), hip_snapshot(many)
+    for key in a:
+        G.assert_same(b[key], a[key], f'{what}: {key}')
+    for name in ('_cumulative', '_actions', '_frozen_scaled', '_act_map_offsets', 'num_moves'):
+        assert torch.equal(getattr(one, name), getattr(many, name)), f'{what}: {name}'
+
+
+@pytest.mark.parametrize('build,B,max_steps,steps,kwargs,launches', [
+    (configs.cyber_openness, 65536, 50, 50, {}, 1),                                   # the bench workload (exact <3,4,2> kernel)
+    (configs.cyber_openness, 1000, 50, 7, {}, 1),                                     # ragged last chunk
+    (configs.cyber_rich, 3000, 40, 9, dict(show_bad_actions=False), 1),               # runtime-shape kernel, every observation flag
+    (lambda: configs.cyber_grid(7, 4, 4), 1300, 30, 8, {}, 1),                        # <8,8>
+    (lambda: configs.cyber_grid(12, 5, 7), 600, 30, 5, {}, 5),                        # 16-node kernel: no multi-step launch, one per step
+    (configs.cyber_openness, 1500, 5, 8, {}, 1),                                      # every env truncated after 5 of the 8 steps
+    (configs.cyber_openness, 1500, 5, 9, {}, 1),
+], ids=['bench', 'ragged', 'rich', '7n8a', 'fallback_12n', 'ends_at_5_of_8', 'ends_at_5_of_9'])
+def test_multi_step_launch_equals_single_step_launches(build, B, max_steps, steps, kwargs, launches):
+    """rollout_random_policy(n) — one launch whose state role keeps its envs in registers across the n steps — leaves exactly what n
+    step_random_policy launches leave (state, rewards, observations, sampled actions, action mappings), also when the episode ends
+    inside the launch; off unless the caller declares the device its own."""
+    one, many = [make_env(build, B, max_steps, rng='philox', **kwargs) for _ in range(2)]
+    many.set_exclusive_device(True)
+    assert many._lib.frz_cybersecurity_rollout_launches(many._handle, steps, _capi.FRZ_RNG_PHILOX) == launches
+    assert one._lib.frz_cybersecurity_rollout_launches(one._handle, steps, _capi.FRZ_RNG_PHILOX) == steps
+    for env in (one, many):
+        env.reset(seed=torch.arange(B, dtype=torch.int32) + 5)
+    for t in range(steps):
+        one.step_random_policy(policy_seed=3, policy_step=t)
+    many.rollout_random_policy(steps, policy_seed=3, first_step=0)
+    assert_same_rollout(one, many, 'first rollout')
+    for t in range(steps, steps + 3):
+        one.step_random_policy(policy_seed=3, policy_step=t)
+    many.rollout_random_policy(3, policy_seed=3, first_step=steps)
+    assert_same_rollout(one, many, 'second rollout')
+    for env in (one, many):
+        env.reset(seed=torch.arange(B, dtype=torch.int32) + 6)
+    one.step_random_policy(policy_seed=3, policy_step=0), one.step_random_policy(policy_seed=3, policy_step=1)
+    many.rollout_random_policy(2, policy_seed=3, first_step=0)
+    assert_same_rollout(one, many, 'after a reset')
+    one.check()
+    many.check()
