@@ -11,6 +11,7 @@ B, EP = 65536, 50
 dev = torch.device('cuda')
 env = wildfire_v0.parallel_env(configuration=configs.wildfire_openness(), parallel_envs=B, max_steps=EP, device=dev, rng='philox', exact_shapes=False)
 env.reset(seed=torch.arange(B, dtype=torch.int32))
+env.set_exclusive_device(True)
 metrics = torch.zeros(len(env.agents) + 2, dtype=torch.float64, device=dev)
 lib, h, s, acts = env._lib, env._handle, stream_ptr(dev), env._actions.data_ptr()
 done = torch.cuda.Event()
@@ -28,8 +29,7 @@ for K in (20, 50, 100, 500):
         while left > 0:
             n = min(EP, left)
             lib.frz_wildfire_reset_reseed(h, 1000003, s)
-            lib.frz_wildfire_rollout_random_policy(h, 1, 0, n, acts, _capi.FRZ_RNG_PHILOX, s)
-            lib.frz_wildfire_episode_metrics(h, metrics.data_ptr(), s)
+            lib.frz_wildfire_rollout_random_policy_metrics(h, 1, 0, n, acts, _capi.FRZ_RNG_PHILOX, metrics.data_ptr(), s)
             left -= n
         wait()
     for name, f in (('graph', graph_block), ('eager', eager_block)):

@@ -12,9 +12,8 @@ module, build = {'wildfire': (wildfire_v0, configs.wildfire_openness), 'cybersec
 B = 65536
 env = module.parallel_env(configuration=build(), parallel_envs=B, max_steps=50, device=torch.device('cuda'), rng='philox', exact_shapes=False)
 env.reset(seed=torch.arange(B, dtype=torch.int32))
-if domain == 'wildfire':
+if domain in ('wildfire', 'cybersecurity'):  # the episode's steps as the bench launches them: one multi-step launch where the library has one
     env.set_exclusive_device(True)
-if domain == 'wildfire':  # the episode's steps as the bench's timed region launches them: one multi-step launch where the library has one
     env.rollout_random_policy(50, policy_seed=20260104, first_step=0)
 else:
     for t in range(50):
