@@ -694,169 +694,169 @@ __global__ void __launch_bounds__(kRoleBlock, 2) cy_roles_kernel(char* __restric
     if (view) {
         // ================================================================================================ view role
         for (int t = 0; t < n_steps; ++t) {
-        // (no per-step opaque copies here, unlike wildfire_roles.hip: with them this kernel needs 160 instead of 219 VGPRs and is slower,
-        // 7.7 against 7.4 us per step — its row addresses are better computed once, above the step loop)
-        if constexpr (PERSIST) {
-            if (t > 0) request_totals();
-        }
-        const int nm_step = nm_in + t;
-        // ---------------------------------------------------------------- the step's draws (streams: cy_step_kernel above)
-        if (RNG == FRZ_RNG_INJECTED) {
-#pragma unroll
-            for (int k = 0; k < NMAX + AMAX; ++k) s_draw[k][tid] = r_in[k];
-        } else if constexpr (RNG == FRZ_RNG_MT19937) {
-            constexpr int U = NMAX + AMAX, kN = 624, kM = 397;
-            static_assert(U <= kN - kM, "a batch must not read a word it rewrites");
-            uint32_t* const mt = reinterpret_cast<uint32_t*>(arena + L.off_mt_state);
-            const int used = N + A;
-            uint32_t w[U + 1], far[U];
-#pragma unroll
-            for (int k = 0; k <= U; ++k) {
-                int j = mti + k;
-                j -= j >= kN ? kN : 0;
-                w[k] = mt[(int64_t)j * B + bl];
+            // (no per-step opaque copies here, unlike wildfire_roles.hip: with them this kernel needs 160 instead of 219 VGPRs and is slower,
+            // 7.7 against 7.4 us per step — its row addresses are better computed once, above the step loop)
+            if constexpr (PERSIST) {
+                if (t > 0) request_totals();
             }
+            const int nm_step = nm_in + t;
+            // ---------------------------------------------------------------- the step's draws (streams: cy_step_kernel above)
+            if (RNG == FRZ_RNG_INJECTED) {
 #pragma unroll
-            for (int k = 0; k < U; ++k) {
-                int j = mti + k + kM;
-                j -= j >= kN ? kN : 0;
-                j -= j >= kN ? kN : 0;
-                far[k] = mt[(int64_t)j * B + bl];
-            }
-            float uni[U];
+                for (int k = 0; k < NMAX + AMAX; ++k) s_draw[k][tid] = r_in[k];
+            } else if constexpr (RNG == FRZ_RNG_MT19937) {
+                constexpr int U = NMAX + AMAX, kN = 624, kM = 397;
+                static_assert(U <= kN - kM, "a batch must not read a word it rewrites");
+                uint32_t* const mt = reinterpret_cast<uint32_t*>(arena + L.off_mt_state);
+                const int used = N + A;
+                uint32_t w[U + 1], far[U];
 #pragma unroll
-            for (int k = 0; k < U; ++k) {
-                const uint32_t y = (w[k] & 0x80000000u) | (w[k + 1] & 0x7fffffffu);
-                uint32_t v = far[k] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-                int j = mti + k;
-                j -= j >= kN ? kN : 0;
-                if (active && k < used) mt[(int64_t)j * B + bl] = v;
-                v ^= v >> 11;
-                v ^= (v << 7) & 0x9d2c5680u;
-                v ^= (v << 15) & 0xefc60000u;
-                v ^= v >> 18;
-                uni[k] = (float)(v & 0xFFFFFFu) * (1.0f / 16777216.0f);
-            }
-            if (active) {
-                int j = mti + used;
-                j -= j >= kN ? kN : 0;
-                at32(rows, (uint32_t)(r_seeds + 1) * Bu + bl) = j;
-            }
+                for (int k = 0; k <= U; ++k) {
+                    int j = mti + k;
+                    j -= j >= kN ? kN : 0;
+                    w[k] = mt[(int64_t)j * B + bl];
+                }
 #pragma unroll
-            for (int n = 0; n < NMAX; ++n) s_draw[n][tid] = uni[n];  // node n is draw n, agent a is draw N + a
+                for (int k = 0; k < U; ++k) {
+                    int j = mti + k + kM;
+                    j -= j >= kN ? kN : 0;
+                    j -= j >= kN ? kN : 0;
+                    far[k] = mt[(int64_t)j * B + bl];
+                }
+                float uni[U];
 #pragma unroll
-            for (int a = 0; a < AMAX; ++a) {
-                float u = 0.0f;
+                for (int k = 0; k < U; ++k) {
+                    const uint32_t y = (w[k] & 0x80000000u) | (w[k + 1] & 0x7fffffffu);
+                    uint32_t v = far[k] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                    int j = mti + k;
+                    j -= j >= kN ? kN : 0;
+                    if (active && k < used) mt[(int64_t)j * B + bl] = v;
+                    v ^= v >> 11;
+                    v ^= (v << 7) & 0x9d2c5680u;
+                    v ^= (v << 15) & 0xefc60000u;
+                    v ^= v >> 18;
+                    uni[k] = (float)(v & 0xFFFFFFu) * (1.0f / 16777216.0f);
+                }
+                if (active) {
+                    int j = mti + used;
+                    j -= j >= kN ? kN : 0;
+                    at32(rows, (uint32_t)(r_seeds + 1) * Bu + bl) = j;
+                }
 #pragma unroll
-                for (int k = 0; k < U; ++k) u = (k == N + a) ? uni[k] : u;
-                s_draw[NMAX + a][tid] = u;
-            }
-        } else {
+                for (int n = 0; n < NMAX; ++n) s_draw[n][tid] = uni[n];  // node n is draw n, agent a is draw N + a
 #pragma unroll
-            for (int q = 0; q < (NMAX + 3) / 4; ++q) {
-                frz::Philox4 w{{0u, 0u, 0u, 0u}};
-                const bool drawn = q * 4 < N && (flags & kStochState);
-                if (drawn) w = frz::philox4x32_10((uint32_t)q, (uint32_t)nm_step, 0u, 0u, seed, 0x46525A01u);
+                for (int a = 0; a < AMAX; ++a) {
+                    float u = 0.0f;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (q * 4 + j < NMAX) s_draw[q * 4 + j][tid] = drawn ? frz::u32_to_unit_float(w.w[j]) : 0.0f;
-            }
+                    for (int k = 0; k < U; ++k) u = (k == N + a) ? uni[k] : u;
+                    s_draw[NMAX + a][tid] = u;
+                }
+            } else {
 #pragma unroll
-            for (int q = 0; q < (AMAX + 3) / 4; ++q) {
-                frz::Philox4 w{{0u, 0u, 0u, 0u}};
-                const bool drawn = q * 4 < A;
-                if (drawn) w = frz::philox4x32_10((uint32_t)q, (uint32_t)nm_step, 1u, 0u, seed, 0x46525A01u);
+                for (int q = 0; q < (NMAX + 3) / 4; ++q) {
+                    frz::Philox4 w{{0u, 0u, 0u, 0u}};
+                    const bool drawn = q * 4 < N && (flags & kStochState);
+                    if (drawn) w = frz::philox4x32_10((uint32_t)q, (uint32_t)nm_step, 0u, 0u, seed, 0x46525A01u);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (q * 4 + j < AMAX) s_draw[NMAX + q * 4 + j][tid] = drawn ? frz::u32_to_unit_float(w.w[j]) : 0.0f;
-            }
-        }
-        if constexpr (PERSIST) {
-            if (t > 0) {
-                await_totals();
-                if (finished) break;  // (the state role leaves at the same barrier)
-            }
-        }
-        __syncthreads();  // (2) draws ready
-        // addresses of this env's observation rows, while the state role works
-        float* const self_att = reinterpret_cast<float*>(arena + d.off_self_att);
-        float* const self_def = reinterpret_cast<float*>(arena + d.off_self_def);
-        float* const others_att = reinterpret_cast<float*>(arena + d.off_others_att);
-        float* const others_def = reinterpret_cast<float*>(arena + d.off_others_def);
-        int64_t* const tasks = reinterpret_cast<int64_t*>(arena + d.off_tasks);
-        const bool op = (flags & kObsPower) != 0, opr = (flags & kObsPresence) != 0, ol = (flags & kObsLocation) != 0;
-        const int ka = (op ? 1 : 0) + (opr ? 1 : 0), kd = ka + (ol ? 1 : 0);
-        __syncthreads();  // (3) post-transition state ready
+                    for (int j = 0; j < 4; ++j)
+                        if (q * 4 + j < NMAX) s_draw[q * 4 + j][tid] = drawn ? frz::u32_to_unit_float(w.w[j]) : 0.0f;
+                }
 #pragma unroll
-        for (int n = 0; n < NMAX; ++n) state[n] = s_post[n][tid];
+                for (int q = 0; q < (AMAX + 3) / 4; ++q) {
+                    frz::Philox4 w{{0u, 0u, 0u, 0u}};
+                    const bool drawn = q * 4 < A;
+                    if (drawn) w = frz::philox4x32_10((uint32_t)q, (uint32_t)nm_step, 1u, 0u, seed, 0x46525A01u);
 #pragma unroll
-        for (int k = 0; k < AMAX; ++k) {
-            loc[k] = s_post[NMAX + k][tid];
-            last[k] = s_post[NMAX + AMAX + k][tid];
-        }
-        const uint32_t pres_bits = (uint32_t)s_post[NMAX + 2 * AMAX][tid];
-        bool pres[AMAX];
-#pragma unroll
-        for (int a = 0; a < AMAX; ++a) pres[a] = (pres_bits >> a) & 1u;
-        frz::scan_chunk_passive_front();
-        if (active) {
-#pragma unroll
-            for (int a = 0; a < AMAX; ++a) {
-                if (a < Att) {  // attackers: (threat, presence) (:481-484)
-                    reinterpret_cast<float2*>(self_att)[a * B + b] = make_float2(d.threat[a], pres[a] ? 1.0f : 0.0f);
-                    float* others = others_att + (a * B + b) * (int64_t)((Att - 1) * ka);
-                    int col = 0;
-#pragma unroll
-                    for (int o = 0; o < AMAX; ++o)
-                        if (o < Att && o != a) {
-                            if (op) others[col++] = d.threat[o];
-                            if (opr) others[col++] = pres[o] ? 1.0f : 0.0f;
-                        }
+                    for (int j = 0; j < 4; ++j)
+                        if (q * 4 + j < AMAX) s_draw[NMAX + q * 4 + j][tid] = drawn ? frz::u32_to_unit_float(w.w[j]) : 0.0f;
                 }
             }
+            if constexpr (PERSIST) {
+                if (t > 0) {
+                    await_totals();
+                    if (finished) break;  // (the state role leaves at the same barrier)
+                }
+            }
+            __syncthreads();  // (2) draws ready
+            // addresses of this env's observation rows, while the state role works
+            float* const self_att = reinterpret_cast<float*>(arena + d.off_self_att);
+            float* const self_def = reinterpret_cast<float*>(arena + d.off_self_def);
+            float* const others_att = reinterpret_cast<float*>(arena + d.off_others_att);
+            float* const others_def = reinterpret_cast<float*>(arena + d.off_others_def);
+            int64_t* const tasks = reinterpret_cast<int64_t*>(arena + d.off_tasks);
+            const bool op = (flags & kObsPower) != 0, opr = (flags & kObsPresence) != 0, ol = (flags & kObsLocation) != 0;
+            const int ka = (op ? 1 : 0) + (opr ? 1 : 0), kd = ka + (ol ? 1 : 0);
+            __syncthreads();  // (3) post-transition state ready
+#pragma unroll
+            for (int n = 0; n < NMAX; ++n) state[n] = s_post[n][tid];
 #pragma unroll
             for (int k = 0; k < AMAX; ++k) {
-                if (k < D) {  // defenders: (mitigation, presence, location) (:475-479)
-                    bool present_k = false;
-#pragma unroll
-                    for (int a = 0; a < AMAX; ++a) present_k = (a == Att + k) ? pres[a] : present_k;
-                    float* self = self_def + (k * B + b) * 3;
-                    self[0] = d.mitigation[k];
-                    self[1] = present_k ? 1.0f : 0.0f;
-                    self[2] = (float)loc[k];
-                    float* others = others_def + (k * B + b) * (int64_t)((D - 1) * kd);
-                    int col = 0;
-#pragma unroll
-                    for (int o = 0; o < AMAX; ++o)
-                        if (o < D && o != k) {
-                            bool present_o = false;
-#pragma unroll
-                            for (int a = 0; a < AMAX; ++a) present_o = (a == Att + o) ? pres[a] : present_o;
-                            if (op) others[col++] = d.mitigation[o];
-                            if (opr) others[col++] = present_o ? 1.0f : 0.0f;
-                            if (ol) others[col++] = (float)loc[o];
-                        }
-                }
+                loc[k] = s_post[NMAX + k][tid];
+                last[k] = s_post[NMAX + AMAX + k][tid];
             }
-            // tasks (state, criticality) per agent; a defender sees them only right after monitoring (:497, :510-511)
+            const uint32_t pres_bits = (uint32_t)s_post[NMAX + 2 * AMAX][tid];
+            bool pres[AMAX];
 #pragma unroll
-            for (int a = 0; a < AMAX; ++a) {
-                if (a < A) {
-                    bool hidden = false;
-                    if (flags & kPartial) {
+            for (int a = 0; a < AMAX; ++a) pres[a] = (pres_bits >> a) & 1u;
+            frz::scan_chunk_passive_front();
+            if (active) {
 #pragma unroll
-                        for (int k = 0; k < AMAX; ++k) hidden = (a == Att + k && k < D) ? last[k] != -3 : hidden;
+                for (int a = 0; a < AMAX; ++a) {
+                    if (a < Att) {  // attackers: (threat, presence) (:481-484)
+                        reinterpret_cast<float2*>(self_att)[a * B + b] = make_float2(d.threat[a], pres[a] ? 1.0f : 0.0f);
+                        float* others = others_att + (a * B + b) * (int64_t)((Att - 1) * ka);
+                        int col = 0;
+#pragma unroll
+                        for (int o = 0; o < AMAX; ++o)
+                            if (o < Att && o != a) {
+                                if (op) others[col++] = d.threat[o];
+                                if (opr) others[col++] = pres[o] ? 1.0f : 0.0f;
+                            }
                     }
-                    int64_t* t = tasks + (a * B + b) * (int64_t)(N * 2);
+                }
 #pragma unroll
-                    for (int n = 0; n < NMAX; ++n)
-                        if (n < N)
-                            reinterpret_cast<longlong2*>(t)[n] =
-                                hidden ? make_longlong2(-100, -100) : make_longlong2(state[n], d.criticality[n]);
+                for (int k = 0; k < AMAX; ++k) {
+                    if (k < D) {  // defenders: (mitigation, presence, location) (:475-479)
+                        bool present_k = false;
+#pragma unroll
+                        for (int a = 0; a < AMAX; ++a) present_k = (a == Att + k) ? pres[a] : present_k;
+                        float* self = self_def + (k * B + b) * 3;
+                        self[0] = d.mitigation[k];
+                        self[1] = present_k ? 1.0f : 0.0f;
+                        self[2] = (float)loc[k];
+                        float* others = others_def + (k * B + b) * (int64_t)((D - 1) * kd);
+                        int col = 0;
+#pragma unroll
+                        for (int o = 0; o < AMAX; ++o)
+                            if (o < D && o != k) {
+                                bool present_o = false;
+#pragma unroll
+                                for (int a = 0; a < AMAX; ++a) present_o = (a == Att + o) ? pres[a] : present_o;
+                                if (op) others[col++] = d.mitigation[o];
+                                if (opr) others[col++] = present_o ? 1.0f : 0.0f;
+                                if (ol) others[col++] = (float)loc[o];
+                            }
+                    }
+                }
+                // tasks (state, criticality) per agent; a defender sees them only right after monitoring (:497, :510-511)
+#pragma unroll
+                for (int a = 0; a < AMAX; ++a) {
+                    if (a < A) {
+                        bool hidden = false;
+                        if (flags & kPartial) {
+#pragma unroll
+                            for (int k = 0; k < AMAX; ++k) hidden = (a == Att + k && k < D) ? last[k] != -3 : hidden;
+                        }
+                        int64_t* t = tasks + (a * B + b) * (int64_t)(N * 2);
+#pragma unroll
+                        for (int n = 0; n < NMAX; ++n)
+                            if (n < N)
+                                reinterpret_cast<longlong2*>(t)[n] =
+                                    hidden ? make_longlong2(-100, -100) : make_longlong2(state[n], d.criticality[n]);
+                    }
                 }
             }
-        }
-        frz::scan_chunk_passive_back();
+            frz::scan_chunk_passive_back();
         }  // steps of this launch
         return;
     }
@@ -903,192 +903,192 @@ __global__ void __launch_bounds__(kRoleBlock, 2) cy_roles_kernel(char* __restric
         }
     };
     for (int t = 0; t < n_steps; ++t) {
-    const int64_t copy = (PERSIST && t < n_steps - 1) ? L.copy_delta : (int64_t)0;  // the caller's buffers at the last step only
-    if constexpr (PERSIST) {
-        if (t > 0) {
-            request_totals();
+        const int64_t copy = (PERSIST && t < n_steps - 1) ? L.copy_delta : (int64_t)0;  // the caller's buffers at the last step only
+        if constexpr (PERSIST) {
+            if (t > 0) {
+                request_totals();
 #pragma unroll
-            for (int a = 0; a < AMAX; ++a) act_in[a] = make_int2(0, -1);
-        }
-    }
-
-    if (L.policy) {  // the stream of cy_policy_kernel (see cy_step_kernel)
-        frz::Philox4 policy_words[(AMAX + 3) / 4];
-#pragma unroll
-        for (int q = 0; q < (AMAX + 3) / 4; ++q)
-            if (q * 4 < A) {
-                const uint64_t policy_step = (((uint64_t)L.policy_step_hi << 32) | L.policy_step_lo) + (uint64_t)(PERSIST ? t : 0);
-                policy_words[q] = frz::philox4x32_10((uint32_t)q, 0u, (uint32_t)policy_step, (uint32_t)(policy_step >> 32), L.policy_seed_lo ^ seed,
-                                                     L.policy_seed_hi);
+                for (int a = 0; a < AMAX; ++a) act_in[a] = make_int2(0, -1);
             }
+        }
+
+        if (L.policy) {  // the stream of cy_policy_kernel (see cy_step_kernel)
+            frz::Philox4 policy_words[(AMAX + 3) / 4];
+#pragma unroll
+            for (int q = 0; q < (AMAX + 3) / 4; ++q)
+                if (q * 4 < A) {
+                    const uint64_t policy_step = (((uint64_t)L.policy_step_hi << 32) | L.policy_step_lo) + (uint64_t)(PERSIST ? t : 0);
+                    policy_words[q] = frz::philox4x32_10((uint32_t)q, 0u, (uint32_t)policy_step, (uint32_t)(policy_step >> 32), L.policy_seed_lo ^ seed,
+                                                         L.policy_seed_hi);
+                }
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a) {
+                if (a < A) {
+                    const int n = (flags & kShowBad) ? N : (pres[a] ? N : 0);
+                    int tail1 = -3, nt = 1;
+                    if (a >= Att && n > 0) {
+                        int home_loc = 0;
+#pragma unroll
+                        for (int k = 0; k < AMAX; ++k) home_loc = (a == Att + k) ? loc[k] : home_loc;
+                        const bool patchable = (flags & kShowBad) || home_loc != -1;
+                        tail1 = patchable ? -2 : -3;
+                        nt = patchable ? 3 : 2;
+                    }
+                    const int j = (int)(((uint64_t)policy_words[a >> 2].w[a & 3] * (uint64_t)(n + nt)) >> 32);
+                    const int value = j < n ? 0 : (j - n == 0 ? -1 : (j - n == 1 ? tail1 : -3));
+                    act_in[a] = make_int2(j, value);
+                    if constexpr (!PERSIST) {
+                        if (active) reinterpret_cast<int2*>(L.actions_out)[(int64_t)a * B + b] = act_in[a];
+                    }
+                }
+            }
+        }
+        // --------------------------------------------------- action decode (cybersecurity.py:326-384), agent order
+        uint32_t attack_set[NMAX], patch_set[NMAX];
+#pragma unroll
+        for (int n = 0; n < NMAX; ++n) attack_set[n] = patch_set[n] = 0u;
+        float rew[AMAX];
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a) {
+            rew[a] = 0.0f;
+            if (a < A) {
+                const int2 v = act_in[a];
+                const int idx = v.x, act = v.y;
+                const bool bad_target = act == 0 && (idx < 0 || idx >= N);
+                if (bad_target && active) err |= FRZ_ERR_INVALID_TARGET;
+                if (!bad_target && !(flags & kShowBad) && !pres[a] && act != -1 && active) err |= FRZ_ERR_ABSENT_ACTION;
+                if (a < Att) {
+                    const bool attack = act == 0 && !bad_target;
+#pragma unroll
+                    for (int n = 0; n < NMAX; ++n) attack_set[n] |= (attack && idx == n) ? (1u << a) : 0u;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < AMAX; ++k) {
+            if (k < D) {
+                int2 v = make_int2(0, -1);
+#pragma unroll
+                for (int a = 0; a < AMAX; ++a) v = (a == Att + k) ? act_in[a] : v;
+                const int idx = v.x, act = v.y;
+                const bool bad_target = act == 0 && (idx < 0 || idx >= N);
+                const bool move = act == 0 && !bad_target;
+                const bool patch = act == -2 && loc[k] != -1 && !bad_target;
+#pragma unroll
+                for (int n = 0; n < NMAX; ++n) patch_set[n] |= (patch && loc[k] == n) ? (1u << k) : 0u;
+                const float pr = patch ? d.patch_reward : 0.0f;
+#pragma unroll
+                for (int a = 0; a < AMAX; ++a) rew[a] = (a == Att + k) ? rew[a] + pr : rew[a];
+                loc[k] = move ? idx : loc[k];
+                last[k] = bad_target ? last[k] : act;
+            }
+        }
+        if constexpr (PERSIST) {
+            // nothing of this step has left the registers yet: now the totals of the step before it (requested above) must be here
+            if (t > 0) {
+                await_totals();
+                if (finished) {  // utils/env.py:211-213: nothing more happens in this launch
+                    if (active && !at32(rows1, (uint32_t)d.u_frozen * Bu + bl)) {  // stale rewards, once (utils/conversions.py:87-90)
+                        for (int a = 0; a < A; ++a) {
+                            const float r = at32(rowsf, (uint32_t)(d.r_rewards + a) * Bu + bl);
+                            float acc = 0.0f;
+                            for (int j = 0; j < A; ++j) acc = acc + r;
+                            at32(rowsf, (uint32_t)(d.r_rewards + a) * Bu + bl) = acc;
+                        }
+                        at32(rows1, (uint32_t)d.u_frozen * Bu + bl) = 1;
+                    }
+                    emit_mappings(0);  // the last mappings went to the second copy: once more, into the caller's buffers
+                    break;
+                }
+            }
+            if (L.policy && active) {
+#pragma unroll
+                for (int a = 0; a < AMAX; ++a)
+                    if (a < A) reinterpret_cast<int2*>(L.actions_out)[(int64_t)a * B + b] = act_in[a];
+            }
+        }
+        __syncthreads();  // (2) draws ready
+        // ------------------------------------------------- presence (transitions/presence.py:46-58), same draw for both tests
 #pragma unroll
         for (int a = 0; a < AMAX; ++a) {
             if (a < A) {
-                const int n = (flags & kShowBad) ? N : (pres[a] ? N : 0);
-                int tail1 = -3, nt = 1;
-                if (a >= Att && n > 0) {
-                    int home_loc = 0;
+                const float u = s_draw[NMAX + a][tid];
+                const bool ret = !pres[a] && u < d.back[a];
+                const bool leave = pres[a] && u >= d.persist[a];
+                pres[a] = ret ? true : (leave ? false : pres[a]);
 #pragma unroll
-                    for (int k = 0; k < AMAX; ++k) home_loc = (a == Att + k) ? loc[k] : home_loc;
-                    const bool patchable = (flags & kShowBad) || home_loc != -1;
-                    tail1 = patchable ? -2 : -3;
-                    nt = patchable ? 3 : 2;
-                }
-                const int j = (int)(((uint64_t)policy_words[a >> 2].w[a & 3] * (uint64_t)(n + nt)) >> 32);
-                const int value = j < n ? 0 : (j - n == 0 ? -1 : (j - n == 1 ? tail1 : -3));
-                act_in[a] = make_int2(j, value);
-                if constexpr (!PERSIST) {
-                    if (active) reinterpret_cast<int2*>(L.actions_out)[(int64_t)a * B + b] = act_in[a];
-                }
+                for (int k = 0; k < AMAX; ++k) loc[k] = (ret && a == Att + k) ? -1 : loc[k];
             }
         }
-    }
-    // --------------------------------------------------- action decode (cybersecurity.py:326-384), agent order
-    uint32_t attack_set[NMAX], patch_set[NMAX];
+        // ------------------------------------------------- subnetwork transition (transitions/subnetwork.py:53-70)
+        float net_reward = 0.0f;
 #pragma unroll
-    for (int n = 0; n < NMAX; ++n) attack_set[n] = patch_set[n] = 0u;
-    float rew[AMAX];
-#pragma unroll
-    for (int a = 0; a < AMAX; ++a) {
-        rew[a] = 0.0f;
-        if (a < A) {
-            const int2 v = act_in[a];
-            const int idx = v.x, act = v.y;
-            const bool bad_target = act == 0 && (idx < 0 || idx >= N);
-            if (bad_target && active) err |= FRZ_ERR_INVALID_TARGET;
-            if (!bad_target && !(flags & kShowBad) && !pres[a] && act != -1 && active) err |= FRZ_ERR_ABSENT_ACTION;
-            if (a < Att) {
-                const bool attack = act == 0 && !bad_target;
-#pragma unroll
-                for (int n = 0; n < NMAX; ++n) attack_set[n] |= (attack && idx == n) ? (1u << a) : 0u;
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < AMAX; ++k) {
-        if (k < D) {
-            int2 v = make_int2(0, -1);
-#pragma unroll
-            for (int a = 0; a < AMAX; ++a) v = (a == Att + k) ? act_in[a] : v;
-            const int idx = v.x, act = v.y;
-            const bool bad_target = act == 0 && (idx < 0 || idx >= N);
-            const bool move = act == 0 && !bad_target;
-            const bool patch = act == -2 && loc[k] != -1 && !bad_target;
-#pragma unroll
-            for (int n = 0; n < NMAX; ++n) patch_set[n] |= (patch && loc[k] == n) ? (1u << k) : 0u;
-            const float pr = patch ? d.patch_reward : 0.0f;
-#pragma unroll
-            for (int a = 0; a < AMAX; ++a) rew[a] = (a == Att + k) ? rew[a] + pr : rew[a];
-            loc[k] = move ? idx : loc[k];
-            last[k] = bad_target ? last[k] : act;
-        }
-    }
-    if constexpr (PERSIST) {
-        // nothing of this step has left the registers yet: now the totals of the step before it (requested above) must be here
-        if (t > 0) {
-            await_totals();
-            if (finished) {  // utils/env.py:211-213: nothing more happens in this launch
-                if (active && !at32(rows1, (uint32_t)d.u_frozen * Bu + bl)) {  // stale rewards, once (utils/conversions.py:87-90)
-                    for (int a = 0; a < A; ++a) {
-                        const float r = at32(rowsf, (uint32_t)(d.r_rewards + a) * Bu + bl);
-                        float acc = 0.0f;
-                        for (int j = 0; j < A; ++j) acc = acc + r;
-                        at32(rowsf, (uint32_t)(d.r_rewards + a) * Bu + bl) = acc;
-                    }
-                    at32(rows1, (uint32_t)d.u_frozen * Bu + bl) = 1;
+        for (int n = 0; n < NMAX; ++n) {
+            if (n < N) {
+                const uint32_t index = (patch_set[n] << Att) | attack_set[n];
+                const float danger = s_lut[index];
+                bool better = danger > 0.0f, worse = danger < 0.0f;
+                if (flags & kStochState) {
+                    const bool gate = fabsf(danger) <= s_draw[n][tid];
+                    better = better && gate;
+                    worse = worse && gate;
                 }
-                emit_mappings(0);  // the last mappings went to the second copy: once more, into the caller's buffers
-                break;
+                int s = state[n] - (better ? 1 : 0) + (worse ? 1 : 0);
+                s = s < 0 ? 0 : (s > d.S - 1 ? d.S - 1 : s);
+                state[n] = s;
+                net_reward = __fadd_rn(net_reward, __fmul_rn(cfg_lds->state_rewards[s], (float)d.criticality[n]));
             }
         }
-        if (L.policy && active) {
+        uint32_t pres_bits = 0;
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a) pres_bits |= pres[a] ? (1u << a) : 0u;
+#pragma unroll
+        for (int n = 0; n < NMAX; ++n) s_post[n][tid] = state[n];
+#pragma unroll
+        for (int k = 0; k < AMAX; ++k) {
+            s_post[NMAX + k][tid] = loc[k];
+            s_post[NMAX + AMAX + k][tid] = last[k];
+        }
+        s_post[NMAX + 2 * AMAX][tid] = (int)pres_bits;
+        __syncthreads();  // (3) post-transition state ready
+        nm += 1;
+        trunc = (flags & kTruncate) ? nm >= d.max_steps : trunc;
+
+        uint32_t cnt[AMAX];
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a) cnt[a] = (active && a < A && pres[a]) ? 1u : 0u;
+        if (active) {
+#pragma unroll
+            for (int n = 0; n < NMAX; ++n)
+                if (n < N) at32(rows, (uint32_t)(d.r_state + n) * Bu + bl) = state[n];
+#pragma unroll
+            for (int k = 0; k < AMAX; ++k)
+                if (k < D) {
+                    at32(rows, (uint32_t)(d.r_loc + k) * Bu + bl) = loc[k];
+                    at32(rows, (uint32_t)(d.r_last + k) * Bu + bl) = last[k];
+                }
 #pragma unroll
             for (int a = 0; a < AMAX; ++a)
-                if (a < A) reinterpret_cast<int2*>(L.actions_out)[(int64_t)a * B + b] = act_in[a];
-        }
-    }
-    __syncthreads();  // (2) draws ready
-    // ------------------------------------------------- presence (transitions/presence.py:46-58), same draw for both tests
-#pragma unroll
-    for (int a = 0; a < AMAX; ++a) {
-        if (a < A) {
-            const float u = s_draw[NMAX + a][tid];
-            const bool ret = !pres[a] && u < d.back[a];
-            const bool leave = pres[a] && u >= d.persist[a];
-            pres[a] = ret ? true : (leave ? false : pres[a]);
-#pragma unroll
-            for (int k = 0; k < AMAX; ++k) loc[k] = (ret && a == Att + k) ? -1 : loc[k];
-        }
-    }
-    // ------------------------------------------------- subnetwork transition (transitions/subnetwork.py:53-70)
-    float net_reward = 0.0f;
-#pragma unroll
-    for (int n = 0; n < NMAX; ++n) {
-        if (n < N) {
-            const uint32_t index = (patch_set[n] << Att) | attack_set[n];
-            const float danger = s_lut[index];
-            bool better = danger > 0.0f, worse = danger < 0.0f;
-            if (flags & kStochState) {
-                const bool gate = fabsf(danger) <= s_draw[n][tid];
-                better = better && gate;
-                worse = worse && gate;
-            }
-            int s = state[n] - (better ? 1 : 0) + (worse ? 1 : 0);
-            s = s < 0 ? 0 : (s > d.S - 1 ? d.S - 1 : s);
-            state[n] = s;
-            net_reward = __fadd_rn(net_reward, __fmul_rn(cfg_lds->state_rewards[s], (float)d.criticality[n]));
-        }
-    }
-    uint32_t pres_bits = 0;
-#pragma unroll
-    for (int a = 0; a < AMAX; ++a) pres_bits |= pres[a] ? (1u << a) : 0u;
-#pragma unroll
-    for (int n = 0; n < NMAX; ++n) s_post[n][tid] = state[n];
-#pragma unroll
-    for (int k = 0; k < AMAX; ++k) {
-        s_post[NMAX + k][tid] = loc[k];
-        s_post[NMAX + AMAX + k][tid] = last[k];
-    }
-    s_post[NMAX + 2 * AMAX][tid] = (int)pres_bits;
-    __syncthreads();  // (3) post-transition state ready
-    nm += 1;
-    trunc = (flags & kTruncate) ? nm >= d.max_steps : trunc;
-
-    uint32_t cnt[AMAX];
-#pragma unroll
-    for (int a = 0; a < AMAX; ++a) cnt[a] = (active && a < A && pres[a]) ? 1u : 0u;
-    if (active) {
-#pragma unroll
-        for (int n = 0; n < NMAX; ++n)
-            if (n < N) at32(rows, (uint32_t)(d.r_state + n) * Bu + bl) = state[n];
-#pragma unroll
-        for (int k = 0; k < AMAX; ++k)
-            if (k < D) {
-                at32(rows, (uint32_t)(d.r_loc + k) * Bu + bl) = loc[k];
-                at32(rows, (uint32_t)(d.r_last + k) * Bu + bl) = last[k];
-            }
-#pragma unroll
-        for (int a = 0; a < AMAX; ++a)
-            if (a < A) {
-                const float r = a < Att ? __fadd_rn(rew[a], __fmul_rn(net_reward, -1.0f)) : __fadd_rn(rew[a], net_reward);
-                at32(rows1, (uint32_t)(d.u_presence + a) * Bu + bl) = (uint8_t)pres[a];
-                at32(rowsf, (uint32_t)(d.r_rewards + a) * Bu + bl) = r;
-                if (flags & kTruncate) at32(rows1, (uint32_t)(d.u_trunc + a) * Bu + bl) = (uint8_t)trunc;
-                if (flags & kTrackCumulative) {
-                    const float total = __fadd_rn(cum_in[a], r);
-                    at32(rowsf, (uint32_t)(d.r_cum + a) * Bu + bl) = total;
-                    if constexpr (PERSIST) cum_in[a] = total;
+                if (a < A) {
+                    const float r = a < Att ? __fadd_rn(rew[a], __fmul_rn(net_reward, -1.0f)) : __fadd_rn(rew[a], net_reward);
+                    at32(rows1, (uint32_t)(d.u_presence + a) * Bu + bl) = (uint8_t)pres[a];
+                    at32(rowsf, (uint32_t)(d.r_rewards + a) * Bu + bl) = r;
+                    if (flags & kTruncate) at32(rows1, (uint32_t)(d.u_trunc + a) * Bu + bl) = (uint8_t)trunc;
+                    if (flags & kTrackCumulative) {
+                        const float total = __fadd_rn(cum_in[a], r);
+                        at32(rowsf, (uint32_t)(d.r_cum + a) * Bu + bl) = total;
+                        if constexpr (PERSIST) cum_in[a] = total;
+                    }
+                    at32(rows, (uint32_t)(d.r_atc + a) * Bu + bl) = pres[a] ? N : 0;
                 }
-                at32(rows, (uint32_t)(d.r_atc + a) * Bu + bl) = pres[a] ? N : 0;
-            }
-        at32(rows, (uint32_t)d.r_moves * Bu + bl) = nm;
-    }
-    {
-        const frz::ScanLaunch step{epoch_now, epoch_now + 1u, nullptr, ws.totals + (epoch_now & 1u) * frz::kTotalsStride};
-        frz::scan_chunk<AMAX>(s_scan, ws, step, cnt, active, active && !trunc, A, chunk, nchunks, excl, &err);
-    }
-    emit_mappings(copy);
-    executed = t + 1;
+            at32(rows, (uint32_t)d.r_moves * Bu + bl) = nm;
+        }
+        {
+            const frz::ScanLaunch step{epoch_now, epoch_now + 1u, nullptr, ws.totals + (epoch_now & 1u) * frz::kTotalsStride};
+            frz::scan_chunk<AMAX>(s_scan, ws, step, cnt, active, active && !trunc, A, chunk, nchunks, excl, &err);
+        }
+        emit_mappings(copy);
+        executed = t + 1;
     }  // steps of this launch
     if (err) atomicOr(reinterpret_cast<uint32_t*>(arena + d.off_error), err);
     // The workgroup that owns the last chunk finished its last look-back only after every other chunk published, i.e. after every

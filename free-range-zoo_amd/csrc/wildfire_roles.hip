@@ -502,276 +502,276 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                 }
             };
             for (int t = 0; t < n_steps; ++t) {
-            const int64_t copy = list_copy(t);
-            // per-step opaque copies: the flag tests stay next to their uses, and in a multi-step launch so do the row addresses — hoisted
-            // out of the step loop, the ~100 store addresses and ~40 row bases of a step would all be live from the top of the kernel
-            // (256 VGPRs, >100 spilled scalars)
-            uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)flags_word);
-            asm volatile("" : "+s"(flags));
-            uint32_t bl = bl_launch, Bu = Bu_launch;
-            if constexpr (PERSIST) {
-                asm volatile("" : "+v"(bl));
-                asm volatile("" : "+s"(Bu));
-                asm volatile("" ::: "memory");  // and the configuration is read from LDS where a step uses it, not once above the loop
-            }
-            const WfHot& d = PERSIST ? static_cast<const WfHot&>(s_cfg) : d_launch;
-            if constexpr (PERSIST) {
-                if (t > 0) request_totals();
-            }
-            // ---- phase 1: the step's field draws
-            float r_field[3][CMAX];
-            if (MODE == kStep) {
-                if constexpr (kInjected) {
-#pragma unroll
-                    for (int e = 0; e < 3; ++e)
-#pragma unroll
-                        for (int c = 0; c < CMAX; ++c) r_field[e][c] = fdraws.r[e][c];
-                } else if constexpr (kPhilox) {
-                    if (PERSIST && t > 0) {  // drawn while this role waited for the previous step's hand-off (below)
+                const int64_t copy = list_copy(t);
+                // per-step opaque copies: the flag tests stay next to their uses, and in a multi-step launch so do the row addresses — hoisted
+                // out of the step loop, the ~100 store addresses and ~40 row bases of a step would all be live from the top of the kernel
+                // (256 VGPRs, >100 spilled scalars)
+                uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)flags_word);
+                asm volatile("" : "+s"(flags));
+                uint32_t bl = bl_launch, Bu = Bu_launch;
+                if constexpr (PERSIST) {
+                    asm volatile("" : "+v"(bl));
+                    asm volatile("" : "+s"(Bu));
+                    asm volatile("" ::: "memory");  // and the configuration is read from LDS where a step uses it, not once above the loop
+                }
+                const WfHot& d = PERSIST ? static_cast<const WfHot&>(s_cfg) : d_launch;
+                if constexpr (PERSIST) {
+                    if (t > 0) request_totals();
+                }
+                // ---- phase 1: the step's field draws
+                float r_field[3][CMAX];
+                if (MODE == kStep) {
+                    if constexpr (kInjected) {
 #pragma unroll
                         for (int e = 0; e < 3; ++e)
 #pragma unroll
-                            for (int c = 0; c < CMAX; ++c) r_field[e][c] = next_field[e][c];
+                            for (int c = 0; c < CMAX; ++c) r_field[e][c] = fdraws.r[e][c];
+                    } else if constexpr (kPhilox) {
+                        if (PERSIST && t > 0) {  // drawn while this role waited for the previous step's hand-off (below)
 #pragma unroll
-                        for (int i = 0; i < 5 * AMAX; ++i) x_draw[i][slot] = next_agent[i];
-                    } else {
-                        float agent_draws[5 * AMAX];
-                        philox_draws(fld.nm, flags, r_field, agent_draws);
+                            for (int e = 0; e < 3; ++e)
 #pragma unroll
-                        for (int i = 0; i < 5 * AMAX; ++i) x_draw[i][slot] = agent_draws[i];
-                    }
-                } else if constexpr (kMt) {
-                    // FRZ_RNG_MT19937: the env's own MT19937 stream (mt19937.hip: state word j of env b at [j][b], twisted
-                    // lazily, one word per draw), bit-identical to the reference's per-env torch CPU generator.  The step
-                    // draws U consecutive floats: generate(B, 3, (H, W)) then generate(B, 5, (A,)) (wildfire.py:409-410), i.e.
-                    // field event e of cell c is draw e * HW + c, agent event e of agent a is draw 3 * HW + e * A + a.
-                    // U <= 227, so no word read here is rewritten by this batch: every load is issued before the first use.
-                    constexpr int U = 3 * CMAX + 5 * AMAX, kN = 624, kM = 397;
-                    static_assert(U <= kN - kM, "a batch must not read a word it rewrites");
-                    uint32_t* const mt = reinterpret_cast<uint32_t*>(arena + launch.off_mt_state);
-                    const int i0 = fld.mti;
-                    uint32_t w[U + 1], far[U];
+                                for (int c = 0; c < CMAX; ++c) r_field[e][c] = next_field[e][c];
 #pragma unroll
-                    for (int k = 0; k <= U; ++k) {
-                        int j = i0 + k;
-                        j -= j >= kN ? kN : 0;
-                        w[k] = mt[(int64_t)j * B + bl];
-                    }
+                            for (int i = 0; i < 5 * AMAX; ++i) x_draw[i][slot] = next_agent[i];
+                        } else {
+                            float agent_draws[5 * AMAX];
+                            philox_draws(fld.nm, flags, r_field, agent_draws);
 #pragma unroll
-                    for (int k = 0; k < U; ++k) {
-                        int j = i0 + k + kM;
-                        j -= j >= kN ? kN : 0;
-                        far[k] = mt[(int64_t)j * B + bl];
-                    }
-                    float uni[U];
+                            for (int i = 0; i < 5 * AMAX; ++i) x_draw[i][slot] = agent_draws[i];
+                        }
+                    } else if constexpr (kMt) {
+                        // FRZ_RNG_MT19937: the env's own MT19937 stream (mt19937.hip: state word j of env b at [j][b], twisted
+                        // lazily, one word per draw), bit-identical to the reference's per-env torch CPU generator.  The step
+                        // draws U consecutive floats: generate(B, 3, (H, W)) then generate(B, 5, (A,)) (wildfire.py:409-410), i.e.
+                        // field event e of cell c is draw e * HW + c, agent event e of agent a is draw 3 * HW + e * A + a.
+                        // U <= 227, so no word read here is rewritten by this batch: every load is issued before the first use.
+                        constexpr int U = 3 * CMAX + 5 * AMAX, kN = 624, kM = 397;
+                        static_assert(U <= kN - kM, "a batch must not read a word it rewrites");
+                        uint32_t* const mt = reinterpret_cast<uint32_t*>(arena + launch.off_mt_state);
+                        const int i0 = fld.mti;
+                        uint32_t w[U + 1], far[U];
 #pragma unroll
-                    for (int k = 0; k < U; ++k) {
-                        const uint32_t y = (w[k] & 0x80000000u) | (w[k + 1] & 0x7fffffffu);
-                        uint32_t v = far[k] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-                        int j = i0 + k;
-                        j -= j >= kN ? kN : 0;
-                        mt[(int64_t)j * B + bl] = v;
-                        v ^= v >> 11;
-                        v ^= (v << 7) & 0x9d2c5680u;
-                        v ^= (v << 15) & 0xefc60000u;
-                        v ^= v >> 18;
-                        uni[k] = (float)(v & 0xFFFFFFu) * (1.0f / 16777216.0f);
+                        for (int k = 0; k <= U; ++k) {
+                            int j = i0 + k;
+                            j -= j >= kN ? kN : 0;
+                            w[k] = mt[(int64_t)j * B + bl];
+                        }
+#pragma unroll
+                        for (int k = 0; k < U; ++k) {
+                            int j = i0 + k + kM;
+                            j -= j >= kN ? kN : 0;
+                            far[k] = mt[(int64_t)j * B + bl];
+                        }
+                        float uni[U];
+#pragma unroll
+                        for (int k = 0; k < U; ++k) {
+                            const uint32_t y = (w[k] & 0x80000000u) | (w[k + 1] & 0x7fffffffu);
+                            uint32_t v = far[k] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                            int j = i0 + k;
+                            j -= j >= kN ? kN : 0;
+                            mt[(int64_t)j * B + bl] = v;
+                            v ^= v >> 11;
+                            v ^= (v << 7) & 0x9d2c5680u;
+                            v ^= (v << 15) & 0xefc60000u;
+                            v ^= v >> 18;
+                            uni[k] = (float)(v & 0xFFFFFFu) * (1.0f / 16777216.0f);
+                        }
+                        {
+                            int j = i0 + U;
+                            j -= j >= kN ? kN : 0;
+                            at32(rows, (uint32_t)(r_seeds + 1) * Bu + bl) = j;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 3; ++e)
+#pragma unroll
+                            for (int c = 0; c < CMAX; ++c) r_field[e][c] = uni[e * CMAX + c];
+#pragma unroll
+                        for (int i = 0; i < 5 * AMAX; ++i) x_draw[i][slot] = uni[3 * CMAX + i];
                     }
-                    {
-                        int j = i0 + U;
-                        j -= j >= kN ? kN : 0;
-                        at32(rows, (uint32_t)(r_seeds + 1) * Bu + bl) = j;
-                    }
+                }
+                if (MODE == kStep) {
+                    // the draws are final BEFORE the barrier: the field role reaches it early (the crew's decode is longer) and
+                    // the compiler would otherwise sink the generator arithmetic behind it, into the transitions on the critical path
 #pragma unroll
                     for (int e = 0; e < 3; ++e)
 #pragma unroll
-                        for (int c = 0; c < CMAX; ++c) r_field[e][c] = uni[e * CMAX + c];
-#pragma unroll
-                    for (int i = 0; i < 5 * AMAX; ++i) x_draw[i][slot] = uni[3 * CMAX + i];
+                        for (int c = 0; c < CMAX; ++c) asm volatile("" : "+v"(r_field[e][c]));
                 }
-            }
-            if (MODE == kStep) {
-                // the draws are final BEFORE the barrier: the field role reaches it early (the crew's decode is longer) and
-                // the compiler would otherwise sink the generator arithmetic behind it, into the transitions on the critical path
+                if constexpr (PERSIST) {
+                    // Between two steps of a multi-step launch.  The draws above need nothing from the other workgroups, so the wait for
+                    // the totals of the step that just ended (the launch's only inter-step barrier) comes after them: the crew, which needs
+                    // the totals for its decode, waits first, and this role's ~700 instructions of Philox cover the same time.
+                    if (t > 0) await_totals();
+                    if (is_frozen()) {
+                        frozen_step();
+                        if (t > 0) {  // the last lists went to the second copy: once more, into the caller's buffers
+                            mask_t lit_last = 0;
 #pragma unroll
-                for (int e = 0; e < 3; ++e)
-#pragma unroll
-                    for (int c = 0; c < CMAX; ++c) asm volatile("" : "+v"(r_field[e][c]));
-            }
-            if constexpr (PERSIST) {
-                // Between two steps of a multi-step launch.  The draws above need nothing from the other workgroups, so the wait for
-                // the totals of the step that just ended (the launch's only inter-step barrier) comes after them: the crew, which needs
-                // the totals for its decode, waits first, and this role's ~700 instructions of Philox cover the same time.
-                if (t > 0) await_totals();
-                if (is_frozen()) {
-                    frozen_step();
-                    if (t > 0) {  // the last lists went to the second copy: once more, into the caller's buffers
-                        mask_t lit_last = 0;
-#pragma unroll
-                        for (int c = 0; c < CMAX; ++c) lit_last |= (mask_t)(f[c] > 0) << c;
-                        emit_field(active ? lit_last : (mask_t)0, 0);
-                    }
-                    break;
-                }
-            }
-            FRZ_RSTAMP(3);
-            __syncthreads();  // (1) applied power visible
-            FRZ_RSTAMP(4);
-
-            // ---- phase 2: fire increase / decrease, spread, dead test
-            mask_t burned = 0, put_out = 0, lit1 = 0;
-            bool dead = false;
-            if (MODE == kStep) {
-                float ap[CMAX];
-#pragma unroll
-                for (int c = 0; c < CMAX; ++c) ap[c] = c < HW ? x_power[c][slot] : 0.0f;
-                mask_t lit2 = 0;
-                const int almost_state = d.num_fire_states - 2, burnout_state = d.num_fire_states - 1;
-                const float p_unmet = (flags & kStochIncrease) ? d.p_increase : 1.0f;
-                const float p_almost = (flags & kStochBurnouts) ? d.p_burnout : d.p_increase;  // fire_increase.py:77-80
-#pragma unroll
-                for (int c = 0; c < CMAX; ++c) {
-                    if (c < HW) {
-                        {  // transitions/fire_increase.py:61-91
-                            const int required = f[c] >= 0 ? f[c] : 0;
-                            const float diff = (float)required - ap[c];
-                            const bool lit = f[c] > 0 && in[c] > 0;
-                            const bool unmet = diff > 0.0f && lit;
-                            const bool almost = unmet && in[c] == almost_state;
-                            float prob = unmet ? (almost ? p_almost : p_unmet) : 0.0f;
-                            prob = clamp01(prob);
-                            const bool inc = r_field[0][c] < prob;
-                            in[c] += inc ? 1 : 0;
-                            const bool bo = inc && in[c] >= burnout_state;
-                            f[c] = bo ? -f[c] : f[c];
-                            fu[c] = bo ? (fu[c] - 1 < 0 ? 0 : fu[c] - 1) : fu[c];
-                            burned |= (mask_t)bo << c;
+                            for (int c = 0; c < CMAX; ++c) lit_last |= (mask_t)(f[c] > 0) << c;
+                            emit_field(active ? lit_last : (mask_t)0, 0);
                         }
-                        {  // transitions/fire_decrease.py:56-77: p = p_dec + ((-1 * diff) * bonus), each op rounded
-                            const int required = f[c] >= 0 ? f[c] : 0;
-                            const float diff = (float)required - ap[c];
-                            const bool lit = f[c] > 0 && in[c] > 0;
-                            const bool met = diff <= 0.0f && lit;
-                            const float stoch_p = __fadd_rn(d.p_decrease, __fmul_rn(__fmul_rn(-1.0f, diff), d.decrease_bonus));
-                            float prob = met ? ((flags & kStochDecrease) ? stoch_p : 1.0f) : 0.0f;
-                            prob = clamp01(prob);
-                            const bool dec = r_field[1][c] < prob;
-                            in[c] -= dec ? 1 : 0;
-                            const bool po = dec && in[c] <= 0;
-                            f[c] = po ? -f[c] : f[c];
-                            fu[c] = po ? fu[c] - 1 : fu[c];  // unclamped, :75
-                            put_out |= (mask_t)po << c;
-                        }
-                        lit2 |= (mask_t)(f[c] > 0 && in[c] > 0) << c;
+                        break;
                     }
                 }
-                // fire spread stencil (transitions/fire_spreads.py:44-57)
-                int fuel_sum = 0;
-                bool any_fire = false;
-                const mask_t from_n = (lit2 << W) & (mask_t)d.has_n, from_s = (lit2 >> W) & (mask_t)d.has_s;
-                const mask_t from_w = (lit2 << 1) & (mask_t)d.has_w, from_e = (lit2 >> 1) & (mask_t)d.has_e;
-#pragma unroll
-                for (int c = 0; c < CMAX; ++c) {
-                    if (c < HW) {
-                        float prob = 0.0f;  // conv2d accumulation order: N, W, E, S
-                        prob = __fadd_rn(prob, ((from_n >> c) & 1) ? d.spread_n : 0.0f);
-                        prob = __fadd_rn(prob, ((from_w >> c) & 1) ? d.spread_w : 0.0f);
-                        prob = __fadd_rn(prob, ((from_e >> c) & 1) ? d.spread_e : 0.0f);
-                        prob = __fadd_rn(prob, ((from_s >> c) & 1) ? d.spread_s : 0.0f);
-                        bool unlit = f[c] < 0 && in[c] == 0;
-                        unlit = unlit && (!(flags & kUseFuel) || fu[c] > 0);
-                        prob = unlit ? __fadd_rn(prob, d.random_ignition) : 0.0f;
-                        const bool spread = r_field[2][c] < prob;
-                        f[c] = spread ? -f[c] : f[c];
-                        in[c] = spread ? d.ignition[c] : in[c];
-                        fuel_sum += fu[c];
-                        any_fire = any_fire || f[c] > 0;
-                    }
-                }
-                // termination test (wildfire.py:560-570): no lit fire left (and no fuel when fuel is tracked)
-                dead = !any_fire;
-                if (flags & kUseFuel) dead = dead && fuel_sum <= 0;
-#pragma unroll
-                for (int c = 0; c < CMAX; ++c) f[c] = dead ? 0 : f[c];  // :570
-            }
-#pragma unroll
-            for (int c = 0; c < CMAX; ++c) lit1 |= (mask_t)(f[c] > 0) << c;
-            x_lit[slot] = lit1;  // as it is also for the lanes that shadow the last env: a multi-step launch steps them like their owner
-            lit1 = active ? lit1 : (mask_t)0;
-            x_fate[slot] = (fate_t)burned | ((fate_t)put_out << MB) | ((fate_t)dead << (2 * MB));
-            FRZ_RSTAMP(5);
-            __syncthreads();  // (2) lit mask and fates visible to the crew
-            FRZ_RSTAMP(6);
+                FRZ_RSTAMP(3);
+                __syncthreads();  // (1) applied power visible
+                FRZ_RSTAMP(4);
 
-            // ---- phase 3: cell rows (the crew scans meanwhile)
-            if ((MODE == kStep || MODE == kReset) && !FRZ_SKIP(2)) {
+                // ---- phase 2: fire increase / decrease, spread, dead test
+                mask_t burned = 0, put_out = 0, lit1 = 0;
+                bool dead = false;
+                if (MODE == kStep) {
+                    float ap[CMAX];
 #pragma unroll
-                for (int c = 0; c < CMAX; ++c)
-                    if (c < HW) {
-                        at32(rows, (uint32_t)(r_fires + c) * Bu + bl) = f[c];
-                        at32(rows, (uint32_t)(r_intensity + c) * Bu + bl) = in[c];
-                        at32(rows, (uint32_t)(r_fuel + c) * Bu + bl) = fu[c];
-                    }
-            }
-            if (!FRZ_SKIP(1)) {  // agent observations (wildfire.py:677-681, 704-716): the suppressants arrive from the crew
-                // Agents do not move and their base power is configuration: of an observation record only the suppressant
-                // column changes from step to step.  reset / rebuild write whole records; a step rewrites only that column
-                // (the records stay what the reference would rebuild; nothing is written twice with the same bytes).
-                float supp[AMAX];
+                    for (int c = 0; c < CMAX; ++c) ap[c] = c < HW ? x_power[c][slot] : 0.0f;
+                    mask_t lit2 = 0;
+                    const int almost_state = d.num_fire_states - 2, burnout_state = d.num_fire_states - 1;
+                    const float p_unmet = (flags & kStochIncrease) ? d.p_increase : 1.0f;
+                    const float p_almost = (flags & kStochBurnouts) ? d.p_burnout : d.p_increase;  // fire_increase.py:77-80
 #pragma unroll
-                for (int a = 0; a < AMAX; ++a) supp[a] = a < A ? x_supp[a][slot] : 0.0f;
-                const int k = d.others_k, width = (A - 1) * k;  // k = 2 + power column + suppressant column
-                const bool op = (flags & kObsPower) != 0, os = (flags & kObsSupp) != 0;
-                const bool whole = MODE != kStep || FRZ_SKIP(6);
-#pragma unroll
-                for (int a = 0; a < AMAX; ++a)
-                    if (a < A) {
-                        if (whole)
-                            reinterpret_cast<float4*>(obs_self)[a * B + bl] = make_float4((float)d.ay[a], (float)d.ax[a], d.power[a], supp[a]);
-                        else
-                            frz::store_through(&obs_self[(a * B + bl) * 4 + 3], supp[a]);
-                        float* const others = obs_others + (a * B + bl) * (int64_t)width;
-                        int j = 0;  // record index: the other agents in agent order
-#pragma unroll
-                        for (int o = 0; o < AMAX; ++o)
-                            if (o < A && o != a) {
-                                float* const rec = others + j * k;
-                                if (whole) {
-                                    const float y = (float)d.ay[o], x = (float)d.ax[o];
-                                    if (k == 4) {
-                                        *reinterpret_cast<float4*>(rec) = make_float4(y, x, d.power[o], supp[o]);
-                                    } else if (k == 3) {
-                                        rec[0] = y;
-                                        rec[1] = x;
-                                        rec[2] = op ? d.power[o] : supp[o];
-                                    } else {
-                                        *reinterpret_cast<float2*>(rec) = make_float2(y, x);
-                                    }
-                                } else if (os) {
-                                    frz::store_through(&rec[k - 1], supp[o]);  // the suppressant column is the last one
-                                }
-                                ++j;
+                    for (int c = 0; c < CMAX; ++c) {
+                        if (c < HW) {
+                            {  // transitions/fire_increase.py:61-91
+                                const int required = f[c] >= 0 ? f[c] : 0;
+                                const float diff = (float)required - ap[c];
+                                const bool lit = f[c] > 0 && in[c] > 0;
+                                const bool unmet = diff > 0.0f && lit;
+                                const bool almost = unmet && in[c] == almost_state;
+                                float prob = unmet ? (almost ? p_almost : p_unmet) : 0.0f;
+                                prob = clamp01(prob);
+                                const bool inc = r_field[0][c] < prob;
+                                in[c] += inc ? 1 : 0;
+                                const bool bo = inc && in[c] >= burnout_state;
+                                f[c] = bo ? -f[c] : f[c];
+                                fu[c] = bo ? (fu[c] - 1 < 0 ? 0 : fu[c] - 1) : fu[c];
+                                burned |= (mask_t)bo << c;
                             }
+                            {  // transitions/fire_decrease.py:56-77: p = p_dec + ((-1 * diff) * bonus), each op rounded
+                                const int required = f[c] >= 0 ? f[c] : 0;
+                                const float diff = (float)required - ap[c];
+                                const bool lit = f[c] > 0 && in[c] > 0;
+                                const bool met = diff <= 0.0f && lit;
+                                const float stoch_p = __fadd_rn(d.p_decrease, __fmul_rn(__fmul_rn(-1.0f, diff), d.decrease_bonus));
+                                float prob = met ? ((flags & kStochDecrease) ? stoch_p : 1.0f) : 0.0f;
+                                prob = clamp01(prob);
+                                const bool dec = r_field[1][c] < prob;
+                                in[c] -= dec ? 1 : 0;
+                                const bool po = dec && in[c] <= 0;
+                                f[c] = po ? -f[c] : f[c];
+                                fu[c] = po ? fu[c] - 1 : fu[c];  // unclamped, :75
+                                put_out |= (mask_t)po << c;
+                            }
+                            lit2 |= (mask_t)(f[c] > 0 && in[c] > 0) << c;
+                        }
                     }
-            }
-            FRZ_RSTAMP(7);
-            __syncthreads();  // (3) wavefront sums visible
+                    // fire spread stencil (transitions/fire_spreads.py:44-57)
+                    int fuel_sum = 0;
+                    bool any_fire = false;
+                    const mask_t from_n = (lit2 << W) & (mask_t)d.has_n, from_s = (lit2 >> W) & (mask_t)d.has_s;
+                    const mask_t from_w = (lit2 << 1) & (mask_t)d.has_w, from_e = (lit2 >> 1) & (mask_t)d.has_e;
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c) {
+                        if (c < HW) {
+                            float prob = 0.0f;  // conv2d accumulation order: N, W, E, S
+                            prob = __fadd_rn(prob, ((from_n >> c) & 1) ? d.spread_n : 0.0f);
+                            prob = __fadd_rn(prob, ((from_w >> c) & 1) ? d.spread_w : 0.0f);
+                            prob = __fadd_rn(prob, ((from_e >> c) & 1) ? d.spread_e : 0.0f);
+                            prob = __fadd_rn(prob, ((from_s >> c) & 1) ? d.spread_s : 0.0f);
+                            bool unlit = f[c] < 0 && in[c] == 0;
+                            unlit = unlit && (!(flags & kUseFuel) || fu[c] > 0);
+                            prob = unlit ? __fadd_rn(prob, d.random_ignition) : 0.0f;
+                            const bool spread = r_field[2][c] < prob;
+                            f[c] = spread ? -f[c] : f[c];
+                            in[c] = spread ? d.ignition[c] : in[c];
+                            fuel_sum += fu[c];
+                            any_fire = any_fire || f[c] > 0;
+                        }
+                    }
+                    // termination test (wildfire.py:560-570): no lit fire left (and no fuel when fuel is tracked)
+                    dead = !any_fire;
+                    if (flags & kUseFuel) dead = dead && fuel_sum <= 0;
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c) f[c] = dead ? 0 : f[c];  // :570
+                }
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) lit1 |= (mask_t)(f[c] > 0) << c;
+                x_lit[slot] = lit1;  // as it is also for the lanes that shadow the last env: a multi-step launch steps them like their owner
+                lit1 = active ? lit1 : (mask_t)0;
+                x_fate[slot] = (fate_t)burned | ((fate_t)put_out << MB) | ((fate_t)dead << (2 * MB));
+                FRZ_RSTAMP(5);
+                __syncthreads();  // (2) lit mask and fates visible to the crew
+                FRZ_RSTAMP(6);
 
-            // ---- phase 4 belongs to the crew (hand-off)
-            if constexpr (kPhilox && PERSIST) {
-                if (t + 1 < n_steps) philox_draws(fld.nm + 1, flags, next_field, next_agent);
-            }
-            FRZ_RSTAMP(8);
-            __syncthreads();  // (4)
-            __syncthreads();  // (5) chunk prefix visible
-            FRZ_RSTAMP(9);
+                // ---- phase 3: cell rows (the crew scans meanwhile)
+                if ((MODE == kStep || MODE == kReset) && !FRZ_SKIP(2)) {
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c)
+                        if (c < HW) {
+                            at32(rows, (uint32_t)(r_fires + c) * Bu + bl) = f[c];
+                            at32(rows, (uint32_t)(r_intensity + c) * Bu + bl) = in[c];
+                            at32(rows, (uint32_t)(r_fuel + c) * Bu + bl) = fu[c];
+                        }
+                }
+                if (!FRZ_SKIP(1)) {  // agent observations (wildfire.py:677-681, 704-716): the suppressants arrive from the crew
+                    // Agents do not move and their base power is configuration: of an observation record only the suppressant
+                    // column changes from step to step.  reset / rebuild write whole records; a step rewrites only that column
+                    // (the records stay what the reference would rebuild; nothing is written twice with the same bytes).
+                    float supp[AMAX];
+#pragma unroll
+                    for (int a = 0; a < AMAX; ++a) supp[a] = a < A ? x_supp[a][slot] : 0.0f;
+                    const int k = d.others_k, width = (A - 1) * k;  // k = 2 + power column + suppressant column
+                    const bool op = (flags & kObsPower) != 0, os = (flags & kObsSupp) != 0;
+                    const bool whole = MODE != kStep || FRZ_SKIP(6);
+#pragma unroll
+                    for (int a = 0; a < AMAX; ++a)
+                        if (a < A) {
+                            if (whole)
+                                reinterpret_cast<float4*>(obs_self)[a * B + bl] = make_float4((float)d.ay[a], (float)d.ax[a], d.power[a], supp[a]);
+                            else
+                                frz::store_through(&obs_self[(a * B + bl) * 4 + 3], supp[a]);
+                            float* const others = obs_others + (a * B + bl) * (int64_t)width;
+                            int j = 0;  // record index: the other agents in agent order
+#pragma unroll
+                            for (int o = 0; o < AMAX; ++o)
+                                if (o < A && o != a) {
+                                    float* const rec = others + j * k;
+                                    if (whole) {
+                                        const float y = (float)d.ay[o], x = (float)d.ax[o];
+                                        if (k == 4) {
+                                            *reinterpret_cast<float4*>(rec) = make_float4(y, x, d.power[o], supp[o]);
+                                        } else if (k == 3) {
+                                            rec[0] = y;
+                                            rec[1] = x;
+                                            rec[2] = op ? d.power[o] : supp[o];
+                                        } else {
+                                            *reinterpret_cast<float2*>(rec) = make_float2(y, x);
+                                        }
+                                    } else if (os) {
+                                        frz::store_through(&rec[k - 1], supp[o]);  // the suppressant column is the last one
+                                    }
+                                    ++j;
+                                }
+                        }
+                }
+                FRZ_RSTAMP(7);
+                __syncthreads();  // (3) wavefront sums visible
 
-            // ---- phase 6: task list (wildfire.py:586-717)
-            emit_field(lit1, copy);
-            FRZ_RSTAMP(10);
-            FRZ_RWALL(1);
-            if constexpr (PERSIST) fld.nm += 1;
-            executed = t + 1;
+                // ---- phase 4 belongs to the crew (hand-off)
+                if constexpr (kPhilox && PERSIST) {
+                    if (t + 1 < n_steps) philox_draws(fld.nm + 1, flags, next_field, next_agent);
+                }
+                FRZ_RSTAMP(8);
+                __syncthreads();  // (4)
+                __syncthreads();  // (5) chunk prefix visible
+                FRZ_RSTAMP(9);
+
+                // ---- phase 6: task list (wildfire.py:586-717)
+                emit_field(lit1, copy);
+                FRZ_RSTAMP(10);
+                FRZ_RWALL(1);
+                if constexpr (PERSIST) fld.nm += 1;
+                executed = t + 1;
             }  // steps of this launch
             // The workgroup owning the last chunk finished its look-back only after every other chunk published, i.e.
             // after every workgroup of this launch read the epoch: it can advance it for the next launch.
@@ -804,415 +804,415 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                 }
             };
             for (int t = 0; t < n_steps; ++t) {
-            if constexpr (PERSIST) {
-                if (t == 0 && is_frozen()) break;  // (later steps: tested in phase 1, once the totals of the step before have arrived)
-            }
-            const int64_t copy = list_copy(t);
-            // per-step opaque copies: the flag tests stay next to their uses, and in a multi-step launch so do the row addresses — hoisted
-            // out of the step loop, the ~100 store addresses and ~40 row bases of a step would all be live from the top of the kernel
-            // (256 VGPRs, >100 spilled scalars)
-            uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)flags_word);
-            asm volatile("" : "+s"(flags));
-            uint32_t bl = bl_launch, Bu = Bu_launch;
-            if constexpr (PERSIST) {
-                asm volatile("" : "+v"(bl));
-                asm volatile("" : "+s"(Bu));
-                asm volatile("" ::: "memory");  // and the configuration is read from LDS where a step uses it, not once above the loop
-            }
-            const WfHot& d = PERSIST ? static_cast<const WfHot&>(s_cfg) : d_launch;
-            if constexpr (PERSIST) {
-                if (t > 0) request_totals();
-            }
-#pragma unroll
-            for (int a = 0; a < AMAX; ++a) rew[a] = 0.0f, hit[a] = -1, users[a] = false, refill[a] = false;
-            const bool term0 = crw.term != 0, trunc0 = crw.trunc != 0;
-
-            // ---- phase 1: action decode (wildfire.py:427-483) -> applied power per cell
-            // The action mapping of the previous rebuild is a pure function of the state it was built from, which is the
-            // state just loaded: attackable set of agent a = lit fires within its (equipment-adjusted) range, non-empty
-            // only while it has suppressant (wildfire.py:604-623).
-            bool stop = false;  // multi-step launch: the batch turned out to be finished
-            if (MODE == kStep) {
-                const mask_t lit0 = lit_before;
-                float ap[CMAX];
-                const bool show_bad = (flags & kShowBad) != 0;
-                // stream of frz_wildfire_random_policy: agent a draws word a % 4 of block (a / 4, policy step), keyed by the env seed
-                frz::Philox4 policy_block[(AMAX + 3) / 4]{};  // agent a draws word a % 4 of block a / 4
-                if (launch.policy) {
-                    // (a multi-step launch samples step t of its rollout with policy step first + t)
-                    const uint64_t policy_step = (((uint64_t)launch.policy_step_hi << 32) | launch.policy_step_lo) + (uint64_t)(PERSIST ? t : 0);
-#pragma unroll
-                    for (int q = 0; q < (AMAX + 3) / 4; ++q)
-                        if (q * 4 < A) policy_block[q] = frz::philox4x32_10((uint32_t)q, 0u, (uint32_t)policy_step, (uint32_t)(policy_step >> 32),
-                                                                           launch.policy_seed_lo ^ crw.seed, launch.policy_seed_hi);
+                if constexpr (PERSIST) {
+                    if (t == 0 && is_frozen()) break;  // (later steps: tested in phase 1, once the totals of the step before have arrived)
                 }
-                // A later step of a multi-step launch decodes BEFORE the totals of the step that just ended are here (they are the launch's
-                // inter-step barrier: a memory round trip after the last chunk has published them), assuming what is true of every
-                // ordinary step — no agent is skipped, the batch is not finished — and only repeats the decode when the totals say
-                // otherwise.  Nothing of this phase leaves the registers before that test.
-                int2 sampled[AMAX];
-                uint32_t err1 = 0;
-                for (int attempt = 0; attempt < (PERSIST ? 2 : 1); ++attempt) {
-                const bool assume_ordinary = PERSIST && t > 0 && attempt == 0;
-                err1 = 0;
+                const int64_t copy = list_copy(t);
+                // per-step opaque copies: the flag tests stay next to their uses, and in a multi-step launch so do the row addresses — hoisted
+                // out of the step loop, the ~100 store addresses and ~40 row bases of a step would all be live from the top of the kernel
+                // (256 VGPRs, >100 spilled scalars)
+                uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)flags_word);
+                asm volatile("" : "+s"(flags));
+                uint32_t bl = bl_launch, Bu = Bu_launch;
+                if constexpr (PERSIST) {
+                    asm volatile("" : "+v"(bl));
+                    asm volatile("" : "+s"(Bu));
+                    asm volatile("" ::: "memory");  // and the configuration is read from LDS where a step uses it, not once above the loop
+                }
+                const WfHot& d = PERSIST ? static_cast<const WfHot&>(s_cfg) : d_launch;
+                if constexpr (PERSIST) {
+                    if (t > 0) request_totals();
+                }
 #pragma unroll
-                for (int c = 0; c < CMAX; ++c) ap[c] = 0.0f;
+                for (int a = 0; a < AMAX; ++a) rew[a] = 0.0f, hit[a] = -1, users[a] = false, refill[a] = false;
+                const bool term0 = crw.term != 0, trunc0 = crw.trunc != 0;
+
+                // ---- phase 1: action decode (wildfire.py:427-483) -> applied power per cell
+                // The action mapping of the previous rebuild is a pure function of the state it was built from, which is the
+                // state just loaded: attackable set of agent a = lit fires within its (equipment-adjusted) range, non-empty
+                // only while it has suppressant (wildfire.py:604-623).
+                bool stop = false;  // multi-step launch: the batch turned out to be finished
+                if (MODE == kStep) {
+                    const mask_t lit0 = lit_before;
+                    float ap[CMAX];
+                    const bool show_bad = (flags & kShowBad) != 0;
+                    // stream of frz_wildfire_random_policy: agent a draws word a % 4 of block (a / 4, policy step), keyed by the env seed
+                    frz::Philox4 policy_block[(AMAX + 3) / 4]{};  // agent a draws word a % 4 of block a / 4
+                    if (launch.policy) {
+                        // (a multi-step launch samples step t of its rollout with policy step first + t)
+                        const uint64_t policy_step = (((uint64_t)launch.policy_step_hi << 32) | launch.policy_step_lo) + (uint64_t)(PERSIST ? t : 0);
 #pragma unroll
-                for (int a = 0; a < AMAX; ++a) {
-                    sampled[a] = make_int2(0, -1);
-                    if (a < A) {
-                        const mask_t ok = supp[a] > 0.0f ? (lit0 & (mask_t)s_cfg.range_mask[a][eqs[a]]) : (mask_t)0;
-                        const mask_t sel = show_bad ? lit0 : ok;  // the tasks the agent's action space lists
-                        int act_idx = crw.act_idx[a], act_id = crw.act_id[a];
-                        if (launch.policy) {
-                            // uniform random policy over OneOf([task] * n + [noop]) (spaces/actions.py:23-41,
-                            // baselines/random.py:20), the stream of frz_wildfire_random_policy: member j ~ U{0..n};
-                            // j < n -> [j, 0] (fight task j), j == n -> [n, -1] (noop / refill)
-                            const int n = popc(sel);
-                            const int j = (int)(((uint64_t)policy_block[a >> 2].w[a & 3] * (uint64_t)(n + 1)) >> 32);
-                            act_idx = j < n ? j : n;
-                            act_id = j < n ? 0 : -1;
-                            sampled[a] = make_int2(act_idx, act_id);
-                            if constexpr (!PERSIST) frz::store_through(&reinterpret_cast<int2*>(launch.actions_out)[a * B + bl], sampled[a]);
+                        for (int q = 0; q < (AMAX + 3) / 4; ++q)
+                            if (q * 4 < A) policy_block[q] = frz::philox4x32_10((uint32_t)q, 0u, (uint32_t)policy_step, (uint32_t)(policy_step >> 32),
+                                                                               launch.policy_seed_lo ^ crw.seed, launch.policy_seed_hi);
+                    }
+                    // A later step of a multi-step launch decodes BEFORE the totals of the step that just ended are here (they are the launch's
+                    // inter-step barrier: a memory round trip after the last chunk has published them), assuming what is true of every
+                    // ordinary step — no agent is skipped, the batch is not finished — and only repeats the decode when the totals say
+                    // otherwise.  Nothing of this phase leaves the registers before that test.
+                    int2 sampled[AMAX];
+                    uint32_t err1 = 0;
+                    for (int attempt = 0; attempt < (PERSIST ? 2 : 1); ++attempt) {
+                    const bool assume_ordinary = PERSIST && t > 0 && attempt == 0;
+                    err1 = 0;
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c) ap[c] = 0.0f;
+#pragma unroll
+                    for (int a = 0; a < AMAX; ++a) {
+                        sampled[a] = make_int2(0, -1);
+                        if (a < A) {
+                            const mask_t ok = supp[a] > 0.0f ? (lit0 & (mask_t)s_cfg.range_mask[a][eqs[a]]) : (mask_t)0;
+                            const mask_t sel = show_bad ? lit0 : ok;  // the tasks the agent's action space lists
+                            int act_idx = crw.act_idx[a], act_id = crw.act_id[a];
+                            if (launch.policy) {
+                                // uniform random policy over OneOf([task] * n + [noop]) (spaces/actions.py:23-41,
+                                // baselines/random.py:20), the stream of frz_wildfire_random_policy: member j ~ U{0..n};
+                                // j < n -> [j, 0] (fight task j), j == n -> [n, -1] (noop / refill)
+                                const int n = popc(sel);
+                                const int j = (int)(((uint64_t)policy_block[a >> 2].w[a & 3] * (uint64_t)(n + 1)) >> 32);
+                                act_idx = j < n ? j : n;
+                                act_id = j < n ? 0 : -1;
+                                sampled[a] = make_int2(act_idx, act_id);
+                                if constexpr (!PERSIST) frz::store_through(&reinterpret_cast<int2*>(launch.actions_out)[a * B + bl], sampled[a]);
+                            }
+                            refill[a] = act_id == -1;
+                            // quirk wildfire.py:434-435: an agent with no attackable task in ANY env of the batch is skipped
+                            const bool skipped = !assume_ordinary && prev[1 + a] == 0u;
+                            const bool fight = !refill[a] && !skipped;
+                            const bool valid = act_idx >= 0 && act_idx < popc(sel);
+                            int target = 0, seen = 0;
+#pragma unroll
+                            for (int c = 0; c < CMAX; ++c) {
+                                const int bit = (int)((sel >> c) & 1);
+                                target = (bit && seen == act_idx) ? c : target;
+                                seen += bit;
+                            }
+                            const bool attackable = ((ok >> target) & 1) != 0;
+                            const bool good = fight && valid && (!show_bad || attackable);
+                            if (fight && !valid && active) err1 |= FRZ_ERR_BAD_ACTION_INDEX;
+                            const float power = d.power[a] + s_cfg.eq[eqs[a]][1];
+#pragma unroll
+                            for (int c = 0; c < CMAX; ++c) ap[c] = ap[c] + ((good && target == c) ? power : 0.0f);  // agent order
+                            users[a] = good;
+                            hit[a] = good ? target : -1;
+                            rew[a] = (fight && !good) ? d.bad_attack_penalty : 0.0f;  // assignment, :477
                         }
-                        refill[a] = act_id == -1;
-                        // quirk wildfire.py:434-435: an agent with no attackable task in ANY env of the batch is skipped
-                        const bool skipped = !assume_ordinary && prev[1 + a] == 0u;
-                        const bool fight = !refill[a] && !skipped;
-                        const bool valid = act_idx >= 0 && act_idx < popc(sel);
-                        int target = 0, seen = 0;
+                    }
+                    if constexpr (PERSIST) {
+                        if (!assume_ordinary) break;
+                        await_totals();
+                        stop = is_frozen();
+                        bool someone_skipped = false;
 #pragma unroll
-                        for (int c = 0; c < CMAX; ++c) {
-                            const int bit = (int)((sel >> c) & 1);
-                            target = (bit && seen == act_idx) ? c : target;
-                            seen += bit;
+                        for (int a = 0; a < AMAX; ++a) someone_skipped = someone_skipped || (a < A && prev[1 + a] == 0u);
+                        if (stop || !someone_skipped) break;
+                    }
+                    }  // attempts
+                    if (!stop) {
+                        err |= err1;
+                        if constexpr (PERSIST) {
+                            if (launch.policy) {
+#pragma unroll
+                                for (int a = 0; a < AMAX; ++a)
+                                    if (a < A) frz::store_through(&reinterpret_cast<int2*>(launch.actions_out)[a * B + bl], sampled[a]);
+                            }
                         }
-                        const bool attackable = ((ok >> target) & 1) != 0;
-                        const bool good = fight && valid && (!show_bad || attackable);
-                        if (fight && !valid && active) err1 |= FRZ_ERR_BAD_ACTION_INDEX;
-                        const float power = d.power[a] + s_cfg.eq[eqs[a]][1];
 #pragma unroll
-                        for (int c = 0; c < CMAX; ++c) ap[c] = ap[c] + ((good && target == c) ? power : 0.0f);  // agent order
-                        users[a] = good;
-                        hit[a] = good ? target : -1;
-                        rew[a] = (fight && !good) ? d.bad_attack_penalty : 0.0f;  // assignment, :477
+                        for (int c = 0; c < CMAX; ++c)
+                            if (c < HW) x_power[c][slot] = ap[c];
                     }
                 }
                 if constexpr (PERSIST) {
-                    if (!assume_ordinary) break;
-                    await_totals();
-                    stop = is_frozen();
-                    bool someone_skipped = false;
-#pragma unroll
-                    for (int a = 0; a < AMAX; ++a) someone_skipped = someone_skipped || (a < A && prev[1 + a] == 0u);
-                    if (stop || !someone_skipped) break;
-                }
-                }  // attempts
-                if (!stop) {
-                    err |= err1;
-                    if constexpr (PERSIST) {
-                        if (launch.policy) {
+                    if (stop) {  // utils/env.py:211-213: nothing more happens in this launch
+                        {  // (t > 0 here) the last lists went to the second copy: once more, into the caller's buffers
+                            mask_t ok_last[AMAX];
 #pragma unroll
                             for (int a = 0; a < AMAX; ++a)
-                                if (a < A) frz::store_through(&reinterpret_cast<int2*>(launch.actions_out)[a * B + bl], sampled[a]);
+                                ok_last[a] = (a < A && supp[a] > 0.0f) ? (lit_before & (mask_t)s_cfg.range_mask[a][eqs[a]]) : (mask_t)0;
+                            emit_crew(lit_before, ok_last, 0);
+                        }
+                        break;
+                    }
+                }
+                FRZ_RSTAMP(3);
+                __syncthreads();  // (1) applied power visible to the field role
+                FRZ_RSTAMP(4);
+
+                // ---- phase 2: agent draws, agent transitions, agent rows, agent observations
+                if (MODE == kStep) {
+                    float r_agent[5][AMAX];
+                    if constexpr (kInjected) {
+#pragma unroll
+                        for (int e = 0; e < 5; ++e)
+#pragma unroll
+                            for (int a = 0; a < AMAX; ++a) r_agent[e][a] = cdraws.r[e][a];
+                    } else if constexpr (kPhilox || kMt) {
+#pragma unroll
+                        for (int e = 0; e < 5; ++e)
+#pragma unroll
+                            for (int a = 0; a < AMAX; ++a) r_agent[e][a] = x_draw[e * AMAX + a][slot];  // drawn by the field role
+                    }
+#pragma unroll
+                    for (int a = 0; a < AMAX; ++a) {
+                        if (a < A) {
+                            // transitions/suppressant_decrease.py:56-61
+                            const bool dec = users[a] && (!(flags & kStochSuppDecrease) || r_agent[0][a] < d.p_supp_decrease);
+                            float s = dec ? supp[a] - 1.0f : supp[a];
+                            s = s < 0.0f ? 0.0f : s;
+                            // transitions/equipment.py:51-75 (masks from the value before any write)
+                            const int e0 = eqs[a], top = d.S - 1;
+                            const bool pristine = e0 == top, damaged = e0 == 0, inter = !pristine && !damaged;
+                            const float r1 = r_agent[1][a];
+                            const bool repairs = (flags & kStochRepair) ? (damaged && r1 < d.p_repair) : damaged;
+                            const bool crit = (flags & kCritical) && pristine && r1 < d.p_critical;
+                            bool degr = (flags & kStochDegrade) ? ((pristine || inter) && r1 < d.p_degrade) : (inter || pristine);
+                            degr = degr && !crit;
+                            int e = repairs ? top : e0;
+                            e = crit ? 0 : e;
+                            e = degr ? e - 1 : e;
+                            // transitions/suppressant_refill.py:63-70 (bonus from the NEW equipment state)
+                            const bool inc = refill[a] && (!(flags & kStochRefill) || r_agent[2][a] < d.p_refill);
+                            s = inc ? capa[a] + s_cfg.eq[e][0] : s;
+                            // transitions/capacity.py:52-64: bucketize(r, cumsum) = #{j : cum[j] < r} (cum padded with +inf,
+                            // clamped to the last capacity where the reference would raise IndexError)
+                            int ci = 0;
+#pragma unroll
+                            for (int j = 0; j < FRZ_MAX_CAPACITIES; ++j) ci += r_agent[3][a] > d.cum[j] ? 1 : 0;
+                            ci = ci > d.K - 1 ? d.K - 1 : ci;
+                            const float new_max = s_cfg.caps[ci];
+                            const bool sw = inc && (!(flags & kStochSwitch) || r_agent[4][a] < d.p_switch);
+                            const float bonus = s - capa[a];
+                            capa[a] = sw ? new_max : capa[a];
+                            s = sw ? new_max + bonus : s;
+                            supp[a] = s;
+                            eqs[a] = e;
+                            at32(rowsf, (uint32_t)(r_supp + a) * Bu + bl) = supp[a];
+                            at32(rowsf, (uint32_t)(r_cap + a) * Bu + bl) = capa[a];
+                            at32(rows, (uint32_t)(r_equip + a) * Bu + bl) = eqs[a];
                         }
                     }
-#pragma unroll
-                    for (int c = 0; c < CMAX; ++c)
-                        if (c < HW) x_power[c][slot] = ap[c];
                 }
-            }
-            if constexpr (PERSIST) {
-                if (stop) {  // utils/env.py:211-213: nothing more happens in this launch
-                    {  // (t > 0 here) the last lists went to the second copy: once more, into the caller's buffers
-                        mask_t ok_last[AMAX];
+                if (MODE == kReset) {  // the configured agent state + zeroed bookkeeping (utils/env.py:137-160)
 #pragma unroll
-                        for (int a = 0; a < AMAX; ++a)
-                            ok_last[a] = (a < A && supp[a] > 0.0f) ? (lit_before & (mask_t)s_cfg.range_mask[a][eqs[a]]) : (mask_t)0;
-                        emit_crew(lit_before, ok_last, 0);
-                    }
-                    break;
+                    for (int a = 0; a < AMAX; ++a)
+                        if (a < A) {
+                            at32(rowsf, (uint32_t)(r_supp + a) * Bu + bl) = supp[a];
+                            at32(rowsf, (uint32_t)(r_cap + a) * Bu + bl) = capa[a];
+                            at32(rows, (uint32_t)(r_equip + a) * Bu + bl) = eqs[a];
+                            at32(rowsf, (uint32_t)(r_rewards + a) * Bu + bl) = 0.0f;
+                            at32(rowsf, (uint32_t)(r_cum + a) * Bu + bl) = 0.0f;
+                            at32(rows1, (u_term + (uint32_t)a) * Bu + bl) = (uint8_t)0;
+                            at32(rows1, (u_trunc + (uint32_t)a) * Bu + bl) = (uint8_t)0;
+                        }
+                    at32(rows, (uint32_t)r_moves * Bu + bl) = 0;
+                    at32(rows, (uint32_t)r_burnouts * Bu + bl) = 0;
+                    if (launch.seed_increment != 0 && active) at32(rows, (uint32_t)r_seeds * Bu + bl) += launch.seed_increment;  // fresh seeds per episode
+                    at32(rows8, q_burnouts * Bu + bl) = 0;
+                    at32(rows8, q_putouts * Bu + bl) = 0;
+                    at32(rows1, u_frozen * Bu + bl) = (uint8_t)0;
                 }
-            }
-            FRZ_RSTAMP(3);
-            __syncthreads();  // (1) applied power visible to the field role
-            FRZ_RSTAMP(4);
-
-            // ---- phase 2: agent draws, agent transitions, agent rows, agent observations
-            if (MODE == kStep) {
-                float r_agent[5][AMAX];
-                if constexpr (kInjected) {
-#pragma unroll
-                    for (int e = 0; e < 5; ++e)
-#pragma unroll
-                        for (int a = 0; a < AMAX; ++a) r_agent[e][a] = cdraws.r[e][a];
-                } else if constexpr (kPhilox || kMt) {
-#pragma unroll
-                    for (int e = 0; e < 5; ++e)
-#pragma unroll
-                        for (int a = 0; a < AMAX; ++a) r_agent[e][a] = x_draw[e * AMAX + a][slot];  // drawn by the field role
-                }
-#pragma unroll
-                for (int a = 0; a < AMAX; ++a) {
-                    if (a < A) {
-                        // transitions/suppressant_decrease.py:56-61
-                        const bool dec = users[a] && (!(flags & kStochSuppDecrease) || r_agent[0][a] < d.p_supp_decrease);
-                        float s = dec ? supp[a] - 1.0f : supp[a];
-                        s = s < 0.0f ? 0.0f : s;
-                        // transitions/equipment.py:51-75 (masks from the value before any write)
-                        const int e0 = eqs[a], top = d.S - 1;
-                        const bool pristine = e0 == top, damaged = e0 == 0, inter = !pristine && !damaged;
-                        const float r1 = r_agent[1][a];
-                        const bool repairs = (flags & kStochRepair) ? (damaged && r1 < d.p_repair) : damaged;
-                        const bool crit = (flags & kCritical) && pristine && r1 < d.p_critical;
-                        bool degr = (flags & kStochDegrade) ? ((pristine || inter) && r1 < d.p_degrade) : (inter || pristine);
-                        degr = degr && !crit;
-                        int e = repairs ? top : e0;
-                        e = crit ? 0 : e;
-                        e = degr ? e - 1 : e;
-                        // transitions/suppressant_refill.py:63-70 (bonus from the NEW equipment state)
-                        const bool inc = refill[a] && (!(flags & kStochRefill) || r_agent[2][a] < d.p_refill);
-                        s = inc ? capa[a] + s_cfg.eq[e][0] : s;
-                        // transitions/capacity.py:52-64: bucketize(r, cumsum) = #{j : cum[j] < r} (cum padded with +inf,
-                        // clamped to the last capacity where the reference would raise IndexError)
-                        int ci = 0;
-#pragma unroll
-                        for (int j = 0; j < FRZ_MAX_CAPACITIES; ++j) ci += r_agent[3][a] > d.cum[j] ? 1 : 0;
-                        ci = ci > d.K - 1 ? d.K - 1 : ci;
-                        const float new_max = s_cfg.caps[ci];
-                        const bool sw = inc && (!(flags & kStochSwitch) || r_agent[4][a] < d.p_switch);
-                        const float bonus = s - capa[a];
-                        capa[a] = sw ? new_max : capa[a];
-                        s = sw ? new_max + bonus : s;
-                        supp[a] = s;
-                        eqs[a] = e;
-                        at32(rowsf, (uint32_t)(r_supp + a) * Bu + bl) = supp[a];
-                        at32(rowsf, (uint32_t)(r_cap + a) * Bu + bl) = capa[a];
-                        at32(rows, (uint32_t)(r_equip + a) * Bu + bl) = eqs[a];
-                    }
-                }
-            }
-            if (MODE == kReset) {  // the configured agent state + zeroed bookkeeping (utils/env.py:137-160)
 #pragma unroll
                 for (int a = 0; a < AMAX; ++a)
-                    if (a < A) {
-                        at32(rowsf, (uint32_t)(r_supp + a) * Bu + bl) = supp[a];
-                        at32(rowsf, (uint32_t)(r_cap + a) * Bu + bl) = capa[a];
-                        at32(rows, (uint32_t)(r_equip + a) * Bu + bl) = eqs[a];
-                        at32(rowsf, (uint32_t)(r_rewards + a) * Bu + bl) = 0.0f;
-                        at32(rowsf, (uint32_t)(r_cum + a) * Bu + bl) = 0.0f;
-                        at32(rows1, (u_term + (uint32_t)a) * Bu + bl) = (uint8_t)0;
-                        at32(rows1, (u_trunc + (uint32_t)a) * Bu + bl) = (uint8_t)0;
-                    }
-                at32(rows, (uint32_t)r_moves * Bu + bl) = 0;
-                at32(rows, (uint32_t)r_burnouts * Bu + bl) = 0;
-                if (launch.seed_increment != 0 && active) at32(rows, (uint32_t)r_seeds * Bu + bl) += launch.seed_increment;  // fresh seeds per episode
-                at32(rows8, q_burnouts * Bu + bl) = 0;
-                at32(rows8, q_putouts * Bu + bl) = 0;
-                at32(rows1, u_frozen * Bu + bl) = (uint8_t)0;
-            }
-#pragma unroll
-            for (int a = 0; a < AMAX; ++a)
-                if (a < A) x_supp[a][slot] = supp[a];  // the field role stores the agent observations
-            FRZ_RSTAMP(5);
-            __syncthreads();  // (2) lit mask and fates visible
-            FRZ_RSTAMP(6);
+                    if (a < A) x_supp[a][slot] = supp[a];  // the field role stores the agent observations
+                FRZ_RSTAMP(5);
+                __syncthreads();  // (2) lit mask and fates visible
+                FRZ_RSTAMP(6);
 
-            // ---- phase 3: open-task sets, per-env counts, wavefront scan
-            const mask_t lit_all = x_lit[slot];
-            const mask_t lit1 = active ? lit_all : (mask_t)0;
-            const fate_t fate = x_fate[slot];
-            const mask_t burned = (mask_t)(fate & (fate_t)((1u << MB) - 1u)), put_out = (mask_t)((fate >> MB) & (fate_t)((1u << MB) - 1u));
-            const bool dead = ((fate >> (2 * MB)) & 1u) != 0;
-            bool term = term0, trunc = trunc0;
-            if (MODE == kStep) {
-                const int nm = crw.nm + 1;
-                trunc = (flags & kTruncate) ? nm >= d.max_steps : trunc0;
-                term = term0 || dead;
-                at32(rows, (uint32_t)r_moves * Bu + bl) = nm;
-            }
-            mask_t ok1[AMAX];
-            uint64_t packed[PW], incl[PW], base[PW];
-#pragma unroll
-            for (int w = 0; w < PW; ++w) packed[w] = 0;
-            const int F = popc(lit1);
-            packed[0] = (uint64_t)F;
-#pragma unroll
-            for (int a = 0; a < AMAX; ++a) {
-                ok1[a] = 0;
-                if (a < A) {
-                    ok1[a] = supp[a] > 0.0f ? (lit1 & (mask_t)s_cfg.range_mask[a][eqs[a]]) : (mask_t)0;
-                    packed[(a + 1) >> 2] |= (uint64_t)popc(ok1[a]) << (16 * ((a + 1) & 3));
+                // ---- phase 3: open-task sets, per-env counts, wavefront scan
+                const mask_t lit_all = x_lit[slot];
+                const mask_t lit1 = active ? lit_all : (mask_t)0;
+                const fate_t fate = x_fate[slot];
+                const mask_t burned = (mask_t)(fate & (fate_t)((1u << MB) - 1u)), put_out = (mask_t)((fate >> MB) & (fate_t)((1u << MB) - 1u));
+                const bool dead = ((fate >> (2 * MB)) & 1u) != 0;
+                bool term = term0, trunc = trunc0;
+                if (MODE == kStep) {
+                    const int nm = crw.nm + 1;
+                    trunc = (flags & kTruncate) ? nm >= d.max_steps : trunc0;
+                    term = term0 || dead;
+                    at32(rows, (uint32_t)r_moves * Bu + bl) = nm;
                 }
-            }
+                mask_t ok1[AMAX];
+                uint64_t packed[PW], incl[PW], base[PW];
 #pragma unroll
-            for (int w = 0; w < PW; ++w) incl[w] = frz::wave_inclusive_scan(packed[w]);
-            const uint32_t live_nt = (uint32_t)__popcll(__ballot(active && !term));
-            const uint32_t live_ntr = (uint32_t)__popcll(__ballot(active && !trunc));
-            if (lane == 63) {
-#pragma unroll
-                for (int w = 0; w < PW; ++w) s_wave_scan[wave][w] = incl[w];
-                s_wave_live[wave][0] = live_nt;
-                s_wave_live[wave][1] = live_ntr;
-            }
-#pragma unroll
-            for (int w = 0; w < PW; ++w) x_excl[w][slot] = incl[w] - packed[w];
-            {
-                pack_t oks = 0;
-#pragma unroll
-                for (int a = 0; a < AMAX; ++a) oks |= (pack_t)ok1[a] << (MB * a);
-                x_ok[slot] = oks;
-            }
-            FRZ_RSTAMP(7);
-            __syncthreads();  // (3) wavefront sums visible
-
-            // ---- phase 4: chunk sums published; rewards / bookkeeping hide the hand-off; look-back
-            const int round_first = chunk & ~(kRound - 1);  // chunks are handed off in windows of kRound
-            uint64_t block_total[PW];
-#pragma unroll
-            for (int w = 0; w < PW; ++w) {
-                base[w] = 0;
-                block_total[w] = 0;
-#pragma unroll
-                for (int j = 0; j < frz::kWaves; ++j) {
-                    const uint64_t t = s_wave_scan[j][w];
-                    base[w] += j < wave ? t : 0ull;
-                    block_total[w] += t;
-                }
-            }
-            uint32_t my_total = 0;  // this chunk's sum of channel `slot` (slot < nch)
-            if (slot < nch) {
-                if (slot <= A) {
-                    uint64_t word = block_total[0];
-#pragma unroll
-                    for (int w = 1; w < PW; ++w) word = (slot >> 2) == w ? block_total[w] : word;
-                    my_total = (uint32_t)((word >> (16 * (slot & 3))) & 0xFFFFull);
-                } else {
-                    const int which = slot - ch_nt;
-#pragma unroll
-                    for (int j = 0; j < frz::kWaves; ++j) my_total += s_wave_live[j][which];
-                }
-                frz::granule_store(agg + (int64_t)chunk * nch + slot, tag, my_total);
-            }
-
-            if (MODE == kStep) {
-                // rewards and termination (wildfire.py:534-582)
-                float fire_reward_sum = 0.0f, burnout_total = 0.0f;
-#pragma unroll
-                for (int c = 0; c < CMAX; ++c) {
-                    if (c < HW) {
-                        const float fr = d.fire_rewards[c];
-                        fire_reward_sum = __fadd_rn(fire_reward_sum, ((put_out >> c) & 1) ? fr : 0.0f);
-                        const float pen = (flags & kPenaltyScaled) ? __fmul_rn(-1.0f, fr) : d.burnout_penalty;
-                        burnout_total = __fadd_rn(burnout_total, ((burned >> c) & 1) ? pen : 0.0f);
-                    }
-                }
-                const bool newly = !term0 && dead;
-                // correctly rounded float32 log via double (matches the oracle bit for bit; the reference's torch.log is
-                // a <=1-ulp float32 log).  Only evaluated by wavefronts that hold a newly terminated env.
-                float log_burnouts = 0.0f;
-                if (newly && d.termination_kappa != 0.0f) log_burnouts = (float)log((double)crw.nb + 1.0);
-                const float penalty = __fmul_rn(d.termination_kappa, log_burnouts);
-                float term_reward = __fsub_rn(d.termination_reward, penalty);
-                term_reward = term_reward < 0.0f ? 0.0f : term_reward;
-                const int n_burn = popc(burned), n_put = popc(put_out);
-                const bool localize = (flags & kLocalize) != 0;
-                const bool track = (flags & kTrackCumulative) != 0, write_trunc = (flags & kTruncate) != 0;
+                for (int w = 0; w < PW; ++w) packed[w] = 0;
+                const int F = popc(lit1);
+                packed[0] = (uint64_t)F;
 #pragma unroll
                 for (int a = 0; a < AMAX; ++a) {
+                    ok1[a] = 0;
                     if (a < A) {
-                        float base_reward = fire_reward_sum;
-                        if (localize) {
-                            base_reward = 0.0f;
-#pragma unroll
-                            for (int c = 0; c < CMAX; ++c)
-                                if (c < HW) base_reward = (hit[a] == c && ((put_out >> c) & 1)) ? d.fire_rewards[c] : base_reward;
-                        }
-                        rew[a] = __fadd_rn(rew[a], __fadd_rn(base_reward, burnout_total));
-                        rew[a] = newly ? __fadd_rn(rew[a], term_reward) : rew[a];
-                        at32(rowsf, (uint32_t)(r_rewards + a) * Bu + bl) = rew[a];
-                        at32(rows1, (u_term + (uint32_t)a) * Bu + bl) = (uint8_t)term;
-                        if (write_trunc) at32(rows1, (u_trunc + (uint32_t)a) * Bu + bl) = (uint8_t)trunc;
-                        if (track) {
-                            const float total = __fadd_rn(crw.cum[a], rew[a]);
-                            at32(rowsf, (uint32_t)(r_cum + a) * Bu + bl) = total;
-                            if constexpr (PERSIST) crw.cum[a] = total;
-                        }
+                        ok1[a] = supp[a] > 0.0f ? (lit1 & (mask_t)s_cfg.range_mask[a][eqs[a]]) : (mask_t)0;
+                        packed[(a + 1) >> 2] |= (uint64_t)popc(ok1[a]) << (16 * ((a + 1) & 3));
                     }
                 }
-                at32(rows, (uint32_t)r_burnouts * Bu + bl) = crw.nb + n_burn;
-                if constexpr (PERSIST) crw.nb += n_burn;
-                at32(rows8, q_burnouts * Bu + bl) = n_burn;
-                at32(rows8, q_putouts * Bu + bl) = n_put;
-            }
-            if (active) {
 #pragma unroll
-                for (int a = 0; a < AMAX; ++a)
-                    if (a < A) at32(rows, (uint32_t)(r_atc + a) * Bu + bl) = popc(ok1[a]);
-                at32(rows8, q_etc * Bu + bl) = F;
-            }
-            // inter-workgroup exclusive prefix (single pass), as in wildfire.hip: crew thread t sums channel (t % NCHP) over
-            // predecessors t / NCHP, t / NCHP + PP, ...; the window's loads are unconditional so they are in flight together
-            bool timed_out = false;
-            uint32_t acc = 0;
-            {
-                const int ch = slot & (NCHP - 1), pslot = slot / NCHP;
-                constexpr int PP = kBlock / NCHP, UNR = 8;
-                for (int first = round_first; first < (FRZ_SKIP(7) ? round_first : chunk); first += PP * UNR) {  // (bit 7: timing experiments)
-                    uint32_t part = 0;
-                    for (int spin = 0;; ++spin) {  // bounded: every granule of the window must carry this launch's tag
-                        bool all = true;
-                        part = 0;
+                for (int w = 0; w < PW; ++w) incl[w] = frz::wave_inclusive_scan(packed[w]);
+                const uint32_t live_nt = (uint32_t)__popcll(__ballot(active && !term));
+                const uint32_t live_ntr = (uint32_t)__popcll(__ballot(active && !trunc));
+                if (lane == 63) {
 #pragma unroll
-                        for (int u = 0; u < UNR; ++u) {
-                            const int pred = first + u * PP + pslot;
-                            const bool valid = pred < chunk && ch < nch;
-                            const uint64_t g = frz::granule_load(agg + (valid ? (int64_t)pred * nch + ch : (int64_t)0));
-                            all = all && (!valid || (uint32_t)(g >> 32) == tag);
-                            part += valid ? (uint32_t)g : 0u;
-                        }
-                        if (all) break;
-                        if (gave_up || spin >= (1 << 22)) {
-                            timed_out = gave_up = true;
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(2);
+                    for (int w = 0; w < PW; ++w) s_wave_scan[wave][w] = incl[w];
+                    s_wave_live[wave][0] = live_nt;
+                    s_wave_live[wave][1] = live_ntr;
+                }
+#pragma unroll
+                for (int w = 0; w < PW; ++w) x_excl[w][slot] = incl[w] - packed[w];
+                {
+                    pack_t oks = 0;
+#pragma unroll
+                    for (int a = 0; a < AMAX; ++a) oks |= (pack_t)ok1[a] << (MB * a);
+                    x_ok[slot] = oks;
+                }
+                FRZ_RSTAMP(7);
+                __syncthreads();  // (3) wavefront sums visible
+
+                // ---- phase 4: chunk sums published; rewards / bookkeeping hide the hand-off; look-back
+                const int round_first = chunk & ~(kRound - 1);  // chunks are handed off in windows of kRound
+                uint64_t block_total[PW];
+#pragma unroll
+                for (int w = 0; w < PW; ++w) {
+                    base[w] = 0;
+                    block_total[w] = 0;
+#pragma unroll
+                    for (int j = 0; j < frz::kWaves; ++j) {
+                        const uint64_t t = s_wave_scan[j][w];
+                        base[w] += j < wave ? t : 0ull;
+                        block_total[w] += t;
                     }
-                    acc += part;
                 }
-                if (round_first > 0 && slot < nch) acc += frz::granule_wait(prefix + (int64_t)(round_first - 1) * nch + slot, tag, &timed_out);
+                uint32_t my_total = 0;  // this chunk's sum of channel `slot` (slot < nch)
+                if (slot < nch) {
+                    if (slot <= A) {
+                        uint64_t word = block_total[0];
 #pragma unroll
-                for (int dd = NCHP; dd < 64; dd <<= 1) acc += __shfl_xor(acc, dd, 64);
-                if (lane < NCHP) s_reduce[wave][lane] = acc;
-            }
-            FRZ_RSTAMP(8);
-            __syncthreads();  // (4) look-back partial sums visible
-
-            // ---- phase 5: chunk prefix
-            if (slot < nch) {
-                uint32_t s = 0;
+                        for (int w = 1; w < PW; ++w) word = (slot >> 2) == w ? block_total[w] : word;
+                        my_total = (uint32_t)((word >> (16 * (slot & 3))) & 0xFFFFull);
+                    } else {
+                        const int which = slot - ch_nt;
 #pragma unroll
-                for (int j = 0; j < frz::kWaves; ++j) s += s_reduce[j][slot];
-                s_prefix[slot] = s;
-                const bool round_last = (chunk & (kRound - 1)) == kRound - 1 || chunk == nchunks - 1;
-                if (round_last) {
-                    frz::granule_store(prefix + (int64_t)chunk * nch + slot, tag, s + my_total);
-                    if (chunk == nchunks - 1) cur_totals[slot] = s + my_total;  // batch totals, read by the next launch
+                        for (int j = 0; j < frz::kWaves; ++j) my_total += s_wave_live[j][which];
+                    }
+                    frz::granule_store(agg + (int64_t)chunk * nch + slot, tag, my_total);
                 }
-            }
-            __syncthreads();  // (5) chunk prefix visible
-            FRZ_RSTAMP(9);
-            if (timed_out) err |= FRZ_ERR_SCAN_TIMEOUT;
 
-            // ---- phase 6: the even agents' action lists (the field role writes the odd ones and the task list)
-            emit_crew(lit1, ok1, copy);
-            FRZ_RSTAMP(10);
-            FRZ_RWALL(1);
-            if constexpr (PERSIST) {  // what the next step of this launch starts from
-                lit_before = lit_all;
-                crw.term = term ? 1u : 0u, crw.trunc = trunc ? 1u : 0u;
-                crw.nm += 1;
-            }
+                if (MODE == kStep) {
+                    // rewards and termination (wildfire.py:534-582)
+                    float fire_reward_sum = 0.0f, burnout_total = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c) {
+                        if (c < HW) {
+                            const float fr = d.fire_rewards[c];
+                            fire_reward_sum = __fadd_rn(fire_reward_sum, ((put_out >> c) & 1) ? fr : 0.0f);
+                            const float pen = (flags & kPenaltyScaled) ? __fmul_rn(-1.0f, fr) : d.burnout_penalty;
+                            burnout_total = __fadd_rn(burnout_total, ((burned >> c) & 1) ? pen : 0.0f);
+                        }
+                    }
+                    const bool newly = !term0 && dead;
+                    // correctly rounded float32 log via double (matches the oracle bit for bit; the reference's torch.log is
+                    // a <=1-ulp float32 log).  Only evaluated by wavefronts that hold a newly terminated env.
+                    float log_burnouts = 0.0f;
+                    if (newly && d.termination_kappa != 0.0f) log_burnouts = (float)log((double)crw.nb + 1.0);
+                    const float penalty = __fmul_rn(d.termination_kappa, log_burnouts);
+                    float term_reward = __fsub_rn(d.termination_reward, penalty);
+                    term_reward = term_reward < 0.0f ? 0.0f : term_reward;
+                    const int n_burn = popc(burned), n_put = popc(put_out);
+                    const bool localize = (flags & kLocalize) != 0;
+                    const bool track = (flags & kTrackCumulative) != 0, write_trunc = (flags & kTruncate) != 0;
+#pragma unroll
+                    for (int a = 0; a < AMAX; ++a) {
+                        if (a < A) {
+                            float base_reward = fire_reward_sum;
+                            if (localize) {
+                                base_reward = 0.0f;
+#pragma unroll
+                                for (int c = 0; c < CMAX; ++c)
+                                    if (c < HW) base_reward = (hit[a] == c && ((put_out >> c) & 1)) ? d.fire_rewards[c] : base_reward;
+                            }
+                            rew[a] = __fadd_rn(rew[a], __fadd_rn(base_reward, burnout_total));
+                            rew[a] = newly ? __fadd_rn(rew[a], term_reward) : rew[a];
+                            at32(rowsf, (uint32_t)(r_rewards + a) * Bu + bl) = rew[a];
+                            at32(rows1, (u_term + (uint32_t)a) * Bu + bl) = (uint8_t)term;
+                            if (write_trunc) at32(rows1, (u_trunc + (uint32_t)a) * Bu + bl) = (uint8_t)trunc;
+                            if (track) {
+                                const float total = __fadd_rn(crw.cum[a], rew[a]);
+                                at32(rowsf, (uint32_t)(r_cum + a) * Bu + bl) = total;
+                                if constexpr (PERSIST) crw.cum[a] = total;
+                            }
+                        }
+                    }
+                    at32(rows, (uint32_t)r_burnouts * Bu + bl) = crw.nb + n_burn;
+                    if constexpr (PERSIST) crw.nb += n_burn;
+                    at32(rows8, q_burnouts * Bu + bl) = n_burn;
+                    at32(rows8, q_putouts * Bu + bl) = n_put;
+                }
+                if (active) {
+#pragma unroll
+                    for (int a = 0; a < AMAX; ++a)
+                        if (a < A) at32(rows, (uint32_t)(r_atc + a) * Bu + bl) = popc(ok1[a]);
+                    at32(rows8, q_etc * Bu + bl) = F;
+                }
+                // inter-workgroup exclusive prefix (single pass), as in wildfire.hip: crew thread t sums channel (t % NCHP) over
+                // predecessors t / NCHP, t / NCHP + PP, ...; the window's loads are unconditional so they are in flight together
+                bool timed_out = false;
+                uint32_t acc = 0;
+                {
+                    const int ch = slot & (NCHP - 1), pslot = slot / NCHP;
+                    constexpr int PP = kBlock / NCHP, UNR = 8;
+                    for (int first = round_first; first < (FRZ_SKIP(7) ? round_first : chunk); first += PP * UNR) {  // (bit 7: timing experiments)
+                        uint32_t part = 0;
+                        for (int spin = 0;; ++spin) {  // bounded: every granule of the window must carry this launch's tag
+                            bool all = true;
+                            part = 0;
+#pragma unroll
+                            for (int u = 0; u < UNR; ++u) {
+                                const int pred = first + u * PP + pslot;
+                                const bool valid = pred < chunk && ch < nch;
+                                const uint64_t g = frz::granule_load(agg + (valid ? (int64_t)pred * nch + ch : (int64_t)0));
+                                all = all && (!valid || (uint32_t)(g >> 32) == tag);
+                                part += valid ? (uint32_t)g : 0u;
+                            }
+                            if (all) break;
+                            if (gave_up || spin >= (1 << 22)) {
+                                timed_out = gave_up = true;
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(2);
+                        }
+                        acc += part;
+                    }
+                    if (round_first > 0 && slot < nch) acc += frz::granule_wait(prefix + (int64_t)(round_first - 1) * nch + slot, tag, &timed_out);
+#pragma unroll
+                    for (int dd = NCHP; dd < 64; dd <<= 1) acc += __shfl_xor(acc, dd, 64);
+                    if (lane < NCHP) s_reduce[wave][lane] = acc;
+                }
+                FRZ_RSTAMP(8);
+                __syncthreads();  // (4) look-back partial sums visible
+
+                // ---- phase 5: chunk prefix
+                if (slot < nch) {
+                    uint32_t s = 0;
+#pragma unroll
+                    for (int j = 0; j < frz::kWaves; ++j) s += s_reduce[j][slot];
+                    s_prefix[slot] = s;
+                    const bool round_last = (chunk & (kRound - 1)) == kRound - 1 || chunk == nchunks - 1;
+                    if (round_last) {
+                        frz::granule_store(prefix + (int64_t)chunk * nch + slot, tag, s + my_total);
+                        if (chunk == nchunks - 1) cur_totals[slot] = s + my_total;  // batch totals, read by the next launch
+                    }
+                }
+                __syncthreads();  // (5) chunk prefix visible
+                FRZ_RSTAMP(9);
+                if (timed_out) err |= FRZ_ERR_SCAN_TIMEOUT;
+
+                // ---- phase 6: the even agents' action lists (the field role writes the odd ones and the task list)
+                emit_crew(lit1, ok1, copy);
+                FRZ_RSTAMP(10);
+                FRZ_RWALL(1);
+                if constexpr (PERSIST) {  // what the next step of this launch starts from
+                    lit_before = lit_all;
+                    crw.term = term ? 1u : 0u, crw.trunc = trunc ? 1u : 0u;
+                    crw.nm += 1;
+                }
             }  // steps of this launch
             if (err) atomicOr(error_word, err);
         }
