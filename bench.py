@@ -354,6 +354,32 @@ def main():
             task_sum[0] += env.environment_task_count.sum()
             task_sum[1:] += env.agent_task_count.sum(dim=1)
     torch.cuda.synchronize(device)
+    # what a timed block is made of: its reset launch and — where an episode's steps are one launch — that launch at the block's own
+    # length (the first K steps of an episode, its most list-heavy ones), each by events around the dispatch; the rest of the block's
+    # median is graph launch, gaps between the launches and the completion hand-back
+    block_parts = None
+    if steps_per_launch > 1:
+        first = min(K, EPISODE)
+        reset_ms, rollout_ms = [], []
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(5):
+            torch.cuda.synchronize(device)
+            e0.record()
+            _capi.check(lib.frz_wildfire_reset_reseed(handle, 0, stream), 'frz_wildfire_reset_reseed')
+            e1.record()
+            torch.cuda.synchronize(device)
+            reset_ms.append(e0.elapsed_time(e1))
+            one = ctypes.c_float()
+            if first > 1:
+                _capi.check(lib.frz_wildfire_timed_rollout_launch(handle, policy_seed, 0, first, env._actions.data_ptr(), mode, stream, ctypes.byref(one)),
+                            'frz_wildfire_timed_rollout_launch')
+                rollout_ms.append(one.value)
+        if rollout_ms:
+            episodes = math.ceil(K / EPISODE)
+            block_parts = {'reset_launch_ms': float(np.median(reset_ms)), f'first_{first}_steps_launch_ms': float(np.median(rollout_ms)),
+                           'launches_per_block': 2 * episodes,
+                           'note': 'event-to-event around eager dispatches (the reset figure includes its launch gap); in the timed graph the '
+                                   'episode metrics ride in the rollout launch\'s tail'}
     n_probe = PROBE_EPISODES * EPISODE
     single_step_ms_avg = float(np.mean(kernel_ms))
     # duration of the dominant kernel's launch as the timed region runs it (per launch; per step = / steps_per_launch)
@@ -390,7 +416,7 @@ def main():
                                    f'{repeats} times, each bracketed by barrier + synchronize; median block over the max-over-ranks times',
                        'blocks': repeats, 'block_ms_median': 1e3 * median_s, 'block_ms_min': 1e3 * float(block_s.min()),
                        'block_ms_max': 1e3 * float(block_s.max()), 'block_ms_mean': 1e3 * float(block_s.mean()),
-                       'steps_timed_in_total': repeats * K,
+                       'steps_timed_in_total': repeats * K, 'block_parts': block_parts,
                        'job_metrics': {'mean_episode_return_per_agent': (finished_metrics[:A] / max(world * B * episodes_per_block * repeats, 1)).tolist(),
                                        'env_steps_counted': float(finished_metrics[A].item())}},
             'agent_steps_per_s': value * A,
