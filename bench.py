@@ -423,8 +423,7 @@ def main():
             'python_api_env_steps_per_s': api_value,
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'traffic_source': traffic_source,
-                         'kernel': ('wf_roles_kernel<6,3,exact,philox,step,multi-step>' if steps_per_launch > 1 else
-                                    'wf_roles_kernel<6,3,exact,philox,step>' if args.rng == 'philox' else 'wf_roles_kernel<6,3,exact,mt19937,step>'),
+                         'kernel': f'wf_roles_kernel<6,3,exact,{args.rng},step' + (',multi-step>' if steps_per_launch > 1 else '>'),
                          'steps_per_launch': steps_per_launch,
                          'kernel_ms_avg': kernel_ms_avg, 'kernel_ms_median': float(np.median(launch_ms if launch_ms else kernel_ms)),
                          'launches_timed': len(launch_ms) if launch_ms else n_probe,

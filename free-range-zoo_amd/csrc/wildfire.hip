@@ -1627,8 +1627,8 @@ int frz_wildfire_set_exclusive_device(frz_wildfire_env* env, int exclusive) {
 
 int frz_wildfire_rollout_launches(const frz_wildfire_env* env, int32_t n_steps, int rng_mode) {
     if (!env || n_steps < 0) return FRZ_E_INVALID;
-    const bool one = n_steps > 1 && env->exclusive_device && env->list_copy_delta != 0 && !env->ticketed && rng_mode == FRZ_RNG_PHILOX &&
-                     env->dev.roles && !env->dev.grid;
+    const bool one = n_steps > 1 && env->exclusive_device && env->list_copy_delta != 0 && !env->ticketed &&
+                     (rng_mode == FRZ_RNG_PHILOX || rng_mode == FRZ_RNG_MT19937) && env->dev.roles && !env->dev.grid;
     return one ? 1 : n_steps;
 }
 

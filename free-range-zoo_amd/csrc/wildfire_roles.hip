@@ -290,7 +290,8 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
     const int ch_nt = A + 1, ch_ntr = A + 2;
     const uint32_t flags_word = d.flags;
 
-    static_assert(!PERSIST || (EXACT && RNG == FRZ_RNG_PHILOX && MODE == kStep), "the multi-step launch exists for the exact Philox step kernels");
+    static_assert(!PERSIST || (EXACT && (RNG == FRZ_RNG_PHILOX || RNG == FRZ_RNG_MT19937) && MODE == kStep),
+                  "the multi-step launch exists for the exact step kernels that draw in-kernel");
     const int n_steps = PERSIST ? launch.n_steps : 1;
     uint32_t epoch_now = epoch;     // the epoch the current step runs under (advances with every executed step of a multi-step launch)
     uint32_t tag = epoch + 1u;      // never 0 on a zero-filled arena
@@ -501,6 +502,20 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                     }
                 }
             };
+            // Between two steps of a multi-step launch: the totals of the step that just ended (the launch's only inter-step barrier); true when
+            // they say that the batch is finished — nothing more happens in this launch (utils/env.py:211-213)
+            auto between_steps = [&](int t) {
+                if (t > 0) await_totals();
+                if (!is_frozen()) return false;
+                frozen_step();
+                if (t > 0) {  // the last lists went to the second copy: once more, into the caller's buffers
+                    mask_t lit_last = 0;
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c) lit_last |= (mask_t)(f[c] > 0) << c;
+                    emit_field(active ? lit_last : (mask_t)0, 0);
+                }
+                return true;
+            };
             for (int t = 0; t < n_steps; ++t) {
                 const int64_t copy = list_copy(t);
                 // per-step opaque copies: the flag tests stay next to their uses, and in a multi-step launch so do the row addresses — hoisted
@@ -517,6 +532,11 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                 const WfHot& d = PERSIST ? static_cast<const WfHot&>(s_cfg) : d_launch;
                 if constexpr (PERSIST) {
                     if (t > 0) request_totals();
+                }
+                if constexpr (PERSIST && kMt) {
+                    // MT19937: a finished batch must leave the env streams where they are (the reference returns before drawing), so the test
+                    // comes before the draws
+                    if (between_steps(t)) break;
                 }
                 // ---- phase 1: the step's field draws
                 float r_field[3][CMAX];
@@ -581,6 +601,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                             int j = i0 + U;
                             j -= j >= kN ? kN : 0;
                             at32(rows, (uint32_t)(r_seeds + 1) * Bu + bl) = j;
+                            if constexpr (PERSIST) fld.mti = j;
                         }
 #pragma unroll
                         for (int e = 0; e < 3; ++e)
@@ -598,21 +619,10 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
 #pragma unroll
                         for (int c = 0; c < CMAX; ++c) asm volatile("" : "+v"(r_field[e][c]));
                 }
-                if constexpr (PERSIST) {
-                    // Between two steps of a multi-step launch.  The draws above need nothing from the other workgroups, so the wait for
-                    // the totals of the step that just ended (the launch's only inter-step barrier) comes after them: the crew, which needs
-                    // the totals for its decode, waits first, and this role's ~700 instructions of Philox cover the same time.
-                    if (t > 0) await_totals();
-                    if (is_frozen()) {
-                        frozen_step();
-                        if (t > 0) {  // the last lists went to the second copy: once more, into the caller's buffers
-                            mask_t lit_last = 0;
-#pragma unroll
-                            for (int c = 0; c < CMAX; ++c) lit_last |= (mask_t)(f[c] > 0) << c;
-                            emit_field(active ? lit_last : (mask_t)0, 0);
-                        }
-                        break;
-                    }
+                if constexpr (PERSIST && !kMt) {
+                    // Philox: the draws above need nothing from the other workgroups, so the wait for the totals of the step that just ended
+                    // comes after them — the crew, which needs the totals for its decode, waits first, and this role's draws cover the same time
+                    if (between_steps(t)) break;
                 }
                 FRZ_RSTAMP(3);
                 __syncthreads();  // (1) applied power visible
@@ -1308,9 +1318,14 @@ void launch_roles_variant(const WfArgs& a, const WfDev* dev, int grid, int rng, 
                                    a.field_rand, a.agent_rand, batch);
         }
     } else if (rng == FRZ_RNG_MT19937) {
-        if constexpr (EXACT)
-            launch_step_kernel(a, wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_MT19937, kStep>, grid, kRoleBlock, stream, a.arena, dev, a.actions,
-                               a.field_rand, a.agent_rand, batch);
+        if constexpr (EXACT) {
+            if (a.n_steps > 1)
+                launch_step_kernel(a, wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_MT19937, kStep, true>, grid, kRoleBlock, stream, a.arena, dev,
+                                   a.actions, a.field_rand, a.agent_rand, batch);
+            else
+                launch_step_kernel(a, wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_MT19937, kStep>, grid, kRoleBlock, stream, a.arena, dev, a.actions,
+                                   a.field_rand, a.agent_rand, batch);
+        }
     } else {
         launch_step_kernel(a, wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kStep>, grid, kRoleBlock, stream, a.arena, dev, a.actions,
                            a.field_rand, a.agent_rand, batch);

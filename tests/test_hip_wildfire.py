@@ -713,3 +713,24 @@ def test_rollout_with_metrics_equals_rollout_then_metrics(B, steps, max_steps):
     two.accumulate_episode_metrics(m_two)
     one.accumulate_episode_metrics(m_one)
     assert torch.equal(m_two, m_one)
+
+
+@pytest.mark.parametrize('B,steps,max_steps', [(65536, 50, 50), (1000, 7, 50), (1500, 9, 5), (1500, 8, 5)])
+def test_multi_step_launch_with_mt19937_streams(B, steps, max_steps):
+    """The default RNG (per-env MT19937 streams, bit-identical to the reference's generator) through the multi-step launch: same results and
+    the same stream positions as single-step launches — also when the episode ends inside the launch, where the finished batch must leave
+    the streams where they are (the reference returns before drawing, utils/env.py:211-213)."""
+    one, many = [make_env(configs.wildfire_openness, B, max_steps, rng='mt19937', exact_shapes=False) for _ in range(2)]
+    many.set_exclusive_device(True)
+    for env in (one, many):
+        env.reset(seed=torch.arange(B, dtype=torch.int32) + 21)
+    assert many._lib.frz_wildfire_rollout_launches(many._handle, steps, _capi.FRZ_RNG_MT19937) == 1
+    for t in range(steps):
+        one.step_random_policy(policy_seed=6, policy_step=t)
+    many.rollout_random_policy(steps, policy_seed=6, first_step=0)
+    assert_same_env(one, many, 'mt19937 rollout')
+    assert torch.equal(one.generator.generator_index, many.generator.generator_index), 'stream positions'
+    assert torch.equal(one.generator.generator_states, many.generator.generator_states), 'stream states'
+    assert int(one.num_moves.max()) == min(steps, max_steps)
+    one.check()
+    many.check()
