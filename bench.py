@@ -391,6 +391,8 @@ def main():
     traffic, traffic_source = recorded_traffic('wf_step_kernel_bytes_per_step')
     if traffic is not None:
         traffic *= steps_per_launch  # per launch, like `achieved`
+    if args.rng != 'philox':  # the counter passes were made in the Philox mode (the MT19937 mode also streams 67 generator words per env-step)
+        traffic, traffic_source = None, 'recorded for rng=philox only'
 
     if rank == 0:
         env.check()
