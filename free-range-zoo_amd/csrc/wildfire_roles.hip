@@ -540,6 +540,11 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                 }
                 // ---- phase 1: the step's field draws
                 float r_field[3][CMAX];
+                // FRZ_RNG_MT19937: the twisted words of this step and where they go — stored behind barrier (1).  The lanes that shadow the
+                // last env of a ragged batch read that env's stream too and must see it as its owner does: every load of a step is then
+                // ordered before every store of the step by a workgroup barrier (they used to be ordered by timing only)
+                uint32_t mt_twisted[kMt ? 3 * CMAX + 5 * AMAX : 1];
+                int mt_first = 0;
                 if (MODE == kStep) {
                     if constexpr (kInjected) {
 #pragma unroll
@@ -588,21 +593,14 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                         for (int k = 0; k < U; ++k) {
                             const uint32_t y = (w[k] & 0x80000000u) | (w[k + 1] & 0x7fffffffu);
                             uint32_t v = far[k] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-                            int j = i0 + k;
-                            j -= j >= kN ? kN : 0;
-                            mt[(int64_t)j * B + bl] = v;
+                            mt_twisted[k] = v;
                             v ^= v >> 11;
                             v ^= (v << 7) & 0x9d2c5680u;
                             v ^= (v << 15) & 0xefc60000u;
                             v ^= v >> 18;
                             uni[k] = (float)(v & 0xFFFFFFu) * (1.0f / 16777216.0f);
                         }
-                        {
-                            int j = i0 + U;
-                            j -= j >= kN ? kN : 0;
-                            at32(rows, (uint32_t)(r_seeds + 1) * Bu + bl) = j;
-                            if constexpr (PERSIST) fld.mti = j;
-                        }
+                        mt_first = i0;
 #pragma unroll
                         for (int e = 0; e < 3; ++e)
 #pragma unroll
@@ -627,6 +625,20 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                 FRZ_RSTAMP(3);
                 __syncthreads();  // (1) applied power visible
                 FRZ_RSTAMP(4);
+                if constexpr (kMt) {  // the stream moves on: twisted words in place, new position
+                    constexpr int U = 3 * CMAX + 5 * AMAX, kN = 624;
+                    uint32_t* const mt = reinterpret_cast<uint32_t*>(arena + launch.off_mt_state);
+#pragma unroll
+                    for (int k = 0; k < U; ++k) {
+                        int j = mt_first + k;
+                        j -= j >= kN ? kN : 0;
+                        mt[(int64_t)j * B + bl] = mt_twisted[k];
+                    }
+                    int j = mt_first + U;
+                    j -= j >= kN ? kN : 0;
+                    at32(rows, (uint32_t)(r_seeds + 1) * Bu + bl) = j;
+                    if constexpr (PERSIST) fld.mti = j;
+                }
 
                 // ---- phase 2: fire increase / decrease, spread, dead test
                 mask_t burned = 0, put_out = 0, lit1 = 0;

@@ -734,3 +734,27 @@ def test_multi_step_launch_with_mt19937_streams(B, steps, max_steps):
     assert int(one.num_moves.max()) == min(steps, max_steps)
     one.check()
     many.check()
+
+
+EXACT_SHAPES = [(2, 3, 3), (2, 3, 2), (3, 3, 3), (3, 3, 4), (2, 4, 3), (2, 4, 4), (3, 4, 3), (3, 4, 4), (4, 4, 3), (4, 4, 4), (2, 2, 2), (2, 2, 3),
+                (2, 4, 2), (3, 3, 2), (3, 4, 2), (4, 4, 2), (2, 3, 4)]
+
+
+@pytest.mark.parametrize('shape', EXACT_SHAPES, ids=lambda s: 'x'.join(map(str, s)))
+def test_multi_step_launch_of_every_exact_shape(shape):
+    """Every shape with an exact field/crew instantiation (FRZ_WF_VARIANT_LIST) has a multi-step kernel: each against single-step launches,
+    fully stochastic configuration, ragged batch, both RNG modes that draw in-kernel."""
+    H, Wd, A = shape
+    B = 777
+    for rng, mode in (('philox', _capi.FRZ_RNG_PHILOX), ('mt19937', _capi.FRZ_RNG_MT19937)):
+        build = lambda: configs.wildfire_grid(H, Wd, A, seed=H * 7 + Wd * 3 + A)  # noqa: E731
+        one, many = [make_env(build, B, 30, rng=rng, exact_shapes=False) for _ in range(2)]
+        many.set_exclusive_device(True)
+        assert many._lib.frz_wildfire_rollout_launches(many._handle, 6, mode) == 1, f'{shape} has no multi-step launch'
+        for env in (one, many):
+            env.reset(seed=torch.arange(B, dtype=torch.int32) + 2)
+        for t in range(6):
+            one.step_random_policy(policy_seed=9, policy_step=t)
+        many.rollout_random_policy(6, policy_seed=9, first_step=0)
+        assert_same_env(one, many, f'{shape} {rng}')
+        many.check()
