@@ -225,7 +225,8 @@ int frz_wildfire_step_random_policy(frz_wildfire_env* env, uint64_t policy_seed,
  * leave — state, rewards, the last step's observations, lists and sampled actions; intermediate steps' outputs are produced and
  * overwritten, as a loop over step() overwrites them — stream-ordered; rng_mode FRZ_RNG_PHILOX or FRZ_RNG_MT19937 (capture it into a
  * HIP graph for rollouts).  One launch per step, or — after frz_wildfire_set_exclusive_device(env, 1), for exact field/crew shapes
- * with FRZ_RNG_PHILOX and parallel_envs <= 256 x CUs — ONE launch whose workgroups keep their envs in registers from step to step
+ * with FRZ_RNG_PHILOX or FRZ_RNG_MT19937 and parallel_envs <= 256 x CUs — ONE launch whose workgroups keep their envs in registers
+ * from step to step
  * (frz_wildfire_rollout_launches tells which). */
 int frz_wildfire_rollout_random_policy(frz_wildfire_env* env, uint64_t policy_seed, uint64_t first_step, int32_t n_steps,
                                        int32_t* actions_out, int rng_mode, void* stream);
@@ -284,7 +285,7 @@ int frz_wildfire_rollout_random_policy_metrics(frz_wildfire_env* env, uint64_t p
  * for its own stragglers can stall both until their bounded spins give up (FRZ_ERR_SCAN_TIMEOUT).  Off by default. */
 int frz_wildfire_set_exclusive_device(frz_wildfire_env* env, int exclusive);
 /* How many kernel launches frz_wildfire_rollout_random_policy(n_steps) enqueues for this env and RNG mode: 1 when the whole rollout runs
- * as one multi-step launch (exact field/crew shapes, FRZ_RNG_PHILOX, every chunk's workgroup resident at once,
+ * as one multi-step launch (exact field/crew shapes, FRZ_RNG_PHILOX or FRZ_RNG_MT19937, every chunk's workgroup resident at once,
  * frz_wildfire_set_exclusive_device on), n_steps otherwise. */
 int frz_wildfire_rollout_launches(const frz_wildfire_env* env, int32_t n_steps, int rng_mode);
 /* Measurement aid: frz_wildfire_rollout_random_policy(n_steps) when it is ONE launch, bracketed by a pair of HIP events that take that
