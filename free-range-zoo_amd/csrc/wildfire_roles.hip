@@ -253,6 +253,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
     // over chunks: the kernel body is straight-line code per role (a chunk loop made the compiler hoist every
     // loop-invariant scalar in front of it: +~700 instructions and ~60 spilled scalar registers per wavefront).
     __shared__ int s_ticket;
+    __shared__ int s_stop;  // multi-step launches: the workgroup's verdict on "the batch is finished", see `stop` in the crew role
     int chunk = blockIdx.x;
     if (launch.ticketed) {
         uint32_t* const counter = reinterpret_cast<uint32_t*>(arena + launch.off_epoch) + 32;
@@ -502,20 +503,6 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                     }
                 }
             };
-            // Between two steps of a multi-step launch: the totals of the step that just ended (the launch's only inter-step barrier); true when
-            // they say that the batch is finished — nothing more happens in this launch (utils/env.py:211-213)
-            auto between_steps = [&](int t) {
-                if (t > 0) await_totals();
-                if (!is_frozen()) return false;
-                frozen_step();
-                if (t > 0) {  // the last lists went to the second copy: once more, into the caller's buffers
-                    mask_t lit_last = 0;
-#pragma unroll
-                    for (int c = 0; c < CMAX; ++c) lit_last |= (mask_t)(f[c] > 0) << c;
-                    emit_field(active ? lit_last : (mask_t)0, 0);
-                }
-                return true;
-            };
             for (int t = 0; t < n_steps; ++t) {
                 const int64_t copy = list_copy(t);
                 // per-step opaque copies: the flag tests stay next to their uses, and in a multi-step launch so do the row addresses — hoisted
@@ -530,14 +517,6 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                     asm volatile("" ::: "memory");  // and the configuration is read from LDS where a step uses it, not once above the loop
                 }
                 const WfHot& d = PERSIST ? static_cast<const WfHot&>(s_cfg) : d_launch;
-                if constexpr (PERSIST) {
-                    if (t > 0) request_totals();
-                }
-                if constexpr (PERSIST && kMt) {
-                    // MT19937: a finished batch must leave the env streams where they are (the reference returns before drawing), so the test
-                    // comes before the draws
-                    if (between_steps(t)) break;
-                }
                 // ---- phase 1: the step's field draws
                 float r_field[3][CMAX];
                 // FRZ_RNG_MT19937: the twisted words of this step and where they go — stored behind barrier (1).  The lanes that shadow the
@@ -617,14 +596,25 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
 #pragma unroll
                         for (int c = 0; c < CMAX; ++c) asm volatile("" : "+v"(r_field[e][c]));
                 }
-                if constexpr (PERSIST && !kMt) {
-                    // Philox: the draws above need nothing from the other workgroups, so the wait for the totals of the step that just ended
-                    // comes after them — the crew, which needs the totals for its decode, waits first, and this role's draws cover the same time
-                    if (between_steps(t)) break;
-                }
                 FRZ_RSTAMP(3);
                 __syncthreads();  // (1) applied power visible
                 FRZ_RSTAMP(4);
+                if constexpr (PERSIST) {
+                    // Is the batch finished (utils/env.py:211-213: nothing more happens in this launch)?  The crew's first wavefront has
+                    // looked at the totals of the step that just ended and left its verdict in LDS: one verdict per workgroup, so that both
+                    // roles leave the loop at the same barrier whatever each wavefront's own polls returned.  (An MT19937 stream has not
+                    // moved yet: its words are stored below.)
+                    if (s_stop) {
+                        frozen_step();
+                        if (t > 0) {  // the last lists went to the second copy: once more, into the caller's buffers
+                            mask_t lit_last = 0;
+#pragma unroll
+                            for (int c = 0; c < CMAX; ++c) lit_last |= (mask_t)(f[c] > 0) << c;
+                            emit_field(active ? lit_last : (mask_t)0, 0);
+                        }
+                        break;
+                    }
+                }
                 if constexpr (kMt) {  // the stream moves on: twisted words in place, new position
                     constexpr int U = 3 * CMAX + 5 * AMAX, kN = 624;
                     uint32_t* const mt = reinterpret_cast<uint32_t*>(arena + launch.off_mt_state);
@@ -826,9 +816,6 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                 }
             };
             for (int t = 0; t < n_steps; ++t) {
-                if constexpr (PERSIST) {
-                    if (t == 0 && is_frozen()) break;  // (later steps: tested in phase 1, once the totals of the step before have arrived)
-                }
                 const int64_t copy = list_copy(t);
                 // per-step opaque copies: the flag tests stay next to their uses, and in a multi-step launch so do the row addresses — hoisted
                 // out of the step loop, the ~100 store addresses and ~40 row bases of a step would all be live from the top of the kernel
@@ -854,6 +841,10 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                 // state just loaded: attackable set of agent a = lit fires within its (equipment-adjusted) range, non-empty
                 // only while it has suppressant (wildfire.py:604-623).
                 bool stop = false;  // multi-step launch: the batch turned out to be finished
+                int2 sampled[AMAX];  // the policy's choices and the decode's error bits: kept until the workgroup's verdict (behind barrier 1)
+                uint32_t err1 = 0;
+#pragma unroll
+                for (int a = 0; a < AMAX; ++a) sampled[a] = make_int2(0, -1);
                 if (MODE == kStep) {
                     const mask_t lit0 = lit_before;
                     float ap[CMAX];
@@ -872,8 +863,6 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                     // inter-step barrier: a memory round trip after the last chunk has published them), assuming what is true of every
                     // ordinary step — no agent is skipped, the batch is not finished — and only repeats the decode when the totals say
                     // otherwise.  Nothing of this phase leaves the registers before that test.
-                    int2 sampled[AMAX];
-                    uint32_t err1 = 0;
                     for (int attempt = 0; attempt < (PERSIST ? 2 : 1); ++attempt) {
                     const bool assume_ordinary = PERSIST && t > 0 && attempt == 0;
                     err1 = 0;
@@ -923,30 +912,26 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                     if constexpr (PERSIST) {
                         if (!assume_ordinary) break;
                         await_totals();
-                        stop = is_frozen();
                         bool someone_skipped = false;
 #pragma unroll
                         for (int a = 0; a < AMAX; ++a) someone_skipped = someone_skipped || (a < A && prev[1 + a] == 0u);
-                        if (stop || !someone_skipped) break;
+                        if (!someone_skipped) break;
                     }
                     }  // attempts
-                    if (!stop) {
-                        err |= err1;
-                        if constexpr (PERSIST) {
-                            if (launch.policy) {
 #pragma unroll
-                                for (int a = 0; a < AMAX; ++a)
-                                    if (a < A) frz::store_through(&reinterpret_cast<int2*>(launch.actions_out)[a * B + bl], sampled[a]);
-                            }
-                        }
-#pragma unroll
-                        for (int c = 0; c < CMAX; ++c)
-                            if (c < HW) x_power[c][slot] = ap[c];
+                    for (int c = 0; c < CMAX; ++c)
+                        if (c < HW) x_power[c][slot] = ap[c];
+                    if constexpr (PERSIST) {
+                        if (threadIdx.x == 0) s_stop = is_frozen() ? 1 : 0;  // the workgroup's verdict (see the field role, behind barrier 1)
                     }
                 }
+                FRZ_RSTAMP(3);
+                __syncthreads();  // (1) applied power visible to the field role
+                FRZ_RSTAMP(4);
                 if constexpr (PERSIST) {
+                    stop = s_stop != 0;
                     if (stop) {  // utils/env.py:211-213: nothing more happens in this launch
-                        {  // (t > 0 here) the last lists went to the second copy: once more, into the caller's buffers
+                        if (t > 0) {  // the last lists went to the second copy: once more, into the caller's buffers
                             mask_t ok_last[AMAX];
 #pragma unroll
                             for (int a = 0; a < AMAX; ++a)
@@ -955,10 +940,15 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                         }
                         break;
                     }
+                    err |= err1;
+                    if (launch.policy) {  // nothing of the step had left the registers before the verdict
+#pragma unroll
+                        for (int a = 0; a < AMAX; ++a)
+                            if (a < A) frz::store_through(&reinterpret_cast<int2*>(launch.actions_out)[a * B + bl], sampled[a]);
+                    }
+                } else {
+                    err |= err1;
                 }
-                FRZ_RSTAMP(3);
-                __syncthreads();  // (1) applied power visible to the field role
-                FRZ_RSTAMP(4);
 
                 // ---- phase 2: agent draws, agent transitions, agent rows, agent observations
                 if (MODE == kStep) {
