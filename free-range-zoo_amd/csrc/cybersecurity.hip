@@ -574,6 +574,7 @@ __global__ void __launch_bounds__(kRoleBlock, 2) cy_roles_kernel(char* __restric
     __shared__ uint4 s_cfg[kCfgPieces];
     __shared__ float s_draw[NMAX + AMAX][kBlock];     // view -> state: this step's uniforms (nodes, then agents)
     __shared__ int s_post[NMAX + 2 * AMAX + 1][kBlock];  // state -> view: state, location, last action, presence bits after the step
+    __shared__ int s_stop;  // multi-step launches: the workgroup's verdict on "every env is finished" (one per workgroup: both roles leave at the same barrier)
 
     const int tid = threadIdx.x & (kBlock - 1);
     const bool view = threadIdx.x >= kBlock;  // wave-uniform
@@ -696,9 +697,6 @@ __global__ void __launch_bounds__(kRoleBlock, 2) cy_roles_kernel(char* __restric
         for (int t = 0; t < n_steps; ++t) {
             // (no per-step opaque copies here, unlike wildfire_roles.hip: with them this kernel needs 160 instead of 219 VGPRs and is slower,
             // 7.7 against 7.4 us per step — its row addresses are better computed once, above the step loop)
-            if constexpr (PERSIST) {
-                if (t > 0) request_totals();
-            }
             const int nm_step = nm_in + t;
             // ---------------------------------------------------------------- the step's draws (streams: cy_step_kernel above)
             if (RNG == FRZ_RNG_INJECTED) {
@@ -771,13 +769,10 @@ __global__ void __launch_bounds__(kRoleBlock, 2) cy_roles_kernel(char* __restric
                         if (q * 4 + j < AMAX) s_draw[NMAX + q * 4 + j][tid] = drawn ? frz::u32_to_unit_float(w.w[j]) : 0.0f;
                 }
             }
-            if constexpr (PERSIST) {
-                if (t > 0) {
-                    await_totals();
-                    if (finished) break;  // (the state role leaves at the same barrier)
-                }
-            }
             __syncthreads();  // (2) draws ready
+            if constexpr (PERSIST) {
+                if (s_stop) break;  // the state role's verdict (it has looked at the totals of the step that just ended): nothing more happens
+            }
             // addresses of this env's observation rows, while the state role works
             float* const self_att = reinterpret_cast<float*>(arena + d.off_self_att);
             float* const self_def = reinterpret_cast<float*>(arena + d.off_self_def);
@@ -984,22 +979,25 @@ __global__ void __launch_bounds__(kRoleBlock, 2) cy_roles_kernel(char* __restric
             }
         }
         if constexpr (PERSIST) {
-            // nothing of this step has left the registers yet: now the totals of the step before it (requested above) must be here
-            if (t > 0) {
-                await_totals();
-                if (finished) {  // utils/env.py:211-213: nothing more happens in this launch
-                    if (active && !at32(rows1, (uint32_t)d.u_frozen * Bu + bl)) {  // stale rewards, once (utils/conversions.py:87-90)
-                        for (int a = 0; a < A; ++a) {
-                            const float r = at32(rowsf, (uint32_t)(d.r_rewards + a) * Bu + bl);
-                            float acc = 0.0f;
-                            for (int j = 0; j < A; ++j) acc = acc + r;
-                            at32(rowsf, (uint32_t)(d.r_rewards + a) * Bu + bl) = acc;
-                        }
-                        at32(rows1, (uint32_t)d.u_frozen * Bu + bl) = 1;
+            // nothing of this step has left the registers yet: now the totals of the step before it (requested above) must be here.  One
+            // verdict per workgroup (the first thread's), read by both roles behind the barrier
+            if (t > 0) await_totals();
+            if (threadIdx.x == 0) s_stop = (t > 0 && finished) ? 1 : 0;
+        }
+        __syncthreads();  // (2) draws ready
+        if constexpr (PERSIST) {
+            if (s_stop) {  // utils/env.py:211-213: nothing more happens in this launch
+                if (active && !at32(rows1, (uint32_t)d.u_frozen * Bu + bl)) {  // stale rewards, once (utils/conversions.py:87-90)
+                    for (int a = 0; a < A; ++a) {
+                        const float r = at32(rowsf, (uint32_t)(d.r_rewards + a) * Bu + bl);
+                        float acc = 0.0f;
+                        for (int j = 0; j < A; ++j) acc = acc + r;
+                        at32(rowsf, (uint32_t)(d.r_rewards + a) * Bu + bl) = acc;
                     }
-                    emit_mappings(0);  // the last mappings went to the second copy: once more, into the caller's buffers
-                    break;
+                    at32(rows1, (uint32_t)d.u_frozen * Bu + bl) = 1;
                 }
+                emit_mappings(0);  // the last mappings went to the second copy: once more, into the caller's buffers
+                break;
             }
             if (L.policy && active) {
 #pragma unroll
@@ -1007,7 +1005,6 @@ __global__ void __launch_bounds__(kRoleBlock, 2) cy_roles_kernel(char* __restric
                     if (a < A) reinterpret_cast<int2*>(L.actions_out)[(int64_t)a * B + b] = act_in[a];
             }
         }
-        __syncthreads();  // (2) draws ready
         // ------------------------------------------------- presence (transitions/presence.py:46-58), same draw for both tests
 #pragma unroll
         for (int a = 0; a < AMAX; ++a) {
