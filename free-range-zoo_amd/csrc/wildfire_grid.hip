@@ -177,16 +177,29 @@ __global__ void __launch_bounds__(kBlock) wg_env_kernel(char* __restrict__ arena
         // event e of cell c is draw e * HW + c, agent event e of agent a is draw 3 * HW + e * A + a.  Lane j computes blocks j, j + 64, ...
         // and parks their draws in LDS by draw number.
         float r_field[3][CPL], r_agent[5];
+        // The fused policy draws Philox blocks too (ceil(A / 4) of them, another key and counter): when they fit into the lanes the step's
+        // own blocks leave idle, both streams are ONE Philox evaluation with per-lane inputs (~110 vector instructions less per env);
+        // `policy_words` then sits in lanes NB .. NB + ceil(A / 4) - 1.
+        frz::Philox4 policy_words{{0u, 0u, 0u, 0u}};
+        int policy_lane0 = -1;  // >= 0: first lane that holds a policy block
         if (kPhilox) {
-            const int U = 3 * HW + 5 * A, NB = (U + 4) / 5;
-            for (int j = lane; j < NB; j += 64) {
-                const frz::Philox4 w = frz::philox4x32_10((uint32_t)j, (uint32_t)nm, 0u, 0u, seed, 0x46525A00u);
-                float* const out = &s_draw[wave][5 * j];  // the tail past U stays inside the array (sized for 5 * NB)
-                out[0] = frz::philox_unit24<0>(w);
-                out[1] = frz::philox_unit24<1>(w);
-                out[2] = frz::philox_unit24<2>(w);
-                out[3] = frz::philox_unit24<3>(w);
-                out[4] = frz::philox_unit24<4>(w);
+            const int U = 3 * HW + 5 * A, NB = (U + 4) / 5, PB = (A + 3) / 4;
+            const bool merged = pol.on && NB + PB <= 64;
+            policy_lane0 = merged ? NB : -1;
+            for (int j = lane; j < NB + (merged ? PB : 0); j += 64) {
+                const bool mine = j < NB;  // a block of the step's draws; otherwise policy block j - NB
+                const frz::Philox4 w = frz::philox4x32_10(mine ? (uint32_t)j : (uint32_t)(j - NB), mine ? (uint32_t)nm : 0u, mine ? 0u : pol.step_lo,
+                                                          mine ? 0u : pol.step_hi, mine ? seed : (pol.seed_lo ^ seed), mine ? 0x46525A00u : pol.seed_hi);
+                if (mine) {
+                    float* const out = &s_draw[wave][5 * j];  // the tail past U stays inside the array (sized for 5 * NB)
+                    out[0] = frz::philox_unit24<0>(w);
+                    out[1] = frz::philox_unit24<1>(w);
+                    out[2] = frz::philox_unit24<2>(w);
+                    out[3] = frz::philox_unit24<3>(w);
+                    out[4] = frz::philox_unit24<4>(w);
+                } else {
+                    policy_words = w;
+                }
             }
         }
         // ------------------------------------------------------------ (2) action decode (wildfire.py:427-483)
@@ -205,7 +218,14 @@ __global__ void __launch_bounds__(kBlock) wg_env_kernel(char* __restrict__ arena
             // uniform random policy over OneOf([task] * n + [noop]) (spaces/actions.py:23-41, baselines/random.py:20), the stream of
             // frz_wildfire_random_policy: agent a draws word a % 4 of Philox(counter (a / 4, 0, step), key (policy seed ^ env seed));
             // member j ~ U{0..n}; j < n -> [j, 0] (fight task j), j == n -> [n, -1] (noop / refill)
-            const frz::Philox4 w = frz::philox4x32_10((uint32_t)lane >> 2, 0u, pol.step_lo, pol.step_hi, pol.seed_lo ^ seed, pol.seed_hi);
+            frz::Philox4 w;
+            if (policy_lane0 >= 0) {  // drawn above, in lane policy_lane0 + (agent / 4): every lane fetches its agent's block (all lanes active)
+                const int holder = policy_lane0 + (lane >> 2);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) w.w[i] = (uint32_t)from_lane(holder & 63, (int)policy_words.w[i]);
+            } else {
+                w = frz::philox4x32_10((uint32_t)lane >> 2, 0u, pol.step_lo, pol.step_hi, pol.seed_lo ^ seed, pol.seed_hi);
+            }
             uint32_t word = w.w[0];
             word = (lane & 3) == 1 ? w.w[1] : word;
             word = (lane & 3) == 2 ? w.w[2] : word;
