@@ -65,6 +65,50 @@ __global__ void __launch_bounds__(kBlock) wf_fill_kernel(char* arena, int32_t se
     rows1[d.u_frozen * B + b] = 0;
 }
 
+// frz_wildfire_reset_masked: wf_fill_kernel on the envs a device-side mask selects (mask == nullptr: the finished ones — all agents
+// terminated or all truncated; agents share one value per env, row 0 is read) — the state part of reset_batches (utils/env.py:162-189,
+// wildfire.py:376-397); the rebuild launch that follows refreshes observations and lists.  cells_env_major: the grid family's layout.
+__global__ void __launch_bounds__(kBlock) wf_masked_fill_kernel(char* arena, const uint8_t* mask, uint32_t seed_increment, int64_t off_cells,
+                                                                int64_t off_cell_tables) {
+    const WfDev& d = *reinterpret_cast<const WfDev*>(arena);
+    const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t B = d.B;
+    if (b >= B) return;
+    int32_t* rows = reinterpret_cast<int32_t*>(arena + d.off_rows4);
+    float* rowsf = reinterpret_cast<float*>(arena + d.off_rows4);
+    uint8_t* rows1 = reinterpret_cast<uint8_t*>(arena + d.off_rows1);
+    const bool selected = mask ? mask[b] != 0 : (rows1[d.u_term * B + b] != 0 || rows1[d.u_trunc * B + b] != 0);
+    if (!selected) return;
+    reinterpret_cast<uint32_t*>(rows)[d.r_seeds * B + b] += seed_increment;  // modulo 2^32
+    if (off_cells != 0) {  // grid family: cells env-major [3][B][HW]; initial fires / intensity / fuel are tables 2..4 of the cell-table block
+        const int32_t* tables = reinterpret_cast<const int32_t*>(arena + off_cell_tables);
+        int32_t* cells = reinterpret_cast<int32_t*>(arena + off_cells);
+        const int64_t HW = d.HW;
+        for (int k = 0; k < 3; ++k)
+            for (int64_t c = 0; c < HW; ++c) cells[((int64_t)k * B + b) * HW + c] = tables[(2 + k) * HW + c];
+    } else {
+        for (int c = 0; c < d.HW; ++c) {
+            const int type = d.fire_types[c];
+            const int f = d.lit[c] ? type : -type;
+            rows[(d.r_fires + c) * B + b] = f;
+            rows[(d.r_intensity + c) * B + b] = d.lit[c] ? d.ignition[c] : 0;
+            rows[(d.r_fuel + c) * B + b] = f != 0 ? d.initial_fuel : 0;
+        }
+    }
+    for (int a = 0; a < d.A; ++a) {
+        rowsf[(d.r_supp + a) * B + b] = d.initial_suppressant;
+        rowsf[(d.r_cap + a) * B + b] = d.initial_capacity;
+        rows[(d.r_equip + a) * B + b] = d.initial_equipment;
+        rowsf[(d.r_rewards + a) * B + b] = 0.0f;
+        rowsf[(d.r_cum + a) * B + b] = 0.0f;
+        rows1[(d.u_term + a) * B + b] = 0;
+        rows1[(d.u_trunc + a) * B + b] = 0;
+    }
+    rows[d.r_moves * B + b] = 0;
+    rows[d.r_burnouts * B + b] = 0;
+    rows1[d.u_frozen * B + b] = 0;
+}
+
 // EXACT: the grid has exactly CMAX cells and AMAX agents (every loop bound is a compile-time constant).
 // Diagnostic build only (-DFRZ_WF_STAMPS, tools/stamps.py): thread 0 of workgroup 0 records the shader clock at phase
 // boundaries into a buffer nothing else reads.  No stamp executes in the production library.
@@ -851,7 +895,9 @@ __global__ void __launch_bounds__(kBlock) wf_policy_kernel(const char* arena, ui
 // stores before the workgroup's barrier, one lane then takes the ticket (MI355X_MICROARCH.md, inter-workgroup visibility).
 constexpr int kMetricBlocks = 256;
 
-__global__ void __launch_bounds__(kBlock) wf_metrics_kernel(char* __restrict__ arena, double* __restrict__ out) {
+// ended_only (step-by-step rollouts with FRZ_ROLLOUT_AUTO_RESET, between a step and the reset of its finished envs): the returns of the
+// finished envs only, one env-step per env, the number of finished envs
+__global__ void __launch_bounds__(kBlock) wf_metrics_kernel(char* __restrict__ arena, double* __restrict__ out, int ended_only) {
     const WfDev& d = *reinterpret_cast<const WfDev*>(arena);
     const int64_t B = d.B;
     const int A = d.A, nrow = A + 2;
@@ -868,12 +914,13 @@ __global__ void __launch_bounds__(kBlock) wf_metrics_kernel(char* __restrict__ a
     for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < B; b += (int64_t)nblocks * kBlock) {
         bool all_term = true, all_trunc = true;
         for (int a = 0; a < A; ++a) {
-            acc[a] += (double)rowsf[(int64_t)(d.r_cum + a) * B + b];
             all_term = all_term && rows1[(int64_t)(d.u_term + a) * B + b] != 0;
             all_trunc = all_trunc && rows1[(int64_t)(d.u_trunc + a) * B + b] != 0;
         }
-        acc[A] += (double)rows[(int64_t)d.r_moves * B + b];
-        acc[A + 1] += (all_term || all_trunc) ? 1.0 : 0.0;
+        const bool finished = all_term || all_trunc;
+        for (int a = 0; a < A; ++a) acc[a] += (ended_only && !finished) ? 0.0 : (double)rowsf[(int64_t)(d.r_cum + a) * B + b];
+        acc[A] += ended_only ? 1.0 : (double)rows[(int64_t)d.r_moves * B + b];
+        acc[A + 1] += finished ? 1.0 : 0.0;
     }
     const int lane = frz::lane_id(), wave = frz::wave_id();
     for (int i = 0; i < nrow; ++i) {
@@ -937,6 +984,7 @@ struct frz_wildfire_env {
     int64_t list_copy_delta = 0;
     int32_t rollout_steps = 1;
     double* rollout_metrics = nullptr;  // frz_wildfire_rollout_random_policy_metrics: folded into the multi-step launch being enqueued
+    const frz_rollout_spec* rollout_spec = nullptr;  // frz_wildfire_rollout: the spec of the multi-step launch being enqueued
     bool exclusive_device = false;  // frz_wildfire_set_exclusive_device: multi-step launches allowed
     // grids above 16 cells (wildfire_grid.hip): the kernels' configuration and the tables uploaded into the arena at bind
     WgDev gdev;
@@ -1025,6 +1073,21 @@ int launch(frz_wildfire_env* env, const WfArgs& args, int rng, int mode, hipStre
         a.n_steps = env->rollout_steps;
         a.scratch_delta = env->list_copy_delta;
         a.metrics_out = env->rollout_metrics;
+        if (const frz_rollout_spec* spec = env->rollout_spec) {  // one multi-step launch driven by a rollout spec
+            const WfDev& p = env->dev;
+            const int64_t AB2 = (int64_t)p.A * p.B * 2;
+            a.rollout_flags = spec->flags;
+            a.seed_increment = spec->seed_increment;
+            a.seed_stride = spec->seed_stride;
+            a.tape_actions_step = spec->action_tape ? AB2 : 0;
+            if (spec->list_record) {
+                a.list_record_delta = static_cast<char*>(spec->list_record) - (env->arena + p.off_task_offsets);
+                a.list_record_step = p.off_actions - p.off_task_offsets;
+            }
+            a.reward_tape = spec->reward_tape;
+            a.done_tape = spec->done_tape;
+            a.actions_out_step = spec->record_actions ? AB2 : 0;
+        }
         return launch_roles(a, env->variant, env->dev.nchunks, rng, mode, stream);  // one workgroup per chunk
     }
 }
@@ -1103,6 +1166,8 @@ int create_grid(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
     for (int j = 0; j < FRZ_MAX_CAPACITIES; ++j) g.cum[j] = j < cfg->num_capacities ? cfg->capacity_cumprobs[j] : __builtin_inff();
     g.initial_fuel = cfg->initial_fuel, g.initial_equipment = cfg->initial_equipment_state;
     g.initial_suppressant = cfg->initial_suppressant, g.initial_capacity = cfg->initial_capacity;
+    p.initial_fuel = cfg->initial_fuel, p.initial_equipment = cfg->initial_equipment_state;  // (wf_masked_fill_kernel reads the WfDev block)
+    p.initial_suppressant = cfg->initial_suppressant, p.initial_capacity = cfg->initial_capacity;
 
     // tables a lane indexes by agent / equipment state / cell
     WgAgentTable& t = env->agent_table;
@@ -1324,6 +1389,15 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
     std::memcpy(p.ignition, cfg->ignition_temp, sizeof(p.ignition));
     std::memcpy(p.fire_types, cfg->fire_types, sizeof(p.fire_types));
     std::memcpy(p.lit, cfg->lit, sizeof(p.lit));
+    for (int c = 0; c < HW && c < 16; ++c) {  // the configured initial state of a cell (wildfire.py:347-351)
+        const int f0 = cfg->lit[c] ? cfg->fire_types[c] : -cfg->fire_types[c];
+        p.init_fires[c] = f0;
+        p.init_intensity[c] = cfg->lit[c] ? cfg->ignition_temp[c] : 0;
+        p.init_fuel[c] = f0 != 0 ? cfg->initial_fuel : 0;
+    }
+    p.init_equipment = cfg->initial_equipment_state;
+    p.init_suppressant = cfg->initial_suppressant;
+    p.init_capacity = cfg->initial_capacity;
     for (int c = 0; c < HW; ++c) {
         const int y = c / W, x = c % W;
         p.cell_yx[c] = (y << 16) | x;
@@ -1628,7 +1702,7 @@ int frz_wildfire_set_exclusive_device(frz_wildfire_env* env, int exclusive) {
 int frz_wildfire_rollout_launches(const frz_wildfire_env* env, int32_t n_steps, int rng_mode) {
     if (!env || n_steps < 0) return FRZ_E_INVALID;
     const bool one = n_steps > 1 && env->exclusive_device && env->list_copy_delta != 0 && !env->ticketed &&
-                     (rng_mode == FRZ_RNG_PHILOX || rng_mode == FRZ_RNG_MT19937) && env->dev.roles && !env->dev.grid;
+                     (rng_mode == FRZ_RNG_PHILOX || rng_mode == FRZ_RNG_MT19937 || rng_mode == FRZ_RNG_INJECTED) && env->dev.roles && !env->dev.grid;
     return one ? 1 : n_steps;
 }
 
@@ -1685,11 +1759,125 @@ int frz_wildfire_rollout_random_policy_metrics(frz_wildfire_env* env, uint64_t p
     return rc != FRZ_OK ? rc : frz_wildfire_episode_metrics(env, metrics, stream);
 }
 
+int frz_wildfire_list_block(const frz_wildfire_env* env, void** block, int64_t* bytes) {
+    if (!env || !block || !bytes) return FRZ_E_INVALID;
+    if (!env->arena) return FRZ_E_UNBOUND;
+    *block = env->arena + env->dev.off_task_offsets;
+    *bytes = env->dev.off_actions - env->dev.off_task_offsets;
+    return FRZ_OK;
+}
+
+int frz_wildfire_reset_masked(frz_wildfire_env* env, const uint8_t* mask, int32_t seed_increment, void* stream) {
+    if (!env) return FRZ_E_INVALID;
+    if (!env->arena) return FRZ_E_UNBOUND;
+    if (!env->was_reset) return FRZ_E_INVALID;
+    const int blocks = (env->cfg.parallel_envs + kBlock - 1) / kBlock;
+    const int64_t off_cells = env->dev.grid ? env->gdev.off_cells : 0, off_tables = env->dev.grid ? env->gdev.off_cell_tables : 0;
+    hipLaunchKernelGGL(wf_masked_fill_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), env->arena, mask,
+                       (uint32_t)seed_increment, off_cells, off_tables);
+    if (hipGetLastError() != hipSuccess) return FRZ_E_LAUNCH;
+    return frz_wildfire_rebuild(env, stream);
+}
+
+int frz_wildfire_rollout(frz_wildfire_env* env, const frz_rollout_spec* spec, void* stream) {
+    if (!env || !spec || spec->n_steps < 0) return FRZ_E_INVALID;
+    if (!env->arena) return FRZ_E_UNBOUND;
+    if (!env->was_reset) return FRZ_E_INVALID;
+    const WfDev& p = env->dev;
+    const int mode = spec->rng_mode;
+    const bool policy = spec->action_tape == nullptr;
+    const bool auto_reset = (spec->flags & FRZ_ROLLOUT_AUTO_RESET) != 0, reset_first = (spec->flags & FRZ_ROLLOUT_RESET_FIRST) != 0;
+    if (mode != FRZ_RNG_INJECTED && mode != FRZ_RNG_PHILOX && mode != FRZ_RNG_MT19937) return FRZ_E_INVALID;
+    if (mode == FRZ_RNG_INJECTED && spec->n_steps > 0 && (!spec->randomness_tape_a || !spec->randomness_tape_b)) return FRZ_E_INVALID;
+    if (policy && !spec->actions_out) return FRZ_E_INVALID;
+    if (auto_reset && mode == FRZ_RNG_MT19937) return FRZ_E_INVALID;  // (an in-kernel re-seed of a 624-word stream; not built)
+    if (spec->n_steps == 0) return reset_first ? frz_wildfire_reset_reseed(env, spec->seed_increment, stream) : FRZ_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t B = p.B, A = p.A, HW = p.HW, AB2 = A * B * 2;
+    const int64_t block_bytes = p.off_actions - p.off_task_offsets;
+
+    // ONE multi-step launch (wildfire_roles.inl, PERSIST) ...
+    const bool mt_reset = reset_first && mode == FRZ_RNG_MT19937;  // the opening reset re-seeds the streams from the host side: separate launches
+    if (frz_wildfire_rollout_launches(env, spec->n_steps, mode) == 1) {
+        frz_rollout_spec inner = *spec;
+        if (mt_reset) {
+            const int rc = frz_wildfire_reset_reseed(env, spec->seed_increment, stream);
+            if (rc != FRZ_OK) return rc;
+            const int rs = frz_mt19937_seed(at<uint32_t>(env->arena, p.off_mt_state), at<int32_t>(env->arena, p.off_rows4 + (int64_t)p.r_mti * B * 4),
+                                            at<int32_t>(env->arena, p.off_rows4 + (int64_t)p.r_seeds * B * 4), nullptr, 0, B, stream);
+            if (rs != FRZ_OK) return rs;
+            inner.flags &= ~FRZ_ROLLOUT_RESET_FIRST;
+        }
+        env->rollout_spec = &inner;
+        env->rollout_steps = spec->n_steps;
+        env->rollout_metrics = spec->metrics;
+        int rc;
+        if (policy) {
+            rc = frz_wildfire_step_random_policy(env, spec->policy_seed, spec->first_step, spec->actions_out, mode, spec->randomness_tape_a,
+                                                 spec->randomness_tape_b, stream);
+        } else {
+            rc = frz_wildfire_step(env, spec->action_tape, mode, spec->randomness_tape_a, spec->randomness_tape_b, stream);
+        }
+        env->rollout_spec = nullptr;
+        env->rollout_steps = 1;
+        env->rollout_metrics = nullptr;
+        return rc;
+    }
+
+    // ... or the same thing step by step (every other shape, shared devices): one launch per step, the records copied out between them
+    if (reset_first) {
+        const int rc = frz_wildfire_reset_reseed(env, spec->seed_increment, stream);
+        if (rc != FRZ_OK) return rc;
+        if (mode == FRZ_RNG_MT19937) {
+            const int rs = frz_mt19937_seed(at<uint32_t>(env->arena, p.off_mt_state), at<int32_t>(env->arena, p.off_rows4 + (int64_t)p.r_mti * B * 4),
+                                            at<int32_t>(env->arena, p.off_rows4 + (int64_t)p.r_seeds * B * 4), nullptr, 0, B, stream);
+            if (rs != FRZ_OK) return rs;
+        }
+    }
+    for (int32_t t = 0; t < spec->n_steps; ++t) {
+        const float* ra = spec->randomness_tape_a ? spec->randomness_tape_a + (int64_t)t * 3 * B * HW : nullptr;
+        const float* rb = spec->randomness_tape_b ? spec->randomness_tape_b + (int64_t)t * 5 * B * A : nullptr;
+        int rc;
+        if (policy)
+            rc = frz_wildfire_step_random_policy(env, spec->policy_seed, spec->first_step + (uint64_t)t,
+                                                 spec->actions_out + (spec->record_actions ? (int64_t)t * AB2 : 0), mode, ra, rb, stream);
+        else
+            rc = frz_wildfire_step(env, spec->action_tape + (int64_t)t * AB2, mode, ra, rb, stream);
+        if (rc != FRZ_OK) return rc;
+        bool ok = true;
+        if (spec->reward_tape)
+            ok = ok && hipMemcpyAsync(spec->reward_tape + (int64_t)t * A * B, env->arena + p.off_rows4 + (int64_t)p.r_rewards * B * 4, (size_t)(A * B * 4),
+                                      hipMemcpyDeviceToDevice, s) == hipSuccess;
+        if (spec->done_tape) {
+            ok = ok && hipMemcpyAsync(spec->done_tape + ((int64_t)t * 2 + 0) * B, env->arena + p.off_rows1 + (int64_t)p.u_term * B, (size_t)B,
+                                      hipMemcpyDeviceToDevice, s) == hipSuccess;
+            ok = ok && hipMemcpyAsync(spec->done_tape + ((int64_t)t * 2 + 1) * B, env->arena + p.off_rows1 + (int64_t)p.u_trunc * B, (size_t)B,
+                                      hipMemcpyDeviceToDevice, s) == hipSuccess;
+        }
+        if (!ok) return FRZ_E_LAUNCH;
+        if (auto_reset) {
+            if (spec->metrics) {  // returns of the envs about to be reset
+                const int blocks = p.nchunks < kMetricBlocks ? p.nchunks : kMetricBlocks;
+                hipLaunchKernelGGL(wf_metrics_kernel, dim3(blocks), dim3(kBlock), 0, s, env->arena, spec->metrics, 1);
+                if (hipGetLastError() != hipSuccess) return FRZ_E_LAUNCH;
+            }
+            rc = frz_wildfire_reset_masked(env, nullptr, (int32_t)spec->seed_stride, stream);
+            if (rc != FRZ_OK) return rc;
+        }
+        if (spec->list_record && t < spec->n_steps - 1 &&  // the lists as the step (and the reset of its finished envs) left them
+            hipMemcpyAsync(static_cast<char*>(spec->list_record) + (int64_t)t * block_bytes, env->arena + p.off_task_offsets, (size_t)block_bytes,
+                           hipMemcpyDeviceToDevice, s) != hipSuccess)
+            return FRZ_E_LAUNCH;
+    }
+    if (spec->metrics && !auto_reset) return frz_wildfire_episode_metrics(env, spec->metrics, stream);
+    return FRZ_OK;
+}
+
 int frz_wildfire_episode_metrics(frz_wildfire_env* env, double* metrics, void* stream) {
     if (!env || !metrics) return FRZ_E_INVALID;
     if (!env->arena) return FRZ_E_UNBOUND;
     const int blocks = env->dev.nchunks < kMetricBlocks ? env->dev.nchunks : kMetricBlocks;
-    hipLaunchKernelGGL(wf_metrics_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), env->arena, metrics);
+    hipLaunchKernelGGL(wf_metrics_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), env->arena, metrics, 0);
     return hipGetLastError() == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;
 }
 

@@ -61,6 +61,12 @@ struct WfStaged : WfHot {
     float caps[FRZ_MAX_CAPACITIES];
     float eq[FRZ_MAX_EQUIPMENT_STATES][4];  // (capacity, power, range, -)
     uint64_t range_mask[FRZ_MAX_AGENTS][FRZ_MAX_EQUIPMENT_STATES];  // cells agent a reaches at equipment state s
+    // the configured initial state (wildfire.py:347-354) of the field/crew kernels' grids (<= 16 cells): what a multi-step launch that
+    // starts with a reset, or resets finished envs between its steps, puts in its registers
+    int32_t init_fires[16], init_intensity[16], init_fuel[16];
+    int32_t init_equipment;
+    float init_suppressant, init_capacity;
+    int32_t pad2_;
 };
 static_assert(sizeof(WfStaged) % 16 == 0 && sizeof(WfStaged) / 16 <= kBlock, "WfStaged is staged with one 16-byte copy per thread");
 
@@ -87,6 +93,15 @@ struct WfLaunch {
     int32_t n_steps;         // multi-step launches (wf_roles_kernel<..., PERSIST>): steps of the rollout this launch performs
     int64_t scratch_delta;   // multi-step launches: byte distance from the packed list buffers to their second copy
     double* metrics_out;     // multi-step launches: frz_wildfire_episode_metrics folded into the launch's tail (nullptr: not asked for)
+    // frz_wildfire_rollout (multi-step launches): what drives the steps and what they leave behind besides the last step's outputs
+    uint32_t rollout_flags;      // FRZ_ROLLOUT_* (include/frz.h)
+    uint32_t seed_stride;        // FRZ_ROLLOUT_AUTO_RESET: added (mod 2^32) to the seed of an env each time the launch resets it
+    int64_t tape_actions_step;   // elements between two steps of the action tape (`actions` = its step 0); 0: no tape
+    int64_t list_record_delta;   // bytes from the arena's list block (off_task_offsets) to step 0's copy in the list record; 0: no record
+    int64_t list_record_step;    // bytes between two steps' copies
+    float* reward_tape;          // optional float32 [n_steps][A][B]: every step's rewards
+    uint8_t* done_tape;          // optional uint8 [n_steps][2][B]: every step's (terminated, truncated)
+    int64_t actions_out_step;    // elements between two steps of actions_out (0: every step overwrites the one buffer)
 };
 
 struct WfArgs {
@@ -105,6 +120,10 @@ struct WfArgs {
     int32_t n_steps = 1;         // > 1: one multi-step launch (frz_wildfire_rollout_random_policy, field/crew exact Philox kernels)
     int64_t scratch_delta = 0;
     double* metrics_out = nullptr;
+    uint32_t rollout_flags = 0, seed_stride = 0;
+    int64_t tape_actions_step = 0, list_record_delta = 0, list_record_step = 0, actions_out_step = 0;
+    float* reward_tape = nullptr;
+    uint8_t* done_tape = nullptr;
 };
 
 // The (CMAX, AMAX) instantiations of the step kernels: X(index, CMAX, AMAX, exact).  An env runs the first entry that holds its shape;
@@ -115,6 +134,8 @@ struct WfArgs {
     X(7, 12, 4, true) X(8, 16, 3, true) X(9, 16, 4, true) X(10, 4, 2, true) X(11, 4, 3, true) X(12, 8, 2, true) X(13, 9, 2, true)     \
     X(14, 12, 2, true) X(15, 16, 2, true) X(16, 6, 4, true)                                                                         \
     X(17, 8, 4, false) X(18, 16, 4, false) X(19, 8, 8, false) X(20, 16, 8, false) X(21, 24, 8, false)
+
+#define FRZ_WF_ROLES_GROUPS 6  // translation units the field/crew instantiations are dealt to (wildfire_roles_g<k>.hip)
 
 // launch a step kernel; with timing events the dispatch itself is bracketed (what a profiler's kernel trace reports)
 template <typename K, typename... Args>
@@ -142,7 +163,8 @@ inline uint32_t experiment_skip() {
 inline WfLaunch make_launch(const WfArgs& a) {
     const WfDev* host = a.host_dev;
     return WfLaunch{host->B, a.policy ? 1u : 0u, host->off_rows1, host->off_epoch, host->off_totals, host->off_mt_state, (uint32_t)a.policy_seed,
-                    (uint32_t)(a.policy_seed >> 32), (uint32_t)a.policy_step, (uint32_t)(a.policy_step >> 32), a.actions_out, a.ticketed ? 1u : 0u, experiment_skip(), a.seed_increment, a.n_steps, a.scratch_delta, a.metrics_out};
+                    (uint32_t)(a.policy_seed >> 32), (uint32_t)a.policy_step, (uint32_t)(a.policy_step >> 32), a.actions_out, a.ticketed ? 1u : 0u, experiment_skip(), a.seed_increment, a.n_steps, a.scratch_delta, a.metrics_out,
+                    a.rollout_flags, a.seed_stride, a.tape_actions_step, a.list_record_delta, a.list_record_step, a.reward_tape, a.done_tape, a.actions_out_step};
 }
 
 // Staging the configuration: the 16-byte piece is requested by the kernel's FIRST vector-memory instruction (before the

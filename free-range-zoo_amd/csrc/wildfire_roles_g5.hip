@@ -1,0 +1,3 @@
+// one of the FRZ_WF_ROLES_GROUPS translation units of the field/crew wildfire kernels (wildfire_roles.inl): variants i with i % groups == 5
+#define FRZ_WF_ROLES_GROUP 5
+#include "wildfire_roles.inl"

@@ -410,6 +410,17 @@ class raw_env(BatchedParallelEnv):
                    lambda: (policy_seed, policy_step, self._actions, mode, len(self.agents), self.parallel_envs))
         return self._after_fused(logged)
 
+    def _check_randomness_tapes(self, steps: int, a: torch.Tensor, b: torch.Tensor) -> None:
+        B, HW, A = self.parallel_envs, self.max_y * self.max_x, len(self.agents)
+        if a.numel() != steps * 3 * B * HW or b.numel() != steps * 5 * B * A:
+            raise ValueError('randomness tapes must hold [steps, 3, B, H, W] and [steps, 5, B, A] float32 values')
+
+    def _after_rollout(self) -> None:
+        self._publish()
+        self.infos = {agent: {} for agent in self.agents}
+        self.infos['burnouts'] = self._burnouts
+        self.infos['putouts'] = self._putouts
+
     def set_exclusive_device(self, exclusive: bool = True) -> None:
         """State that nothing else uses this GPU while the env's rollouts run (no other process, no concurrent stream).  It allows
         ``rollout_random_policy`` / ``capture_random_rollout`` to run a whole rollout as ONE launch where the library has a multi-step

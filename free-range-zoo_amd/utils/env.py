@@ -311,6 +311,105 @@ class BatchedParallelEnv:
         """Called by reset / step / rebuild: the task counts changed, samples drawn before are stale."""
         self._epoch_counter = getattr(self, '_epoch_counter', 0) + 1
 
+    # -- rollouts: n steps of a rollout loop enqueued by one call (include/frz.h: frz_rollout_spec) ---------------------------------
+    @torch.no_grad()
+    def rollout(self, steps: int, actions: Optional[torch.Tensor] = None, randomness=None, policy_seed: int = 0, first_step: int = 0,
+                reset_first: bool = False, seed_increment: int = 0, auto_reset: bool = False, seed_stride: int = 0,
+                record: bool = False, metrics: Optional[torch.Tensor] = None) -> Dict[str, Any]:
+        """
+        ``steps`` x ``step`` as ONE call through the C boundary (``frz_<domain>_rollout``) — one multi-step launch where the library has one
+        for the shape (after ``set_exclusive_device``), otherwise one launch per step — with the results a loop over ``step()`` leaves.
+
+        Args:
+            actions: an ACTION TAPE, int32 ``[steps, A, B, 2]`` on the env's device (what the loop would pass to ``step`` one by one: the
+                reference's recorded trajectories, a scripted policy's plan); None: the device-side uniform random policy
+                (``policy_seed``, policy steps ``first_step ...``), as ``step_random_policy``.
+            randomness: injected randomness tapes ``(a, b)`` — the tensors the env's generator would return, one pair per step
+                (wildfire: ``[steps, 3, B, H, W]`` and ``[steps, 5, B, A]``); None: the env's own ``rng``.
+            reset_first / seed_increment: the rollout starts with ``reset`` of every env (seeds += seed_increment), inside the same launch.
+            auto_reset / seed_stride: an env that finishes at step t is reset (seed += seed_stride) inside step t — `step()` followed by
+                `reset_batches(finished)`: continuous rollouts at fixed B.  The reset zeroes that env's rewards / flags like the
+                reference's; what the step produced is in the ``record`` tapes and the ``metrics``.
+            record: keep EVERY step's outputs — returns ``{'rewards': [steps, A, B], 'dones': [steps, 2, B], 'actions': [steps, A, B, 2]
+                (policy), 'lists': uint8 [steps - 1, block_bytes]}`` (``lists[t]`` = a copy of the env's packed-list block after step t).
+            metrics: float64 ``[A + 2]``, accumulated in place (see ``frz_rollout_spec.metrics``).
+        """
+        if not self._has_reset:
+            raise RuntimeError('reset() must be called before rollout()')
+        if self.logger is not None:
+            raise NotImplementedError('rollout() does not feed the logging tap: step() does')
+        A, B = len(self.agents), self.parallel_envs
+        spec = _capi.frz_rollout_spec()
+        spec.n_steps = int(steps)
+        spec.flags = (_capi.FRZ_ROLLOUT_RESET_FIRST if reset_first else 0) | (_capi.FRZ_ROLLOUT_AUTO_RESET if auto_reset else 0)
+        spec.seed_increment, spec.seed_stride = int(seed_increment), int(seed_stride) & 0xFFFFFFFF
+        spec.policy_seed, spec.first_step = int(policy_seed), int(first_step)
+        keep = []
+        out: Dict[str, Any] = {}
+        if actions is not None:
+            if actions.dtype != torch.int32 or not actions.is_contiguous() or tuple(actions.shape) != (steps, A, B, 2) or actions.device != self.device:
+                raise ValueError('the action tape must be a contiguous int32 [steps, A, B, 2] tensor on the env device')
+            spec.action_tape = actions.data_ptr()
+            keep.append(actions)
+        else:
+            if record:
+                out['actions'] = torch.zeros((steps, A, B, 2), dtype=torch.int32, device=self.device)
+                spec.actions_out, spec.record_actions = out['actions'].data_ptr(), 1
+            else:
+                spec.actions_out = self._actions.data_ptr()
+        if randomness is not None:
+            a, b = (t.to(device=self.device, dtype=torch.float32).contiguous() for t in randomness)
+            self._check_randomness_tapes(steps, a, b)
+            spec.rng_mode, spec.randomness_tape_a, spec.randomness_tape_b = _capi.FRZ_RNG_INJECTED, a.data_ptr(), b.data_ptr()
+            keep += [a, b]
+        else:
+            spec.rng_mode = self._fused_rng_mode()
+        if record:
+            out['rewards'] = torch.zeros((steps, A, B), dtype=torch.float32, device=self.device)
+            out['dones'] = torch.zeros((steps, 2, B), dtype=torch.uint8, device=self.device)
+            spec.reward_tape, spec.done_tape = out['rewards'].data_ptr(), out['dones'].data_ptr()
+            block, nbytes = ctypes.c_void_p(), ctypes.c_int64()
+            _capi.check(getattr(self._lib, f'frz_{self._domain}_list_block')(self._handle, ctypes.byref(block), ctypes.byref(nbytes)), 'list_block')
+            out['lists'] = torch.zeros((max(steps - 1, 0), nbytes.value), dtype=torch.uint8, device=self.device)
+            out['list_block_offset'] = block.value - self._arena.data_ptr()
+            spec.list_record = out['lists'].data_ptr() if steps > 1 else None
+        if metrics is not None:
+            if metrics.dtype != torch.float64 or metrics.numel() != A + 2 or not metrics.is_contiguous() or metrics.device != self.device:
+                raise ValueError('metrics must be a contiguous float64 [A + 2] tensor on the env device')
+            spec.metrics = metrics.data_ptr()
+        symbol = f'frz_{self._domain}_rollout'
+        _capi.check(getattr(self._lib, symbol)(self._handle, ctypes.byref(spec), stream_ptr(self.device)), symbol)
+        self._rollout_keepalive = keep  # the launch reads the tapes after this call returns
+        self._after_rollout()
+        return out
+
+    def _check_randomness_tapes(self, steps: int, a: torch.Tensor, b: torch.Tensor) -> None:
+        raise NotImplementedError
+
+    def _after_rollout(self) -> None:
+        self._publish()
+
+    @torch.no_grad()
+    def reset_finished(self, mask: Optional[torch.Tensor] = None, seed_increment: int = 0) -> None:
+        """``reset_batches`` with the selection left on the device (utils/env.py:162-189): envs with ``mask[b] != 0`` (uint8 / bool ``[B]``) —
+        or, ``mask=None``, the finished ones — go back to their initial state, bookkeeping zeroed, ``seeds += seed_increment``; no host
+        read, no indices on the host.  (The MT19937 streams of the reset envs are re-seeded from the new seeds.)"""
+        if not self._has_reset:
+            raise RuntimeError('reset() must be called before reset_finished()')
+        if mask is not None:
+            mask = mask.to(device=self.device).view(torch.uint8) if mask.dtype == torch.bool else mask.to(device=self.device, dtype=torch.uint8)
+            mask = mask.contiguous()
+            if mask.numel() != self.parallel_envs:
+                raise ValueError('mask must have one entry per env')
+        if self.rng == 'mt19937':
+            selected = (mask != 0) if mask is not None else self.finished
+            self._mt_reseed_mask = selected.clone()
+        symbol = f'frz_{self._domain}_reset_masked'
+        _capi.check(getattr(self._lib, symbol)(self._handle, None if mask is None else mask.data_ptr(), int(seed_increment), stream_ptr(self.device)), symbol)
+        if self.rng == 'mt19937' and not self.single_seeding:
+            self.generator.reseed_where(self._mt_reseed_mask)
+        self._publish()
+
     # -- refreshing the published outputs after the state was edited in place (planning / search code) -----------------------------
     _rebuild_symbol: Optional[str] = None  # set by the domain envs: the C-ABI entry that rebuilds task lists, observations, spaces
 

@@ -74,6 +74,17 @@ class RandomGenerator:
                 self._seed_streams(indices)
         self.has_been_seeded = True
 
+    @torch.no_grad()
+    def reseed_where(self, mask: torch.Tensor) -> None:
+        """Restart the MT19937 streams of the envs ``mask`` selects from ``self.seeds`` (which a device-side partial reset has already
+        moved on): the per-env part of ``seed(..., partial_seeding=...)`` for a selection that lives on the device.  Streams that have
+        not been expanded yet are left to the lazy seeding."""
+        if self.single_seeding or not self._streams_valid:
+            return
+        indices = mask.nonzero().reshape(-1).to(torch.int32)
+        if indices.numel():
+            self._seed_streams(indices.contiguous())
+
     def _seed_streams(self, indices: Optional[torch.Tensor]) -> None:
         if self.generator_states is None:
             self.generator_states = torch.empty((624, self.parallel_envs), dtype=torch.int32, device=self.device)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FRZ_ABI_VERSION 3
+#define FRZ_ABI_VERSION 4
 
 #define FRZ_MAX_AGENTS 16
 #define FRZ_MAX_CELLS 1024 /* 32 x 32; grids above 16 cells run one env per wavefront with the cells across its lanes */
@@ -278,6 +278,63 @@ int frz_wildfire_episode_metrics(frz_wildfire_env* env, double* metrics, void* s
  * are made in that launch's tail from the values its workgroups still hold, otherwise it is the two calls. */
 int frz_wildfire_rollout_random_policy_metrics(frz_wildfire_env* env, uint64_t policy_seed, uint64_t first_step, int32_t n_steps,
                                                int32_t* actions_out, int rng_mode, double* metrics, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Rollouts: n_steps ParallelEnv.step() calls of a rollout loop enqueued by ONE call (reference: the loop of
+ * utils/conversions.py:59-99 over given actions; docs/source/events/moasei-2026/evaluation.md `test()`; the partial resets
+ * of utils/env.py:162-189 + wildfire.py:376-397 between steps).  The same spec drives every domain.
+ * ---------------------------------------------------------------------------------------------- */
+#define FRZ_ROLLOUT_RESET_FIRST 1u /* the rollout starts from the configured initial state: frz_<dom>_reset_reseed(seed_increment) folded
+                                      into the first step (state, bookkeeping, seeds; its lists are never visible) */
+#define FRZ_ROLLOUT_AUTO_RESET 2u  /* continuous rollouts at fixed B: an env that is finished (all agents terminated or truncated) at the
+                                      end of step t is reset inside the same step — initial state, bookkeeping zeroed, seed += seed_stride
+                                      (mod 2^32), observations / lists rebuilt from the fresh state — i.e. `env.step(...)` followed by
+                                      `env.reset_batches(finished.nonzero(), seed)`: like the reference's, the reset zeroes the env's
+                                      rewards / terminations / truncations, so what the step itself produced is read from the reward /
+                                      done tapes (or the metrics).  The all-done early-out (utils/env.py:211-213) cannot trigger. */
+
+typedef struct frz_rollout_spec {
+    int32_t n_steps;
+    int32_t rng_mode;        /* FRZ_RNG_* */
+    uint32_t flags;          /* FRZ_ROLLOUT_* */
+    int32_t seed_increment;  /* FRZ_ROLLOUT_RESET_FIRST: added (mod 2^32) to every env seed by the opening reset */
+    uint32_t seed_stride;    /* FRZ_ROLLOUT_AUTO_RESET: added (mod 2^32) to an env's seed by each of its resets */
+    uint32_t pad_;
+    /* what the agents do: a tape of given actions, or (NULL) the uniform random policy of frz_<dom>_random_policy sampled in-kernel with
+     * policy steps first_step, first_step + 1, ... */
+    const int32_t* action_tape; /* int32 [n_steps][A][B][2] */
+    uint64_t policy_seed, first_step;
+    int32_t* actions_out;       /* policy only: the sampled actions, int32 [A][B][2] (the last executed step's), or every step's,
+                                   int32 [n_steps][A][B][2], with record_actions != 0 */
+    int32_t record_actions;
+    int32_t pad2_;
+    /* FRZ_RNG_INJECTED: the tensors RandomGenerator.generate() would return, one pair per step
+     * (wildfire: float32 [n_steps][3][B][H*W] and [n_steps][5][B][A]; cybersecurity: [n_steps][B][N] and [n_steps][B][A]) */
+    const float* randomness_tape_a;
+    const float* randomness_tape_b;
+    /* optional per-step records (NULL: not kept).  Without them a rollout leaves what a loop over step() leaves: the last step's outputs */
+    float* reward_tape;  /* float32 [n_steps][A][B] */
+    uint8_t* done_tape;  /* uint8 [n_steps][2][B]: (terminated, truncated) as the step set them */
+    void* list_record;   /* n_steps - 1 copies of the env's packed-list block (frz_<dom>_list_block: offsets and values of every jagged
+                            output, in arena order), copy t = the lists of step t; the last step's lists are in the env's own buffers */
+    double* metrics;     /* float64 [A + 2], accumulated in place: frz_wildfire_episode_metrics at the end of the rollout; with
+                            FRZ_ROLLOUT_AUTO_RESET instead: [a] += returns of the episodes that ENDED inside the rollout (needs
+                            track_cumulative_rewards), [A] += env-steps executed, [A + 1] += episodes ended */
+} frz_rollout_spec;
+
+/* n_steps steps driven by `spec`; same results as the equivalent loop over frz_wildfire_step / frz_wildfire_step_random_policy (and
+ * frz_wildfire_reset_masked for FRZ_ROLLOUT_AUTO_RESET).  ONE multi-step launch where the library has one (see
+ * frz_wildfire_rollout_launches: exact field/crew shapes, any rng_mode, frz_wildfire_set_exclusive_device on), otherwise one launch per step
+ * (plus the reset launches).  FRZ_ROLLOUT_AUTO_RESET is not available with FRZ_RNG_MT19937 (FRZ_E_INVALID). */
+int frz_wildfire_rollout(frz_wildfire_env* env, const frz_rollout_spec* spec, void* stream);
+/* the packed-list block of the bound arena: device pointer and size in bytes (task_offsets, act_map_offsets, bad_map_offsets, task_values,
+ * obs_map_values, act_map_values, bad_map_values, contiguous in this order, each 256-byte aligned); a list record holds copies of it */
+int frz_wildfire_list_block(const frz_wildfire_env* env, void** block, int64_t* bytes);
+/* replaces reset_batches (utils/env.py:162-189 + wildfire.py:376-397) with the selection on the device: env b is reset when mask[b] != 0
+ * (mask uint8 [B]), or — mask NULL — when it is finished (all agents terminated or all truncated); seeds[b] += seed_increment (mod 2^32) for
+ * the reset envs (the FRZ_RNG_PHILOX key; MT19937 streams are re-seeded by the caller: frz_mt19937_seed_masked); then the observations and
+ * lists of the whole batch are rebuilt.  Two launches, no host synchronisation. */
+int frz_wildfire_reset_masked(frz_wildfire_env* env, const uint8_t* mask, int32_t seed_increment, void* stream);
 
 /* The caller states that nothing else runs on the device while this env's rollouts do (no other process, no concurrent stream): the
  * precondition of the multi-step launch, whose workgroups wait INSIDE the kernel for the other workgroups of their own grid (the batch

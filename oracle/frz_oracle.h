@@ -58,6 +58,9 @@ int frz_oracle_wildfire_rebuild(const frz_wildfire_cfg* cfg, frz_oracle_wildfire
 int frz_oracle_wildfire_step(const frz_wildfire_cfg* cfg, frz_oracle_wildfire_bufs* s, const int32_t* actions,
                              const float* field_randomness, const float* agent_randomness);
 
+int frz_oracle_wildfire_reset_masked(const frz_wildfire_cfg* cfg, frz_oracle_wildfire_bufs* s, const uint8_t* mask, int32_t* seeds,
+                                     int32_t seed_increment);
+
 /* single transitions on batch-major arrays, for the reference's known-answer transition tests */
 void frz_oracle_wf_suppressant_decrease(const frz_wildfire_cfg* cfg, float* supp, const uint8_t* users, const float* r,
                                         int64_t n);

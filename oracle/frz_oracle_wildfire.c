@@ -284,6 +284,53 @@ int frz_oracle_wildfire_reset(const frz_wildfire_cfg* cfg, frz_oracle_wildfire_b
     return frz_oracle_wildfire_rebuild(cfg, s);
 }
 
+/* BatchedAECEnv.reset_batches (utils/env.py:162-189) + raw_env.reset_batches (wildfire.py:376-397) with the selection given as a mask:
+ * for every selected env b — rewards, cumulative rewards, terminations, truncations zeroed, num_moves = 0 (utils/env.py:176-188);
+ * state restored from the saved initial state (wildfire.py:383-384: here the configured one, what reset() saved), num_burnouts = 0
+ * (wildfire.py:386); then update_observations / update_actions of the whole batch (wildfire.py:394-397).  mask NULL selects the
+ * finished envs (all agents terminated or all truncated: utils/env.py:331-359).  `seeds` (nullable, in/out) += seed_increment for the
+ * selected envs, modulo 2^32 (the generator.seed(..., partial_seeding) call of utils/env.py:170-174 with seed = old seed + increment). */
+int frz_oracle_wildfire_reset_masked(const frz_wildfire_cfg* cfg, frz_oracle_wildfire_bufs* s, const uint8_t* mask, int32_t* seeds,
+                                     int32_t seed_increment) {
+    const int64_t B = cfg->parallel_envs;
+    const int32_t HW = cfg->grid_height * cfg->grid_width, A = cfg->num_agents;
+    for (int64_t b = 0; b < B; ++b) {
+        int selected;
+        if (mask) {
+            selected = mask[b] != 0;
+        } else {
+            int all_term = 1, all_trunc = 1;
+            for (int32_t a = 0; a < A; ++a) {
+                all_term = all_term && s->terminations[(int64_t)a * B + b];
+                all_trunc = all_trunc && s->truncations[(int64_t)a * B + b];
+            }
+            selected = all_term || all_trunc;
+        }
+        if (!selected) continue;
+        if (seeds) seeds[b] = (int32_t)((uint32_t)seeds[b] + (uint32_t)seed_increment);
+        for (int32_t c = 0; c < HW; ++c) {
+            const int32_t type = cfg->fire_types[c];
+            const int32_t f = cfg->lit[c] ? type : -type;
+            s->fires[b * HW + c] = f;
+            s->intensity[b * HW + c] = cfg->lit[c] ? cfg->ignition_temp[c] : 0;
+            s->fuel[b * HW + c] = f != 0 ? cfg->initial_fuel : 0;
+        }
+        for (int32_t a = 0; a < A; ++a) {
+            s->suppressants[b * A + a] = cfg->initial_suppressant;
+            s->capacity[b * A + a] = cfg->initial_capacity;
+            s->equipment[b * A + a] = cfg->initial_equipment_state;
+            s->rewards[(int64_t)a * B + b] = 0.0f;
+            if (s->cumulative_rewards) s->cumulative_rewards[(int64_t)a * B + b] = 0.0f;
+            s->terminations[(int64_t)a * B + b] = 0;
+            s->truncations[(int64_t)a * B + b] = 0;
+        }
+        s->num_moves[b] = 0;
+        s->num_burnouts[b] = 0;
+    }
+    s->frozen[0] = s->frozen[1] = 0;
+    return frz_oracle_wildfire_rebuild(cfg, s);
+}
+
 /* One ParallelEnv.step(): utils/conversions.py:59-99 -> utils/env.py:203-242 -> wildfire.py:399-584 -> rebuild */
 int frz_oracle_wildfire_step(const frz_wildfire_cfg* cfg, frz_oracle_wildfire_bufs* s, const int32_t* actions,
                              const float* field_randomness, const float* agent_randomness) {

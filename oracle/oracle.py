@@ -99,6 +99,13 @@ class WildfireOracle:
         assert actions.shape == (A, B, 2) and fr.size == 3 * B * HW and ar.size == 5 * B * A
         assert lib().frz_oracle_wildfire_step(ctypes.byref(self.cfg), ctypes.byref(self.bufs), _ptr(actions), _ptr(fr), _ptr(ar)) == 0
 
+    def reset_masked(self, mask, seeds: np.ndarray = None, seed_increment: int = 0):
+        """reset_batches with the selection as a mask (None: the finished envs); ``seeds`` (int32 [B]) moves on in place for the selected envs."""
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        assert seeds is None or (seeds.dtype == np.int32 and seeds.flags['C_CONTIGUOUS'])
+        assert lib().frz_oracle_wildfire_reset_masked(ctypes.byref(self.cfg), ctypes.byref(self.bufs), None if m is None else _ptr(m),
+                                                      None if seeds is None else _ptr(seeds), ctypes.c_int32(seed_increment)) == 0
+
     def rollout(self, env_seeds: np.ndarray, policy_seed: int, first_step: int, n_steps: int) -> int:
         """``n_steps`` x (uniform random policy, the step's Philox randomness, step) in ONE C call (the loop smoke() drives from Python);
         the interpreter lock is released for its whole duration, so host threads stepping their own shards run in parallel."""
