@@ -45,9 +45,10 @@ PROBE_EPISODES = 4     # whole episodes behind the kernel-level figures (indepen
 MIN_BLOCKS, TARGET_TIMED_S = 10, 0.05
 
 
-def wildfire_bytes_per_env_step(HW, A, k, mean_tasks, mean_agent_tasks_sum, injected_randomness=False):
-    """reference-visible dtypes, every array read or written once per env-step."""
-    state = 2 * (3 * HW * 4 + 3 * A * 4)
+def wildfire_bytes_per_env_step(HW, A, k, mean_tasks, mean_agent_tasks_sum, injected_randomness=False, state_passes=2.0):
+    """reference-visible dtypes, every array read or written once per env-step.  state_passes = 2: the state read and
+    written every step (the formula as the survey states it); 1 + 1/n: a launch of n steps reads the state once and writes it every step."""
+    state = state_passes * (3 * HW * 4 + 3 * A * 4)
     io = 8 * A + 4 * A + 2 * A + 24
     obs = 16 * A + 4 * k * A * (A - 1)
     tasks = 32 * mean_tasks + 8
@@ -321,78 +322,124 @@ def main():
     barrier()
     api_value = world * B * api_steps / (time.perf_counter() - t1)
 
-    # ---- kernel-level pass (not part of `value`; always PROBE_EPISODES whole episodes, whatever --steps is): two HIP events on the
-    # launch stream take each step dispatch's own begin and end timestamps (hipExtLaunchKernel start/stop events: what rocprofv3's
-    # kernel trace reports, profiles/) + mean task counts over the same episodes for the algorithmic bytes
+    # ---- kernel-level pass (not part of `value`; always PROBE_EPISODES whole episodes, whatever --steps is): HIP events on the
+    # launch stream take each dispatch's own begin and end timestamps (hipExtLaunchKernel start/stop events: what rocprofv3's kernel
+    # trace reports, profiles/) + mean task counts per step index over the same episodes for the algorithmic bytes
     from free_range_zoo_amd import _capi
     from free_range_zoo_amd.utils.env import stream_ptr
     lib, handle = env._lib, env._handle
     mode = _capi.FRZ_RNG_MT19937 if args.rng == 'mt19937' else _capi.FRZ_RNG_PHILOX
-    kernel_ms, launch_ms = [], []
-    task_sum = torch.zeros(1 + A, dtype=torch.float64, device=device)
+    kernel_ms = []
+    task_sum = torch.zeros((EPISODE, 1 + A), dtype=torch.float64, device=device)  # per step index: lit fires, attackable fires per agent
     stream = stream_ptr(device)
-    # the launches of the timed region: an episode's steps are ONE multi-step launch where the library has one for the shape
-    # (frz_wildfire_rollout_launches), otherwise one launch per step
-    steps_per_launch = EPISODE if lib.frz_wildfire_rollout_launches(handle, EPISODE, mode) == 1 else 1
+    # the launches of the timed region: an episode's steps (and its opening reset, and its metrics) are ONE multi-step launch where the
+    # library has one for the shape (frz_wildfire_rollout_launches), otherwise a reset launch and one launch per step
+    multi_step = lib.frz_wildfire_rollout_launches(handle, EPISODE, mode) == 1
+    reset_in_launch = multi_step and args.rng == 'philox'  # (the MT19937 streams are re-seeded by a launch of their own)
+
+    def timed_rollout(n, first_step=0, reset_first=True, with_metrics=True, auto_reset=False):
+        """ONE multi-step launch as the timed graph holds it, by events around the dispatch (ms)."""
+        spec = _capi.frz_rollout_spec()
+        spec.n_steps, spec.rng_mode, spec.policy_seed, spec.first_step = n, mode, policy_seed, first_step
+        spec.flags = (_capi.FRZ_ROLLOUT_RESET_FIRST if reset_first else 0) | (_capi.FRZ_ROLLOUT_AUTO_RESET if auto_reset else 0)
+        spec.seed_increment = spec.seed_stride = seed_stride
+        spec.actions_out = env._actions.data_ptr()
+        spec.metrics = metrics.data_ptr() if with_metrics else None
+        one = ctypes.c_float()
+        _capi.check(lib.frz_wildfire_timed_rollout_spec(handle, ctypes.byref(spec), stream, ctypes.byref(one)), 'frz_wildfire_timed_rollout_spec')
+        return one.value
+
     for episode in range(PROBE_EPISODES):
-        env.reset(seed=base_seed + 17 + 1000003 * episode)
+        env.reset(seed=base_seed + 17 + seed_stride * episode)
         torch.cuda.synchronize(device)
         out = (ctypes.c_float * EPISODE)()
         _capi.check(lib.frz_wildfire_timed_rollout(handle, policy_seed, 0, EPISODE, env._actions.data_ptr(), mode, stream, out), 'frz_wildfire_timed_rollout')
         kernel_ms.extend(out[i] for i in range(EPISODE))
-        if steps_per_launch > 1:
-            env.reset(seed=base_seed + 17 + 1000003 * episode)
-            torch.cuda.synchronize(device)
-            one = ctypes.c_float()
-            _capi.check(lib.frz_wildfire_timed_rollout_launch(handle, policy_seed, 0, EPISODE, env._actions.data_ptr(), mode, stream, ctypes.byref(one)),
-                        'frz_wildfire_timed_rollout_launch')
-            launch_ms.append(one.value)
     for episode in range(PROBE_EPISODES):  # the same episodes again, step by step, for the task counts (not timed)
-        env.reset(seed=base_seed + 17 + 1000003 * episode)
+        env.reset(seed=base_seed + 17 + seed_stride * episode)
         for t in range(EPISODE):
             lib.frz_wildfire_step_random_policy(handle, policy_seed, t, env._actions.data_ptr(), mode, None, None, stream)
-            task_sum[0] += env.environment_task_count.sum()
-            task_sum[1:] += env.agent_task_count.sum(dim=1)
+            task_sum[t, 0] += env.environment_task_count.sum()
+            task_sum[t, 1:] += env.agent_task_count.sum(dim=1)
     torch.cuda.synchronize(device)
-    # what a timed block is made of: its reset launch and — where an episode's steps are one launch — that launch at the block's own
-    # length (the first K steps of an episode, its most list-heavy ones), each by events around the dispatch; the rest of the block's
-    # median is graph launch, gaps between the launches and the completion hand-back
-    block_parts = None
-    if steps_per_launch > 1:
-        first = min(K, EPISODE)
-        reset_ms, rollout_ms = [], []
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for _ in range(5):
-            torch.cuda.synchronize(device)
-            e0.record()
-            _capi.check(lib.frz_wildfire_reset_reseed(handle, 0, stream), 'frz_wildfire_reset_reseed')
-            e1.record()
-            torch.cuda.synchronize(device)
-            reset_ms.append(e0.elapsed_time(e1))
-            one = ctypes.c_float()
-            if first > 1:
-                _capi.check(lib.frz_wildfire_timed_rollout_launch(handle, policy_seed, 0, first, env._actions.data_ptr(), mode, stream, ctypes.byref(one)),
-                            'frz_wildfire_timed_rollout_launch')
-                rollout_ms.append(one.value)
-        if rollout_ms:
-            episodes = math.ceil(K / EPISODE)
-            block_parts = {'reset_launch_ms': float(np.median(reset_ms)), f'first_{first}_steps_launch_ms': float(np.median(rollout_ms)),
-                           'launches_per_block': 2 * episodes,
-                           'note': 'event-to-event around eager dispatches (the reset figure includes its launch gap); in the timed graph the '
-                                   'episode metrics ride in the rollout launch\'s tail'}
-    n_probe = PROBE_EPISODES * EPISODE
+    task_mean = (task_sum / (PROBE_EPISODES * B)).cpu().numpy()  # [step index][lit fires, attackable per agent]
+
+    def bytes_per_env_step(n_first, state_passes=2.0):
+        """algorithmic bytes per env-step averaged over the first n_first steps of an episode (F measured over exactly those steps)"""
+        window = task_mean[:n_first]
+        return wildfire_bytes_per_env_step(HW, A, env._k, float(window[:, 0].mean()), float(window[:, 1:].sum(axis=1).mean()),
+                                           injected_randomness=(args.rng == 'mt19937'), state_passes=state_passes)
+
+    # the dominant kernel of the timed region = the launch a block is made of: the first min(K, 50) steps of an episode with the
+    # opening reset and the episode metrics inside (a block of K > 50 steps is ceil(K / 50) such launches; the whole-episode launch is
+    # reported beside it).  Both by events around the dispatch itself.
+    n_block = min(K, EPISODE)
+    block_launch_ms, episode_launch_ms = [], []
+    if multi_step and n_block > 1:
+        for rep_i in range(12):
+            env.reset(seed=base_seed + 17)
+            block_launch_ms.append(timed_rollout(n_block, reset_first=reset_in_launch))
+            if n_block != EPISODE:
+                env.reset(seed=base_seed + 17)
+                episode_launch_ms.append(timed_rollout(EPISODE, reset_first=reset_in_launch))
+        block_launch_ms, episode_launch_ms = block_launch_ms[2:], episode_launch_ms[2:]  # (the first two: clocks and caches)
+        if n_block == EPISODE:
+            episode_launch_ms = block_launch_ms
     single_step_ms_avg = float(np.mean(kernel_ms))
-    # duration of the dominant kernel's launch as the timed region runs it (per launch; per step = / steps_per_launch)
-    kernel_ms_avg = float(np.mean(launch_ms)) if launch_ms else single_step_ms_avg
-    mean_tasks = float(task_sum[0].item()) / (n_probe * B)
-    mean_agent_tasks = float(task_sum[1:].sum().item()) / (n_probe * B)
-    per_env = wildfire_bytes_per_env_step(HW, A, env._k, mean_tasks, mean_agent_tasks, injected_randomness=(args.rng == 'mt19937'))
+    steps_per_launch = n_block if block_launch_ms else 1
+    kernel_ms_avg = float(np.mean(block_launch_ms)) if block_launch_ms else single_step_ms_avg
+    per_env = bytes_per_env_step(n_block)
+    per_env_state_once = bytes_per_env_step(n_block, state_passes=1.0 + 1.0 / steps_per_launch)
+    per_env_episode = bytes_per_env_step(EPISODE)
     achieved = per_env * B * steps_per_launch / (kernel_ms_avg * 1e-3) / 1e9  # algorithmic bytes of one launch / its duration
-    traffic, traffic_source = recorded_traffic('wf_step_kernel_bytes_per_step')
-    if traffic is not None:
-        traffic *= steps_per_launch  # per launch, like `achieved`
+    traffic, traffic_source = recorded_traffic(f'wildfire_rollout{steps_per_launch}_bytes_per_launch' if block_launch_ms else 'wildfire_single_step_bytes_per_launch')
     if args.rng != 'philox':  # the counter passes were made in the Philox mode (the MT19937 mode also streams 67 generator words per env-step)
         traffic, traffic_source = None, 'recorded for rng=philox only'
+
+    # ---- continuous rollouts at fixed B (SURVEY §8f #3): the same K-step block with device-side auto-reset instead of the episode structure
+    # (an env that finishes is reset inside the step that finished it: no env idles extinguished until the episode's horizon)
+    dense = None
+    if multi_step and args.rng == 'philox' and K > 1:
+        env.reset(seed=base_seed)
+        dense_metrics = torch.zeros_like(metrics)
+        dense_graph = env.capture_random_rollout(K, policy_seed=policy_seed, include_reset=False, seed_stride=seed_stride, metrics=dense_metrics,
+                                                 auto_reset=True)
+        dense_warm = max(3, math.ceil(150 / K))
+        for _ in range(dense_warm):  # into the steady state of the continuous rollout (episode phases spread out)
+            dense_graph.replay()
+        dense_s = []
+        for _ in range(repeats):
+            barrier()
+            t0 = time.perf_counter()
+            dense_graph.replay()
+            done_event.record()
+            while not done_event.query():
+                pass
+            torch.cuda.synchronize(device)
+            dense_s.append(time.perf_counter() - t0)
+        dense_t = torch.tensor(dense_s, dtype=torch.float64, device=device)
+        if dist is not None:
+            dist.all_reduce(dense_t, op=dist.ReduceOp.MAX)
+        dense_median = float(np.median(dense_t.cpu().numpy()))
+        del dense_graph
+        counts = torch.zeros(1 + A, dtype=torch.float64, device=device)
+        for t in range(60):  # mean task counts of the steady state (not timed): one-step rollouts, counts read between them
+            env.rollout(1, policy_seed=policy_seed, first_step=1000 + t, auto_reset=True, seed_stride=seed_stride)
+            counts[0] += env.environment_task_count.sum()
+            counts[1:] += env.agent_task_count.sum(dim=1)
+        counts = (counts / (60 * B)).tolist()
+        dense_launch = [timed_rollout(n_block, first_step=2000 + i * n_block, reset_first=False, with_metrics=True, auto_reset=True) for i in range(10)][2:]
+        dense_per_env = wildfire_bytes_per_env_step(HW, A, env._k, counts[0], sum(counts[1:]))
+        dense_ms = float(np.mean(dense_launch))
+        dense_frac = dense_per_env * B * n_block / (dense_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        dense = {'value': world * B * K / dense_median, 'unit': 'env-steps/s', 'ms_per_step': 1e3 * dense_median / K, 'auto_reset': True,
+                 'semantics': 'step(); reset_batches(finished, seed + stride) inside the launch (frz_rollout_spec FRZ_ROLLOUT_AUTO_RESET): every env is '
+                              'always mid-episode; NOT the headline (the reference loop lets finished envs idle until all are done)',
+                 'mean_tasks_per_env': counts[0], 'mean_agent_tasks_per_env': sum(counts[1:]),
+                 'episodes_ended_per_block': float(dense_metrics[A + 1].item()) / (repeats + dense_warm),
+                 'roofline': {'bound': 'hbm', 'achieved': dense_frac * HBM_PEAK_GBS, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': dense_frac, 'traffic': None,
+                              'kernel': f'wf_roles_kernel<6,3,exact,{args.rng},step,multi-step> with auto-reset', 'steps_per_launch': n_block,
+                              'kernel_ms_avg': dense_ms, 'kernel_ms_per_step': dense_ms / n_block, 'algorithmic_bytes_per_env_step': dense_per_env}}
 
     if rank == 0:
         env.check()
@@ -414,26 +461,43 @@ def main():
                                    f'policy sampled inside the step launch, rng={args.rng}',
                        'parallel_envs_per_gpu': B, 'agents': A,
                        'sharding': f'env-batch axis x{world}, no step-path collective, one metrics all-reduce per timed block'},
-            'timing': {'protocol': f'{K}-step block = ONE HIP graph ({episodes_per_block} x [reseed, reset, <= {EPISODE} steps, episode metrics]); timed '
+            'timing': {'protocol': f'{K}-step block = ONE HIP graph ({episodes_per_block} x [reseed, reset, <= {EPISODE} steps, episode metrics]'
+                                   + (' = ONE launch each' if reset_in_launch else '') + '); timed '
                                    f'{repeats} times, each bracketed by barrier + synchronize; median block over the max-over-ranks times',
                        'blocks': repeats, 'block_ms_median': 1e3 * median_s, 'block_ms_min': 1e3 * float(block_s.min()),
                        'block_ms_max': 1e3 * float(block_s.max()), 'block_ms_mean': 1e3 * float(block_s.mean()),
-                       'steps_timed_in_total': repeats * K, 'block_parts': block_parts,
+                       'steps_timed_in_total': repeats * K,
+                       'launches_per_block': ((1 if reset_in_launch else 2) * episodes_per_block) if multi_step else None,
                        'job_metrics': {'mean_episode_return_per_agent': (finished_metrics[:A] / max(world * B * episodes_per_block * repeats, 1)).tolist(),
                                        'env_steps_counted': float(finished_metrics[A].item())}},
             'agent_steps_per_s': value * A,
             'python_api_env_steps_per_s': api_value,
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'frac_algorithmic': achieved / HBM_PEAK_GBS,
+                         'frac_algorithmic_state_read_once': per_env_state_once * B * steps_per_launch / (kernel_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         'frac_measured': (traffic / (kernel_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         'fractions': 'frac = frac_algorithmic: SURVEY 8(d) bytes (state read AND written every env-step, reference dtypes) / launch '
+                                      'duration / 8 TB/s; frac_algorithmic_state_read_once: the same with the state read once per launch (a multi-step '
+                                      'launch keeps it in registers); frac_measured: HBM bytes the counters saw (traffic) / launch duration / 8 TB/s',
                          'traffic': traffic, 'traffic_source': traffic_source,
                          'kernel': f'wf_roles_kernel<6,3,exact,{args.rng},step' + (',multi-step>' if steps_per_launch > 1 else '>'),
+                         'launch': ((f'the launch a timed block is made of: the first {steps_per_launch} steps of an episode, '
+                                     + ('opening reset and ' if reset_in_launch else '') + 'episode metrics inside') if steps_per_launch > 1 else 'one step'),
                          'steps_per_launch': steps_per_launch,
-                         'kernel_ms_avg': kernel_ms_avg, 'kernel_ms_median': float(np.median(launch_ms if launch_ms else kernel_ms)),
-                         'launches_timed': len(launch_ms) if launch_ms else n_probe,
+                         'kernel_ms_avg': kernel_ms_avg, 'kernel_ms_median': float(np.median(block_launch_ms if block_launch_ms else kernel_ms)),
+                         'launches_timed': len(block_launch_ms) if block_launch_ms else len(kernel_ms),
                          'kernel_ms_per_step': kernel_ms_avg / steps_per_launch,
                          'single_step_launch_ms_avg': single_step_ms_avg,
                          'algorithmic_bytes_per_launch': per_env * B * steps_per_launch,
-                         'algorithmic_bytes_per_env_step': per_env, 'mean_tasks_per_env': mean_tasks, 'mean_agent_tasks_per_env': mean_agent_tasks,
+                         'algorithmic_bytes_per_env_step': per_env,
+                         'mean_tasks_per_env': float(task_mean[:n_block, 0].mean()), 'mean_agent_tasks_per_env': float(task_mean[:n_block, 1:].sum(axis=1).mean()),
+                         'whole_episode_launch': ({'steps_per_launch': EPISODE, 'kernel_ms_avg': float(np.mean(episode_launch_ms)),
+                                                   'kernel_ms_per_step': float(np.mean(episode_launch_ms)) / EPISODE,
+                                                   'algorithmic_bytes_per_env_step': per_env_episode,
+                                                   'frac': per_env_episode * B * EPISODE / (float(np.mean(episode_launch_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                                  if episode_launch_ms else None),
                          'frac_at_driver_ms_per_step': per_env * B / (median_s / K) / 1e9 / HBM_PEAK_GBS},
+            'auto_reset_workload': dense,
             'reference_cpu_env_steps_per_s': {'value': 21112, 'source': 'BASELINE.md §2: unmodified reference, 8 vCPU, B=65536 (survey container)'},
         }
         if world == 1 and not args.no_cpu_baseline:

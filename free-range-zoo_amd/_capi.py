@@ -59,6 +59,7 @@ SIGNATURES = {
     'frz_wildfire_timed_rollout_launch': (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int32, _P, ctypes.c_int, _P,
                                                         ctypes.POINTER(ctypes.c_float)]),
     'frz_wildfire_rollout': (ctypes.c_int, [_P, _P, _P]),
+    'frz_wildfire_timed_rollout_spec': (ctypes.c_int, [_P, _P, _P, ctypes.POINTER(ctypes.c_float)]),
     'frz_wildfire_list_block': (ctypes.c_int, [_P, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64)]),
     'frz_wildfire_reset_masked': (ctypes.c_int, [_P, _P, ctypes.c_int32, _P]),
     'frz_cybersecurity_create': (ctypes.c_int, [_P, ctypes.POINTER(_P)]),

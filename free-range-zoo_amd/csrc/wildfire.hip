@@ -1873,6 +1873,24 @@ int frz_wildfire_rollout(frz_wildfire_env* env, const frz_rollout_spec* spec, vo
     return FRZ_OK;
 }
 
+int frz_wildfire_timed_rollout_spec(frz_wildfire_env* env, const frz_rollout_spec* spec, void* stream, float* launch_ms) {
+    if (!env || !spec || !launch_ms || frz_wildfire_rollout_launches(env, spec->n_steps, spec->rng_mode) != 1) return FRZ_E_INVALID;
+    if ((spec->flags & FRZ_ROLLOUT_RESET_FIRST) && spec->rng_mode == FRZ_RNG_MT19937) return FRZ_E_INVALID;  // (then the reset is its own launch)
+    while ((int)env->timing_events.size() < 2) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return FRZ_E_LAUNCH;
+        env->timing_events.push_back(e);
+    }
+    env->start_event = env->timing_events[0];
+    env->stop_event = env->timing_events[1];
+    env->timed = true;
+    const int rc = frz_wildfire_rollout(env, spec, stream);
+    env->timed = false;
+    if (rc != FRZ_OK) return rc;
+    if (hipStreamSynchronize(static_cast<hipStream_t>(stream)) != hipSuccess) return FRZ_E_LAUNCH;
+    return hipEventElapsedTime(launch_ms, env->timing_events[0], env->timing_events[1]) == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;
+}
+
 int frz_wildfire_episode_metrics(frz_wildfire_env* env, double* metrics, void* stream) {
     if (!env || !metrics) return FRZ_E_INVALID;
     if (!env->arena) return FRZ_E_UNBOUND;

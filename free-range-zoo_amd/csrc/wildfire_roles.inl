@@ -62,7 +62,10 @@ constexpr int kRound = 256;             // look-back window: a chunk sums at mos
 // before it (a launch that finds the batch finished early writes its last lists once more, into the caller's buffers); (iii) what
 // crosses workgroups (chunk sums, batch totals) travels in tagged granules read with agent-scope loads.  The totals of step t — which every workgroup needs before step t + 1:
 // all-done test, skip-agent quirk — are the last chunk's inclusive-prefix granules: waiting for them is the only inter-step barrier.
-template <int CMAX, int AMAX, bool EXACT, int RNG, int MODE, bool PERSIST = false>
+// EXTRA (multi-step launches only): everything a frz_rollout_spec can ask for beyond "policy sampled in-kernel, opening reset, episode
+// metrics" — an action tape, randomness tapes, reward / done / action records, the list record, FRZ_ROLLOUT_AUTO_RESET.  A separate
+// instantiation because the plain rollout is the kernel the bench times: with these as run-time options its step was 0.45 us longer.
+template <int CMAX, int AMAX, bool EXACT, int RNG, int MODE, bool PERSIST = false, bool EXTRA = false>
 __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX > 8 || !EXACT || PERSIST) ? 2 : 4)) wf_roles_kernel(char* __restrict__ arena, const WfDev* __restrict__ dev,
                                                                const int32_t* __restrict__ actions, const float* __restrict__ field_rand,
                                                                const float* __restrict__ agent_rand, const WfLaunch launch) {
@@ -92,8 +95,8 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
     __shared__ float x_supp[AMAX][kBlock];   // crew -> field: suppressant after the agent transitions (agent observations)
     __shared__ float x_draw[(kPhilox || kMt) ? 5 * AMAX : 1][kBlock];  // field -> crew: the step's agent draws (in-kernel RNG)
     // FRZ_ROLLOUT_AUTO_RESET: returns of the episodes that ended inside this launch (float64, per env slot: deterministic) and their number
-    __shared__ double x_return[PERSIST ? AMAX : 1][PERSIST ? kBlock : 1];
-    __shared__ uint32_t x_ended[PERSIST ? kBlock : 1];
+    __shared__ double x_return[EXTRA ? AMAX : 1][EXTRA ? kBlock : 1];
+    __shared__ uint32_t x_ended[EXTRA ? kBlock : 1];
 
     const int tid = threadIdx.x;
     const uint4 cfg_piece = stage_request(dev);  // first vector-memory instruction of the kernel
@@ -160,7 +163,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
     // multi-step launches (frz_wildfire_rollout): FRZ_ROLLOUT_RESET_FIRST starts from the configured initial state (taken from the staged
     // configuration below instead of loaded here), FRZ_ROLLOUT_AUTO_RESET resets an env at the end of the step that finishes it
     const bool reset_first = PERSIST && (launch.rollout_flags & FRZ_ROLLOUT_RESET_FIRST) != 0;
-    const bool auto_reset = PERSIST && (launch.rollout_flags & FRZ_ROLLOUT_AUTO_RESET) != 0;
+    const bool auto_reset = EXTRA && (launch.rollout_flags & FRZ_ROLLOUT_AUTO_RESET) != 0;
     auto load_cells = [&](int chunk) {
         Cells e;
         const uint32_t bl = env_index(chunk);
@@ -316,6 +319,8 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
     const uint32_t flags_word = d.flags;
 
     static_assert(!PERSIST || (EXACT && MODE == kStep), "the multi-step launch exists for the exact step kernels");
+    static_assert(!EXTRA || PERSIST, "the rollout options belong to the multi-step launch");
+    static_assert(!(PERSIST && kInjected) || EXTRA, "randomness tapes are a rollout option");
     const int n_steps = PERSIST ? launch.n_steps : 1;
     if constexpr (PERSIST) {
         if (reset_first) {  // the configured initial state (wildfire.py:347-354) + zeroed bookkeeping (utils/env.py:137-160), in registers
@@ -330,10 +335,12 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                     if (a < A) crw.supp[a] = s_cfg.init_suppressant, crw.capa[a] = s_cfg.init_capacity, crw.eqs[a] = s_cfg.init_equipment;
             }
         }
-        if (auto_reset) {
+        if constexpr (EXTRA) {
+            if (auto_reset) {
 #pragma unroll
-            for (int a = 0; a < AMAX; ++a) x_return[a][slot] = 0.0;
-            x_ended[slot] = 0u;
+                for (int a = 0; a < AMAX; ++a) x_return[a][slot] = 0.0;
+                x_ended[slot] = 0u;
+            }
         }
     }
     uint32_t epoch_now = epoch;     // the epoch the current step runs under (advances with every executed step of a multi-step launch)
@@ -440,9 +447,9 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
     // which stays: every step's lists can then be read back (tests: against the oracle's)
     auto list_copy = [&](int t) -> int64_t {
         if (!PERSIST || t >= n_steps - 1) return 0;
-        return launch.list_record_delta != 0 ? launch.list_record_delta + (int64_t)t * launch.list_record_step : launch.scratch_delta;
+        return (EXTRA && launch.list_record_delta != 0) ? launch.list_record_delta + (int64_t)t * launch.list_record_step : launch.scratch_delta;
     };
-    auto offsets_copy = [&](int t) -> int64_t { return (PERSIST && t < n_steps - 1 && launch.list_record_delta != 0) ? list_copy(t) : (int64_t)0; };
+    auto offsets_copy = [&](int t) -> int64_t { return (EXTRA && t < n_steps - 1 && launch.list_record_delta != 0) ? list_copy(t) : (int64_t)0; };
     int executed = 0;    // steps the field role performed (it advances the epoch by as many)
     int crew_steps = 0;  // ... and the crew
     // After barrier 5 either role can place any list of its env: the chunk's offsets (s_prefix), the sums of the chunk's
@@ -589,7 +596,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                 int mt_first = 0;
                 if (MODE == kStep) {
                     if constexpr (kInjected) {
-                        if (PERSIST && t > 0) load_field_draws(chunk, t, fdraws);  // the tape's next pair
+                        if (EXTRA && t > 0) load_field_draws(chunk, t, fdraws);  // the tape's next pair
 #pragma unroll
                         for (int e = 0; e < 3; ++e)
 #pragma unroll
@@ -773,7 +780,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                 // FRZ_ROLLOUT_AUTO_RESET: the env this step finished (terminated: no fire left; truncated: the horizon) starts over — this
                 // role's share of reset_batches (wildfire.py:376-397): the cells, the step counter behind the draws, the seed that keys them
                 bool fresh = false;
-                if constexpr (PERSIST) {
+                if constexpr (EXTRA) {
                     if (auto_reset) {
                         fresh = dead || ((flags & kTruncate) && fld.nm + 1 >= d.max_steps);
 #pragma unroll
@@ -911,7 +918,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                 const WfHot& d = PERSIST ? static_cast<const WfHot&>(s_cfg) : d_launch;
                 if constexpr (PERSIST) {
                     if (t > 0) request_totals();
-                    if (t > 0 && !launch.policy) {  // the action tape's next step (frz_rollout_spec.action_tape)
+                    if (EXTRA && t > 0 && !launch.policy) {  // the action tape's next step (frz_rollout_spec.action_tape)
                         const int2* const tape = reinterpret_cast<const int2*>(actions + (int64_t)t * launch.tape_actions_step);
                         int2 v[AMAX];
 #pragma unroll
@@ -919,7 +926,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
 #pragma unroll
                         for (int a = 0; a < AMAX; ++a) crw.act_idx[a] = v[a].x, crw.act_id[a] = v[a].y;
                     }
-                    if (t > 0) load_crew_draws(chunk, t, cdraws);
+                    if (EXTRA && t > 0) load_crew_draws(chunk, t, cdraws);
                 }
 #pragma unroll
                 for (int a = 0; a < AMAX; ++a) rew[a] = 0.0f, hit[a] = -1, users[a] = false, refill[a] = false;
@@ -1031,7 +1038,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                     }
                     err |= err1;
                     if (launch.policy) {  // nothing of the step had left the registers before the verdict
-                        int2* const out = reinterpret_cast<int2*>(launch.actions_out + (int64_t)t * launch.actions_out_step);
+                        int2* const out = reinterpret_cast<int2*>(launch.actions_out + (EXTRA ? (int64_t)t * launch.actions_out_step : (int64_t)0));
 #pragma unroll
                         for (int a = 0; a < AMAX; ++a)
                             if (a < A) frz::store_through(&out[a * B + bl], sampled[a]);
@@ -1136,7 +1143,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                     const int nm = crw.nm + 1;
                     trunc = (flags & kTruncate) ? nm >= d.max_steps : trunc0;
                     term = term0 || dead;
-                    if constexpr (PERSIST) {
+                    if constexpr (EXTRA) {
                         fresh = auto_reset && (term || trunc);
                         if (fresh) {  // wildfire.py:352-354 on this env; the rows were written with the step's values above
 #pragma unroll
@@ -1255,7 +1262,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                             at32(rowsf, (uint32_t)(r_rewards + a) * Bu + bl) = fresh ? 0.0f : rew[a];
                             at32(rows1, (u_term + (uint32_t)a) * Bu + bl) = (uint8_t)(term && !fresh);
                             if (write_trunc) at32(rows1, (u_trunc + (uint32_t)a) * Bu + bl) = (uint8_t)(trunc && !fresh);
-                            if constexpr (PERSIST) {
+                            if constexpr (EXTRA) {
                                 if (launch.reward_tape != nullptr) launch.reward_tape[((int64_t)t * A + a) * B + bl] = rew[a];
                             }
                             if (track) {
@@ -1266,7 +1273,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                             }
                         }
                     }
-                    if constexpr (PERSIST) {
+                    if constexpr (EXTRA) {
                         if (launch.done_tape != nullptr) {
                             launch.done_tape[((int64_t)t * 2 + 0) * B + bl] = (uint8_t)term;
                             launch.done_tape[((int64_t)t * 2 + 1) * B + bl] = (uint8_t)trunc;
@@ -1378,7 +1385,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                 double mine[AMAX + 2];
 #pragma unroll
                 for (int i = 0; i < AMAX + 2; ++i) mine[i] = 0.0;
-                if (active && auto_reset) {  // returns of the episodes that ended in this launch, env-steps executed, episodes ended
+                if (EXTRA && active && auto_reset) {  // returns of the episodes that ended in this launch, env-steps executed, episodes ended
 #pragma unroll
                     for (int a = 0; a < AMAX; ++a) mine[a] = a < A ? x_return[a][slot] : 0.0;
 #pragma unroll
@@ -1438,41 +1445,24 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
 template <int CMAX, int AMAX, bool EXACT>
 void launch_roles_variant(const WfArgs& a, const WfDev* dev, int grid, int rng, int mode, hipStream_t stream) {
     const WfLaunch batch = make_launch(a);
-    if (mode == kReset) {
-        launch_step_kernel(a, wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kReset>, grid, kRoleBlock, stream, a.arena, dev, a.actions,
-                           a.field_rand, a.agent_rand, batch);
-    } else if (mode == kRebuild) {
-        launch_step_kernel(a, wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kRebuild>, grid, kRoleBlock, stream, a.arena, dev, a.actions,
-                           a.field_rand, a.agent_rand, batch);
-    } else if (rng == FRZ_RNG_PHILOX) {
-        if constexpr (EXACT) {
-            if (a.n_steps > 1)  // one launch for the whole rollout (the caller has checked policy, residency and the second list copy)
-                launch_step_kernel(a, wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_PHILOX, kStep, true>, grid, kRoleBlock, stream, a.arena, dev,
-                                   a.actions, a.field_rand, a.agent_rand, batch);
-            else
-                launch_step_kernel(a, wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_PHILOX, kStep>, grid, kRoleBlock, stream, a.arena, dev, a.actions,
-                                   a.field_rand, a.agent_rand, batch);
+    auto go = [&](auto kernel) { launch_step_kernel(a, kernel, grid, kRoleBlock, stream, a.arena, dev, a.actions, a.field_rand, a.agent_rand, batch); };
+    if (mode == kReset) return go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kReset>);
+    if (mode == kRebuild) return go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kRebuild>);
+    if constexpr (EXACT) {
+        if (a.n_steps > 1) {  // one launch for the whole rollout (the caller has checked residency and the second list copy)
+            // the plain rollout (policy in-kernel, opening reset, metrics) or the one with every option of a frz_rollout_spec
+            const bool extra = !a.policy || a.tape_actions_step != 0 || a.list_record_delta != 0 || a.reward_tape || a.done_tape || a.actions_out_step != 0 ||
+                               (a.rollout_flags & FRZ_ROLLOUT_AUTO_RESET) != 0;
+            if (rng == FRZ_RNG_PHILOX)
+                return extra ? go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_PHILOX, kStep, true, true>) : go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_PHILOX, kStep, true, false>);
+            if (rng == FRZ_RNG_MT19937)
+                return extra ? go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_MT19937, kStep, true, true>) : go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_MT19937, kStep, true, false>);
+            return go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kStep, true, true>);  // action + randomness tapes: golden trajectories
         }
-    } else if (rng == FRZ_RNG_MT19937) {
-        if constexpr (EXACT) {
-            if (a.n_steps > 1)
-                launch_step_kernel(a, wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_MT19937, kStep, true>, grid, kRoleBlock, stream, a.arena, dev,
-                                   a.actions, a.field_rand, a.agent_rand, batch);
-            else
-                launch_step_kernel(a, wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_MT19937, kStep>, grid, kRoleBlock, stream, a.arena, dev, a.actions,
-                                   a.field_rand, a.agent_rand, batch);
-        }
-    } else {
-        if constexpr (EXACT) {
-            if (a.n_steps > 1) {  // golden trajectories and scripted rollouts through the multi-step launch: action tape + randomness tapes
-                launch_step_kernel(a, wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kStep, true>, grid, kRoleBlock, stream, a.arena, dev,
-                                   a.actions, a.field_rand, a.agent_rand, batch);
-                return;
-            }
-        }
-        launch_step_kernel(a, wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kStep>, grid, kRoleBlock, stream, a.arena, dev, a.actions,
-                           a.field_rand, a.agent_rand, batch);
+        if (rng == FRZ_RNG_PHILOX) return go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_PHILOX, kStep>);
+        if (rng == FRZ_RNG_MT19937) return go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_MT19937, kStep>);
     }
+    if (rng == FRZ_RNG_INJECTED) go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kStep>);
 }
 
 }  // namespace

@@ -327,29 +327,36 @@ class raw_env(BatchedParallelEnv):
     @torch.no_grad()
     def capture_random_rollout(self, steps: int, policy_seed: int = 0, include_reset: bool = True, episode_length: Optional[int] = None,
                                seed_stride: int = 0, metrics: Optional[torch.Tensor] = None,
-                               metrics_copy: Optional[torch.Tensor] = None) -> 'torch.cuda.CUDAGraph':
+                               metrics_copy: Optional[torch.Tensor] = None, auto_reset: bool = False) -> 'torch.cuda.CUDAGraph':
         """
-        Capture ``[reset] + steps x (random policy + step, one launch where the grid shape has a fused kernel)`` into a HIP
-        graph and return it.
+        Capture ``[reset] + steps x (random policy + step)`` into a HIP graph and return it: one ``frz_wildfire_rollout`` per episode —
+        ONE launch where the library has a multi-step kernel for the shape (the opening reset, the steps and the episode metrics all
+        inside it), otherwise a reset launch and one launch per step.
 
-        Launch-bound rollouts (one ~10 us kernel per step) are replayed with ``graph.replay()`` without per-step host
-        work; results land in the same persistent buffers ``step()`` fills.  The env seeds are read at replay time
-        (``env.seeds`` may be changed between replays); the reset inside the graph restores the configured initial
-        state (it does not re-run the Python-side ``save_initial``).
+        Launch-bound rollouts are replayed with ``graph.replay()`` without per-step host work; results land in the same persistent
+        buffers ``step()`` fills.  The env seeds are read at replay time (``env.seeds`` may be changed between replays); the reset
+        inside the graph restores the configured initial state (it does not re-run the Python-side ``save_initial``).
 
         A whole rollout loop as ONE graph: with ``episode_length`` the ``steps`` are cut into episodes, each starting with a
-        reset (policy steps restart at 0); ``seed_stride`` (an int) is added to ``env.seeds`` by every reset launch (fresh seeds per
-        episode); ``metrics`` (float64 ``[A + 2]``) receives ``accumulate_episode_metrics`` after every
-        episode and is copied to ``metrics_copy`` at the end of the graph (the buffer a collective then reduces).
+        reset (policy steps restart at 0); ``seed_stride`` (an int) is added to ``env.seeds`` by every reset (fresh seeds per
+        episode); ``metrics`` (float64 ``[A + 2]``) receives ``accumulate_episode_metrics`` after every episode and is copied to
+        ``metrics_copy`` at the end of the graph (the buffer a collective then reduces).
+
+        ``auto_reset=True``: no episode structure — the ``steps`` are one continuous rollout in which an env that finishes is reset
+        inside the step that finished it (seed += ``seed_stride``); ``metrics`` then receives the returns of the episodes that ended.
         """
         if not self._has_reset:
             raise RuntimeError('reset() must be called once before capturing a rollout')
         if metrics is not None and (metrics.dtype != torch.float64 or metrics.numel() != len(self.agents) + 2 or not metrics.is_contiguous()):
             raise ValueError('metrics must be a contiguous float64 [A + 2] tensor on the env device')
-        lib, handle, actions = self._lib, self._handle, self._actions.data_ptr()
+        lib, handle = self._lib, self._handle
         mode = self._fused_rng_mode()
-        mt = mode == _capi.FRZ_RNG_MT19937
-        episode = steps if not episode_length else int(episode_length)
+        episode = steps if (not episode_length or auto_reset) else int(episode_length)
+        spec = _capi.frz_rollout_spec()
+        spec.rng_mode, spec.policy_seed, spec.actions_out = mode, int(policy_seed), self._actions.data_ptr()
+        spec.metrics = metrics.data_ptr() if metrics is not None else None
+        spec.flags = (_capi.FRZ_ROLLOUT_RESET_FIRST if include_reset else 0) | (_capi.FRZ_ROLLOUT_AUTO_RESET if auto_reset else 0)
+        spec.seed_increment, spec.seed_stride = int(seed_stride), int(seed_stride) & 0xFFFFFFFF
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
         # thread-local capture: other threads of the process (e.g. the RCCL watchdog of torch.distributed) may touch the HIP
@@ -357,23 +364,12 @@ class raw_env(BatchedParallelEnv):
         with torch.cuda.graph(graph, capture_error_mode='thread_local'):
             stream = stream_ptr(self.device)
             done = 0
-            while done < steps or (steps == 0 and done == 0):
-                n = min(episode, steps - done) if steps else 0
-                if include_reset:
-                    _capi.check(lib.frz_wildfire_reset_reseed(handle, int(seed_stride), stream), 'frz_wildfire_reset_reseed')
-                    if mt:  # the streams restart from the (new) seeds; the reset launch does not touch them
-                        _capi.check(lib.frz_mt19937_seed(self._bufs.mt_state, self._bufs.mt_index, self._bufs.seeds, None, 0,
-                                                         self.parallel_envs, stream), 'frz_mt19937_seed')
-                if metrics is not None and n > 0:  # the episode and its reductions (one launch where the library has a multi-step kernel)
-                    _capi.check(lib.frz_wildfire_rollout_random_policy_metrics(handle, policy_seed, 0 if include_reset else done, n, actions, mode,
-                                                                               metrics.data_ptr(), stream), 'frz_wildfire_rollout_random_policy_metrics')
-                else:
-                    _capi.check(lib.frz_wildfire_rollout_random_policy(handle, policy_seed, 0 if include_reset else done, n, actions, mode, stream),
-                                'frz_wildfire_rollout_random_policy')
-                    if metrics is not None:
-                        _capi.check(lib.frz_wildfire_episode_metrics(handle, metrics.data_ptr(), stream), 'frz_wildfire_episode_metrics')
+            while True:
+                n = min(episode, steps - done)
+                spec.n_steps, spec.first_step = n, 0 if include_reset else done
+                _capi.check(lib.frz_wildfire_rollout(handle, ctypes.byref(spec), stream), 'frz_wildfire_rollout')
                 done += n
-                if n == 0:
+                if done >= steps:
                     break
             if metrics is not None and metrics_copy is not None:
                 metrics_copy.copy_(metrics)

@@ -351,6 +351,9 @@ int frz_wildfire_rollout_launches(const frz_wildfire_env* env, int32_t n_steps, 
 int frz_wildfire_timed_rollout_launch(frz_wildfire_env* env, uint64_t policy_seed, uint64_t first_step, int32_t n_steps, int32_t* actions_out,
                                       int rng_mode, void* stream, float* launch_ms);
 
+/* Measurement aid: frz_wildfire_rollout(spec) when it is ONE launch, bracketed like frz_wildfire_timed_rollout_launch (FRZ_E_INVALID otherwise) */
+int frz_wildfire_timed_rollout_spec(frz_wildfire_env* env, const frz_rollout_spec* spec, void* stream, float* launch_ms);
+
 /* Measurement aid: n_steps launches of frz_wildfire_step_random_policy (policy steps first_step ...), back to back with no
  * host synchronisation in between, each bracketed by its own pair of HIP events that take the step dispatch's begin / end
  * timestamps on `stream` (what a profiler's kernel trace reports); synchronises once at the end and returns the durations

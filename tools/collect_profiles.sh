@@ -5,11 +5,11 @@
 # summary — profiles/hbm_traffic.json carries the fingerprint of the kernel sources — so that the bench lines that follow report
 # `roofline.traffic` from this very build; then the bench lines; then the kernel traces of the same commands.
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for domain in wildfire cybersecurity rideshare; do
+for domain in wildfire wildfire20 cybersecurity rideshare; do
   for counter in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $counter --output-format csv -d $OUT/pmc_${domain}_${counter} -o pmc -- python3 $GRAFT_REPO_ROOT/tools/traffic_run.py $domain > $OUT/pmc_${domain}_${counter}.log 2>&1 || echo "pmc $domain $counter failed"
   done

@@ -79,7 +79,29 @@ for domain in STEP_KERNELS:
         out[f'{domain}_read_bytes_per_env_step'] = 2 * f[0] * 1024 / 65536
         out[f'{domain}_write_bytes_per_env_step'] = w[0] * 1024 / 65536
         out[f'{domain}_steps_counted'] = f[1]
-if 'wildfire_bytes_per_step' in out:  # bench.py scales it by the steps one launch of its timed region performs
-    out['wf_step_kernel_bytes_per_step'] = out['wildfire_bytes_per_step']
+if 'wildfire_bytes_per_step' in out:  # the 50-step launch of tools/traffic_run.py wildfire: opening reset + 50 steps + episode metrics
+    out['wildfire_rollout50_bytes_per_launch'] = out['wildfire_bytes_per_step'] * 50
+
+
+def rollout_launch(tagname, steps):
+    """bytes of the ONE multi-step dispatch of `tools/traffic_run.py wildfire<steps>` (pass directories pmc_<tagname>_<COUNTER>)"""
+    values = {}
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        files = glob.glob(os.path.join(src, f'pmc_{tagname}_{counter}', '**', '*counter_collection.csv'), recursive=True)
+        if not files:
+            return None
+        rows = [r for r in csv.DictReader(open(files[0])) if r['Counter_Name'] == counter and re.search(r'wf_roles_kernel<[^>]*(true|1)>', r['Kernel_Name'])
+                and re.search(r'wf_roles_kernel<([^>]*)>', r['Kernel_Name']).group(1).split(',')[4].strip() == '0']
+        if len(rows) != 1:
+            return None
+        values[counter] = float(rows[0]['Counter_Value'])
+    return (2 * values['FETCH_SIZE'] + values['WRITE_SIZE']) * 1024
+
+
+for steps in (20, ):
+    b = rollout_launch(f'wildfire{steps}', steps)
+    if b:
+        out[f'wildfire_rollout{steps}_bytes_per_launch'] = b
+        out[f'wildfire_rollout{steps}_bytes_per_env_step'] = b / 65536 / steps
 json.dump(out, open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json'), 'w'), indent=1)
 print(json.dumps(out, indent=1))
