@@ -269,12 +269,37 @@ def main():
     # ---- the block: K steps as ONE graph = per episode (fresh seeds, reset, <= 50 x fused policy+step, episode metrics), metrics copy
     env.reset(seed=base_seed)
     seed_stride = 1000003
-    block = env.capture_random_rollout(K, policy_seed=policy_seed, include_reset=True, episode_length=EPISODE, seed_stride=seed_stride,
-                                       metrics=metrics, metrics_copy=job_metrics if dist is not None else None)
+    from free_range_zoo_amd import _capi
+    from free_range_zoo_amd.utils.env import stream_ptr
+    fused_mode = _capi.FRZ_RNG_MT19937 if args.rng == 'mt19937' else _capi.FRZ_RNG_PHILOX
+    one_launch_per_episode = env._lib.frz_wildfire_rollout_launches(env._handle, min(K, EPISODE), fused_mode) == 1 and args.rng == 'philox'
+    if one_launch_per_episode:
+        # an episode (opening reset with fresh seeds, its steps, its metrics) is ONE launch: the block's few launches are enqueued
+        # directly through the C-ABI — a one-node graph costs more to launch than the launch it holds (169 vs 161 us per 20-step block)
+        specs = []
+        for first in range(0, K, EPISODE):
+            spec = _capi.frz_rollout_spec()
+            spec.n_steps, spec.rng_mode, spec.policy_seed, spec.first_step = min(EPISODE, K - first), fused_mode, policy_seed, 0
+            spec.flags, spec.seed_increment = _capi.FRZ_ROLLOUT_RESET_FIRST, seed_stride
+            spec.actions_out, spec.metrics = env._actions.data_ptr(), metrics.data_ptr()
+            specs.append(ctypes.byref(spec))
+            specs.append(spec)  # (keeps the struct alive)
+        spec_refs = specs[0::2]
+        rollout_entry, env_handle, launch_stream = env._lib.frz_wildfire_rollout, env._handle, stream_ptr(device)
+
+        def enqueue_block():
+            for ref in spec_refs:
+                rollout_entry(env_handle, ref, launch_stream)
+            if dist is not None:
+                job_metrics.copy_(metrics)
+    else:
+        block = env.capture_random_rollout(K, policy_seed=policy_seed, include_reset=True, episode_length=EPISODE, seed_stride=seed_stride,
+                                           metrics=metrics, metrics_copy=job_metrics if dist is not None else None)
+        enqueue_block = block.replay
     done_event = torch.cuda.Event()
 
     def run_block():
-        block.replay()
+        enqueue_block()
         if dist is not None:  # the job's one collective; every rank's result needs every rank's contribution: it closes the block
             sharding.reduce_metrics(job_metrics)
         done_event.record()
@@ -325,8 +350,33 @@ def main():
     # ---- kernel-level pass (not part of `value`; always PROBE_EPISODES whole episodes, whatever --steps is): HIP events on the
     # launch stream take each dispatch's own begin and end timestamps (hipExtLaunchKernel start/stop events: what rocprofv3's kernel
     # trace reports, profiles/) + mean task counts per step index over the same episodes for the algorithmic bytes
-    from free_range_zoo_amd import _capi
-    from free_range_zoo_amd.utils.env import stream_ptr
+    # ---- the reference-shaped rollout loop (docs/source/events/moasei-2026/evaluation.md `test()`, baselines/random.py:20): per agent
+    # `env.action_space(agent).sample_nested()`, `env.step(actions)`, `torch.all(env.finished)` once per episode, reset per episode — through
+    # the drop-in API with its defaults (exact_shapes=True).  The samples are handed to step() untouched, so they are drawn inside the step
+    # launch (utils/env.py LazySample): one launch per step; the per-episode reset and the finished test (one host read) are in the time.
+    loop_env = wildfire_v0.parallel_env(configuration=configs.wildfire_openness(), parallel_envs=B, max_steps=EPISODE, device=device, rng=args.rng)
+    loop_seed = base_seed.to(device)
+
+    def reference_loop(episodes):
+        steps = 0
+        for episode in range(episodes):
+            loop_env.reset(seed=loop_seed + seed_stride * episode)
+            while True:
+                for _ in range(EPISODE):
+                    loop_env.step({agent: loop_env.action_space(agent).sample_nested() for agent in loop_env.agents})
+                steps += EPISODE
+                if torch.all(loop_env.finished):
+                    break
+        return steps
+
+    reference_loop(1)
+    barrier()
+    t2 = time.perf_counter()
+    loop_steps = reference_loop(6)
+    barrier()
+    reference_loop_value = world * B * loop_steps / (time.perf_counter() - t2)
+    del loop_env
+
     lib, handle = env._lib, env._handle
     mode = _capi.FRZ_RNG_MT19937 if args.rng == 'mt19937' else _capi.FRZ_RNG_PHILOX
     kernel_ms = []
@@ -461,8 +511,9 @@ def main():
                                    f'policy sampled inside the step launch, rng={args.rng}',
                        'parallel_envs_per_gpu': B, 'agents': A,
                        'sharding': f'env-batch axis x{world}, no step-path collective, one metrics all-reduce per timed block'},
-            'timing': {'protocol': f'{K}-step block = ONE HIP graph ({episodes_per_block} x [reseed, reset, <= {EPISODE} steps, episode metrics]'
-                                   + (' = ONE launch each' if reset_in_launch else '') + '); timed '
+            'timing': {'protocol': (f'{K}-step block = {episodes_per_block} x [reseed, reset, <= {EPISODE} steps, episode metrics] = {episodes_per_block} '
+                                    'launch(es) enqueued through the C-ABI' if one_launch_per_episode else
+                                    f'{K}-step block = ONE HIP graph ({episodes_per_block} x [reseed, reset, <= {EPISODE} steps, episode metrics])') + '; timed '
                                    f'{repeats} times, each bracketed by barrier + synchronize; median block over the max-over-ranks times',
                        'blocks': repeats, 'block_ms_median': 1e3 * median_s, 'block_ms_min': 1e3 * float(block_s.min()),
                        'block_ms_max': 1e3 * float(block_s.max()), 'block_ms_mean': 1e3 * float(block_s.mean()),
@@ -472,6 +523,9 @@ def main():
                                        'env_steps_counted': float(finished_metrics[A].item())}},
             'agent_steps_per_s': value * A,
             'python_api_env_steps_per_s': api_value,
+            'reference_loop_env_steps_per_s': reference_loop_value,
+            'reference_loop': 'per agent env.action_space(agent).sample_nested(), env.step(dict), torch.all(env.finished) once per episode, reset per '
+                              'episode; exact_shapes=True (the default); one step launch per step (samples drawn inside it)',
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'frac_algorithmic': achieved / HBM_PEAK_GBS,
                          'frac_algorithmic_state_read_once': per_env_state_once * B * steps_per_launch / (kernel_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,

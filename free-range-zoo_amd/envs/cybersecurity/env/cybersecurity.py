@@ -9,6 +9,8 @@ from typing import Any, Callable, Dict, List, Optional, Tuple
 
 import torch
 
+from free_range_zoo_amd.utils.spaces import bounds as _space_bounds
+
 from free_range_zoo_amd import _capi
 from free_range_zoo_amd.utils.env import BatchedParallelEnv, jagged, stream_ptr
 from free_range_zoo_amd.utils.spaces import BatchedOneOfSpace
@@ -362,7 +364,7 @@ class raw_env(BatchedParallelEnv):
         from free_range_zoo_amd.envs.cybersecurity.env.spaces import observations
         return observations.build_observation_space(
             agent_type=agent.split('_')[0], num_nodes=self._N, parallel_envs=self.parallel_envs, num_attackers=self._Att, num_defenders=self._D,
-            attacker_high=tuple(int(v) for v in self.config.attacker_observation_bounds),
-            defender_high=tuple(int(v) for v in self.config.defender_observation_bounds),
-            network_high=tuple(int(v) for v in self.config.network_observation_bounds), include_power=self.observe_other_power,
+            attacker_high=_space_bounds(self.config.attacker_observation_bounds),
+            defender_high=_space_bounds(self.config.defender_observation_bounds),
+            network_high=_space_bounds(self.config.network_observation_bounds), include_power=self.observe_other_power,
             include_presence=self.observe_other_presence, include_location=self.observe_other_location)

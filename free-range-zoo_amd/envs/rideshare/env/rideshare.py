@@ -11,6 +11,8 @@ from typing import Any, Callable, Dict, List, Optional
 
 import torch
 
+from free_range_zoo_amd.utils.spaces import bounds as _space_bounds
+
 from free_range_zoo_amd import _capi
 from free_range_zoo_amd.utils.env import BatchedParallelEnv, jagged, stream_ptr
 from free_range_zoo_amd.utils.spaces import BatchedOneOfSpace
@@ -315,5 +317,5 @@ class raw_env(BatchedParallelEnv):
         """Per-env ``Dict{self, others, tasks}`` sized by the tasks the agent sees (rideshare.py:489-504), count-based."""
         from free_range_zoo_amd.envs.rideshare.env.spaces import observations
         return observations.build_observation_space(self.agent_task_count[self.possible_agents.index(agent)], len(self.possible_agents),
-                                                     tuple(int(v) for v in self.agent_observation_bounds),
-                                                     tuple(int(v) if v is not None else 0 for v in self.passenger_observation_bounds))
+                                                     _space_bounds(self.agent_observation_bounds),
+                                                     _space_bounds(self.passenger_observation_bounds))

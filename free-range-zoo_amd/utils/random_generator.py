@@ -19,7 +19,7 @@ from free_range_zoo_amd import _capi
 
 
 def _stream_ptr(device) -> int:
-    return torch.cuda.current_stream(device).cuda_stream
+    return torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch.cuda.current_device())
 
 
 class RandomGenerator:

@@ -37,11 +37,26 @@ class OneOf:
         return f'OneOf({self.spaces})'
 
 
-class Box:
-    """Integer box ``[low, high]`` per dimension (``free_range_rust.Space.Box``)."""
+def _bound(value):
+    """A box bound as the reference's builders hand it to ``free_range_rust.Space.Box``: a plain number — integral values as int, others as
+    float (``max_fire_reduction_power`` may be 1.5) — or None where the configuration leaves it open (``max_steps=None``,
+    ``suppressant_states=None``)."""
+    if value is None:
+        return None
+    value = value.item() if hasattr(value, 'item') else value
+    return int(value) if float(value) == int(value) else float(value)
 
-    def __init__(self, low: Sequence[int], high: Sequence[int]):
-        self.low, self.high = [int(v) for v in low], [int(v) for v in high]
+
+def bounds(values) -> tuple:
+    """Observation bounds as a hashable tuple of plain numbers / None (the builders are lru-cached on them)."""
+    return tuple(_bound(v) for v in values)
+
+
+class Box:
+    """Box ``[low, high]`` per dimension (``free_range_rust.Space.Box``)."""
+
+    def __init__(self, low: Sequence, high: Sequence):
+        self.low, self.high = [_bound(v) for v in low], [_bound(v) for v in high]
         if len(self.low) != len(self.high):
             raise ValueError('low and high must have the same length')
 
@@ -216,13 +231,16 @@ class BatchedOneOfSpace:
             out.append(OneOf(members))
         return out
 
-    @torch.no_grad()
     def sample_nested(self, generator: torch.Generator = None) -> torch.Tensor:
         """Uniform member per env -> int32 ``[B, 2]`` = (member index, member value), on the counts' device.  Spaces handed out by an
-        env sample through its policy kernel (one launch serves every agent of the step); an explicit ``generator`` selects the
-        torch path below."""
+        env sample through its policy kernel (one launch serves every agent of the step; made when a sample is first looked at, or inside
+        the step launch: utils/env.py LazySample); an explicit ``generator`` selects the torch path."""
         if self.sampler is not None and generator is None:
             return self.sampler()
+        return self._sample_with_torch(generator)
+
+    @torch.no_grad()
+    def _sample_with_torch(self, generator: torch.Generator = None) -> torch.Tensor:
         counts = self.task_counts.to(torch.int64)
         device = counts.device
         B = counts.shape[0]

@@ -71,3 +71,51 @@ def compare_wildfire(snap, data, prefix, A, what):
         if prefix + 'burnouts' in data.files:
             assert_same(snap['burnouts'], data[prefix + 'burnouts'], f'{what} burnouts')
             assert_same(snap['putouts'], data[prefix + 'putouts'], f'{what} putouts')
+
+
+# ------------------------------------------------------------------------------------------------------------
+# spaces: the structure free_range_rust's constructors were given (tests/golden/spaces_*.npz, tools/refharness/make_golden.py spaces)
+# ------------------------------------------------------------------------------------------------------------
+def canon_space(space):
+    """Plain-JSON structure of one of free_range_zoo_amd.utils.spaces' objects, in the fixture's vocabulary."""
+    from free_range_zoo_amd.utils import spaces as S
+
+    def number(v):
+        v = v.item() if hasattr(v, 'item') else v
+        if v is None:
+            return None
+        return int(v) if float(v) == int(v) else float(v)
+
+    if isinstance(space, S.Discrete):
+        return {'kind': 'Discrete', 'n': number(space.n), 'start': number(space.start)}
+    if isinstance(space, S.Box):
+        return {'kind': 'Box', 'low': [number(v) for v in space.low], 'high': [number(v) for v in space.high]}
+    if isinstance(space, S.OneOf):
+        return {'kind': 'OneOf', 'spaces': [canon_space(s) for s in space.spaces]}
+    if isinstance(space, S.Tuple):
+        return {'kind': 'Tuple', 'spaces': [canon_space(s) for s in space.spaces]}
+    if isinstance(space, S.Dict):
+        return {'kind': 'Dict', 'spaces': {key: canon_space(value) for key, value in space.spaces.items()}}
+    if isinstance(space, (S.Vector, S.BatchedOneOfSpace)):
+        return {'kind': 'Vector', 'spaces': [canon_space(s) for s in space.spaces]}
+    if isinstance(space, (S.BatchedSpace, list, tuple)):
+        return {'kind': 'list', 'spaces': [canon_space(s) for s in space]}
+    raise TypeError(f'not a space: {type(space)}')
+
+
+def compare_spaces(env, data, table, prefix, what):
+    """env.action_space(agent) / observation_space(agent) of every agent against the reference's at the same point of the trajectory."""
+    for a, agent in enumerate(env.agents):
+        for which, build, container in (('action', env.action_space, str(data['action_container'])),
+                                        ('observation', env.observation_space, str(data['observation_container']))):
+            got = canon_space(build(agent))
+            assert got['kind'] == container, f'{what} {which} space of {agent}: a {got["kind"]}, the reference hands out a {container}'
+            want = [table[i] for i in data[f'{prefix}{which}_{a}']]
+            assert len(got['spaces']) == len(want), f'{what} {which} space of {agent}: {len(got["spaces"])} envs != {len(want)}'
+            for b, (g, w) in enumerate(zip(got['spaces'], want)):
+                assert g == w, f'{what} {which} space of {agent}, env {b}:\n got={json.dumps(g, sort_keys=True)}\nwant={json.dumps(w, sort_keys=True)}'
+
+
+def load_spaces(domain, name):
+    data = np.load(golden_path(f'spaces_{domain}_{name}.npz'))
+    return data, [json.loads(text) for text in json.loads(str(data['table']))]

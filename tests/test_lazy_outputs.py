@@ -71,3 +71,36 @@ def test_observation_space_objects(domain):
             assert isinstance(single['tasks'], Tuple) and len(single['tasks']) == counts[b]
             if len(single['others']) and obs['others'].shape[-1]:
                 assert len(single['others'][0]) == obs['others'].shape[-1]
+
+
+def test_reference_shaped_random_rollout_draws_inside_the_step_launch():
+    """The reference's loop (docs/source/events/moasei-2026/evaluation.md test(): per agent `env.action_space(agent).sample_nested()`, then
+    `env.step(actions)`): the samples are LazySample tensors; handed to step() untouched they are drawn inside the step launch — one launch
+    per step — with exactly the values the policy launch produces when a sample is looked at first, and they stay readable afterwards."""
+    from free_range_zoo_amd.envs import wildfire_v0
+    from free_range_zoo_amd.utils.env import LazySample
+    B = 3001
+    fused, looked, plain = [wildfire_v0.parallel_env(configuration=configs.wildfire_openness(), parallel_envs=B, max_steps=30, device=torch.device('cuda'),
+                                                     rng='philox') for _ in range(3)]
+    for env in (fused, looked, plain):
+        env.reset(seed=torch.arange(B, dtype=torch.int32) + 5)
+    for t in range(34):  # past the horizon: the last steps are frozen
+        a = {agent: fused.action_space(agent).sample_nested() for agent in fused.agents}
+        assert all(type(v) is LazySample for v in a.values()) and fused._pending_samples[3] is False
+        live = not bool(fused.finished.all())
+        fused.step(a)
+        assert fused._pending_samples[3] is True
+        b = {agent: looked.action_space(agent).sample_nested() for agent in looked.agents}
+        first = b[looked.agents[0]].clone()  # looking at a sample launches the policy kernel for the whole draw
+        assert type(first) is torch.Tensor and looked._pending_samples[3] is True
+        looked.step(b)
+        acts = plain.random_policy_actions(plain.policy_seed, t).clone()
+        plain.step(acts)
+        if live:
+            for i, agent in enumerate(fused.agents):
+                assert torch.equal(a[agent].as_subclass(torch.Tensor), acts[i]), f'step {t}: samples drawn inside the step launch, {agent}'
+                assert torch.equal(b[agent].as_subclass(torch.Tensor), acts[i]), f'step {t}: samples drawn by the policy launch, {agent}'
+        for name in ('_fires', '_intensity', '_fuel', '_suppressants', '_rewards', '_task_offsets', '_act_map_offsets'):
+            assert torch.equal(getattr(fused, name), getattr(plain, name)) and torch.equal(getattr(looked, name), getattr(plain, name)), f'{name} at step {t}'
+    assert bool(fused.finished.all())
+    fused.check()

@@ -11,6 +11,9 @@ Parts:
   partial   reference runs of reset_batches(batch_indices, seed) in the middle of an episode and of
             reset(options={'initial_state': ...}) (wildfire, cybersecurity), with the steps that follow.
   rng       the reference's RandomGenerator: buffered (buffer_size > 0, keyed) and single_seeding draws.
+  spaces    the objects raw_env.action_space(agent) / observation_space(agent) of the reference hand out at the reset and after every
+            step of the recorded trajectories (the same runs, replayed from the same seeds), as structure: kind, n, start, low, high,
+            members — what the reference's builders (envs/*/env/spaces/*.py) pass to free_range_rust's constructors.
 
 Fixtures hold DATA only (inputs / expected outputs / the plain-C configuration fields), never reference source.
 """
@@ -1098,7 +1101,109 @@ def record_rng():
     np.savez_compressed(os.path.join(GOLDEN, 'rng_modes.npz'), **out)
     print('rng_modes.npz written')
 
-PARTS = {'partial': record_partial_resets, 'rng': record_rng, 'ka': record_known_answers, 'baselines_wildfire': record_wildfire_baselines, 'baselines_rideshare': record_rideshare_baselines, 'baselines_cybersecurity': record_cyber_baselines, 'logs': record_logs, 'logs_sql': record_sql_logs, 'pickles': record_pickles, 'traj_wildfire': record_wildfire_trajectories, 'traj_cybersecurity': record_cyber_trajectories,
+# ----------------------------------------------------------------------------------------------------------
+# action / observation spaces along the recorded trajectories
+# ----------------------------------------------------------------------------------------------------------
+def _canon_space(space):
+    """Structure of a space as the reference's builders construct it (the stand-in for free_range_rust.Space in shim.py keeps the
+    constructor name and arguments): plain JSON."""
+    def number(v):
+        v = v.item() if hasattr(v, 'item') else v
+        if v is None:  # (a bound the configuration leaves open, e.g. AgentConfiguration.suppressant_states)
+            return None
+        return int(v) if float(v) == int(v) else float(v)
+
+    if isinstance(space, (list, tuple)):
+        return {'kind': 'list', 'spaces': [_canon_space(s) for s in space]}
+    kind, args, kwargs = space.kind, space.args, space.kwargs
+    if kind == 'Discrete':
+        return {'kind': 'Discrete', 'n': number(args[0]), 'start': number(kwargs.get('start', args[1] if len(args) > 1 else 0))}
+    if kind == 'Box':
+        low = kwargs['low'] if 'low' in kwargs else args[0]
+        high = kwargs['high'] if 'high' in kwargs else args[1]
+        return {'kind': 'Box', 'low': [number(v) for v in low], 'high': [number(v) for v in high]}
+    if kind in ('OneOf', 'Tuple', 'Vector'):
+        return {'kind': kind, 'spaces': [_canon_space(s) for s in args[0]]}
+    if kind == 'Dict':
+        return {'kind': 'Dict', 'spaces': {key: _canon_space(value) for key, value in args[0].items()}}
+    raise ValueError(f'unknown space constructor {kind}')
+
+
+class _SpaceTable:
+    """Per-env spaces deduplicated: `table` holds each distinct structure once (JSON text), the per-step arrays index into it."""
+
+    def __init__(self):
+        self.table, self.index = [], {}
+
+    def ids(self, batch):
+        """batch: a Vector / list of per-env spaces -> (container kind, int32 [B] table indices)."""
+        canon = _canon_space(batch)
+        out = []
+        for entry in canon['spaces']:
+            text = json.dumps(entry, sort_keys=True)
+            if text not in self.index:
+                self.index[text] = len(self.table)
+                self.table.append(text)
+            out.append(self.index[text])
+        return canon['kind'], np.asarray(out, np.int32)
+
+
+def _record_spaces_of(env, table, out, prefix):
+    aec = env.aec_env
+    for a, agent in enumerate(aec.agents):
+        kind, ids = table.ids(aec.action_space(agent))
+        out[f'{prefix}action_{a}'] = ids
+        out.setdefault('action_container', np.asarray(kind))
+        assert str(out['action_container']) == kind
+        kind, ids = table.ids(aec.observation_space(agent))
+        out[f'{prefix}observation_{a}'] = ids
+        out.setdefault('observation_container', np.asarray(kind))
+        assert str(out['observation_container']) == kind
+
+
+def record_spaces():
+    """Replays the trajectory runs (same variants, seeds, policies and injected randomness as the traj_* parts: the recorded task counts
+    are asserted to agree step by step) and records every agent's action / observation space at the reset and after each step."""
+    from free_range_zoo.envs import cybersecurity_v0, rideshare_v0, wildfire_v0
+
+    def run(domain, name, env, steps, policy, rng, count_of):
+        reference = np.load(os.path.join(GOLDEN, f'traj_{domain}_{name}.npz'))
+        table, out = _SpaceTable(), {'steps': np.asarray(steps)}
+        _record_spaces_of(env, table, out, 'r_')
+        agents = list(env.aec_env.agents)
+        for t in range(steps):
+            actions = policy(env.aec_env, rng)
+            assert np.array_equal(actions, reference[f's{t}_actions']), f'{domain} {name}: the replay left the recorded trajectory at step {t}'
+            env.step({agent: torch.from_numpy(actions[a]) for a, agent in enumerate(agents)})
+            assert np.array_equal(_np(count_of(env.aec_env)), reference[f's{t}_env_task_count']), (domain, name, t)
+            _record_spaces_of(env, table, out, f's{t}_')
+        out['table'] = np.asarray(json.dumps(table.table))
+        path = os.path.join(GOLDEN, f'spaces_{domain}_{name}.npz')
+        np.savez_compressed(path, **out)
+        print(f'{path}: {len(table.table)} distinct per-env spaces over {steps + 1} snapshots')
+
+    for name, configuration, kwargs, B, max_steps, steps, seed in wildfire_variants():
+        flags = dict(show_bad_actions=False, observe_other_power=False, observe_other_suppressant=False)
+        flags.update(kwargs)
+        env = wildfire_v0.parallel_env(parallel_envs=B, max_steps=max_steps, configuration=configuration, device=torch.device('cpu'), **flags)
+        env.reset(seed=torch.arange(B, dtype=torch.int32))
+        env.aec_env.generator.generate = InjectedRandomness(seed)
+        run('wildfire', name, env, steps, wildfire_policy, np.random.default_rng(seed), lambda aec: aec.environment_task_count)
+    for name, configuration, kwargs, B, max_steps, steps, seed in cyber_variants():
+        flags = dict(observe_other_location=False, observe_other_presence=False, observe_other_power=True, partially_observable=True,
+                     show_bad_actions=True)
+        flags.update(kwargs)
+        env = cybersecurity_v0.parallel_env(parallel_envs=B, max_steps=max_steps, configuration=configuration, device=torch.device('cpu'), **flags)
+        env.reset(seed=torch.arange(B, dtype=torch.int32))
+        env.aec_env.generator.generate = InjectedRandomness(seed)
+        run('cybersecurity', name, env, steps, cyber_policy, np.random.default_rng(seed), lambda aec: aec.environment_task_count)
+    for name, configuration, B, max_steps, steps, seed in rideshare_variants():
+        env = rideshare_v0.parallel_env(parallel_envs=B, max_steps=max_steps, configuration=configuration, device=torch.device('cpu'))
+        env.reset(seed=torch.arange(B, dtype=torch.int32))
+        run('rideshare', name, env, steps, rideshare_policy, np.random.default_rng(seed), lambda aec: aec.environment_task_count)
+
+
+PARTS = {'spaces': record_spaces, 'partial': record_partial_resets, 'rng': record_rng, 'ka': record_known_answers, 'baselines_wildfire': record_wildfire_baselines, 'baselines_rideshare': record_rideshare_baselines, 'baselines_cybersecurity': record_cyber_baselines, 'logs': record_logs, 'logs_sql': record_sql_logs, 'pickles': record_pickles, 'traj_wildfire': record_wildfire_trajectories, 'traj_cybersecurity': record_cyber_trajectories,
          'traj_rideshare': record_rideshare_trajectories,
          'misc': record_misc}
 
