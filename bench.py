@@ -254,7 +254,7 @@ def main():
     A, HW = len(env.agents), env.max_y * env.max_x
     # one process per GPU and one stream: the device is this env's alone, which is what a multi-step launch needs (its workgroups wait
     # for each other inside the kernel).  Not so in the shared-device rehearsal, where two ranks run on one GPU.
-    env.set_exclusive_device(not rehearsal)
+    exclusive = env.set_exclusive_device(not rehearsal)  # False: refused by the library's own residency check, or the rehearsal
     base_seed = sharding.shard_seeds(rank, B)  # seed = global env index = rank * B + i
     metrics = torch.zeros(A + 2, dtype=torch.float64, device=device)  # (sum reward per agent, env-steps, finished)
     job_metrics = torch.zeros_like(metrics)                           # what the collective reduces (copied at the end of the graph)
@@ -321,6 +321,20 @@ def main():
     block_t = torch.tensor(block_s, dtype=torch.float64, device=device)
     if dist is not None:
         dist.all_reduce(block_t, op=dist.ReduceOp.MAX)  # MAX over ranks, block by block
+    # what the N > 1 record is checked with: the ranks RCCL saw, the devices behind them, every rank's own median block
+    distributed = None
+    if dist is not None:
+        try:
+            uuid = str(torch.cuda.get_device_properties(device).uuid)
+        except Exception:  # noqa: BLE001
+            uuid = f'cuda:{device_index}'
+        seen = [None] * world
+        dist.all_gather_object(seen, {'rank': rank, 'local_rank': local_rank, 'device': device_index, 'uuid': uuid, 'host': os.uname().nodename,
+                                      'block_ms_median': 1e3 * float(np.median(block_s))})
+        probe = torch.ones(1, dtype=torch.float64, device=device)
+        dist.all_reduce(probe)  # one more collective on the job's backend: the number of ranks it really reduces over
+        distributed = {'world_size': dist.get_world_size(), 'backend': dist.get_backend(), 'ranks_in_all_reduce': int(probe.item()),
+                       'distinct_devices': len({(r['host'], r['uuid']) for r in seen}), 'ranks': seen}
     block_s = block_t.cpu().numpy()
     median_s = float(np.median(block_s))
     value = world * B * K / median_s
@@ -507,6 +521,7 @@ def main():
             'vs_baseline': None,
             'dtype': 'i32/f32',
             'data': 'synthetic',
+            'multi_step_launches': bool(exclusive),
             'config': {'workload': f'wildfire_v0 cfg2 (2x3 grid, 3 agents, agent+task openness on), batch={B} per GPU, max_steps={EPISODE}, uniform random '
                                    f'policy sampled inside the step launch, rng={args.rng}',
                        'parallel_envs_per_gpu': B, 'agents': A,
@@ -521,6 +536,7 @@ def main():
                        'launches_per_block': ((1 if reset_in_launch else 2) * episodes_per_block) if multi_step else None,
                        'job_metrics': {'mean_episode_return_per_agent': (finished_metrics[:A] / max(world * B * episodes_per_block * repeats, 1)).tolist(),
                                        'env_steps_counted': float(finished_metrics[A].item())}},
+            'distributed': distributed,
             'agent_steps_per_s': value * A,
             'python_api_env_steps_per_s': api_value,
             'reference_loop_env_steps_per_s': reference_loop_value,

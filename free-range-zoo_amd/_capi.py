@@ -31,6 +31,8 @@ _lib = None
 _P = ctypes.c_void_p
 SIGNATURES = {
     'frz_abi_version': (ctypes.c_int, []),
+    'frz_handle_kind': (ctypes.c_int, [_P]),
+    'frz_handle_shape': (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     'frz_wildfire_create': (ctypes.c_int, [_P, ctypes.POINTER(_P)]),
     'frz_wildfire_destroy': (None, [_P]),
     'frz_wildfire_arena_bytes': (ctypes.c_int64, [_P]),
@@ -55,6 +57,9 @@ SIGNATURES = {
     'frz_wildfire_timed_rollout': (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int32, _P, ctypes.c_int, _P,
                                                  ctypes.POINTER(ctypes.c_float)]),
     'frz_wildfire_set_exclusive_device': (ctypes.c_int, [_P, ctypes.c_int]),
+    'frz_exclusive_launch_fits': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    'frz_wildfire_export_totals': (ctypes.c_int, [_P, _P, _P]),
+    'frz_wildfire_import_totals': (ctypes.c_int, [_P, _P, _P]),
     'frz_wildfire_rollout_launches': (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int]),
     'frz_wildfire_timed_rollout_launch': (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int32, _P, ctypes.c_int, _P,
                                                         ctypes.POINTER(ctypes.c_float)]),

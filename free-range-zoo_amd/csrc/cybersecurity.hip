@@ -1330,11 +1330,15 @@ int frz_cybersecurity_create(const frz_cybersecurity_cfg* cfg, frz_cybersecurity
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     }
     env->ticketed = p.nchunks > cus;  // one workgroup per chunk; one 256-thread workgroup per CU is always resident
+    frz::handle_register(env, 2, A, cfg->parallel_envs, N);
     *out = env;
     return FRZ_OK;
 }
 
-void frz_cybersecurity_destroy(frz_cybersecurity_env* env) { delete env; }
+void frz_cybersecurity_destroy(frz_cybersecurity_env* env) {
+    if (env) frz::handle_unregister(env);
+    delete env;
+}
 
 int64_t frz_cybersecurity_arena_bytes(const frz_cybersecurity_env* env) { return env ? env->dev.total_bytes : FRZ_E_INVALID; }
 

@@ -154,4 +154,10 @@ struct RowRef<const T> {
 int mt19937_generate_pair_gated(uint32_t* mt_state, int32_t* mt_index, float* out, int64_t events, int64_t count, float* out2, int64_t events2,
                                 int64_t count2, int64_t B, const uint32_t* epoch, const uint32_t* totals, int channel, int stride, void* stream);
 
+
+// handles.hip: the registry behind frz_handle_kind / frz_handle_shape (kind 1 wildfire, 2 cybersecurity, 3 rideshare; units = cells / nodes /
+// passenger slots per env)
+void handle_register(const void* handle, int kind, int64_t agents, int64_t envs, int64_t units);
+void handle_unregister(const void* handle);
+
 }  // namespace frz

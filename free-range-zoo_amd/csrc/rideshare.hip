@@ -930,12 +930,14 @@ int frz_rideshare_create(const frz_rideshare_cfg* cfg, const int32_t* schedule, 
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     }
     env->ticketed = p.nchunks > cus;  // one workgroup per chunk; one 256-thread workgroup per CU is always resident
+    frz::handle_register(env, 3, A, cfg->parallel_envs, P);
     *out = env;
     return FRZ_OK;
 }
 
 void frz_rideshare_destroy(frz_rideshare_env* env) {
     if (!env) return;
+    frz::handle_unregister(env);
     for (hipEvent_t e : env->timing_events) (void)hipEventDestroy(e);
     delete env;
 }

@@ -8,6 +8,7 @@
 //   * raises (TORCH_CHECK) on shape / dtype / device mismatches and on negative FRZ_E_* codes.
 // No kernel lives here; the ctypes binding (free-range-zoo_amd/_capi.py) remains the torch-free path to the same entry points.
 #include <ATen/core/Tensor.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
@@ -26,9 +27,46 @@ void inside(const at::Tensor& arena, const void* p, const char* what) {
     const char* lo = static_cast<const char*>(arena.data_ptr());
     TORCH_CHECK(static_cast<const char*>(p) >= lo && static_cast<const char*>(p) < lo + arena.numel(), what, ": the handle is not bound to this arena");
 }
-const int32_t* actions_ptr(const at::Tensor& arena, const at::Tensor& actions, int64_t agents, int64_t envs) {
+// Every op starts here: `handle` is a live handle of the expected domain (the library keeps a registry: a stale or foreign integer is
+// refused, not dereferenced), it is bound to THIS arena, and the sizes the op works with are the handle's own — the agents / envs / units
+// arguments of the schemas are checked against them, never trusted.  The guard makes the arena's device current for the launch.
+struct Env {
+    void* handle;
+    int64_t A, B, U;  // agents, envs, units (cells / nodes / passenger slots per env)
+    c10::hip::HIPGuardMasqueradingAsCUDA guard;
+};
+enum Kind { kWildfire = 1, kCybersecurity = 2, kRideshare = 3 };
+Env checked(const at::Tensor& arena, int64_t handle, int kind, const char* what) {
+    check_arena(arena);
+    void* h = reinterpret_cast<void*>(handle);
+    TORCH_CHECK(frz_handle_kind(h) == kind, what, ": not a live ", (kind == kWildfire ? "wildfire" : (kind == kCybersecurity ? "cybersecurity" : "rideshare")),
+                " env handle of this library");
+    int64_t A = 0, B = 0, U = 0;
+    ok(frz_handle_shape(h, &A, &B, &U), "frz_handle_shape");
+    const void* bound = nullptr;
+    if (kind == kWildfire) {
+        frz_wildfire_bufs bufs;
+        ok(frz_wildfire_get_bufs(static_cast<frz_wildfire_env*>(h), &bufs), "frz_wildfire_get_bufs");
+        bound = bufs.error_flags;
+    } else if (kind == kCybersecurity) {
+        frz_cybersecurity_bufs bufs;
+        ok(frz_cybersecurity_get_bufs(static_cast<frz_cybersecurity_env*>(h), &bufs), "frz_cybersecurity_get_bufs");
+        bound = bufs.error_flags;
+    } else {
+        frz_rideshare_bufs bufs;
+        ok(frz_rideshare_get_bufs(static_cast<frz_rideshare_env*>(h), &bufs), "frz_rideshare_get_bufs");
+        bound = bufs.error_flags;
+    }
+    inside(arena, bound, what);
+    return Env{h, A, B, U, c10::hip::HIPGuardMasqueradingAsCUDA(arena.device())};
+}
+void same_sizes(const Env& e, int64_t agents, int64_t envs, int64_t units, const char* what) {
+    TORCH_CHECK(agents == e.A && envs == e.B && (units < 0 || units == e.U), what, ": sizes (", agents, ", ", envs, ", ", units, ") are not the handle's (", e.A,
+                ", ", e.B, ", ", e.U, ")");
+}
+const int32_t* actions_ptr(const at::Tensor& arena, const at::Tensor& actions, const Env& e) {
     TORCH_CHECK(actions.is_cuda() && actions.device() == arena.device() && actions.scalar_type() == at::kInt && actions.is_contiguous() &&
-                    actions.numel() == agents * envs * 2,
+                    actions.numel() == e.A * e.B * 2,
                 "actions must be a contiguous int32 [A, B, 2] tensor on the env's device");
     return actions.data_ptr<int32_t>();
 }
@@ -40,112 +78,108 @@ const float* floats_or_null(const at::Tensor& arena, const c10::optional<at::Ten
 }
 
 // ---------------------------------------------------------------------------------------------------- wildfire
-struct Wf {
-    frz_wildfire_env* env;
-    frz_wildfire_bufs bufs;
-    int64_t A, B, HW;
-};
-Wf wildfire(const at::Tensor& arena, int64_t handle, int64_t agents, int64_t envs, int64_t cells) {
-    check_arena(arena);
-    Wf w{reinterpret_cast<frz_wildfire_env*>(handle), {}, agents, envs, cells};
-    ok(frz_wildfire_get_bufs(w.env, &w.bufs), "frz_wildfire_get_bufs");
-    inside(arena, w.bufs.error_flags, "wildfire");
-    return w;
-}
 void wildfire_reset(at::Tensor arena, int64_t handle) {
-    check_arena(arena);
-    ok(frz_wildfire_reset(reinterpret_cast<frz_wildfire_env*>(handle), current_stream(arena)), "frz_wildfire_reset");
+    const Env e = checked(arena, handle, kWildfire, "wildfire_reset");
+    ok(frz_wildfire_reset(static_cast<frz_wildfire_env*>(e.handle), current_stream(arena)), "frz_wildfire_reset");
 }
 void wildfire_reset_reseed(at::Tensor arena, int64_t handle, int64_t seed_increment) {
-    check_arena(arena);
-    ok(frz_wildfire_reset_reseed(reinterpret_cast<frz_wildfire_env*>(handle), (int32_t)seed_increment, current_stream(arena)), "frz_wildfire_reset_reseed");
+    const Env e = checked(arena, handle, kWildfire, "wildfire_reset_reseed");
+    ok(frz_wildfire_reset_reseed(static_cast<frz_wildfire_env*>(e.handle), (int32_t)seed_increment, current_stream(arena)), "frz_wildfire_reset_reseed");
 }
 void wildfire_rebuild(at::Tensor arena, int64_t handle) {
-    check_arena(arena);
-    ok(frz_wildfire_rebuild(reinterpret_cast<frz_wildfire_env*>(handle), current_stream(arena)), "frz_wildfire_rebuild");
+    const Env e = checked(arena, handle, kWildfire, "wildfire_rebuild");
+    ok(frz_wildfire_rebuild(static_cast<frz_wildfire_env*>(e.handle), current_stream(arena)), "frz_wildfire_rebuild");
 }
 void wildfire_step(at::Tensor arena, int64_t handle, const at::Tensor& actions, int64_t rng_mode, const c10::optional<at::Tensor>& field_randomness,
                    const c10::optional<at::Tensor>& agent_randomness, int64_t agents, int64_t envs, int64_t cells) {
-    const Wf w = wildfire(arena, handle, agents, envs, cells);
-    ok(frz_wildfire_step(w.env, actions_ptr(arena, actions, agents, envs), (int)rng_mode,
-                         floats_or_null(arena, field_randomness, 3 * envs * cells, "field_randomness"),
-                         floats_or_null(arena, agent_randomness, 5 * envs * agents, "agent_randomness"), current_stream(arena)),
+    const Env e = checked(arena, handle, kWildfire, "wildfire_step");
+    same_sizes(e, agents, envs, cells, "wildfire_step");
+    ok(frz_wildfire_step(static_cast<frz_wildfire_env*>(e.handle), actions_ptr(arena, actions, e), (int)rng_mode,
+                         floats_or_null(arena, field_randomness, 3 * e.B * e.U, "field_randomness"),
+                         floats_or_null(arena, agent_randomness, 5 * e.B * e.A, "agent_randomness"), current_stream(arena)),
        "frz_wildfire_step");
 }
 void wildfire_random_policy(const at::Tensor& arena, int64_t handle, int64_t policy_seed, int64_t policy_step, at::Tensor actions_out, int64_t agents,
                             int64_t envs) {
-    check_arena(arena);
-    ok(frz_wildfire_random_policy(reinterpret_cast<frz_wildfire_env*>(handle), (uint64_t)policy_seed, (uint64_t)policy_step,
-                                  const_cast<int32_t*>(actions_ptr(arena, actions_out, agents, envs)), current_stream(arena)),
+    const Env e = checked(arena, handle, kWildfire, "wildfire_random_policy");
+    same_sizes(e, agents, envs, -1, "wildfire_random_policy");
+    ok(frz_wildfire_random_policy(static_cast<frz_wildfire_env*>(e.handle), (uint64_t)policy_seed, (uint64_t)policy_step,
+                                  const_cast<int32_t*>(actions_ptr(arena, actions_out, e)), current_stream(arena)),
        "frz_wildfire_random_policy");
 }
 void wildfire_step_random_policy(at::Tensor arena, int64_t handle, int64_t policy_seed, int64_t policy_step, at::Tensor actions_out, int64_t rng_mode,
                                  int64_t agents, int64_t envs) {
-    check_arena(arena);
-    ok(frz_wildfire_step_random_policy(reinterpret_cast<frz_wildfire_env*>(handle), (uint64_t)policy_seed, (uint64_t)policy_step,
-                                       const_cast<int32_t*>(actions_ptr(arena, actions_out, agents, envs)), (int)rng_mode, nullptr, nullptr,
-                                       current_stream(arena)),
+    const Env e = checked(arena, handle, kWildfire, "wildfire_step_random_policy");
+    same_sizes(e, agents, envs, -1, "wildfire_step_random_policy");
+    ok(frz_wildfire_step_random_policy(static_cast<frz_wildfire_env*>(e.handle), (uint64_t)policy_seed, (uint64_t)policy_step,
+                                       const_cast<int32_t*>(actions_ptr(arena, actions_out, e)), (int)rng_mode, nullptr, nullptr, current_stream(arena)),
        "frz_wildfire_step_random_policy");
 }
 
 // ---------------------------------------------------------------------------------------------------- cybersecurity
 void cybersecurity_reset(at::Tensor arena, int64_t handle) {
-    check_arena(arena);
-    ok(frz_cybersecurity_reset(reinterpret_cast<frz_cybersecurity_env*>(handle), current_stream(arena)), "frz_cybersecurity_reset");
+    const Env e = checked(arena, handle, kCybersecurity, "cybersecurity_reset");
+    ok(frz_cybersecurity_reset(static_cast<frz_cybersecurity_env*>(e.handle), current_stream(arena)), "frz_cybersecurity_reset");
 }
 void cybersecurity_rebuild(at::Tensor arena, int64_t handle) {
-    check_arena(arena);
-    ok(frz_cybersecurity_rebuild(reinterpret_cast<frz_cybersecurity_env*>(handle), current_stream(arena)), "frz_cybersecurity_rebuild");
+    const Env e = checked(arena, handle, kCybersecurity, "cybersecurity_rebuild");
+    ok(frz_cybersecurity_rebuild(static_cast<frz_cybersecurity_env*>(e.handle), current_stream(arena)), "frz_cybersecurity_rebuild");
 }
 void cybersecurity_step(at::Tensor arena, int64_t handle, const at::Tensor& actions, int64_t rng_mode, const c10::optional<at::Tensor>& network_randomness,
                         const c10::optional<at::Tensor>& agent_randomness, int64_t agents, int64_t envs, int64_t nodes) {
-    check_arena(arena);
-    ok(frz_cybersecurity_step(reinterpret_cast<frz_cybersecurity_env*>(handle), actions_ptr(arena, actions, agents, envs), (int)rng_mode,
-                              floats_or_null(arena, network_randomness, envs * nodes, "network_randomness"),
-                              floats_or_null(arena, agent_randomness, envs * agents, "agent_randomness"), current_stream(arena)),
+    const Env e = checked(arena, handle, kCybersecurity, "cybersecurity_step");
+    same_sizes(e, agents, envs, nodes, "cybersecurity_step");
+    ok(frz_cybersecurity_step(static_cast<frz_cybersecurity_env*>(e.handle), actions_ptr(arena, actions, e), (int)rng_mode,
+                              floats_or_null(arena, network_randomness, e.B * e.U, "network_randomness"),
+                              floats_or_null(arena, agent_randomness, e.B * e.A, "agent_randomness"), current_stream(arena)),
        "frz_cybersecurity_step");
 }
 void cybersecurity_random_policy(const at::Tensor& arena, int64_t handle, int64_t policy_seed, int64_t policy_step, at::Tensor actions_out, int64_t agents,
                                  int64_t envs) {
-    check_arena(arena);
-    ok(frz_cybersecurity_random_policy(reinterpret_cast<frz_cybersecurity_env*>(handle), (uint64_t)policy_seed, (uint64_t)policy_step,
-                                       const_cast<int32_t*>(actions_ptr(arena, actions_out, agents, envs)), current_stream(arena)),
+    const Env e = checked(arena, handle, kCybersecurity, "cybersecurity_random_policy");
+    same_sizes(e, agents, envs, -1, "cybersecurity_random_policy");
+    ok(frz_cybersecurity_random_policy(static_cast<frz_cybersecurity_env*>(e.handle), (uint64_t)policy_seed, (uint64_t)policy_step,
+                                       const_cast<int32_t*>(actions_ptr(arena, actions_out, e)), current_stream(arena)),
        "frz_cybersecurity_random_policy");
 }
 void cybersecurity_step_random_policy(at::Tensor arena, int64_t handle, int64_t policy_seed, int64_t policy_step, at::Tensor actions_out, int64_t rng_mode,
                                       int64_t agents, int64_t envs) {
-    check_arena(arena);
-    ok(frz_cybersecurity_step_random_policy(reinterpret_cast<frz_cybersecurity_env*>(handle), (uint64_t)policy_seed, (uint64_t)policy_step,
-                                            const_cast<int32_t*>(actions_ptr(arena, actions_out, agents, envs)), (int)rng_mode, nullptr, nullptr,
+    const Env e = checked(arena, handle, kCybersecurity, "cybersecurity_step_random_policy");
+    same_sizes(e, agents, envs, -1, "cybersecurity_step_random_policy");
+    ok(frz_cybersecurity_step_random_policy(static_cast<frz_cybersecurity_env*>(e.handle), (uint64_t)policy_seed, (uint64_t)policy_step,
+                                            const_cast<int32_t*>(actions_ptr(arena, actions_out, e)), (int)rng_mode, nullptr, nullptr,
                                             current_stream(arena)),
        "frz_cybersecurity_step_random_policy");
 }
 
 // ---------------------------------------------------------------------------------------------------- rideshare
 void rideshare_reset(at::Tensor arena, int64_t handle) {
-    check_arena(arena);
-    ok(frz_rideshare_reset(reinterpret_cast<frz_rideshare_env*>(handle), current_stream(arena)), "frz_rideshare_reset");
+    const Env e = checked(arena, handle, kRideshare, "rideshare_reset");
+    ok(frz_rideshare_reset(static_cast<frz_rideshare_env*>(e.handle), current_stream(arena)), "frz_rideshare_reset");
 }
 void rideshare_rebuild(at::Tensor arena, int64_t handle) {
-    check_arena(arena);
-    ok(frz_rideshare_rebuild(reinterpret_cast<frz_rideshare_env*>(handle), current_stream(arena)), "frz_rideshare_rebuild");
+    const Env e = checked(arena, handle, kRideshare, "rideshare_rebuild");
+    ok(frz_rideshare_rebuild(static_cast<frz_rideshare_env*>(e.handle), current_stream(arena)), "frz_rideshare_rebuild");
 }
 void rideshare_step(at::Tensor arena, int64_t handle, const at::Tensor& actions, int64_t agents, int64_t envs) {
-    check_arena(arena);
-    ok(frz_rideshare_step(reinterpret_cast<frz_rideshare_env*>(handle), actions_ptr(arena, actions, agents, envs), current_stream(arena)), "frz_rideshare_step");
+    const Env e = checked(arena, handle, kRideshare, "rideshare_step");
+    same_sizes(e, agents, envs, -1, "rideshare_step");
+    ok(frz_rideshare_step(static_cast<frz_rideshare_env*>(e.handle), actions_ptr(arena, actions, e), current_stream(arena)), "frz_rideshare_step");
 }
 void rideshare_random_policy(const at::Tensor& arena, int64_t handle, int64_t policy_seed, int64_t policy_step, at::Tensor actions_out, int64_t agents,
                              int64_t envs) {
-    check_arena(arena);
-    ok(frz_rideshare_random_policy(reinterpret_cast<frz_rideshare_env*>(handle), (uint64_t)policy_seed, (uint64_t)policy_step,
-                                   const_cast<int32_t*>(actions_ptr(arena, actions_out, agents, envs)), current_stream(arena)),
+    const Env e = checked(arena, handle, kRideshare, "rideshare_random_policy");
+    same_sizes(e, agents, envs, -1, "rideshare_random_policy");
+    ok(frz_rideshare_random_policy(static_cast<frz_rideshare_env*>(e.handle), (uint64_t)policy_seed, (uint64_t)policy_step,
+                                   const_cast<int32_t*>(actions_ptr(arena, actions_out, e)), current_stream(arena)),
        "frz_rideshare_random_policy");
 }
 void rideshare_step_random_policy(at::Tensor arena, int64_t handle, int64_t policy_seed, int64_t policy_step, at::Tensor actions_out, int64_t agents,
                                   int64_t envs) {
-    check_arena(arena);
-    ok(frz_rideshare_step_random_policy(reinterpret_cast<frz_rideshare_env*>(handle), (uint64_t)policy_seed, (uint64_t)policy_step,
-                                        const_cast<int32_t*>(actions_ptr(arena, actions_out, agents, envs)), current_stream(arena)),
+    const Env e = checked(arena, handle, kRideshare, "rideshare_step_random_policy");
+    same_sizes(e, agents, envs, -1, "rideshare_step_random_policy");
+    ok(frz_rideshare_step_random_policy(static_cast<frz_rideshare_env*>(e.handle), (uint64_t)policy_seed, (uint64_t)policy_step,
+                                        const_cast<int32_t*>(actions_ptr(arena, actions_out, e)), current_stream(arena)),
        "frz_rideshare_step_random_policy");
 }
 

@@ -38,7 +38,8 @@ __global__ void __launch_bounds__(kBlock) wf_fill_kernel(char* arena, int32_t se
     const int64_t B = d.B;
     if (b >= B) return;
     int32_t* rows = reinterpret_cast<int32_t*>(arena + d.off_rows4);
-    if (seed_increment != 0) rows[d.r_seeds * B + b] += seed_increment;  // frz_wildfire_reset_reseed: fresh env seeds per episode
+    // frz_wildfire_reset_reseed: fresh env seeds per episode — modulo 2^32 (a graph replayed for days wraps around; signed overflow would be UB)
+    if (seed_increment != 0) reinterpret_cast<uint32_t*>(rows)[d.r_seeds * B + b] += (uint32_t)seed_increment;
     float* rowsf = reinterpret_cast<float*>(arena + d.off_rows4);
     int64_t* rows8 = reinterpret_cast<int64_t*>(arena + d.off_rows8);
     uint8_t* rows1 = reinterpret_cast<uint8_t*>(arena + d.off_rows1);
@@ -895,6 +896,31 @@ __global__ void __launch_bounds__(kBlock) wf_policy_kernel(const char* arena, ui
 // stores before the workgroup's barrier, one lane then takes the ticket (MI355X_MICROARCH.md, inter-workgroup visibility).
 constexpr int kMetricBlocks = 256;
 
+// frz_wildfire_export_totals / import_totals: the batch totals the last executed step left (channel 0: lit fires, 1 + a: fires agent a can
+// attack, A + 1 / A + 2: envs not terminated / not truncated) — what the next step's batch-global tests read (utils/env.py:211-213,
+// wildfire.py:434-435) — copied out of / into the slot the current epoch selects.  One wavefront.
+__global__ void __launch_bounds__(64) wf_totals_kernel(char* arena, int32_t* staging, int import) {
+    const WfDev& d = *reinterpret_cast<const WfDev*>(arena);
+    uint32_t* const epoch_block = reinterpret_cast<uint32_t*>(arena + d.off_epoch);  // [0] epoch, [1] epoch of the last export, [2 ..] the shard's own totals then
+    const uint32_t epoch = epoch_block[0];
+    uint32_t* const slot = reinterpret_cast<uint32_t*>(arena + d.off_totals) + ((epoch + 1u) & 1u) * kTotalsStride;  // written under epoch - 1
+    const int i = threadIdx.x;
+    if (i >= d.nch) return;
+    if (import) {
+        slot[i] = (uint32_t)staging[i];
+        return;
+    }
+    // a launch that found the batch finished left epoch and totals alone, and the slot then already holds the job's sums: the shard's own
+    // totals are kept beside the epoch they belong to, so that exporting twice under one epoch exports the same values
+    const bool fresh = epoch_block[1] != epoch;
+    const uint32_t mine = fresh ? slot[i] : epoch_block[2 + i];
+    if (fresh) epoch_block[2 + i] = mine;
+    staging[i] = (int32_t)mine;
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    if (fresh && i == 0) epoch_block[1] = epoch;
+}
+
 // ended_only (step-by-step rollouts with FRZ_ROLLOUT_AUTO_RESET, between a step and the reset of its finished envs): the returns of the
 // finished envs only, one env-step per env, the number of finished envs
 __global__ void __launch_bounds__(kBlock) wf_metrics_kernel(char* __restrict__ arena, double* __restrict__ out, int ended_only) {
@@ -1264,6 +1290,7 @@ int create_grid(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     }
     env->ticketed = p.nchunks > cus;  // wg_offsets_kernel: one workgroup per chunk, handed out in arrival order beyond one per CU
+    frz::handle_register(env, 1, A, cfg->parallel_envs, HW);
     *out = env;
     return FRZ_OK;
 }
@@ -1495,12 +1522,14 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     }
     env->ticketed = p.nchunks > cus;
+    frz::handle_register(env, 1, A, cfg->parallel_envs, HW);
     *out = env;
     return FRZ_OK;
 }
 
 void frz_wildfire_destroy(frz_wildfire_env* env) {
     if (!env) return;
+    frz::handle_unregister(env);
     for (hipEvent_t e : env->timing_events) (void)hipEventDestroy(e);
     delete env;
 }
@@ -1693,10 +1722,54 @@ int frz_wildfire_timed_rollout(frz_wildfire_env* env, uint64_t policy_seed, uint
     return FRZ_OK;
 }
 
+int frz_exclusive_launch_fits(int64_t workgroups, int workgroups_per_cu, int compute_units, int cu_mask_set) {
+    // every workgroup of a multi-step launch must be resident at once: they wait for each other inside the kernel
+    if (cu_mask_set) return 0;  // a CU mask shrinks the device without changing the properties the runtime reports
+    if (workgroups <= 0 || workgroups_per_cu <= 0 || compute_units <= 0) return 0;
+    return workgroups <= (int64_t)workgroups_per_cu * compute_units ? 1 : 0;
+}
+
 int frz_wildfire_set_exclusive_device(frz_wildfire_env* env, int exclusive) {
     if (!env) return FRZ_E_INVALID;
-    env->exclusive_device = exclusive != 0;
+    if (!exclusive) {
+        env->exclusive_device = false;
+        return FRZ_OK;
+    }
+    if (env->list_copy_delta == 0 || !env->dev.roles || env->dev.grid) {  // no multi-step kernel for this shape: nothing to allow, nothing to guard
+        env->exclusive_device = true;
+        return FRZ_OK;
+    }
+    // the caller's promise covers OTHER work on the device; whether this env's own grid fits is checked here: the device that owns the
+    // arena (when bound), the occupancy of the multi-step instantiation, no CU mask in force
+    int device = 0;
+    if (env->arena) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, env->arena) == hipSuccess) device = attr.device;
+        else (void)hipGetLastError();
+    } else if (hipGetDevice(&device) != hipSuccess) {
+        return FRZ_E_NODEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return FRZ_E_NODEVICE;
+    const int per_cu = roles_persist_occupancy(env->variant);
+    const bool masked = std::getenv("ROC_GLOBAL_CU_MASK") != nullptr || std::getenv("HSA_CU_MASK") != nullptr;
+    if (!frz_exclusive_launch_fits(env->dev.nchunks, per_cu, prop.multiProcessorCount, masked ? 1 : 0)) return FRZ_E_INVALID;
+    env->exclusive_device = true;
     return FRZ_OK;
+}
+
+int frz_wildfire_export_totals(frz_wildfire_env* env, int32_t* staging, void* stream) {
+    if (!env || !staging) return FRZ_E_INVALID;
+    if (!env->arena) return FRZ_E_UNBOUND;
+    hipLaunchKernelGGL(wf_totals_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), env->arena, staging, 0);
+    return hipGetLastError() == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;
+}
+
+int frz_wildfire_import_totals(frz_wildfire_env* env, const int32_t* staging, void* stream) {
+    if (!env || !staging) return FRZ_E_INVALID;
+    if (!env->arena) return FRZ_E_UNBOUND;
+    hipLaunchKernelGGL(wf_totals_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), env->arena, const_cast<int32_t*>(staging), 1);
+    return hipGetLastError() == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;
 }
 
 int frz_wildfire_rollout_launches(const frz_wildfire_env* env, int32_t n_steps, int rng_mode) {

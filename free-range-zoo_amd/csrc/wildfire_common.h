@@ -205,6 +205,8 @@ __device__ __forceinline__ int popc(M m) {
 
 // field/crew wavefront-pair kernels for grids of <= 8 cells (wildfire_roles.hip); variant as in wildfire.hip's table
 int launch_roles(const WfArgs& args, int variant, int grid, int rng, int mode, hipStream_t stream);
+// workgroups of the variant's multi-step kernel one CU holds at once (hipOccupancyMaxActiveBlocksPerMultiprocessor); 0: none / no device
+int roles_persist_occupancy(int variant);
 
 // ---- grids above 16 cells: one env per wavefront, cells across its lanes (wildfire_grid.hip) -------------------------------------
 // Configuration of the grid kernels, passed BY VALUE as a kernel argument.  Tables indexed by a lane (per agent, per cell, range sets)

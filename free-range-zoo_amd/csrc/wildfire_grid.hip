@@ -453,7 +453,8 @@ __global__ void __launch_bounds__(kBlock) wg_env_kernel(char* __restrict__ arena
             frz::at32(rows8, (uint32_t)d.q_burnouts * Bu + bu) = 0;
             frz::at32(rows8, (uint32_t)d.q_putouts * Bu + bu) = 0;
             frz::at32(rows1, (uint32_t)d.u_frozen * Bu + bu) = 0;
-            if (pol.on) frz::at32(rows, (uint32_t)d.r_seeds * Bu + bu) += (int32_t)pol.seed_lo;  // frz_wildfire_reset_reseed: seed increment
+            if (pol.on)  // frz_wildfire_reset_reseed: seed increment, modulo 2^32
+                frz::at32(rows, (uint32_t)d.r_seeds * Bu + bu) = (int32_t)((uint32_t)frz::at32(rows, (uint32_t)d.r_seeds * Bu + bu) + pol.seed_lo);
         }
     }
     uint32_t ok1[W2];

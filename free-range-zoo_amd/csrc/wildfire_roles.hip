@@ -22,4 +22,23 @@ int launch_roles(const WfArgs& args, int variant, int grid, int rng, int mode, h
     }
 }
 
+
+int roles_persist_occupancy_group_0(int);
+int roles_persist_occupancy_group_1(int);
+int roles_persist_occupancy_group_2(int);
+int roles_persist_occupancy_group_3(int);
+int roles_persist_occupancy_group_4(int);
+int roles_persist_occupancy_group_5(int);
+
+int roles_persist_occupancy(int variant) {
+    switch (variant % FRZ_WF_ROLES_GROUPS) {
+        case 0: return roles_persist_occupancy_group_0(variant);
+        case 1: return roles_persist_occupancy_group_1(variant);
+        case 2: return roles_persist_occupancy_group_2(variant);
+        case 3: return roles_persist_occupancy_group_3(variant);
+        case 4: return roles_persist_occupancy_group_4(variant);
+        default: return roles_persist_occupancy_group_5(variant);
+    }
+}
+
 }  // namespace frz_wf

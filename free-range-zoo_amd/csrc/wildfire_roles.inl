@@ -1119,7 +1119,8 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                         }
                     at32(rows, (uint32_t)r_moves * Bu + bl) = 0;
                     at32(rows, (uint32_t)r_burnouts * Bu + bl) = 0;
-                    if (launch.seed_increment != 0 && active) at32(rows, (uint32_t)r_seeds * Bu + bl) += launch.seed_increment;  // fresh seeds per episode
+                    if (launch.seed_increment != 0 && active)  // fresh seeds per episode, modulo 2^32
+                        at32(rows, (uint32_t)r_seeds * Bu + bl) = (int32_t)((uint32_t)at32(rows, (uint32_t)r_seeds * Bu + bl) + (uint32_t)launch.seed_increment);
                     at32(rows8, q_burnouts * Bu + bl) = 0;
                     at32(rows8, q_putouts * Bu + bl) = 0;
                     at32(rows1, u_frozen * Bu + bl) = (uint8_t)0;
@@ -1488,6 +1489,28 @@ int FRZ_WF_CONCAT(launch_roles_group_, FRZ_WF_ROLES_GROUP)(const WfArgs& args, i
         default: return FRZ_E_INVALID;
     }
     return hipGetLastError() == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;
+}
+
+
+// resident workgroups per CU of the variant's multi-step instantiation (the plain rollout: the one with the larger grid of users), 0 if the
+// variant is not in this unit
+int FRZ_WF_CONCAT(roles_persist_occupancy_group_, FRZ_WF_ROLES_GROUP)(int variant) {
+    int blocks = 0;
+    switch (variant) {
+#define FRZ_X(i, c, a, e)                                                                                                                  \
+    case i:                                                                                                                                \
+        if constexpr ((i) % FRZ_WF_ROLES_GROUPS == FRZ_WF_ROLES_GROUP && e && c <= 16 && a * (c <= 8 ? 8 : 16) <= 64) {                      \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, wf_roles_kernel<c, a, true, FRZ_RNG_PHILOX, kStep, true, false>, kRoleBlock, 0) != hipSuccess) { \
+                (void)hipGetLastError();                                                                                                   \
+                blocks = 0;                                                                                                                \
+            }                                                                                                                              \
+        }                                                                                                                                  \
+        break;
+        FRZ_WF_VARIANT_LIST(FRZ_X)
+#undef FRZ_X
+        default: break;
+    }
+    return blocks;
 }
 
 }  // namespace frz_wf

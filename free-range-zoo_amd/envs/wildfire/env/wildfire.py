@@ -395,6 +395,7 @@ class raw_env(BatchedParallelEnv):
         """
         if not self._has_reset:
             raise RuntimeError('reset() must be called once before capturing a rollout')
+        self._no_multi_step_while_consistent('capture_random_rollout()')
         if metrics is not None and (metrics.dtype != torch.float64 or metrics.numel() != len(self.agents) + 2 or not metrics.is_contiguous()):
             raise ValueError('metrics must be a contiguous float64 [A + 2] tensor on the env device')
         lib, handle = self._lib, self._handle
@@ -445,6 +446,8 @@ class raw_env(BatchedParallelEnv):
     def _after_fast_step(self):
         """_after_fused(False) of the exact-shapes default, inlined for the per-step hot path of the reference-shaped rollout loop."""
         d = self.__dict__
+        if d.get('_global_group', False) is not False:
+            self._exchange_batch_totals()
         self._epoch_counter += 1
         if self.exact_shapes:
             for name in self._LAZY_OUTPUTS:
@@ -481,12 +484,54 @@ class raw_env(BatchedParallelEnv):
         self.infos['burnouts'] = self._burnouts
         self.infos['putouts'] = self._putouts
 
-    def set_exclusive_device(self, exclusive: bool = True) -> None:
+    def set_exclusive_device(self, exclusive: bool = True) -> bool:
         """State that nothing else uses this GPU while the env's rollouts run (no other process, no concurrent stream).  It allows
-        ``rollout_random_policy`` / ``capture_random_rollout`` to run a whole rollout as ONE launch where the library has a multi-step
-        kernel for the shape (include/frz.h: frz_wildfire_set_exclusive_device): its workgroups wait inside the kernel for each other
-        between steps, which is only safe when all of them are resident.  Off by default."""
-        _capi.check(self._lib.frz_wildfire_set_exclusive_device(self._handle, 1 if exclusive else 0), 'frz_wildfire_set_exclusive_device')
+        ``rollout`` / ``rollout_random_policy`` / ``capture_random_rollout`` to run a whole rollout as ONE launch where the library has a
+        multi-step kernel for the shape (include/frz.h: frz_wildfire_set_exclusive_device): its workgroups wait inside the kernel for each
+        other between steps, which is only safe when all of them are resident.  Off by default.  The library checks its own part — the
+        launch's workgroups fit on the device that owns the arena (occupancy query x compute units, no CU mask): if they do not, the request
+        is refused, rollouts keep taking one launch per step, and False is returned."""
+        if exclusive and self.__dict__.get('_global_group', False) is not False:
+            return False  # globally consistent batch semantics exchange the totals between any two steps
+        return self._lib.frz_wildfire_set_exclusive_device(self._handle, 1 if exclusive else 0) == 0
+
+    # ------------------------------------------------------------------------ sharded jobs: globally consistent batch semantics (optional)
+    def set_global_consistency(self, enabled: bool = True, group=None) -> None:
+        """Evaluate the two batch-global semantics of a step over the WHOLE sharded job instead of this shard (off by default):
+        the all-done early-out (utils/env.py:211-213) and the skip of an agent without a task in any env (wildfire.py:434-435).  After
+        every ``reset`` / ``step`` / ``step_random_policy`` / ``update_observations`` the batch totals the kernels keep (lit fires, fires
+        each agent can attack, envs not terminated / not truncated: A + 3 integers) are summed over the ranks of ``group`` — one tiny
+        ``all_reduce`` per step, stream-ordered with RCCL — and the next step reads the sums: a sharded run is then the unsharded one env
+        for env also when a whole shard finishes early or with ``show_bad_actions``.  Multi-step launches cannot stop for the exchange:
+        ``rollout`` / ``rollout_random_policy`` / ``capture_random_rollout`` raise while this is on."""
+        self._global_group = group if enabled else False
+        if enabled:
+            self._lib.frz_wildfire_set_exclusive_device(self._handle, 0)
+            if self.__dict__.get('_totals_staging') is None:
+                self._totals_staging = torch.zeros(len(self.possible_agents) + 3, dtype=torch.int32, device=self.device)
+
+    def _publish(self) -> None:
+        if self.__dict__.get('_global_group', False) is not False:
+            self._exchange_batch_totals()
+        super()._publish()
+
+    def _exchange_batch_totals(self) -> None:
+        import torch.distributed as dist
+        from free_range_zoo_amd.utils import sharding
+        staging, stream = self._totals_staging, stream_ptr(self.device)
+        _capi.check(self._lib.frz_wildfire_export_totals(self._handle, staging.data_ptr(), stream), 'frz_wildfire_export_totals')
+        if dist.is_available() and dist.is_initialized() and dist.get_backend(self._global_group) == 'gloo':
+            host = staging.cpu()  # (gloo reduces host tensors: the CPU rehearsal of the exchange; RCCL keeps it on the device)
+            sharding.globalize_totals(host, self._global_group)
+            staging.copy_(host)
+        else:
+            sharding.globalize_totals(staging, self._global_group)
+        _capi.check(self._lib.frz_wildfire_import_totals(self._handle, staging.data_ptr(), stream), 'frz_wildfire_import_totals')
+
+    def _no_multi_step_while_consistent(self, what: str) -> None:
+        if self.__dict__.get('_global_group', False) is not False:
+            raise NotImplementedError(f'{what} enqueues several steps without the per-step exchange of set_global_consistency(); use step() / '
+                                      f'step_random_policy()')
 
     @torch.no_grad()
     def rollout_random_policy(self, steps: int, policy_seed: int = 0, first_step: int = 0):
@@ -494,6 +539,7 @@ class raw_env(BatchedParallelEnv):
         steps are taken one by one so that every one of them reaches the CSV files."""
         if not self._has_reset:
             raise RuntimeError('reset() must be called before rollout_random_policy()')
+        self._no_multi_step_while_consistent('rollout_random_policy()')
         if self.logger is not None:
             out = None
             for t in range(steps):

@@ -42,9 +42,15 @@ class LazyAgentDict(dict):
     def __init__(self, env, agents):
         super().__init__()
         self._env, self._agents, self._filled = env, tuple(agents), False
+        self._epoch = env._epoch_counter  # the step whose observations this dict stands for
 
     def _fill(self):
         if not self._filled:
+            if self._env._epoch_counter != self._epoch:
+                # the buffers behind this dict now hold a later step: filling it would silently hand out that step's observations (a replay
+                # buffer that stores `obs` and reads it after the next step would get `next_obs` twice)
+                raise RuntimeError('these observations belong to an earlier step(): like every tensor the env hands out they were valid until the '
+                                   'next step() / reset() — look at (or .copy()) them before stepping again')
             self._filled = True
             observations = self._env.observations
             dict.update(self, {agent: observations[agent] for agent in self._agents})
@@ -394,6 +400,8 @@ class BatchedParallelEnv:
         """
         if not self._has_reset:
             raise RuntimeError('reset() must be called before rollout()')
+        if self.__dict__.get('_global_group', False) is not False and steps > 1:
+            raise NotImplementedError('rollout() enqueues several steps without the per-step exchange of set_global_consistency()')
         if self.logger is not None:
             raise NotImplementedError('rollout() does not feed the logging tap: step() does')
         A, B = len(self.agents), self.parallel_envs

@@ -30,6 +30,18 @@ def episode_metrics(cumulative_rewards: torch.Tensor, finished: torch.Tensor, en
     return out
 
 
+def globalize_totals(totals: torch.Tensor, group=None) -> torch.Tensor:
+    """Sum a shard's batch totals (int32 / int64 ``[A + 3]``: lit fires, fires each agent can attack, envs not terminated, envs not
+    truncated) over the ranks, in place: the OPTIONAL per-step exchange of a sharded job that wants the reference's two batch-global step
+    semantics — "every env is finished" (utils/env.py:211-213) and "agent a has no task in any env" (wildfire.py:434-435) — evaluated over
+    the whole job instead of per shard.  With the ``nccl`` backend (RCCL) the tensor stays on the device; ``gloo`` needs it
+    on the host (tests).  A no-op without an initialised process group."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(totals, op=dist.ReduceOp.SUM, group=group)
+    return totals
+
+
 def reduce_metrics(metrics: torch.Tensor, group=None) -> torch.Tensor:
     """Sum the metrics vector over all ranks (the job's only collective; a no-op without an initialised process group)."""
     import torch.distributed as dist

@@ -183,6 +183,10 @@ typedef struct frz_wildfire_bufs {
 typedef struct frz_wildfire_env frz_wildfire_env; /* opaque host handle */
 
 int frz_abi_version(void);
+/* What a binding that is handed a handle as a plain integer can check before using it: 0 = not a live handle of this library, 1 wildfire,
+ * 2 cybersecurity, 3 rideshare; and the sizes the handle was created with (units = cells / nodes / passenger slots per env). */
+int frz_handle_kind(const void* handle);
+int frz_handle_shape(const void* handle, int64_t* agents, int64_t* envs, int64_t* units);
 int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out);
 void frz_wildfire_destroy(frz_wildfire_env* env);
 /* size of the device arena (state + outputs + RNG state + library scratch) for this configuration */
@@ -194,7 +198,7 @@ int frz_wildfire_get_bufs(const frz_wildfire_env* env, frz_wildfire_bufs* out);
 /* replaces raw_env.reset()'s state fill (wildfire.py:347-354) + bookkeeping zeroing (utils/env.py:137-160)
  * followed by update_observations/update_actions */
 int frz_wildfire_reset(frz_wildfire_env* env, void* stream);
-/* frz_wildfire_reset that first adds seed_increment to every env seed (bufs.seeds; the FRZ_RNG_PHILOX key and the value the next
+/* frz_wildfire_reset that first adds seed_increment (modulo 2^32: the seeds wrap around, no signed overflow) to every env seed (bufs.seeds; the FRZ_RNG_PHILOX key and the value the next
  * frz_mt19937_seed starts the env's stream from): the "fresh seeds, reset" pair at the top of every episode of a rollout loop
  * (the reference's `env.reset(seed=...)`, utils/env.py:94-160) as one launch */
 int frz_wildfire_reset_reseed(frz_wildfire_env* env, int32_t seed_increment, void* stream);
@@ -341,6 +345,16 @@ int frz_wildfire_reset_masked(frz_wildfire_env* env, const uint8_t* mask, int32_
  * totals of step t gate step t + 1) and therefore must all be resident at once — sharing the CUs with another kernel that also waits
  * for its own stragglers can stall both until their bounded spins give up (FRZ_ERR_SCAN_TIMEOUT).  Off by default. */
 int frz_wildfire_set_exclusive_device(frz_wildfire_env* env, int exclusive);
+/* The library's own check behind frz_<dom>_set_exclusive_device(env, 1), which returns FRZ_E_INVALID when it fails: the launch's workgroups
+ * (one per 256-env chunk) all fit on the device that owns the arena — occupancy of the multi-step instantiation
+ * (hipOccupancyMaxActiveBlocksPerMultiprocessor) x its compute units — and no CU mask (ROC_GLOBAL_CU_MASK / HSA_CU_MASK) is in force.  The
+ * decision itself, exported so that it can be unit-tested without a device: 1 = fits. */
+int frz_exclusive_launch_fits(int64_t workgroups, int workgroups_per_cu, int compute_units, int cu_mask_set);
+/* Globally consistent batch semantics under sharding (optional): the two batch-global tests of a step — "every env is finished"
+ * (utils/env.py:211-213) and "agent a has no task in ANY env" (wildfire.py:434-435) — read the batch totals the previous step left.  Between
+ * two steps a sharded job sums them over its ranks: export (int32 [A + 3], device), all_reduce(SUM), import.  Stream-ordered, no host read. */
+int frz_wildfire_export_totals(frz_wildfire_env* env, int32_t* staging, void* stream);
+int frz_wildfire_import_totals(frz_wildfire_env* env, const int32_t* staging, void* stream);
 /* How many kernel launches frz_wildfire_rollout_random_policy(n_steps) enqueues for this env and RNG mode: 1 when the whole rollout runs
  * as one multi-step launch (exact field/crew shapes, FRZ_RNG_PHILOX or FRZ_RNG_MT19937, every chunk's workgroup resident at once,
  * frz_wildfire_set_exclusive_device on), n_steps otherwise. */

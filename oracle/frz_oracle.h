@@ -51,6 +51,10 @@ typedef struct frz_oracle_wildfire_bufs {
     /* BatchedAECEnv.step early-out bookkeeping (utils/env.py:211-213): 1 once every env is terminated or every
      * env is truncated; further steps leave everything untouched except rewards (see frz_oracle_wildfire_step) */
     int32_t* frozen; /* [2]: {frozen, stale_rewards_already_scaled} */
+    /* optional (NULL: this batch is the whole batch): totals of the batch this one is a SHARD of, int64 [A + 3] = (lit fires, fires agent a can
+     * attack ..., envs not terminated, envs not truncated), as they stand before the step — the two batch-global tests of a step
+     * (utils/env.py:211-213, wildfire.py:434-435) are then evaluated on them: the reference's semantics for the unsharded batch */
+    const int64_t* global_totals;
 } frz_oracle_wildfire_bufs;
 
 int frz_oracle_wildfire_reset(const frz_wildfire_cfg* cfg, frz_oracle_wildfire_bufs* s);

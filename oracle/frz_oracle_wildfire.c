@@ -347,6 +347,10 @@ int frz_oracle_wildfire_step(const frz_wildfire_cfg* cfg, frz_oracle_wildfire_bu
             all_term = all_term && s->terminations[b];
             all_trunc = all_trunc && s->truncations[b];
         }
+        if (s->global_totals) { /* this batch is a shard: "all" ranges over the whole batch */
+            all_term = s->global_totals[A + 1] == 0;
+            all_trunc = s->global_totals[A + 2] == 0;
+        }
         if (all_term || all_trunc) {
             if (!s->frozen[1]) {
                 for (int64_t i = 0; i < (int64_t)A * B; ++i) {
@@ -381,6 +385,7 @@ int frz_oracle_wildfire_step(const frz_wildfire_cfg* cfg, frz_oracle_wildfire_bu
     for (int32_t a = 0; a < A; ++a) {
         int64_t agent_tasks_anywhere = 0;
         for (int64_t b = 0; b < B; ++b) agent_tasks_anywhere += s->agent_task_count[(int64_t)a * B + b];
+        if (s->global_totals) agent_tasks_anywhere = s->global_totals[1 + a];
         for (int64_t b = 0; b < B; ++b) {
             const int32_t idx = actions[((int64_t)a * B + b) * 2 + 0];
             const int32_t act = actions[((int64_t)a * B + b) * 2 + 1];

@@ -99,6 +99,22 @@ class WildfireOracle:
         assert actions.shape == (A, B, 2) and fr.size == 3 * B * HW and ar.size == 5 * B * A
         assert lib().frz_oracle_wildfire_step(ctypes.byref(self.cfg), ctypes.byref(self.bufs), _ptr(actions), _ptr(fr), _ptr(ar)) == 0
 
+    def batch_totals(self) -> np.ndarray:
+        """int64 [A + 3]: (lit fires, fires agent a can attack ..., envs not terminated, envs not truncated) of this batch, as the next step's
+        batch-global tests read them."""
+        A = self.cfg.num_agents
+        out = np.zeros(A + 3, np.int64)
+        out[0] = self.env_task_count.sum()
+        out[1:1 + A] = self.agent_task_count.sum(axis=1)
+        out[A + 1] = (~self.terminations[0].astype(bool)).sum()
+        out[A + 2] = (~self.truncations[0].astype(bool)).sum()
+        return out
+
+    def set_global_totals(self, totals) -> None:
+        """The totals of the batch this one is a shard of (None: it is the whole batch) for the next step."""
+        self._global_totals = None if totals is None else np.ascontiguousarray(totals, np.int64)
+        self.bufs.global_totals = None if totals is None else _ptr(self._global_totals)
+
     def reset_masked(self, mask, seeds: np.ndarray = None, seed_increment: int = 0):
         """reset_batches with the selection as a mask (None: the finished envs); ``seeds`` (int32 [B]) moves on in place for the selected envs."""
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)

@@ -104,3 +104,33 @@ def test_reference_shaped_random_rollout_draws_inside_the_step_launch():
             assert torch.equal(getattr(fused, name), getattr(plain, name)) and torch.equal(getattr(looked, name), getattr(plain, name)), f'{name} at step {t}'
     assert bool(fused.finished.all())
     fused.check()
+
+
+def test_observations_of_an_earlier_step_refuse_to_fill_late():
+    """The dict step() returns stands for THAT step: filled after the next step it would hold the next step's observations — it
+    raises instead; looked at in time (or copied) it keeps working."""
+    from free_range_zoo_amd.envs import wildfire_v0
+    B = 33
+    env = wildfire_v0.parallel_env(configuration=configs.wildfire_openness(), parallel_envs=B, max_steps=10, device=torch.device('cuda'), rng='philox')
+    obs0, _ = env.reset(seed=torch.arange(B, dtype=torch.int32))
+    obs1 = env.step_random_policy(policy_seed=1, policy_step=0)[0]
+    held = obs1.copy()  # filled in time
+    obs2 = env.step_random_policy(policy_seed=1, policy_step=1)[0]
+    with pytest.raises(RuntimeError, match='earlier step'):
+        obs0[env.agents[0]]  # never looked at before the env moved on
+    assert set(held) == set(env.agents) and set(obs2.keys()) == set(env.agents)
+    assert obs1[env.agents[0]]['self'].shape == (B, 4) and obs2[env.agents[0]]['self'].shape == (B, 4)
+
+
+def test_seed_increments_wrap_modulo_2_to_the_32():
+    """frz_wildfire_reset_reseed / the reset folded into a rollout add the episode stride in unsigned arithmetic: a graph replayed
+    for days passes 2^31."""
+    from free_range_zoo_amd.envs import wildfire_v0
+    B = 300
+    env = wildfire_v0.parallel_env(configuration=configs.wildfire_openness(), parallel_envs=B, max_steps=10, device=torch.device('cuda'), rng='philox')
+    env.set_exclusive_device(True)
+    start = torch.full((B, ), 2**31 - 5, dtype=torch.int64)
+    env.reset(seed=start.to(torch.int32))
+    env.rollout(3, policy_seed=1, reset_first=True, seed_increment=1000003)
+    want = ((start + 1000003) % 2**32).to(torch.int64)
+    assert torch.equal(env.seeds.cpu().to(torch.int64) % 2**32, want)

@@ -123,3 +123,173 @@ def test_two_rank_sharded_product_rollout_equals_unsharded():
     assert np.array_equal(fires, whole.fires)
     np.testing.assert_allclose(reduced[:3], whole.cumulative_rewards.sum(axis=1, dtype=np.float64), rtol=1e-9)
     assert reduced[3] == world * per_rank * steps
+
+
+# ------------------------------------------------------------------------------------------------------------
+# globally consistent batch semantics (optional per-step exchange of the batch totals): cases where a per-shard evaluation of
+# the reference's two batch-global tests differs from the unsharded run — one shard finishes early (utils/env.py:211-213); with
+# show_bad_actions an agent has no task in any env of ONE shard only (wildfire.py:434-435)
+# ------------------------------------------------------------------------------------------------------------
+def _consistency_case(per_rank, world, which):
+    """(configuration builder, env flags, per-env initial-state edit) for a job of world x per_rank envs (global env index g)."""
+    import configs
+    n = world * per_rank
+    if which == 'shard_finishes_early':  # the envs of shard 0 start without any fire: they are all terminated after the first step
+        dead = np.arange(n) < per_rank
+        return configs.wildfire_openness, {}, lambda fires, intensity, g: (np.where(dead[g, None], 0, fires), np.where(dead[g, None], 0, intensity))
+    # firefighter_1 at (0, 0) reaches cells 0, 1, 3, 4 of the 2 x 3 grid; in shard 0 only cell 5 is lit: it has no task in any env there,
+    # while it has tasks in shard 1.  It attacks listed fires all the same (show_bad_actions): penalised unless the agent is skipped.
+    def edit(fires, intensity, g):
+        far = (g < per_rank)[:, None] & (np.arange(6)[None, :] != 5)
+        return np.where(far & (fires > 0), -fires, fires), np.where(far, 0, intensity)
+    return configs.wildfire_non_stochastic, dict(show_bad_actions=True), edit
+
+
+def _forced_actions(agent_counts, env_counts, show_bad, t):
+    """deterministic: every agent fights its listed task (t mod n) when there is one, else noop"""
+    n = env_counts[None, :].repeat(agent_counts.shape[0], 0) if show_bad else agent_counts
+    idx = np.where(n > 0, t % np.maximum(n, 1), n)
+    return np.stack([idx, np.where(n > 0, 0, -1)], axis=-1).astype(np.int32)
+
+
+def _consistent_oracle_worker(rank, world, port, per_rank, steps, which, out_queue, exchange):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from oracle import oracle
+    from free_range_zoo_amd.envs.wildfire.env.structures.configuration import to_cstruct
+    from free_range_zoo_amd.utils import sharding
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+    build, flags, edit = _consistency_case(per_rank, world, which)
+    cfg = to_cstruct(build(), per_rank, 12, **flags)
+    o = oracle.WildfireOracle(cfg)
+    o.reset()
+    g = np.arange(per_rank) + rank * per_rank
+    o.fires[:], o.intensity[:] = edit(o.fires, o.intensity, g)
+    o.rebuild()
+    seeds = sharding.shard_seeds(rank, per_rank).numpy()
+    for t in range(steps):
+        if exchange:  # the per-step exchange: the shard's totals summed over the ranks
+            o.set_global_totals(sharding.globalize_totals(torch.from_numpy(o.batch_totals())).numpy())
+        actions = _forced_actions(o.agent_task_count, o.env_task_count, bool(cfg.show_bad_actions), t)
+        field, agent = oracle.wildfire_philox_randomness(cfg, seeds, o.num_moves)
+        o.step(actions, field, agent)
+    parts = [torch.from_numpy(np.ascontiguousarray(a)) for a in (o.fires, o.num_moves, o.suppressants, o.cumulative_rewards.T.copy())]
+    gathered = [[torch.zeros_like(p) for _ in range(world)] for p in parts]
+    for p, out in zip(parts, gathered):
+        dist.all_gather(out, p)
+    if rank == 0:
+        out_queue.put([torch.cat(out).numpy() for out in gathered])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _unsharded_oracle(per_rank, world, steps, which):
+    from oracle import oracle
+    from free_range_zoo_amd.envs.wildfire.env.structures.configuration import to_cstruct
+    build, flags, edit = _consistency_case(per_rank, world, which)
+    n = per_rank * world
+    cfg = to_cstruct(build(), n, 12, **flags)
+    o = oracle.WildfireOracle(cfg)
+    o.reset()
+    o.fires[:], o.intensity[:] = edit(o.fires, o.intensity, np.arange(n))
+    o.rebuild()
+    seeds = np.arange(n, dtype=np.int32)
+    for t in range(steps):
+        actions = _forced_actions(o.agent_task_count, o.env_task_count, bool(cfg.show_bad_actions), t)
+        field, agent = oracle.wildfire_philox_randomness(cfg, seeds, o.num_moves)
+        o.step(actions, field, agent)
+    return [o.fires, o.num_moves, o.suppressants, o.cumulative_rewards.T.copy()]
+
+
+def _run_two_ranks(target, args):
+    ctx = mp.get_context('spawn')
+    queue = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, 2, port) + args[:-1] + (queue, args[-1])) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = queue.get()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    return out
+
+
+@pytest.mark.parametrize('which', ['shard_finishes_early', 'agent_idle_in_one_shard'])
+def test_global_totals_exchange_makes_sharded_equal_unsharded(which):
+    """World 2, gloo, CPU (the oracle stands in for the kernels; the exchange is the product's own sharding.globalize_totals): with the
+    per-step sum of the batch totals the two shards reproduce the unsharded batch env for env; without it this case differs — which is
+    what the mode is for."""
+    sys.path.insert(0, ROOT)
+    per_rank, steps = 40, 9
+    whole = _unsharded_oracle(per_rank, 2, steps, which)
+    consistent = _run_two_ranks(_consistent_oracle_worker, (per_rank, steps, which, True))
+    for got, want, name in zip(consistent, whole, ('fires', 'num_moves', 'suppressants', 'cumulative rewards')):
+        assert np.array_equal(got, want), f'{which}: {name} with the exchange'
+    per_shard = _run_two_ranks(_consistent_oracle_worker, (per_rank, steps, which, False))
+    assert any(not np.array_equal(got, want) for got, want in zip(per_shard, whole)), f'{which}: the case must show the per-shard deviation'
+
+
+def _consistent_product_worker(rank, world, port, per_rank, steps, which, out_queue, exchange):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from free_range_zoo_amd.envs import wildfire_v0
+    from free_range_zoo_amd.utils import sharding
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+    got = _product_rollout(per_rank, world, steps, which, rank, exchange)
+    parts = [torch.from_numpy(np.ascontiguousarray(a)) for a in got]
+    gathered = [[torch.zeros_like(p) for _ in range(world)] for p in parts]
+    for p, out in zip(parts, gathered):
+        dist.all_gather(out, p)
+    if rank == 0:
+        out_queue.put([torch.cat(out).numpy() for out in gathered])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _product_rollout(per_rank, world, steps, which, rank, exchange):
+    """rank None: the unsharded job on one env object"""
+    from free_range_zoo_amd.envs import wildfire_v0
+    build, flags, edit = _consistency_case(per_rank, world, which)
+    n = per_rank * world if rank is None else per_rank
+    g = np.arange(n) if rank is None else np.arange(per_rank) + rank * per_rank
+    env = wildfire_v0.parallel_env(configuration=build(), parallel_envs=n, max_steps=12, device=torch.device('cuda', 0), rng='philox', **flags)
+    if exchange:
+        env.set_global_consistency(True)
+    env.reset(seed=torch.from_numpy(g.astype(np.int32)))
+    state = env.state().clone()
+    fires, intensity = edit(state.fires.reshape(n, -1).cpu().numpy(), state.intensity.reshape(n, -1).cpu().numpy(), g)
+    state.fires, state.intensity = torch.from_numpy(fires).view_as(state.fires).cuda(), torch.from_numpy(intensity).view_as(state.intensity).cuda()
+    env.reset(options={'initial_state': state, 'skip_seeding': True})
+    for t in range(steps):
+        actions = _forced_actions(env.agent_task_count.cpu().numpy(), env.environment_task_count.cpu().numpy(), bool(flags.get('show_bad_actions')), t)
+        env.step(torch.from_numpy(actions).cuda())
+    env.check()
+    return [env.state().fires.reshape(n, -1).cpu().numpy(), env.num_moves.cpu().numpy(), env.state().suppressants.cpu().numpy().copy(),
+            env._cumulative.t().cpu().numpy().copy()]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('which', ['shard_finishes_early', 'agent_idle_in_one_shard'])
+def test_global_consistency_mode_of_the_product(which):
+    """The same two cases on the HIP envs: two ranks (gloo, both on the box's GPU) with env.set_global_consistency() are the unsharded env
+    object env for env; without it they are not."""
+    per_rank, steps = 600, 9
+    whole = _product_rollout(per_rank, 2, steps, which, None, False)
+    consistent = _run_two_ranks(_consistent_product_worker, (per_rank, steps, which, True))
+    for got, want, name in zip(consistent, whole, ('fires', 'num_moves', 'suppressants', 'cumulative rewards')):
+        assert np.array_equal(got, want), f'{which}: {name} with set_global_consistency()'
+    per_shard = _run_two_ranks(_consistent_product_worker, (per_rank, steps, which, False))
+    assert any(not np.array_equal(got, want) for got, want in zip(per_shard, whole)), f'{which}: the case must show the per-shard deviation'
+
+
+def test_the_exclusive_device_guard_decision():
+    """frz_exclusive_launch_fits (include/frz.h), the decision behind set_exclusive_device(): every workgroup of a multi-step launch resident
+    at once — workgroups <= occupancy x compute units — and no CU mask in force.  No device needed."""
+    sys.path.insert(0, ROOT)
+    from free_range_zoo_amd import _capi
+    fits = _capi.lib().frz_exclusive_launch_fits
+    assert fits(256, 1, 256, 0) == 1 and fits(257, 1, 256, 0) == 0          # B = 65 536 on a whole MI355X; one chunk more
+    assert fits(256, 1, 256, 1) == 0                                          # a CU mask shrinks the device behind the runtime's back
+    assert fits(64, 1, 32, 0) == 0 and fits(64, 2, 32, 0) == 1               # a partition of 32 CUs: depends on the occupancy
+    assert fits(10, 0, 256, 0) == 0 and fits(0, 1, 256, 0) == 0               # no occupancy information / nothing to launch: refused

@@ -77,3 +77,40 @@ def test_op_argument_checks():
         ops.wildfire_step(torch.zeros_like(env._arena), env._handle.value, good, 1, None, None, 3, 64, 6)
     ops.wildfire_step(env._arena, env._handle.value, good, 1, None, None, 3, 64, 6)
     assert int(env.num_moves.max()) == 1
+
+
+@pytest.mark.gpu
+def test_ops_refuse_handles_arenas_and_sizes_they_cannot_vouch_for():
+    """The ops receive the env handle as a plain integer: a stale / foreign one, a handle bound to another arena, sizes that are not the
+    handle's own, or a handle of another domain are TORCH_CHECK failures before anything is launched (the library keeps a registry of its
+    live handles: include/frz.h frz_handle_kind / frz_handle_shape)."""
+    from free_range_zoo_amd import _torch_ops
+    from free_range_zoo_amd.envs import cybersecurity_v0, wildfire_v0
+    ops = _torch_ops.load()
+    B = 64
+    wf = wildfire_v0.parallel_env(configuration=configs.wildfire_openness(), parallel_envs=B, max_steps=5, device=torch.device('cuda'), rng='philox',
+                                  dispatch='torch')
+    other = wildfire_v0.parallel_env(configuration=configs.wildfire_openness(), parallel_envs=B, max_steps=5, device=torch.device('cuda'), rng='philox')
+    cy = cybersecurity_v0.parallel_env(configuration=configs.cyber_openness(), parallel_envs=B, max_steps=5, device=torch.device('cuda'), rng='philox')
+    wf.reset(seed=torch.arange(B, dtype=torch.int32))
+    handle, A = wf._handle.value, len(wf.agents)
+    acts = torch.zeros((A, B, 2), dtype=torch.int32, device='cuda')
+    ops.wildfire_step(wf._arena, handle, acts, 1, None, None, A, B, 6)  # the well-formed call
+    with pytest.raises(RuntimeError, match='not a live wildfire env handle'):
+        ops.wildfire_step(wf._arena, handle + 64, acts, 1, None, None, A, B, 6)
+    with pytest.raises(RuntimeError, match='not a live wildfire env handle'):
+        ops.wildfire_reset(wf._arena, cy._handle.value)  # a live handle, of another domain
+    with pytest.raises(RuntimeError, match='not bound to this arena'):
+        ops.wildfire_reset(other._arena, handle)
+    with pytest.raises(RuntimeError, match="are not the handle's"):
+        ops.wildfire_step(wf._arena, handle, acts, 1, None, None, A, B * 2, 6)
+    with pytest.raises(RuntimeError, match='actions must be'):
+        ops.wildfire_step(wf._arena, handle, acts[:, :B // 2].contiguous(), 1, None, None, A, B, 6)
+    dead = wildfire_v0.parallel_env(configuration=configs.wildfire_openness(), parallel_envs=B, max_steps=5, device=torch.device('cuda'), rng='philox')
+    stale, arena = dead._handle.value, dead._arena
+    del dead  # frz_wildfire_destroy unregisters the handle
+    import gc
+    gc.collect()
+    with pytest.raises(RuntimeError, match='not a live wildfire env handle'):
+        ops.wildfire_reset(arena, stale)
+    wf.check()
