@@ -65,6 +65,15 @@ struct CyLaunch {
     int32_t lut_entries;
     int32_t n_steps;       // multi-step launches (cy_roles_kernel<..., PERSIST>): steps of the rollout this launch performs
     int64_t copy_delta;    // multi-step launches: byte distance from the packed action-mapping values to their second copy
+    // frz_cybersecurity_rollout (cy_roles_kernel<..., PERSIST, EXTRA>): what drives the steps and what they leave besides the last step's outputs
+    uint32_t rollout_flags;     // FRZ_ROLLOUT_RESET_FIRST
+    uint32_t pad_;
+    int64_t tape_actions_step;  // elements between two steps of the action tape (`actions` = its step 0); 0: no tape
+    int64_t list_record_delta;  // bytes from the arena's list block (off_act_values) to step 0's copy in the list record; 0: none
+    int64_t list_record_step;
+    float* reward_tape;         // optional float32 [n_steps][A][B]
+    uint8_t* done_tape;         // optional uint8 [n_steps][2][B]
+    int64_t actions_out_step;   // elements between two steps of actions_out (0: one buffer)
 };
 
 // (plain stores: written through, frz_device.h, the rows of this kernel gained nothing — 11.4 vs 11.3 us — most of its bytes are
@@ -562,12 +571,16 @@ constexpr int kRoleBlock = 2 * kBlock;
 // outputs are rewritten by the same workgroup every step; the packed action mappings go to the caller's buffers at the last step only
 // and to a second copy, which nobody reads, before it; the batch totals of the step that just ended (all-truncated test) arrive as the
 // last chunk's inclusive-prefix granules — requested at the top of a step, looked at before the step's first store.
-template <int NMAX, int AMAX, int ATT, int RNG, bool PERSIST = false>
+// EXTRA (multi-step launches): the options of a frz_rollout_spec beyond the plain random-policy rollout — an action tape, randomness tapes
+// (FRZ_RNG_INJECTED), reward / done / action records, the list record, the opening reset — as a separate instantiation (see wildfire_roles.inl).
+template <int NMAX, int AMAX, int ATT, int RNG, bool PERSIST = false, bool EXTRA = false>
 __global__ void __launch_bounds__(kRoleBlock, 2) cy_roles_kernel(char* __restrict__ arena, const CyDev* __restrict__ dev,
                                                               const int32_t* __restrict__ actions, const float* __restrict__ net_rand,
                                                               const float* __restrict__ agent_rand, const CyLaunch L) {
     static_assert(AMAX <= 8, "the danger table is staged with one load per state-role thread");
-    static_assert(!PERSIST || RNG == FRZ_RNG_PHILOX, "multi-step launches draw with Philox");
+    static_assert(!PERSIST || RNG == FRZ_RNG_PHILOX || (RNG == FRZ_RNG_INJECTED && EXTRA), "multi-step launches draw with Philox, or from tapes");
+    static_assert(!EXTRA || PERSIST, "the rollout options belong to the multi-step launch");
+    const bool reset_first = EXTRA && (L.rollout_flags & FRZ_ROLLOUT_RESET_FIRST) != 0;
     __shared__ frz::ScanShared<AMAX> s_scan;
     __shared__ int s_ticket;
     __shared__ float s_lut[1 << AMAX];
@@ -604,7 +617,7 @@ __global__ void __launch_bounds__(kRoleBlock, 2) cy_roles_kernel(char* __restric
     uint32_t trunc_raw = 0;
     int2 act_in[AMAX];
     float r_in[NMAX + AMAX];
-    const int nm_in = at32(rows, (uint32_t)r_moves * Bu + bl);
+    const int nm_in = reset_first ? 0 : (int)at32(rows, (uint32_t)r_moves * Bu + bl);
     const uint32_t seed = (RNG == FRZ_RNG_PHILOX || L.policy) ? (uint32_t)at32(rows, (uint32_t)r_seeds * Bu + bl) : 0u;
     int mti = 0;
     if (!view) {
@@ -642,8 +655,20 @@ __global__ void __launch_bounds__(kRoleBlock, 2) cy_roles_kernel(char* __restric
     const uint32_t flags = d.flags;
     ws.agg = reinterpret_cast<uint64_t*>(arena + d.off_agg);
     ws.prefix = reinterpret_cast<uint64_t*>(arena + d.off_prefix);
+    if constexpr (EXTRA) {
+        if (reset_first && !view) {  // cybersecurity.py:218-266 + utils/env.py:137-160, in registers (the rows are written by the first step)
+#pragma unroll
+            for (int n = 0; n < NMAX; ++n) state[n] = cfg_lds->initial_state[n < N ? n : 0];
+#pragma unroll
+            for (int k = 0; k < AMAX; ++k) loc[k] = cfg_lds->initial_location[k < D ? k : 0], last[k] = -2;
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a) pres_raw[a] = cfg_lds->initial_presence[a < A ? a : 0] != 0 ? 1u : 0u, cum_in[a] = 0.0f;
+            trunc_raw = 0;
+            if (active) at32(rows1, (uint32_t)d.u_frozen * Bu + bl) = 0;
+        }
+    }
 
-    if (launch.prev[A] == 0u || launch.prev[A + 1] == 0u) {  // frozen batch (utils/env.py:211-213): see cy_step_kernel
+    if (!reset_first && (launch.prev[A] == 0u || launch.prev[A + 1] == 0u)) {  // frozen batch (utils/env.py:211-213): see cy_step_kernel
         if (!view && active && !at32(rows1, (uint32_t)d.u_frozen * Bu + bl)) {
             for (int a = 0; a < A; ++a) {
                 const float r = at32(rowsf, (uint32_t)(d.r_rewards + a) * Bu + bl);
@@ -700,6 +725,14 @@ __global__ void __launch_bounds__(kRoleBlock, 2) cy_roles_kernel(char* __restric
             const int nm_step = nm_in + t;
             // ---------------------------------------------------------------- the step's draws (streams: cy_step_kernel above)
             if (RNG == FRZ_RNG_INJECTED) {
+                if constexpr (EXTRA) {
+                    if (t > 0) {  // the randomness tapes' next pair
+#pragma unroll
+                        for (int n = 0; n < NMAX; ++n) r_in[n] = net_rand[((int64_t)t * B + bl) * N + min(n, N - 1)];
+#pragma unroll
+                        for (int a = 0; a < AMAX; ++a) r_in[NMAX + a] = agent_rand[((int64_t)t * B + bl) * A + min(a, A - 1)];
+                    }
+                }
 #pragma unroll
                 for (int k = 0; k < NMAX + AMAX; ++k) s_draw[k][tid] = r_in[k];
             } else if constexpr (RNG == FRZ_RNG_MT19937) {
@@ -877,10 +910,10 @@ __global__ void __launch_bounds__(kRoleBlock, 2) cy_roles_kernel(char* __restric
 #pragma unroll
     for (int a = 0; a < AMAX; ++a) excl[a] = 0;
     // action mapping: arange(N) while present, empty otherwise (:441-457); `copy`: byte distance to the copy of the packed values to write
-    auto emit_mappings = [&](int64_t copy) {
+    auto emit_mappings = [&](int64_t copy, int64_t ocopy) {
         if (active) {
             int32_t* const act_values = reinterpret_cast<int32_t*>(arena + d.off_act_values + copy);
-            int64_t* const act_offsets = reinterpret_cast<int64_t*>(arena + d.off_act_offsets);
+            int64_t* const act_offsets = reinterpret_cast<int64_t*>(arena + d.off_act_offsets + ocopy);
 #pragma unroll
             for (int a = 0; a < AMAX; ++a) {
                 if (a < A) {
@@ -898,12 +931,24 @@ __global__ void __launch_bounds__(kRoleBlock, 2) cy_roles_kernel(char* __restric
         }
     };
     for (int t = 0; t < n_steps; ++t) {
-        const int64_t copy = (PERSIST && t < n_steps - 1) ? L.copy_delta : (int64_t)0;  // the caller's buffers at the last step only
+        // the caller's buffers at the last step only; before it the second copy, or — with a list record — that step's copy of the whole
+        // list block, offsets included
+        const bool recorded = EXTRA && L.list_record_delta != 0 && t < n_steps - 1;
+        const int64_t copy = (PERSIST && t < n_steps - 1) ? (recorded ? L.list_record_delta + (int64_t)t * L.list_record_step : L.copy_delta) : (int64_t)0;
+        const int64_t ocopy = recorded ? copy : (int64_t)0;
         if constexpr (PERSIST) {
             if (t > 0) {
                 request_totals();
 #pragma unroll
                 for (int a = 0; a < AMAX; ++a) act_in[a] = make_int2(0, -1);
+                if constexpr (EXTRA) {
+                    if (!L.policy) {  // the action tape's next step
+                        const int2* const tape = reinterpret_cast<const int2*>(actions + (int64_t)t * L.tape_actions_step);
+#pragma unroll
+                        for (int a = 0; a < AMAX; ++a)
+                            if (a < A) act_in[a] = tape[(int64_t)a * B + bl];
+                    }
+                }
             }
         }
 
@@ -996,13 +1041,14 @@ __global__ void __launch_bounds__(kRoleBlock, 2) cy_roles_kernel(char* __restric
                     }
                     at32(rows1, (uint32_t)d.u_frozen * Bu + bl) = 1;
                 }
-                emit_mappings(0);  // the last mappings went to the second copy: once more, into the caller's buffers
+                emit_mappings(0, 0);  // the last mappings went to the second copy: once more, into the caller's buffers
                 break;
             }
             if (L.policy && active) {
+                int2* const out = reinterpret_cast<int2*>(L.actions_out + (EXTRA ? (int64_t)t * L.actions_out_step : (int64_t)0));
 #pragma unroll
                 for (int a = 0; a < AMAX; ++a)
-                    if (a < A) reinterpret_cast<int2*>(L.actions_out)[(int64_t)a * B + b] = act_in[a];
+                    if (a < A) out[(int64_t)a * B + b] = act_in[a];
             }
         }
         // ------------------------------------------------- presence (transitions/presence.py:46-58), same draw for both tests
@@ -1070,6 +1116,9 @@ __global__ void __launch_bounds__(kRoleBlock, 2) cy_roles_kernel(char* __restric
                     const float r = a < Att ? __fadd_rn(rew[a], __fmul_rn(net_reward, -1.0f)) : __fadd_rn(rew[a], net_reward);
                     at32(rows1, (uint32_t)(d.u_presence + a) * Bu + bl) = (uint8_t)pres[a];
                     at32(rowsf, (uint32_t)(d.r_rewards + a) * Bu + bl) = r;
+                    if constexpr (EXTRA) {
+                        if (L.reward_tape != nullptr) L.reward_tape[((int64_t)t * A + a) * B + bl] = r;
+                    }
                     if (flags & kTruncate) at32(rows1, (uint32_t)(d.u_trunc + a) * Bu + bl) = (uint8_t)trunc;
                     if (flags & kTrackCumulative) {
                         const float total = __fadd_rn(cum_in[a], r);
@@ -1079,12 +1128,18 @@ __global__ void __launch_bounds__(kRoleBlock, 2) cy_roles_kernel(char* __restric
                     at32(rows, (uint32_t)(d.r_atc + a) * Bu + bl) = pres[a] ? N : 0;
                 }
             at32(rows, (uint32_t)d.r_moves * Bu + bl) = nm;
+            if constexpr (EXTRA) {
+                if (L.done_tape != nullptr) {  // terminations never set (cybersecurity.py:298)
+                    L.done_tape[((int64_t)t * 2 + 0) * B + bl] = (uint8_t)0;
+                    L.done_tape[((int64_t)t * 2 + 1) * B + bl] = (uint8_t)trunc;
+                }
+            }
         }
         {
             const frz::ScanLaunch step{epoch_now, epoch_now + 1u, nullptr, ws.totals + (epoch_now & 1u) * frz::kTotalsStride};
             frz::scan_chunk<AMAX>(s_scan, ws, step, cnt, active, active && !trunc, A, chunk, nchunks, excl, &err);
         }
-        emit_mappings(copy);
+        emit_mappings(copy, ocopy);
         executed = t + 1;
     }  // steps of this launch
     if (err) atomicOr(reinterpret_cast<uint32_t*>(arena + d.off_error), err);
@@ -1141,6 +1196,13 @@ struct frz_cybersecurity_env {
     bool exclusive_device = false;
     int64_t copy_delta = 0;
     int32_t rollout_steps = 1;
+    struct RolloutOptions {  // frz_cybersecurity_rollout: the options of the multi-step launch being enqueued
+        bool extra = false;
+        uint32_t flags = 0;
+        int64_t tape_actions_step = 0, list_record_delta = 0, list_record_step = 0, actions_out_step = 0;
+        float* reward_tape = nullptr;
+        uint8_t* done_tape = nullptr;
+    } rollout;
 };
 
 namespace {
@@ -1165,11 +1227,17 @@ void launch_variant(frz_cybersecurity_env* env, const int32_t* actions, const fl
     const CyDev& p = env->dev;
     const CyLaunch L{p.B, p.N, p.Att, p.D, p.A, env->ticketed ? 1u : 0u, p.off_rows1, p.off_epoch, p.off_totals, policy.on ? 1u : 0u,
                      (uint32_t)policy.seed, (uint32_t)(policy.seed >> 32), (uint32_t)policy.step, (uint32_t)(policy.step >> 32), policy.actions_out,
-                     p.off_mt_state, p.off_lut, p.lut_entries, env->rollout_steps, env->copy_delta};
+                     p.off_mt_state, p.off_lut, p.lut_entries, env->rollout_steps, env->copy_delta,
+                     env->rollout.flags, 0u, env->rollout.tape_actions_step, env->rollout.list_record_delta, env->rollout.list_record_step,
+                     env->rollout.reward_tape, env->rollout.done_tape, env->rollout.actions_out_step};
     if constexpr (NMAX <= 8) {
         if (mode == kStep && env->roles) {  // state / view roles: two wavefronts per 64 envs (cy_roles_kernel)
             const dim3 wide(kRoleBlock);
-            if (rng == FRZ_RNG_PHILOX && env->rollout_steps > 1)
+            if (rng == FRZ_RNG_INJECTED && env->rollout_steps > 1)
+                hipLaunchKernelGGL((cy_roles_kernel<NMAX, AMAX, ATT, FRZ_RNG_INJECTED, true, true>), grid, wide, 0, stream, env->arena, dev, actions, nr, ar, L);
+            else if (rng == FRZ_RNG_PHILOX && env->rollout_steps > 1 && env->rollout.extra)
+                hipLaunchKernelGGL((cy_roles_kernel<NMAX, AMAX, ATT, FRZ_RNG_PHILOX, true, true>), grid, wide, 0, stream, env->arena, dev, actions, nr, ar, L);
+            else if (rng == FRZ_RNG_PHILOX && env->rollout_steps > 1)
                 hipLaunchKernelGGL((cy_roles_kernel<NMAX, AMAX, ATT, FRZ_RNG_PHILOX, true>), grid, wide, 0, stream, env->arena, dev, actions, nr, ar, L);
             else if (rng == FRZ_RNG_PHILOX)
                 hipLaunchKernelGGL((cy_roles_kernel<NMAX, AMAX, ATT, FRZ_RNG_PHILOX>), grid, wide, 0, stream, env->arena, dev, actions, nr, ar, L);
@@ -1462,7 +1530,8 @@ int frz_cybersecurity_set_exclusive_device(frz_cybersecurity_env* env, int exclu
 
 int frz_cybersecurity_rollout_launches(const frz_cybersecurity_env* env, int32_t n_steps, int rng_mode) {
     if (!env || n_steps < 0) return FRZ_E_INVALID;
-    const bool one = n_steps > 1 && env->exclusive_device && env->roles && env->copy_delta != 0 && !env->ticketed && rng_mode == FRZ_RNG_PHILOX;
+    const bool one = n_steps > 1 && env->exclusive_device && env->roles && env->copy_delta != 0 && !env->ticketed &&
+                     (rng_mode == FRZ_RNG_PHILOX || rng_mode == FRZ_RNG_INJECTED);
     return one ? 1 : n_steps;
 }
 
@@ -1481,6 +1550,82 @@ int frz_cybersecurity_rollout_random_policy(frz_cybersecurity_env* env, uint64_t
     for (int32_t t = 0; t < n_steps; ++t) {
         const int rc = frz_cybersecurity_step_random_policy(env, policy_seed, first_step + (uint64_t)t, actions_out, rng_mode, nullptr, nullptr, stream);
         if (rc != FRZ_OK) return rc;
+    }
+    return FRZ_OK;
+}
+
+int frz_cybersecurity_list_block(const frz_cybersecurity_env* env, void** block, int64_t* bytes) {
+    if (!env || !block || !bytes) return FRZ_E_INVALID;
+    if (!env->arena) return FRZ_E_UNBOUND;
+    *block = env->arena + env->dev.off_act_values;
+    *bytes = env->dev.off_obs_map - env->dev.off_act_values;
+    return FRZ_OK;
+}
+
+int frz_cybersecurity_rollout(frz_cybersecurity_env* env, const frz_rollout_spec* spec, void* stream) {
+    if (!env || !spec || spec->n_steps < 0) return FRZ_E_INVALID;
+    if (!env->arena) return FRZ_E_UNBOUND;
+    if (!env->was_reset) return FRZ_E_INVALID;
+    const CyDev& p = env->dev;
+    const int mode = spec->rng_mode;
+    const bool policy = spec->action_tape == nullptr, reset_first = (spec->flags & FRZ_ROLLOUT_RESET_FIRST) != 0;
+    if (mode != FRZ_RNG_INJECTED && mode != FRZ_RNG_PHILOX && mode != FRZ_RNG_MT19937) return FRZ_E_INVALID;
+    if (mode == FRZ_RNG_INJECTED && spec->n_steps > 0 && (!spec->randomness_tape_a || !spec->randomness_tape_b)) return FRZ_E_INVALID;
+    if (policy && !spec->actions_out) return FRZ_E_INVALID;
+    if ((spec->flags & FRZ_ROLLOUT_AUTO_RESET) || spec->metrics) return FRZ_E_INVALID;  // (episodes end together here: cybersecurity.py:298; no metrics entry)
+    if (spec->n_steps == 0) return reset_first ? frz_cybersecurity_reset(env, stream) : FRZ_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t B = p.B, A = p.A, N = p.N, AB2 = A * B * 2;
+    const int64_t block_bytes = p.off_obs_map - p.off_act_values;
+
+    if (frz_cybersecurity_rollout_launches(env, spec->n_steps, mode) == 1) {  // ONE multi-step launch
+        frz_cybersecurity_env::RolloutOptions& o = env->rollout;
+        o.extra = !policy || spec->list_record || spec->reward_tape || spec->done_tape || spec->record_actions || reset_first;
+        o.flags = spec->flags;
+        o.tape_actions_step = policy ? 0 : AB2;
+        o.list_record_delta = spec->list_record ? static_cast<char*>(spec->list_record) - (env->arena + p.off_act_values) : 0;
+        o.list_record_step = block_bytes;
+        o.reward_tape = spec->reward_tape, o.done_tape = spec->done_tape;
+        o.actions_out_step = spec->record_actions ? AB2 : 0;
+        env->rollout_steps = spec->n_steps;
+        int rc;
+        if (policy)
+            rc = frz_cybersecurity_step_random_policy(env, spec->policy_seed, spec->first_step, spec->actions_out, mode, spec->randomness_tape_a,
+                                                      spec->randomness_tape_b, stream);
+        else
+            rc = frz_cybersecurity_step(env, spec->action_tape, mode, spec->randomness_tape_a, spec->randomness_tape_b, stream);
+        env->rollout_steps = 1;
+        o = frz_cybersecurity_env::RolloutOptions();
+        return rc;
+    }
+    // the same step by step
+    if (reset_first) {
+        const int rc = frz_cybersecurity_reset(env, stream);
+        if (rc != FRZ_OK) return rc;
+    }
+    for (int32_t t = 0; t < spec->n_steps; ++t) {
+        const float* ra = spec->randomness_tape_a ? spec->randomness_tape_a + (int64_t)t * B * N : nullptr;
+        const float* rb = spec->randomness_tape_b ? spec->randomness_tape_b + (int64_t)t * B * A : nullptr;
+        int rc;
+        if (policy)
+            rc = frz_cybersecurity_step_random_policy(env, spec->policy_seed, spec->first_step + (uint64_t)t,
+                                                      spec->actions_out + (spec->record_actions ? (int64_t)t * AB2 : 0), mode, ra, rb, stream);
+        else
+            rc = frz_cybersecurity_step(env, spec->action_tape + (int64_t)t * AB2, mode, ra, rb, stream);
+        if (rc != FRZ_OK) return rc;
+        bool ok = true;
+        if (spec->reward_tape)
+            ok = ok && hipMemcpyAsync(spec->reward_tape + (int64_t)t * A * B, env->arena + p.off_rows4 + (int64_t)p.r_rewards * B * 4, (size_t)(A * B * 4),
+                                      hipMemcpyDeviceToDevice, s) == hipSuccess;
+        if (spec->done_tape) {
+            ok = ok && hipMemsetAsync(spec->done_tape + ((int64_t)t * 2 + 0) * B, 0, (size_t)B, s) == hipSuccess;
+            ok = ok && hipMemcpyAsync(spec->done_tape + ((int64_t)t * 2 + 1) * B, env->arena + p.off_rows1 + (int64_t)p.u_trunc * B, (size_t)B,
+                                      hipMemcpyDeviceToDevice, s) == hipSuccess;
+        }
+        if (spec->list_record && t < spec->n_steps - 1)
+            ok = ok && hipMemcpyAsync(static_cast<char*>(spec->list_record) + (int64_t)t * block_bytes, env->arena + p.off_act_values, (size_t)block_bytes,
+                                      hipMemcpyDeviceToDevice, s) == hipSuccess;
+        if (!ok) return FRZ_E_LAUNCH;
     }
     return FRZ_OK;
 }

@@ -324,6 +324,18 @@ class raw_env(BatchedParallelEnv):
                         'frz_cybersecurity_rollout_random_policy')
         return graph
 
+    def _fused_rng_mode(self) -> int:
+        if self.rng != 'mt19937':
+            return _capi.FRZ_RNG_PHILOX
+        if self.single_seeding or self.generator.buffer_size:
+            raise NotImplementedError('fused rollouts need the per-env device streams (no single_seeding / buffer_size)')
+        self.generator._ensure_streams()
+        return _capi.FRZ_RNG_MT19937
+
+    def _check_randomness_tapes(self, steps: int, a: torch.Tensor, b: torch.Tensor) -> None:
+        if a.numel() != steps * self.parallel_envs * self._N or b.numel() != steps * self.parallel_envs * len(self.agents):
+            raise ValueError('randomness tapes must hold [steps, B, N] and [steps, B, A] float32 values')
+
     def set_exclusive_device(self, exclusive: bool = True) -> None:
         """State that nothing else uses this GPU while the env's rollouts run: allows ``rollout_random_policy`` / ``capture_random_rollout`` to
         run a rollout as ONE launch (include/frz.h: frz_cybersecurity_set_exclusive_device; see the wildfire env).  Off by default."""

@@ -472,6 +472,13 @@ int frz_cybersecurity_step_random_policy(frz_cybersecurity_env* env, uint64_t po
  * frz_wildfire_rollout_random_policy / frz_wildfire_set_exclusive_device: same scheme, same precondition). */
 int frz_cybersecurity_rollout_random_policy(frz_cybersecurity_env* env, uint64_t policy_seed, uint64_t first_step, int32_t n_steps,
                                             int32_t* actions_out, int rng_mode, void* stream);
+/* n_steps steps driven by a frz_rollout_spec (see frz_wildfire_rollout): an action tape or the in-kernel uniform policy, FRZ_RNG_INJECTED tapes
+ * (network float32 [n_steps][B][N], agent float32 [n_steps][B][A]), FRZ_ROLLOUT_RESET_FIRST, reward / done / action records and the list record
+ * (frz_cybersecurity_list_block: act_map_values, act_map_offsets).  Episodes of this domain end together (truncation only,
+ * cybersecurity.py:298): FRZ_ROLLOUT_AUTO_RESET and `metrics` are refused (FRZ_E_INVALID).  ONE multi-step launch for shapes up to 8 nodes / 8
+ * agents with FRZ_RNG_PHILOX or FRZ_RNG_INJECTED after frz_cybersecurity_set_exclusive_device, otherwise one launch per step. */
+int frz_cybersecurity_rollout(frz_cybersecurity_env* env, const frz_rollout_spec* spec, void* stream);
+int frz_cybersecurity_list_block(const frz_cybersecurity_env* env, void** block, int64_t* bytes);
 int frz_cybersecurity_set_exclusive_device(frz_cybersecurity_env* env, int exclusive);
 int frz_cybersecurity_rollout_launches(const frz_cybersecurity_env* env, int32_t n_steps, int rng_mode);
 

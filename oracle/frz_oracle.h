@@ -186,6 +186,8 @@ void frz_oracle_wildfire_philox_randomness(const frz_wildfire_cfg* cfg, const in
 void frz_oracle_wildfire_random_policy(const frz_wildfire_cfg* cfg, const int32_t* agent_task_count, const int64_t* env_task_count,
                                        const int32_t* env_seeds, uint64_t seed, uint64_t step, int32_t* actions);
 
+int frz_oracle_cybersecurity_rollout(const frz_cybersecurity_cfg* cfg, frz_oracle_cybersecurity_bufs* s, const int32_t* env_seeds, uint64_t policy_seed,
+                                     uint64_t first_step, int32_t n_steps, int32_t* actions, float* network, float* agent);
 /* n_steps x (random policy, Philox randomness, step) in one call (bench.py's cpu_baseline threads) */
 int frz_oracle_wildfire_rollout(const frz_wildfire_cfg* cfg, frz_oracle_wildfire_bufs* s, const int32_t* env_seeds, uint64_t policy_seed,
                                 uint64_t first_step, int32_t n_steps, int32_t* actions, float* field, float* agent);

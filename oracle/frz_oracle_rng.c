@@ -362,6 +362,20 @@ void frz_oracle_cyber_focus_policy(const int64_t* tasks, int64_t env_stride, int
  * frz_oracle_wildfire_step: the loop tests/ and bench.py otherwise drive from Python, one call per episode so that many host
  * threads can each step their own shard without meeting on the interpreter lock.  actions int32 [A][B][2], field float32
  * [3][B][H*W], agent float32 [5][B][A]: caller-provided scratch.  Returns the number of steps taken, or a negative error. */
+/* the cybersecurity twin: n_steps x (uniform random policy of spaces/actions.py:11-99 on the stream of frz_cybersecurity_random_policy, the
+ * step's FRZ_RNG_PHILOX randomness, frz_oracle_cybersecurity_step) — the loop `env.step({a: action_space(a).sample_nested()})` of
+ * baselines/random.py:20 that frz_cybersecurity_rollout enqueues as one launch */
+int frz_oracle_cybersecurity_rollout(const frz_cybersecurity_cfg* cfg, frz_oracle_cybersecurity_bufs* s, const int32_t* env_seeds, uint64_t policy_seed,
+                                     uint64_t first_step, int32_t n_steps, int32_t* actions, float* network, float* agent) {
+    for (int32_t t = 0; t < n_steps; ++t) {
+        frz_oracle_cybersecurity_random_policy(cfg, s->agent_task_count, s->location, env_seeds, policy_seed, first_step + (uint64_t)t, actions);
+        frz_oracle_cybersecurity_philox_randomness(cfg, env_seeds, s->num_moves, network, agent);
+        const int rc = frz_oracle_cybersecurity_step(cfg, s, actions, network, agent);
+        if (rc != 0) return rc < 0 ? rc : -rc;
+    }
+    return n_steps;
+}
+
 int frz_oracle_wildfire_rollout(const frz_wildfire_cfg* cfg, frz_oracle_wildfire_bufs* s, const int32_t* env_seeds, uint64_t policy_seed,
                                 uint64_t first_step, int32_t n_steps, int32_t* actions, float* field, float* agent) {
     for (int32_t t = 0; t < n_steps; ++t) {

@@ -314,6 +314,16 @@ class CybersecurityOracle(_ArrayOracle):
         assert actions.shape == (A, B, 2) and nr.size == B * N and ar.size == B * A
         assert lib().frz_oracle_cybersecurity_step(ctypes.byref(self.cfg), ctypes.byref(self.bufs), _ptr(actions), _ptr(nr), _ptr(ar)) == 0
 
+    def rollout(self, env_seeds: np.ndarray, policy_seed: int, first_step: int, n_steps: int) -> int:
+        """``n_steps`` x (uniform random policy, the step's Philox randomness, step) in one C call."""
+        B, N, A = self.cfg.parallel_envs, self.cfg.num_nodes, self.cfg.num_attackers + self.cfg.num_defenders
+        actions, network, agent = np.zeros((A, B, 2), np.int32), np.zeros((1, B, N), np.float32), np.zeros((1, B, A), np.float32)
+        seeds = np.ascontiguousarray(env_seeds, np.int32)
+        done = lib().frz_oracle_cybersecurity_rollout(ctypes.byref(self.cfg), ctypes.byref(self.bufs), _ptr(seeds), ctypes.c_uint64(policy_seed),
+                                                      ctypes.c_uint64(first_step), ctypes.c_int32(n_steps), _ptr(actions), _ptr(network), _ptr(agent))
+        assert done == n_steps, done
+        return done
+
     def action_map(self, a):
         off = self.act_map_offsets[a]
         return self.act_map_values[a, :int(off[-1])], off

@@ -358,3 +358,123 @@ def test_masked_reset_of_the_finished_envs_in_every_kernel_family(oracle, family
             G.assert_same(np_(env.seeds), s, 'seeds')
     compare_snapshots(hip_snapshot(env), oracle_snapshot(o), f'{family}: end')
     env.check()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# 6. cybersecurity: the multi-step launch against the oracle and the reference's recorded trajectories
+# ------------------------------------------------------------------------------------------------------------
+def cyber_list_views(env, block: np.ndarray):
+    A, B, N = len(env.agents), env.parallel_envs, env._N
+    base = env._arena.data_ptr() + env._list_block_offset
+    values = block[env._bufs.act_map_values - base:][:A * B * N * 4].view(np.int32).reshape(A, B * N)
+    offsets = block[env._bufs.act_map_offsets - base:][:A * (B + 1) * 8].view(np.int64).reshape(A, B + 1)
+    return {f'act_map_offsets_{a}': offsets[a] for a in range(A)} | {f'act_map_values_{a}': values[a, :int(offsets[a, -1])] for a in range(A)}
+
+
+@pytest.mark.parametrize('case', [dict(B=65536, max_steps=50, steps=50, kwargs={}),                       # cfg4 as bench.py's secondary workload runs it
+                                  dict(B=1000, max_steps=30, steps=34, kwargs={}),                          # ragged, past the horizon
+                                  dict(B=2500, max_steps=40, steps=21, kwargs=dict(show_bad_actions=False, observe_other_presence=True))],
+                         ids=['cfg4_B65536', 'ragged_past_the_horizon', 'no_bad_actions'])
+def test_cybersecurity_multi_step_launch_against_the_oracle(oracle, case):
+    """frz_cybersecurity_rollout as ONE launch vs the oracle's steps (frz_oracle_cybersecurity_rollout's loop, unrolled here to look at every
+    step): sampled actions, rewards, truncations and action mappings of every step, then the whole final state."""
+    import test_hip_cybersecurity as C
+    from free_range_zoo_amd.envs.cybersecurity.env.structures.configuration import to_cstruct
+    B, steps, kwargs = case['B'], case['steps'], case['kwargs']
+    flags = dict(configs.CYBER_DEFAULT_FLAGS)
+    flags.update(kwargs)
+    cfg = to_cstruct(configs.cyber_openness(), B, case['max_steps'], **flags)
+    env = C.make_env(configs.cyber_openness, B, case['max_steps'], rng='philox', **kwargs)
+    env.set_exclusive_device(True)
+    assert env._lib.frz_cybersecurity_rollout_launches(env._handle, steps, _capi.FRZ_RNG_PHILOX) == 1
+    seeds = torch.arange(B, dtype=torch.int32) * 3 + 2
+    env.reset(seed=seeds)
+    rec = env.rollout(steps, policy_seed=31, record=True)
+    prepare(env, rec)
+    rewards, dones, actions, lists = (np_(rec[k]) for k in ('rewards', 'dones', 'actions', 'lists'))
+    o = oracle.CybersecurityOracle(cfg)
+    o.reset()
+    executed = 0
+    for t in range(steps):
+        if bool(o.truncations[0].all()):
+            break
+        acts = oracle.cybersecurity_random_policy(cfg, o.agent_task_count, o.location, seeds.numpy(), 31, t)
+        nr, ar = oracle.cybersecurity_philox_randomness(cfg, seeds.numpy(), o.num_moves)
+        o.step(acts, nr, ar)
+        executed = t + 1
+        G.assert_same(actions[t], acts, f'step {t} sampled actions')
+        G.assert_same(rewards[t], o.rewards, f'step {t} rewards')
+        G.assert_same(dones[t, 1].astype(bool), o.truncations[0].astype(bool), f'step {t} truncations')
+        assert not dones[t, 0].any()
+        if t < steps - 1 and not bool(o.truncations[0].all()):
+            got = cyber_list_views(env, lists[t])
+            for a in range(len(env.agents)):
+                v, off = o.action_map(a)
+                G.assert_same(got[f'act_map_offsets_{a}'], off, f'step {t} (list record) offsets of agent {a}')
+                G.assert_same(got[f'act_map_values_{a}'], v, f'step {t} (list record) values of agent {a}')
+    assert executed == min(steps, case['max_steps'])
+    if executed < steps:
+        A = len(env.agents)
+        o.step(np.zeros((A, B, 2), np.int32), np.zeros((1, B, cfg.num_nodes), np.float32), np.zeros((1, B, A), np.float32))
+    C.compare_snapshots(C.hip_snapshot(env), C.oracle_snapshot(o), f'after {steps} steps in one launch')
+    # the C twin of this loop (what a CPU baseline would time) ends in the same state
+    twin = oracle.CybersecurityOracle(cfg)
+    twin.reset()
+    twin.rollout(seeds.numpy(), 31, 0, steps)
+    assert np.array_equal(twin.network_state, o.network_state) and np.array_equal(twin.rewards, o.rewards)
+    env.check()
+
+
+@pytest.mark.parametrize('name', sorted(configs.CYBER_GOLDEN))
+def test_cybersecurity_golden_trajectory_through_the_multi_step_launch(name):
+    """The recorded trajectories of the unmodified reference through `rollout(actions=tape, randomness=tapes)`: the whole trajectory as one
+    launch (reward / truncation tapes compared step by step) and prefixes of 1 .. T steps against the reference's snapshot after each."""
+    import test_hip_cybersecurity as C
+    from test_oracle_cybersecurity import compare_cyber
+    build, kwargs = configs.CYBER_GOLDEN[name]
+    data = np.load(G.golden_path(f'traj_cybersecurity_{name}.npz'))
+    cfg = G.load_cfg(data, _capi.frz_cybersecurity_cfg)
+    B, N, A, T = cfg.parallel_envs, cfg.num_nodes, cfg.num_attackers + cfg.num_defenders, int(data['steps'])
+    env = C.make_env(build, B, None if cfg.max_steps < 0 else cfg.max_steps, **kwargs)
+    env.set_exclusive_device(True)
+    assert env._lib.frz_cybersecurity_rollout_launches(env._handle, T, _capi.FRZ_RNG_INJECTED) == (1 if max(N, A) <= 8 else T)
+    acts = np.zeros((T, A, B, 2), np.int32)
+    net, agent = np.zeros((T, B, N), np.float32), np.zeros((T, B, A), np.float32)
+    for t in range(T):
+        acts[t] = data[f's{t}_actions']
+        if bool(data[f's{t}_stepped']):
+            net[t], agent[t] = data[f's{t}_network_randomness'].reshape(B, N), data[f's{t}_agent_randomness'].reshape(B, A)
+    acts, net, agent = torch.from_numpy(acts).cuda(), torch.from_numpy(net).cuda(), torch.from_numpy(agent).cuda()
+    seeds = torch.arange(B, dtype=torch.int32)
+    env.reset(seed=seeds)
+    rec = env.rollout(T, actions=acts, randomness=(net, agent), record=True)
+    rewards, dones = np_(rec['rewards']), np_(rec['dones'])
+    for t in range(T):
+        if not bool(data[f's{t}_stepped']):
+            break
+        G.assert_same(rewards[t], data[f's{t}_rewards'], f'{name} step {t} reward tape', G.REWARD_RTOL)
+        G.assert_same(dones[t, 1].astype(bool), data[f's{t}_truncations'][0], f'{name} step {t} truncation tape')
+    compare_cyber(C.hip_snapshot(env), data, f's{T - 1}_', A, f'{name} after the whole trajectory in one launch')
+    for n in range(1, T + 1):
+        env.reset(seed=seeds)
+        env.rollout(n, actions=acts[:n].contiguous(), randomness=(net[:n].contiguous(), agent[:n].contiguous()))
+        compare_cyber(C.hip_snapshot(env), data, f's{n - 1}_', A, f'{name}: {n} steps in one launch')
+    env.check()
+
+
+def test_cybersecurity_rollout_with_the_reset_folded_in(oracle):
+    import test_hip_cybersecurity as C
+    from free_range_zoo_amd.envs.cybersecurity.env.structures.configuration import to_cstruct
+    B = 3000
+    cfg = to_cstruct(configs.cyber_openness(), B, 50, **configs.CYBER_DEFAULT_FLAGS)
+    env = C.make_env(configs.cyber_openness, B, 50, rng='philox')
+    env.set_exclusive_device(True)
+    seeds = torch.arange(B, dtype=torch.int32) + 7
+    env.reset(seed=seeds)
+    env.rollout(9, policy_seed=1)
+    env.rollout(17, policy_seed=2, reset_first=True)
+    o = oracle.CybersecurityOracle(cfg)
+    o.reset()
+    o.rollout(seeds.numpy(), 2, 0, 17)
+    C.compare_snapshots(C.hip_snapshot(env), C.oracle_snapshot(o), 'reset folded into the launch')
+    env.check()
