@@ -158,10 +158,13 @@ def secondary_workloads(device, B):
     batch, reported beside the headline (never part of `value`), each with its own roofline record: whole episodes replayed as HIP
     graphs for the rate, HIP events around an episode's steps for the step time, task counts averaged over the same episode."""
     import configs
-    from free_range_zoo_amd.envs import cybersecurity_v0, rideshare_v0
+    from free_range_zoo_amd.envs import cybersecurity_v0, rideshare_v0, wildfire_v0
     out = {}
     specs = (('cybersecurity_v0 cfg4 (3 nodes, 2+2 agents, agent openness on)', cybersecurity_v0, configs.cyber_openness(), 20),
-             ('rideshare_v0 cfg3 (10x10 grid, 8 agents, 2 passengers entering per step)', rideshare_v0, configs.rideshare_busy(), 5))
+             ('rideshare_v0 cfg3 (10x10 grid, 8 agents, 2 passengers entering per step)', rideshare_v0, configs.rideshare_busy(), 5),
+             # the wildfire scaling variants of SURVEY 8(d): grids beyond the bench shape run one env per wavefront (csrc/wildfire_grid.hip)
+             ('wildfire_v0 8x8 grid, 12 agents (every stochastic switch on)', wildfire_v0, configs.wildfire_grid(8, 8, 12), 5),
+             ('wildfire_v0 16x16 grid, 6 agents (every stochastic switch on)', wildfire_v0, configs.wildfire_grid(16, 16, 6), 5))
     for name, module, configuration, reps in specs:
         env = module.parallel_env(configuration=configuration, parallel_envs=B, max_steps=EPISODE, device=device, rng='philox', exact_shapes=False)
         env.reset(seed=torch.arange(B, dtype=torch.int32))
@@ -189,7 +192,12 @@ def secondary_workloads(device, B):
             sums[0] += env.environment_task_count.sum()
             sums[1] += env.agent_task_count.sum()
         mean_env, mean_agents = (sums / (EPISODE * B)).tolist()
-        if module is cybersecurity_v0:
+        if module is wildfire_v0:
+            HW = env.max_y * env.max_x
+            per_env = wildfire_bytes_per_env_step(HW, A, env._k, mean_env, mean_agents)
+            kernels = 'wg_env_kernel + wg_offsets_kernel + wg_emit_kernel (env per wavefront, cells across its lanes; policy sampled in the first launch)'
+            counts = {'mean_tasks_per_env': mean_env, 'mean_agent_tasks_per_env': mean_agents, 'cells': HW}
+        elif module is cybersecurity_v0:
             N = env.network_config.num_nodes
             Att, D = env.attacker_config.num_attackers, env.defender_config.num_defenders
             per_env = cybersecurity_bytes_per_env_step(N, Att, D, mean_agents / N)
@@ -200,7 +208,8 @@ def secondary_workloads(device, B):
             kernels = getattr(env, 'step_kernels', 'rs_step_kernel + rs_policy_kernel')
             counts = {'mean_passengers_per_env': mean_env, 'mean_visible_tasks_per_env_summed_over_agents': mean_agents}
         achieved = per_env * B / (step_ms * 1e-3) / 1e9
-        traffic, traffic_source = recorded_traffic(('cybersecurity' if module is cybersecurity_v0 else 'rideshare') + '_bytes_per_step')
+        traffic_key = {cybersecurity_v0: 'cybersecurity', rideshare_v0: 'rideshare'}.get(module, 'wildfire_grid_%dx%d' % (getattr(env, 'max_y', 0), getattr(env, 'max_x', 0)))
+        traffic, traffic_source = recorded_traffic(traffic_key + '_bytes_per_step')
         out[name] = {'env_steps_per_s': B * EPISODE / elapsed, 'ms_per_step': 1e3 * elapsed / EPISODE, 'parallel_envs': B, 'steps': EPISODE,
                      'episodes_timed': reps,
                      'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
