@@ -378,12 +378,13 @@ def main():
     # the drop-in API with its defaults (exact_shapes=True).  The samples are handed to step() untouched, so they are drawn inside the step
     # launch (utils/env.py LazySample): one launch per step; the per-episode reset and the finished test (one host read) are in the time.
     loop_env = wildfire_v0.parallel_env(configuration=configs.wildfire_openness(), parallel_envs=B, max_steps=EPISODE, device=device, rng=args.rng)
-    loop_seed = base_seed.to(device)
+    loop_seeds = [base_seed.to(device) + seed_stride * episode for episode in range(8)]  # (on the device: a reset does not cross PCIe)
+    torch.cuda.synchronize(device)
 
     def reference_loop(episodes):
         steps = 0
         for episode in range(episodes):
-            loop_env.reset(seed=loop_seed + seed_stride * episode)
+            loop_env.reset(seed=loop_seeds[episode])
             while True:
                 for _ in range(EPISODE):
                     loop_env.step({agent: loop_env.action_space(agent).sample_nested() for agent in loop_env.agents})
@@ -392,10 +393,10 @@ def main():
                     break
         return steps
 
-    reference_loop(1)
+    reference_loop(2)
     barrier()
     t2 = time.perf_counter()
-    loop_steps = reference_loop(6)
+    loop_steps = reference_loop(8)
     barrier()
     reference_loop_value = world * B * loop_steps / (time.perf_counter() - t2)
     del loop_env

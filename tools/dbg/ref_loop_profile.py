@@ -8,7 +8,7 @@ import torch, configs
 from free_range_zoo_amd.envs import wildfire_v0
 B = 65536
 env = wildfire_v0.parallel_env(configuration=configs.wildfire_openness(), parallel_envs=B, max_steps=50, device=torch.device('cuda'), rng='philox')
-seed = torch.arange(B, dtype=torch.int32)
+seed = torch.arange(B, dtype=torch.int32).cuda()
 
 
 def episode():

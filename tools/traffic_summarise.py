@@ -90,8 +90,13 @@ def rollout_launch(tagname, steps):
         files = glob.glob(os.path.join(src, f'pmc_{tagname}_{counter}', '**', '*counter_collection.csv'), recursive=True)
         if not files:
             return None
-        rows = [r for r in csv.DictReader(open(files[0])) if r['Counter_Name'] == counter and re.search(r'wf_roles_kernel<[^>]*(true|1)>', r['Kernel_Name'])
-                and re.search(r'wf_roles_kernel<([^>]*)>', r['Kernel_Name']).group(1).split(',')[4].strip() == '0']
+        def multi_step(name):  # wf_roles_kernel<CMAX, AMAX, EXACT, RNG, MODE, PERSIST, EXTRA>: a step-mode multi-step instantiation
+            m = re.search(r'wf_roles_kernel<([^>]*)>', name)
+            if not m:
+                return False
+            arguments = [a.strip() for a in m.group(1).split(',')]
+            return arguments[4] == '0' and len(arguments) > 5 and arguments[5] in ('true', '1')
+        rows = [r for r in csv.DictReader(open(files[0])) if r['Counter_Name'] == counter and multi_step(r['Kernel_Name'])]
         if len(rows) != 1:
             return None
         values[counter] = float(rows[0]['Counter_Value'])
