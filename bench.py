@@ -229,6 +229,8 @@ def main():
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='parallel_envs per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the cybersecurity / rideshare rollouts reported beside the headline')
+    ap.add_argument('--no-episode-probe', action='store_true', help='skip the whole-episode (50-step) launches timed beside the block\'s own launch and the '
+                    'auto-reset workload: a kernel trace of the run then shows the block\'s launch in a row of its own')
     args = ap.parse_args()
     if args.steps <= 0:
         raise SystemExit('--steps must be positive')
@@ -453,7 +455,7 @@ def main():
         for rep_i in range(12):
             env.reset(seed=base_seed + 17)
             block_launch_ms.append(timed_rollout(n_block, reset_first=reset_in_launch))
-            if n_block != EPISODE:
+            if n_block != EPISODE and not args.no_episode_probe:
                 env.reset(seed=base_seed + 17)
                 episode_launch_ms.append(timed_rollout(EPISODE, reset_first=reset_in_launch))
         block_launch_ms, episode_launch_ms = block_launch_ms[2:], episode_launch_ms[2:]  # (the first two: clocks and caches)
@@ -473,7 +475,7 @@ def main():
     # ---- continuous rollouts at fixed B: the same K-step block with device-side auto-reset instead of the episode structure
     # (an env that finishes is reset inside the step that finished it: no env idles extinguished until the episode's horizon)
     dense = None
-    if multi_step and args.rng == 'philox' and K > 1:
+    if multi_step and args.rng == 'philox' and K > 1 and not args.no_episode_probe:
         env.reset(seed=base_seed)
         dense_metrics = torch.zeros_like(metrics)
         dense_graph = env.capture_random_rollout(K, policy_seed=policy_seed, include_reset=False, seed_stride=seed_stride, metrics=dense_metrics,

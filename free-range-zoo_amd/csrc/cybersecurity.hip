@@ -1522,9 +1522,31 @@ static int step_impl(frz_cybersecurity_env* env, const int32_t* actions, int rng
     return launch(env, actions, network_randomness, agent_randomness, rng_mode, kStep, static_cast<hipStream_t>(stream), policy);
 }
 
+extern "C" int frz_exclusive_launch_fits(int64_t workgroups, int workgroups_per_cu, int compute_units, int cu_mask_set);
+
 int frz_cybersecurity_set_exclusive_device(frz_cybersecurity_env* env, int exclusive) {
     if (!env) return FRZ_E_INVALID;
-    env->exclusive_device = exclusive != 0;
+    if (!exclusive || !env->roles || env->copy_delta == 0) {  // switching off / no multi-step kernel for this shape: nothing to guard
+        env->exclusive_device = exclusive != 0;
+        return FRZ_OK;
+    }
+    // the library's own part of the residency promise (see frz_wildfire_set_exclusive_device): one 512-thread workgroup per chunk, all at once,
+    // on the device that owns the arena.  The multi-step instantiations need a whole CU's registers: one workgroup per CU.
+    int device = 0;
+    if (env->arena) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, env->arena) == hipSuccess) device = attr.device;
+        else (void)hipGetLastError();
+    } else if (hipGetDevice(&device) != hipSuccess) {
+        return FRZ_E_NODEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return FRZ_E_NODEVICE;
+    int cus = prop.multiProcessorCount;
+    if (const char* assumed = std::getenv("FRZ_ASSUME_COMPUTE_UNITS")) cus = std::atoi(assumed);
+    const bool masked = std::getenv("ROC_GLOBAL_CU_MASK") != nullptr || std::getenv("HSA_CU_MASK") != nullptr;
+    if (!frz_exclusive_launch_fits(env->dev.nchunks, 1, cus, masked ? 1 : 0)) return FRZ_E_INVALID;
+    env->exclusive_device = true;
     return FRZ_OK;
 }
 

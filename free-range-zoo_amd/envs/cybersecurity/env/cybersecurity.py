@@ -336,10 +336,11 @@ class raw_env(BatchedParallelEnv):
         if a.numel() != steps * self.parallel_envs * self._N or b.numel() != steps * self.parallel_envs * len(self.agents):
             raise ValueError('randomness tapes must hold [steps, B, N] and [steps, B, A] float32 values')
 
-    def set_exclusive_device(self, exclusive: bool = True) -> None:
-        """State that nothing else uses this GPU while the env's rollouts run: allows ``rollout_random_policy`` / ``capture_random_rollout`` to
-        run a rollout as ONE launch (include/frz.h: frz_cybersecurity_set_exclusive_device; see the wildfire env).  Off by default."""
-        _capi.check(self._lib.frz_cybersecurity_set_exclusive_device(self._handle, 1 if exclusive else 0), 'frz_cybersecurity_set_exclusive_device')
+    def set_exclusive_device(self, exclusive: bool = True) -> bool:
+        """State that nothing else uses this GPU while the env's rollouts run: allows ``rollout`` / ``rollout_random_policy`` /
+        ``capture_random_rollout`` to run a rollout as ONE launch (include/frz.h: frz_cybersecurity_set_exclusive_device; see the wildfire
+        env).  Off by default.  False: the library's own residency check refused (the rollouts keep taking one launch per step)."""
+        return self._lib.frz_cybersecurity_set_exclusive_device(self._handle, 1 if exclusive else 0) == 0
 
     @torch.no_grad()
     def rollout_random_policy(self, steps: int, policy_seed: int = 0, first_step: int = 0):

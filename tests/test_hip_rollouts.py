@@ -478,3 +478,37 @@ def test_cybersecurity_rollout_with_the_reset_folded_in(oracle):
     o.rollout(seeds.numpy(), 2, 0, 17)
     C.compare_snapshots(C.hip_snapshot(env), C.oracle_snapshot(o), 'reset folded into the launch')
     env.check()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# 7. the residency guard of set_exclusive_device
+# ------------------------------------------------------------------------------------------------------------
+def test_exclusive_device_is_refused_when_the_launch_would_not_fit(oracle, monkeypatch):
+    """The workgroups of a multi-step launch wait for each other inside the kernel, so all of them must be resident: the library checks its
+    own part (occupancy x compute units of the arena's device >= chunks, no CU mask) and refuses otherwise — rollouts then take one launch per
+    step, with the same results.  FRZ_ASSUME_COMPUTE_UNITS stands in for a smaller / partitioned device."""
+    import test_hip_cybersecurity as C
+    from free_range_zoo_amd.envs.wildfire.env.structures.configuration import to_cstruct
+    B = 8192  # 32 chunks
+    env = make_env(configs.wildfire_openness, B, 30, rng='philox')
+    cy = C.make_env(configs.cyber_openness, B, 30, rng='philox')
+    monkeypatch.setenv('FRZ_ASSUME_COMPUTE_UNITS', '16')
+    assert env.set_exclusive_device(True) is False and cy.set_exclusive_device(True) is False
+    assert env._lib.frz_wildfire_rollout_launches(env._handle, 10, _capi.FRZ_RNG_PHILOX) == 10
+    assert cy._lib.frz_cybersecurity_rollout_launches(cy._handle, 10, _capi.FRZ_RNG_PHILOX) == 10
+    monkeypatch.setenv('ROC_GLOBAL_CU_MASK', '0xffff')
+    monkeypatch.setenv('FRZ_ASSUME_COMPUTE_UNITS', '256')
+    assert env.set_exclusive_device(True) is False  # a CU mask: the reported properties cannot be trusted
+    monkeypatch.delenv('ROC_GLOBAL_CU_MASK')
+    seeds = torch.arange(B, dtype=torch.int32)
+    env.reset(seed=seeds)
+    monkeypatch.setenv('FRZ_ASSUME_COMPUTE_UNITS', '16')
+    assert env.set_exclusive_device(True) is False
+    env.rollout(12, policy_seed=3)  # launch per step
+    cfg = to_cstruct(configs.wildfire_openness(), B, 30)
+    o = oracle.WildfireOracle(cfg)
+    o.reset()
+    o.rollout(seeds.numpy(), 3, 0, 12)
+    compare_snapshots(hip_snapshot(env), oracle_snapshot(o), 'refused: one launch per step')
+    monkeypatch.setenv('FRZ_ASSUME_COMPUTE_UNITS', '64')
+    assert env.set_exclusive_device(True) is True and env._lib.frz_wildfire_rollout_launches(env._handle, 10, _capi.FRZ_RNG_PHILOX) == 1

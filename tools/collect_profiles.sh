@@ -21,6 +21,6 @@ python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-s
 python3 $GRAFT_REPO_ROOT/bench.py --rng mt19937 --no-cpu-baseline --no-secondary > $OUT/${TAG}_bench_mt19937.json 2> $OUT/bench_mt.err || echo "bench mt19937 failed"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_bench -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $OUT/trace_bench.log 2>&1 || echo "trace failed"
 cp $OUT/trace_bench/bench_kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_bench20 -o bench20 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $OUT/trace_bench20.log 2>&1 || echo "trace 20 failed"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_bench20 -o bench20 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-episode-probe > $OUT/trace_bench20.log 2>&1 || echo "trace 20 failed"
 cp $OUT/trace_bench20/bench20_kernel_stats.csv $OUT/${TAG}_bench_steps20_kernel_stats.csv 2>/dev/null
 ls $OUT

@@ -33,8 +33,8 @@ def per_step(domain, counter):
             total += float(r['Counter_Value'])
             steps += 50 if (len(arguments) > 5 and arguments[5] in ('true', '1')) else 1
             continue
-        roles = re.search(r'cy_roles_kernel<([^>]*)>', name)
-        if roles and roles.group(1).split(',')[-1].strip() in ('true', '1') and len(roles.group(1).split(',')) > 4:
+        roles = re.search(r'cy_roles_kernel<([^>]*)>', name)  # <NMAX, AMAX, ATT, RNG, PERSIST, EXTRA>
+        if roles and len(roles.group(1).split(',')) > 4 and roles.group(1).split(',')[4].strip() in ('true', '1'):
             total += float(r['Counter_Value'])
             steps += 50  # a multi-step launch carries the whole 50-step episode of tools/traffic_run.py
             continue
