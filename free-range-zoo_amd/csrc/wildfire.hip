@@ -1254,6 +1254,9 @@ int create_grid(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
     g.off_agent_table = take(sizeof(WgAgentTable));
     g.off_cell_tables = take((int64_t)5 * HW * 4);
     g.off_range = take((int64_t)A * S * chunks * 8);
+    g.off_litmap = take((int64_t)chunks * B * 8);
+    g.off_okmap = take((int64_t)A * chunks * B * 8);
+    g.off_lit_cells = take(B * (int64_t)((HW + 1) & ~1) * 8);
     p.off_obs_self = take((int64_t)A * B * 16);
     p.off_obs_others = take((int64_t)A * B * (A - 1) * ok * 4);
     p.off_task_offsets = take((B + 1) * 8);

@@ -235,7 +235,10 @@ struct WgDev {
         off_cell_tables /* float fire_rewards[HW]; int32 ignition[HW], initial fires[HW], initial intensity[HW], initial fuel[HW] */,
         off_range /* uint64 [A][S][chunks]: cells agent a reaches at equipment state s, bit i of chunk k = cell 64 k + i */,
         off_obs_self, off_obs_others, off_task_values, off_task_offsets, off_obs_map, off_act_values, off_act_offsets, off_bad_values,
-        off_bad_offsets, off_error, off_epoch, off_totals, off_agg, off_prefix;
+        off_bad_offsets, off_error, off_epoch, off_totals, off_agg, off_prefix,
+        off_litmap /* uint64 [chunks][B]: the lit cells (fires > 0) of every env as mask words, left by wg_env_kernel for wg_lists_kernel */,
+        off_okmap /* uint64 [A][chunks][B]: agent a's attackable cells (lit, in range at its equipment state, suppressant left) */,
+        off_lit_cells /* int2 [B][HW rounded up to even]: (fires, intensity) of env b's lit cells in row-major (= task) order */;
 };
 struct WgPolicy {  // the uniform random policy sampled inside the step launch
     uint32_t on, seed_lo, seed_hi, step_lo, step_hi;

@@ -477,6 +477,22 @@ __global__ void __launch_bounds__(kBlock) wg_env_kernel(char* __restrict__ arena
         s_supp[wave][lane] = supp;
     }
     if (lane == 0) frz::at32(rows8, (uint32_t)d.q_etc * Bu + bu) = n_fires;
+    {   // what wg_lists_kernel reads instead of the cells: the lit mask words and (fires, intensity) of the lit cells in task order
+        uint64_t* const litmap = reinterpret_cast<uint64_t*>(arena + d.off_litmap);
+        uint64_t* const okmap = reinterpret_cast<uint64_t*>(arena + d.off_okmap);
+        if (is_agent) {
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) okmap[((int64_t)lane * CPL + k) * B + b] = (uint64_t)ok1[2 * k] | ((uint64_t)ok1[2 * k + 1] << 32);
+        }
+        int2* const lit_cells = reinterpret_cast<int2*>(arena + d.off_lit_cells) + (int64_t)b * ((HW + 1) & ~1);  // 16-byte aligned rows
+        int before = 0;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            if (lane == 0) litmap[(int64_t)k * B + b] = lit[k];
+            if ((lit[k] >> lane) & 1ull) frz::at32(lit_cells, (uint32_t)(before + lane_rank(lit[k]))) = make_int2(f[k], in[k]);
+            before += (int)__popcll(lit[k]);
+        }
+    }
     // agent observations: self = (y, x, fire_reduction_power, suppressant); others = (y, x[, power][, suppressant]) of the other agents.
     // Agents do not move and their base power is configuration: reset / rebuild write whole records, a step only the suppressant column.
     float* const obs_self = reinterpret_cast<float*>(arena + d.off_obs_self);
@@ -645,6 +661,192 @@ __global__ void __launch_bounds__(kBlock) wg_emit_kernel(char* __restrict__ aren
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// wg_lists_kernel: offsets AND lists in one launch, one env per LANE.  A 1024-thread workgroup owns a 256-env chunk: wavefronts 0-3 run
+// the launch-wide scan (one env per lane) and park every env's segment starts in LDS; then all 16 wavefronts write lists — wavefront w
+// takes the 64 envs of group w & 3 and the items (0 = task rows, 1 = observation map, 2 + a = agent a's lists) congruent to w >> 2
+// modulo 4.  The 64 segments of a wavefront's envs are ONE contiguous range of the output (env-major order), so the lanes walk the set
+// bits of their env's mask words (left by wg_env_kernel: lit cells, attackable cells per agent, (fires, intensity) of the lit cells in
+// task order), stage their entries in an LDS tile at the positions the scan gave them, and the wavefront copies the tile out with
+// lane-consecutive 8-byte stores: the cells are not read again, an env costs a lane's few loop iterations instead of a wavefront, and
+// the stores are whole lines however many fires burn.
+// ------------------------------------------------------------------------------------------------------------------------------------
+template <int CPL>
+struct ListShared {  // per wavefront: its 64 envs' mask words and segment starts, addressed by env
+    uint64_t lit[64][CPL], sel[64][CPL];
+    int rel[65];
+};
+
+// One list of one item for the wavefront's 64 envs, one OUTPUT entry per lane: the 64 segments are one contiguous range of dst, so entry
+// i of that range belongs to the env e with rel[e] <= i < rel[e + 1] (binary search in LDS) and is the (i - rel[e])-th listed cell of e
+// (a population-count descent on its mask words): every lane works whatever the fires per env, and every store instruction writes 64
+// consecutive entries.  sel: the cells the lane's env lists (all lanes pass theirs); first: where its segment starts in dst;
+// emit(entry index in dst, env slot, position in the env's segment, cell, task index of the cell).
+template <int CPL, bool RANK, typename F>
+__device__ __forceinline__ void output_parallel_list(ListShared<CPL>& sh, const uint64_t (&sel)[CPL], int64_t first, int lane, F&& emit) {
+    int n = 0;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) n += (int)__popcll(sel[k]);
+    const int64_t wave_first = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)first) | ((int64_t)__builtin_amdgcn_readfirstlane((int)(first >> 32)) << 32);
+    const int rel = (int)(first - wave_first);
+    const int total = read_lane(rel + n, 63);
+    wave_lds_sync();  // the previous list's readers are done
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) sh.sel[lane][k] = sel[k];
+    sh.rel[lane] = rel;
+    if (lane == 63) sh.rel[64] = total;
+    wave_lds_sync();
+    for (int base = 0; base < total; base += 64) {
+        const int i = base + lane;
+        int e = 0;
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) e += sh.rel[e + step] <= i ? step : 0;  // the last env that starts at or before i
+        const int j = i - sh.rel[e];
+        uint32_t w[2 * CPL];
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            const uint64_t v = sh.sel[e][k];
+            w[2 * k] = (uint32_t)v, w[2 * k + 1] = (uint32_t)(v >> 32);
+        }
+        const int c = select_nth(w, i < total ? j : -1);  // -1 past the range
+        int rank = j;
+        if (RANK) {  // the cell's rank among the env's lit cells
+            rank = 0;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                const uint64_t v = sh.lit[e][k];
+                const uint64_t below = (c >> 6) > k ? ~0ull : ((c >> 6) == k ? (1ull << (c & 63)) - 1ull : 0ull);
+                rank += (int)__popcll(v & below);
+            }
+        }
+        if (c >= 0) emit(wave_first + i, e, j, c, rank);
+    }
+}
+
+template <int AMAX, int CPL, int BITS>
+__global__ void __launch_bounds__(64 * (CPL >= 8 ? 4 : 16)) wg_lists_kernel(char* __restrict__ arena, const WgDev d, uint32_t ticketed) {
+    constexpr int kListWaves = CPL >= 8 ? 4 : 16, kListParts = kListWaves / frz::kWaves;
+    constexpr int kChannels = AMAX + 1;
+    constexpr int kItems = (AMAX + 2 + kListParts - 1) / kListParts;  // items per wavefront
+    constexpr bool kEager = CPL <= 4 && kListParts > 1;                // every item's mask words loaded before the scan
+    __shared__ frz::ScanShared<kChannels, BITS> s_scan;
+    __shared__ int s_ticket;
+    __shared__ uint32_t s_first[kChannels][kBlock];  // exclusive prefix of channel ch at the chunk's env e
+    __shared__ ListShared<CPL> s_list[kListWaves];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, group = wave & (frz::kWaves - 1), part = wave >> 2;
+    const int64_t B = d.B;
+    const int A = d.A, HW = d.HW, Wd = d.W;
+    frz::ScanWorkspace ws{reinterpret_cast<uint32_t*>(arena + d.off_epoch), reinterpret_cast<uint32_t*>(arena + d.off_totals),
+                          reinterpret_cast<uint64_t*>(arena + d.off_agg), reinterpret_cast<uint64_t*>(arena + d.off_prefix)};
+    const frz::ScanLaunch launch = frz::scan_begin(ws);
+    const int chunk = frz::scan_take_chunk(ws, d.nchunks, ticketed != 0, &s_ticket);
+    const int el = group * 64 + lane;  // the lane's env within the chunk
+    const int64_t b = (int64_t)chunk * kBlock + el;
+    const bool active = b < B;
+    const int64_t bl = active ? b : B - 1;
+    const int32_t* rows = reinterpret_cast<const int32_t*>(arena + d.off_rows4);
+    const int64_t* rows8 = reinterpret_cast<const int64_t*>(arena + d.off_rows8);
+    const uint8_t* rows1 = reinterpret_cast<const uint8_t*>(arena + d.off_rows1);
+
+    // ---------------------------------------------------------------- loads of the list phase, in flight while the scan runs
+    const uint64_t* const litmap = reinterpret_cast<const uint64_t*>(arena + d.off_litmap);
+    const uint64_t* const okmap = reinterpret_cast<const uint64_t*>(arena + d.off_okmap);
+    uint64_t lit[CPL], ok[kEager ? kItems : 1][CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) lit[k] = active ? litmap[(int64_t)k * B + bl] : 0ull;
+    if (kEager) {
+#pragma unroll
+        for (int j = 0; j < kItems; ++j) {
+            const int item = part + kListParts * j, a = item >= 2 && item < A + 2 ? item - 2 : 0;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) ok[j][k] = active ? okmap[((int64_t)a * CPL + k) * B + bl] : 0ull;
+        }
+    }
+    ListShared<CPL>& sh = s_list[wave];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) sh.lit[lane][k] = lit[k];
+
+    // ---------------------------------------------------------------- the scan (wavefronts 0-3)
+    uint32_t err = 0;
+    if (part == 0) {
+        uint32_t cnt[kChannels], excl[kChannels];
+        cnt[0] = active ? (uint32_t)rows8[(int64_t)d.q_etc * B + bl] : 0u;
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a) cnt[a + 1] = (active && a < A) ? (uint32_t)rows[(int64_t)(d.r_atc + (a < A ? a : 0)) * B + bl] : 0u;
+        const bool term = rows1[(int64_t)d.u_term * B + bl] != 0, trunc = rows1[(int64_t)d.u_trunc * B + bl] != 0;
+        frz::scan_chunk<kChannels, BITS>(s_scan, ws, launch, cnt, active && !term, active && !trunc, A + 1, chunk, d.nchunks, excl, &err);
+#pragma unroll
+        for (int ch = 0; ch < kChannels; ++ch) s_first[ch][el] = excl[ch];
+        if (active) {
+            int64_t* const task_offsets = reinterpret_cast<int64_t*>(arena + d.off_task_offsets);
+            int64_t* const act_offsets = reinterpret_cast<int64_t*>(arena + d.off_act_offsets);
+            int64_t* const bad_offsets = reinterpret_cast<int64_t*>(arena + d.off_bad_offsets);
+            const bool show_bad = (d.flags & kShowBad) != 0;
+            task_offsets[b] = excl[0];
+            if (b == B - 1) task_offsets[B] = (int64_t)excl[0] + cnt[0];
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a)
+                if (a < A) {
+                    act_offsets[a * (B + 1) + b] = excl[a + 1];
+                    if (b == B - 1) act_offsets[a * (B + 1) + B] = (int64_t)excl[a + 1] + cnt[a + 1];
+                    if (show_bad) {  // bad = listed but not attackable
+                        bad_offsets[a * (B + 1) + b] = (int64_t)excl[0] - excl[a + 1];
+                        if (b == B - 1) bad_offsets[a * (B + 1) + B] = ((int64_t)excl[0] + cnt[0]) - ((int64_t)excl[a + 1] + cnt[a + 1]);
+                    }
+                }
+        }
+    } else {
+        frz::scan_chunk_passive_front();
+        frz::scan_chunk_passive_back();
+    }
+    __syncthreads();
+    if (err) atomicOr(reinterpret_cast<uint32_t*>(arena + d.off_error), err);
+    frz::scan_end(ws, launch, chunk, d.nchunks);
+
+    // ---------------------------------------------------------------- the lists (wildfire.py:586-717)
+    const int64_t cap = B * (int64_t)HW;
+    const int64_t task_first = s_first[0][el];
+    const bool show_bad = (d.flags & kShowBad) != 0;
+    const int64_t wave_env0 = (int64_t)chunk * kBlock + group * 64;  // env of lane 0
+#pragma unroll
+    for (int j = 0; j < kItems; ++j) {
+        const int item = part + kListParts * j;
+        if (item >= A + 2) break;
+        if (item == 0) {
+            // task rows (y, x, fires level, intensity) of the lit fires in row-major order
+            longlong2* const task_values = reinterpret_cast<longlong2*>(arena + d.off_task_values);
+            const int2* const lit_cells = reinterpret_cast<const int2*>(arena + d.off_lit_cells);
+            const int64_t stride = (HW + 1) & ~1;
+            output_parallel_list<CPL, false>(sh, lit, task_first, lane, [&](int64_t at, int e, int idx, int c, int) {
+                const int2 cell = lit_cells[(wave_env0 + e) * stride + idx];
+                const int y = (int)(((uint32_t)c * d.inv_w) >> 16), x = c - y * Wd;
+                task_values[2 * at] = make_longlong2(y, x);
+                task_values[2 * at + 1] = make_longlong2(cell.x, cell.y);
+            });
+        } else if (item == 1) {
+            // the observation map: task j of the env observes task j
+            int64_t* const obs_map = reinterpret_cast<int64_t*>(arena + d.off_obs_map);
+            output_parallel_list<CPL, false>(sh, lit, task_first, lane, [&](int64_t at, int, int idx, int, int) { obs_map[at] = idx; });
+        } else {
+            // agent a: the task indices of its attackable fires (and, with show_bad_actions, of the listed-but-not-attackable ones)
+            const int a = item - 2;
+            uint64_t mine[CPL];
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) mine[k] = kEager ? ok[kEager ? j : 0][k] : (active ? okmap[((int64_t)a * CPL + k) * B + bl] : 0ull);
+            const int64_t first = s_first[a + 1][el];
+            int64_t* const act_values = reinterpret_cast<int64_t*>(arena + d.off_act_values) + (int64_t)a * cap;
+            output_parallel_list<CPL, true>(sh, mine, first, lane, [&](int64_t at, int, int, int, int rank) { act_values[at] = rank; });
+            if (show_bad) {
+                uint64_t bad[CPL];
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) bad[k] = lit[k] & ~mine[k];
+                int64_t* const bad_values = reinterpret_cast<int64_t*>(arena + d.off_bad_values) + (int64_t)a * cap;
+                output_parallel_list<CPL, true>(sh, bad, task_first - first, lane, [&](int64_t at, int, int, int, int rank) { bad_values[at] = rank; });
+            }
+        }
+    }
+}
+
 template <int CPL>
 int launch_cpl(const WgDev& dev, char* arena, const WfArgs& args, int rng, int mode, bool ticketed, hipStream_t stream) {
     const dim3 waves((unsigned)((dev.B + kEnvsPerBlock - 1) / kEnvsPerBlock)), lanes((unsigned)dev.nchunks), block(kBlock);
@@ -668,17 +870,24 @@ int launch_cpl(const WgDev& dev, char* arena, const WfArgs& args, int rng, int m
     }
     {
         const uint32_t tk = ticketed ? 1u : 0u;
-        const bool narrow = dev.HW < 256;
-        if (dev.A <= 4 && narrow) hipLaunchKernelGGL((wg_offsets_kernel<4, 16>), lanes, block, 0, stream, arena, dev, tk);
-        else if (dev.A <= 8 && narrow) hipLaunchKernelGGL((wg_offsets_kernel<8, 16>), lanes, block, 0, stream, arena, dev, tk);
-        else if (narrow) hipLaunchKernelGGL((wg_offsets_kernel<16, 16>), lanes, block, 0, stream, arena, dev, tk);
-        else if (dev.A <= 8) hipLaunchKernelGGL((wg_offsets_kernel<8, 32>), lanes, block, 0, stream, arena, dev, tk);
-        else hipLaunchKernelGGL((wg_offsets_kernel<16, 32>), lanes, block, 0, stream, arena, dev, tk);
+        const dim3 list_block(64 * (CPL >= 8 ? 4 : 16));
+        auto lists = [&](auto kernel) {
+            if (args.stop_event)
+                hipExtLaunchKernelGGL(kernel, lanes, list_block, 0, stream, nullptr, args.stop_event, 0, arena, dev, tk);
+            else
+                hipLaunchKernelGGL(kernel, lanes, list_block, 0, stream, arena, dev, tk);
+        };
+        constexpr int BITS = CPL <= 2 ? 16 : 32;  // the scan packs 16-bit counts while an env has at most 255 cells
+        if (CPL == 4 && dev.HW < 256) {
+            if (dev.A <= 4) lists(wg_lists_kernel<4, CPL, 16>);
+            else if (dev.A <= 8) lists(wg_lists_kernel<8, CPL, 16>);
+            else lists(wg_lists_kernel<16, CPL, 16>);
+        } else {
+            if (dev.A <= 4) lists(wg_lists_kernel<4, CPL, BITS>);
+            else if (dev.A <= 8) lists(wg_lists_kernel<8, CPL, BITS>);
+            else lists(wg_lists_kernel<16, CPL, BITS>);
+        }
     }
-    if (args.stop_event)
-        hipExtLaunchKernelGGL(wg_emit_kernel<CPL>, waves, block, 0, stream, nullptr, args.stop_event, 0, arena, dev);
-    else
-        hipLaunchKernelGGL(wg_emit_kernel<CPL>, waves, block, 0, stream, arena, dev);
     return hipGetLastError() == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;
 }
 
