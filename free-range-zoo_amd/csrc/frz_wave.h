@@ -44,6 +44,13 @@ __device__ __forceinline__ void write_lane_c(uint32_t& lo, uint32_t& hi, uint64_
         : "+v"(lo), "+v"(hi)
         : "s"((uint32_t)scalar), "s"((uint32_t)(scalar >> 32)), "n"(LANE));
 }
+// `value` in the lanes whose bit of a wave-uniform mask is set, 0.0f elsewhere: the mask is the instruction's lane predicate (one
+// vector instruction; written as `(mask >> lane) & 1` the compiler shifts a 64-bit value per lane)
+__device__ __forceinline__ float where_lane(uint64_t mask, float value) {
+    float out;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(out) : "v"(value), "s"(mask));
+    return out;
+}
 template <typename F, int... Is>
 __device__ __forceinline__ void for_each_index(std::integer_sequence<int, Is...>, F&& f) {
     (f(std::integral_constant<int, Is>{}), ...);

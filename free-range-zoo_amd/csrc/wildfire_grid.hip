@@ -17,6 +17,8 @@
 #include "frz_scan.h"
 #include "frz_wave.h"
 
+#include <cstddef>
+
 #include "../../include/frz.h"
 
 #include "wildfire_common.h"
@@ -47,32 +49,62 @@ __device__ __forceinline__ CellTables cell_tables(const char* arena, const WgDev
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
-// wg_env_kernel: everything of a step that concerns ONE env (MODE kStep), or the counts / observations of the state as it stands
-// (kRebuild), or of the configured initial state (kReset).  "cell-lane" values: element k of lane l belongs to cell 64 k + l;
-// "agent-lane" values: lane a < A holds agent a's value (lanes >= A carry inert values).
+// wg_env_kernel: everything of a step that concerns the FOUR envs of a workgroup (MODE kStep), or the counts / observations of their state
+// as it stands (kRebuild), or of the configured initial state (kReset).
+//   * every wavefront is the FIELD of one env: "cell-lane" values, element k of lane l belongs to cell 64 k + l.  It loads the cells,
+//     makes the env's Philox draws, runs the fire transitions and the spread, writes the cells a transition touched, the lit mask words
+//     and the lit cells' (fires, intensity) for the lists launch, and reduces what the rewards need;
+//   * ONE wavefront of the workgroup (a different one from workgroup to workgroup, so the four SIMDs share that work) is also the CREW of
+//     all four envs: lane 16 e + a holds agent a of the workgroup's env e.  It decodes the actions (or samples the uniform policy),
+//     hands the fire-fighting power to the fields, runs the agent transitions, and after the fields are done computes rewards,
+//     termination, the attackable sets and the observations.  An agent's rows are 4-byte pieces of [rows][B] arrays: one crew wavefront
+//     touches 16 bytes of each line where four did 4 bytes each (the launch was bound by the number of such requests and by vector issue:
+//     the agent phases ran at 12 / 64 lanes, four times per workgroup).
+// The fields and the crew meet at three workgroup barriers and exchange through LDS.
 // ------------------------------------------------------------------------------------------------------------------------------------
+struct FieldSums {  // what an env's field leaves for the crew
+    float fire_reward_sum, burnout_total;
+    int n_put, n_burn, dead, pad_;
+};
+
 template <int CPL, int MODE, int RNG>
 __global__ void __launch_bounds__(kBlock) wg_env_kernel(char* __restrict__ arena, const WgDev d, const int32_t* __restrict__ actions,
                                                          const float* __restrict__ field_rand, const float* __restrict__ agent_rand, const WgPolicy pol) {
     constexpr int W2 = 2 * CPL;  // 32-bit words of a cell mask
     constexpr int kCells = 64 * CPL;
+    constexpr int E = kEnvsPerBlock, AP = 64 / E;  // envs per workgroup; crew lanes per env
+    static_assert(AP >= FRZ_MAX_AGENTS, "a crew lane per agent");
     constexpr bool kStepping = MODE == kStep;
     constexpr bool kPhilox = kStepping && RNG == FRZ_RNG_PHILOX;
-    __shared__ float s_draw[kEnvsPerBlock][kPhilox ? 3 * kCells + 5 * FRZ_MAX_AGENTS + 8 : 1];  // the step's draws, by draw number (+ the last block's tail)
-    __shared__ float s_power[kEnvsPerBlock][kStepping ? kCells : 1];                         // fire-fighting power applied to each cell
-    __shared__ uint32_t s_hits[kEnvsPerBlock][kStepping ? kCells : 1];                       // agents fighting each cell
-    __shared__ uint8_t s_lit[kEnvsPerBlock][kStepping ? kCells : 4];                         // lit map after increase / decrease (spread stencil)
-    __shared__ uint8_t s_put[kEnvsPerBlock][kStepping ? kCells : 4];                         // cells put out this step (localized rewards)
-    __shared__ float s_supp[kEnvsPerBlock][FRZ_MAX_AGENTS];                                  // suppressants after the agent transitions
-    const int b = frz::env_of_wave<kEnvsPerBlock>(d.B);
-    if (b < 0) return;  // no workgroup barrier in this kernel: a wavefront without an env just leaves
+    __shared__ float s_draw[E][kPhilox ? 3 * kCells + 5 * FRZ_MAX_AGENTS + 8 : 1];  // the step's draws, by draw number (+ the last block's tail)
+    __shared__ uint32_t s_policy[E][kPhilox ? 16 : 1];                          // the fused policy's Philox words: word a of env e
+    __shared__ float s_power[E][kStepping ? kCells : 1];                        // fire-fighting power applied to each cell
+    __shared__ uint32_t s_hits[E][kStepping ? kCells : 1];                      // agents fighting each cell
+    __shared__ uint8_t s_put[E][kStepping ? kCells : 4];                        // cells put out this step (localized rewards)
+    __shared__ float s_supp[E][FRZ_MAX_AGENTS];                                 // suppressants after the agent transitions
+    __shared__ uint64_t s_lit[2][E][CPL];                                       // lit mask words: [0] of the loaded state, [1] after the step
+    __shared__ FieldSums s_sums[E];
+    // The small tables a crew lane indexes with values it has just loaded (equipment state -> bonuses, capacity index -> capacity, (agent,
+    // equipment state) -> cells in range) are staged in LDS by the crew's FIRST loads: a lookup behind a loaded index is then an LDS read,
+    // not one more trip to memory.
+    constexpr int kTableWords = (int)(sizeof(WgAgentTable) / 4), kRangeStaged = CPL <= 4 ? 128 : 1;
+    static_assert(kTableWords <= 128, "WgAgentTable is staged by two loads per lane");
+    __shared__ uint32_t s_table[128];
+    __shared__ uint64_t s_range[kRangeStaged];
+    const int b = frz::env_of_wave<E>(d.B);
+    if (b < 0) return;  // before any barrier: a barrier does not wait for wavefronts that have ended
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t B = d.B;
     const uint32_t Bu = (uint32_t)d.B, bu = (uint32_t)b;
     const int HW = d.HW, A = d.A, Wd = d.W;
     const uint32_t flags = d.flags;
-    const bool is_agent = lane < A;
-    const int agent = is_agent ? lane : A - 1;  // clamped: unconditional loads
+    const int b0 = b - wave;                                                   // the workgroup's first env
+    const int n_envs = (int)(B - b0 < E ? B - b0 : E);                         // its envs (the last workgroup of a ragged batch has fewer)
+    const bool crew = wave == (int)(blockIdx.x % (uint32_t)n_envs);            // wave-uniform
+    const int ce = lane / AP, ca = lane % AP;                                  // crew lane -> (env of the workgroup, agent)
+    const bool is_agent = ca < A && ce < n_envs;
+    const int agent = ca < A ? ca : A - 1;                                     // clamped: unconditional loads
+    const uint32_t cbu = (uint32_t)(b0 + (ce < n_envs ? ce : n_envs - 1));     // the crew lane's env
     int32_t* const rows = reinterpret_cast<int32_t*>(arena + d.off_rows4);
     float* const rowsf = reinterpret_cast<float*>(arena + d.off_rows4);
     int64_t* const rows8 = reinterpret_cast<int64_t*>(arena + d.off_rows8);
@@ -82,110 +114,132 @@ __global__ void __launch_bounds__(kBlock) wg_env_kernel(char* __restrict__ arena
     int32_t* const fuel = intensity + B * HW;
     const WgAgentTable* const table = reinterpret_cast<const WgAgentTable*>(arena + d.off_agent_table);
     const CellTables cells = cell_tables(arena, d);
+    const uint64_t* const range = reinterpret_cast<const uint64_t*>(arena + d.off_range);
+    const int range_words = A * d.S * CPL;
+    const bool range_staged = CPL <= 4 && range_words <= kRangeStaged;  // uniform
 
-    // ---------------------------------------------------------------- loads
+    // ---------------------------------------------------------------- loads: field
     const uint32_t epoch = *reinterpret_cast<const uint32_t*>(arena + d.off_epoch);
     const uint32_t* const totals = reinterpret_cast<const uint32_t*>(arena + d.off_totals);
-    int f[CPL], in[CPL], fu[CPL];
+    int f[CPL], in[CPL], fu[CPL], ign[kStepping ? CPL : 1];
+    float fire_reward[kStepping ? CPL : 1];
     bool inside[CPL];  // the lane's k-th cell exists
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
         const int c = lane + 64 * k;
         inside[k] = c < HW;
         const uint32_t cc = (uint32_t)(inside[k] ? c : HW - 1);
+        if (kStepping) ign[k] = frz::at32(cells.ignition, cc), fire_reward[k] = frz::at32(cells.fire_rewards, cc);  // with the first loads, not behind the tests that need them
         if (MODE == kReset) {  // wildfire.py:347-351: +type on the configured lit cells, -type elsewhere, ...
             f[k] = frz::at32(cells.fires0, cc), in[k] = frz::at32(cells.intensity0, cc), fu[k] = frz::at32(cells.fuel0, cc);
         } else {
             f[k] = frz::at32(fires, cc), in[k] = frz::at32(intensity, cc), fu[k] = frz::at32(fuel, cc);
         }
     }
-    float supp = d.initial_suppressant, capa = d.initial_capacity, cum0 = 0.0f;
-    int eqs = d.initial_equipment;
-    if (MODE != kReset) {
-        supp = frz::at32(rowsf, (uint32_t)(d.r_supp + agent) * Bu + bu);
-        capa = frz::at32(rowsf, (uint32_t)(d.r_cap + agent) * Bu + bu);
-        eqs = frz::at32(rows, (uint32_t)(d.r_equip + agent) * Bu + bu);
-    }
-    const float base_power = table->power[agent];
-    int nm = 0, nb = 0;
-    uint32_t seed = 0;
-    bool term0 = false, trunc0 = false;
-    int act_idx = 0, act_id = -1;
-    uint32_t agent_tasks_anywhere = 1;  // agent-lane: the batch total of the agent's attackable tasks after the previous launch
+    int nm = 0;         // the field's env: moves so far (Philox counter)
+    uint32_t seed = 0;  // and its seed
     uint32_t left_alive = 1, left_running = 1;
     if (kStepping) {
         nm = frz::at32(rows, (uint32_t)d.r_moves * Bu + bu);
-        nb = frz::at32(rows, (uint32_t)d.r_burnouts * Bu + bu);
         seed = (uint32_t)frz::at32(rows, (uint32_t)d.r_seeds * Bu + bu);
-        term0 = frz::at32(rows1, (uint32_t)d.u_term * Bu + bu) != 0;
-        trunc0 = frz::at32(rows1, (uint32_t)d.u_trunc * Bu + bu) != 0;
-        if (flags & kTrackCumulative) cum0 = frz::at32(rowsf, (uint32_t)(d.r_cum + agent) * Bu + bu);
-        if (!pol.on) {
-            const int2 a2 = frz::at32(reinterpret_cast<const int2*>(actions), (uint32_t)agent * Bu + bu);
-            act_idx = a2.x;
-            act_id = is_agent ? a2.y : -1;
+        // what the lists launch left after the previous step: slot (epoch + 1) & 1 — both slots are requested with everything else and
+        // the epoch picks one (a load whose address waits for the epoch would be one more trip to memory)
+        const bool odd = ((epoch + 1u) & 1u) != 0u;
+        const uint32_t tl0 = totals[A + 1], tl1 = totals[kTotalsStride + A + 1], tr0 = totals[A + 2], tr1 = totals[kTotalsStride + A + 2];
+        left_alive = odd ? tl1 : tl0;
+        left_running = odd ? tr1 : tr0;
+    }
+    // ---------------------------------------------------------------- loads: crew (lane 16 e + a: agent a of the workgroup's env e)
+    float supp = d.initial_suppressant, capa = d.initial_capacity, cum0 = 0.0f;
+    int eqs = d.initial_equipment;
+    int c_nm = 0, c_nb = 0;
+    uint32_t c_seed = 0;
+    bool term0 = false, trunc0 = false;
+    int act_idx = 0, act_id = -1;
+    uint32_t agent_tasks_anywhere = 1;  // the batch total of the agent's attackable tasks after the previous launch
+    uint32_t table_w0 = 0, table_w1 = 0;
+    uint64_t range_w0 = 0, range_w1 = 0;
+    if (crew) {
+        table_w0 = reinterpret_cast<const uint32_t*>(table)[lane < kTableWords ? lane : 0];
+        table_w1 = reinterpret_cast<const uint32_t*>(table)[lane + 64 < kTableWords ? lane + 64 : 0];
+        if (CPL <= 4) {
+            range_w0 = range[lane < range_words ? lane : 0];
+            range_w1 = range[lane + 64 < range_words ? lane + 64 : 0];
         }
-        const uint32_t* prev = totals + ((epoch + 1u) & 1u) * kTotalsStride;  // what wg_offsets_kernel left after the previous launch
-        agent_tasks_anywhere = prev[1 + agent];
-        left_alive = prev[A + 1];
-        left_running = prev[A + 2];
-    } else if (MODE == kRebuild) {
-        term0 = frz::at32(rows1, (uint32_t)d.u_term * Bu + bu) != 0;
-        trunc0 = frz::at32(rows1, (uint32_t)d.u_trunc * Bu + bu) != 0;
+        if (MODE != kReset) {
+            supp = frz::at32(rowsf, (uint32_t)(d.r_supp + agent) * Bu + cbu);
+            capa = frz::at32(rowsf, (uint32_t)(d.r_cap + agent) * Bu + cbu);
+            eqs = frz::at32(rows, (uint32_t)(d.r_equip + agent) * Bu + cbu);
+            term0 = frz::at32(rows1, (uint32_t)d.u_term * Bu + cbu) != 0;
+            trunc0 = frz::at32(rows1, (uint32_t)d.u_trunc * Bu + cbu) != 0;
+        }
+        if (kStepping) {
+            c_nm = frz::at32(rows, (uint32_t)d.r_moves * Bu + cbu);
+            c_nb = frz::at32(rows, (uint32_t)d.r_burnouts * Bu + cbu);
+            c_seed = (uint32_t)frz::at32(rows, (uint32_t)d.r_seeds * Bu + cbu);
+            if (flags & kTrackCumulative) cum0 = frz::at32(rowsf, (uint32_t)(d.r_cum + agent) * Bu + cbu);
+            if (!pol.on) {
+                const int2 a2 = frz::at32(reinterpret_cast<const int2*>(actions), (uint32_t)agent * Bu + cbu);
+                act_idx = a2.x;
+                act_id = is_agent ? a2.y : -1;
+            }
+            const uint32_t ta0 = totals[1 + agent], ta1 = totals[kTotalsStride + 1 + agent];
+            agent_tasks_anywhere = ((epoch + 1u) & 1u) ? ta1 : ta0;
+        }
     }
 
     if (kStepping) {
         // utils/env.py:211-213 — every per-agent step() is a no-op once ALL envs are terminated or ALL are truncated; the parallel adapter
-        // (utils/conversions.py:87-90) then adds the stale aec rewards once per agent call
+        // (utils/conversions.py:87-90) then adds the stale aec rewards once per agent call.  (Batch totals: every wavefront takes this branch or none.)
         if (left_alive == 0u || left_running == 0u) {
-            if (!frz::at32(rows1, (uint32_t)d.u_frozen * Bu + bu)) {
+            if (crew && !frz::at32(rows1, (uint32_t)d.u_frozen * Bu + cbu)) {
                 if (is_agent) {
-                    const float r = frz::at32(rowsf, (uint32_t)(d.r_rewards + lane) * Bu + bu);
+                    const float r = frz::at32(rowsf, (uint32_t)(d.r_rewards + agent) * Bu + cbu);
                     float acc = 0.0f;
                     for (int j = 0; j < A; ++j) acc = acc + r;
-                    frz::at32(rowsf, (uint32_t)(d.r_rewards + lane) * Bu + bu) = acc;
+                    frz::at32(rowsf, (uint32_t)(d.r_rewards + agent) * Bu + cbu) = acc;
                 }
-                if (lane == 0) frz::at32(rows1, (uint32_t)d.u_frozen * Bu + bu) = 1;
+                wave_lds_sync();  // (nothing in LDS: keeps the flag's store behind every lane's read of it)
+                if (ca == 0 && ce < n_envs) frz::at32(rows1, (uint32_t)d.u_frozen * Bu + cbu) = 1;
             }
             return;
         }
     }
 
-    // cells the agent reaches at its equipment state (utils/in_range_check.py:5-23 precomputed per (agent, state) at create), as mask words
-    const uint64_t* const range = reinterpret_cast<const uint64_t*>(arena + d.off_range);
-    auto attackable_words = [&](const uint64_t (&lit)[CPL], float suppressant, int equipment, uint32_t (&out)[W2]) {
-        const uint64_t* mine = range + ((int64_t)agent * d.S + equipment) * CPL;  // the table's stride is the kernel's chunk count
+    uint64_t lit[CPL];  // the field's lit fires (fires > 0) per 64-cell chunk, wave-uniform
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) lit[k] = __ballot(inside[k] && f[k] > 0);
+    uint32_t err = 0;
+
+    // cells a crew lane's agent reaches at an equipment state (utils/in_range_check.py:5-23 precomputed per (agent, state) at create) that
+    // are lit in its env, as mask words
+    auto attackable_words = [&](int slot, float suppressant, int equipment, uint32_t (&out)[W2]) {
+        const int at = (agent * d.S + equipment) * CPL;  // the table's stride is the kernel's chunk count
 #pragma unroll
         for (int k = 0; k < CPL; ++k) {
-            const uint64_t m = suppressant > 0.0f ? (lit[k] & mine[k]) : 0ull;  // no suppressant: nothing to attack (wildfire.py:604-623)
+            const uint64_t mine = range_staged ? s_range[CPL <= 4 ? at + k : 0] : range[at + k];
+            const uint64_t m = suppressant > 0.0f ? (s_lit[slot][ce][k] & mine) : 0ull;  // no suppressant: nothing to attack (wildfire.py:604-623)
             out[2 * k] = (uint32_t)m;
             out[2 * k + 1] = (uint32_t)(m >> 32);
         }
     };
-    uint64_t lit[CPL];  // lit fires (fires > 0) per 64-cell chunk, wave-uniform
-#pragma unroll
-    for (int k = 0; k < CPL; ++k) lit[k] = __ballot(inside[k] && f[k] > 0);
+    constexpr int kEqAt = (int)(offsetof(WgAgentTable, eq) / 4), kCapsAt = (int)(offsetof(WgAgentTable, caps) / 4);
+    constexpr int kAyAt = (int)(offsetof(WgAgentTable, ay) / 4), kAxAt = (int)(offsetof(WgAgentTable, ax) / 4);
+    const float* const tablef = reinterpret_cast<const float*>(s_table);
 
-    uint32_t err = 0;
     float reward = 0.0f;
-    bool term = term0, trunc = trunc0;
-    int n_burn = 0, n_put = 0;
-
+    int hit = -1, tcell = 0;
+    float r_field[kStepping ? 3 : 1][CPL];
     if (kStepping) {
-        // ------------------------------------------------------------ (1) the step's draws
+        // ------------------------------------------------------------ (1) field: the env's draws, the loaded state's lit words
         // FRZ_RNG_PHILOX (include/frz.h): draw u = 24-bit field u % 5 of block (u / 5, step, 0, 0) keyed by (seed, 0x46525A00); field
         // event e of cell c is draw e * HW + c, agent event e of agent a is draw 3 * HW + e * A + a.  Lane j computes blocks j, j + 64, ...
-        // and parks their draws in LDS by draw number.
-        float r_field[3][CPL], r_agent[5];
-        // The fused policy draws Philox blocks too (ceil(A / 4) of them, another key and counter): when they fit into the lanes the step's
-        // own blocks leave idle, both streams are ONE Philox evaluation with per-lane inputs (~110 vector instructions less per env);
-        // `policy_words` then sits in lanes NB .. NB + ceil(A / 4) - 1.
-        frz::Philox4 policy_words{{0u, 0u, 0u, 0u}};
-        int policy_lane0 = -1;  // >= 0: first lane that holds a policy block
+        // and parks their draws in LDS by draw number.  The fused policy draws Philox blocks too (ceil(A / 4) of them, another key and
+        // counter): when they fit into the lanes the step's own blocks leave idle, both streams are ONE Philox evaluation with per-lane
+        // inputs; the policy words go to s_policy.
+        const int U = 3 * HW + 5 * A, NB = (U + 4) / 5, PB = (A + 3) / 4;
+        const bool merged = kPhilox && pol.on && NB + PB <= 64;
         if (kPhilox) {
-            const int U = 3 * HW + 5 * A, NB = (U + 4) / 5, PB = (A + 3) / 4;
-            const bool merged = pol.on && NB + PB <= 64;
-            policy_lane0 = merged ? NB : -1;
             for (int j = lane; j < NB + (merged ? PB : 0); j += 64) {
                 const bool mine = j < NB;  // a block of the step's draws; otherwise policy block j - NB
                 const frz::Philox4 w = frz::philox4x32_10(mine ? (uint32_t)j : (uint32_t)(j - NB), mine ? (uint32_t)nm : 0u, mine ? 0u : pol.step_lo,
@@ -198,137 +252,160 @@ __global__ void __launch_bounds__(kBlock) wg_env_kernel(char* __restrict__ arena
                     out[3] = frz::philox_unit24<3>(w);
                     out[4] = frz::philox_unit24<4>(w);
                 } else {
-                    policy_words = w;
+                    uint32_t* const out = &s_policy[wave][4 * (j - NB)];
+                    out[0] = w.w[0], out[1] = w.w[1], out[2] = w.w[2], out[3] = w.w[3];
                 }
             }
         }
-        // ------------------------------------------------------------ (2) action decode (wildfire.py:427-483)
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            s_power[wave][lane + 64 * k] = 0.0f, s_hits[wave][lane + 64 * k] = 0u;
+            if (lane == 0) s_lit[0][wave][k] = lit[k];
+        }
+        if (crew) {
+            s_table[lane] = table_w0, s_table[lane + 64] = table_w1;
+            if constexpr (CPL <= 4) {
+                if (range_staged) s_range[lane] = range_w0, s_range[lane + 64] = range_w1;
+            }
+        }
+        __syncthreads();
+
+        // ------------------------------------------------------------ (2) crew: action decode (wildfire.py:427-483)
         // The action mapping of the previous rebuild is a pure function of the state it was built from, which is the state just
         // loaded: attackable set of agent a = lit fires within its (equipment-adjusted) range, non-empty only while it has suppressant.
-        uint32_t ok0[W2], sel[W2];
-        attackable_words(lit, supp, eqs, ok0);
-        const bool show_bad = (flags & kShowBad) != 0;
+        bool good = false, refill = false;
+        float r_agent[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        if (crew) {
+            const float base_power = tablef[agent];
+            uint32_t ok0[W2], sel[W2];
+            attackable_words(0, supp, eqs, ok0);
+            const bool show_bad = (flags & kShowBad) != 0;
 #pragma unroll
-        for (int k = 0; k < CPL; ++k) {  // the tasks the agent's action space lists
-            sel[2 * k] = show_bad ? (uint32_t)lit[k] : ok0[2 * k];
-            sel[2 * k + 1] = show_bad ? (uint32_t)(lit[k] >> 32) : ok0[2 * k + 1];
-        }
-        const int n_listed = popc_words(sel);
-        if (pol.on) {
-            // uniform random policy over OneOf([task] * n + [noop]) (spaces/actions.py:23-41, baselines/random.py:20), the stream of
-            // frz_wildfire_random_policy: agent a draws word a % 4 of Philox(counter (a / 4, 0, step), key (policy seed ^ env seed));
-            // member j ~ U{0..n}; j < n -> [j, 0] (fight task j), j == n -> [n, -1] (noop / refill)
-            frz::Philox4 w;
-            if (policy_lane0 >= 0) {  // drawn above, in lane policy_lane0 + (agent / 4): every lane fetches its agent's block (all lanes active)
-                const int holder = policy_lane0 + (lane >> 2);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) w.w[i] = (uint32_t)from_lane(holder & 63, (int)policy_words.w[i]);
-            } else {
-                w = frz::philox4x32_10((uint32_t)lane >> 2, 0u, pol.step_lo, pol.step_hi, pol.seed_lo ^ seed, pol.seed_hi);
+            for (int k = 0; k < CPL; ++k) {  // the tasks the agent's action space lists
+                const uint64_t l = s_lit[0][ce][k];
+                sel[2 * k] = show_bad ? (uint32_t)l : ok0[2 * k];
+                sel[2 * k + 1] = show_bad ? (uint32_t)(l >> 32) : ok0[2 * k + 1];
             }
-            uint32_t word = w.w[0];
-            word = (lane & 3) == 1 ? w.w[1] : word;
-            word = (lane & 3) == 2 ? w.w[2] : word;
-            word = (lane & 3) == 3 ? w.w[3] : word;
-            const int j = (int)(((uint64_t)word * (uint64_t)(n_listed + 1)) >> 32);
-            act_idx = j < n_listed ? j : n_listed;
-            act_id = (is_agent && j < n_listed) ? 0 : -1;
-            if (is_agent) frz::at32(reinterpret_cast<int2*>(pol.actions_out), (uint32_t)lane * Bu + bu) = make_int2(act_idx, act_id);
-        }
-        const bool refill = act_id == -1;
-        const bool skipped = agent_tasks_anywhere == 0u;  // quirk wildfire.py:434-435: no attackable task in ANY env of the batch
-        const bool fight = is_agent && !refill && !skipped;
-        const int target = select_nth(sel, act_idx);  // the cell of the index-th listed task, -1 outside the list
-        const bool valid = target >= 0;
-        const int tcell = valid ? target : 0;
-        bool attackable = false;
-#pragma unroll
-        for (int i = 0; i < W2; ++i) attackable = attackable || ((tcell >> 5) == i && ((ok0[i] >> (tcell & 31)) & 1u));
-        const bool good = fight && valid && (!show_bad || attackable);
-        if (__ballot(fight && !valid)) err |= FRZ_ERR_BAD_ACTION_INDEX;
-        const float power = base_power + table->eq[eqs][1];
-        const int hit = good ? tcell : -1;
-        reward = (fight && !good) ? d.bad_attack_penalty : 0.0f;  // assignment, wildfire.py:477
-        // applied power per cell (wildfire.py:455-470).  The reference adds the agents' powers in agent order; float addition of TWO
-        // terms does not depend on the order, so the agents add theirs with one LDS atomic each unless some cell is hit by three or
-        // more agents — then one agent lane at a time, in order.
-#pragma unroll
-        for (int k = 0; k < CPL; ++k) s_power[wave][lane + 64 * k] = 0.0f, s_hits[wave][lane + 64 * k] = 0u;
-        wave_lds_sync();
-        if (good) atomicAdd(&s_hits[wave][tcell], 1u);
-        wave_lds_sync();
-        if (__ballot(good && s_hits[wave][tcell] > 2u)) {
-            for (int a = 0; a < A; ++a) {
-                if (lane == a && good) s_power[wave][tcell] = s_power[wave][tcell] + power;
-                wave_lds_sync();
+            const int n_listed = popc_words(sel);
+            if (pol.on) {
+                // uniform random policy over OneOf([task] * n + [noop]) (spaces/actions.py:23-41, baselines/random.py:20), the stream of
+                // frz_wildfire_random_policy: agent a draws word a % 4 of Philox(counter (a / 4, 0, step), key (policy seed ^ env seed));
+                // member j ~ U{0..n}; j < n -> [j, 0] (fight task j), j == n -> [n, -1] (noop / refill)
+                uint32_t word;
+                if (merged) {
+                    word = s_policy[ce][agent];
+                } else {
+                    const frz::Philox4 w = frz::philox4x32_10((uint32_t)agent >> 2, 0u, pol.step_lo, pol.step_hi, pol.seed_lo ^ c_seed, pol.seed_hi);
+                    word = w.w[0];
+                    word = (agent & 3) == 1 ? w.w[1] : word;
+                    word = (agent & 3) == 2 ? w.w[2] : word;
+                    word = (agent & 3) == 3 ? w.w[3] : word;
+                }
+                const int j = (int)(((uint64_t)word * (uint64_t)(n_listed + 1)) >> 32);
+                act_idx = j < n_listed ? j : n_listed;
+                act_id = (is_agent && j < n_listed) ? 0 : -1;
+                if (is_agent) frz::at32(reinterpret_cast<int2*>(pol.actions_out), (uint32_t)agent * Bu + cbu) = make_int2(act_idx, act_id);
             }
-        } else {
-            if (good) atomicAdd(&s_power[wave][tcell], power);
+            refill = act_id == -1;
+            const bool skipped = agent_tasks_anywhere == 0u;  // quirk wildfire.py:434-435: no attackable task in ANY env of the batch
+            const bool fight = is_agent && !refill && !skipped;
+            const int target = select_nth(sel, act_idx);  // the cell of the index-th listed task, -1 outside the list
+            const bool valid = target >= 0;
+            tcell = valid ? target : 0;
+            bool attackable = false;
+#pragma unroll
+            for (int i = 0; i < W2; ++i) attackable = attackable || ((tcell >> 5) == i && ((ok0[i] >> (tcell & 31)) & 1u));
+            good = fight && valid && (!show_bad || attackable);
+            if (__ballot(fight && !valid)) err |= FRZ_ERR_BAD_ACTION_INDEX;
+            const float power = base_power + tablef[kEqAt + 4 * eqs + 1];
+            hit = good ? tcell : -1;
+            reward = (fight && !good) ? d.bad_attack_penalty : 0.0f;  // assignment, wildfire.py:477
+            // applied power per cell (wildfire.py:455-470).  The reference adds the agents' powers in agent order; float addition of TWO
+            // terms does not depend on the order, so the agents add theirs with one LDS atomic each unless some cell is hit by three or
+            // more agents — then one agent of every env at a time, in order.
+            if (good) atomicAdd(&s_hits[ce][tcell], 1u);
             wave_lds_sync();
+            if (__ballot(good && s_hits[ce][tcell] > 2u)) {
+                for (int a = 0; a < A; ++a) {
+                    if (ca == a && good) s_power[ce][tcell] = s_power[ce][tcell] + power;
+                    wave_lds_sync();
+                }
+            } else {
+                if (good) atomicAdd(&s_power[ce][tcell], power);
+            }
+            // the agents' draws
+            if (kPhilox) {
+#pragma unroll
+                for (int e = 0; e < 5; ++e) r_agent[e] = s_draw[ce][3 * HW + e * A + agent];
+            } else {  // the tensor generator.generate(B, 5, (A,)) returns (wildfire.py:409-410)
+#pragma unroll
+                for (int e = 0; e < 5; ++e) r_agent[e] = agent_rand[((int64_t)e * B + cbu) * A + agent];
+            }
+            // -------------------------------------------------------- (3) crew: agent transitions (suppressant decrease, equipment, refill, capacity)
+            {
+                // transitions/suppressant_decrease.py:56-61
+                const bool dec = good && (!(flags & kStochSuppDecrease) || r_agent[0] < d.p_supp_decrease);
+                float s = dec ? supp - 1.0f : supp;
+                s = s < 0.0f ? 0.0f : s;
+                // transitions/equipment.py:51-75 (masks from the value before any write)
+                const int e0 = eqs, top = d.S - 1;
+                const bool pristine = e0 == top, damaged = e0 == 0, inter = !pristine && !damaged;
+                const float r1 = r_agent[1];
+                const bool repairs = (flags & kStochRepair) ? (damaged && r1 < d.p_repair) : damaged;
+                const bool crit = (flags & kCritical) && pristine && r1 < d.p_critical;
+                bool degr = (flags & kStochDegrade) ? ((pristine || inter) && r1 < d.p_degrade) : (inter || pristine);
+                degr = degr && !crit;
+                int e = repairs ? top : e0;
+                e = crit ? 0 : e;
+                e = degr ? e - 1 : e;
+                // transitions/suppressant_refill.py:63-70 (bonus from the NEW equipment state)
+                const bool inc = refill && (!(flags & kStochRefill) || r_agent[2] < d.p_refill);
+                s = inc ? capa + tablef[kEqAt + 4 * e] : s;
+                // transitions/capacity.py:52-64: bucketize(r, cumsum) = #{j : cum[j] < r} (cum padded with +inf, clamped to the last capacity)
+                int ci = 0;
+#pragma unroll
+                for (int j = 0; j < FRZ_MAX_CAPACITIES; ++j) ci += r_agent[3] > d.cum[j] ? 1 : 0;
+                ci = ci > d.K - 1 ? d.K - 1 : ci;
+                const float new_max = tablef[kCapsAt + ci];
+                const bool sw = inc && (!(flags & kStochSwitch) || r_agent[4] < d.p_switch);
+                const float bonus = s - capa;
+                capa = sw ? new_max : capa;
+                s = sw ? new_max + bonus : s;
+                supp = s;
+                eqs = e;
+            }
         }
-        // ------------------------------------------------------------ draws
+        __syncthreads();
+
+        // ------------------------------------------------------------ field: the cells' draws
         if (kPhilox) {
 #pragma unroll
             for (int e = 0; e < 3; ++e)
 #pragma unroll
                 for (int k = 0; k < CPL; ++k) r_field[e][k] = inside[k] ? s_draw[wave][e * HW + lane + 64 * k] : 1.0f;
-#pragma unroll
-            for (int e = 0; e < 5; ++e) r_agent[e] = s_draw[wave][3 * HW + e * A + agent];
-        } else {  // the tensors generator.generate(B, 3, (H, W)) / generate(B, 5, (A,)) return (wildfire.py:409-410)
+        } else {  // the tensor generator.generate(B, 3, (H, W)) returns (wildfire.py:409-410)
 #pragma unroll
             for (int e = 0; e < 3; ++e)
 #pragma unroll
-                for (int k = 0; k < CPL; ++k)
-                    r_field[e][k] = inside[k] ? field_rand[((int64_t)e * B + b) * HW + lane + 64 * k] : 1.0f;
-#pragma unroll
-            for (int e = 0; e < 5; ++e) r_agent[e] = agent_rand[((int64_t)e * B + b) * A + agent];
+                for (int k = 0; k < CPL; ++k) r_field[e][k] = inside[k] ? field_rand[((int64_t)e * B + b) * HW + lane + 64 * k] : 1.0f;
         }
-        // ------------------------------------------------------------ (3) agent transitions (suppressant decrease, equipment, refill, capacity)
-        {
-            // transitions/suppressant_decrease.py:56-61
-            const bool dec = good && (!(flags & kStochSuppDecrease) || r_agent[0] < d.p_supp_decrease);
-            float s = dec ? supp - 1.0f : supp;
-            s = s < 0.0f ? 0.0f : s;
-            // transitions/equipment.py:51-75 (masks from the value before any write)
-            const int e0 = eqs, top = d.S - 1;
-            const bool pristine = e0 == top, damaged = e0 == 0, inter = !pristine && !damaged;
-            const float r1 = r_agent[1];
-            const bool repairs = (flags & kStochRepair) ? (damaged && r1 < d.p_repair) : damaged;
-            const bool crit = (flags & kCritical) && pristine && r1 < d.p_critical;
-            bool degr = (flags & kStochDegrade) ? ((pristine || inter) && r1 < d.p_degrade) : (inter || pristine);
-            degr = degr && !crit;
-            int e = repairs ? top : e0;
-            e = crit ? 0 : e;
-            e = degr ? e - 1 : e;
-            // transitions/suppressant_refill.py:63-70 (bonus from the NEW equipment state)
-            const bool inc = refill && (!(flags & kStochRefill) || r_agent[2] < d.p_refill);
-            s = inc ? capa + table->eq[e][0] : s;
-            // transitions/capacity.py:52-64: bucketize(r, cumsum) = #{j : cum[j] < r} (cum padded with +inf, clamped to the last capacity)
-            int ci = 0;
+        int f_in[CPL], in_in[CPL], fu_in[CPL];  // the state as loaded
 #pragma unroll
-            for (int j = 0; j < FRZ_MAX_CAPACITIES; ++j) ci += r_agent[3] > d.cum[j] ? 1 : 0;
-            ci = ci > d.K - 1 ? d.K - 1 : ci;
-            const float new_max = table->caps[ci];
-            const bool sw = inc && (!(flags & kStochSwitch) || r_agent[4] < d.p_switch);
-            const float bonus = s - capa;
-            capa = sw ? new_max : capa;
-            s = sw ? new_max + bonus : s;
-            supp = s;
-            eqs = e;
-        }
-        // ------------------------------------------------------------ (4) fire increase / decrease per cell
+        for (int k = 0; k < CPL; ++k) f_in[k] = f[k], in_in[k] = in[k], fu_in[k] = fu[k];
+        // ------------------------------------------------------------ (4) field: fire increase / decrease per cell
         const int almost_state = d.num_fire_states - 2, burnout_state = d.num_fire_states - 1;
         const float p_unmet = (flags & kStochIncrease) ? d.p_increase : 1.0f;
         const float p_almost = (flags & kStochBurnouts) ? d.p_burnout : d.p_increase;  // fire_increase.py:77-80
         bool burned[CPL], put_out[CPL];
+        uint64_t burning[CPL];  // wave-uniform mask words, as `lit`
 #pragma unroll
         for (int k = 0; k < CPL; ++k) {
             const float ap = s_power[wave][lane + 64 * k];
             {  // transitions/fire_increase.py:61-91
                 const int required = f[k] >= 0 ? f[k] : 0;
                 const float diff = (float)required - ap;
-                const bool burning = f[k] > 0 && in[k] > 0;
-                const bool unmet = diff > 0.0f && burning;
+                const bool burns = f[k] > 0 && in[k] > 0;
+                const bool unmet = diff > 0.0f && burns;
                 const bool almost = unmet && in[k] == almost_state;
                 float prob = unmet ? (almost ? p_almost : p_unmet) : 0.0f;
                 prob = clamp01(prob);
@@ -342,8 +419,8 @@ __global__ void __launch_bounds__(kBlock) wg_env_kernel(char* __restrict__ arena
             {  // transitions/fire_decrease.py:56-77: p = p_dec + ((-1 * diff) * bonus), each op rounded
                 const int required = f[k] >= 0 ? f[k] : 0;
                 const float diff = (float)required - ap;
-                const bool burning = f[k] > 0 && in[k] > 0;
-                const bool met = diff <= 0.0f && burning;
+                const bool burns = f[k] > 0 && in[k] > 0;
+                const bool met = diff <= 0.0f && burns;
                 const float stoch_p = __fadd_rn(d.p_decrease, __fmul_rn(__fmul_rn(-1.0f, diff), d.decrease_bonus));
                 float prob = met ? ((flags & kStochDecrease) ? stoch_p : 1.0f) : 0.0f;
                 prob = clamp01(prob);
@@ -354,34 +431,35 @@ __global__ void __launch_bounds__(kBlock) wg_env_kernel(char* __restrict__ arena
                 fu[k] = po ? fu[k] - 1 : fu[k];  // unclamped, :75
                 put_out[k] = po;
             }
-            s_lit[wave][lane + 64 * k] = (uint8_t)(inside[k] && f[k] > 0 && in[k] > 0);
+            burning[k] = __ballot(inside[k] && f[k] > 0 && in[k] > 0);  // lit map after increase / decrease
             if (flags & kLocalize) s_put[wave][lane + 64 * k] = (uint8_t)put_out[k];
         }
-        wave_lds_sync();
-        // ------------------------------------------------------------ (5) fire spread: 4-neighbour stencil on the parked lit map
-        // (transitions/fire_spreads.py:44-57; conv2d accumulation order N, W, E, S)
+        // ------------------------------------------------------------ (5) field: fire spread, 4-neighbour stencil on the lit map
+        // (transitions/fire_spreads.py:44-57; conv2d accumulation order N, W, E, S).  The map is CPL wave-uniform mask words, so "my
+        // northern neighbour burns" is the map shifted by a row — scalar shifts — and the shifted word is the lane predicate of the add.
         bool any_fire = false;
         int fuel_sum = 0;
 #pragma unroll
         for (int k = 0; k < CPL; ++k) {
             const int c = lane + 64 * k;
-            const int cc = inside[k] ? c : 0;
-            const int y = (int)(((uint32_t)cc * d.inv_w) >> 16), x = cc - y * Wd;
-            const bool from_n = y > 0 && s_lit[wave][y > 0 ? cc - Wd : cc] != 0;
-            const bool from_w = x > 0 && s_lit[wave][x > 0 ? cc - 1 : cc] != 0;
-            const bool from_e = x < Wd - 1 && s_lit[wave][x < Wd - 1 ? cc + 1 : cc] != 0;
-            const bool from_s = y < d.H - 1 && s_lit[wave][y < d.H - 1 ? cc + Wd : cc] != 0;
+            const int y = (int)(((uint32_t)c * d.inv_w) >> 16), x = c - y * Wd;
+            const uint64_t first_col = __ballot(x == 0), last_col = __ballot(x == Wd - 1);
+            const uint64_t below = k > 0 ? burning[k > 0 ? k - 1 : 0] : 0ull, above = k + 1 < CPL ? burning[k + 1 < CPL ? k + 1 : k] : 0ull;
+            const uint64_t from_n = (burning[k] << Wd) | (below >> (64 - Wd));        // cell c - W burns (W <= 32; nothing shifts in above row 0)
+            const uint64_t from_s = (burning[k] >> Wd) | (above << (64 - Wd));        // cell c + W burns (no bits past the last cell)
+            const uint64_t from_w = ((burning[k] << 1) | (below >> 63)) & ~first_col;  // cell c - 1, same row
+            const uint64_t from_e = ((burning[k] >> 1) | (above << 63)) & ~last_col;   // cell c + 1, same row
             float prob = 0.0f;
-            prob = __fadd_rn(prob, from_n ? d.spread_n : 0.0f);
-            prob = __fadd_rn(prob, from_w ? d.spread_w : 0.0f);
-            prob = __fadd_rn(prob, from_e ? d.spread_e : 0.0f);
-            prob = __fadd_rn(prob, from_s ? d.spread_s : 0.0f);
+            prob = __fadd_rn(prob, frz::where_lane(from_n, d.spread_n));
+            prob = __fadd_rn(prob, frz::where_lane(from_w, d.spread_w));
+            prob = __fadd_rn(prob, frz::where_lane(from_e, d.spread_e));
+            prob = __fadd_rn(prob, frz::where_lane(from_s, d.spread_s));
             bool unlit = f[k] < 0 && in[k] == 0;
             unlit = unlit && (!(flags & kUseFuel) || fu[k] > 0);
             prob = unlit ? __fadd_rn(prob, d.random_ignition) : 0.0f;
             const bool spread = inside[k] && r_field[2][k] < prob;
             f[k] = spread ? -f[k] : f[k];
-            in[k] = spread ? frz::at32(cells.ignition, (uint32_t)cc) : in[k];
+            in[k] = spread ? ign[k] : in[k];
             any_fire = any_fire || (inside[k] && f[k] > 0);
             fuel_sum += inside[k] ? fu[k] : 0;
         }
@@ -391,22 +469,30 @@ __global__ void __launch_bounds__(kBlock) wg_env_kernel(char* __restrict__ arena
 #pragma unroll
         for (int k = 0; k < CPL; ++k) {
             f[k] = dead ? 0 : f[k];  // :570
-            if (inside[k]) {
-                const uint32_t c = (uint32_t)(lane + 64 * k);
-                frz::at32(fires, c) = f[k], frz::at32(intensity, c) = in[k], frz::at32(fuel, c) = fu[k];
+            // a 64-cell run that no transition touched (most of a large grid, most steps) is not written back
+            const uint32_t c = (uint32_t)(lane + 64 * k);
+            if (__ballot(inside[k] && f[k] != f_in[k])) {
+                if (inside[k]) frz::at32(fires, c) = f[k];
+            }
+            if (__ballot(inside[k] && in[k] != in_in[k])) {
+                if (inside[k]) frz::at32(intensity, c) = in[k];
+            }
+            if (__ballot(inside[k] && fu[k] != fu_in[k])) {
+                if (inside[k]) frz::at32(fuel, c) = fu[k];
             }
             lit[k] = __ballot(inside[k] && f[k] > 0);
         }
-        // ------------------------------------------------------------ (6) rewards and termination (wildfire.py:534-582)
+        // ------------------------------------------------------------ (6) field: what the rewards need (wildfire.py:534-582)
         // put-out cells pay their reward, burnt-out cells their penalty: summed in cell order (few cells: a walk over the set bits)
         float fire_reward_sum = 0.0f, burnout_total = 0.0f;
+        int n_burn = 0, n_put = 0;
 #pragma unroll
         for (int k = 0; k < CPL; ++k) {
             const uint64_t pm = __ballot(put_out[k]), bm = __ballot(burned[k]);
             n_put += (int)__popcll(pm);
             n_burn += (int)__popcll(bm);
             if (pm | bm) {
-                const float fr = frz::at32(cells.fire_rewards, (uint32_t)(inside[k] ? lane + 64 * k : 0));
+                const float fr = fire_reward[k];
                 for (uint64_t m = pm; m; m &= m - 1) fire_reward_sum = __fadd_rn(fire_reward_sum, __int_as_float(read_lane(__float_as_int(fr), frz::first_bit(m))));
                 for (uint64_t m = bm; m; m &= m - 1) {
                     const float r = __int_as_float(read_lane(__float_as_int(fr), frz::first_bit(m)));
@@ -414,32 +500,8 @@ __global__ void __launch_bounds__(kBlock) wg_env_kernel(char* __restrict__ arena
                 }
             }
         }
-        const bool newly = !term0 && dead;
-        // correctly rounded float32 log via double (matches the oracle bit for bit; the reference's torch.log is a <=1-ulp float32 log)
-        float log_burnouts = 0.0f;
-        if (newly && d.termination_kappa != 0.0f) log_burnouts = (float)log((double)nb + 1.0);
-        float term_reward = __fsub_rn(d.termination_reward, __fmul_rn(d.termination_kappa, log_burnouts));
-        term_reward = term_reward < 0.0f ? 0.0f : term_reward;
-        float base_reward = fire_reward_sum;
-        if (flags & kLocalize) {  // only the put-outs this agent last hit (:546-553)
-            const bool mine = hit >= 0 && s_put[wave][tcell] != 0;
-            base_reward = mine ? frz::at32(cells.fire_rewards, (uint32_t)tcell) : 0.0f;
-        }
-        reward = __fadd_rn(reward, __fadd_rn(base_reward, burnout_total));
-        reward = newly ? __fadd_rn(reward, term_reward) : reward;
-        const int nm1 = nm + 1;
-        trunc = (flags & kTruncate) ? nm1 >= d.max_steps : trunc0;
-        term = term0 || dead;
-        if (lane == 0) {
-            frz::at32(rows, (uint32_t)d.r_moves * Bu + bu) = nm1;
-            frz::at32(rows, (uint32_t)d.r_burnouts * Bu + bu) = nb + n_burn;
-            frz::at32(rows8, (uint32_t)d.q_burnouts * Bu + bu) = n_burn;
-            frz::at32(rows8, (uint32_t)d.q_putouts * Bu + bu) = n_put;
-        }
+        if (lane == 0) s_sums[wave] = FieldSums{fire_reward_sum, burnout_total, n_put, n_burn, dead ? 1 : 0, 0};
     }
-
-    // ---------------------------------------------------------------- per-env outputs that are not lists: state rows of the agents,
-    // counts of the rebuilt spaces (wildfire.py:586-666), agent observations (wildfire.py:668-717)
     if (MODE == kReset) {
 #pragma unroll
         for (int k = 0; k < CPL; ++k)
@@ -447,218 +509,119 @@ __global__ void __launch_bounds__(kBlock) wg_env_kernel(char* __restrict__ arena
                 const uint32_t c = (uint32_t)(lane + 64 * k);
                 frz::at32(fires, c) = f[k], frz::at32(intensity, c) = in[k], frz::at32(fuel, c) = fu[k];
             }
-        if (lane == 0) {
-            frz::at32(rows, (uint32_t)d.r_moves * Bu + bu) = 0;
-            frz::at32(rows, (uint32_t)d.r_burnouts * Bu + bu) = 0;
-            frz::at32(rows8, (uint32_t)d.q_burnouts * Bu + bu) = 0;
-            frz::at32(rows8, (uint32_t)d.q_putouts * Bu + bu) = 0;
-            frz::at32(rows1, (uint32_t)d.u_frozen * Bu + bu) = 0;
-            if (pol.on)  // frz_wildfire_reset_reseed: seed increment, modulo 2^32
-                frz::at32(rows, (uint32_t)d.r_seeds * Bu + bu) = (int32_t)((uint32_t)frz::at32(rows, (uint32_t)d.r_seeds * Bu + bu) + pol.seed_lo);
-        }
     }
-    uint32_t ok1[W2];
-    attackable_words(lit, supp, eqs, ok1);
-    const int n_attackable = popc_words(ok1);
-    int n_fires = 0;
-#pragma unroll
-    for (int k = 0; k < CPL; ++k) n_fires += (int)__popcll(lit[k]);
-    if (is_agent) {
-        if (MODE != kRebuild) {
-            frz::at32(rowsf, (uint32_t)(d.r_supp + lane) * Bu + bu) = supp;
-            frz::at32(rowsf, (uint32_t)(d.r_cap + lane) * Bu + bu) = capa;
-            frz::at32(rows, (uint32_t)(d.r_equip + lane) * Bu + bu) = eqs;
-            frz::at32(rowsf, (uint32_t)(d.r_rewards + lane) * Bu + bu) = reward;
-            frz::at32(rows1, (uint32_t)(d.u_term + lane) * Bu + bu) = (uint8_t)term;
-            if (MODE == kReset || (flags & kTruncate)) frz::at32(rows1, (uint32_t)(d.u_trunc + lane) * Bu + bu) = (uint8_t)trunc;
-            if (MODE == kReset || (flags & kTrackCumulative)) frz::at32(rowsf, (uint32_t)(d.r_cum + lane) * Bu + bu) = __fadd_rn(cum0, reward);
-        }
-        frz::at32(rows, (uint32_t)(d.r_atc + lane) * Bu + bu) = n_attackable;
-        s_supp[wave][lane] = supp;
-    }
-    if (lane == 0) frz::at32(rows8, (uint32_t)d.q_etc * Bu + bu) = n_fires;
-    {   // what wg_lists_kernel reads instead of the cells: the lit mask words and (fires, intensity) of the lit cells in task order
+    // ---------------------------------------------------------------- field: what the lists launch reads instead of the cells — the lit
+    // mask words and (fires, intensity) of the lit cells in task order
+    {
         uint64_t* const litmap = reinterpret_cast<uint64_t*>(arena + d.off_litmap);
-        uint64_t* const okmap = reinterpret_cast<uint64_t*>(arena + d.off_okmap);
-        if (is_agent) {
-#pragma unroll
-            for (int k = 0; k < CPL; ++k) okmap[((int64_t)lane * CPL + k) * B + b] = (uint64_t)ok1[2 * k] | ((uint64_t)ok1[2 * k + 1] << 32);
-        }
         int2* const lit_cells = reinterpret_cast<int2*>(arena + d.off_lit_cells) + (int64_t)b * ((HW + 1) & ~1);  // 16-byte aligned rows
         int before = 0;
 #pragma unroll
         for (int k = 0; k < CPL; ++k) {
-            if (lane == 0) litmap[(int64_t)k * B + b] = lit[k];
+            if (lane == 0) litmap[(int64_t)k * B + b] = lit[k], s_lit[1][wave][k] = lit[k];
             if ((lit[k] >> lane) & 1ull) frz::at32(lit_cells, (uint32_t)(before + lane_rank(lit[k]))) = make_int2(f[k], in[k]);
             before += (int)__popcll(lit[k]);
         }
+        if (lane == 0) frz::at32(rows8, (uint32_t)d.q_etc * Bu + bu) = before;  // environment_task_count
+    }
+    if (!kStepping && crew) {
+        s_table[lane] = table_w0, s_table[lane + 64] = table_w1;
+        if constexpr (CPL <= 4) {
+            if (range_staged) s_range[lane] = range_w0, s_range[lane + 64] = range_w1;
+        }
+    }
+    __syncthreads();
+    if (!crew) {
+        if (err) atomicOr(reinterpret_cast<uint32_t*>(arena + d.off_error), err);
+        return;
+    }
+
+    // ---------------------------------------------------------------- crew: rewards and termination (wildfire.py:534-582), bookkeeping,
+    // state rows of the agents, counts of the rebuilt spaces (wildfire.py:586-666), agent observations (wildfire.py:668-717)
+    const float base_power = tablef[agent];
+    bool term = term0, trunc = trunc0;
+    if (kStepping) {
+        const FieldSums sums = s_sums[ce < n_envs ? ce : 0];
+        const bool dead = sums.dead != 0;
+        const bool newly = !term0 && dead;
+        // correctly rounded float32 log via double (matches the oracle bit for bit; the reference's torch.log is a <=1-ulp float32 log)
+        float log_burnouts = 0.0f;
+        if (newly && d.termination_kappa != 0.0f) log_burnouts = (float)log((double)c_nb + 1.0);
+        float term_reward = __fsub_rn(d.termination_reward, __fmul_rn(d.termination_kappa, log_burnouts));
+        term_reward = term_reward < 0.0f ? 0.0f : term_reward;
+        float base_reward = sums.fire_reward_sum;
+        if (flags & kLocalize) {  // only the put-outs this agent last hit (:546-553)
+            const bool mine = hit >= 0 && s_put[ce][tcell] != 0;
+            base_reward = mine ? frz::at32(cells.fire_rewards, (uint32_t)tcell) : 0.0f;
+        }
+        reward = __fadd_rn(reward, __fadd_rn(base_reward, sums.burnout_total));
+        reward = newly ? __fadd_rn(reward, term_reward) : reward;
+        const int nm1 = c_nm + 1;
+        trunc = (flags & kTruncate) ? nm1 >= d.max_steps : trunc0;
+        term = term0 || dead;
+        if (ca == 0 && ce < n_envs) {
+            frz::at32(rows, (uint32_t)d.r_moves * Bu + cbu) = nm1;
+            frz::at32(rows, (uint32_t)d.r_burnouts * Bu + cbu) = c_nb + sums.n_burn;
+            frz::at32(rows8, (uint32_t)d.q_burnouts * Bu + cbu) = sums.n_burn;
+            frz::at32(rows8, (uint32_t)d.q_putouts * Bu + cbu) = sums.n_put;
+        }
+    }
+    if (MODE == kReset && ca == 0 && ce < n_envs) {
+        frz::at32(rows, (uint32_t)d.r_moves * Bu + cbu) = 0;
+        frz::at32(rows, (uint32_t)d.r_burnouts * Bu + cbu) = 0;
+        frz::at32(rows8, (uint32_t)d.q_burnouts * Bu + cbu) = 0;
+        frz::at32(rows8, (uint32_t)d.q_putouts * Bu + cbu) = 0;
+        frz::at32(rows1, (uint32_t)d.u_frozen * Bu + cbu) = 0;
+        if (pol.on)  // frz_wildfire_reset_reseed: seed increment, modulo 2^32
+            frz::at32(rows, (uint32_t)d.r_seeds * Bu + cbu) = (int32_t)((uint32_t)frz::at32(rows, (uint32_t)d.r_seeds * Bu + cbu) + pol.seed_lo);
+    }
+    uint32_t ok1[W2];
+    attackable_words(1, supp, eqs, ok1);
+    const int n_attackable = popc_words(ok1);
+    if (is_agent) {
+        if (MODE != kRebuild) {
+            frz::at32(rowsf, (uint32_t)(d.r_supp + agent) * Bu + cbu) = supp;
+            frz::at32(rowsf, (uint32_t)(d.r_cap + agent) * Bu + cbu) = capa;
+            frz::at32(rows, (uint32_t)(d.r_equip + agent) * Bu + cbu) = eqs;
+            frz::at32(rowsf, (uint32_t)(d.r_rewards + agent) * Bu + cbu) = reward;
+            frz::at32(rows1, (uint32_t)(d.u_term + agent) * Bu + cbu) = (uint8_t)term;
+            if (MODE == kReset || (flags & kTruncate)) frz::at32(rows1, (uint32_t)(d.u_trunc + agent) * Bu + cbu) = (uint8_t)trunc;
+            if (MODE == kReset || (flags & kTrackCumulative)) frz::at32(rowsf, (uint32_t)(d.r_cum + agent) * Bu + cbu) = __fadd_rn(cum0, reward);
+        }
+        frz::at32(rows, (uint32_t)(d.r_atc + agent) * Bu + cbu) = n_attackable;
+        s_supp[ce][agent] = supp;
+        uint64_t* const okmap = reinterpret_cast<uint64_t*>(arena + d.off_okmap);
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) okmap[((int64_t)agent * CPL + k) * B + cbu] = (uint64_t)ok1[2 * k] | ((uint64_t)ok1[2 * k + 1] << 32);
     }
     // agent observations: self = (y, x, fire_reduction_power, suppressant); others = (y, x[, power][, suppressant]) of the other agents.
-    // Agents do not move and their base power is configuration: reset / rebuild write whole records, a step only the suppressant column.
+    // Agents do not move and their base power is configuration, so only the suppressant column changes in a step — but whole records are
+    // written (a 4-byte piece of a 16-byte record leaves every sector of these arrays partly dirty).
     float* const obs_self = reinterpret_cast<float*>(arena + d.off_obs_self);
     float* const obs_others = reinterpret_cast<float*>(arena + d.off_obs_others);
-    if (is_agent) {
-        if (kStepping)
-            frz::at32(obs_self, ((uint32_t)lane * Bu + bu) * 4u + 3u) = supp;
-        else
-            frz::at32(reinterpret_cast<float4*>(obs_self), (uint32_t)lane * Bu + bu) = make_float4((float)table->ay[lane], (float)table->ax[lane], base_power, supp);
-    }
+    if (is_agent)
+        frz::at32(reinterpret_cast<float4*>(obs_self), (uint32_t)agent * Bu + cbu) = make_float4((float)(int)s_table[kAyAt + agent], (float)(int)s_table[kAxAt + agent], base_power, supp);
     wave_lds_sync();
     {
         const int others = A - 1, pairs = A * others, width = d.others_k;
         const bool op = (flags & kObsPower) != 0, os = (flags & kObsSupp) != 0;
         if (!kStepping || os)
-            for (int q = lane; q < pairs; q += 64) {  // one lane per (agent, other agent) record
-                const int a = (int)(((uint32_t)q * d.inv_others) >> 16), j = q - a * others, o = j < a ? j : j + 1;
-                float* const rec = obs_others + ((int64_t)a * B + b) * (others * width) + j * width;
-                const float so = s_supp[wave][o];
-                if (kStepping) {
-                    rec[width - 1] = so;  // the suppressant column is the last one
-                } else {
-                    rec[0] = (float)table->ay[o];
-                    rec[1] = (float)table->ax[o];
-                    if (op) rec[2] = table->power[o];
-                    if (os) rec[width - 1] = so;
+            for (int e = 0; e < n_envs; ++e)
+                for (int q = lane; q < pairs; q += 64) {  // one lane per (agent, other agent) record
+                    const int a = (int)(((uint32_t)q * d.inv_others) >> 16), j = q - a * others, o = j < a ? j : j + 1;
+                    float* const rec = obs_others + ((int64_t)a * B + b0 + e) * (others * width) + j * width;
+                    const float so = s_supp[e][o], y = (float)(int)s_table[kAyAt + o], x = (float)(int)s_table[kAxAt + o];
+                    if (width == 4) {
+                        *reinterpret_cast<float4*>(rec) = make_float4(y, x, tablef[o], so);
+                    } else {
+                        rec[0] = y;
+                        rec[1] = x;
+                        if (op) rec[2] = tablef[o];
+                        if (os) rec[width - 1] = so;
+                    }
                 }
-            }
     }
     if (err) atomicOr(reinterpret_cast<uint32_t*>(arena + d.off_error), err);
-}
-
-// ------------------------------------------------------------------------------------------------------------------------------------
-// wg_offsets_kernel: one env per lane.  Exclusive prefix sums over the batch of (lit fires, attackable fires of agent 0, 1, ...) = where
-// each env's segment of each jagged list starts; the batch totals (the skip-agent quirk, the freeze test) stay for the next launch.
-// ------------------------------------------------------------------------------------------------------------------------------------
-template <int AMAX, int BITS>  // BITS = 16: at most 255 cells per env (the scan packs four counts per word), else 32
-__global__ void __launch_bounds__(kBlock) wg_offsets_kernel(char* __restrict__ arena, const WgDev d, uint32_t ticketed) {
-    constexpr int kChannels = AMAX + 1;  // scan channels: lit fires, attackable fires of each agent
-    __shared__ frz::ScanShared<kChannels, BITS> s_scan;
-    __shared__ int s_ticket;
-    const int tid = threadIdx.x;
-    const int64_t B = d.B;
-    const int A = d.A;
-    frz::ScanWorkspace ws{reinterpret_cast<uint32_t*>(arena + d.off_epoch), reinterpret_cast<uint32_t*>(arena + d.off_totals),
-                          reinterpret_cast<uint64_t*>(arena + d.off_agg), reinterpret_cast<uint64_t*>(arena + d.off_prefix)};
-    const frz::ScanLaunch launch = frz::scan_begin(ws);
-    const int chunk = frz::scan_take_chunk(ws, d.nchunks, ticketed != 0, &s_ticket);
-    const int64_t b = (int64_t)chunk * kBlock + tid;
-    const bool active = b < B;
-    const int64_t bl = active ? b : B - 1;
-    const int32_t* rows = reinterpret_cast<const int32_t*>(arena + d.off_rows4);
-    const int64_t* rows8 = reinterpret_cast<const int64_t*>(arena + d.off_rows8);
-    const uint8_t* rows1 = reinterpret_cast<const uint8_t*>(arena + d.off_rows1);
-    uint32_t cnt[kChannels], excl[kChannels];
-    cnt[0] = active ? (uint32_t)rows8[(int64_t)d.q_etc * B + bl] : 0u;
-#pragma unroll
-    for (int a = 0; a < AMAX; ++a) cnt[a + 1] = (active && a < A) ? (uint32_t)rows[(int64_t)(d.r_atc + (a < A ? a : 0)) * B + bl] : 0u;
-    const bool term = rows1[(int64_t)d.u_term * B + bl] != 0, trunc = rows1[(int64_t)d.u_trunc * B + bl] != 0;
-    uint32_t err = 0;
-    frz::scan_chunk<kChannels, BITS>(s_scan, ws, launch, cnt, active && !term, active && !trunc, A + 1, chunk, d.nchunks, excl, &err);
-    if (active) {
-        int64_t* const task_offsets = reinterpret_cast<int64_t*>(arena + d.off_task_offsets);
-        int64_t* const act_offsets = reinterpret_cast<int64_t*>(arena + d.off_act_offsets);
-        int64_t* const bad_offsets = reinterpret_cast<int64_t*>(arena + d.off_bad_offsets);
-        const bool show_bad = (d.flags & kShowBad) != 0;
-        task_offsets[b] = excl[0];
-        if (b == B - 1) task_offsets[B] = (int64_t)excl[0] + cnt[0];
-#pragma unroll
-        for (int a = 0; a < AMAX; ++a)
-            if (a < A) {
-                act_offsets[a * (B + 1) + b] = excl[a + 1];
-                if (b == B - 1) act_offsets[a * (B + 1) + B] = (int64_t)excl[a + 1] + cnt[a + 1];
-                if (show_bad) {  // bad = listed but not attackable
-                    bad_offsets[a * (B + 1) + b] = (int64_t)excl[0] - excl[a + 1];
-                    if (b == B - 1) bad_offsets[a * (B + 1) + B] = ((int64_t)excl[0] + cnt[0]) - ((int64_t)excl[a + 1] + cnt[a + 1]);
-                }
-            }
-    }
-    if (err) atomicOr(reinterpret_cast<uint32_t*>(arena + d.off_error), err);
-    frz::scan_end(ws, launch, chunk, d.nchunks);
-}
-
-// ------------------------------------------------------------------------------------------------------------------------------------
-// wg_emit_kernel: the lists of update_actions / update_observations (wildfire.py:586-717) for ONE env per wavefront: task rows
-// (y, x, fires level, intensity) of the lit fires in row-major order, the observation map (0 .. F-1), and per agent the task indices of
-// its attackable fires (and, with show_bad_actions, of the listed-but-not-attackable ones).  A fire's task index is its rank among the
-// lit cells; its place in an agent's list is its rank among that agent's attackable cells: ballots and lane ranks, chunk by chunk.
-// ------------------------------------------------------------------------------------------------------------------------------------
-template <int CPL>
-__global__ void __launch_bounds__(kBlock) wg_emit_kernel(char* __restrict__ arena, const WgDev d) {
-    const int b = frz::env_of_wave<kEnvsPerBlock>(d.B);
-    if (b < 0) return;
-    const int lane = threadIdx.x & 63;
-    const int64_t B = d.B;
-    const uint32_t Bu = (uint32_t)d.B, bu = (uint32_t)b;
-    const int HW = d.HW, A = d.A, Wd = d.W;
-    const bool is_agent = lane < A;
-    const int agent = is_agent ? lane : A - 1;
-    const int32_t* rows = reinterpret_cast<const int32_t*>(arena + d.off_rows4);
-    const float* rowsf = reinterpret_cast<const float*>(arena + d.off_rows4);
-    const int32_t* fires = reinterpret_cast<const int32_t*>(arena + d.off_cells) + (int64_t)b * HW;
-    const int32_t* intensity = fires + B * HW;
-    int f[CPL], in[CPL];
-    uint64_t lit[CPL];
-#pragma unroll
-    for (int k = 0; k < CPL; ++k) {
-        const int c = lane + 64 * k;
-        const uint32_t cc = (uint32_t)(c < HW ? c : HW - 1);
-        f[k] = frz::at32(fires, cc), in[k] = frz::at32(intensity, cc);
-    }
-    const float supp = frz::at32(rowsf, (uint32_t)(d.r_supp + agent) * Bu + bu);
-    const int eqs = frz::at32(rows, (uint32_t)(d.r_equip + agent) * Bu + bu);
-    const int64_t task_base = reinterpret_cast<const int64_t*>(arena + d.off_task_offsets)[b];
-    const int64_t act_first = reinterpret_cast<const int64_t*>(arena + d.off_act_offsets)[(int64_t)agent * (B + 1) + b];  // agent-lane
-    const uint64_t* mine = reinterpret_cast<const uint64_t*>(arena + d.off_range) + ((int64_t)agent * d.S + eqs) * CPL;
-    uint32_t ok_lo[CPL], ok_hi[CPL];  // agent-lane: the agent's attackable cells
-#pragma unroll
-    for (int k = 0; k < CPL; ++k) {
-        lit[k] = __ballot(lane + 64 * k < HW && f[k] > 0);
-        const uint64_t m = (is_agent && supp > 0.0f) ? (lit[k] & mine[k]) : 0ull;
-        ok_lo[k] = (uint32_t)m, ok_hi[k] = (uint32_t)(m >> 32);
-    }
-    const int64_t cap = B * (int64_t)HW;
-    int64_t* const task_values = reinterpret_cast<int64_t*>(arena + d.off_task_values);
-    int64_t* const obs_map = reinterpret_cast<int64_t*>(arena + d.off_obs_map);
-    int64_t* const act_values = reinterpret_cast<int64_t*>(arena + d.off_act_values);
-    int64_t* const bad_values = reinterpret_cast<int64_t*>(arena + d.off_bad_values);
-    const bool show_bad = (d.flags & kShowBad) != 0;
-    int rank[CPL];  // cell-lane: the fire's task index (rank among the lit cells)
-    {
-        int before = 0;
-#pragma unroll
-        for (int k = 0; k < CPL; ++k) {
-            rank[k] = before + lane_rank(lit[k]);
-            before += (int)__popcll(lit[k]);
-            if ((lit[k] >> lane) & 1ull) {
-                const int c = lane + 64 * k;
-                const int y = (int)(((uint32_t)c * d.inv_w) >> 16), x = c - y * Wd;
-                longlong2* const row = reinterpret_cast<longlong2*>(task_values + (task_base + rank[k]) * 4);
-                row[0] = make_longlong2(y, x);
-                row[1] = make_longlong2(f[k], in[k]);
-                obs_map[task_base + rank[k]] = rank[k];
-            }
-        }
-    }
-    for (int a = 0; a < A; ++a) {
-        const int64_t first = (int64_t)a * cap + ((int64_t)(uint32_t)read_lane((int)(uint32_t)act_first, a) | ((int64_t)read_lane((int)(act_first >> 32), a) << 32));
-        const int64_t bad_first = (int64_t)a * cap + task_base - (first - (int64_t)a * cap);
-        int placed = 0, placed_bad = 0;
-#pragma unroll
-        for (int k = 0; k < CPL; ++k) {
-            const uint64_t ok = (uint64_t)(uint32_t)read_lane((int)ok_lo[k], a) | ((uint64_t)(uint32_t)read_lane((int)ok_hi[k], a) << 32);
-            if (ok) {
-                if ((ok >> lane) & 1ull) act_values[first + placed + lane_rank(ok)] = rank[k];
-                placed += (int)__popcll(ok);
-            }
-            if (show_bad) {
-                const uint64_t bad = lit[k] & ~ok;
-                if (bad) {
-                    if ((bad >> lane) & 1ull) bad_values[bad_first + placed_bad + lane_rank(bad)] = rank[k];
-                    placed_bad += (int)__popcll(bad);
-                }
-            }
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
