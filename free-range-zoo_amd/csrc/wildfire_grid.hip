@@ -229,6 +229,7 @@ __global__ void __launch_bounds__(kBlock) wg_env_kernel(char* __restrict__ arena
 
     float reward = 0.0f;
     int hit = -1, tcell = 0;
+    bool good = false, refill = false;  // crew: the agent fights a listed task / refills
     float r_field[kStepping ? 3 : 1][CPL];
     if (kStepping) {
         // ------------------------------------------------------------ (1) field: the env's draws, the loaded state's lit words
@@ -270,11 +271,10 @@ __global__ void __launch_bounds__(kBlock) wg_env_kernel(char* __restrict__ arena
         }
         __syncthreads();
 
-        // ------------------------------------------------------------ (2) crew: action decode (wildfire.py:427-483)
+        // ------------------------------------------------------------ (2) crew: action decode (wildfire.py:427-483).  Only what the fields
+        // wait for — who fights which cell with what power; the agent transitions follow when the fields are done.
         // The action mapping of the previous rebuild is a pure function of the state it was built from, which is the state just
         // loaded: attackable set of agent a = lit fires within its (equipment-adjusted) range, non-empty only while it has suppressant.
-        bool good = false, refill = false;
-        float r_agent[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         if (crew) {
             const float base_power = tablef[agent];
             uint32_t ok0[W2], sel[W2];
@@ -333,51 +333,8 @@ __global__ void __launch_bounds__(kBlock) wg_env_kernel(char* __restrict__ arena
             } else {
                 if (good) atomicAdd(&s_power[ce][tcell], power);
             }
-            // the agents' draws
-            if (kPhilox) {
-#pragma unroll
-                for (int e = 0; e < 5; ++e) r_agent[e] = s_draw[ce][3 * HW + e * A + agent];
-            } else {  // the tensor generator.generate(B, 5, (A,)) returns (wildfire.py:409-410)
-#pragma unroll
-                for (int e = 0; e < 5; ++e) r_agent[e] = agent_rand[((int64_t)e * B + cbu) * A + agent];
-            }
-            // -------------------------------------------------------- (3) crew: agent transitions (suppressant decrease, equipment, refill, capacity)
-            {
-                // transitions/suppressant_decrease.py:56-61
-                const bool dec = good && (!(flags & kStochSuppDecrease) || r_agent[0] < d.p_supp_decrease);
-                float s = dec ? supp - 1.0f : supp;
-                s = s < 0.0f ? 0.0f : s;
-                // transitions/equipment.py:51-75 (masks from the value before any write)
-                const int e0 = eqs, top = d.S - 1;
-                const bool pristine = e0 == top, damaged = e0 == 0, inter = !pristine && !damaged;
-                const float r1 = r_agent[1];
-                const bool repairs = (flags & kStochRepair) ? (damaged && r1 < d.p_repair) : damaged;
-                const bool crit = (flags & kCritical) && pristine && r1 < d.p_critical;
-                bool degr = (flags & kStochDegrade) ? ((pristine || inter) && r1 < d.p_degrade) : (inter || pristine);
-                degr = degr && !crit;
-                int e = repairs ? top : e0;
-                e = crit ? 0 : e;
-                e = degr ? e - 1 : e;
-                // transitions/suppressant_refill.py:63-70 (bonus from the NEW equipment state)
-                const bool inc = refill && (!(flags & kStochRefill) || r_agent[2] < d.p_refill);
-                s = inc ? capa + tablef[kEqAt + 4 * e] : s;
-                // transitions/capacity.py:52-64: bucketize(r, cumsum) = #{j : cum[j] < r} (cum padded with +inf, clamped to the last capacity)
-                int ci = 0;
-#pragma unroll
-                for (int j = 0; j < FRZ_MAX_CAPACITIES; ++j) ci += r_agent[3] > d.cum[j] ? 1 : 0;
-                ci = ci > d.K - 1 ? d.K - 1 : ci;
-                const float new_max = tablef[kCapsAt + ci];
-                const bool sw = inc && (!(flags & kStochSwitch) || r_agent[4] < d.p_switch);
-                const float bonus = s - capa;
-                capa = sw ? new_max : capa;
-                s = sw ? new_max + bonus : s;
-                supp = s;
-                eqs = e;
-            }
         }
-        __syncthreads();
-
-        // ------------------------------------------------------------ field: the cells' draws
+        // ------------------------------------------------------------ field: the cells' draws (read while the crew decodes)
         if (kPhilox) {
 #pragma unroll
             for (int e = 0; e < 3; ++e)
@@ -389,6 +346,8 @@ __global__ void __launch_bounds__(kBlock) wg_env_kernel(char* __restrict__ arena
 #pragma unroll
                 for (int k = 0; k < CPL; ++k) r_field[e][k] = inside[k] ? field_rand[((int64_t)e * B + b) * HW + lane + 64 * k] : 1.0f;
         }
+        __syncthreads();
+
         int f_in[CPL], in_in[CPL], fu_in[CPL];  // the state as loaded
 #pragma unroll
         for (int k = 0; k < CPL; ++k) f_in[k] = f[k], in_in[k] = in[k], fu_in[k] = fu[k];
@@ -541,6 +500,48 @@ __global__ void __launch_bounds__(kBlock) wg_env_kernel(char* __restrict__ arena
     const float base_power = tablef[agent];
     bool term = term0, trunc = trunc0;
     if (kStepping) {
+        // the agents' draws (the fields' LDS is theirs until the workgroup ends)
+        float r_agent[5];
+        if (kPhilox) {
+#pragma unroll
+            for (int e = 0; e < 5; ++e) r_agent[e] = s_draw[ce][3 * HW + e * A + agent];
+        } else {  // the tensor generator.generate(B, 5, (A,)) returns (wildfire.py:409-410)
+#pragma unroll
+            for (int e = 0; e < 5; ++e) r_agent[e] = agent_rand[((int64_t)e * B + cbu) * A + agent];
+        }
+        // -------------------------------------------------------- (3) crew: agent transitions (suppressant decrease, equipment, refill, capacity)
+        {
+            // transitions/suppressant_decrease.py:56-61
+            const bool dec = good && (!(flags & kStochSuppDecrease) || r_agent[0] < d.p_supp_decrease);
+            float s = dec ? supp - 1.0f : supp;
+            s = s < 0.0f ? 0.0f : s;
+            // transitions/equipment.py:51-75 (masks from the value before any write)
+            const int e0 = eqs, top = d.S - 1;
+            const bool pristine = e0 == top, damaged = e0 == 0, inter = !pristine && !damaged;
+            const float r1 = r_agent[1];
+            const bool repairs = (flags & kStochRepair) ? (damaged && r1 < d.p_repair) : damaged;
+            const bool crit = (flags & kCritical) && pristine && r1 < d.p_critical;
+            bool degr = (flags & kStochDegrade) ? ((pristine || inter) && r1 < d.p_degrade) : (inter || pristine);
+            degr = degr && !crit;
+            int e = repairs ? top : e0;
+            e = crit ? 0 : e;
+            e = degr ? e - 1 : e;
+            // transitions/suppressant_refill.py:63-70 (bonus from the NEW equipment state)
+            const bool inc = refill && (!(flags & kStochRefill) || r_agent[2] < d.p_refill);
+            s = inc ? capa + tablef[kEqAt + 4 * e] : s;
+            // transitions/capacity.py:52-64: bucketize(r, cumsum) = #{j : cum[j] < r} (cum padded with +inf, clamped to the last capacity)
+            int ci = 0;
+#pragma unroll
+            for (int j = 0; j < FRZ_MAX_CAPACITIES; ++j) ci += r_agent[3] > d.cum[j] ? 1 : 0;
+            ci = ci > d.K - 1 ? d.K - 1 : ci;
+            const float new_max = tablef[kCapsAt + ci];
+            const bool sw = inc && (!(flags & kStochSwitch) || r_agent[4] < d.p_switch);
+            const float bonus = s - capa;
+            capa = sw ? new_max : capa;
+            s = sw ? new_max + bonus : s;
+            supp = s;
+            eqs = e;
+        }
         const FieldSums sums = s_sums[ce < n_envs ? ce : 0];
         const bool dead = sums.dead != 0;
         const bool newly = !term0 && dead;
@@ -645,8 +646,8 @@ struct ListShared {  // per wavefront: its 64 envs' mask words and segment start
 // (a population-count descent on its mask words): every lane works whatever the fires per env, and every store instruction writes 64
 // consecutive entries.  sel: the cells the lane's env lists (all lanes pass theirs); first: where its segment starts in dst;
 // emit(entry index in dst, env slot, position in the env's segment, cell, task index of the cell).
-template <int CPL, bool RANK, typename F>
-__device__ __forceinline__ void output_parallel_list(ListShared<CPL>& sh, const uint64_t (&sel)[CPL], int64_t first, int lane, F&& emit) {
+template <int CPL, bool RANK, typename L, typename F>
+__device__ __forceinline__ void output_parallel_list(ListShared<CPL>& sh, const uint64_t (&sel)[CPL], int64_t first, int lane, L&& fetch, F&& emit) {
     int n = 0;
 #pragma unroll
     for (int k = 0; k < CPL; ++k) n += (int)__popcll(sel[k]);
@@ -659,31 +660,47 @@ __device__ __forceinline__ void output_parallel_list(ListShared<CPL>& sh, const 
     sh.rel[lane] = rel;
     if (lane == 63) sh.rel[64] = total;
     wave_lds_sync();
-    for (int base = 0; base < total; base += 64) {
-        const int i = base + lane;
-        int e = 0;
+    auto tiles = [&](auto width, int from, int to) {
+      constexpr int U = decltype(width)::value;
+      for (int base = from; base < to; base += 64 * U) {
+        int e[U], j[U], c[U], rank[U];
+        decltype(fetch(0, 0)) got[U];
 #pragma unroll
-        for (int step = 32; step >= 1; step >>= 1) e += sh.rel[e + step] <= i ? step : 0;  // the last env that starts at or before i
-        const int j = i - sh.rel[e];
-        uint32_t w[2 * CPL];
+        for (int u = 0; u < U; ++u) {
+            const int i = base + 64 * u + lane;
+            e[u] = 0;
 #pragma unroll
-        for (int k = 0; k < CPL; ++k) {
-            const uint64_t v = sh.sel[e][k];
-            w[2 * k] = (uint32_t)v, w[2 * k + 1] = (uint32_t)(v >> 32);
-        }
-        const int c = select_nth(w, i < total ? j : -1);  // -1 past the range
-        int rank = j;
-        if (RANK) {  // the cell's rank among the env's lit cells
-            rank = 0;
+            for (int step = 32; step >= 1; step >>= 1) e[u] += sh.rel[e[u] + step] <= i ? step : 0;  // the last env that starts at or before i
+            j[u] = i - sh.rel[e[u]];
+            uint32_t w[2 * CPL];
 #pragma unroll
             for (int k = 0; k < CPL; ++k) {
-                const uint64_t v = sh.lit[e][k];
-                const uint64_t below = (c >> 6) > k ? ~0ull : ((c >> 6) == k ? (1ull << (c & 63)) - 1ull : 0ull);
-                rank += (int)__popcll(v & below);
+                const uint64_t v = sh.sel[e[u]][k];
+                w[2 * k] = (uint32_t)v, w[2 * k + 1] = (uint32_t)(v >> 32);
+            }
+            c[u] = select_nth(w, i < total ? j[u] : -1);  // -1 past the range
+            if (c[u] >= 0) got[u] = fetch(e[u], j[u]);
+            rank[u] = j[u];
+            if (RANK) {  // the cell's rank among the env's lit cells
+                rank[u] = 0;
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) {
+                    const uint64_t v = sh.lit[e[u]][k];
+                    const uint64_t below = (c[u] >> 6) > k ? ~0ull : ((c[u] >> 6) == k ? (1ull << (c[u] & 63)) - 1ull : 0ull);
+                    rank[u] += (int)__popcll(v & below);
+                }
             }
         }
-        if (c >= 0) emit(wave_first + i, e, j, c, rank);
-    }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (c[u] >= 0) emit(wave_first + base + 64 * u + lane, j[u], c[u], rank[u], got[u]);
+      }
+    };
+    // four tiles of 64 entries in flight while there are that many (what an entry fetches from memory is requested for all four before the
+    // first is used), single tiles for the rest (a sparse step has one tile per list)
+    const int bulk = total & ~255;
+    tiles(std::integral_constant<int, 4>{}, 0, bulk);
+    tiles(std::integral_constant<int, 1>{}, bulk, total);
 }
 
 template <int AMAX, int CPL, int BITS>
@@ -771,7 +788,8 @@ __global__ void __launch_bounds__(64 * (CPL >= 8 ? 4 : 16)) wg_lists_kernel(char
     const int64_t task_first = s_first[0][el];
     const bool show_bad = (d.flags & kShowBad) != 0;
     const int64_t wave_env0 = (int64_t)chunk * kBlock + group * 64;  // env of lane 0
-#pragma unroll
+    constexpr int kUnrollItems = kEager ? kItems : 1;  // (the eager mask words are a register array indexed by j)
+#pragma unroll kUnrollItems
     for (int j = 0; j < kItems; ++j) {
         const int item = part + kListParts * j;
         if (item >= A + 2) break;
@@ -780,16 +798,17 @@ __global__ void __launch_bounds__(64 * (CPL >= 8 ? 4 : 16)) wg_lists_kernel(char
             longlong2* const task_values = reinterpret_cast<longlong2*>(arena + d.off_task_values);
             const int2* const lit_cells = reinterpret_cast<const int2*>(arena + d.off_lit_cells);
             const int64_t stride = (HW + 1) & ~1;
-            output_parallel_list<CPL, false>(sh, lit, task_first, lane, [&](int64_t at, int e, int idx, int c, int) {
-                const int2 cell = lit_cells[(wave_env0 + e) * stride + idx];
-                const int y = (int)(((uint32_t)c * d.inv_w) >> 16), x = c - y * Wd;
-                task_values[2 * at] = make_longlong2(y, x);
-                task_values[2 * at + 1] = make_longlong2(cell.x, cell.y);
-            });
+            output_parallel_list<CPL, false>(
+                sh, lit, task_first, lane, [&](int e, int idx) { return lit_cells[(wave_env0 + e) * stride + idx]; },
+                [&](int64_t at, int, int c, int, int2 cell) {
+                    const int y = (int)(((uint32_t)c * d.inv_w) >> 16), x = c - y * Wd;
+                    task_values[2 * at] = make_longlong2(y, x);
+                    task_values[2 * at + 1] = make_longlong2(cell.x, cell.y);
+                });
         } else if (item == 1) {
             // the observation map: task j of the env observes task j
             int64_t* const obs_map = reinterpret_cast<int64_t*>(arena + d.off_obs_map);
-            output_parallel_list<CPL, false>(sh, lit, task_first, lane, [&](int64_t at, int, int idx, int, int) { obs_map[at] = idx; });
+            output_parallel_list<CPL, false>(sh, lit, task_first, lane, [](int, int) { return 0; }, [&](int64_t at, int idx, int, int, int) { obs_map[at] = idx; });
         } else {
             // agent a: the task indices of its attackable fires (and, with show_bad_actions, of the listed-but-not-attackable ones)
             const int a = item - 2;
@@ -798,13 +817,13 @@ __global__ void __launch_bounds__(64 * (CPL >= 8 ? 4 : 16)) wg_lists_kernel(char
             for (int k = 0; k < CPL; ++k) mine[k] = kEager ? ok[kEager ? j : 0][k] : (active ? okmap[((int64_t)a * CPL + k) * B + bl] : 0ull);
             const int64_t first = s_first[a + 1][el];
             int64_t* const act_values = reinterpret_cast<int64_t*>(arena + d.off_act_values) + (int64_t)a * cap;
-            output_parallel_list<CPL, true>(sh, mine, first, lane, [&](int64_t at, int, int, int, int rank) { act_values[at] = rank; });
+            output_parallel_list<CPL, true>(sh, mine, first, lane, [](int, int) { return 0; }, [&](int64_t at, int, int, int rank, int) { act_values[at] = rank; });
             if (show_bad) {
                 uint64_t bad[CPL];
 #pragma unroll
                 for (int k = 0; k < CPL; ++k) bad[k] = lit[k] & ~mine[k];
                 int64_t* const bad_values = reinterpret_cast<int64_t*>(arena + d.off_bad_values) + (int64_t)a * cap;
-                output_parallel_list<CPL, true>(sh, bad, task_first - first, lane, [&](int64_t at, int, int, int, int rank) { bad_values[at] = rank; });
+                output_parallel_list<CPL, true>(sh, bad, task_first - first, lane, [](int, int) { return 0; }, [&](int64_t at, int, int, int rank, int) { bad_values[at] = rank; });
             }
         }
     }
