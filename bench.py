@@ -79,7 +79,7 @@ def source_fingerprint():
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, 'free-range-zoo_amd', 'csrc')
     for name in sorted(os.listdir(csrc)):
-        if name.endswith(('.hip', '.h')):
+        if name.endswith(('.hip', '.h', '.inl')):
             h.update(name.encode())
             h.update(open(os.path.join(csrc, name), 'rb').read())
     return h.hexdigest()[:16]
@@ -195,7 +195,7 @@ def secondary_workloads(device, B):
         if module is wildfire_v0:
             HW = env.max_y * env.max_x
             per_env = wildfire_bytes_per_env_step(HW, A, env._k, mean_env, mean_agents)
-            kernels = 'wg_env_kernel + wg_offsets_kernel + wg_emit_kernel (env per wavefront, cells across its lanes; policy sampled in the first launch)'
+            kernels = 'wg_env_kernel (a wavefront per env for the cells, one crew wavefront per four envs for the agents; policy sampled in it) + wg_lists_kernel (offsets and lists, an output entry per lane)'
             counts = {'mean_tasks_per_env': mean_env, 'mean_agent_tasks_per_env': mean_agents, 'cells': HW}
         elif module is cybersecurity_v0:
             N = env.network_config.num_nodes

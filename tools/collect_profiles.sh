@@ -9,7 +9,7 @@ TAG=${1:-r03}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for domain in wildfire wildfire20 cybersecurity rideshare; do
+for domain in wildfire wildfire20 cybersecurity rideshare wildfire_grid_8x8 wildfire_grid_16x16; do
   for counter in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $counter --output-format csv -d $OUT/pmc_${domain}_${counter} -o pmc -- python3 $GRAFT_REPO_ROOT/tools/traffic_run.py $domain > $OUT/pmc_${domain}_${counter}.log 2>&1 || echo "pmc $domain $counter failed"
   done

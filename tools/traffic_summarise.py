@@ -8,7 +8,8 @@ sys.path.insert(0, ROOT)
 from bench import source_fingerprint
 
 src, tag = sys.argv[1], sys.argv[2]
-STEP_KERNELS = {'wildfire': ('wf_roles_kernel', ), 'cybersecurity': ('cy_roles_kernel', ), 'rideshare': ('rs_env_kernel', 'rs_offsets_kernel', 'rs_emit_kernel')}
+STEP_KERNELS = {'wildfire': ('wf_roles_kernel', ), 'cybersecurity': ('cy_roles_kernel', ), 'rideshare': ('rs_env_kernel', 'rs_offsets_kernel', 'rs_emit_kernel'),
+                'wildfire_grid_8x8': ('wg_env_kernel', 'wg_lists_kernel'), 'wildfire_grid_16x16': ('wg_env_kernel', 'wg_lists_kernel')}
 
 
 def per_step(domain, counter):
@@ -24,6 +25,9 @@ def per_step(domain, counter):
             continue
         if re.search(r'rs_env_kernel<[^>]*, 1>', name):
             continue  # rebuild-mode instantiation (reset), not a step
+        grid = re.search(r'wg_env_kernel<([^>]*)>', name)  # <CPL, MODE, RNG>
+        if grid and grid.group(1).split(',')[1].strip() != '0':
+            continue  # reset / rebuild mode (its lists launch is counted: negligible against 50 steps)
         roles = re.search(r'wf_roles_kernel<([^>]*)>', name)
         if roles:
             arguments = [a.strip() for a in roles.group(1).split(',')]
