@@ -1,4 +1,4 @@
-"""GPU: the wildfire step for grids above 16 cells (csrc/wildfire_grid.hip: one env per wavefront, cells across its lanes) against the
+"""GPU: the wildfire step for grids above 16 cells (csrc/wildfire_grid.hip: a wavefront per env for the cells, one crew wavefront per four envs for the agents, an output entry per lane for the lists) against the
 reference's golden trajectories (run through it with FRZ_WF_KERNEL=grid), against the CPU oracle on grids up to 32 x 32 with 3 .. 16
 agents in every RNG mode, and against the env-per-lane kernels on a shape both accept."""
 from dataclasses import replace
@@ -52,6 +52,15 @@ def test_grids_match_the_oracle(oracle, shape, rng):
     env, o = run_against_oracle(oracle, lambda: configs.wildfire_grid(H, Wd, A, seed=H + A), {}, B, 12, 14, seed=H * Wd + A, rng=rng)
     assert env._cells_env_major
     assert int(o.env_task_count.max()) > 0
+
+
+@pytest.mark.parametrize('B', [1, 2, 3, 5, 259])
+def test_workgroups_with_fewer_than_four_envs(oracle, B):
+    """One crew wavefront serves the (up to) four envs of a workgroup: the last workgroup of these batches has one, two or three, and the
+    crew is then one of the wavefronts that exist."""
+    run_against_oracle(oracle, lambda: rich_grid(8, 8, 12), dict(show_bad_actions=True, observe_other_suppressant=True), B, 10, 12, seed=40 + B, rng='philox',
+                       policy='device')
+    run_against_oracle(oracle, lambda: configs.wildfire_grid(16, 16, 6, seed=5), {}, B, 8, 10, seed=50 + B, rng='mt19937')
 
 
 def rich_grid(H, Wd, A):
