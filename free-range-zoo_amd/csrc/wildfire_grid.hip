@@ -637,9 +637,29 @@ __global__ void __launch_bounds__(kBlock) wg_env_kernel(char* __restrict__ arena
 // ------------------------------------------------------------------------------------------------------------------------------------
 template <int CPL>
 struct ListShared {  // per wavefront: its 64 envs' mask words and segment starts, addressed by env
+    static constexpr int PW = CPL < 4 ? 4 : CPL;  // (four 16-bit prefixes are read as one 8-byte word)
     uint64_t lit[64][CPL], sel[64][CPL];
+    alignas(8) uint16_t lit_before[64][PW], sel_before[64][PW];  // set bits of the env's words before word k
     int rel[65];
 };
+
+// position of the n-th (0-based) set bit of a 64-bit mask (n below its population count)
+__device__ __forceinline__ int select_nth64(uint64_t m, int n) {
+    const uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+    const int c = __popc(lo);
+    const bool up0 = n >= c;
+    int rem = up0 ? n - c : n, pos = up0 ? 32 : 0;
+    uint32_t w = up0 ? hi : lo;
+#pragma unroll
+    for (int width = 16; width >= 1; width >>= 1) {
+        const int cc = __popc(w & ((1u << width) - 1u));
+        const bool up = rem >= cc;
+        rem -= up ? cc : 0;
+        w = up ? w >> width : w;
+        pos += up ? width : 0;
+    }
+    return pos;
+}
 
 // One list of one item for the wavefront's 64 envs, one OUTPUT entry per lane: the 64 segments are one contiguous range of dst, so entry
 // i of that range belongs to the env e with rel[e] <= i < rel[e + 1] (binary search in LDS) and is the (i - rel[e])-th listed cell of e
@@ -647,60 +667,79 @@ struct ListShared {  // per wavefront: its 64 envs' mask words and segment start
 // consecutive entries.  sel: the cells the lane's env lists (all lanes pass theirs); first: where its segment starts in dst;
 // emit(entry index in dst, env slot, position in the env's segment, cell, task index of the cell).
 template <int CPL, bool RANK, typename L, typename F>
-__device__ __forceinline__ void output_parallel_list(ListShared<CPL>& sh, const uint64_t (&sel)[CPL], int64_t first, int lane, L&& fetch, F&& emit) {
-    int n = 0;
-#pragma unroll
-    for (int k = 0; k < CPL; ++k) n += (int)__popcll(sel[k]);
+__device__ __forceinline__ void output_parallel_list(ListShared<CPL>& sh, const uint64_t (&sel)[CPL], int64_t first, int total, int lane, int tile0, int tile_stride,
+                                                     L&& fetch, F&& emit) {
+    // tiles of 64 entries tile0, tile0 + tile_stride, ... of the wavefront's `total` entries are this wavefront's (the others belong to
+    // the wavefronts that serve the same 64 envs)
     const int64_t wave_first = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)first) | ((int64_t)__builtin_amdgcn_readfirstlane((int)(first >> 32)) << 32);
     const int rel = (int)(first - wave_first);
-    const int total = read_lane(rel + n, 63);
     wave_lds_sync();  // the previous list's readers are done
+    {
+        int before = 0;
 #pragma unroll
-    for (int k = 0; k < CPL; ++k) sh.sel[lane][k] = sel[k];
+        for (int k = 0; k < CPL; ++k) {
+            sh.sel[lane][k] = sel[k];
+            sh.sel_before[lane][k] = (uint16_t)before;
+            before += (int)__popcll(sel[k]);
+        }
+    }
     sh.rel[lane] = rel;
     if (lane == 63) sh.rel[64] = total;
     wave_lds_sync();
-    auto tiles = [&](auto width, int from, int to) {
+    const int ntiles = (total + 63) >> 6;
+    auto tiles = [&](auto width) {
       constexpr int U = decltype(width)::value;
-      for (int base = from; base < to; base += 64 * U) {
+      for (int tile = tile0; tile < ntiles; tile += U * tile_stride) {
         int e[U], j[U], c[U], rank[U];
         decltype(fetch(0, 0)) got[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int i = base + 64 * u + lane;
+            const int i = 64 * (tile + u * tile_stride) + lane;
             e[u] = 0;
 #pragma unroll
             for (int step = 32; step >= 1; step >>= 1) e[u] += sh.rel[e[u] + step] <= i ? step : 0;  // the last env that starts at or before i
             j[u] = i - sh.rel[e[u]];
-            uint32_t w[2 * CPL];
+            // the word that holds the env's j-th listed cell (the per-word prefix counts, four to an 8-byte LDS word), then the bit in it
+            int kk = 0, skip = 0;
+            if (CPL > 1) {
+                if (CPL <= 4) {
+                    const uint64_t pre = *reinterpret_cast<const uint64_t*>(sh.sel_before[e[u]]);
 #pragma unroll
-            for (int k = 0; k < CPL; ++k) {
-                const uint64_t v = sh.sel[e[u]][k];
-                w[2 * k] = (uint32_t)v, w[2 * k + 1] = (uint32_t)(v >> 32);
+                    for (int k = 1; k < CPL; ++k) {
+                        const int p = (int)((pre >> (16 * k)) & 0xFFFFull);
+                        const bool past = j[u] >= p;
+                        kk = past ? k : kk, skip = past ? p : skip;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 1; k < CPL; ++k) {
+                        const int p = sh.sel_before[e[u]][k];
+                        const bool past = j[u] >= p;
+                        kk = past ? k : kk, skip = past ? p : skip;
+                    }
+                }
             }
-            c[u] = select_nth(w, i < total ? j[u] : -1);  // -1 past the range
-            if (c[u] >= 0) got[u] = fetch(e[u], j[u]);
+            const bool valid = i < total;
+            const int bit = select_nth64(sh.sel[e[u]][kk], j[u] - skip);
+            c[u] = valid ? 64 * kk + bit : -1;  // -1 past the range
+            if (valid) got[u] = fetch(e[u], j[u]);
             rank[u] = j[u];
             if (RANK) {  // the cell's rank among the env's lit cells
-                rank[u] = 0;
-#pragma unroll
-                for (int k = 0; k < CPL; ++k) {
-                    const uint64_t v = sh.lit[e[u]][k];
-                    const uint64_t below = (c[u] >> 6) > k ? ~0ull : ((c[u] >> 6) == k ? (1ull << (c[u] & 63)) - 1ull : 0ull);
-                    rank[u] += (int)__popcll(v & below);
-                }
+                const uint64_t v = sh.lit[e[u]][kk];
+                rank[u] = (int)sh.lit_before[e[u]][kk] + (int)__popcll(v & ((1ull << bit) - 1ull));
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (c[u] >= 0) emit(wave_first + base + 64 * u + lane, j[u], c[u], rank[u], got[u]);
+            if (c[u] >= 0) emit(wave_first + 64 * (tile + u * tile_stride) + lane, j[u], c[u], rank[u], got[u]);
       }
     };
-    // four tiles of 64 entries in flight while there are that many (what an entry fetches from memory is requested for all four before the
-    // first is used), single tiles for the rest (a sparse step has one tile per list)
-    const int bulk = total & ~255;
-    tiles(std::integral_constant<int, 4>{}, 0, bulk);
-    tiles(std::integral_constant<int, 1>{}, bulk, total);
+    // four of the wavefront's tiles in flight when it has more than one (what an entry fetches from memory is requested for all four
+    // before the first is used); a sparse step has one tile per list
+    if (tile0 + tile_stride < ntiles)
+        tiles(std::integral_constant<int, 2>{});
+    else
+        tiles(std::integral_constant<int, 1>{});
 }
 
 template <int AMAX, int CPL, int BITS>
@@ -711,7 +750,7 @@ __global__ void __launch_bounds__(64 * (CPL >= 8 ? 4 : 16)) wg_lists_kernel(char
     constexpr bool kEager = CPL <= 4 && kListParts > 1;                // every item's mask words loaded before the scan
     __shared__ frz::ScanShared<kChannels, BITS> s_scan;
     __shared__ int s_ticket;
-    __shared__ uint32_t s_first[kChannels][kBlock];  // exclusive prefix of channel ch at the chunk's env e
+    __shared__ uint32_t s_first[kChannels][kBlock + 1];  // exclusive prefix of channel ch at the chunk's env e; [kBlock]: at the chunk's end
     __shared__ ListShared<CPL> s_list[kListWaves];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, group = wave & (frz::kWaves - 1), part = wave >> 2;
     const int64_t B = d.B;
@@ -743,8 +782,15 @@ __global__ void __launch_bounds__(64 * (CPL >= 8 ? 4 : 16)) wg_lists_kernel(char
         }
     }
     ListShared<CPL>& sh = s_list[wave];
+    {
+        int before = 0;
 #pragma unroll
-    for (int k = 0; k < CPL; ++k) sh.lit[lane][k] = lit[k];
+        for (int k = 0; k < CPL; ++k) {
+            sh.lit[lane][k] = lit[k];
+            sh.lit_before[lane][k] = (uint16_t)before;
+            before += (int)__popcll(lit[k]);
+        }
+    }
 
     // ---------------------------------------------------------------- the scan (wavefronts 0-3)
     uint32_t err = 0;
@@ -756,7 +802,10 @@ __global__ void __launch_bounds__(64 * (CPL >= 8 ? 4 : 16)) wg_lists_kernel(char
         const bool term = rows1[(int64_t)d.u_term * B + bl] != 0, trunc = rows1[(int64_t)d.u_trunc * B + bl] != 0;
         frz::scan_chunk<kChannels, BITS>(s_scan, ws, launch, cnt, active && !term, active && !trunc, A + 1, chunk, d.nchunks, excl, &err);
 #pragma unroll
-        for (int ch = 0; ch < kChannels; ++ch) s_first[ch][el] = excl[ch];
+        for (int ch = 0; ch < kChannels; ++ch) {
+            s_first[ch][el] = excl[ch];
+            if (el == kBlock - 1) s_first[ch][kBlock] = excl[ch] + cnt[ch];
+        }
         if (active) {
             int64_t* const task_offsets = reinterpret_cast<int64_t*>(arena + d.off_task_offsets);
             int64_t* const act_offsets = reinterpret_cast<int64_t*>(arena + d.off_act_offsets);
@@ -788,42 +837,64 @@ __global__ void __launch_bounds__(64 * (CPL >= 8 ? 4 : 16)) wg_lists_kernel(char
     const int64_t task_first = s_first[0][el];
     const bool show_bad = (d.flags & kShowBad) != 0;
     const int64_t wave_env0 = (int64_t)chunk * kBlock + group * 64;  // env of lane 0
+    // Every wavefront of a group walks ALL the items; tile t of item m is written by the wavefront with part == (t + m) mod parts: a
+    // sparse step has one tile per list and the items spread over the parts as (m mod parts); in the first steps of an episode on a
+    // large grid a list has tens of tiles and the parts share them (one wavefront writing all the task rows held the launch up).
+    const int ends = group * 64 + 64;  // the chunk's env behind this wavefront's last one
     constexpr int kUnrollItems = kEager ? kItems : 1;  // (the eager mask words are a register array indexed by j)
 #pragma unroll kUnrollItems
     for (int j = 0; j < kItems; ++j) {
-        const int item = part + kListParts * j;
-        if (item >= A + 2) break;
-        if (item == 0) {
-            // task rows (y, x, fires level, intensity) of the lit fires in row-major order
-            longlong2* const task_values = reinterpret_cast<longlong2*>(arena + d.off_task_values);
-            const int2* const lit_cells = reinterpret_cast<const int2*>(arena + d.off_lit_cells);
-            const int64_t stride = (HW + 1) & ~1;
-            output_parallel_list<CPL, false>(
-                sh, lit, task_first, lane, [&](int e, int idx) { return lit_cells[(wave_env0 + e) * stride + idx]; },
-                [&](int64_t at, int, int c, int, int2 cell) {
-                    const int y = (int)(((uint32_t)c * d.inv_w) >> 16), x = c - y * Wd;
-                    task_values[2 * at] = make_longlong2(y, x);
-                    task_values[2 * at + 1] = make_longlong2(cell.x, cell.y);
-                });
-        } else if (item == 1) {
-            // the observation map: task j of the env observes task j
-            int64_t* const obs_map = reinterpret_cast<int64_t*>(arena + d.off_obs_map);
-            output_parallel_list<CPL, false>(sh, lit, task_first, lane, [](int, int) { return 0; }, [&](int64_t at, int idx, int, int, int) { obs_map[at] = idx; });
-        } else {
+        for (int q = 0; q < kListParts; ++q) {
+            const int item = q + kListParts * j;
+            if (item >= A + 2) break;
+            const int tile0 = (part - item) & (kListParts - 1);
+            const int task_total = (int)(s_first[0][ends] - s_first[0][group * 64]);
+            if (item <= 1) {
+                if (64 * tile0 >= task_total) continue;
+                if (item == 0) {
+                    // task rows (y, x, fires level, intensity) of the lit fires in row-major order
+                    longlong2* const task_values = reinterpret_cast<longlong2*>(arena + d.off_task_values);
+                    const int2* const lit_cells = reinterpret_cast<const int2*>(arena + d.off_lit_cells);
+                    const int64_t stride = (HW + 1) & ~1;
+                    output_parallel_list<CPL, false>(
+                        sh, lit, task_first, task_total, lane, tile0, kListParts, [&](int e, int idx) { return lit_cells[(wave_env0 + e) * stride + idx]; },
+                        [&](int64_t at, int, int c, int, int2 cell) {
+                            const int y = (int)(((uint32_t)c * d.inv_w) >> 16), x = c - y * Wd;
+                            task_values[2 * at] = make_longlong2(y, x);
+                            task_values[2 * at + 1] = make_longlong2(cell.x, cell.y);
+                        });
+                } else {
+                    // the observation map: task j of the env observes task j
+                    int64_t* const obs_map = reinterpret_cast<int64_t*>(arena + d.off_obs_map);
+                    output_parallel_list<CPL, false>(sh, lit, task_first, task_total, lane, tile0, kListParts, [](int, int) { return 0; },
+                                                     [&](int64_t at, int idx, int, int, int) { obs_map[at] = idx; });
+                }
+                continue;
+            }
             // agent a: the task indices of its attackable fires (and, with show_bad_actions, of the listed-but-not-attackable ones)
             const int a = item - 2;
+            const int ok_total = (int)(s_first[a + 1][ends] - s_first[a + 1][group * 64]), bad_total = show_bad ? task_total - ok_total : 0;
+            if (64 * tile0 >= ok_total && 64 * tile0 >= bad_total) continue;
             uint64_t mine[CPL];
 #pragma unroll
-            for (int k = 0; k < CPL; ++k) mine[k] = kEager ? ok[kEager ? j : 0][k] : (active ? okmap[((int64_t)a * CPL + k) * B + bl] : 0ull);
+            for (int k = 0; k < CPL; ++k) {
+                if (kEager && q == part)
+                    mine[k] = ok[kEager ? j : 0][k];
+                else
+                    mine[k] = active ? okmap[((int64_t)a * CPL + k) * B + bl] : 0ull;
+            }
             const int64_t first = s_first[a + 1][el];
             int64_t* const act_values = reinterpret_cast<int64_t*>(arena + d.off_act_values) + (int64_t)a * cap;
-            output_parallel_list<CPL, true>(sh, mine, first, lane, [](int, int) { return 0; }, [&](int64_t at, int, int, int rank, int) { act_values[at] = rank; });
-            if (show_bad) {
+            if (64 * tile0 < ok_total)
+                output_parallel_list<CPL, true>(sh, mine, first, ok_total, lane, tile0, kListParts, [](int, int) { return 0; },
+                                                [&](int64_t at, int, int, int rank, int) { act_values[at] = rank; });
+            if (64 * tile0 < bad_total) {
                 uint64_t bad[CPL];
 #pragma unroll
                 for (int k = 0; k < CPL; ++k) bad[k] = lit[k] & ~mine[k];
                 int64_t* const bad_values = reinterpret_cast<int64_t*>(arena + d.off_bad_values) + (int64_t)a * cap;
-                output_parallel_list<CPL, true>(sh, bad, task_first - first, lane, [](int, int) { return 0; }, [&](int64_t at, int, int, int rank, int) { bad_values[at] = rank; });
+                output_parallel_list<CPL, true>(sh, bad, task_first - first, bad_total, lane, tile0, kListParts, [](int, int) { return 0; },
+                                                [&](int64_t at, int, int, int rank, int) { bad_values[at] = rank; });
             }
         }
     }
