@@ -1,7 +1,8 @@
 // rideshare.hip — rideshare environment step for gfx950 (MI355X): one environment per WAVEFRONT, passenger slots across its lanes.
 //
 // One ParallelEnv.step() of the reference (rideshare.py:248-467) = three stream-ordered launches:
-//   rs_env_kernel      (wave per env)  action decode through the open action mapping (optionally the uniform random policy, sampled in
+//   rs_env_kernel      (four envs per workgroup: a wavefront per env for the passenger table, one crew wavefront for the agents of all
+//                                      four) action decode through the open action mapping (optionally the uniform random policy, sampled in
 //                                      the launch) -> movement -> passenger state (accept-conflict resolution, picks) -> passenger exit
 //                                      (drops, fares, ordered in-place compaction by ballot + lane rank) -> passenger entry (schedule)
 //                                      -> rewards -> truncation -> agent observations, per-env task counts
@@ -14,9 +15,10 @@
 // The reference keeps one global passenger table sorted by env and re-sorts / boolean-compacts it every step; here each env owns
 // max_passengers slots in table order, env-major records [B][slot][10]: lane s of the env's wavefront holds slot s (and s + 64 when an
 // env has more than 64 slots) and moves its 40-byte record with three wide accesses (the columns a step can change come first, so a
-// changed slot is two stores), per-agent quantities live in lanes 0..A-1 of the same wavefront, and everything that crosses between
-// "slot lanes" and "agent lanes" is a ballot, a v_writelane, a ds_bpermute or an LDS word per slot: no workgroup barrier anywhere (a
-// 256-thread workgroup is four independent envs).  Deterministic integer/byte work, HBM-bound: no MFMA.
+// changed slot is two stores).  In the env launch the per-agent quantities of a workgroup's four envs live in the lanes of ONE of its
+// wavefronts (the crew: lane 16 e + a = agent a of env e) and what crosses between slot lanes and agent lanes is an LDS word — masks,
+// per-slot claim / effect words, the agents' moves — across three workgroup barriers; in the emit launch a wavefront is one env and the
+// crossings are ballots, v_writelane and ds_bpermute.  Deterministic integer/byte work, HBM-bound: no MFMA.
 #include "frz_scan.h"
 #include "frz_wave.h"
 
@@ -183,86 +185,121 @@ __global__ void __launch_bounds__(kBlock) rs_fill_kernel(char* __restrict__ aren
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
-// rs_env_kernel: everything of a step that concerns ONE env.  SPL = slots per lane (1: up to 64 passenger slots per env, 2: up to 128).
-// "slot-lane" values: lane s holds slot s + 64 * k in element k.  "agent-lane" values: lane a < A holds agent a's value (lanes >= A carry
-// inert values).  A CU has ONE scalar unit for its four SIMDs, so per-agent work is not a scalar loop over the agents: each agent's
-// "passengers I drive" set is a ballot moved into that agent's lane (v_cmp + v_writelane), and everything per agent — the visible set,
-// the index-th visible passenger, the counts of the rebuilt spaces — is vector arithmetic on those masks, all agents at once.  What
-// agents do to slots (accept / pick / drop) and the accept claims travel through two LDS words per slot.
+// rs_env_kernel: everything of a step that concerns the FOUR envs of a workgroup.  SPL = slots per lane (1: up to 64 passenger slots per
+// env, 2: up to 128).
+//   * every wavefront is the FIELD of one env: "slot-lane" values, lane s holds slot s + 64 * k in element k.  It loads the table, turns
+//     it into masks (who drives what, the three passenger states) and parks what an agent may ask about a passenger in LDS; after the crew
+//     has decided it applies the effects (accepted / picked / dropped, riding passengers follow their driver), compacts the table in
+//     place, lets the next timestep's passengers enter and evaluates the waiting costs;
+//   * ONE wavefront of the workgroup (blockIdx % envs: the four SIMDs share that work) is also the CREW of all four envs: lane 16 e + a
+//     holds agent a of env e.  It decodes the actions through the open action mapping (or samples the uniform policy), moves the agents,
+//     settles the accept conflicts, and after the fields are done computes rewards, truncation, the counts of the rebuilt spaces and the
+//     agent observations.  (Round 2's kernel had every wavefront do both for its own env: the agent phases ran at 8 of 64 lanes, four
+//     times per workgroup, and a launch of these kernels is bound by the instructions its wavefronts issue.)
+// The fields and the crew meet at three workgroup barriers and exchange through LDS: masks, the per-slot claim / effect words, the agents'
+// moves, the fields' counts.
 // ------------------------------------------------------------------------------------------------------------------------------------
+struct RsFieldOut {  // what an env's field leaves for the crew once the table is updated
+    int count, entered;
+    float global;  // the waiting costs every agent of the env pays
+    int pad_;
+};
+enum TargetCol { TSTATE = 0, TY, TX, TYD, TXD, TFARE, TCOLS };
+
 template <int AMAX, int SPL, int MODE>
 __global__ void __launch_bounds__(kBlock) rs_env_kernel(char* __restrict__ arena, const RsDev d, const int32_t* __restrict__ actions,
                                                          const RsPolicy pol) {
     constexpr int W = 2 * SPL;  // 32-bit words of a slot mask
-    __shared__ uint32_t s_claim[kEnvsPerBlock][SPL * 64];   // accepting agents per slot
-    __shared__ uint32_t s_effect[kEnvsPerBlock][SPL * 64];  // (winning agent + 1) << 8 | picked << 1 | dropped << 2
-    __shared__ int4 s_self[kEnvsPerBlock][AMAX];            // the agents' self observation rows
-    const int b = frz::env_of_wave<kEnvsPerBlock>(d.B);
-    if (b < 0) return;  // no workgroup barrier in this kernel: a wavefront without an env just leaves
+    constexpr int E = kEnvsPerBlock, AP = 64 / E, S = 64 * SPL;
+    static_assert(AMAX <= AP, "a crew lane per agent");
+    __shared__ uint32_t s_claim[E][S];              // accepting agents per slot
+    __shared__ uint32_t s_effect[E][S];             // (winning agent + 1) << 8 | picked << 1 | dropped << 2
+    __shared__ int s_target[E][S][TCOLS];           // what an agent reads of the passenger it chose (state before the step)
+    __shared__ uint32_t s_driven[E][AMAX][W];       // the passengers each agent drives, as mask words
+    __shared__ uint64_t s_mask[E][4][SPL];          // unaccepted / accepted / riding / kept slots; after the fields' second phase: of the new table
+    __shared__ int s_move[E][AP];                   // the agents' moves (y | x << 16)
+    __shared__ RsFieldOut s_out[E];
+    __shared__ int4 s_self[E][AMAX];                // the agents' self observation rows
+    const int b = frz::env_of_wave<E>(d.B);
+    if (b < 0) return;  // before any barrier: a barrier does not wait for wavefronts that have ended
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t B = d.B;
     const int A = d.A, P = d.P;
     const uint32_t flags = d.flags;
-    const bool is_agent = lane < A;
-    const int agent = is_agent ? lane : A - 1;  // clamped: unconditional loads
+    const int b0 = b - wave;                                         // the workgroup's first env
+    const int n_envs = (int)(B - b0 < E ? B - b0 : E);
+    const bool crew = wave == (int)(blockIdx.x % (uint32_t)n_envs);  // wave-uniform
+    const int ce = lane / AP, ca = lane % AP;                        // crew lane -> (env of the workgroup, agent)
+    const bool is_agent = ca < A && ce < n_envs;
+    const int agent = ca < A ? ca : A - 1;                           // clamped: unconditional loads
+    const int cb = b0 + (ce < n_envs ? ce : n_envs - 1);             // the crew lane's env
     int32_t* const rows = reinterpret_cast<int32_t*>(arena + d.off_rows4);
     float* const rowsf = reinterpret_cast<float*>(arena + d.off_rows4);
     uint8_t* const rows1 = reinterpret_cast<uint8_t*>(arena + d.off_rows1);
     int32_t* const pas = reinterpret_cast<int32_t*>(arena + d.off_passengers) + (int64_t)b * PCOLS * P;  // this env's table [slot][column]
-    int2* const agents = reinterpret_cast<int2*>(arena + d.off_agents) + (int64_t)b * A;
-    const uint32_t Bu = (uint32_t)B, bu = (uint32_t)b;
+    int2* const agents = reinterpret_cast<int2*>(arena + d.off_agents);
+    const uint32_t Bu = (uint32_t)B, bu = (uint32_t)b, cbu = (uint32_t)cb;
 
-    // ---------------------------------------------------------------- loads: everything the step reads, requested before anything is
-    // waited for except the passenger count (lanes past it re-read the last live record: the same cache lines, no extra traffic)
+    // ---------------------------------------------------------------- loads, field: everything the step reads of the env's table,
+    // requested before anything is waited for except the passenger count (lanes past it re-read the last live record: the same cache
+    // lines, no extra traffic)
     const uint32_t epoch = *reinterpret_cast<const uint32_t*>(arena + d.off_epoch);
     const uint32_t* const totals = reinterpret_cast<const uint32_t*>(arena + d.off_totals);
     const uint32_t left0[2] = {totals[A + 1], totals[A + 2]}, left1[2] = {totals[frz::kTotalsStride + A + 1], totals[frz::kTotalsStride + A + 2]};
     const int count0 = at32(rows, (uint32_t)d.r_count * Bu + bu);
-    int nm = MODE == kStep ? at32(rows, (uint32_t)d.r_moves * Bu + bu) : 0;
-    bool trunc = at32(rows1, (uint32_t)d.u_trunc * Bu + bu) != 0;
+    const int nm = MODE == kStep ? at32(rows, (uint32_t)d.r_moves * Bu + bu) : 0;
     int v[SPL][PCOLS];
 #pragma unroll
     for (int k = 0; k < SPL; ++k) {
         const int slot = lane + 64 * k;
         load_record(pas, (uint32_t)(slot < count0 ? slot : (count0 > 0 ? count0 - 1 : 0)), v[k]);
     }
-    const int2 pos0 = at32(agents, (uint32_t)agent);
-    int act_idx = 0, act_id = -1;
-    float cum0 = 0.0f;
-    if (MODE == kStep) {
-        if (!pol.on) {
-            const int2 a2 = at32(reinterpret_cast<const int2*>(actions), (uint32_t)agent * Bu + bu);
-            act_idx = a2.x;
-            act_id = is_agent ? a2.y : -1;
-        }
-        if (flags & kTrackCumulative) cum0 = at32(rowsf, (uint32_t)(d.r_cum + agent) * Bu + bu);
-    }
     const Schedule sch{reinterpret_cast<const int32_t*>(arena + d.off_schedule), reinterpret_cast<const int32_t*>(arena + d.off_schedule_index),
                        d.max_time};
     EntryPlan plan;
     if (MODE == kStep) plan = entry_prefetch(sch, nm + 1);  // the next timestep's schedule rows (rideshare.py:308): in flight early
+    // ---------------------------------------------------------------- loads, crew (lane 16 e + a: agent a of the workgroup's env e)
+    int2 pos0 = make_int2(0, 0);
+    int act_idx = 0, act_id = -1, c_nm = 0;
+    float cum0 = 0.0f;
+    bool trunc = false;
+    if (crew) {
+        pos0 = at32(agents, cbu * (uint32_t)A + (uint32_t)agent);
+        trunc = at32(rows1, (uint32_t)d.u_trunc * Bu + cbu) != 0;
+        if (MODE == kStep) {
+            c_nm = at32(rows, (uint32_t)d.r_moves * Bu + cbu);
+            if (!pol.on) {
+                const int2 a2 = at32(reinterpret_cast<const int2*>(actions), (uint32_t)agent * Bu + cbu);
+                act_idx = a2.x;
+                act_id = is_agent ? a2.y : -1;
+            }
+            if (flags & kTrackCumulative) cum0 = at32(rowsf, (uint32_t)(d.r_cum + agent) * Bu + cbu);
+        }
+    }
 
     if (MODE == kStep) {
         // utils/env.py:211-213 (terminations never set, rideshare.py:252): frozen once every env is truncated.  Channels A + 1 / A + 2 of
-        // the batch totals rs_offsets_kernel left after the previous step = number of envs not terminated / not truncated
+        // the batch totals rs_offsets_kernel left after the previous step = number of envs not terminated / not truncated.  (Batch
+        // totals: every wavefront takes this branch or none.)
         const bool odd = ((epoch + 1u) & 1u) != 0;
         const uint32_t left_alive = odd ? left1[0] : left0[0], left_running = odd ? left1[1] : left0[1];
         if (left_alive == 0u || left_running == 0u) {
             // the parallel adapter sums the stale rewards once per agent call (utils/conversions.py:87-90)
-            if (!at32(rows1, (uint32_t)d.u_frozen * Bu + bu)) {
+            if (crew && !at32(rows1, (uint32_t)d.u_frozen * Bu + cbu)) {
                 if (is_agent) {
-                    const float r = at32(rowsf, (uint32_t)(d.r_rewards + lane) * Bu + bu);
+                    const float r = at32(rowsf, (uint32_t)(d.r_rewards + agent) * Bu + cbu);
                     float acc = 0.0f;
                     for (int j = 0; j < A; ++j) acc = acc + r;
-                    at32(rowsf, (uint32_t)(d.r_rewards + lane) * Bu + bu) = acc;
+                    at32(rowsf, (uint32_t)(d.r_rewards + agent) * Bu + cbu) = acc;
                 }
-                if (lane == 0) at32(rows1, (uint32_t)d.u_frozen * Bu + bu) = 1;
+                wave_lds_sync();
+                if (ca == 0 && ce < n_envs) at32(rows1, (uint32_t)d.u_frozen * Bu + cbu) = 1;
             }
             return;
         }
     }
 
-    int ay = pos0.x, ax = pos0.y;
+    // ---------------------------------------------------------------- field: the table as masks
     bool live[SPL];
 #pragma unroll
     for (int k = 0; k < SPL; ++k) {
@@ -270,142 +307,151 @@ __global__ void __launch_bounds__(kBlock) rs_env_kernel(char* __restrict__ arena
         v[k][PSTATE] = live[k] ? v[k][PSTATE] : -1;  // lanes past the count hold no passenger
         v[k][PDRIVER] = live[k] ? v[k][PDRIVER] : -2;
     }
-    if (MODE == kStep) {
-        // the LDS words of this env's slots start clear
-#pragma unroll
-        for (int k = 0; k < SPL; ++k) s_claim[wave][lane + 64 * k] = 0u, s_effect[wave][lane + 64 * k] = 0u;
-    }
-    // the passengers each agent drives, as a mask in that agent's lane (slot 64 k + 32 h + i = bit i of word 2 k + h)
-    uint32_t driven[W];
-#pragma unroll
-    for (int i = 0; i < W; ++i) driven[i] = 0u;
-    for_each_index(std::make_integer_sequence<int, AMAX>{}, [&](auto ic) {
-        constexpr int a = decltype(ic)::value;
-#pragma unroll
-        for (int k = 0; k < SPL; ++k) {
-            write_lane_c<a>(driven[2 * k], driven[2 * k + 1], __ballot(v[k][PDRIVER] == a));
-        }
-    });
     uint64_t st0[SPL], st1[SPL], st2[SPL];  // unaccepted / accepted / riding passengers (wave-uniform masks)
+    uint64_t kept_mask[SPL];                // the slots that stay in the table
 #pragma unroll
     for (int k = 0; k < SPL; ++k) {
         st0[k] = __ballot(v[k][PSTATE] == 0);
         st1[k] = __ballot(v[k][PSTATE] == 1);
         st2[k] = __ballot(v[k][PSTATE] == 2);
+        kept_mask[k] = __ballot(live[k]);
     }
-
-    uint32_t err = 0;
-    uint64_t kept_mask[SPL];  // the slots that stay in the table
+    // the passengers each agent drives (slot 64 k + 32 h + i = bit i of word 2 k + h), for the crew: every driven slot sets its bit in
+    // its driver's words (one LDS atomic per slot lane; a ballot per agent was eight times the instructions)
+    if (lane < AMAX * W) (&s_driven[wave][0][0])[lane] = 0u;
+    wave_lds_sync();
 #pragma unroll
-    for (int k = 0; k < SPL; ++k) kept_mask[k] = __ballot(live[k]);
+    for (int k = 0; k < SPL; ++k) {
+        const int drv = v[k][PDRIVER];
+        if (drv >= 0 && drv < AMAX) atomicOr(&s_driven[wave][drv][2 * k + (lane >> 5)], 1u << (lane & 31));
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < SPL; ++k) s_mask[wave][0][k] = st0[k], s_mask[wave][1][k] = st1[k], s_mask[wave][2][k] = st2[k], s_mask[wave][3][k] = kept_mask[k];
+    }
+    uint32_t err = 0;
     int count = count0, entered = 0;
-    float reward = 0.0f;
+    float global = 0.0f;
+
+    // crew state that lives across the barriers
+    uint32_t driven[W];
+#pragma unroll
+    for (int i = 0; i < W; ++i) driven[i] = 0u;
+    int ay = pos0.x, ax = pos0.y;
+    float cost = 0.0f;
+    int fare = 0, tslot = 0;
+    bool wins = false;
 
     if (MODE == kStep) {
-        // ------------------------------------------------------------ (1) action decode (rideshare.py:256-300)
-        // the agent's action mapping lists, in table order, the passengers that are unaccepted or its own (rideshare.py:378-392): entry i
-        // of the mapping = the i-th set bit of (unaccepted | driven)
-        uint32_t seen[W];
 #pragma unroll
         for (int k = 0; k < SPL; ++k) {
-            seen[2 * k] = driven[2 * k] | (uint32_t)st0[k];
-            seen[2 * k + 1] = driven[2 * k + 1] | (uint32_t)(st0[k] >> 32);
+            const int slot = lane + 64 * k;
+            s_claim[wave][slot] = 0u, s_effect[wave][slot] = 0u;  // the LDS words of this env's slots start clear
+            int* const t = s_target[wave][slot];
+            t[TSTATE] = v[k][PSTATE], t[TY] = v[k][PY], t[TX] = v[k][PX], t[TYD] = v[k][PYD], t[TXD] = v[k][PXD], t[TFARE] = v[k][PFARE];
         }
-        const int n_visible = popc_words(seen);
-        if (pol.on) {
-            // uniform member of OneOf([Discrete(1, start=state_t) for visible task t] + [noop]) (spaces/actions.py:10-50), the stream
-            // of frz_rideshare_random_policy: word 0 of Philox(counter (agent, global env, step), key seed), all agents at once
-            const frz::Philox4 w = frz::philox4x32_10((uint32_t)lane, (uint32_t)(b + d.first_env_index), pol.step_lo, pol.step_hi, pol.seed_lo, pol.seed_hi);
-            act_idx = (int)(((uint64_t)w.w[0] * (uint64_t)(n_visible + 1)) >> 32);
-        }
-        const int target = is_agent ? select_nth(seen, act_idx) : -1;  // slot of the chosen passenger, -1 = none
-        // a column of the chosen passenger, read from its slot lane (unconditional: a ds_bpermute reads 0 from switched-off lanes)
-        auto of_target = [&](int col) {
-            const int t = target < 0 ? 0 : target;
-            int got = from_lane(t & 63, v[0][col]);
-            if (SPL > 1) {
-                const int hi = from_lane(t & 63, v[SPL - 1][col]);
-                got = t >= 64 ? hi : got;
-            }
-            return got;
-        };
-        const int t_state = of_target(PSTATE);
-        if (pol.on) {
-            act_id = (is_agent && target >= 0) ? t_state : -1;
-            if (is_agent) at32(reinterpret_cast<int2*>(pol.actions_out), (uint32_t)lane * (uint32_t)B + (uint32_t)b) = make_int2(act_idx, act_id);
-        }
-        // act_idx inside the mapping <=> target >= 0 (lanes that are no agent carry act_id -1 and target -1)
-        if (__ballot(act_id != -1 && target < 0)) err |= FRZ_ERR_BAD_ACTION_INDEX;  // the reference reads a garbage row
-        const int kind = target >= 0 ? act_id : -1;
-        const bool accept = kind == 0, pick = kind == 1, drop = kind == 2;
-        const bool has_vec = (uint32_t)kind <= 2u;
-        // goal of the task vector: the passenger's position, or its destination for a drop — from the state BEFORE movement
-        const int t_y = of_target(PY), t_x = of_target(PX), t_yd = of_target(PYD), t_xd = of_target(PXD), t_fare = of_target(PFARE);
-        const int gy = drop ? t_yd : t_y, gx = drop ? t_xd : t_x;
-        // ------------------------------------------------------------ (2) movement (transitions/movement.py:56-116)
-        int my = 0, mx = 0;
-        float cost = 0.0f;
-        uint32_t dist2 = 0;  // squared pre-move distance to the goal (coordinates within +-16383: fits): sqrt is monotonic, zero iff zero
-        {
-            const int dy = ay - gy, dx = ax - gx;
-            uint32_t best = (uint32_t)(dy * dy) + (uint32_t)(dx * dx);
-            dist2 = has_vec ? best : 0u;
-            int by = 0, bx = 0;
-            if (flags & kFast) {
-                by = -dy;
-                bx = -dx;
-            } else {  // first minimum over {stay, N, E, S, W(, NW, NE, SE, SW)}
-                const int cy[9] = {0, -1, 0, 1, 0, -1, -1, 1, 1}, cx[9] = {0, 0, 1, 0, -1, -1, 1, 1, -1};
-                const int ndirs = (flags & kDiagonal) ? 9 : 5;
+        __syncthreads();
+
+        if (crew) {
+            // -------------------------------------------------------- (1) crew: action decode (rideshare.py:256-300)
+            // the agent's action mapping lists, in table order, the passengers that are unaccepted or its own (rideshare.py:378-392): entry i
+            // of the mapping = the i-th set bit of (unaccepted | driven)
 #pragma unroll
-                for (int k = 1; k < 9; ++k) {
-                    if (k < ndirs) {
-                        const int ey = dy + cy[k], ex = dx + cx[k];
-                        const uint32_t e = (uint32_t)(ey * ey) + (uint32_t)(ex * ex);
-                        const bool better = e < best;
-                        best = better ? e : best;
-                        by = better ? cy[k] : by;
-                        bx = better ? cx[k] : bx;
+            for (int i = 0; i < W; ++i) driven[i] = is_agent ? s_driven[ce][agent][i] : 0u;
+            uint32_t seen[W];
+#pragma unroll
+            for (int k = 0; k < SPL; ++k) {
+                const uint64_t u = s_mask[ce][0][k];
+                seen[2 * k] = driven[2 * k] | (uint32_t)u;
+                seen[2 * k + 1] = driven[2 * k + 1] | (uint32_t)(u >> 32);
+            }
+            const int n_visible = popc_words(seen);
+            if (pol.on) {
+                // uniform member of OneOf([Discrete(1, start=state_t) for visible task t] + [noop]) (spaces/actions.py:10-50), the stream
+                // of frz_rideshare_random_policy: word 0 of Philox(counter (agent, global env, step), key seed), all agents at once
+                const frz::Philox4 w = frz::philox4x32_10((uint32_t)agent, (uint32_t)(cb + d.first_env_index), pol.step_lo, pol.step_hi, pol.seed_lo, pol.seed_hi);
+                act_idx = (int)(((uint64_t)w.w[0] * (uint64_t)(n_visible + 1)) >> 32);
+            }
+            const int target = is_agent ? select_nth(seen, act_idx) : -1;  // slot of the chosen passenger, -1 = none
+            const int* const chosen = s_target[ce][target < 0 ? 0 : target];  // its record as the field parked it
+            const int t_state = chosen[TSTATE];
+            if (pol.on) {
+                act_id = (is_agent && target >= 0) ? t_state : -1;
+                if (is_agent) at32(reinterpret_cast<int2*>(pol.actions_out), (uint32_t)agent * Bu + cbu) = make_int2(act_idx, act_id);
+            }
+            // act_idx inside the mapping <=> target >= 0 (lanes that are no agent carry act_id -1 and target -1)
+            if (__ballot(act_id != -1 && target < 0)) err |= FRZ_ERR_BAD_ACTION_INDEX;  // the reference reads a garbage row
+            const int kind = target >= 0 ? act_id : -1;
+            const bool accept = kind == 0, pick = kind == 1, drop = kind == 2;
+            const bool has_vec = (uint32_t)kind <= 2u;
+            // goal of the task vector: the passenger's position, or its destination for a drop — from the state BEFORE movement
+            const int t_y = chosen[TY], t_x = chosen[TX], t_yd = chosen[TYD], t_xd = chosen[TXD], t_fare = chosen[TFARE];
+            const int gy = drop ? t_yd : t_y, gx = drop ? t_xd : t_x;
+            // -------------------------------------------------------- (2) crew: movement (transitions/movement.py:56-116)
+            int my = 0, mx = 0;
+            uint32_t dist2 = 0;  // squared pre-move distance to the goal (coordinates within +-16383: fits): sqrt is monotonic, zero iff zero
+            {
+                const int dy = ay - gy, dx = ax - gx;
+                uint32_t best = (uint32_t)(dy * dy) + (uint32_t)(dx * dx);
+                dist2 = has_vec ? best : 0u;
+                int by = 0, bx = 0;
+                if (flags & kFast) {
+                    by = -dy;
+                    bx = -dx;
+                } else {  // first minimum over {stay, N, E, S, W(, NW, NE, SE, SW)}
+                    const int cy[9] = {0, -1, 0, 1, 0, -1, -1, 1, 1}, cx[9] = {0, 0, 1, 0, -1, -1, 1, 1, -1};
+                    const int ndirs = (flags & kDiagonal) ? 9 : 5;
+#pragma unroll
+                    for (int k = 1; k < 9; ++k) {
+                        if (k < ndirs) {
+                            const int ey = dy + cy[k], ex = dx + cx[k];
+                            const uint32_t e = (uint32_t)(ey * ey) + (uint32_t)(ex * ex);
+                            const bool better = e < best;
+                            best = better ? e : best;
+                            by = better ? cy[k] : by;
+                            bx = better ? cx[k] : bx;
+                        }
                     }
                 }
+                my = has_vec ? by : 0;
+                mx = has_vec ? bx : 0;
+                const float fy = (float)my, fx = (float)mx;
+                cost = (flags & kDiagonal) ? __fsqrt_rn(__fadd_rn(__fmul_rn(fy, fy), __fmul_rn(fx, fx))) : __fadd_rn(fabsf(fy), fabsf(fx));
+                ay += my;
+                ax += mx;
             }
-            my = has_vec ? by : 0;
-            mx = has_vec ? bx : 0;
-            const float fy = (float)my, fx = (float)mx;
-            cost = (flags & kDiagonal) ? __fsqrt_rn(__fadd_rn(__fmul_rn(fy, fy), __fmul_rn(fx, fx))) : __fadd_rn(fabsf(fy), fabsf(fx));
-            ay += my;
-            ax += mx;
-        }
-        // ------------------------------------------------------------ (3) accept conflicts (passenger_state.py:54-74)
-        // while a passenger is claimed by several accepting agents, per env only the closest of ALL contested agents keeps its claim
-        // (lowest index on ties); uncontested accepts survive.  One pass settles an env.  Claims are counted per slot in LDS.
-        const int tslot = target < 0 ? 0 : target;
-        wave_lds_sync();
-        if (accept) atomicAdd(&s_claim[wave][tslot], 1u);
-        wave_lds_sync();
-        const bool contested = accept && s_claim[wave][tslot] > 1u;
-        const uint64_t contested_mask = __ballot(contested);
-        int winner = -1;
-        if (contested_mask) {  // rare
-            uint32_t best = 0;
+            // -------------------------------------------------------- (3) crew: accept conflicts (passenger_state.py:54-74)
+            // while a passenger is claimed by several accepting agents, per env only the closest of ALL contested agents keeps its claim
+            // (lowest index on ties); uncontested accepts survive.  One pass settles an env.  Claims are counted per slot in LDS.
+            tslot = target < 0 ? 0 : target;
+            if (accept) atomicAdd(&s_claim[ce][tslot], 1u);
+            wave_lds_sync();
+            const bool contested = accept && s_claim[ce][tslot] > 1u;
+            int winner = -1;
+            if (__ballot(contested)) {  // rare; every lane looks at the agents of its own env, in agent order
+                uint32_t best = 0;
 #pragma unroll
-            for (int o = 0; o < AMAX; ++o)
-                if (o < A && ((contested_mask >> o) & 1)) {
-                    const uint32_t d_o = (uint32_t)read_lane((int)dist2, o);
-                    if (winner < 0 || d_o < best) best = d_o, winner = o;
+                for (int o = 0; o < AMAX; ++o) {
+                    const bool c_o = from_lane(ce * AP + o, contested ? 1 : 0) != 0;
+                    const uint32_t d_o = (uint32_t)from_lane(ce * AP + o, (int)dist2);
+                    const bool better = o < A && c_o && (winner < 0 || d_o < best);
+                    best = better ? d_o : best;
+                    winner = better ? o : winner;
                 }
+            }
+            wins = accept && (!contested || ca == winner);
+            const bool picked = pick && dist2 == 0;   // distance < 1e-6: the agent already stood on the passenger (:88-90)
+            const bool dropped = drop && dist2 == 0;  // transitions/passenger_exit.py:43-46
+            fare = dropped ? t_fare : 0;
+            // what this step does to each slot, and where the agents go (riding passengers follow their driver)
+            const uint32_t effect = (wins ? (uint32_t)(ca + 1) << 8 : 0u) | (picked ? 2u : 0u) | (dropped ? 4u : 0u);
+            if (effect) atomicOr(&s_effect[ce][tslot], effect);
+            s_move[ce][ca] = is_agent ? ((my & 0xFFFF) | (mx << 16)) : 0;
         }
-        const bool wins = accept && (!contested || lane == winner);
-        const bool picked = pick && dist2 == 0;   // distance < 1e-6: the agent already stood on the passenger (:88-90)
-        const bool dropped = drop && dist2 == 0;  // transitions/passenger_exit.py:43-46
-        const int fare = dropped ? t_fare : 0;
-        // ------------------------------------------------------------ what this step does to each slot
-        const uint32_t effect = (wins ? (uint32_t)(lane + 1) << 8 : 0u) | (picked ? 2u : 0u) | (dropped ? 4u : 0u);
-        if (effect) atomicOr(&s_effect[wave][tslot], effect);
-        wave_lds_sync();
-        // ------------------------------------------------------------ (2b/3/4) riding passengers follow their driver, winners accept,
-        // picks ride, drops leave (order-preserving compaction: a kept slot's new place = its rank among the kept ones)
-        const int move_word = is_agent ? ((my & 0xFFFF) | (mx << 16)) : 0;
+        __syncthreads();
+
+        // ------------------------------------------------------------ (2b/3/4) field: riding passengers follow their driver, winners
+        // accept, picks ride, drops leave (order-preserving compaction: a kept slot's new place = its rank among the kept ones)
         uint64_t taken_mask[SPL], boarded_mask[SPL];
         int place[SPL];
         bool keep[SPL], moved[SPL], taken[SPL], boarded[SPL];
@@ -415,8 +461,8 @@ __global__ void __launch_bounds__(kBlock) rs_env_kernel(char* __restrict__ arena
             const uint32_t e = s_effect[wave][lane + 64 * k];
             // best_moves[env, driver]; driver -1 wraps to the last agent like Python's index (movement.py:107-108)
             const int drv0 = v[k][PDRIVER] < 0 ? A + v[k][PDRIVER] : v[k][PDRIVER];
-            const int word = from_lane(drv0 < 0 ? 0 : (drv0 > 63 ? 63 : drv0), move_word);
             const bool rides = v[k][PSTATE] == 2 && drv0 >= 0 && drv0 < A;
+            const int word = s_move[wave][rides ? drv0 : 0];
             const int sy = (int)(short)(word & 0xFFFF), sx = word >> 16;
             moved[k] = rides && word != 0;
             v[k][PY] += rides ? sy : 0;
@@ -449,28 +495,20 @@ __global__ void __launch_bounds__(kBlock) rs_env_kernel(char* __restrict__ arena
             if (shifted) store_cold(pas, (uint32_t)place[k], v[k]);
             if (shifted || (keep[k] && (moved[k] || taken[k] || boarded[k]))) store_hot(pas, (uint32_t)place[k], v[k]);
         }
-        // ------------------------------------------------------------ (5) entry of the next timestep (rideshare.py:308)
+        // ------------------------------------------------------------ (5) field: entry of the next timestep (rideshare.py:308)
         entered = entry_commit(sch, plan, pas, P, b, nm + 1, kept, err);
         count = kept + entered;
-        // ------------------------------------------------------------ the new table as masks over the OLD slot numbers (counts do not care)
+        // the new table as masks over the OLD slot numbers (counts do not care)
 #pragma unroll
         for (int k = 0; k < SPL; ++k) {
             st0[k] = st0[k] & ~taken_mask[k] & ~boarded_mask[k] & kept_mask[k];
             st1[k] = ((st1[k] | taken_mask[k]) & ~boarded_mask[k]) & kept_mask[k];
             st2[k] = (st2[k] | boarded_mask[k]) & kept_mask[k];
         }
-        // an accepted passenger had no driver or this one (it was visible to the agent): the winner's bit joins its driven set
-        {
-            const uint32_t bit = wins ? 1u << (tslot & 31) : 0u;
-            const int word = tslot >> 5;
-#pragma unroll
-            for (int i = 0; i < W; ++i) driven[i] |= word == i ? bit : 0u;
-        }
-        // ------------------------------------------------------------ (6) rewards (rideshare.py:310-363)
+        // ------------------------------------------------------------ (6) field: the waiting costs of the env (rideshare.py:310-339)
         int unaccepted = entered;
 #pragma unroll
         for (int k = 0; k < SPL; ++k) unaccepted += (int)__popcll(st0[k]);
-        float global = 0.0f;
         if (flags & kWaiting) {
             // `global_rewards[envs] += cost` is an index_put without accumulation: per statement only the LAST passenger (table order) of
             // the env in that state takes effect (:323-333); the passengers that just entered are the last unaccepted ones
@@ -496,10 +534,41 @@ __global__ void __launch_bounds__(kBlock) rs_env_kernel(char* __restrict__ arena
             const int slots = A * d.pool_limit;
             global = __fadd_rn(global, __fmul_rn(__fmul_rn(unaccepted >= slots - count ? 1.0f : 0.0f, -0.5f), (float)(slots - count)));
         }
+        if (lane == 0) {
+            at32(rows, (uint32_t)d.r_moves * Bu + bu) = nm + 1;
+            at32(rows, (uint32_t)d.r_count * Bu + bu) = count;
+#pragma unroll
+            for (int k = 0; k < SPL; ++k) s_mask[wave][0][k] = st0[k], s_mask[wave][1][k] = st1[k], s_mask[wave][2][k] = st2[k], s_mask[wave][3][k] = kept_mask[k];
+        }
+    }
+    if (lane == 0) {
+        s_out[wave] = RsFieldOut{count, entered, global, 0};
+        reinterpret_cast<int64_t*>(arena + d.off_etc)[b] = count;
+    }
+    __syncthreads();
+    if (!crew) {
+        if (err) atomicOr(reinterpret_cast<uint32_t*>(arena + d.off_error), err);
+        return;
+    }
+
+    // ---------------------------------------------------------------- crew: rewards (rideshare.py:340-363), truncation, the counts of
+    // update_actions / update_observations that are not lists (rideshare.py:427-463), self = (y, x, #accepted, #riding), others = the
+    // other agents' self rows
+    const RsFieldOut out = s_out[ce < n_envs ? ce : 0];
+    uint64_t n0[SPL], n1[SPL], n2[SPL], nk[SPL];  // the new table's masks
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) n0[k] = s_mask[ce][0][k], n1[k] = s_mask[ce][1][k], n2[k] = s_mask[ce][2][k], nk[k] = s_mask[ce][3][k];
+    if (MODE == kStep) {
+        // an accepted passenger had no driver or this one (it was visible to the agent): the winner's bit joins its driven set
+        {
+            const uint32_t bit = wins ? 1u << (tslot & 31) : 0u;
+            const int word = tslot >> 5;
+#pragma unroll
+            for (int i = 0; i < W; ++i) driven[i] |= word == i ? bit : 0u;
+        }
         int owned = 0;  // passengers whose driver is this agent, any state (rideshare.py:343-344)
 #pragma unroll
-        for (int k = 0; k < SPL; ++k)
-            owned += __popc(driven[2 * k] & (uint32_t)kept_mask[k]) + __popc(driven[2 * k + 1] & (uint32_t)(kept_mask[k] >> 32));
+        for (int k = 0; k < SPL; ++k) owned += __popc(driven[2 * k] & (uint32_t)nk[k]) + __popc(driven[2 * k + 1] & (uint32_t)(nk[k] >> 32));
         float r = 0.0f;
         r = __fadd_rn(r, owned > d.pool_limit ? d.pool_limit_cost : 0.0f);
         r = __fadd_rn(r, __fmul_rn(act_id == -1 ? 1.0f : 0.0f, d.noop_cost));
@@ -508,48 +577,43 @@ __global__ void __launch_bounds__(kBlock) rs_env_kernel(char* __restrict__ arena
         float dr = __fmul_rn(cost, d.move_cost);
         if (flags & kVariableMove) dr = __fdiv_rn(dr, (float)(owned + 1));
         r = __fadd_rn(r, dr);
-        reward = __fadd_rn(r, global);
-        const int nm1 = nm + 1;
-        trunc = (flags & kTruncate) ? nm1 >= d.max_steps : trunc;
+        const float reward = __fadd_rn(r, out.global);
+        trunc = (flags & kTruncate) ? c_nm + 1 >= d.max_steps : trunc;
         if (is_agent) {
-            at32(rowsf, (uint32_t)(d.r_rewards + lane) * Bu + bu) = reward;
-            if (flags & kTrackCumulative) at32(rowsf, (uint32_t)(d.r_cum + lane) * Bu + bu) = __fadd_rn(cum0, reward);
-            if (flags & kTruncate) at32(rows1, (uint32_t)(d.u_trunc + lane) * Bu + bu) = (uint8_t)trunc;
-            at32(agents, (uint32_t)lane) = make_int2(ay, ax);
+            at32(rowsf, (uint32_t)(d.r_rewards + agent) * Bu + cbu) = reward;
+            if (flags & kTrackCumulative) at32(rowsf, (uint32_t)(d.r_cum + agent) * Bu + cbu) = __fadd_rn(cum0, reward);
+            if (flags & kTruncate) at32(rows1, (uint32_t)(d.u_trunc + agent) * Bu + cbu) = (uint8_t)trunc;
+            at32(agents, cbu * (uint32_t)A + (uint32_t)agent) = make_int2(ay, ax);
         }
-        if (lane == 0) {
-            at32(rows, (uint32_t)d.r_moves * (uint32_t)B + (uint32_t)b) = nm1;
-            at32(rows, (uint32_t)d.r_count * (uint32_t)B + (uint32_t)b) = count;
-        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < W; ++i) driven[i] = is_agent ? s_driven[ce][agent][i] : 0u;
     }
-
-    // ---------------------------------------------------------------- per-env outputs of update_actions / update_observations that are
-    // not lists (rideshare.py:427-463): counts, self = (y, x, #accepted, #riding), others = the other agents' self rows
-    int n_accepted = 0, n_riding = 0, visible = entered;  // agent-lane
+    int n_accepted = 0, n_riding = 0, visible = out.entered;
 #pragma unroll
     for (int k = 0; k < SPL; ++k) {
-        const uint32_t lo = driven[2 * k] & (uint32_t)kept_mask[k], hi = driven[2 * k + 1] & (uint32_t)(kept_mask[k] >> 32);
-        n_accepted += __popc(lo & (uint32_t)st1[k]) + __popc(hi & (uint32_t)(st1[k] >> 32));
-        n_riding += __popc(lo & (uint32_t)st2[k]) + __popc(hi & (uint32_t)(st2[k] >> 32));
+        const uint32_t lo = driven[2 * k] & (uint32_t)nk[k], hi = driven[2 * k + 1] & (uint32_t)(nk[k] >> 32);
+        n_accepted += __popc(lo & (uint32_t)n1[k]) + __popc(hi & (uint32_t)(n1[k] >> 32));
+        n_riding += __popc(lo & (uint32_t)n2[k]) + __popc(hi & (uint32_t)(n2[k] >> 32));
         // visible = unaccepted or driven by the agent
-        visible += __popc(lo | (uint32_t)st0[k]) + __popc(hi | (uint32_t)(st0[k] >> 32));
+        visible += __popc(lo | (uint32_t)n0[k]) + __popc(hi | (uint32_t)(n0[k] >> 32));
     }
     const int4 self = make_int4(ay, ax, n_accepted, n_riding);
     if (is_agent) {
-        at32(reinterpret_cast<int4*>(arena + d.off_obs_self), (uint32_t)lane * (uint32_t)B + (uint32_t)b) = self;
-        at32(rows, (uint32_t)(d.r_atc + lane) * (uint32_t)B + (uint32_t)b) = visible;
-        s_self[wave][lane] = self;
+        at32(reinterpret_cast<int4*>(arena + d.off_obs_self), (uint32_t)agent * Bu + cbu) = self;
+        at32(rows, (uint32_t)(d.r_atc + agent) * Bu + cbu) = visible;
+        s_self[ce][agent] = self;
     }
     wave_lds_sync();
     {   // others[a][j] = self of the j-th other agent: one lane per (agent, other) pair
         int4* const obs_others = reinterpret_cast<int4*>(arena + d.off_obs_others);
         const int others = A - 1, pairs = A * others;
-        for (int q = lane; q < pairs; q += 64) {
-            const int a = (int)(((uint32_t)q * d.inv_others) >> 16), j = q - a * others;
-            at32(obs_others, ((uint32_t)a * (uint32_t)B + (uint32_t)b) * (uint32_t)others + (uint32_t)j) = s_self[wave][j < a ? j : j + 1];
-        }
+        for (int e = 0; e < n_envs; ++e)
+            for (int q = lane; q < pairs; q += 64) {
+                const int a = (int)(((uint32_t)q * d.inv_others) >> 16), j = q - a * others;
+                at32(obs_others, ((uint32_t)a * Bu + (uint32_t)(b0 + e)) * (uint32_t)others + (uint32_t)j) = s_self[e][j < a ? j : j + 1];
+            }
     }
-    if (lane == 0) reinterpret_cast<int64_t*>(arena + d.off_etc)[b] = count;
     if (err) atomicOr(reinterpret_cast<uint32_t*>(arena + d.off_error), err);
 }
 
