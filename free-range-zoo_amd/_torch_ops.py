@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(_PKG_DIR, 'csrc', 'torch_ops', 'libfrz_torch_ops.so')
 _loaded = False
 
 OPS = ('wildfire_reset', 'wildfire_reset_reseed', 'wildfire_rebuild', 'wildfire_step', 'wildfire_random_policy', 'wildfire_step_random_policy',
+       'wildfire_rollout', 'cybersecurity_rollout',
        'cybersecurity_reset', 'cybersecurity_rebuild', 'cybersecurity_step', 'cybersecurity_random_policy', 'cybersecurity_step_random_policy',
        'rideshare_reset', 'rideshare_rebuild', 'rideshare_step', 'rideshare_random_policy', 'rideshare_step_random_policy', 'mt19937_seed',
        'mt19937_generate')

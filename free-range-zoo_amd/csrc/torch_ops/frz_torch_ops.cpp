@@ -12,6 +12,8 @@
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
+#include <cstring>
+
 #include "../../../include/frz.h"
 
 namespace {
@@ -152,6 +154,74 @@ void cybersecurity_step_random_policy(at::Tensor arena, int64_t handle, int64_t 
        "frz_cybersecurity_step_random_policy");
 }
 
+// ---------------------------------------------------------------------------------------------------- rollouts (frz_rollout_spec)
+// n steps of the rollout loop as one op: every tensor of the spec is an argument (so the dispatcher sees what is read and what is
+// written), checked for device / dtype / contiguity / size before its pointer goes into the spec.
+template <typename T>
+T* tape_or_null(const at::Tensor& arena, const c10::optional<at::Tensor>& t, at::ScalarType dtype, int64_t numel, const char* what) {
+    if (!t.has_value()) return nullptr;
+    TORCH_CHECK(t->is_cuda() && t->device() == arena.device() && t->scalar_type() == dtype && t->is_contiguous() && t->numel() == numel, what,
+                ": expected a contiguous tensor of ", numel, " elements of the documented dtype on the env's device");
+    return static_cast<T*>(t->data_ptr());
+}
+frz_rollout_spec make_spec(const at::Tensor& arena, const Env& e, int64_t units_a, int64_t units_b, int64_t list_block_bytes, int64_t steps, int64_t rng_mode,
+                           int64_t flags, int64_t seed_increment, int64_t seed_stride, int64_t policy_seed, int64_t first_step,
+                           const c10::optional<at::Tensor>& action_tape, const c10::optional<at::Tensor>& randomness_a,
+                           const c10::optional<at::Tensor>& randomness_b, const c10::optional<at::Tensor>& actions_out, bool record_actions,
+                           const c10::optional<at::Tensor>& reward_tape, const c10::optional<at::Tensor>& done_tape,
+                           const c10::optional<at::Tensor>& list_record, const c10::optional<at::Tensor>& metrics) {
+    TORCH_CHECK(steps > 0, "rollout: steps must be positive");
+    frz_rollout_spec spec;
+    std::memset(&spec, 0, sizeof(spec));
+    spec.n_steps = (int32_t)steps;
+    spec.rng_mode = (int32_t)rng_mode;
+    spec.flags = (uint32_t)flags;
+    spec.seed_increment = (int32_t)seed_increment;
+    spec.seed_stride = (uint32_t)seed_stride;
+    spec.policy_seed = (uint64_t)policy_seed;
+    spec.first_step = (uint64_t)first_step;
+    spec.action_tape = tape_or_null<const int32_t>(arena, action_tape, at::kInt, steps * e.A * e.B * 2, "action_tape");
+    spec.randomness_tape_a = tape_or_null<const float>(arena, randomness_a, at::kFloat, steps * units_a, "randomness_a");
+    spec.randomness_tape_b = tape_or_null<const float>(arena, randomness_b, at::kFloat, steps * units_b, "randomness_b");
+    TORCH_CHECK(rng_mode != FRZ_RNG_INJECTED || (spec.randomness_tape_a && spec.randomness_tape_b), "rollout: FRZ_RNG_INJECTED needs both randomness tapes");
+    spec.record_actions = record_actions ? 1 : 0;
+    spec.actions_out = tape_or_null<int32_t>(arena, actions_out, at::kInt, (record_actions ? steps : 1) * e.A * e.B * 2, "actions_out");
+    TORCH_CHECK(spec.action_tape || spec.actions_out, "rollout: the in-kernel policy needs actions_out");
+    spec.reward_tape = tape_or_null<float>(arena, reward_tape, at::kFloat, steps * e.A * e.B, "reward_tape");
+    spec.done_tape = tape_or_null<uint8_t>(arena, done_tape, at::kByte, steps * 2 * e.B, "done_tape");
+    spec.list_record = tape_or_null<uint8_t>(arena, list_record, at::kByte, (steps - 1) * list_block_bytes, "list_record");
+    spec.metrics = tape_or_null<double>(arena, metrics, at::kDouble, e.A + 2, "metrics");
+    return spec;
+}
+void wildfire_rollout(at::Tensor arena, int64_t handle, int64_t steps, int64_t rng_mode, int64_t flags, int64_t seed_increment, int64_t seed_stride,
+                      int64_t policy_seed, int64_t first_step, const c10::optional<at::Tensor>& action_tape, const c10::optional<at::Tensor>& randomness_a,
+                      const c10::optional<at::Tensor>& randomness_b, const c10::optional<at::Tensor>& actions_out, bool record_actions,
+                      const c10::optional<at::Tensor>& reward_tape, const c10::optional<at::Tensor>& done_tape, const c10::optional<at::Tensor>& list_record,
+                      const c10::optional<at::Tensor>& metrics) {
+    const Env e = checked(arena, handle, kWildfire, "wildfire_rollout");
+    void* block = nullptr;
+    int64_t block_bytes = 0;
+    ok(frz_wildfire_list_block(static_cast<frz_wildfire_env*>(e.handle), &block, &block_bytes), "frz_wildfire_list_block");
+    const frz_rollout_spec spec = make_spec(arena, e, 3 * e.B * e.U, 5 * e.B * e.A, block_bytes, steps, rng_mode, flags, seed_increment, seed_stride, policy_seed,
+                                            first_step, action_tape, randomness_a, randomness_b, actions_out, record_actions, reward_tape, done_tape, list_record,
+                                            metrics);
+    ok(frz_wildfire_rollout(static_cast<frz_wildfire_env*>(e.handle), &spec, current_stream(arena)), "frz_wildfire_rollout");
+}
+void cybersecurity_rollout(at::Tensor arena, int64_t handle, int64_t steps, int64_t rng_mode, int64_t flags, int64_t seed_increment, int64_t seed_stride,
+                           int64_t policy_seed, int64_t first_step, const c10::optional<at::Tensor>& action_tape,
+                           const c10::optional<at::Tensor>& randomness_a, const c10::optional<at::Tensor>& randomness_b,
+                           const c10::optional<at::Tensor>& actions_out, bool record_actions, const c10::optional<at::Tensor>& reward_tape,
+                           const c10::optional<at::Tensor>& done_tape, const c10::optional<at::Tensor>& list_record, const c10::optional<at::Tensor>& metrics) {
+    const Env e = checked(arena, handle, kCybersecurity, "cybersecurity_rollout");
+    void* block = nullptr;
+    int64_t block_bytes = 0;
+    ok(frz_cybersecurity_list_block(static_cast<frz_cybersecurity_env*>(e.handle), &block, &block_bytes), "frz_cybersecurity_list_block");
+    const frz_rollout_spec spec = make_spec(arena, e, e.B * e.U, e.B * e.A, block_bytes, steps, rng_mode, flags, seed_increment, seed_stride, policy_seed,
+                                            first_step, action_tape, randomness_a, randomness_b, actions_out, record_actions, reward_tape, done_tape, list_record,
+                                            metrics);
+    ok(frz_cybersecurity_rollout(static_cast<frz_cybersecurity_env*>(e.handle), &spec, current_stream(arena)), "frz_cybersecurity_rollout");
+}
+
 // ---------------------------------------------------------------------------------------------------- rideshare
 void rideshare_reset(at::Tensor arena, int64_t handle) {
     const Env e = checked(arena, handle, kRideshare, "rideshare_reset");
@@ -224,6 +294,14 @@ TORCH_LIBRARY(frz, m) {
     m.def("wildfire_random_policy(Tensor arena, int handle, int policy_seed, int policy_step, Tensor(b!) actions_out, int agents, int envs) -> ()");
     m.def("wildfire_step_random_policy(Tensor(a!) arena, int handle, int policy_seed, int policy_step, Tensor(b!) actions_out, int rng_mode, int agents, "
           "int envs) -> ()");
+    m.def("wildfire_rollout"
+          "(Tensor(a!) arena, int handle, int steps, int rng_mode, int flags, int seed_increment, int seed_stride, int policy_seed, int first_step, "
+          "Tensor? action_tape, Tensor? randomness_a, Tensor? randomness_b, Tensor(b!)? actions_out, bool record_actions, Tensor(c!)? reward_tape, "
+          "Tensor(d!)? done_tape, Tensor(e!)? list_record, Tensor(f!)? metrics) -> ()");
+    m.def("cybersecurity_rollout"
+          "(Tensor(a!) arena, int handle, int steps, int rng_mode, int flags, int seed_increment, int seed_stride, int policy_seed, int first_step, "
+          "Tensor? action_tape, Tensor? randomness_a, Tensor? randomness_b, Tensor(b!)? actions_out, bool record_actions, Tensor(c!)? reward_tape, "
+          "Tensor(d!)? done_tape, Tensor(e!)? list_record, Tensor(f!)? metrics) -> ()");
     m.def("cybersecurity_reset(Tensor(a!) arena, int handle) -> ()");
     m.def("cybersecurity_rebuild(Tensor(a!) arena, int handle) -> ()");
     m.def("cybersecurity_step(Tensor(a!) arena, int handle, Tensor actions, int rng_mode, Tensor? network_randomness, Tensor? agent_randomness, int agents, "
@@ -247,6 +325,8 @@ TORCH_LIBRARY_IMPL(frz, CUDA, m) {  // HIP tensors dispatch on the CUDA key in R
     m.impl("wildfire_step", &wildfire_step);
     m.impl("wildfire_random_policy", &wildfire_random_policy);
     m.impl("wildfire_step_random_policy", &wildfire_step_random_policy);
+    m.impl("wildfire_rollout", &wildfire_rollout);
+    m.impl("cybersecurity_rollout", &cybersecurity_rollout);
     m.impl("cybersecurity_reset", &cybersecurity_reset);
     m.impl("cybersecurity_rebuild", &cybersecurity_rebuild);
     m.impl("cybersecurity_step", &cybersecurity_step);

@@ -443,8 +443,16 @@ class BatchedParallelEnv:
             if metrics.dtype != torch.float64 or metrics.numel() != A + 2 or not metrics.is_contiguous() or metrics.device != self.device:
                 raise ValueError('metrics must be a contiguous float64 [A + 2] tensor on the env device')
             spec.metrics = metrics.data_ptr()
-        symbol = f'frz_{self._domain}_rollout'
-        _capi.check(getattr(self._lib, symbol)(self._handle, ctypes.byref(spec), stream_ptr(self.device)), symbol)
+        if self._ops is not None:  # the same call as a dispatcher-visible op: every tape is an argument
+            tapes = randomness if randomness is None else tuple(keep[-2:])
+            getattr(self._ops, f'{self._domain}_rollout')(
+                self._arena, self._handle.value, int(steps), int(spec.rng_mode), int(spec.flags),
+                int(seed_increment), int(seed_stride) & 0xFFFFFFFF, int(policy_seed), int(first_step), actions, None if tapes is None else tapes[0],
+                None if tapes is None else tapes[1], None if actions is not None else (out['actions'] if record else self._actions), bool(record and actions is None),
+                out.get('rewards'), out.get('dones'), out['lists'] if (record and steps > 1) else None, metrics)
+        else:
+            symbol = f'frz_{self._domain}_rollout'
+            _capi.check(getattr(self._lib, symbol)(self._handle, ctypes.byref(spec), stream_ptr(self.device)), symbol)
         self._rollout_keepalive = keep  # the launch reads the tapes after this call returns
         self._after_rollout()
         return out

@@ -13,6 +13,7 @@ def test_ops_are_registered_with_their_schemas():
     for name in _torch_ops.OPS:
         schema = str(getattr(ops, name).default._schema)
         assert schema.startswith(f'frz::{name}(') and schema.endswith('-> ()'), schema
+    assert 'Tensor? action_tape' in str(ops.wildfire_rollout.default._schema) and 'Tensor(f!)? metrics' in str(ops.cybersecurity_rollout.default._schema)
     step = str(ops.wildfire_step.default._schema)
     assert 'Tensor(a!) arena' in step and 'int handle' in step and 'Tensor? field_randomness' in step
     assert 'Tensor(b!) actions_out' in str(ops.rideshare_step_random_policy.default._schema)
@@ -61,6 +62,47 @@ def test_envs_driven_through_torch_ops_equal_the_c_abi_path(domain):
     a, b = (_state_tensors(env) for env in envs)
     for name in a:
         assert torch.equal(a[name], b[name]), f'{domain}: {name} after rebuild'
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('domain', ['wildfire', 'cybersecurity'])
+def test_rollouts_through_the_rollout_op_equal_the_c_abi_path(domain):
+    """`env.rollout(...)` (frz_rollout_spec) with dispatch='torch' goes through torch.ops.frz.<domain>_rollout: an action tape with every
+    record, then the in-kernel policy with the reset folded in and the metrics, as one multi-step launch and as per-step launches."""
+    from free_range_zoo_amd.envs import cybersecurity_v0, wildfire_v0
+    B, steps = 1800, 7
+    module, build = {'wildfire': (wildfire_v0, configs.wildfire_openness), 'cybersecurity': (cybersecurity_v0, configs.cyber_openness)}[domain]
+    scout = module.parallel_env(configuration=build(), parallel_envs=B, max_steps=20, device=torch.device('cuda'), rng='philox')
+    scout.reset(seed=torch.arange(B, dtype=torch.int32) + 11)
+    tape = scout.rollout(steps, policy_seed=5, record=True)['actions'].clone()  # actions that are valid along this trajectory
+    for exclusive in (False, True):
+        envs = [module.parallel_env(configuration=build(), parallel_envs=B, max_steps=20, device=torch.device('cuda'), dispatch=how, rng='philox')
+                for how in ('ctypes', 'torch')]
+        results = []
+        for env in envs:
+            env.reset(seed=torch.arange(B, dtype=torch.int32) + 11)
+            if exclusive:
+                env.set_exclusive_device(True)
+            first = env.rollout(steps, actions=tape, record=True)
+            metrics = torch.zeros(len(env.agents) + 2, dtype=torch.float64, device='cuda')
+            kwargs = dict(auto_reset=True, seed_stride=17, metrics=metrics) if domain == 'wildfire' else {}  # (cybersecurity: no auto-reset, no metrics entry)
+            second = env.rollout(steps, policy_seed=6, first_step=0, reset_first=True, seed_increment=3, record=True, **kwargs)
+            env.check()
+            results.append((first, second, metrics, _state_tensors(env)))
+        (f0, s0, m0, t0), (f1, s1, m1, t1) = results
+        for a, b in ((f0, f1), (s0, s1)):
+            assert a.keys() == b.keys()
+            for name in a:
+                if torch.is_tensor(a[name]):
+                    assert torch.equal(a[name], b[name]), f'{domain} exclusive={exclusive}: record {name}'
+        assert torch.equal(m0, m1) and (domain != 'wildfire' or float(m0[-1]) > 0)
+        for name in t0:
+            assert torch.equal(t0[name], t1[name]), f'{domain} exclusive={exclusive}: {name}'
+    with pytest.raises(RuntimeError):  # a tape of the wrong size is refused by the op, not read
+        envs[1]._ops.wildfire_rollout(envs[1]._arena, envs[1]._handle.value, 3, 1, 0, 0, 0, 0, 0, torch.zeros(5, dtype=torch.int32, device='cuda'), None, None,
+                                      None, False, None, None, None, None) if domain == 'wildfire' else envs[1]._ops.cybersecurity_rollout(
+            envs[1]._arena, envs[1]._handle.value, 3, 1, 0, 0, 0, 0, 0, torch.zeros(5, dtype=torch.int32, device='cuda'), None, None, None, False, None, None,
+            None, None)
 
 
 @pytest.mark.gpu
