@@ -79,6 +79,8 @@ SIGNATURES = {
     'frz_cybersecurity_step_random_policy': (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_uint64, _P, ctypes.c_int, _P, _P, _P]),
     'frz_cybersecurity_rollout_random_policy': (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int32, _P, ctypes.c_int, _P]),
     'frz_cybersecurity_rollout': (ctypes.c_int, [_P, _P, _P]),
+    'frz_rideshare_rollout': (ctypes.c_int, [_P, _P, _P]),
+    'frz_rideshare_list_block': (ctypes.c_int, [_P, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64)]),
     'frz_cybersecurity_list_block': (ctypes.c_int, [_P, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64)]),
     'frz_cybersecurity_set_exclusive_device': (ctypes.c_int, [_P, ctypes.c_int]),
     'frz_cybersecurity_rollout_launches': (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int]),

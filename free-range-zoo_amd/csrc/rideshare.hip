@@ -1089,6 +1089,58 @@ int frz_rideshare_step_random_policy(frz_rideshare_env* env, uint64_t policy_see
     return launch(env, actions_out, kStep, make_policy(policy_seed, policy_step, actions_out), static_cast<hipStream_t>(stream));
 }
 
+int frz_rideshare_list_block(const frz_rideshare_env* env, void** block, int64_t* bytes) {
+    if (!env || !block || !bytes) return FRZ_E_INVALID;
+    if (!env->arena) return FRZ_E_UNBOUND;
+    *block = env->arena + env->dev.off_task_offsets;  // task / agent offsets, task rows, per-agent task rows, index maps, task states
+    *bytes = env->dev.off_schedule - env->dev.off_task_offsets;
+    return FRZ_OK;
+}
+
+// utils/conversions.py:59-99 over n steps for this domain: one launch sequence per step (the env launch's fields and crew, the offsets,
+// the lists), the records copied out between the steps.  The domain draws nothing (rideshare.py:248-365): rng_mode and the randomness
+// tapes are not looked at; it has no partial reset (rideshare.py:246 raises) and no metrics entry: those options are refused.
+int frz_rideshare_rollout(frz_rideshare_env* env, const frz_rollout_spec* spec, void* stream) {
+    if (!env || !spec || spec->n_steps < 0) return FRZ_E_INVALID;
+    if (!env->arena) return FRZ_E_UNBOUND;
+    if (!env->was_reset) return FRZ_E_INVALID;
+    const RsDev& p = env->dev;
+    const bool policy = spec->action_tape == nullptr, reset_first = (spec->flags & FRZ_ROLLOUT_RESET_FIRST) != 0;
+    if (policy && !spec->actions_out) return FRZ_E_INVALID;
+    if ((spec->flags & FRZ_ROLLOUT_AUTO_RESET) || spec->metrics || spec->seed_increment != 0) return FRZ_E_INVALID;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (reset_first) {
+        const int rc = frz_rideshare_reset(env, stream);
+        if (rc != FRZ_OK) return rc;
+    }
+    const int64_t B = p.B, A = p.A, AB2 = A * B * 2;
+    const int64_t block_bytes = p.off_schedule - p.off_task_offsets;
+    for (int32_t t = 0; t < spec->n_steps; ++t) {
+        int rc;
+        if (policy)
+            rc = frz_rideshare_step_random_policy(env, spec->policy_seed, spec->first_step + (uint64_t)t,
+                                                  spec->actions_out + (spec->record_actions ? (int64_t)t * AB2 : 0), stream);
+        else
+            rc = frz_rideshare_step(env, spec->action_tape + (int64_t)t * AB2, stream);
+        if (rc != FRZ_OK) return rc;
+        bool ok = true;
+        if (spec->reward_tape)
+            ok = ok && hipMemcpyAsync(spec->reward_tape + (int64_t)t * A * B, env->arena + p.off_rows4 + (int64_t)p.r_rewards * B * 4, (size_t)(A * B * 4),
+                                      hipMemcpyDeviceToDevice, s) == hipSuccess;
+        if (spec->done_tape) {
+            ok = ok && hipMemcpyAsync(spec->done_tape + ((int64_t)t * 2 + 0) * B, env->arena + p.off_rows1 + (int64_t)p.u_term * B, (size_t)B,
+                                      hipMemcpyDeviceToDevice, s) == hipSuccess;
+            ok = ok && hipMemcpyAsync(spec->done_tape + ((int64_t)t * 2 + 1) * B, env->arena + p.off_rows1 + (int64_t)p.u_trunc * B, (size_t)B,
+                                      hipMemcpyDeviceToDevice, s) == hipSuccess;
+        }
+        if (spec->list_record && t < spec->n_steps - 1)
+            ok = ok && hipMemcpyAsync(static_cast<char*>(spec->list_record) + (int64_t)t * block_bytes, env->arena + p.off_task_offsets, (size_t)block_bytes,
+                                      hipMemcpyDeviceToDevice, s) == hipSuccess;
+        if (!ok) return FRZ_E_LAUNCH;
+    }
+    return FRZ_OK;
+}
+
 int frz_rideshare_timed_rollout(frz_rideshare_env* env, uint64_t policy_seed, uint64_t first_step, int32_t n_steps, int32_t* actions_out,
                                 void* stream, float* step_ms) {
     if (!env || !actions_out || !step_ms || n_steps <= 0) return FRZ_E_INVALID;

@@ -280,6 +280,17 @@ class raw_env(BatchedParallelEnv):
             self._log_environment()
         return (self._observations_out(), self.rewards, self.terminations, self.truncations, self.infos)
 
+    # -- rollout(): frz_rideshare_rollout (one launch sequence per step; the domain draws nothing, has no partial reset and no metrics entry)
+    def _fused_rng_mode(self) -> int:
+        return _capi.FRZ_RNG_PHILOX  # not looked at by the library: rideshare.py:248-365 is deterministic given the schedule
+
+    def _check_randomness_tapes(self, steps: int, a: torch.Tensor, b: torch.Tensor) -> None:
+        raise ValueError('rideshare draws no randomness: there are no tapes to inject')
+
+    def _after_rollout(self) -> None:
+        self._publish()
+        self.infos = {agent: {} for agent in self.agents}
+
     @torch.no_grad()
     def capture_random_rollout(self, steps: int, policy_seed: int = 0, include_reset: bool = True) -> 'torch.cuda.CUDAGraph':
         """``[reset] + steps x (device random policy -> fused step)`` as one HIP graph (see the wildfire env)."""

@@ -443,7 +443,7 @@ class BatchedParallelEnv:
             if metrics.dtype != torch.float64 or metrics.numel() != A + 2 or not metrics.is_contiguous() or metrics.device != self.device:
                 raise ValueError('metrics must be a contiguous float64 [A + 2] tensor on the env device')
             spec.metrics = metrics.data_ptr()
-        if self._ops is not None:  # the same call as a dispatcher-visible op: every tape is an argument
+        if self._ops is not None and hasattr(self._ops, f'{self._domain}_rollout'):  # the same call as a dispatcher-visible op: every tape is an argument
             tapes = randomness if randomness is None else tuple(keep[-2:])
             getattr(self._ops, f'{self._domain}_rollout')(
                 self._arena, self._handle.value, int(steps), int(spec.rng_mode), int(spec.flags),

@@ -558,6 +558,14 @@ int frz_rideshare_random_policy(frz_rideshare_env* env, uint64_t policy_seed, ui
  * two calls; the reference's `env.step({a: action_space(a).sample_nested()})` loop, baselines/random.py:20); the sampled actions are left in
  * actions_out (int32 [A][B][2]; not written once every env is finished, when the step is a no-op) */
 int frz_rideshare_step_random_policy(frz_rideshare_env* env, uint64_t policy_seed, uint64_t policy_step, int32_t* actions_out, void* stream);
+/* n steps of the rollout loop (utils/conversions.py:59-99 over rideshare.py:248-467) enqueued by one call, driven by an action tape or the
+ * in-launch uniform policy, with the reward / done / action tapes and the list record of frz_rollout_spec (frz_rideshare_list_block: task and
+ * agent offsets, task rows, per-agent task rows, index maps, task states): one launch sequence per step, the records copied out between
+ * the steps.  The domain draws nothing (rng_mode and the randomness tapes are not looked at); FRZ_ROLLOUT_RESET_FIRST is frz_rideshare_reset;
+ * FRZ_ROLLOUT_AUTO_RESET, a seed increment and metrics are refused (FRZ_E_INVALID): the reference has no partial reset here
+ * (rideshare.py:246) and the episodes of the batch end together */
+int frz_rideshare_rollout(frz_rideshare_env* env, const frz_rollout_spec* spec, void* stream);
+int frz_rideshare_list_block(const frz_rideshare_env* env, void** block, int64_t* bytes);
 /* Measurement aid (bench.py): n_steps x frz_rideshare_step_random_policy back to back with no host synchronisation in between; a pair of
  * HIP events on `stream` takes the begin timestamp of each step's first dispatch and the end timestamp of its last one; synchronises once
  * at the end and returns the step durations in milliseconds */

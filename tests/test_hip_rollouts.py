@@ -5,6 +5,8 @@ reference's recorded trajectories, step by step: every step's sampled actions, r
 Also: the action-tape mode (the golden trajectories of the unmodified reference replayed through ONE launch), the opening reset folded
 into the launch, device-side auto-reset against `step(); reset_batches(finished)` of the oracle, and `reset_finished(mask)` against the
 reference's partial-reset recordings."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -512,3 +514,43 @@ def test_exclusive_device_is_refused_when_the_launch_would_not_fit(oracle, monke
     compare_snapshots(hip_snapshot(env), oracle_snapshot(o), 'refused: one launch per step')
     monkeypatch.setenv('FRZ_ASSUME_COMPUTE_UNITS', '64')
     assert env.set_exclusive_device(True) is True and env._lib.frz_wildfire_rollout_launches(env._handle, 10, _capi.FRZ_RNG_PHILOX) == 1
+
+
+@pytest.mark.gpu
+def test_rideshare_rollout_equals_the_step_loop():
+    """frz_rideshare_rollout (one launch sequence per step): an action tape, then the in-launch policy with the reset folded in, against the
+    same steps taken one `step()` at a time; every record (rewards, flags, actions, the packed-list block) is compared."""
+    from free_range_zoo_amd.envs import rideshare_v0
+    B, steps = 900, 9
+    build = lambda: configs.rideshare_busy(A=4, steps=20, per_step=2, seed=4)
+    make = lambda: rideshare_v0.parallel_env(configuration=build(), parallel_envs=B, max_steps=12, device=torch.device('cuda'))
+    loop, roll = make(), make()
+    for env in (loop, roll):
+        env.reset(seed=torch.arange(B, dtype=torch.int32))
+    rewards, dones, actions, lists = [], [], [], []
+    block, nbytes = ctypes.c_void_p(), ctypes.c_int64()
+    _capi.check(loop._lib.frz_rideshare_list_block(loop._handle, ctypes.byref(block), ctypes.byref(nbytes)), 'list_block')
+    offset = block.value - loop._arena.data_ptr()
+    for t in range(steps):
+        loop.step_random_policy(policy_seed=21, policy_step=t)
+        rewards.append(loop._rewards.clone()), actions.append(loop._actions.clone())
+        dones.append(torch.stack([loop._terminations[0], loop._truncations[0]]).to(torch.uint8))
+        lists.append(loop._arena[offset:offset + nbytes.value].clone())
+    tape = torch.stack(actions).contiguous()
+    out = roll.rollout(steps, actions=tape, record=True)
+    assert torch.equal(out['rewards'], torch.stack(rewards)) and torch.equal(out['dones'], torch.stack(dones))
+    assert out['list_block_offset'] == offset
+    for t in range(steps - 1):
+        assert torch.equal(out['lists'][t], lists[t]), f'lists after step {t}'
+    assert torch.equal(roll._arena[offset:offset + nbytes.value], lists[-1])
+    assert torch.equal(roll._passengers, loop._passengers) and torch.equal(roll._agents, loop._agents)
+    # the in-launch policy with the reset folded in = reset + the same policy steps
+    loop.reset(seed=torch.arange(B, dtype=torch.int32))
+    for t in range(steps):
+        loop.step_random_policy(policy_seed=21, policy_step=t)
+    out = roll.rollout(steps, policy_seed=21, first_step=0, reset_first=True, record=True)
+    assert torch.equal(out['actions'], tape) and torch.equal(out['rewards'], torch.stack(rewards))
+    assert torch.equal(roll._passengers, loop._passengers) and torch.equal(roll._rewards, loop._rewards)
+    roll.check()
+    with pytest.raises(Exception):
+        roll.rollout(2, auto_reset=True)  # no partial reset in this domain (rideshare.py:246)
