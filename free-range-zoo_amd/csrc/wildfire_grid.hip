@@ -1,19 +1,21 @@
-// wildfire_grid.hip — the wildfire step for grids above 16 cells: one environment per WAVEFRONT, the grid's cells across its lanes.
+// wildfire_grid.hip — the wildfire step for grids above 16 cells: the grid's cells across the lanes of a wavefront.
 //
 // The reference's fire spread is a conv2d over any H x W (transitions/fire_spreads.py:32-59) and its open task / action sets are
-// `nonzero()` lists over the whole grid (wildfire.py:586-717).  Here lane l of the env's wavefront holds cells l, l + 64, l + 128, ...
+// `nonzero()` lists over the whole grid (wildfire.py:586-717).  Here lane l of an env's FIELD wavefront holds cells l, l + 64, l + 128, ...
 // (row-major cell index c = y * W + x; CPL = cells per lane, up to 16: 32 x 32 grids), so
 //   * the cell arrays are env-major [B][H*W] (the reference's own layout): a row of 64 cells is one coalesced access;
-//   * the 4-neighbour stencil reads the lit map the wavefront has just parked in LDS (N, W, E, S in the reference's accumulation order);
+//   * the lit map is CPL wave-uniform mask words: the 4-neighbour stencil is that map shifted by a row / a column (scalar shifts), the
+//     shifted word being the lane predicate of the add (N, W, E, S in the reference's accumulation order);
 //   * "the lit fires in row-major order" is a ballot per 64-cell chunk: a fire's task index = lit bits below it (lane rank) + the
-//     chunks before; an agent's attackable set = lit mask & its precomputed range mask (per equipment state), kept as mask words in
-//     that agent's lane, so the index-th listed task is a population-count descent and the per-agent counts are popcounts;
-//   * agents (lanes 0..A-1) hand their fire-fighting power to the cells through an LDS array, added in agent order.
-// One ParallelEnv.step() = three stream-ordered launches, as for rideshare: wg_env_kernel (decode, optionally the uniform random policy,
-// the 7 transitions, rewards / termination / bookkeeping, agent observations, per-env counts), wg_offsets_kernel (launch-wide prefix
-// sums -> jagged offsets + the batch totals the next step reads), wg_emit_kernel (task rows, observation map, per-agent action / bad lists).
-// Same results as the env-per-lane kernels of wildfire.hip (the parity tests run both on shapes both accept).  No MFMA: HBM-bound
-// integer / float32 elementwise work.
+//     chunks before; an agent's attackable set = lit mask & its precomputed range mask (per equipment state), so the index-th listed
+//     task is a population-count descent and the per-agent counts are popcounts;
+//   * the agents of a workgroup's four envs live in the lanes of ONE of its wavefronts (the CREW: lane 16 e + a) and hand their
+//     fire-fighting power to the fields through an LDS array, added in agent order.
+// One ParallelEnv.step() = two stream-ordered launches: wg_env_kernel (decode, optionally the uniform random policy, the 7 transitions,
+// rewards / termination / bookkeeping, agent observations, per-env counts and the mask words the lists are made from) and wg_lists_kernel
+// (launch-wide prefix sums -> jagged offsets + the batch totals the next step reads, then task rows, observation map and per-agent
+// action / bad lists, one output entry per lane).  Same results as the env-per-lane kernels of wildfire.hip (the parity tests run both on
+// shapes both accept).  No MFMA: integer / float32 elementwise work bound by instruction issue and HBM.
 #include "frz_scan.h"
 #include "frz_wave.h"
 
