@@ -41,7 +41,7 @@ def test_golden_trajectories_through_the_grid_kernels(name, monkeypatch):
     env.check()
 
 
-SHAPES = [(5, 5, 3), (7, 9, 5), (8, 8, 12), (16, 16, 6), (20, 13, 16), (32, 32, 12)]
+SHAPES = [(5, 5, 3), (7, 9, 5), (8, 8, 12), (15, 15, 4), (16, 16, 6), (20, 13, 16), (32, 32, 12)]  # (15 x 15: four cells per lane with 16-bit scan counts)
 
 
 @pytest.mark.parametrize('shape', SHAPES, ids=lambda s: 'x'.join(map(str, s)))
