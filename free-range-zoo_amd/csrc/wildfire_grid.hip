@@ -29,8 +29,6 @@ namespace frz_wf {
 
 namespace {
 
-using frz::for_each_index;
-using frz::from_lane;
 using frz::lane_rank;
 using frz::popc_words;
 using frz::read_lane;
