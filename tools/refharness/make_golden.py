@@ -266,8 +266,39 @@ def wildfire_variants():
         cfg.stochastic_config = replace(cfg.stochastic_config, fire_fuel=False, special_burnout_probability=False)
         return cfg
 
+    def grid(H, Wd, A, seed=11):
+        """tests/configs.py:wildfire_grid built with the reference's classes: a fully stochastic H x Wd grid with A agents — the shapes the
+        cells-across-lanes kernels serve (8 x 8: one cell per lane, 16 x 16: four), recorded from the reference itself."""
+        g = torch.Generator().manual_seed(seed)
+        types = torch.randint(0, 4, (H, Wd), generator=g, dtype=torch.int32)
+        lit = (torch.rand((H, Wd), generator=g) < 0.4) & (types > 0)
+        fire = C.FireConfiguration(
+            fire_types=types, num_fire_states=5, lit=lit, intensity_increase_probability=0.6, intensity_decrease_probability=0.7,
+            extra_power_decrease_bonus=0.1, burnout_probability=0.4, base_spread_rate=30.0, max_spread_rate=67.0,
+            random_ignition_probability=0.01, cell_size=200.0, wind_direction=0.7,
+            ignition_temp=torch.randint(1, 3, (H, Wd), generator=g, dtype=torch.int32), initial_fuel=2)
+        agents = torch.stack([torch.randint(0, H, (A, ), generator=g), torch.randint(0, Wd, (A, ), generator=g)], dim=1).to(torch.int32)
+        agent = C.AgentConfiguration(
+            agents=agents, fire_reduction_power=torch.rand((A, ), generator=g) + 0.5,
+            attack_range=torch.randint(1, 3, (A, ), generator=g, dtype=torch.int32), suppressant_states=4, initial_suppressant=2,
+            suppressant_decrease_probability=0.7, suppressant_refill_probability=0.6, initial_equipment_state=1,
+            equipment_states=torch.tensor([[-1.0, -0.5, -1.0], [0.0, 0.0, 0.0], [1.0, 0.25, 1.0]], dtype=torch.float32),
+            repair_probability=0.5, degrade_probability=0.2, critical_error_probability=0.05, initial_capacity=2,
+            tank_switch_probability=0.5, possible_capacities=torch.tensor([1, 2, 3], dtype=torch.float32),
+            capacity_probabilities=torch.tensor([0.3, 0.4, 0.3], dtype=torch.float32))
+        reward = C.RewardConfiguration(fire_rewards=torch.rand((H, Wd), generator=g) * 30 + 5, bad_attack_penalty=-2.0, burnout_penalty=-1.5,
+                                       burnout_penalty_scaled=False, termination_reward=10.0, termination_kappa=2.0, localize_putouts=False)
+        stoch = C.StochasticConfiguration(special_burnout_probability=True, suppressant_refill=True, suppressant_decrease=True,
+                                          tank_switch=True, critical_error=True, degrade=True, repair=True, fire_increase=True,
+                                          fire_decrease=True, fire_spread=True, realistic_fire_spread=True, random_fire_ignition=True,
+                                          fire_fuel=False)
+        return C.WildfireConfiguration(grid_width=Wd, grid_height=H, fire_config=fire, agent_config=agent, reward_config=reward,
+                                       stochastic_config=stoch)
+
     return [
         # name, configuration, env kwargs, B, max_steps, steps, seed
+        ('grid8x8_12agents', grid(8, 8, 12), dict(observe_other_suppressant=True), 6, 24, 26, 19),
+        ('grid16x16_6agents', grid(16, 16, 6), dict(show_bad_actions=True, observe_other_power=True), 5, 16, 16, 20),
         ('cfg1_nonstochastic', wildfire_configs.non_stochastic(), {}, 4, 15, 18, 11),
         ('cfg2_openness', openness(), {}, 16, 50, 52, 12),
         ('aaai_ol3_2agents', aaai_2025_ol_config(3), {}, 8, 30, 30, 13),
