@@ -416,7 +416,9 @@ __global__ void __launch_bounds__(kBlock) rs_env_kernel(char* __restrict__ arena
                 my = has_vec ? by : 0;
                 mx = has_vec ? bx : 0;
                 const float fy = (float)my, fx = (float)mx;
-                cost = (flags & kDiagonal) ? __fsqrt_rn(__fadd_rn(__fmul_rn(fy, fy), __fmul_rn(fx, fx))) : __fadd_rn(fabsf(fy), fabsf(fx));
+                // sqrtf, not __fsqrt_rn: the intrinsic is the bare v_sqrt_f32 (1 ulp) on this target, sqrtf the correctly rounded sequence the
+                // reference's CPU norm gives (a fast-travel diagonal move such as (5, 9) differed in the last bit: found by tests/test_hip_fuzz.py)
+                cost = (flags & kDiagonal) ? sqrtf(__fadd_rn(__fmul_rn(fy, fy), __fmul_rn(fx, fx))) : __fadd_rn(fabsf(fy), fabsf(fx));
                 ay += my;
                 ax += mx;
             }

@@ -40,8 +40,8 @@ __device__ __forceinline__ float row_key(const Row& r, int my_y, int my_x, bool 
     if constexpr (greedy) {
         const float ty = (float)(r.lo.z - r.lo.x), tx = (float)(r.lo.w - r.lo.y);
         const float my = (float)(r.lo.x - my_y), mx = (float)(r.lo.y - my_x);
-        const float trip = DIAGONAL ? __fsqrt_rn(ty * ty + tx * tx) : fabsf(ty) + fabsf(tx);
-        const float mine = DIAGONAL ? __fsqrt_rn(my * my + mx * mx) : fabsf(my) + fabsf(mx);
+        const float trip = DIAGONAL ? sqrtf(ty * ty + tx * tx) : fabsf(ty) + fabsf(tx);
+        const float mine = DIAGONAL ? sqrtf(my * my + mx * mx) : fabsf(my) + fabsf(mx);
         key = trip + mine;
     } else {
         key = (float)r.hi.w;
