@@ -1,4 +1,4 @@
-"""GPU: randomised shapes against the CPU oracle.  The wildfire grid family (cells across lanes, crew + fields, lists an entry per lane) and the
+"""GPU: randomised shapes against the CPU oracle (all three domains, every wildfire kernel family).  The wildfire grid family (cells across lanes, crew + fields, lists an entry per lane) and the
 rideshare env launch (crew + fields) are driven over grids, agent counts, batch sizes, flags and RNG modes drawn from a seeded generator —
 1 x n and n x 1 grids, widths up to 32 (the stencil's word shifts), one agent, ragged workgroups, more than 64 passenger slots.
 FRZ_FUZZ_CASES scales the number of cases (default: a few seconds' worth per domain)."""
@@ -74,3 +74,51 @@ def test_rideshare_on_random_configurations(oracle, index):
     from test_hip_rideshare import run_against_oracle
     case = rideshare_case(index)
     run_against_oracle(oracle, lambda: build_rideshare(case), case['B'], case['steps'] + 2, case['steps'] + 4, seed=case['seed'], contest=case['contest'])
+
+
+def small_wildfire_case(index):
+    g = np.random.default_rng(9000 + index)
+    H, Wd = int(g.integers(1, 7)), int(g.integers(1, 7))
+    while H * Wd < 2 or H * Wd > 24:
+        H, Wd = int(g.integers(1, 7)), int(g.integers(1, 7))
+    A = int(g.integers(1, 9))
+    flags = {}
+    if g.random() < 0.4:
+        flags['show_bad_actions'] = True
+    if g.random() < 0.5:
+        flags['observe_other_suppressant'] = True
+    if g.random() < 0.3:
+        flags['observe_other_power'] = True
+    rng = ['injected', 'philox', 'mt19937'][int(g.integers(0, 3))]
+    return dict(H=H, Wd=Wd, A=A, flags=flags, rich=bool(g.random() < 0.4), rng=rng, B=int(g.choice([1, 2, 63, 255, 256, 257, 600, 1500])), seed=int(g.integers(0, 1000)),
+                policy='device' if rng == 'philox' and g.random() < 0.5 else 'oracle', kernel=['', 'lane', 'grid'][int(g.integers(0, 3))])
+
+
+@pytest.mark.parametrize('index', range(CASES))
+def test_small_wildfire_grids_in_whatever_family_serves_them(oracle, index, monkeypatch):
+    """Grids of at most 24 cells / 8 agents: the field / crew kernels of the exact shapes, the lane-per-env kernels, or the grid family
+    (FRZ_WF_KERNEL picks among those that accept the shape)."""
+    from test_hip_wildfire import run_against_oracle
+    case = small_wildfire_case(index)
+    if case['kernel']:
+        monkeypatch.setenv('FRZ_WF_KERNEL', case['kernel'])
+    run_against_oracle(oracle, lambda: build_wildfire(case), case['flags'], case['B'], 9, 11, seed=case['seed'], rng=case['rng'], policy=case['policy'])
+
+
+def cyber_case(index):
+    g = np.random.default_rng(13000 + index)
+    N, Att, D = int(g.integers(1, 17)), int(g.integers(1, 9)), int(g.integers(1, 9))
+    flags = dict(observe_other_location=bool(g.random() < 0.5), observe_other_presence=bool(g.random() < 0.5), observe_other_power=bool(g.random() < 0.5),
+                 partially_observable=bool(g.random() < 0.5), show_bad_actions=bool(g.random() < 0.5))
+    return dict(N=N, Att=Att, D=D, flags=flags, rng=['injected', 'philox', 'mt19937'][int(g.integers(0, 3))], B=int(g.choice([1, 2, 63, 255, 256, 257, 900])),
+                seed=int(g.integers(0, 1000)), kernel=['', 'lane'][int(g.integers(0, 2))])
+
+
+@pytest.mark.parametrize('index', range(CASES))
+def test_cybersecurity_on_random_networks(oracle, index, monkeypatch):
+    from test_hip_cybersecurity import run_against_oracle
+    case = cyber_case(index)
+    if case['kernel']:
+        monkeypatch.setenv('FRZ_CY_KERNEL', case['kernel'])
+    run_against_oracle(oracle, lambda: configs.cyber_grid(case['N'], case['Att'], case['D'], seed=case['seed']), case['flags'], case['B'], 8, 10, seed=case['seed'],
+                       rng=case['rng'])
