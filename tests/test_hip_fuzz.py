@@ -122,3 +122,29 @@ def test_cybersecurity_on_random_networks(oracle, index, monkeypatch):
         monkeypatch.setenv('FRZ_CY_KERNEL', case['kernel'])
     run_against_oracle(oracle, lambda: configs.cyber_grid(case['N'], case['Att'], case['D'], seed=case['seed']), case['flags'], case['B'], 8, 10, seed=case['seed'],
                        rng=case['rng'])
+
+
+def rollout_case(index):
+    g = np.random.default_rng(17000 + index)
+    H, Wd = int(g.integers(1, 5)), int(g.integers(1, 5))
+    while H * Wd < 2:
+        H, Wd = int(g.integers(1, 5)), int(g.integers(1, 5))
+    A = int(g.integers(1, 5))
+    kwargs = {}
+    if g.random() < 0.4:
+        kwargs['show_bad_actions'] = True
+    if g.random() < 0.5:
+        kwargs['observe_other_suppressant'] = True
+    seed = int(g.integers(0, 1000))
+    max_steps = int(g.integers(3, 14))
+    return dict(build=lambda: configs.wildfire_grid(H, Wd, A, seed=seed), B=int(g.choice([1, 2, 255, 256, 257, 1025, 2500])), max_steps=max_steps,
+                steps=int(g.integers(2, max_steps + 4)), kwargs=kwargs, shape=(H, Wd, A)), [None, False][int(g.integers(0, 2))]
+
+
+@pytest.mark.parametrize('index', range(CASES))
+def test_policy_rollouts_with_every_record_on_random_small_shapes(oracle, index):
+    """`env.rollout(n, record=True)` — one multi-step launch where the library has one for the shape, per-step launches otherwise or when
+    the device is not declared exclusive — against the oracle at every step (sampled actions, rewards, flags, the packed lists)."""
+    from test_hip_rollouts import check_policy_rollout_against_the_oracle
+    case, one_launch = rollout_case(index)
+    check_policy_rollout_against_the_oracle(oracle, case, one_launch)

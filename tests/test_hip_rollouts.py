@@ -83,14 +83,21 @@ ORACLE_CASES = [
 def test_multi_step_launch_against_the_oracle(oracle, case):
     """rollout(n) as ONE launch (frz_wildfire_rollout_launches == 1) vs n oracle steps: the sampled actions, rewards, terminations /
     truncations and every packed list OF EVERY STEP (tapes + list record), then the whole final state."""
+    check_policy_rollout_against_the_oracle(oracle, case, one_launch=True)
+
+
+def check_policy_rollout_against_the_oracle(oracle, case, one_launch):
+    """(also driven by tests/test_hip_fuzz.py over random shapes; one_launch=None: whatever the library decides for the shape)"""
     from free_range_zoo_amd.envs.wildfire.env.structures.configuration import to_cstruct
     B, steps, kwargs = case['B'], case['steps'], case['kwargs']
     flags = dict(show_bad_actions=False, observe_other_power=False, observe_other_suppressant=False)
     flags.update(kwargs)
     cfg = to_cstruct(case['build'](), B, case['max_steps'], **flags)
     env = make_env(case['build'], B, case['max_steps'], rng='philox', **kwargs)
-    env.set_exclusive_device(True)
-    assert env._lib.frz_wildfire_rollout_launches(env._handle, steps, _capi.FRZ_RNG_PHILOX) == 1
+    if one_launch is not False:
+        env.set_exclusive_device(True)
+    if one_launch:
+        assert env._lib.frz_wildfire_rollout_launches(env._handle, steps, _capi.FRZ_RNG_PHILOX) == 1
     seeds = (torch.arange(B, dtype=torch.int32) * 3 + 11)
     env.reset(seed=seeds)
     rec = env.rollout(steps, policy_seed=77, first_step=0, record=True)
@@ -114,7 +121,7 @@ def test_multi_step_launch_against_the_oracle(oracle, case):
         G.assert_same(dones[t, 1].astype(bool), o.truncations[0].astype(bool), f'step {t} truncations')
         if t < steps - 1 and not bool(o.terminations[0].all() or o.truncations[0].all()):
             compare_lists(list_views(env, lists[t]), oracle_lists(o, env.show_bad_actions), f'step {t} (list record)')
-    assert executed == min(steps, case['max_steps'])
+    assert executed == min(steps, case['max_steps']) or (one_launch is not True and bool(o.terminations[0].all() or o.truncations[0].all()))  # (every env of a small random batch may burn out early)
     if executed < steps:  # the frozen steps that follow scale the stale rewards once (utils/conversions.py:87-90)
         acts = np.zeros((cfg.num_agents, B, 2), np.int32)
         o.step(acts, np.zeros((3, B, cfg.grid_height * cfg.grid_width), np.float32), np.zeros((5, B, cfg.num_agents), np.float32))
