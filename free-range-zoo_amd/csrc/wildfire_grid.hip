@@ -747,7 +747,6 @@ __global__ void __launch_bounds__(64 * (CPL >= 8 ? 4 : 16)) wg_lists_kernel(char
     constexpr int kListWaves = CPL >= 8 ? 4 : 16, kListParts = kListWaves / frz::kWaves;
     constexpr int kChannels = AMAX + 1;
     constexpr int kItems = (AMAX + 2 + kListParts - 1) / kListParts;  // items per wavefront
-    constexpr bool kEager = CPL <= 4 && kListParts > 1;                // every item's mask words loaded before the scan
     __shared__ frz::ScanShared<kChannels, BITS> s_scan;
     __shared__ int s_ticket;
     __shared__ uint32_t s_first[kChannels][kBlock + 1];  // exclusive prefix of channel ch at the chunk's env e; [kBlock]: at the chunk's end
@@ -770,17 +769,9 @@ __global__ void __launch_bounds__(64 * (CPL >= 8 ? 4 : 16)) wg_lists_kernel(char
     // ---------------------------------------------------------------- loads of the list phase, in flight while the scan runs
     const uint64_t* const litmap = reinterpret_cast<const uint64_t*>(arena + d.off_litmap);
     const uint64_t* const okmap = reinterpret_cast<const uint64_t*>(arena + d.off_okmap);
-    uint64_t lit[CPL], ok[kEager ? kItems : 1][CPL];
+    uint64_t lit[CPL];
 #pragma unroll
     for (int k = 0; k < CPL; ++k) lit[k] = active ? litmap[(int64_t)k * B + bl] : 0ull;
-    if (kEager) {
-#pragma unroll
-        for (int j = 0; j < kItems; ++j) {
-            const int item = part + kListParts * j, a = item >= 2 && item < A + 2 ? item - 2 : 0;
-#pragma unroll
-            for (int k = 0; k < CPL; ++k) ok[j][k] = active ? okmap[((int64_t)a * CPL + k) * B + bl] : 0ull;
-        }
-    }
     ListShared<CPL>& sh = s_list[wave];
     {
         int before = 0;
@@ -841,8 +832,6 @@ __global__ void __launch_bounds__(64 * (CPL >= 8 ? 4 : 16)) wg_lists_kernel(char
     // sparse step has one tile per list and the items spread over the parts as (m mod parts); in the first steps of an episode on a
     // large grid a list has tens of tiles and the parts share them (one wavefront writing all the task rows held the launch up).
     const int ends = group * 64 + 64;  // the chunk's env behind this wavefront's last one
-    constexpr int kUnrollItems = kEager ? kItems : 1;  // (the eager mask words are a register array indexed by j)
-#pragma unroll kUnrollItems
     for (int j = 0; j < kItems; ++j) {
         for (int q = 0; q < kListParts; ++q) {
             const int item = q + kListParts * j;
@@ -875,14 +864,11 @@ __global__ void __launch_bounds__(64 * (CPL >= 8 ? 4 : 16)) wg_lists_kernel(char
             const int a = item - 2;
             const int ok_total = (int)(s_first[a + 1][ends] - s_first[a + 1][group * 64]), bad_total = show_bad ? task_total - ok_total : 0;
             if (64 * tile0 >= ok_total && 64 * tile0 >= bad_total) continue;
+            // (the mask words are loaded here, per item: holding every item's words from before the scan cost registers the 1024-thread
+            // workgroup does not have — it spilled — and the launch was 3 us slower for it)
             uint64_t mine[CPL];
 #pragma unroll
-            for (int k = 0; k < CPL; ++k) {
-                if (kEager && q == part)
-                    mine[k] = ok[kEager ? j : 0][k];
-                else
-                    mine[k] = active ? okmap[((int64_t)a * CPL + k) * B + bl] : 0ull;
-            }
+            for (int k = 0; k < CPL; ++k) mine[k] = active ? okmap[((int64_t)a * CPL + k) * B + bl] : 0ull;
             const int64_t first = s_first[a + 1][el];
             int64_t* const act_values = reinterpret_cast<int64_t*>(arena + d.off_act_values) + (int64_t)a * cap;
             if (64 * tile0 < ok_total)
@@ -931,13 +917,17 @@ int launch_cpl(const WgDev& dev, char* arena, const WfArgs& args, int rng, int m
                 hipLaunchKernelGGL(kernel, lanes, list_block, 0, stream, arena, dev, tk);
         };
         constexpr int BITS = CPL <= 2 ? 16 : 32;  // the scan packs 16-bit counts while an env has at most 255 cells
+        // (AMAX 12: with the 17 scan channels of AMAX 16 the scan's registers do not fit the 128 a 1024-thread workgroup leaves a
+        // wavefront, and the kernel spills)
         if (CPL == 4 && dev.HW < 256) {
             if (dev.A <= 4) lists(wg_lists_kernel<4, CPL, 16>);
             else if (dev.A <= 8) lists(wg_lists_kernel<8, CPL, 16>);
+            else if (dev.A <= 12) lists(wg_lists_kernel<12, CPL, 16>);
             else lists(wg_lists_kernel<16, CPL, 16>);
         } else {
             if (dev.A <= 4) lists(wg_lists_kernel<4, CPL, BITS>);
             else if (dev.A <= 8) lists(wg_lists_kernel<8, CPL, BITS>);
+            else if (dev.A <= 12) lists(wg_lists_kernel<12, CPL, BITS>);
             else lists(wg_lists_kernel<16, CPL, BITS>);
         }
     }
