@@ -93,7 +93,11 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
     __shared__ uint64_t x_excl[PW][kBlock];  // crew -> both: packed per-env counts of the preceding envs of the same wavefront
     __shared__ pack_t x_ok[kBlock];          // crew -> both: attackable cells of agent a in field a (MB bits each, AMAX * MB <= 64)
     __shared__ float x_supp[AMAX][kBlock];   // crew -> field: suppressant after the agent transitions (agent observations)
-    __shared__ float x_draw[(kPhilox || kMt) ? 5 * AMAX : 1][kBlock];  // field -> crew: the step's agent draws (in-kernel RNG)
+    // field -> crew: the step's agent draws (in-kernel RNG).  Two copies in a multi-step Philox launch: the field parks the NEXT step's
+    // draws in copy (t + 1) & 1 as soon as it has made them, instead of holding 5 * AMAX registers across its list phase and the loop's
+    // back edge (they were spilled)
+    constexpr int kDrawCopies = (RNG == FRZ_RNG_PHILOX && PERSIST) ? 2 : 1;
+    __shared__ float x_draw[kDrawCopies][(kPhilox || kMt) ? 5 * AMAX : 1][kBlock];
     // FRZ_ROLLOUT_AUTO_RESET: returns of the episodes that ended inside this launch (float64, per env slot: deterministic) and their number
     __shared__ double x_return[EXTRA ? AMAX : 1][EXTRA ? kBlock : 1];
     __shared__ uint32_t x_ended[EXTRA ? kBlock : 1];
@@ -542,7 +546,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
             };
             // multi-step launches: the NEXT step's draws (a function of the env seed and the step number only), made while this role
             // waits for the crew's hand-off — between barriers 3 and 4 it has nothing else to do for about as long as the draws take
-            float next_field[kPhilox && PERSIST ? 3 : 1][kPhilox && PERSIST ? CMAX : 1], next_agent[kPhilox && PERSIST ? 5 * AMAX : 1];
+            float next_field[kPhilox && PERSIST ? 3 : 1][kPhilox && PERSIST ? CMAX : 1];
             // phase 6 as a function of (lit cells, copy of the packed lists): a multi-step launch that ends early writes its last lists twice
             auto emit_field = [&](mask_t lit1, int64_t copy, int64_t ocopy) {
                 if (active) {
@@ -607,13 +611,11 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                             for (int e = 0; e < 3; ++e)
 #pragma unroll
                                 for (int c = 0; c < CMAX; ++c) r_field[e][c] = next_field[e][c];
-#pragma unroll
-                            for (int i = 0; i < 5 * AMAX; ++i) x_draw[i][slot] = next_agent[i];
                         } else {
                             float agent_draws[5 * AMAX];
                             philox_draws(fld.nm, flags, r_field, agent_draws);
 #pragma unroll
-                            for (int i = 0; i < 5 * AMAX; ++i) x_draw[i][slot] = agent_draws[i];
+                            for (int i = 0; i < 5 * AMAX; ++i) x_draw[0][i][slot] = agent_draws[i];  // (t == 0: copy 0)
                         }
                     } else if constexpr (kMt) {
                         // FRZ_RNG_MT19937: the env's own MT19937 stream (mt19937.hip: state word j of env b at [j][b], twisted
@@ -656,7 +658,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
 #pragma unroll
                             for (int c = 0; c < CMAX; ++c) r_field[e][c] = uni[e * CMAX + c];
 #pragma unroll
-                        for (int i = 0; i < 5 * AMAX; ++i) x_draw[i][slot] = uni[3 * CMAX + i];
+                        for (int i = 0; i < 5 * AMAX; ++i) x_draw[0][i][slot] = uni[3 * CMAX + i];
                     }
                 }
                 if (MODE == kStep) {
@@ -858,7 +860,12 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
 
                 // ---- phase 4 belongs to the crew (hand-off)
                 if constexpr (kPhilox && PERSIST) {
-                    if (t + 1 < n_steps) philox_draws(fld.nm + 1, flags, next_field, next_agent);
+                    if (t + 1 < n_steps) {
+                        float next_agent[5 * AMAX];
+                        philox_draws(fld.nm + 1, flags, next_field, next_agent);
+#pragma unroll
+                        for (int i = 0; i < 5 * AMAX; ++i) x_draw[(t + 1) & (kDrawCopies - 1)][i][slot] = next_agent[i];
+                    }
                 }
                 FRZ_RSTAMP(8);
                 __syncthreads();  // (4)
@@ -1063,7 +1070,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
 #pragma unroll
                         for (int e = 0; e < 5; ++e)
 #pragma unroll
-                            for (int a = 0; a < AMAX; ++a) r_agent[e][a] = x_draw[e * AMAX + a][slot];  // drawn by the field role
+                            for (int a = 0; a < AMAX; ++a) r_agent[e][a] = x_draw[t & (kDrawCopies - 1)][e * AMAX + a][slot];  // drawn by the field role
                     }
 #pragma unroll
                     for (int a = 0; a < AMAX; ++a) {
