@@ -247,6 +247,13 @@ def rideshare_small(diagonal: bool, fast: bool) -> R.RideshareConfiguration:
     return cfg
 
 
+def rideshare_fast_diagonal() -> R.RideshareConfiguration:
+    """Fast travel and diagonal moves together (tools/refharness/make_golden.py:fast_diagonal): move costs are square roots of arbitrary sums."""
+    cfg = rideshare_busy(A=4, steps=14, per_step=2, grid=12, seed=5, env_specific=1, B=8)
+    cfg.agent_config = replace(cfg.agent_config, use_diagonal_travel=True, use_fast_travel=True, pool_limit=2)
+    return cfg
+
+
 RIDESHARE_GOLDEN = {
     'nonstochastic': rideshare_non_stochastic,
     'cfg3_busy': rideshare_busy,
@@ -254,4 +261,5 @@ RIDESHARE_GOLDEN = {
                                                  wait_limit=torch.tensor([2, 3, 4]), long_wait_time=6),
     'small_diagonal': lambda: rideshare_small(True, False),
     'small_fast_travel': lambda: rideshare_small(False, True),
+    'fast_diagonal': lambda: rideshare_fast_diagonal(),
 }

@@ -559,6 +559,14 @@ def rideshare_variants():
         cfg.agent_config = replace(cfg.agent_config, use_diagonal_travel=diagonal, use_fast_travel=fast, pool_limit=1)
         return cfg
 
+    def fast_diagonal():
+        """Fast travel AND diagonal moves on a 12 x 12 grid with the variable move cost: an agent jumps to its goal in one move of any
+        (dy, dx), so the move cost is the square root of an arbitrary sum of squares (and is divided by the passengers on board + 1) —
+        the float path a unit-move trajectory never exercises (tests/test_hip_fuzz.py found a last-bit difference there)."""
+        cfg = busy(A=4, steps=14, per_step=2, grid=12, seed=5, env_specific=1, B=8)
+        cfg.agent_config = replace(cfg.agent_config, use_diagonal_travel=True, use_fast_travel=True, pool_limit=2)
+        return cfg
+
     return [
         ('nonstochastic', rideshare_configs.non_stochastic(), 4, 15, 18, 31),
         ('cfg3_busy', busy(), 12, 50, 52, 32),
@@ -566,6 +574,7 @@ def rideshare_variants():
                                     long_wait_time=6), 10, 30, 32, 33),
         ('small_diagonal', small_fast(True, False), 6, 20, 22, 34),
         ('small_fast_travel', small_fast(False, True), 6, None, 18, 35),
+        ('fast_diagonal', fast_diagonal(), 8, 16, 18, 36),
     ]
 
 
