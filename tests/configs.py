@@ -193,6 +193,7 @@ def cyber_grid(N: int, Att: int, D: int, seed: int = 13) -> C.CybersecurityConfi
 CYBER_DEFAULT_FLAGS = dict(observe_other_location=False, observe_other_presence=False, observe_other_power=True, partially_observable=True,
                            show_bad_actions=True)
 CYBER_GOLDEN = {
+    'grid8_4x4': (lambda: cyber_grid(8, 4, 4), dict(observe_other_presence=True)),
     'nonstochastic': (cyber_non_stochastic, {}),
     'cfg4_openness': (cyber_openness, {}),
     'openness_no_bad_actions': (cyber_openness, dict(show_bad_actions=False, observe_other_presence=True, observe_other_location=True)),

@@ -428,7 +428,25 @@ def cyber_variants():
         return C.CybersecurityConfiguration(attacker_config=att, defender_config=dfn, network_config=net, reward_config=rew,
                                             stochastic_config=C.StochasticConfiguration(network_state=True))
 
+    def grid(N, Att, D, seed=13):
+        """tests/configs.py:cyber_grid built with the reference's classes: N subnetworks, Att attackers, D defenders, stochastic — many
+        distinct (patches - attacks) sums, i.e. many arguments of the tanh the subnetwork transition compares its draw with."""
+        g = torch.Generator().manual_seed(seed)
+        adj = torch.rand((N, N), generator=g) < 0.5
+        adj = (adj | adj.T) & ~torch.eye(N, dtype=torch.bool)
+        att = C.AttackerConfiguration(initial_presence=torch.rand((Att, ), generator=g) < 0.6, threat=torch.rand((Att, ), generator=g) + 0.5,
+                                      persist_probs=torch.rand((Att, ), generator=g) * 0.3 + 0.65, return_probs=torch.rand((Att, ), generator=g) * 0.4 + 0.3)
+        dfn = C.DefenderConfiguration(initial_location=torch.randint(-1, N, (D, ), generator=g, dtype=torch.int32),
+                                      initial_presence=torch.rand((D, ), generator=g) < 0.7, mitigation=torch.rand((D, ), generator=g) + 0.5,
+                                      persist_probs=torch.rand((D, ), generator=g) * 0.3 + 0.65, return_probs=torch.rand((D, ), generator=g) * 0.4 + 0.3)
+        net = C.NetworkConfiguration(patched_states=1, vulnerable_states=2, exploited_states=2, temperature=2.3,
+                                     initial_state=torch.randint(0, 5, (N, ), generator=g, dtype=torch.int32), adj_matrix=adj)
+        rew = C.RewardConfiguration(bad_action_penalty=-5.0, patch_reward=-0.5, network_state_rewards=torch.tensor([3.0, 1.0, 0.0, -2.0, -5.0]))
+        return C.CybersecurityConfiguration(attacker_config=att, defender_config=dfn, network_config=net, reward_config=rew,
+                                            stochastic_config=C.StochasticConfiguration(network_state=True))
+
     return [
+        ('grid8_4x4', grid(8, 4, 4), dict(observe_other_presence=True), 24, 40, 40, 26),
         ('nonstochastic', cybersecurity_configs.non_stochastic(), {}, 4, 15, 18, 21),
         ('cfg4_openness', openness(), {}, 16, 50, 52, 22),
         ('openness_no_bad_actions', openness(), dict(show_bad_actions=False, observe_other_presence=True, observe_other_location=True), 8,
