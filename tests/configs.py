@@ -116,6 +116,7 @@ def wildfire_grid(H: int, Wd: int, A: int, seed: int = 11) -> W.WildfireConfigur
 WILDFIRE_GOLDEN = {
     'grid8x8_12agents': (lambda: wildfire_grid(8, 8, 12), dict(observe_other_suppressant=True)),
     'grid16x16_6agents': (lambda: wildfire_grid(16, 16, 6), dict(show_bad_actions=True, observe_other_power=True)),
+    'grid32x32_16agents': (lambda: wildfire_grid(32, 32, 16), dict(observe_other_power=True, observe_other_suppressant=True)),
     'cfg1_nonstochastic': (wildfire_non_stochastic, {}),
     'cfg2_openness': (wildfire_openness, {}),
     'aaai_ol3_2agents': (lambda: aaai_2025_ol_config(3), {}),

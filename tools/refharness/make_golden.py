@@ -299,6 +299,7 @@ def wildfire_variants():
         # name, configuration, env kwargs, B, max_steps, steps, seed
         ('grid8x8_12agents', grid(8, 8, 12), dict(observe_other_suppressant=True), 6, 24, 26, 19),
         ('grid16x16_6agents', grid(16, 16, 6), dict(show_bad_actions=True, observe_other_power=True), 5, 16, 16, 20),
+        ('grid32x32_16agents', grid(32, 32, 16), dict(observe_other_power=True, observe_other_suppressant=True), 3, 9, 10, 21),
         ('cfg1_nonstochastic', wildfire_configs.non_stochastic(), {}, 4, 15, 18, 11),
         ('cfg2_openness', openness(), {}, 16, 50, 52, 12),
         ('aaai_ol3_2agents', aaai_2025_ol_config(3), {}, 8, 30, 30, 13),
