@@ -248,8 +248,10 @@ def oracle_auto_reset_rollout(oracle, cfg, seeds, policy_seed, steps, stride, sh
 
 @pytest.mark.parametrize('exclusive', [True, False], ids=['one_launch', 'launch_per_step'])
 @pytest.mark.parametrize('case', [dict(B=65536, max_steps=50, steps=120, kwargs={}), dict(B=1500, max_steps=7, steps=40, kwargs={}),
-                                  dict(B=777, max_steps=9, steps=25, kwargs=dict(show_bad_actions=True))],
-                         ids=['cfg2_B65536', 'short_horizon_ragged', 'bad_actions'])
+                                  dict(B=777, max_steps=9, steps=25, kwargs=dict(show_bad_actions=True)),
+                                  dict(B=601, max_steps=6, steps=20, kwargs=dict(observe_other_suppressant=True), build=lambda: configs.wildfire_grid(8, 8, 5, seed=2)),
+                                  dict(B=515, max_steps=5, steps=16, kwargs=dict(show_bad_actions=True), build=configs.wildfire_rich_plain)],
+                         ids=['cfg2_B65536', 'short_horizon_ragged', 'bad_actions', 'grid_family_8x8', 'lane_family_4x5'])
 def test_auto_reset_against_the_oracle(oracle, case, exclusive):
     """Continuous rollouts at fixed B: an env that finishes at step t restarts inside step t with seed + stride.  Equals
     the oracle's `step(); reset_batches(finished, seed + stride)` loop: every step's actions, rewards, flags (as the step set them), the
@@ -260,10 +262,11 @@ def test_auto_reset_against_the_oracle(oracle, case, exclusive):
         steps = 60
     flags = dict(show_bad_actions=False, observe_other_power=False, observe_other_suppressant=False)
     flags.update(kwargs)
-    cfg = to_cstruct(configs.wildfire_openness(), B, case['max_steps'], track_cumulative_rewards=True, **flags)
-    env = make_env(configs.wildfire_openness, B, case['max_steps'], rng='philox', track_cumulative_rewards=True, **kwargs)
+    build = case.get('build', configs.wildfire_openness)  # (the other families have no multi-step kernel: one launch sequence per step)
+    cfg = to_cstruct(build(), B, case['max_steps'], track_cumulative_rewards=True, **flags)
+    env = make_env(build, B, case['max_steps'], rng='philox', track_cumulative_rewards=True, **kwargs)
     env.set_exclusive_device(exclusive)
-    assert env._lib.frz_wildfire_rollout_launches(env._handle, steps, _capi.FRZ_RNG_PHILOX) == (1 if exclusive else steps)
+    assert env._lib.frz_wildfire_rollout_launches(env._handle, steps, _capi.FRZ_RNG_PHILOX) == (1 if exclusive and 'build' not in case else steps)
     seeds = torch.arange(B, dtype=torch.int32) * 5 + 1
     env.reset(seed=seeds)
     metrics = torch.zeros(len(env.agents) + 2, dtype=torch.float64, device='cuda')
