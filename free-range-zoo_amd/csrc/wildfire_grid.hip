@@ -67,7 +67,8 @@ struct FieldSums {  // what an env's field leaves for the crew
     int n_put, n_burn, dead, pad_;
 };
 
-template <int CPL, int MODE, int RNG>
+// FULL: H * W == 64 * CPL (8 x 8, 16 x 16, 32 x 32 ...): every lane's every cell exists and the `inside` tests fold away.
+template <int CPL, int MODE, int RNG, bool FULL = false>
 __global__ void __launch_bounds__(kBlock) wg_env_kernel(char* __restrict__ arena, const WgDev d, const int32_t* __restrict__ actions,
                                                          const float* __restrict__ field_rand, const float* __restrict__ agent_rand, const WgPolicy pol) {
     constexpr int W2 = 2 * CPL;  // 32-bit words of a cell mask
@@ -127,7 +128,7 @@ __global__ void __launch_bounds__(kBlock) wg_env_kernel(char* __restrict__ arena
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
         const int c = lane + 64 * k;
-        inside[k] = c < HW;
+        inside[k] = FULL || c < HW;
         const uint32_t cc = (uint32_t)(inside[k] ? c : HW - 1);
         if (kStepping) ign[k] = frz::at32(cells.ignition, cc), fire_reward[k] = frz::at32(cells.fire_rewards, cc);  // with the first loads, not behind the tests that need them
         if (MODE == kReset) {  // wildfire.py:347-351: +type on the configured lit cells, -type elsewhere, ...
@@ -903,9 +904,15 @@ int launch_cpl(const WgDev& dev, char* arena, const WfArgs& args, int rng, int m
     } else if (mode == kRebuild) {
         go(wg_env_kernel<CPL, kRebuild, FRZ_RNG_INJECTED>);
     } else if (rng == FRZ_RNG_PHILOX) {
-        go(wg_env_kernel<CPL, kStep, FRZ_RNG_PHILOX>);
+        if (dev.HW == 64 * CPL)
+            go(wg_env_kernel<CPL, kStep, FRZ_RNG_PHILOX, true>);
+        else
+            go(wg_env_kernel<CPL, kStep, FRZ_RNG_PHILOX>);
     } else {
-        go(wg_env_kernel<CPL, kStep, FRZ_RNG_INJECTED>);
+        if (dev.HW == 64 * CPL)
+            go(wg_env_kernel<CPL, kStep, FRZ_RNG_INJECTED, true>);
+        else
+            go(wg_env_kernel<CPL, kStep, FRZ_RNG_INJECTED>);
     }
     {
         const uint32_t tk = ticketed ? 1u : 0u;
