@@ -229,6 +229,7 @@ __global__ void __launch_bounds__(kBlock) wg_env_kernel(char* __restrict__ arena
     const float* const tablef = reinterpret_cast<const float*>(s_table);
 
     float reward = 0.0f;
+    FieldSums sums{0.0f, 0.0f, 0, 0, 0, 0};  // field: what this step leaves for the crew
     int hit = -1, tcell = 0;
     bool good = false, refill = false;  // crew: the agent fights a listed task / refills
     float r_field[kStepping ? 3 : 1][CPL];
@@ -460,7 +461,7 @@ __global__ void __launch_bounds__(kBlock) wg_env_kernel(char* __restrict__ arena
                 }
             }
         }
-        if (lane == 0) s_sums[wave] = FieldSums{fire_reward_sum, burnout_total, n_put, n_burn, dead ? 1 : 0, 0};
+        sums = FieldSums{fire_reward_sum, burnout_total, n_put, n_burn, dead ? 1 : 0, 0};
     }
     if (MODE == kReset) {
 #pragma unroll
@@ -478,11 +479,15 @@ __global__ void __launch_bounds__(kBlock) wg_env_kernel(char* __restrict__ arena
         int before = 0;
 #pragma unroll
         for (int k = 0; k < CPL; ++k) {
-            if (lane == 0) litmap[(int64_t)k * B + b] = lit[k], s_lit[1][wave][k] = lit[k];
             if ((lit[k] >> lane) & 1ull) frz::at32(lit_cells, (uint32_t)(before + lane_rank(lit[k]))) = make_int2(f[k], in[k]);
             before += (int)__popcll(lit[k]);
         }
-        if (lane == 0) frz::at32(rows8, (uint32_t)d.q_etc * Bu + bu) = before;  // environment_task_count
+        if (lane == 0) {  // (one predicated region for everything lane 0 leaves: each costs three scalar instructions)
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) litmap[(int64_t)k * B + b] = lit[k], s_lit[1][wave][k] = lit[k];
+            frz::at32(rows8, (uint32_t)d.q_etc * Bu + bu) = before;  // environment_task_count
+            if (kStepping) s_sums[wave] = sums;
+        }
     }
     if (!kStepping && crew) {
         s_table[lane] = table_w0, s_table[lane + 64] = table_w1;
@@ -543,29 +548,29 @@ __global__ void __launch_bounds__(kBlock) wg_env_kernel(char* __restrict__ arena
             supp = s;
             eqs = e;
         }
-        const FieldSums sums = s_sums[ce < n_envs ? ce : 0];
-        const bool dead = sums.dead != 0;
+        const FieldSums fsum = s_sums[ce < n_envs ? ce : 0];
+        const bool dead = fsum.dead != 0;
         const bool newly = !term0 && dead;
         // correctly rounded float32 log via double (matches the oracle bit for bit; the reference's torch.log is a <=1-ulp float32 log)
         float log_burnouts = 0.0f;
         if (newly && d.termination_kappa != 0.0f) log_burnouts = (float)log((double)c_nb + 1.0);
         float term_reward = __fsub_rn(d.termination_reward, __fmul_rn(d.termination_kappa, log_burnouts));
         term_reward = term_reward < 0.0f ? 0.0f : term_reward;
-        float base_reward = sums.fire_reward_sum;
+        float base_reward = fsum.fire_reward_sum;
         if (flags & kLocalize) {  // only the put-outs this agent last hit (:546-553)
             const bool mine = hit >= 0 && s_put[ce][tcell] != 0;
             base_reward = mine ? frz::at32(cells.fire_rewards, (uint32_t)tcell) : 0.0f;
         }
-        reward = __fadd_rn(reward, __fadd_rn(base_reward, sums.burnout_total));
+        reward = __fadd_rn(reward, __fadd_rn(base_reward, fsum.burnout_total));
         reward = newly ? __fadd_rn(reward, term_reward) : reward;
         const int nm1 = c_nm + 1;
         trunc = (flags & kTruncate) ? nm1 >= d.max_steps : trunc0;
         term = term0 || dead;
         if (ca == 0 && ce < n_envs) {
             frz::at32(rows, (uint32_t)d.r_moves * Bu + cbu) = nm1;
-            frz::at32(rows, (uint32_t)d.r_burnouts * Bu + cbu) = c_nb + sums.n_burn;
-            frz::at32(rows8, (uint32_t)d.q_burnouts * Bu + cbu) = sums.n_burn;
-            frz::at32(rows8, (uint32_t)d.q_putouts * Bu + cbu) = sums.n_put;
+            frz::at32(rows, (uint32_t)d.r_burnouts * Bu + cbu) = c_nb + fsum.n_burn;
+            frz::at32(rows8, (uint32_t)d.q_burnouts * Bu + cbu) = fsum.n_burn;
+            frz::at32(rows8, (uint32_t)d.q_putouts * Bu + cbu) = fsum.n_put;
         }
     }
     if (MODE == kReset && ca == 0 && ce < n_envs) {
