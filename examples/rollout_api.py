@@ -1,0 +1,50 @@
+"""`env.rollout(...)`: n steps of the reference's rollout loop enqueued by one call through the C boundary (`frz_<domain>_rollout`,
+`frz_rollout_spec` in include/frz.h) — one multi-step launch where the library has one for the shape, otherwise one launch per step,
+with identical results.  Three uses on one MI355X:
+  1. continuous random-policy rollouts at a fixed batch (auto-reset: an env that finishes restarts inside the step) with episode metrics;
+  2. a recorded rollout (`record=True`: every step's rewards, flags and sampled actions) replayed from its action tape;
+  3. the same call for rideshare (one launch sequence per step)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+import time
+import torch
+import configs
+from free_range_zoo_amd.envs import rideshare_v0, wildfire_v0
+
+device = torch.device('cuda')
+B = 65536
+
+# 1. continuous rollouts: every env always mid-episode, returns of the episodes that ended accumulated on the device
+env = wildfire_v0.parallel_env(configuration=configs.wildfire_openness(), parallel_envs=B, max_steps=50, device=device, rng='philox')
+env.reset(seed=torch.arange(B, dtype=torch.int32))
+env.set_exclusive_device(True)  # nothing else on this GPU: a rollout of the small exact shapes is ONE launch
+metrics = torch.zeros(len(env.agents) + 2, dtype=torch.float64, device=device)
+env.rollout(200, policy_seed=1, auto_reset=True, seed_stride=1000003, metrics=metrics)  # warm
+metrics.zero_()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for block in range(10):
+    env.rollout(200, policy_seed=1, first_step=200 * (block + 1), auto_reset=True, seed_stride=1000003, metrics=metrics)
+torch.cuda.synchronize()
+wall = time.perf_counter() - t0
+returns, env_steps, episodes = metrics[:-2], float(metrics[-2]), float(metrics[-1])
+print(f'auto-reset rollouts: {env_steps / wall / 1e9:.2f} G env-steps/s, {episodes:.0f} episodes ended, mean return per agent '
+      f'{(returns / max(episodes, 1)).tolist()}')
+
+# 2. a recorded rollout and its replay from the action tape
+env.reset(seed=torch.arange(B, dtype=torch.int32))
+first = env.rollout(30, policy_seed=7, record=True)
+env.reset(seed=torch.arange(B, dtype=torch.int32))
+again = env.rollout(30, actions=first['actions'], record=True)
+assert torch.equal(first['rewards'], again['rewards']) and torch.equal(first['dones'], again['dones'])
+print(f"recorded rollout: rewards {tuple(first['rewards'].shape)}, dones {tuple(first['dones'].shape)}, actions {tuple(first['actions'].shape)}; "
+      f"the replay from the tape gives the same rewards and flags")
+env.check()
+
+# 3. rideshare: the same spec, one launch sequence per step
+ride = rideshare_v0.parallel_env(configuration=configs.rideshare_busy(), parallel_envs=4096, max_steps=32, device=device)
+ride.reset(seed=torch.arange(4096, dtype=torch.int32))
+out = ride.rollout(32, policy_seed=3, reset_first=True, record=True)
+print(f"rideshare rollout: summed reward {float(out['rewards'].sum()):.1f}, truncated at the end: {bool(out['dones'][-1, 1].all())}")
+ride.check()
