@@ -554,6 +554,7 @@ def main():
             'distributed': distributed,
             'agent_steps_per_s': value * A,
             'python_api_env_steps_per_s': api_value,
+            'python_api_runs_ms': [round(1e3 * t, 3) for t in api_times],  # (five runs of four episodes; the figure above is their median)
             'reference_loop_env_steps_per_s': reference_loop_value,
             'reference_loop': 'per agent env.action_space(agent).sample_nested(), env.step(dict), torch.all(env.finished) once per episode, reset per '
                               'episode; exact_shapes=True (the default); one step launch per step (samples drawn inside it)',
