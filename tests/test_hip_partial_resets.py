@@ -62,7 +62,7 @@ def _run(label, module_name, table, struct, random_names, sizes_of):
     env.check(), env2.check()
 
 
-@pytest.mark.parametrize('label', ['wildfire', 'wildfire_bad_actions'])
+@pytest.mark.parametrize('label', ['wildfire', 'wildfire_bad_actions', 'wildfire_grid8x8'])  # (the last one: the cells-across-lanes family)
 def test_wildfire_partial_resets_match_the_reference(label):
     _run(label, 'wildfire', configs.WILDFIRE_GOLDEN, _capi.frz_wildfire_cfg, ('field_randomness', 'agent_randomness'),
          lambda cfg, B, A: ((3, B, cfg.grid_height * cfg.grid_width), (5, B, A)))

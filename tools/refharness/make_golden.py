@@ -1073,6 +1073,9 @@ def record_partial_resets():
             ('wildfire_bad_actions', wildfire_v0, wf['openness_bad_actions'],
              dict(show_bad_actions=False, observe_other_power=False, observe_other_suppressant=False), wf_cstruct, wildfire_policy, wildfire_snapshot,
              ('field_randomness', 'agent_randomness')),
+            ('wildfire_grid8x8', wildfire_v0, wf['grid8x8_12agents'],
+             dict(show_bad_actions=False, observe_other_power=False, observe_other_suppressant=False), wf_cstruct, wildfire_policy, wildfire_snapshot,
+             ('field_randomness', 'agent_randomness')),
             ('cybersecurity', cybersecurity_v0, cy[sorted(cy)[0]],
              dict(observe_other_location=False, observe_other_presence=False, observe_other_power=True, partially_observable=True, show_bad_actions=True),
              cy_cstruct, cyber_policy, cyber_snapshot, ('network_randomness', 'agent_randomness'))]
