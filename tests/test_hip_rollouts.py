@@ -317,7 +317,7 @@ def test_auto_reset_continues_across_launches(oracle):
 # ------------------------------------------------------------------------------------------------------------
 # 5. reset_finished(mask): reset_batches with the selection on the device, against the reference's recordings
 # ------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('label', ['wildfire', 'wildfire_bad_actions'])
+@pytest.mark.parametrize('label', ['wildfire', 'wildfire_bad_actions', 'wildfire_grid8x8'])
 def test_masked_reset_matches_the_recorded_partial_reset(label):
     """tests/golden/partial_*.npz (reset_batches(batch_indices, seed) recorded from the reference, see test_hip_partial_resets.py) through
     the device-mask entry point: same state, bookkeeping, observations, lists and continuation — no indices on the host."""
