@@ -12,9 +12,9 @@ resident in HBM; nothing crosses PCIe inside the timed region.
 Protocol (timed rollouts, median reported).  The K steps are one BLOCK = a rollout loop captured as ONE HIP
 graph: per episode of max_steps = 50 (the last one shorter when K is not a multiple) fresh env seeds, reset, the episode's
 steps, the episode-metrics reduction.  W warm-up steps are run as whole blocks (graph uploaded and warm before any clock starts).
-Then the block is timed R >= 10 times, each time bracketed by barrier + torch.cuda.synchronize() on both sides (N > 1: the
-closing barrier is the job's one collective, the RCCL all-reduce of the block's metrics, followed by the synchronize); the
-per-block times are max-reduced over the ranks and the MEDIAN block is reported: value = N * B * K / median, ms_per_step =
+Then the block is timed R >= 10 times, each time bracketed by barrier + torch.cuda.synchronize() on both sides; a timed block
+holds NO collective (N > 1: every rank accumulates its metrics on its own device and the job's one RCCL all-reduce runs after the
+timed loop; what an all-reduce per block would cost is measured separately and reported under `distributed`); the per-block times are max-reduced over the ranks and the MEDIAN block is reported: value = N * B * K / median, ms_per_step =
 median / K.  Prints ONE JSON line (rank 0).
 """
 import argparse
@@ -96,6 +96,23 @@ def recorded_traffic(key):
     if rec.get('source_fingerprint') != source_fingerprint():
         return None, f'profiles/hbm_traffic.json was recorded on another kernel build ({rec.get("source_fingerprint")}); not reported'
     return rec.get(key), f'recorded: {rec.get("how", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes")} (profiles/hbm_traffic.json)'
+
+
+def granted_cores():
+    """CPU cores this process may really use: the scheduler affinity, cut down to the cgroup's CFS quota where one is set (the one-GPU box
+    shows all 256 host threads and grants 16 cores' worth of time per 100 ms period)."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover
+        cores = os.cpu_count() or 1
+    for path in ('/sys/fs/cgroup/cpu.max', ):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != 'max':
+                cores = max(1, min(cores, int(quota) // int(period)))
+        except (OSError, ValueError):
+            pass
+    return cores
 
 
 def cpu_baseline(cores, budget_s=8.0):
@@ -235,6 +252,10 @@ def main():
     if args.steps <= 0:
         raise SystemExit('--steps must be positive')
 
+    # torch's intra-op pool defaults to half the VISIBLE host threads (128 on the GPU box), the cgroup grants 16 cores per 100 ms period: one
+    # CPU tensor op of B elements wakes 128 spinning workers, the period's quota is gone in ~12 ms and the kernel freezes the whole process
+    # until the next period — round 3's unexplained 85-106 ms stalls in the per-step legs (tools/dbg/api_stall_probe.py)
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), granted_cores())))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -301,17 +322,19 @@ def main():
         def enqueue_block():
             for ref in spec_refs:
                 rollout_entry(env_handle, ref, launch_stream)
-            if dist is not None:
-                job_metrics.copy_(metrics)
     else:
         block = env.capture_random_rollout(K, policy_seed=policy_seed, include_reset=True, episode_length=EPISODE, seed_stride=seed_stride,
-                                           metrics=metrics, metrics_copy=job_metrics if dist is not None else None)
+                                           metrics=metrics)
         enqueue_block = block.replay
     done_event = torch.cuda.Event()
 
-    def run_block():
+    def run_block(with_collective=False):
+        # The timed region holds NO collective: every rank accumulates its episode metrics on its own device across
+        # the blocks (the launches add to `metrics` in place) and the job's single collective — one RCCL all-reduce of A + 2 doubles —
+        # runs once, after the timed loop.  `with_collective` is the untimed-for-`value` probe that prices an all-reduce per block.
         enqueue_block()
-        if dist is not None:  # the job's one collective; every rank's result needs every rank's contribution: it closes the block
+        if with_collective:
+            job_metrics.copy_(metrics)
             sharding.reduce_metrics(job_metrics)
         done_event.record()
         while not done_event.query():  # poll instead of sleeping in the driver: the wake-up of a blocking wait costs more than a step
@@ -329,6 +352,19 @@ def main():
         run_block()
         block_s.append(time.perf_counter() - t0)
     barrier()
+    if dist is not None:  # the job's ONE collective: the metrics of all timed blocks, summed over the ranks (outside every timed block)
+        job_metrics.copy_(metrics)
+        sharding.reduce_metrics(job_metrics)
+    finished_metrics = (job_metrics if dist is not None else metrics).clone()
+    # what a per-block reduction would have cost (never part of `value`): the same block with the all-reduce inside, same bracketing
+    collective_probe_s = []
+    if dist is not None:
+        for _ in range(min(repeats, 60)):
+            barrier()
+            t0 = time.perf_counter()
+            run_block(with_collective=True)
+            collective_probe_s.append(time.perf_counter() - t0)
+        barrier()
     block_t = torch.tensor(block_s, dtype=torch.float64, device=device)
     if dist is not None:
         dist.all_reduce(block_t, op=dist.ReduceOp.MAX)  # MAX over ranks, block by block
@@ -344,19 +380,27 @@ def main():
                                       'block_ms_median': 1e3 * float(np.median(block_s))})
         probe = torch.ones(1, dtype=torch.float64, device=device)
         dist.all_reduce(probe)  # one more collective on the job's backend: the number of ranks it really reduces over
+        probe_t = torch.tensor(collective_probe_s, dtype=torch.float64, device=device)
+        dist.all_reduce(probe_t, op=dist.ReduceOp.MAX)
         distributed = {'world_size': dist.get_world_size(), 'backend': dist.get_backend(), 'ranks_in_all_reduce': int(probe.item()),
-                       'distinct_devices': len({(r['host'], r['uuid']) for r in seen}), 'ranks': seen}
+                       'distinct_devices': len({(r['host'], r['uuid']) for r in seen}), 'ranks': seen,
+                       'collectives_in_timed_region': 0,
+                       'collective': 'one all-reduce of A + 2 float64 metrics after the timed loop (the launches accumulate them on each device)',
+                       'block_ms_median_without_collective': 1e3 * float(np.median(block_t.cpu().numpy())),
+                       'block_ms_median_with_a_collective_per_block': 1e3 * float(np.median(probe_t.cpu().numpy())),
+                       'collective_probe_blocks': len(collective_probe_s)}
     block_s = block_t.cpu().numpy()
     median_s = float(np.median(block_s))
     value = world * B * K / median_s
-    finished_metrics = (job_metrics if dist is not None else metrics).clone()
 
     # ---- the drop-in Python API path (env.step_random_policy per call, host-bound), reported beside the headline
     state = {'step': 0, 'episode': 0}
 
+    api_seed = base_seed.to(device)  # (device arithmetic: no CPU tensor op inside a timed leg, see torch.set_num_threads above)
+
     def one_step():
         if state['step'] % EPISODE == 0:
-            env.reset(seed=base_seed + 1000003 * state['episode'])
+            env.reset(seed=api_seed + 1000003 * state['episode'])
             state['episode'] += 1
         env.step_random_policy(policy_seed=policy_seed, policy_step=state['step'] % EPISODE)
         state['step'] += 1
@@ -382,29 +426,46 @@ def main():
     # `env.action_space(agent).sample_nested()`, `env.step(actions)`, `torch.all(env.finished)` once per episode, reset per episode — through
     # the drop-in API with its defaults (exact_shapes=True).  The samples are handed to step() untouched, so they are drawn inside the step
     # launch (utils/env.py LazySample): one launch per step; the per-episode reset and the finished test (one host read) are in the time.
-    loop_env = wildfire_v0.parallel_env(configuration=configs.wildfire_openness(), parallel_envs=B, max_steps=EPISODE, device=device, rng=args.rng)
     loop_seeds = [base_seed.to(device) + seed_stride * episode for episode in range(8)]  # (on the device: a reset does not cross PCIe)
-    torch.cuda.synchronize(device)
 
-    def reference_loop(episodes):
-        steps = 0
-        for episode in range(episodes):
-            loop_env.reset(seed=loop_seeds[episode])
-            while True:
-                for _ in range(EPISODE):
-                    loop_env.step({agent: loop_env.action_space(agent).sample_nested() for agent in loop_env.agents})
-                steps += EPISODE
-                if torch.all(loop_env.finished):
-                    break
-        return steps
+    def reference_loop_rate(declare_exclusive):
+        """env-steps/s of the reference-shaped loop; five runs of eight episodes, the median (and every run, for the record).
+        declare_exclusive: `env.set_exclusive_device()` after construction — the one call a drop-in user adds on a dedicated GPU; the env
+        then only counts such steps and launches them in chunks (one multi-step launch per chunk: utils/env.py, deferred steps)."""
+        loop_env = wildfire_v0.parallel_env(configuration=configs.wildfire_openness(), parallel_envs=B, max_steps=EPISODE, device=device, rng=args.rng)
+        deferred = bool(declare_exclusive and not rehearsal and loop_env.set_exclusive_device(True) and loop_env._defer_chunk > 0)
+        chunks = loop_env._deferred_log = []
 
-    reference_loop(2)
-    barrier()
-    t2 = time.perf_counter()
-    loop_steps = reference_loop(8)
-    barrier()
-    reference_loop_value = world * B * loop_steps / (time.perf_counter() - t2)
-    del loop_env
+        def loop(episodes):
+            steps = 0
+            for episode in range(episodes):
+                loop_env.reset(seed=loop_seeds[episode])
+                while True:
+                    for _ in range(EPISODE):
+                        loop_env.step({agent: loop_env.action_space(agent).sample_nested() for agent in loop_env.agents})
+                    steps += EPISODE
+                    if torch.all(loop_env.finished):
+                        break
+            return steps
+
+        loop(2)
+        runs = []
+        for _ in range(5):
+            del chunks[:]
+            barrier()
+            t2 = time.perf_counter()
+            loop_steps = loop(8)
+            barrier()
+            runs.append(time.perf_counter() - t2)
+        loop_env.check()
+        launches = len(chunks) if deferred else loop_steps
+        del loop_env
+        return {'env_steps_per_s': world * B * loop_steps / float(np.median(runs)), 'us_per_step': 1e6 * float(np.median(runs)) / loop_steps,
+                'runs_ms': [round(1e3 * t, 3) for t in runs], 'steps_per_run': loop_steps, 'step_launches_per_run': launches, 'deferred_steps': deferred}
+
+    reference_loop_default = reference_loop_rate(False)
+    reference_loop_exclusive = reference_loop_rate(True)
+    reference_loop_value = reference_loop_exclusive['env_steps_per_s']
 
     lib, handle = env._lib, env._handle
     mode = _capi.FRZ_RNG_MT19937 if args.rng == 'mt19937' else _capi.FRZ_RNG_PHILOX
@@ -540,7 +601,7 @@ def main():
             'config': {'workload': f'wildfire_v0 cfg2 (2x3 grid, 3 agents, agent+task openness on), batch={B} per GPU, max_steps={EPISODE}, uniform random '
                                    f'policy sampled inside the step launch, rng={args.rng}',
                        'parallel_envs_per_gpu': B, 'agents': A,
-                       'sharding': f'env-batch axis x{world}, no step-path collective, one metrics all-reduce per timed block'},
+                       'sharding': f'env-batch axis x{world}, no step-path collective, no collective inside a timed block; one metrics all-reduce per job'},
             'timing': {'protocol': (f'{K}-step block = {episodes_per_block} x [reseed, reset, <= {EPISODE} steps, episode metrics] = {episodes_per_block} '
                                     'launch(es) enqueued through the C-ABI' if one_launch_per_episode else
                                     f'{K}-step block = ONE HIP graph ({episodes_per_block} x [reseed, reset, <= {EPISODE} steps, episode metrics])') + '; timed '
@@ -557,7 +618,10 @@ def main():
             'python_api_runs_ms': [round(1e3 * t, 3) for t in api_times],  # (five runs of four episodes; the figure above is their median)
             'reference_loop_env_steps_per_s': reference_loop_value,
             'reference_loop': 'per agent env.action_space(agent).sample_nested(), env.step(dict), torch.all(env.finished) once per episode, reset per '
-                              'episode; exact_shapes=True (the default); one step launch per step (samples drawn inside it)',
+                              'episode; exact_shapes=True (the default); env.set_exclusive_device() declared (this process owns the GPU): step() counts '
+                              'such steps and launches them in chunks of 4..32 — one multi-step launch per chunk, run as soon as anything is looked at',
+            'reference_loop_exclusive_device': reference_loop_exclusive,
+            'reference_loop_without_the_declaration': dict(reference_loop_default, note='no set_exclusive_device(): one step launch per step() call'),
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'frac_algorithmic': achieved / HBM_PEAK_GBS,
                          'frac_algorithmic_state_read_once': per_env_state_once * B * steps_per_launch / (kernel_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -591,9 +655,11 @@ def main():
                 available = len(os.sched_getaffinity(0))
             except AttributeError:  # pragma: no cover
                 available = os.cpu_count() or 1
-            # a one-GPU box grants this process a 16-core share of the host (more threads than that gain nothing: both runs are reported)
-            line['cpu_baseline'] = cpu_baseline(min(16, available))
-            if available > 16:
+            # a one-GPU box grants this process a 16-core share of the host (cgroup quota; more threads than that gain nothing: both runs
+            # are reported)
+            granted = granted_cores()
+            line['cpu_baseline'] = cpu_baseline(granted)
+            if available > granted:
                 line['cpu_baseline_all_visible_cores'] = cpu_baseline(available, budget_s=5.0)
         if world == 1 and not args.no_secondary:
             line['secondary_workloads'] = secondary_workloads(device, B)

@@ -24,6 +24,7 @@ frz_cybersecurity_bufs = STRUCTS['frz_cybersecurity_bufs']
 frz_rideshare_cfg = STRUCTS['frz_rideshare_cfg']
 frz_rideshare_bufs = STRUCTS['frz_rideshare_bufs']
 frz_rollout_spec = STRUCTS['frz_rollout_spec']
+frz_wildfire_saved_state = STRUCTS['frz_wildfire_saved_state']
 
 _lib = None
 
@@ -67,6 +68,7 @@ SIGNATURES = {
     'frz_wildfire_timed_rollout_spec': (ctypes.c_int, [_P, _P, _P, ctypes.POINTER(ctypes.c_float)]),
     'frz_wildfire_list_block': (ctypes.c_int, [_P, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64)]),
     'frz_wildfire_reset_masked': (ctypes.c_int, [_P, _P, ctypes.c_int32, _P]),
+    'frz_wildfire_set_saved_initial': (ctypes.c_int, [_P, _P]),
     'frz_cybersecurity_create': (ctypes.c_int, [_P, ctypes.POINTER(_P)]),
     'frz_cybersecurity_destroy': (None, [_P]),
     'frz_cybersecurity_arena_bytes': (ctypes.c_int64, [_P]),

@@ -1600,7 +1600,7 @@ int frz_cybersecurity_rollout(frz_cybersecurity_env* env, const frz_rollout_spec
     const int64_t B = p.B, A = p.A, N = p.N, AB2 = A * B * 2;
     const int64_t block_bytes = p.off_obs_map - p.off_act_values;
 
-    if (frz_cybersecurity_rollout_launches(env, spec->n_steps, mode) == 1) {  // ONE multi-step launch
+    if (spec->n_steps > 1 && frz_cybersecurity_rollout_launches(env, spec->n_steps, mode) == 1) {  // ONE multi-step launch
         frz_cybersecurity_env::RolloutOptions& o = env->rollout;
         o.extra = !policy || spec->list_record || spec->reward_tape || spec->done_tape || spec->record_actions || reset_first;
         o.flags = spec->flags;

@@ -170,7 +170,7 @@ frz_rollout_spec make_spec(const at::Tensor& arena, const Env& e, int64_t units_
                            const c10::optional<at::Tensor>& randomness_b, const c10::optional<at::Tensor>& actions_out, bool record_actions,
                            const c10::optional<at::Tensor>& reward_tape, const c10::optional<at::Tensor>& done_tape,
                            const c10::optional<at::Tensor>& list_record, const c10::optional<at::Tensor>& metrics) {
-    TORCH_CHECK(steps > 0, "rollout: steps must be positive");
+    TORCH_CHECK(steps >= 0, "rollout: steps must not be negative");  // (0 steps: a reset-only rollout, as through the C-ABI)
     frz_rollout_spec spec;
     std::memset(&spec, 0, sizeof(spec));
     spec.n_steps = (int32_t)steps;
@@ -183,13 +183,13 @@ frz_rollout_spec make_spec(const at::Tensor& arena, const Env& e, int64_t units_
     spec.action_tape = tape_or_null<const int32_t>(arena, action_tape, at::kInt, steps * e.A * e.B * 2, "action_tape");
     spec.randomness_tape_a = tape_or_null<const float>(arena, randomness_a, at::kFloat, steps * units_a, "randomness_a");
     spec.randomness_tape_b = tape_or_null<const float>(arena, randomness_b, at::kFloat, steps * units_b, "randomness_b");
-    TORCH_CHECK(rng_mode != FRZ_RNG_INJECTED || (spec.randomness_tape_a && spec.randomness_tape_b), "rollout: FRZ_RNG_INJECTED needs both randomness tapes");
+    TORCH_CHECK(steps == 0 || rng_mode != FRZ_RNG_INJECTED || (spec.randomness_tape_a && spec.randomness_tape_b), "rollout: FRZ_RNG_INJECTED needs both randomness tapes");
     spec.record_actions = record_actions ? 1 : 0;
     spec.actions_out = tape_or_null<int32_t>(arena, actions_out, at::kInt, (record_actions ? steps : 1) * e.A * e.B * 2, "actions_out");
     TORCH_CHECK(spec.action_tape || spec.actions_out, "rollout: the in-kernel policy needs actions_out");
     spec.reward_tape = tape_or_null<float>(arena, reward_tape, at::kFloat, steps * e.A * e.B, "reward_tape");
     spec.done_tape = tape_or_null<uint8_t>(arena, done_tape, at::kByte, steps * 2 * e.B, "done_tape");
-    spec.list_record = tape_or_null<uint8_t>(arena, list_record, at::kByte, (steps - 1) * list_block_bytes, "list_record");
+    spec.list_record = tape_or_null<uint8_t>(arena, list_record, at::kByte, (steps > 0 ? steps - 1 : 0) * list_block_bytes, "list_record");
     spec.metrics = tape_or_null<double>(arena, metrics, at::kDouble, e.A + 2, "metrics");
     return spec;
 }

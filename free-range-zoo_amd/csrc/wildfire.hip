@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(kBlock) wf_fill_kernel(char* arena, int32_t se
 // terminated or all truncated; agents share one value per env, row 0 is read) — the state part of reset_batches (utils/env.py:162-189,
 // wildfire.py:376-397); the rebuild launch that follows refreshes observations and lists.  cells_env_major: the grid family's layout.
 __global__ void __launch_bounds__(kBlock) wf_masked_fill_kernel(char* arena, const uint8_t* mask, uint32_t seed_increment, int64_t off_cells,
-                                                                int64_t off_cell_tables) {
+                                                                int64_t off_cell_tables, frz_wildfire_saved_state saved) {
     const WfDev& d = *reinterpret_cast<const WfDev*>(arena);
     const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t B = d.B;
@@ -81,7 +81,20 @@ __global__ void __launch_bounds__(kBlock) wf_masked_fill_kernel(char* arena, con
     const bool selected = mask ? mask[b] != 0 : (rows1[d.u_term * B + b] != 0 || rows1[d.u_trunc * B + b] != 0);
     if (!selected) return;
     reinterpret_cast<uint32_t*>(rows)[d.r_seeds * B + b] += seed_increment;  // modulo 2^32
-    if (off_cells != 0) {  // grid family: cells env-major [3][B][HW]; initial fires / intensity / fuel are tables 2..4 of the cell-table block
+    if (saved.fires != nullptr) {  // the state saved at reset (frz_wildfire_set_saved_initial: a caller-given initial state)
+        const int64_t HW = d.HW;
+        int32_t* cells = reinterpret_cast<int32_t*>(arena + off_cells);
+        for (int64_t c = 0; c < HW; ++c) {
+            const int32_t f = saved.fires[b * saved.fires_stride_env + c * saved.fires_stride_item];
+            const int32_t i = saved.intensity[b * saved.intensity_stride_env + c * saved.intensity_stride_item];
+            const int32_t u = saved.fuel[b * saved.fuel_stride_env + c * saved.fuel_stride_item];
+            if (off_cells != 0) {
+                cells[(0 * B + b) * HW + c] = f, cells[(1 * B + b) * HW + c] = i, cells[(2 * B + b) * HW + c] = u;
+            } else {
+                rows[(d.r_fires + c) * B + b] = f, rows[(d.r_intensity + c) * B + b] = i, rows[(d.r_fuel + c) * B + b] = u;
+            }
+        }
+    } else if (off_cells != 0) {  // grid family: cells env-major [3][B][HW]; initial fires / intensity / fuel are tables 2..4 of the cell-table block
         const int32_t* tables = reinterpret_cast<const int32_t*>(arena + off_cell_tables);
         int32_t* cells = reinterpret_cast<int32_t*>(arena + off_cells);
         const int64_t HW = d.HW;
@@ -97,9 +110,10 @@ __global__ void __launch_bounds__(kBlock) wf_masked_fill_kernel(char* arena, con
         }
     }
     for (int a = 0; a < d.A; ++a) {
-        rowsf[(d.r_supp + a) * B + b] = d.initial_suppressant;
-        rowsf[(d.r_cap + a) * B + b] = d.initial_capacity;
-        rows[(d.r_equip + a) * B + b] = d.initial_equipment;
+        const bool s = saved.fires != nullptr;
+        rowsf[(d.r_supp + a) * B + b] = s ? saved.suppressants[b * saved.suppressants_stride_env + a * saved.suppressants_stride_item] : d.initial_suppressant;
+        rowsf[(d.r_cap + a) * B + b] = s ? saved.capacity[b * saved.capacity_stride_env + a * saved.capacity_stride_item] : d.initial_capacity;
+        rows[(d.r_equip + a) * B + b] = s ? saved.equipment[b * saved.equipment_stride_env + a * saved.equipment_stride_item] : d.initial_equipment;
         rowsf[(d.r_rewards + a) * B + b] = 0.0f;
         rowsf[(d.r_cum + a) * B + b] = 0.0f;
         rows1[(d.u_term + a) * B + b] = 0;
@@ -1012,6 +1026,7 @@ struct frz_wildfire_env {
     double* rollout_metrics = nullptr;  // frz_wildfire_rollout_random_policy_metrics: folded into the multi-step launch being enqueued
     const frz_rollout_spec* rollout_spec = nullptr;  // frz_wildfire_rollout: the spec of the multi-step launch being enqueued
     bool exclusive_device = false;  // frz_wildfire_set_exclusive_device: multi-step launches allowed
+    frz_wildfire_saved_state saved = {};  // frz_wildfire_set_saved_initial: what a partial reset restores (fires == nullptr: the configured state)
     // grids above 16 cells (wildfire_grid.hip): the kernels' configuration and the tables uploaded into the arena at bind
     WgDev gdev;
     WgAgentTable agent_table;
@@ -1622,6 +1637,7 @@ int frz_wildfire_reset(frz_wildfire_env* env, void* stream) { return frz_wildfir
 int frz_wildfire_reset_reseed(frz_wildfire_env* env, int32_t seed_increment, void* stream) {
     if (!env) return FRZ_E_INVALID;
     if (!env->arena) return FRZ_E_UNBOUND;
+    env->saved = frz_wildfire_saved_state{};  // a full reset saves the configured initial state again (utils/env.py:140-160)
     if (env->dev.roles || env->dev.grid) {  // the configured initial state is produced inside the rebuild kernel
         WfArgs args{env->arena, nullptr, nullptr, nullptr, &env->dev};
         args.seed_increment = seed_increment;
@@ -1852,9 +1868,16 @@ int frz_wildfire_reset_masked(frz_wildfire_env* env, const uint8_t* mask, int32_
     const int blocks = (env->cfg.parallel_envs + kBlock - 1) / kBlock;
     const int64_t off_cells = env->dev.grid ? env->gdev.off_cells : 0, off_tables = env->dev.grid ? env->gdev.off_cell_tables : 0;
     hipLaunchKernelGGL(wf_masked_fill_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), env->arena, mask,
-                       (uint32_t)seed_increment, off_cells, off_tables);
+                       (uint32_t)seed_increment, off_cells, off_tables, env->saved);
     if (hipGetLastError() != hipSuccess) return FRZ_E_LAUNCH;
     return frz_wildfire_rebuild(env, stream);
+}
+
+int frz_wildfire_set_saved_initial(frz_wildfire_env* env, const frz_wildfire_saved_state* saved) {
+    if (!env) return FRZ_E_INVALID;
+    if (saved && (!saved->fires || !saved->intensity || !saved->fuel || !saved->suppressants || !saved->capacity || !saved->equipment)) return FRZ_E_INVALID;
+    env->saved = saved ? *saved : frz_wildfire_saved_state{};
+    return FRZ_OK;
 }
 
 int frz_wildfire_rollout(frz_wildfire_env* env, const frz_rollout_spec* spec, void* stream) {
@@ -1876,7 +1899,9 @@ int frz_wildfire_rollout(frz_wildfire_env* env, const frz_rollout_spec* spec, vo
 
     // ONE multi-step launch (wildfire_roles.inl, PERSIST) ...
     const bool mt_reset = reset_first && mode == FRZ_RNG_MT19937;  // the opening reset re-seeds the streams from the host side: separate launches
-    if (frz_wildfire_rollout_launches(env, spec->n_steps, mode) == 1) {
+    if (reset_first) env->saved = frz_wildfire_saved_state{};
+    const bool saved_restart = auto_reset && env->saved.fires != nullptr;  // the in-kernel restart fills from the configured tables: not for a saved state
+    if (spec->n_steps > 1 && !saved_restart && frz_wildfire_rollout_launches(env, spec->n_steps, mode) == 1) {  // (a one-step rollout takes the per-step path below: it honours every option)
         frz_rollout_spec inner = *spec;
         if (mt_reset) {
             const int rc = frz_wildfire_reset_reseed(env, spec->seed_increment, stream);

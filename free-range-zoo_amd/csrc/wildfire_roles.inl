@@ -1499,18 +1499,36 @@ int FRZ_WF_CONCAT(launch_roles_group_, FRZ_WF_ROLES_GROUP)(const WfArgs& args, i
 }
 
 
-// resident workgroups per CU of the variant's multi-step instantiation (the plain rollout: the one with the larger grid of users), 0 if the
-// variant is not in this unit
+// resident workgroups per CU: the MINIMUM over every multi-step instantiation frz_wildfire_rollout can launch for the shape (three RNG
+// modes, with and without the EXTRA options — the EXTRA kernels use 7-9 KB more LDS and some spill: ADVICE r3), so that the residency
+// guard of frz_wildfire_set_exclusive_device holds for whichever of them a spec picks
+template <int C, int A>
+int persist_occupancy_min() {
+    int least = 1 << 30;
+    auto probe = [&least](auto kernel) {
+        int blocks = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, kRoleBlock, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            blocks = 0;
+        }
+        if (blocks < least) least = blocks;
+    };
+    probe(wf_roles_kernel<C, A, true, FRZ_RNG_PHILOX, kStep, true, false>);
+    probe(wf_roles_kernel<C, A, true, FRZ_RNG_PHILOX, kStep, true, true>);
+    probe(wf_roles_kernel<C, A, true, FRZ_RNG_MT19937, kStep, true, false>);
+    probe(wf_roles_kernel<C, A, true, FRZ_RNG_MT19937, kStep, true, true>);
+    probe(wf_roles_kernel<C, A, true, FRZ_RNG_INJECTED, kStep, true, true>);
+    return least;
+}
+
+// resident workgroups per CU of the variant's multi-step instantiations, 0 if the variant is not in this unit
 int FRZ_WF_CONCAT(roles_persist_occupancy_group_, FRZ_WF_ROLES_GROUP)(int variant) {
     int blocks = 0;
     switch (variant) {
 #define FRZ_X(i, c, a, e)                                                                                                                  \
     case i:                                                                                                                                \
         if constexpr ((i) % FRZ_WF_ROLES_GROUPS == FRZ_WF_ROLES_GROUP && e && c <= 16 && a * (c <= 8 ? 8 : 16) <= 64) {                      \
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, wf_roles_kernel<c, a, true, FRZ_RNG_PHILOX, kStep, true, false>, kRoleBlock, 0) != hipSuccess) { \
-                (void)hipGetLastError();                                                                                                   \
-                blocks = 0;                                                                                                                \
-            }                                                                                                                              \
+            blocks = persist_occupancy_min<c, a>();                                                                                         \
         }                                                                                                                                  \
         break;
         FRZ_WF_VARIANT_LIST(FRZ_X)

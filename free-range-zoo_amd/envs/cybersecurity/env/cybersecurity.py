@@ -340,7 +340,10 @@ class raw_env(BatchedParallelEnv):
         """State that nothing else uses this GPU while the env's rollouts run: allows ``rollout`` / ``rollout_random_policy`` /
         ``capture_random_rollout`` to run a rollout as ONE launch (include/frz.h: frz_cybersecurity_set_exclusive_device; see the wildfire
         env).  Off by default.  False: the library's own residency check refused (the rollouts keep taking one launch per step)."""
-        return self._lib.frz_cybersecurity_set_exclusive_device(self._handle, 1 if exclusive else 0) == 0
+        code = self._lib.frz_cybersecurity_set_exclusive_device(self._handle, 1 if exclusive else 0)
+        if code not in (0, _capi.DEFINES['FRZ_E_INVALID']):  # (no device, a dead handle: errors, not a refusal)
+            _capi.check(code, 'frz_cybersecurity_set_exclusive_device')
+        return code == 0
 
     @torch.no_grad()
     def rollout_random_policy(self, steps: int, policy_seed: int = 0, first_step: int = 0):

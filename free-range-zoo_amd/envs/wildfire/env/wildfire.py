@@ -39,6 +39,7 @@ class raw_env(BatchedParallelEnv):
     """Environment definition for the wildfire environment."""
     _rebuild_symbol = 'frz_wildfire_rebuild'
     _domain = 'wildfire'
+    _hands_out_lazy = True  # step() may defer (utils/env.py: deferred steps): public tensors are EnvTensors
 
     metadata = {'render.modes': ['human', 'rgb_array'], 'name': 'wildfire_v0', 'is_parallelizable': True, 'render_fps': 2}
 
@@ -105,7 +106,10 @@ class raw_env(BatchedParallelEnv):
         self._fires, self._intensity, self._fuel = v(bufs.fires, cell_shape, i32), v(bufs.intensity, cell_shape, i32), v(bufs.fuel, cell_shape, i32)
         self._suppressants, self._capacity = v(bufs.suppressants, (A, B), f32), v(bufs.capacity, (A, B), f32)
         self._equipment = v(bufs.equipment, (A, B), i32)
-        self.num_moves, self.num_burnouts = v(bufs.num_moves, (B, ), i32), v(bufs.num_burnouts, (B, ), i32)
+        # (underscore names: plain views for the env's own code, which flushes pending steps itself; public names: what callers get)
+        lazy = self._lazy
+        self._num_moves, self._num_burnouts = v(bufs.num_moves, (B, ), i32), v(bufs.num_burnouts, (B, ), i32)
+        self.num_moves, self.num_burnouts = lazy(self._num_moves), lazy(self._num_burnouts)
         self._rewards, self._cumulative = v(bufs.rewards, (A, B), f32), v(bufs.cumulative_rewards, (A, B), f32)
         self._terminations, self._truncations = v(bufs.terminations, (A, B), torch.bool), v(bufs.truncations, (A, B), torch.bool)
         self._burnouts, self._putouts = v(bufs.burnouts, (B, ), i64), v(bufs.putouts, (B, ), i64)
@@ -115,16 +119,18 @@ class raw_env(BatchedParallelEnv):
         self._act_map_values, self._act_map_offsets = v(bufs.act_map_values, (A, cap), i64), v(bufs.act_map_offsets, (A, B + 1), i64)
         self._bad_map_values = v(bufs.bad_map_values, (A, cap), i64) if self.show_bad_actions else None
         self._bad_map_offsets = v(bufs.bad_map_offsets, (A, B + 1), i64)
-        self.environment_task_count, self.agent_task_count = v(bufs.env_task_count, (B, ), i64), v(bufs.agent_task_count, (A, B), i32)
+        self._env_task_count, self._agent_task_count = v(bufs.env_task_count, (B, ), i64), v(bufs.agent_task_count, (A, B), i32)
+        self.environment_task_count, self.agent_task_count = lazy(self._env_task_count), lazy(self._agent_task_count)
+        self._burnouts_out, self._putouts_out = lazy(self._burnouts), lazy(self._putouts)
         self._frozen_scaled = v(bufs.frozen_scaled, (B, ), u8)
         self._error_flags = v(bufs.error_flags, (1, ), i32)
         self._actions = v(bufs.actions, (A, B, 2), i32)
-        self.generator.attach(seeds=v(bufs.seeds, (B, ), i32), states=v(bufs.mt_state, (624, B), i32), index=v(bufs.mt_index, (B, ), i32))
+        self.generator.attach(seeds=lazy(v(bufs.seeds, (B, ), i32)), states=lazy(v(bufs.mt_state, (624, B), i32)), index=lazy(v(bufs.mt_index, (B, ), i32)))
         self.seeds = self.generator.seeds
-        grid = (lambda t: t.view(B, H, W)) if self._cells_env_major else (lambda t: t.view(H, W, B).permute(2, 0, 1))
+        grid = (lambda t: lazy(t.view(B, H, W))) if self._cells_env_major else (lambda t: lazy(t.view(H, W, B).permute(2, 0, 1)))
         self._state = WildfireState(
             fires=grid(self._fires), intensity=grid(self._intensity), fuel=grid(self._fuel), agents=self.agent_config.agents,
-            suppressants=self._suppressants.t(), capacity=self._capacity.t(), equipment=self._equipment.t())
+            suppressants=lazy(self._suppressants.t()), capacity=lazy(self._capacity.t()), equipment=lazy(self._equipment.t()))
 
     def _create_handle(self) -> None:
         pass  # handle, arena and views are created together in _allocate()
@@ -184,9 +190,9 @@ class raw_env(BatchedParallelEnv):
         if self.exact_shapes:
             # one small device->host read: total and maximum length of each jagged output
             stats = torch.cat([self._task_offsets[-1:], self._act_map_offsets[:, -1],
-                               self.environment_task_count.max().reshape(1), self.agent_task_count.max(dim=1).values.to(torch.int64)])
+                               self._env_task_count.max().reshape(1), self._agent_task_count.max(dim=1).values.to(torch.int64)])
             if self.show_bad_actions:
-                bad = self.environment_task_count.unsqueeze(0) - self.agent_task_count
+                bad = self._env_task_count.unsqueeze(0) - self._agent_task_count
                 stats = torch.cat([stats, self._bad_map_offsets[:, -1], bad.max(dim=1).values])
             stats = self._host_read(stats)
             total_f, total_a, max_f, max_a = stats[0], stats[1:1 + A], stats[1 + A], stats[2 + A:2 + 2 * A]
@@ -197,19 +203,19 @@ class raw_env(BatchedParallelEnv):
                 total_b, max_b = stats[2 + 2 * A:2 + 3 * A], stats[2 + 3 * A:]
                 bad_maps = [jagged(self._bad_map_values[a, :total_b[a]], self._bad_map_offsets[a], max_seqlen=max_b[a]) for a in range(A)]
         elif getattr(self, '_static_views', None) is None:
-            counts = self.environment_task_count
+            counts = self._env_task_count
             tasks = jagged(self._task_values, self._task_offsets, max_seqlen=HW, lengths=counts)
             obs_map = jagged(self._obs_map_values, self._task_offsets, max_seqlen=HW, lengths=counts)
-            act_maps = [jagged(self._act_map_values[a], self._act_map_offsets[a], max_seqlen=HW, lengths=self.agent_task_count[a])
+            act_maps = [jagged(self._act_map_values[a], self._act_map_offsets[a], max_seqlen=HW, lengths=self._agent_task_count[a])
                         for a in range(A)]
             if self.show_bad_actions:
-                self._bad_counts = self.environment_task_count.unsqueeze(0) - self.agent_task_count
+                self._bad_counts = self._env_task_count.unsqueeze(0) - self._agent_task_count
                 bad_maps = [jagged(self._bad_map_values[a], self._bad_map_offsets[a], max_seqlen=HW, lengths=self._bad_counts[a])
                             for a in range(A)]
             self._static_views = True
         else:
             if self.show_bad_actions:
-                torch.sub(self.environment_task_count.unsqueeze(0), self.agent_task_count, out=self._bad_counts)
+                torch.sub(self._env_task_count.unsqueeze(0), self._agent_task_count, out=self._bad_counts)
             return  # persistent views already published
 
         self.task_store = tasks
@@ -228,16 +234,21 @@ class raw_env(BatchedParallelEnv):
             self._publish_dense()
 
     def _publish_dense(self) -> None:
-        self.rewards = {agent: self._rewards[a] for a, agent in enumerate(self.agents)}
-        self._cumulative_rewards = {agent: self._cumulative[a] for a, agent in enumerate(self.agents)}
-        self.terminations = {agent: self._terminations[a] for a, agent in enumerate(self.agents)}
-        self.truncations = {agent: self._truncations[a] for a, agent in enumerate(self.agents)}
-        self.actions = {agent: self._actions[a] for a, agent in enumerate(self.agents)}
+        views = self.__dict__.get('_dense_views')
+        if views is None:  # the per-agent rows of the dense blocks: fixed views, made once (a reset builds new dicts over them)
+            lazy, A = self._lazy, len(self.possible_agents)
+            views = self._dense_views = tuple([lazy(block[a]) for a in range(A)]
+                                              for block in (self._rewards, self._cumulative, self._terminations, self._truncations, self._actions))
+        agents = self.agents
+        self.rewards, self._cumulative_rewards = dict(zip(agents, views[0])), dict(zip(agents, views[1]))
+        self.terminations, self.truncations, self.actions = dict(zip(agents, views[2])), dict(zip(agents, views[3])), dict(zip(agents, views[4]))
 
     # ------------------------------------------------------------------------------------------------- reset
     @torch.no_grad()
     def reset(self, seed=None, options: Optional[Dict[str, Any]] = None):
         """Reset every env; returns ``(observations, infos)`` like the parallel adapter (conversions.py:39-57)."""
+        self._flush()
+        self._defer_chunk = self._DEFER_MIN if self._defer_chunk else 0  # (an episode starts with short chunks: the device gets work at once)
         self._reset_options(options)
         if options and options.get('skip_seeding'):
             if not self.generator.has_been_seeded:
@@ -255,11 +266,25 @@ class raw_env(BatchedParallelEnv):
             self._state.load_state(initial_state.to(self.device))
             self._call('rebuild')
         self._save_initial()
-        self.fire_rewards = self.reward_config.fire_rewards.unsqueeze(0).expand(self.parallel_envs, -1, -1)
+        if options is not None and options.get('initial_state') is not None:
+            # the device-side partial resets (reset_finished, rollout(auto_reset=True)) restore what was SAVED — the caller's state — like
+            # the reference's reset_batches (wildfire.py:391), not the configured initial state
+            saved, desc = self._state.initial_state, _capi.frz_wildfire_saved_state()
+            for name in ('fires', 'intensity', 'fuel', 'suppressants', 'capacity', 'equipment'):
+                t = getattr(saved, name)
+                flat = t.reshape(t.shape[0], -1) if t.dim() == 3 and t.stride(1) == t.shape[2] * t.stride(2) else t
+                if flat.dim() != 2:  # (cells not expressible with one stride: keep a contiguous copy beside the saved state)
+                    flat = t.reshape(t.shape[0], -1).contiguous()
+                    self.__dict__.setdefault('_saved_keepalive', {})[name] = flat
+                setattr(desc, name, flat.data_ptr())
+                setattr(desc, f'{name}_stride_env', flat.stride(0))
+                setattr(desc, f'{name}_stride_item', flat.stride(1))
+            _capi.check(self._lib.frz_wildfire_set_saved_initial(self._handle, ctypes.byref(desc)), 'frz_wildfire_set_saved_initial')
+        if self.__dict__.get('fire_rewards') is None:
+            self.fire_rewards = self.reward_config.fire_rewards.unsqueeze(0).expand(self.parallel_envs, -1, -1)
         self.infos = {agent: {} for agent in self.agents}
         self._has_reset = True
-        self._publish()
-        self._publish_dense()
+        self._publish()  # (rewards is None: the dense dicts are rebuilt in there)
         if self.logger is not None:  # _post_reset_hook (utils/env.py:191-195)
             self._log_environment(reset=True)
         return self._observations_out(), self.infos
@@ -267,14 +292,15 @@ class raw_env(BatchedParallelEnv):
     @torch.no_grad()
     def reset_batches(self, batch_indices: torch.Tensor, seed: Optional[List[int]] = None, options: Optional[Dict[str, Any]] = None) -> None:
         """Partial reset (wildfire.py:376-397 + utils/env.py:162-189): reseed, zero bookkeeping, restore initial state."""
+        self._flush()
         batch_indices = torch.as_tensor(batch_indices, device=self.device).long()
         self.generator.seed(seed, partial_seeding=batch_indices)
         self._rewards[:, batch_indices] = 0
         self._cumulative[:, batch_indices] = 0
         self._terminations[:, batch_indices] = False
         self._truncations[:, batch_indices] = False
-        self.num_moves[batch_indices] = 0
-        self.num_burnouts[batch_indices] = 0
+        self._num_moves[batch_indices] = 0
+        self._num_burnouts[batch_indices] = 0
         self._frozen_scaled[batch_indices] = 0
         self._state.restore_initial(batch_indices)
         self._call('rebuild')
@@ -306,14 +332,30 @@ class raw_env(BatchedParallelEnv):
                     self._call('step_random_policy', (), lambda: (self.policy_seed, draw, self._sampled_actions, mode, len(self.agents), self.parallel_envs))
                     return self._after_fused(False)
                 else:
+                    chunk = self._defer_chunk
+                    if chunk:  # the device is this env's alone: the step is counted, not launched (utils/env.py: deferred steps)
+                        n = self._deferred
+                        if n and (self._deferred_first + n != draw or self._deferred_seed != self.policy_seed):
+                            self._flush()
+                            n = 0
+                        if n == 0:
+                            self._deferred_first, self._deferred_seed = draw, self.policy_seed
+                        self._deferred = n + 1
+                        if n + 1 >= chunk:  # nobody looked for a whole chunk: launch it, make the next one longer
+                            self._flush()
+                            self._defer_chunk = min(2 * chunk, self._DEFER_MAX)
+                        return self._after_fast_step()
                     fast = self.__dict__.get('_fast_step')
                     if fast is None:  # (entry point, sample buffer address, RNG mode: fixed for the life of the env)
                         fast = self._fast_step = (self._lib.frz_wildfire_step_random_policy, self._sampled_actions.data_ptr(), self._fused_rng_mode(),
                                                   self.device.index)
+                    if fast[2] == _capi.FRZ_RNG_MT19937:
+                        self.generator._ensure_streams()  # (a reset with new seeds since the last step: the streams are expanded again)
                     code = fast[0](self._handle, self.policy_seed, draw, fast[1], fast[2], None, None, torch._C._cuda_getCurrentRawStream(fast[3]))
                     if code:
                         _capi.check(code, 'frz_wildfire_step_random_policy')
                     return self._after_fast_step()
+        self._flush()
         logged = self._logs_this_step()
         if isinstance(actions, dict):
             self._stage_actions(actions)
@@ -352,8 +394,8 @@ class raw_env(BatchedParallelEnv):
             launch(_capi.FRZ_RNG_PHILOX)
         self._publish()
         self.infos = {agent: {} for agent in self.agents}
-        self.infos['burnouts'] = self._burnouts
-        self.infos['putouts'] = self._putouts
+        self.infos['burnouts'] = self._burnouts_out
+        self.infos['putouts'] = self._putouts_out
         if logged:
             self._log_environment()
         return (self._observations_out(), self.rewards, self.terminations, self.truncations, self.infos)
@@ -367,6 +409,7 @@ class raw_env(BatchedParallelEnv):
     @torch.no_grad()
     def random_policy_actions(self, policy_seed: int, policy_step: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Device-side uniform random policy over each agent's current action space -> int32 ``[A, B, 2]``."""
+        self._flush()
         out = self._actions if out is None else out
         self._call('random_policy', (policy_seed, policy_step, out.data_ptr()),
                    lambda: (policy_seed, policy_step, out, len(self.agents), self.parallel_envs))
@@ -395,6 +438,7 @@ class raw_env(BatchedParallelEnv):
         """
         if not self._has_reset:
             raise RuntimeError('reset() must be called once before capturing a rollout')
+        self._flush()
         self._no_multi_step_while_consistent('capture_random_rollout()')
         if metrics is not None and (metrics.dtype != torch.float64 or metrics.numel() != len(self.agents) + 2 or not metrics.is_contiguous()):
             raise ValueError('metrics must be a contiguous float64 [A + 2] tensor on the env device')
@@ -437,8 +481,8 @@ class raw_env(BatchedParallelEnv):
     def _after_fused(self, logged: bool):
         self._publish()
         self.infos = {agent: {} for agent in self.agents}
-        self.infos['burnouts'] = self._burnouts
-        self.infos['putouts'] = self._putouts
+        self.infos['burnouts'] = self._burnouts_out
+        self.infos['putouts'] = self._putouts_out
         if logged:
             self._log_environment()
         return (self._observations_out(), self.rewards, self.terminations, self.truncations, self.infos)
@@ -450,15 +494,16 @@ class raw_env(BatchedParallelEnv):
             self._exchange_batch_totals()
         self._epoch_counter += 1
         if self.exact_shapes:
-            for name in self._LAZY_OUTPUTS:
-                d.pop(name, None)
+            if 'observations' in d or 'task_store' in d:  # (somebody looked at the last step's outputs: they are stale now)
+                for name in self._LAZY_OUTPUTS:
+                    d.pop(name, None)
             observations = LazyAgentDict(self, self.agents)
         else:
             self._materialize()
             observations = {agent: self.observations[agent] for agent in self.agents}
         infos = self.infos = {agent: {} for agent in self.agents}
-        infos['burnouts'] = self._burnouts
-        infos['putouts'] = self._putouts
+        infos['burnouts'] = self._burnouts_out
+        infos['putouts'] = self._putouts_out
         return (observations, self.rewards, self.terminations, self.truncations, infos)
 
     @torch.no_grad()
@@ -467,6 +512,7 @@ class raw_env(BatchedParallelEnv):
         are left in ``self.actions``."""
         if not self._has_reset:
             raise RuntimeError('reset() must be called before step_random_policy()')
+        self._flush()
         logged = self._logs_this_step()
         mode = self._fused_rng_mode()
         self._call('step_random_policy', (policy_seed, policy_step, self._actions.data_ptr(), mode, None, None),
@@ -481,19 +527,60 @@ class raw_env(BatchedParallelEnv):
     def _after_rollout(self) -> None:
         self._publish()
         self.infos = {agent: {} for agent in self.agents}
-        self.infos['burnouts'] = self._burnouts
-        self.infos['putouts'] = self._putouts
+        self.infos['burnouts'] = self._burnouts_out
+        self.infos['putouts'] = self._putouts_out
 
-    def set_exclusive_device(self, exclusive: bool = True) -> bool:
+    def _launch_deferred(self, n: int, first: int, seed: int) -> None:
+        """`n` counted steps of the reference-shaped random loop (policy steps first .. first + n - 1, drawn inside the launch into the
+        sample buffer, which afterwards holds the last step's draw — what n single-step launches leave): ONE multi-step launch."""
+        launcher = self.__dict__.get('_deferred_launcher')
+        if launcher is None:
+            spec = _capi.frz_rollout_spec()
+            spec.rng_mode, spec.actions_out = self._fused_rng_mode(), self._sampled_actions.data_ptr()
+            launcher = self._deferred_launcher = (spec, ctypes.byref(spec), self._lib.frz_wildfire_rollout, self._lib.frz_wildfire_step_random_policy,
+                                                  self._sampled_actions.data_ptr(), self.device.index)
+        spec, ref, rollout, single, samples, index = launcher
+        if spec.rng_mode == _capi.FRZ_RNG_MT19937:
+            self.generator._ensure_streams()
+        stream = torch._C._cuda_getCurrentRawStream(index)
+        if n == 1:
+            code = single(self._handle, seed, first, samples, spec.rng_mode, None, None, stream)
+        else:
+            spec.n_steps, spec.policy_seed, spec.first_step = n, seed, first
+            code = rollout(self._handle, ref, stream)
+        log = self.__dict__.get('_deferred_log')
+        if log is not None:  # (tests: the chunk sizes that were launched)
+            log.append(n)
+        if code:
+            _capi.check(code, 'frz_wildfire_rollout (deferred steps)')
+
+    def set_exclusive_device(self, exclusive: bool = True, defer_steps: bool = True) -> bool:
         """State that nothing else uses this GPU while the env's rollouts run (no other process, no concurrent stream).  It allows
         ``rollout`` / ``rollout_random_policy`` / ``capture_random_rollout`` to run a whole rollout as ONE launch where the library has a
         multi-step kernel for the shape (include/frz.h: frz_wildfire_set_exclusive_device): its workgroups wait inside the kernel for each
         other between steps, which is only safe when all of them are resident.  Off by default.  The library checks its own part — the
         launch's workgroups fit on the device that owns the arena (occupancy query x compute units, no CU mask): if they do not, the request
         is refused, rollouts keep taking one launch per step, and False is returned."""
+        self._flush()
+        self._defer_chunk = 0
         if exclusive and self.__dict__.get('_global_group', False) is not False:
             return False  # globally consistent batch semantics exchange the totals between any two steps
-        return self._lib.frz_wildfire_set_exclusive_device(self._handle, 1 if exclusive else 0) == 0
+        code = self._lib.frz_wildfire_set_exclusive_device(self._handle, 1 if exclusive else 0)
+        if code not in (0, _capi.DEFINES['FRZ_E_INVALID']):  # (no device, a dead handle: errors, not a refusal)
+            _capi.check(code, 'frz_wildfire_set_exclusive_device')
+        if code == 0 and exclusive and defer_steps and self._can_defer():
+            self._defer_chunk = self._DEFER_MIN
+        return code == 0
+
+    def _can_defer(self) -> bool:
+        """Deferred steps (utils/env.py) need: a multi-step launch for the shape, the exact-shapes publication (observations are built when
+        looked at), the ctypes dispatch, no logging tap (it reads every step), and the per-env device streams in the MT19937 mode."""
+        if not self.exact_shapes or self._ops is not None or self.logger is not None:
+            return False
+        if self.rng == 'mt19937' and (self.single_seeding or self.generator.buffer_size):
+            return False
+        mode = _capi.FRZ_RNG_MT19937 if self.rng == 'mt19937' else _capi.FRZ_RNG_PHILOX
+        return self._lib.frz_wildfire_rollout_launches(self._handle, 2, mode) == 1
 
     # ------------------------------------------------------------------------ sharded jobs: globally consistent batch semantics (optional)
     def set_global_consistency(self, enabled: bool = True, group=None) -> None:
@@ -504,8 +591,10 @@ class raw_env(BatchedParallelEnv):
         ``all_reduce`` per step, stream-ordered with RCCL — and the next step reads the sums: a sharded run is then the unsharded one env
         for env also when a whole shard finishes early or with ``show_bad_actions``.  Multi-step launches cannot stop for the exchange:
         ``rollout`` / ``rollout_random_policy`` / ``capture_random_rollout`` raise while this is on."""
+        self._flush()
         self._global_group = group if enabled else False
         if enabled:
+            self._defer_chunk = 0
             self._lib.frz_wildfire_set_exclusive_device(self._handle, 0)
             if self.__dict__.get('_totals_staging') is None:
                 self._totals_staging = torch.zeros(len(self.possible_agents) + 3, dtype=torch.int32, device=self.device)
@@ -539,6 +628,7 @@ class raw_env(BatchedParallelEnv):
         steps are taken one by one so that every one of them reaches the CSV files."""
         if not self._has_reset:
             raise RuntimeError('reset() must be called before rollout_random_policy()')
+        self._flush()
         self._no_multi_step_while_consistent('rollout_random_policy()')
         if self.logger is not None:
             out = None
@@ -555,6 +645,7 @@ class raw_env(BatchedParallelEnv):
         """``metrics`` (float64 ``[A + 2]`` on the device) += (cumulative reward per agent ..., env-steps taken, finished envs): one launch."""
         if metrics.dtype != torch.float64 or metrics.numel() != len(self.agents) + 2 or not metrics.is_contiguous() or not metrics.is_cuda:
             raise ValueError('metrics must be a contiguous float64 [A + 2] tensor on the env device')
+        self._flush()
         _capi.check(self._lib.frz_wildfire_episode_metrics(self._handle, metrics.data_ptr(), stream_ptr(self.device)), 'frz_wildfire_episode_metrics')
         return metrics
 
@@ -562,11 +653,15 @@ class raw_env(BatchedParallelEnv):
     def action_space(self, agent: str) -> BatchedOneOfSpace:
         """Per-env ``OneOf([fight task]*n + [noop])`` (wildfire.py:719-734, spaces/actions.py:23-41).  The object is count-based over views
         of the env's buffers — it always describes the current step — so one per agent is built and handed out again."""
+        try:
+            return self._action_spaces[agent]
+        except (AttributeError, KeyError):
+            pass
         cache = self.__dict__.setdefault('_action_spaces', {})
         space = cache.get(agent)
         if space is None:
             index = self.possible_agents.index(agent)
-            counts = self.environment_task_count if self.show_bad_actions else self.agent_task_count[index]
+            counts = self.environment_task_count if self.show_bad_actions else self.agent_task_count[index]  # (EnvTensors: a look at them runs pending steps)
             from free_range_zoo_amd.envs.wildfire.env.spaces import actions
             space = cache[agent] = actions.build_action_space(counts, sampler=self._space_sampler(index))
         return space

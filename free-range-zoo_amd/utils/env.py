@@ -121,6 +121,53 @@ class LazySample(torch.Tensor):
         return func(*plain(args), **{k: plain(v) for k, v in (kwargs or {}).items()})
 
 
+_NO_SUBCLASS_DISPATCH = torch._C.DisableTorchFunctionSubclass
+# attribute reads that say nothing about the contents: they do not make pending steps run
+_METADATA_GETTERS = frozenset(getattr(torch.Tensor, name).__get__ for name in ('shape', 'dtype', 'device', 'ndim', 'is_cuda', 'layout', 'requires_grad'))
+
+
+class EnvTensor(torch.Tensor):
+    """A view of the env's device buffers as the env hands it out (``rewards[agent]``, ``num_moves``, ``state().fires``, ...) when steps may
+    be DEFERRED (``set_exclusive_device``: the reference-shaped random loop enqueues its steps in chunks — one multi-step launch per chunk
+    instead of one launch per step).  It is an ordinary tensor — same storage, same values — whose every use as a tensor (a torch function,
+    a method, indexing, ``.cpu()``, printing, ``data_ptr()``) first runs the steps that are still pending, so that what is read is what a
+    step-by-step execution would have left.  Views derived from it stay ``EnvTensor``s; everything else it produces is a plain tensor.
+    Like every tensor the env hands out: valid until the next ``step()`` / ``reset()``."""
+
+    @staticmethod
+    def __new__(cls, view, env):
+        t = torch.Tensor._make_subclass(cls, view)
+        t._env = env
+        return t
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        env = None
+        for a in args:
+            if type(a) is EnvTensor:
+                env = a._env
+                break
+        else:
+            for a in (kwargs or {}).values():
+                if type(a) is EnvTensor:
+                    env = a._env
+                    break
+            else:  # (nested in a list: torch.stack([...]), torch.cat([...]))
+                for a in args:
+                    if isinstance(a, (list, tuple)):
+                        for v in a:
+                            if type(v) is EnvTensor:
+                                env = v._env
+                                break
+        if env is not None and env._deferred and func not in _METADATA_GETTERS:
+            env._flush()
+        with _NO_SUBCLASS_DISPATCH():
+            out = func(*args, **(kwargs or {}))
+        if env is not None and type(out) is torch.Tensor and out._is_view():
+            return EnvTensor(out, env)
+        return out
+
+
 class BatchedParallelEnv:
     """Common constructor / bookkeeping of the three domains."""
 
@@ -238,6 +285,7 @@ class BatchedParallelEnv:
     def __getattr__(self, name):
         # only reached when normal lookup fails: a stale published output is rebuilt on demand
         if name in BatchedParallelEnv._LAZY_OUTPUTS and self.__dict__.get('_has_reset'):
+            self._flush()
             self._materialize()
             return self.__dict__[name]
         raise AttributeError(f'{type(self).__name__!r} object has no attribute {name!r}')
@@ -247,6 +295,35 @@ class BatchedParallelEnv:
         if self.exact_shapes:
             return LazyAgentDict(self, self.agents)
         return {agent: self.observations[agent] for agent in self.agents}
+
+    # -- deferred steps ------------------------------------------------------------------------------------------------------------
+    # With the device declared exclusive (set_exclusive_device) the library can run n steps as ONE launch that keeps the envs in registers
+    # (6.7 us per step inside it against ~10 us per single-step launch).  The reference-shaped random loop —
+    # `env.step({agent: env.action_space(agent).sample_nested() ...})` with the samples untouched — gives the env everything a step needs
+    # without looking at anything the step produces, so `step()` only COUNTS such a step; the pending steps run as one launch when the
+    # count reaches the current chunk size, or as soon as anything is looked at: every tensor the env hands out in this mode is an
+    # `EnvTensor` / `LazySample` / `LazyAgentDict`, and every method that reads or writes device state starts with `_flush()`.
+    _deferred: int = 0          # steps counted and not launched yet
+    _deferred_first: int = 0    # policy step (draw index) of the first of them
+    _deferred_seed: int = 0     # policy seed they were counted under
+    _defer_chunk: int = 0       # 0: deferral off; else the number of pending steps that triggers a launch (doubles from _DEFER_MIN to _DEFER_MAX while nobody looks)
+    _DEFER_MIN, _DEFER_MAX = 4, 32
+
+    def _flush(self) -> None:
+        """Launch the pending steps (one multi-step launch; a single pending step: the ordinary step launch)."""
+        n = self._deferred
+        if n:
+            self._deferred = 0
+            self._launch_deferred(n, self._deferred_first, self._deferred_seed)
+
+    def _launch_deferred(self, n: int, first: int, seed: int) -> None:
+        raise NotImplementedError
+
+    def _lazy(self, view: torch.Tensor) -> torch.Tensor:
+        """`view` as the env hands it out: an EnvTensor where steps may be deferred."""
+        return EnvTensor(view, self) if self._hands_out_lazy else view
+
+    _hands_out_lazy: bool = False  # set by the domains whose step() can defer (before their views are made)
 
     def _call(self, entry: str, c_args=(), op_args=None) -> None:
         """One stream-ordered launch of ``frz_<domain>_<entry>`` on the current stream of the env's device: a ctypes call into
@@ -266,7 +343,7 @@ class BatchedParallelEnv:
                 _capi.check(code, f'frz_{self._domain}_{entry}')
 
     def _host_read(self, stats: torch.Tensor) -> list:
-        """The one small device->host read of an exact-shapes publication: ``stats`` (int64 list lengths) and, in the same copy, the
+        """(pending steps have run: every caller flushes first.)  The one small device->host read of an exact-shapes publication: ``stats`` (int64 list lengths) and, in the same copy, the
         device error word — a prefix hand-off that timed out (FRZ_ERR_SCAN_TIMEOUT: another stream or process kept part of a launch
         from becoming resident) means the jagged offsets about to be used are wrong, so it is raised here rather than left for
         ``check()``.  Invalid-action bits stay for ``check()`` (sync-free contract of ``step``)."""
@@ -278,6 +355,7 @@ class BatchedParallelEnv:
 
     def _check_errors(self) -> None:
         """Raise the data-dependent errors the kernels flagged (reads one word from the device)."""
+        self._flush()
         flags = int(self._error_flags.item())
         if flags:
             self._error_flags.zero_()
@@ -348,6 +426,7 @@ class BatchedParallelEnv:
     def _materialize_samples(self) -> None:
         """The policy launch behind a ``LazySample`` that is being looked at (once per draw; after its step was taken the buffer holds
         what that step drew)."""
+        self._flush()  # (a sample that a counted step is about to draw: the step runs, the buffer then holds what it drew)
         pending = self.__dict__.get('_pending_samples')
         if pending is not None and not pending[3]:
             pending[3] = True
@@ -400,6 +479,7 @@ class BatchedParallelEnv:
         """
         if not self._has_reset:
             raise RuntimeError('reset() must be called before rollout()')
+        self._flush()
         if self.__dict__.get('_global_group', False) is not False and steps > 1:
             raise NotImplementedError('rollout() enqueues several steps without the per-step exchange of set_global_consistency()')
         if self.logger is not None:
@@ -470,6 +550,10 @@ class BatchedParallelEnv:
         read, no indices on the host.  (The MT19937 streams of the reset envs are re-seeded from the new seeds.)"""
         if not self._has_reset:
             raise RuntimeError('reset() must be called before reset_finished()')
+        self._flush()
+        symbol = f'frz_{self._domain}_reset_masked'
+        if symbol not in _capi.SIGNATURES:  # (the library has the device-mask partial reset for wildfire only)
+            raise NotImplementedError(f'{self._domain}_v0 has no device-side partial reset (no {symbol} in include/frz.h): use reset_batches(indices)')
         if mask is not None:
             mask = mask.to(device=self.device).view(torch.uint8) if mask.dtype == torch.bool else mask.to(device=self.device, dtype=torch.uint8)
             mask = mask.contiguous()
@@ -478,7 +562,6 @@ class BatchedParallelEnv:
         if self.rng == 'mt19937':
             selected = (mask != 0) if mask is not None else self.finished
             self._mt_reseed_mask = selected.clone()
-        symbol = f'frz_{self._domain}_reset_masked'
         _capi.check(getattr(self._lib, symbol)(self._handle, None if mask is None else mask.data_ptr(), int(seed_increment), stream_ptr(self.device)), symbol)
         if self.rng == 'mt19937' and not self.single_seeding:
             self.generator.reseed_where(self._mt_reseed_mask)
@@ -493,7 +576,14 @@ class BatchedParallelEnv:
         e.g. wildfire.py:584-700, called by code that edits ``env.state()`` between steps): one launch, then re-publish."""
         if not self._has_reset:
             raise RuntimeError('reset() must be called before update_observations()')
+        self._flush()
         self._call('rebuild')
+        self._publish()
+
+    def refresh(self) -> None:
+        """Publish what the buffers hold NOW (after ``graph.replay()`` of a captured rollout, which moves the env without going through
+        ``step()``): the exact-shapes outputs are rebuilt on their next access, spaces and samples take a new epoch.  No launch."""
+        self._flush()
         self._publish()
 
     def update_actions(self) -> None:
@@ -507,20 +597,24 @@ class BatchedParallelEnv:
         return self.observations[agent]
 
     def state(self):
+        self._flush()
         return self._state
 
     # `terminated` / `truncated` = all agents' flags (utils/env.py:331-359 of the reference): one reduction over the [A][B] flag block each
     # (the reference stacks the per-agent tensors first)
     @property
     def terminated(self) -> torch.Tensor:
+        self._flush()
         return self._terminations.all(dim=0)
 
     @property
     def truncated(self) -> torch.Tensor:
+        self._flush()
         return self._truncations.all(dim=0)
 
     @property
     def finished(self) -> torch.Tensor:
+        self._flush()
         return torch.logical_or(self._terminations.all(dim=0), self._truncations.all(dim=0))
 
     def close(self) -> None:

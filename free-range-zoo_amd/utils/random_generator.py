@@ -57,7 +57,7 @@ class RandomGenerator:
         if seed is None:
             shape = self.seeds.shape if partial_seeding is None else torch.as_tensor(partial_seeding).shape
             seed = torch.randint(100000000, shape, device=self.device)
-        seed = torch.as_tensor(seed, device=self.device).to(torch.int32)
+        seed = self._to_device(seed)
         if self.single_seeding:  # random_generator.py:59-65: a fresh generator's state, whatever the seed
             self.seeds[:] = seed.reshape(-1)[0] if seed.numel() >= 1 else seed
             self._single_state = torch.Generator(device='cpu').get_state()
@@ -73,6 +73,30 @@ class RandomGenerator:
             if self._streams_valid:
                 self._seed_streams(indices)
         self.has_been_seeded = True
+
+    def _to_device(self, seed) -> torch.Tensor:
+        """``seed`` as an int32 tensor on the device.  Host values are staged in a pinned buffer with a plain ``memmove`` and uploaded
+        asynchronously: reset() stays free of synchronisation points, and no torch CPU kernel runs on the way — a CPU tensor op of B
+        elements goes through torch's intra-op thread pool (128 threads on the GPU box), whose spinning workers exhaust the CFS quota of a
+        16-core cgroup within one 100 ms period; the kernel then freezes every thread of the process, the one enqueuing launches included,
+        for the rest of the period (the 85-95 ms stalls of round 3's per-step API leg: tools/dbg/api_stall_probe.py)."""
+        if isinstance(seed, torch.Tensor) and seed.device.type == 'cuda':
+            return seed.to(device=self.device, dtype=torch.int32)
+        host = torch.as_tensor(seed)
+        if host.dtype != torch.int32 or not host.is_contiguous():
+            host = host.to(torch.int32).contiguous()
+        n = host.numel()
+        staging = self.__dict__.get('_seed_staging')
+        if staging is None or staging[0].numel() < n:
+            staging = self._seed_staging = (torch.empty(max(n, 16), dtype=torch.int32, pin_memory=True), torch.cuda.Event())
+        else:
+            staging[1].synchronize()  # the previous upload out of this buffer has been consumed
+        if n:
+            import ctypes
+            ctypes.memmove(staging[0].data_ptr(), host.data_ptr(), 4 * n)
+        out = staging[0][:n].view(host.shape).to(self.device, non_blocking=True)
+        staging[1].record(torch.cuda.current_stream(self.device))
+        return out
 
     @torch.no_grad()
     def reseed_where(self, mask: torch.Tensor) -> None:

@@ -44,7 +44,10 @@ def _bound(value):
     if value is None:
         return None
     value = value.item() if hasattr(value, 'item') else value
-    return int(value) if float(value) == int(value) else float(value)
+    as_float = float(value)
+    if as_float != as_float or as_float in (float('inf'), float('-inf')):  # an open bound given as inf / nan stays a float
+        return as_float
+    return int(value) if as_float == int(value) else as_float
 
 
 def bounds(values) -> tuple:

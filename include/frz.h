@@ -339,6 +339,28 @@ int frz_wildfire_list_block(const frz_wildfire_env* env, void** block, int64_t* 
  * the reset envs (the FRZ_RNG_PHILOX key; MT19937 streams are re-seeded by the caller: frz_mt19937_seed_masked); then the observations and
  * lists of the whole batch are rebuilt.  Two launches, no host synchronisation. */
 int frz_wildfire_reset_masked(frz_wildfire_env* env, const uint8_t* mask, int32_t seed_increment, void* stream);
+/* The state a partial reset restores.  The reference's reset_batches puts back the state SAVED at reset (`self._state.restore_initial(
+ * batch_indices)`, wildfire.py:391; utils/state.py:36-60) — which is the caller's `options['initial_state']` when reset() was given one, not
+ * the configured initial state.  A binding that loads such a state tells the library where its saved copy lives: six strided device
+ * arrays (element (env b, item i) at ptr[b * stride_env + i * stride_item], in elements; items = cells for fires / intensity / fuel
+ * (int32), agents for suppressants / capacity (float32) / equipment (int32)).  From then on frz_wildfire_reset_masked — and
+ * FRZ_ROLLOUT_AUTO_RESET, which then always takes the per-step path — restore from it.  NULL: back to the configured initial state (what
+ * a plain reset() saves).  The arrays must stay alive and unchanged until the next call. */
+typedef struct frz_wildfire_saved_state {
+    const int32_t* fires;
+    int64_t fires_stride_env, fires_stride_item;
+    const int32_t* intensity;
+    int64_t intensity_stride_env, intensity_stride_item;
+    const int32_t* fuel;
+    int64_t fuel_stride_env, fuel_stride_item;
+    const float* suppressants;
+    int64_t suppressants_stride_env, suppressants_stride_item;
+    const float* capacity;
+    int64_t capacity_stride_env, capacity_stride_item;
+    const int32_t* equipment;
+    int64_t equipment_stride_env, equipment_stride_item;
+} frz_wildfire_saved_state;
+int frz_wildfire_set_saved_initial(frz_wildfire_env* env, const frz_wildfire_saved_state* saved);
 
 /* The caller states that nothing else runs on the device while this env's rollouts do (no other process, no concurrent stream): the
  * precondition of the multi-step launch, whose workgroups wait INSIDE the kernel for the other workgroups of their own grid (the batch

@@ -28,13 +28,18 @@ def test_two_rank_bench_prints_one_contract_line():
     assert line['value'] > 0 and abs(line['value'] - 2 * 65536 * 150 / (line['ms_per_step'] * 150 / 1e3)) / line['value'] < 1e-6
     assert 'cpu_baseline' not in line and 'secondary_workloads' not in line  # rank 0 at N = 1 only
     assert set(line['roofline']) >= {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'}
+    d = line['distributed']
+    assert d['world_size'] == 2 and d['ranks_in_all_reduce'] == 2 and d['collectives_in_timed_region'] == 0
+    # the one collective of the job (after the timed loop) saw both ranks' blocks
+    assert line['timing']['job_metrics']['env_steps_counted'] == 2 * 65536 * 150 * line['timing']['blocks']
 
 
 @pytest.mark.gpu
 def test_one_rank_bench_over_rccl():
     """bench.py under torch.distributed.run with ONE rank and no rehearsal switch: backend 'nccl' (= RCCL) is initialised on device 0 and the
-    job's collectives (the per-block metrics all-reduce, the barriers, the max over ranks) run on the GPU — the N > 1 code path with RCCL
-    itself, as far as one GPU can take it."""
+    job's collectives (the barriers, the max over ranks, the ONE metrics all-reduce after the timed loop) run on the GPU — the N > 1 code
+    path with RCCL itself, as far as one GPU can take it.  No collective sits inside a timed block; the line prices what one
+    per block would cost (`block_ms_median_with_a_collective_per_block`)."""
     env = {k: v for k, v in os.environ.items() if k != 'FRZ_BENCH_SHARE_DEVICE'}
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port', '29533',
            os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '20', '--warmup', '5', '--no-cpu-baseline', '--no-secondary']
@@ -48,6 +53,11 @@ def test_one_rank_bench_over_rccl():
     assert abs(line['ms_per_step'] * 20 - line['timing']['block_ms_median']) < 1e-9
     # every timed block stepped every env 20 times and the all-reduced metrics saw all of them
     assert line['timing']['job_metrics']['env_steps_counted'] == 65536 * 20 * line['timing']['blocks']
+    d = line['distributed']
+    assert d['backend'] == 'nccl' and d['collectives_in_timed_region'] == 0 and d['collective_probe_blocks'] >= 10
+    assert d['block_ms_median_without_collective'] > 0 and d['block_ms_median_with_a_collective_per_block'] > 0
+    print('one-rank RCCL: block median %.4f ms without, %.4f ms with an all-reduce per block' % (
+        d['block_ms_median_without_collective'], d['block_ms_median_with_a_collective_per_block']))
 
 
 @pytest.mark.gpu

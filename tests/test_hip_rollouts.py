@@ -315,6 +315,122 @@ def test_auto_reset_continues_across_launches(oracle):
 
 
 # ------------------------------------------------------------------------------------------------------------
+# 4b. ONE-step rollouts honour every option of the spec (`frz_*_rollout_launches(env, 1, mode)` returns n_steps = 1, which
+#     used to send a one-step rollout down the multi-step branch, where the single-step kernel ignored the spec)
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('family', ['roles', 'lane', 'grid'])
+def test_one_step_rollouts_honour_every_option(oracle, family, monkeypatch):
+    """rollout(1, auto_reset=True, record=True, metrics=...) step by step against the oracle's `step(); reset_batches(finished)` loop, then
+    rollout(1, reset_first=True, ...): in each wildfire kernel family, with the device declared exclusive (the case that went wrong)."""
+    from free_range_zoo_amd.envs.wildfire.env.structures.configuration import to_cstruct
+    monkeypatch.setenv('FRZ_WF_KERNEL', family)
+    B, horizon, steps, stride = 1500, 4, 11, 1000003
+    cfg = to_cstruct(configs.wildfire_openness(), B, horizon, track_cumulative_rewards=True)
+    env = make_env(configs.wildfire_openness, B, horizon, rng='philox', track_cumulative_rewards=True)
+    env.set_exclusive_device(True)
+    seeds = torch.arange(B, dtype=torch.int32) * 3 + 4
+    env.reset(seed=seeds)
+    metrics = torch.zeros(len(env.agents) + 2, dtype=torch.float64, device='cuda')
+    o, want_seeds, want = oracle_auto_reset_rollout(oracle, cfg, seeds.numpy(), 23, steps, stride, False)
+    replay = oracle.WildfireOracle(cfg)
+    replay.reset()
+    s = seeds.numpy().copy()
+    for t in range(steps):
+        rec = env.rollout(1, policy_seed=23, first_step=t, auto_reset=True, seed_stride=stride, record=True, metrics=metrics)
+        assert rec['lists'].shape[0] == 0  # (n - 1 copies: the step's own lists are in the env's buffers)
+        G.assert_same(np_(rec['actions'])[0], want['actions'][t], f'{family} step {t} sampled actions')
+        G.assert_same(np_(rec['rewards'])[0], want['rewards'][t], f'{family} step {t} rewards')
+        G.assert_same(np_(rec['dones'])[0, 0].astype(bool), want['term'][t], f'{family} step {t} terminations')
+        G.assert_same(np_(rec['dones'])[0, 1].astype(bool), want['trunc'][t], f'{family} step {t} truncations')
+        acts = oracle.wildfire_random_policy(cfg, replay.agent_task_count, replay.env_task_count, s, 23, t)
+        fr, ar = oracle.wildfire_philox_randomness(cfg, s, replay.num_moves)
+        replay.step(acts, fr, ar)
+        replay.reset_masked(None, s, stride)
+        compare_snapshots(hip_snapshot(env), oracle_snapshot(replay), f'{family}: after one-step rollout {t} with auto-reset')
+    assert sum(int((a | b).sum()) for a, b in zip(want['term'], want['trunc'])) > B, 'the case must actually reset envs'
+    G.assert_same(np_(env.seeds), want_seeds, 'seeds')
+    np.testing.assert_allclose(metrics.cpu().numpy(), want['metrics'], rtol=1e-9)
+    # the opening reset of a one-step rollout (fresh seeds), its tapes and its metrics
+    m2 = torch.zeros_like(metrics)
+    rec = env.rollout(1, policy_seed=5, reset_first=True, seed_increment=77, record=True, metrics=m2)
+    new_seeds = (want_seeds.astype(np.int64) + 77).astype(np.int32)
+    G.assert_same(np_(env.seeds), new_seeds, 'seeds after the folded-in reset')
+    fresh = oracle.WildfireOracle(cfg)
+    fresh.reset()
+    acts = oracle.wildfire_random_policy(cfg, fresh.agent_task_count, fresh.env_task_count, new_seeds, 5, 0)
+    fr, ar = oracle.wildfire_philox_randomness(cfg, new_seeds, fresh.num_moves)
+    fresh.step(acts, fr, ar)
+    G.assert_same(np_(rec['actions'])[0], acts, f'{family}: actions of the one-step rollout with the reset folded in')
+    G.assert_same(np_(rec['rewards'])[0], fresh.rewards, f'{family}: rewards of the one-step rollout with the reset folded in')
+    compare_snapshots(hip_snapshot(env), oracle_snapshot(fresh), f'{family}: one-step rollout with the reset folded in')
+    want_m = np.concatenate([fresh.cumulative_rewards.astype(np.float64).sum(axis=1), [float(fresh.num_moves.sum())],
+                             [float((fresh.terminations[0].astype(bool) | fresh.truncations[0].astype(bool)).sum())]])
+    np.testing.assert_allclose(m2.cpu().numpy(), want_m, rtol=1e-12)
+    env.check()
+
+
+def test_one_step_graph_capture_keeps_the_reset_and_the_metrics(oracle):
+    """capture_random_rollout with steps % episode_length == 1: the trailing one-step episode must still reset and count."""
+    from free_range_zoo_amd.envs.wildfire.env.structures.configuration import to_cstruct
+    B, horizon = 2048, 5
+    cfg = to_cstruct(configs.wildfire_openness(), B, horizon, track_cumulative_rewards=True)
+    env = make_env(configs.wildfire_openness, B, horizon, rng='philox', track_cumulative_rewards=True)
+    env.set_exclusive_device(True)
+    seeds = torch.arange(B, dtype=torch.int32)
+    env.reset(seed=seeds)
+    metrics = torch.zeros(len(env.agents) + 2, dtype=torch.float64, device='cuda')
+    graph = env.capture_random_rollout(horizon + 1, policy_seed=12, include_reset=True, episode_length=horizon, seed_stride=9, metrics=metrics)
+    graph.replay()
+    torch.cuda.synchronize()
+    env.refresh()  # (a replay moves the env without going through step(): publish what the buffers hold now)
+    s1 = (seeds.numpy().astype(np.int64) + 9).astype(np.int32)
+    first = oracle.WildfireOracle(cfg)
+    first.reset()
+    first.rollout(s1, 12, 0, horizon)
+    s2 = (s1.astype(np.int64) + 9).astype(np.int32)
+    last = oracle.WildfireOracle(cfg)
+    last.reset()
+    last.rollout(s2, 12, 0, 1)
+    compare_snapshots(hip_snapshot(env), oracle_snapshot(last), 'after the trailing one-step episode of the graph')
+    want = np.zeros(len(env.agents) + 2)
+    for o in (first, last):
+        want += np.concatenate([o.cumulative_rewards.astype(np.float64).sum(axis=1), [float(o.num_moves.sum())],
+                                [float((o.terminations[0].astype(bool) | o.truncations[0].astype(bool)).sum())]])
+    np.testing.assert_allclose(metrics.cpu().numpy(), want, rtol=1e-12)
+
+
+def test_reset_finished_says_so_where_the_library_has_no_device_side_partial_reset():
+    import test_hip_cybersecurity as C
+    env = C.make_env(configs.cyber_openness, 64, 10, rng='philox')
+    env.reset(seed=torch.arange(64, dtype=torch.int32))
+    with pytest.raises(NotImplementedError, match='reset_batches'):
+        env.reset_finished()
+
+
+def test_cybersecurity_one_step_rollout_honours_the_spec(oracle):
+    import test_hip_cybersecurity as C
+    from free_range_zoo_amd.envs.cybersecurity.env.structures.configuration import to_cstruct
+    B = 1800
+    cfg = to_cstruct(configs.cyber_openness(), B, 50, **configs.CYBER_DEFAULT_FLAGS)
+    env = C.make_env(configs.cyber_openness, B, 50, rng='philox')
+    env.set_exclusive_device(True)
+    seeds = torch.arange(B, dtype=torch.int32) + 11
+    env.reset(seed=seeds)
+    env.rollout(6, policy_seed=1)
+    rec = env.rollout(1, policy_seed=4, reset_first=True, record=True)
+    o = oracle.CybersecurityOracle(cfg)
+    o.reset()
+    acts = oracle.cybersecurity_random_policy(cfg, o.agent_task_count, o.location, seeds.numpy(), 4, 0)
+    nr, ar = oracle.cybersecurity_philox_randomness(cfg, seeds.numpy(), o.num_moves)
+    o.step(acts, nr, ar)
+    G.assert_same(np_(rec['actions'])[0], acts, 'actions of the one-step rollout')
+    G.assert_same(np_(rec['rewards'])[0], o.rewards, 'rewards of the one-step rollout')
+    G.assert_same(np_(rec['dones'])[0, 1].astype(bool), o.truncations[0].astype(bool), 'truncations of the one-step rollout')
+    C.compare_snapshots(C.hip_snapshot(env), C.oracle_snapshot(o), 'one-step rollout with the reset folded in')
+    env.check()
+
+
+# ------------------------------------------------------------------------------------------------------------
 # 5. reset_finished(mask): reset_batches with the selection on the device, against the reference's recordings
 # ------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('label', ['wildfire', 'wildfire_bad_actions', 'wildfire_grid8x8'])
@@ -342,6 +458,50 @@ def test_masked_reset_matches_the_recorded_partial_reset(label):
         G.assert_same(got.astype(data[key].dtype), data[key], f'{label} {key}')
     _replay(env, data, 'b', 5, names, sizes, G.compare_wildfire, hip_snapshot, A, label)
     env.check()
+
+
+@pytest.mark.parametrize('family', ['roles', 'lane', 'grid'])
+@pytest.mark.parametrize('via', ['reset_finished', 'auto_reset_rollout'])
+def test_device_side_partial_resets_restore_the_saved_state(oracle, family, via, monkeypatch):
+    """After reset(options={'initial_state': ...}) the reference's reset_batches restores THAT state (`self._state.restore_initial`,
+    wildfire.py:391), not the configured one: the device-mask reset and the auto-reset rollouts must too.  Checked
+    against the host-index path (`reset_batches`, itself pinned by tests/golden/partial_wildfire_grid8x8.npz) on a twin env."""
+    monkeypatch.setenv('FRZ_WF_KERNEL', family)
+    B, horizon = 700, 6
+    envs = [make_env(configs.wildfire_openness, B, horizon, rng='philox') for _ in range(2)]
+    seeds = torch.arange(B, dtype=torch.int32) + 3
+    for env in envs:
+        env.set_exclusive_device(True)
+        env.reset(seed=seeds)
+    envs[0].rollout(3, policy_seed=2)  # a state that is not the configured one: three steps in, per env different
+    custom = envs[0].state().clone()
+    for env in envs:
+        env.reset(seed=seeds, options={'initial_state': custom})
+    a, b = envs
+    for t in range(10):
+        if via == 'reset_finished':
+            a.rollout(1, policy_seed=6, first_step=t)
+            a.reset_finished(seed_increment=13)
+        else:
+            a.rollout(1, policy_seed=6, first_step=t, auto_reset=True, seed_stride=13)
+        b.rollout(1, policy_seed=6, first_step=t)
+        finished = b.finished.nonzero().reshape(-1)
+        if finished.numel():
+            b.reset_batches(finished, seed=(b.seeds[finished].to(torch.int64) + 13).to(torch.int32))
+        compare_snapshots(hip_snapshot(a), hip_snapshot(b), f'{family}/{via}: step {t}')
+        G.assert_same(np_(a.seeds), np_(b.seeds), 'seeds')
+    # a multi-step auto-reset rollout with a saved state takes the per-step path and lands in the same place
+    if via == 'auto_reset_rollout':
+        a.rollout(7, policy_seed=6, first_step=10, auto_reset=True, seed_stride=13)
+        for t in range(10, 17):
+            b.rollout(1, policy_seed=6, first_step=t)
+            finished = b.finished.nonzero().reshape(-1)
+            if finished.numel():
+                b.reset_batches(finished, seed=(b.seeds[finished].to(torch.int64) + 13).to(torch.int32))
+        compare_snapshots(hip_snapshot(a), hip_snapshot(b), f'{family}: seven more steps in one call')
+    assert int(np_(a.num_moves).min()) < 3, 'the case must actually restart envs'
+    for env in envs:
+        env.check()
 
 
 @pytest.mark.parametrize('family', ['roles', 'lane', 'grid'])

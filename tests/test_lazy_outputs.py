@@ -106,6 +106,84 @@ def test_reference_shaped_random_rollout_draws_inside_the_step_launch():
     fused.check()
 
 
+@pytest.mark.parametrize('rng', ['philox', 'mt19937'])
+def test_deferred_steps_of_the_reference_shaped_loop_equal_step_by_step(rng):
+    """With the device declared exclusive the reference-shaped random loop only COUNTS its steps and runs them in chunks — one multi-step
+    launch per chunk (utils/env.py: deferred steps).  Whatever is looked at, whenever, must be what a step-by-step execution leaves: a twin env
+    that launches every step is stepped alongside, and at seeded-random points one of the things a caller can look at is compared — the
+    returned dicts, public attributes, the state object taken BEFORE the steps, spaces, an old sample — then everything at every episode end."""
+    import random
+    from free_range_zoo_amd.envs import wildfire_v0
+    from free_range_zoo_amd.utils.env import EnvTensor
+    from test_hip_wildfire import compare_snapshots, hip_snapshot
+    B, horizon = 3001, 30
+    lazy, eager = [wildfire_v0.parallel_env(configuration=configs.wildfire_openness(), parallel_envs=B, max_steps=horizon, device=torch.device('cuda'),
+                                            rng=rng) for _ in range(2)]
+    assert lazy.set_exclusive_device(True) and lazy._defer_chunk > 0 and eager._defer_chunk == 0
+    lazy._deferred_log = log = []
+    picker = random.Random(7)
+    held_state = None
+    steps_taken = 0
+    for episode in range(3):
+        seeds = torch.arange(B, dtype=torch.int32) * 3 + episode
+        for env in (lazy, eager):
+            env.reset(seed=seeds)
+        if held_state is None:
+            held_state = (lazy.state(), eager.state())  # views: they show the current state whenever they are looked at
+        for t in range(horizon + 4):  # past the horizon: frozen steps are counted like any other
+            a = {agent: lazy.action_space(agent).sample_nested() for agent in lazy.agents}
+            out_l = lazy.step(a)
+            out_e = eager.step({agent: eager.action_space(agent).sample_nested() for agent in eager.agents})
+            steps_taken += 1
+            agent = lazy.agents[picker.randrange(len(lazy.agents))]
+            peek = picker.randrange(14)
+            if peek == 0:
+                assert type(out_l[1][agent]) is EnvTensor and torch.equal(out_l[1][agent], out_e[1][agent]), f'rewards at {episode}/{t}'
+            elif peek == 1:
+                assert torch.equal(lazy.num_moves, eager.num_moves) and int(lazy.num_moves.max()) == min(t + 1, horizon)
+            elif peek == 2:
+                assert bool(lazy.finished.all()) == bool(eager.finished.all())
+            elif peek == 3:
+                assert torch.equal(out_l[0][agent]['self'], out_e[0][agent]['self']) and torch.equal(out_l[0][agent]['tasks'].values(), out_e[0][agent]['tasks'].values())
+            elif peek == 4:
+                assert torch.equal(held_state[0].fires, held_state[1].fires) and torch.equal(held_state[0].suppressants, held_state[1].suppressants)
+            elif peek == 5:
+                assert lazy.environment_task_count.tolist() == eager.environment_task_count.tolist()
+            elif peek == 6:
+                assert torch.equal(a[agent].clone(), eager._sampled_actions[lazy.agents.index(agent)]), 'the sample a counted step drew'
+            elif peek == 7:
+                assert torch.equal(out_l[4]['burnouts'], out_e[4]['burnouts']) and torch.equal(out_l[2][agent], out_e[2][agent])
+            elif peek == 8:
+                assert lazy.action_space(agent).spaces[:40] == eager.action_space(agent).spaces[:40]
+            elif peek == 9:
+                assert torch.equal(lazy.agent_action_mapping[agent].values(), eager.agent_action_mapping[agent].values())
+            elif peek == 10:
+                assert float(lazy._cumulative_rewards[agent].sum()) == float(eager._cumulative_rewards[agent].sum())
+            # (11-13: nobody looks: the chunk grows)
+        compare_snapshots(hip_snapshot(lazy), hip_snapshot(eager), f'{rng}: end of episode {episode}')
+        assert torch.equal(lazy.seeds, eager.seeds)
+    lazy.check()
+    assert sum(log) == steps_taken and max(log) > 2, f'chunks launched: {log}'
+
+
+def test_reference_shaped_loop_with_mt19937_streams_across_resets():
+    """The default RNG mode: the step launch of the untouched-samples path advances the env's own MT19937 streams, which a reset with new
+    seeds restarts — also on the second and third episode (the streams used to be expanded only once per env object)."""
+    from free_range_zoo_amd.envs import wildfire_v0
+    B = 777
+    fused, plain = [wildfire_v0.parallel_env(configuration=configs.wildfire_openness(), parallel_envs=B, max_steps=12, device=torch.device('cuda'))
+                    for _ in range(2)]
+    for episode in range(3):
+        seeds = torch.arange(B, dtype=torch.int32) + 100 * episode
+        fused.reset(seed=seeds), plain.reset(seed=seeds)
+        for t in range(12):
+            fused.step({agent: fused.action_space(agent).sample_nested() for agent in fused.agents})
+            plain.step(plain.random_policy_actions(plain.policy_seed, 12 * episode + t).clone())
+            for name in ('_fires', '_intensity', '_fuel', '_suppressants', '_rewards', '_task_offsets'):
+                assert torch.equal(getattr(fused, name), getattr(plain, name)), f'{name} at episode {episode} step {t}'
+    fused.check()
+
+
 def test_observations_of_an_earlier_step_refuse_to_fill_late():
     """The dict step() returns stands for THAT step: filled after the next step it would hold the next step's observations — it
     raises instead; looked at in time (or copied) it keeps working."""

@@ -151,3 +151,11 @@ def test_wildfire_builders_reproduce_the_recorded_reference_spaces(name):
                                                                      kwargs.get('observe_other_suppressant', False), kwargs.get('observe_other_power', False)))
             assert got['kind'] == str(data['observation_container'])
             assert got['spaces'] == [table[i] for i in data[f'{prefix}observation_{a}']], f'{name} {prefix} observation space of agent {a}'
+
+
+def test_open_bounds_given_as_infinity_stay_floats():
+    """`int(inf)` raised OverflowError inside Box."""
+    from free_range_zoo_amd.utils import spaces
+    box = spaces.Box([0, float('-inf')], [float('inf'), 2.5])
+    assert box.low == [0, float('-inf')] and box.high == [float('inf'), 2.5]
+    assert spaces.bounds((3.0, float('inf'), None)) == (3, float('inf'), None)
