@@ -652,6 +652,73 @@ def main():
                               'kernel': f'wf_roles_kernel<6,3,exact,{args.rng},step,multi-step> with auto-reset', 'steps_per_launch': n_block,
                               'kernel_ms_avg': dense_ms, 'kernel_ms_per_step': dense_ms / n_block, 'algorithmic_bytes_per_env_step': dense_per_env}}
 
+    # ---- a rollout a learner can consume (missing #5): the same K-step block with EVERYTHING kept per step — reward / done /
+    # sampled-action tapes, the list record (every step's packed lists: the `tasks` of the observations, the action mappings) and the
+    # observation tape in its compact form (the suppressant column, the only part of the self / others records a step changes) — the EXTRA
+    # instantiation of the multi-step kernel.  N = 1 only, never part of `value`.
+    recorded = None
+    if multi_step and args.rng == 'philox' and K > 1 and world == 1 and not args.no_episode_probe:
+        block, nbytes = ctypes.c_void_p(), ctypes.c_int64()
+        _capi.check(lib.frz_wildfire_list_block(handle, ctypes.byref(block), ctypes.byref(nbytes)), 'frz_wildfire_list_block')
+        rec_specs, rec_keep = [], []
+        for first in range(0, K, EPISODE):
+            n = min(EPISODE, K - first)
+            tapes = {'rewards': torch.zeros((n, A, B), dtype=torch.float32, device=device), 'dones': torch.zeros((n, 2, B), dtype=torch.uint8, device=device),
+                     'actions': torch.zeros((n, A, B, 2), dtype=torch.int32, device=device), 'lists': torch.zeros((max(n - 1, 1), nbytes.value), dtype=torch.uint8, device=device),
+                     'observations': torch.zeros((n, A, B), dtype=torch.float32, device=device)}
+            spec = _capi.frz_rollout_spec()
+            spec.n_steps, spec.rng_mode, spec.policy_seed, spec.first_step = n, mode, policy_seed, 0
+            spec.flags, spec.seed_increment = _capi.FRZ_ROLLOUT_RESET_FIRST | _capi.FRZ_ROLLOUT_OBS_COMPACT, seed_stride
+            spec.actions_out, spec.record_actions, spec.metrics = tapes['actions'].data_ptr(), 1, metrics.data_ptr()
+            spec.reward_tape, spec.done_tape, spec.obs_tape = tapes['rewards'].data_ptr(), tapes['dones'].data_ptr(), tapes['observations'].data_ptr()
+            spec.list_record = tapes['lists'].data_ptr() if n > 1 else None
+            rec_specs.append(spec)
+            rec_keep.append(tapes)
+        rec_refs = [ctypes.byref(spec) for spec in rec_specs]
+        tape_bytes_per_block = sum(sum(t.numel() * t.element_size() for t in tapes.values()) for tapes in rec_keep)
+
+        def recorded_block():
+            for ref in rec_refs:
+                lib.frz_wildfire_rollout(handle, ref, stream)
+            done_event.record()
+            while not done_event.query():
+                pass
+            torch.cuda.synchronize(device)
+
+        env.reset(seed=base_seed)
+        for _ in range(3):
+            recorded_block()
+        rec_s = []
+        for _ in range(min(repeats, 200)):
+            barrier()
+            t0 = time.perf_counter()
+            recorded_block()
+            rec_s.append(time.perf_counter() - t0)
+        barrier()
+        rec_median = float(np.median(rec_s))
+        rec_launch = []
+        for i in range(10):
+            env.reset(seed=base_seed + 17)
+            one = ctypes.c_float()
+            _capi.check(lib.frz_wildfire_timed_rollout_spec(handle, rec_refs[0], stream, ctypes.byref(one)), 'frz_wildfire_timed_rollout_spec')
+            rec_launch.append(one.value)
+        rec_launch = rec_launch[2:]
+        tape_bytes = 4 * A + 2 + 8 * A + 4 * A  # rewards + dones + sampled actions + suppressants, per env-step (the lists go to the record instead of the scratch copy)
+        rec_per_env = bytes_per_env_step(n_block) + tape_bytes
+        rec_ms = float(np.mean(rec_launch))
+        recorded = {'value': B * K / rec_median, 'unit': 'env-steps/s', 'ms_per_step': 1e3 * rec_median / K, 'blocks': len(rec_s),
+                    'keeps_per_step': 'rewards f32[A][B], (terminated, truncated) u8[2][B], sampled actions i32[A][B][2], the packed-list block (task rows = the '
+                                      'observations\' `tasks`, action / observation mappings, offsets), suppressants f32[A][B] (the compact observation tape: '
+                                      'env.recorded_observations(rec, t) rebuilds {agent: self, others, tasks})',
+                    'tape_bytes_per_block': tape_bytes_per_block,
+                    'roofline': {'bound': 'hbm', 'achieved': rec_per_env * B * n_block / (rec_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                 'frac': rec_per_env * B * n_block / (rec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 'frac_at_ms_per_step': rec_per_env * B / (rec_median / K) / 1e9 / HBM_PEAK_GBS, 'traffic': None,
+                                 'kernel': f'wf_roles_kernel<6,3,exact,{args.rng},step,multi-step,EXTRA> (every option of frz_rollout_spec)',
+                                 'steps_per_launch': n_block, 'kernel_ms_avg': rec_ms, 'kernel_ms_per_step': rec_ms / n_block,
+                                 'algorithmic_bytes_per_env_step': rec_per_env, 'of_which_tapes': tape_bytes}}
+        del rec_keep, rec_specs
+
     if rank == 0:
         env.check()
         episodes_per_block = math.ceil(K / EPISODE)
@@ -719,6 +786,7 @@ def main():
                                                   if episode_launch_ms else None),
                          'frac_at_driver_ms_per_step': per_env * B / (median_s / K) / 1e9 / HBM_PEAK_GBS},
             'auto_reset_workload': dense,
+            'recorded_rollout_workload': recorded,
             'reference_cpu_env_steps_per_s': {'value': 21112, 'source': 'BASELINE.md §2: unmodified reference, 8 vCPU, B=65536 (survey container)'},
         }
         if world == 1 and not args.no_cpu_baseline:

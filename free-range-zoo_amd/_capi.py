@@ -67,6 +67,8 @@ SIGNATURES = {
     'frz_wildfire_rollout': (ctypes.c_int, [_P, _P, _P]),
     'frz_wildfire_timed_rollout_spec': (ctypes.c_int, [_P, _P, _P, ctypes.POINTER(ctypes.c_float)]),
     'frz_wildfire_list_block': (ctypes.c_int, [_P, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64)]),
+    'frz_wildfire_obs_block': (ctypes.c_int, [_P, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
+    'frz_wildfire_state_block': (ctypes.c_int, [_P, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64)]),
     'frz_wildfire_reset_masked': (ctypes.c_int, [_P, _P, ctypes.c_int32, _P]),
     'frz_wildfire_set_saved_initial': (ctypes.c_int, [_P, _P]),
     'frz_cybersecurity_create': (ctypes.c_int, [_P, ctypes.POINTER(_P)]),
@@ -84,6 +86,8 @@ SIGNATURES = {
     'frz_rideshare_rollout': (ctypes.c_int, [_P, _P, _P]),
     'frz_rideshare_list_block': (ctypes.c_int, [_P, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64)]),
     'frz_cybersecurity_list_block': (ctypes.c_int, [_P, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64)]),
+    'frz_cybersecurity_obs_block': (ctypes.c_int, [_P, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64)]),
+    'frz_cybersecurity_state_block': (ctypes.c_int, [_P, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64)]),
     'frz_cybersecurity_set_exclusive_device': (ctypes.c_int, [_P, ctypes.c_int]),
     'frz_cybersecurity_rollout_launches': (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int]),
     'frz_rideshare_create': (ctypes.c_int, [_P, _P, ctypes.POINTER(_P)]),

@@ -1584,6 +1584,25 @@ int frz_cybersecurity_list_block(const frz_cybersecurity_env* env, void** block,
     return FRZ_OK;
 }
 
+int frz_cybersecurity_obs_block(const frz_cybersecurity_env* env, void** block, int64_t* bytes) {
+    if (!env || !block || !bytes) return FRZ_E_INVALID;
+    if (!env->arena) return FRZ_E_UNBOUND;
+    *block = env->arena + env->dev.off_self_att;
+    *bytes = env->dev.off_act_values - env->dev.off_self_att;
+    return FRZ_OK;
+}
+
+int frz_cybersecurity_state_block(const frz_cybersecurity_env* env, void** rows, int64_t* rows_bytes, void** presence, int64_t* presence_bytes) {
+    if (!env || !rows || !rows_bytes || !presence || !presence_bytes) return FRZ_E_INVALID;
+    if (!env->arena) return FRZ_E_UNBOUND;
+    const CyDev& p = env->dev;
+    *rows = env->arena + p.off_rows4 + (int64_t)p.r_state * p.B * 4;
+    *rows_bytes = (int64_t)(p.N + 2 * p.D) * p.B * 4;
+    *presence = env->arena + p.off_rows1 + (int64_t)p.u_presence * p.B;
+    *presence_bytes = (int64_t)p.A * p.B;
+    return FRZ_OK;
+}
+
 int frz_cybersecurity_rollout(frz_cybersecurity_env* env, const frz_rollout_spec* spec, void* stream) {
     if (!env || !spec || spec->n_steps < 0) return FRZ_E_INVALID;
     if (!env->arena) return FRZ_E_UNBOUND;
@@ -1600,7 +1619,9 @@ int frz_cybersecurity_rollout(frz_cybersecurity_env* env, const frz_rollout_spec
     const int64_t B = p.B, A = p.A, N = p.N, AB2 = A * B * 2;
     const int64_t block_bytes = p.off_obs_map - p.off_act_values;
 
-    if (spec->n_steps > 1 && frz_cybersecurity_rollout_launches(env, spec->n_steps, mode) == 1) {  // ONE multi-step launch
+    if (spec->flags & FRZ_ROLLOUT_OBS_COMPACT) return FRZ_E_INVALID;  // (every column of this domain's observation rows can change)
+    const bool dense_tapes = spec->obs_tape != nullptr || spec->state_tape != nullptr;  // whole blocks: copied out between the steps' launches
+    if (spec->n_steps > 1 && !dense_tapes && frz_cybersecurity_rollout_launches(env, spec->n_steps, mode) == 1) {  // ONE multi-step launch
         frz_cybersecurity_env::RolloutOptions& o = env->rollout;
         o.extra = !policy || spec->list_record || spec->reward_tape || spec->done_tape || spec->record_actions || reset_first;
         o.flags = spec->flags;
@@ -1647,6 +1668,18 @@ int frz_cybersecurity_rollout(frz_cybersecurity_env* env, const frz_rollout_spec
         if (spec->list_record && t < spec->n_steps - 1)
             ok = ok && hipMemcpyAsync(static_cast<char*>(spec->list_record) + (int64_t)t * block_bytes, env->arena + p.off_act_values, (size_t)block_bytes,
                                       hipMemcpyDeviceToDevice, s) == hipSuccess;
+        if (spec->obs_tape) {
+            const int64_t obs_bytes = p.off_act_values - p.off_self_att;
+            ok = ok && hipMemcpyAsync(static_cast<char*>(spec->obs_tape) + (int64_t)t * obs_bytes, env->arena + p.off_self_att, (size_t)obs_bytes,
+                                      hipMemcpyDeviceToDevice, s) == hipSuccess;
+        }
+        if (spec->state_tape) {
+            const int64_t rows_bytes = (int64_t)(N + 2 * p.D) * B * 4, pres_bytes = A * B;
+            char* const dst = static_cast<char*>(spec->state_tape) + (int64_t)t * align_up(rows_bytes + pres_bytes, 256);  // (a step starts aligned)
+            ok = ok && hipMemcpyAsync(dst, env->arena + p.off_rows4 + (int64_t)p.r_state * B * 4, (size_t)rows_bytes, hipMemcpyDeviceToDevice, s) == hipSuccess;
+            ok = ok && hipMemcpyAsync(dst + rows_bytes, env->arena + p.off_rows1 + (int64_t)p.u_presence * B, (size_t)pres_bytes, hipMemcpyDeviceToDevice, s) ==
+                           hipSuccess;
+        }
         if (!ok) return FRZ_E_LAUNCH;
     }
     return FRZ_OK;

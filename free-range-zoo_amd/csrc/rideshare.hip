@@ -1110,6 +1110,7 @@ int frz_rideshare_rollout(frz_rideshare_env* env, const frz_rollout_spec* spec, 
     const bool policy = spec->action_tape == nullptr, reset_first = (spec->flags & FRZ_ROLLOUT_RESET_FIRST) != 0;
     if (policy && !spec->actions_out) return FRZ_E_INVALID;
     if ((spec->flags & FRZ_ROLLOUT_AUTO_RESET) || spec->metrics || spec->seed_increment != 0) return FRZ_E_INVALID;
+    if (spec->obs_tape || spec->state_tape || (spec->flags & FRZ_ROLLOUT_OBS_COMPACT)) return FRZ_E_INVALID;  // (observation / state tapes: wildfire, cybersecurity)
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (reset_first) {
         const int rc = frz_rideshare_reset(env, stream);

@@ -197,28 +197,48 @@ void wildfire_rollout(at::Tensor arena, int64_t handle, int64_t steps, int64_t r
                       int64_t policy_seed, int64_t first_step, const c10::optional<at::Tensor>& action_tape, const c10::optional<at::Tensor>& randomness_a,
                       const c10::optional<at::Tensor>& randomness_b, const c10::optional<at::Tensor>& actions_out, bool record_actions,
                       const c10::optional<at::Tensor>& reward_tape, const c10::optional<at::Tensor>& done_tape, const c10::optional<at::Tensor>& list_record,
-                      const c10::optional<at::Tensor>& metrics) {
+                      const c10::optional<at::Tensor>& metrics, const c10::optional<at::Tensor>& obs_tape, const c10::optional<at::Tensor>& state_tape) {
     const Env e = checked(arena, handle, kWildfire, "wildfire_rollout");
+    frz_wildfire_env* const env = static_cast<frz_wildfire_env*>(e.handle);
     void* block = nullptr;
     int64_t block_bytes = 0;
-    ok(frz_wildfire_list_block(static_cast<frz_wildfire_env*>(e.handle), &block, &block_bytes), "frz_wildfire_list_block");
-    const frz_rollout_spec spec = make_spec(arena, e, 3 * e.B * e.U, 5 * e.B * e.A, block_bytes, steps, rng_mode, flags, seed_increment, seed_stride, policy_seed,
-                                            first_step, action_tape, randomness_a, randomness_b, actions_out, record_actions, reward_tape, done_tape, list_record,
-                                            metrics);
+    ok(frz_wildfire_list_block(env, &block, &block_bytes), "frz_wildfire_list_block");
+    frz_rollout_spec spec = make_spec(arena, e, 3 * e.B * e.U, 5 * e.B * e.A, block_bytes, steps, rng_mode, flags, seed_increment, seed_stride, policy_seed,
+                                      first_step, action_tape, randomness_a, randomness_b, actions_out, record_actions, reward_tape, done_tape, list_record,
+                                      metrics);
+    {   // observation / state tapes: byte tensors of the sizes the library's own block queries give (v5)
+        void *obs = nullptr, *cells = nullptr, *agents = nullptr;
+        int64_t obs_bytes = 0, others_offset = 0, cells_bytes = 0, agents_bytes = 0;
+        ok(frz_wildfire_obs_block(env, &obs, &obs_bytes, &others_offset), "frz_wildfire_obs_block");
+        ok(frz_wildfire_state_block(env, &cells, &cells_bytes, &agents, &agents_bytes), "frz_wildfire_state_block");
+        const int64_t per_step = (flags & FRZ_ROLLOUT_OBS_COMPACT) ? e.A * e.B * 4 : obs_bytes;
+        spec.obs_tape = tape_or_null<uint8_t>(arena, obs_tape, at::kByte, steps * per_step, "obs_tape");
+        spec.state_tape = tape_or_null<uint8_t>(arena, state_tape, at::kByte, steps * (cells_bytes + agents_bytes), "state_tape");
+    }
     ok(frz_wildfire_rollout(static_cast<frz_wildfire_env*>(e.handle), &spec, current_stream(arena)), "frz_wildfire_rollout");
 }
 void cybersecurity_rollout(at::Tensor arena, int64_t handle, int64_t steps, int64_t rng_mode, int64_t flags, int64_t seed_increment, int64_t seed_stride,
                            int64_t policy_seed, int64_t first_step, const c10::optional<at::Tensor>& action_tape,
                            const c10::optional<at::Tensor>& randomness_a, const c10::optional<at::Tensor>& randomness_b,
                            const c10::optional<at::Tensor>& actions_out, bool record_actions, const c10::optional<at::Tensor>& reward_tape,
-                           const c10::optional<at::Tensor>& done_tape, const c10::optional<at::Tensor>& list_record, const c10::optional<at::Tensor>& metrics) {
+                           const c10::optional<at::Tensor>& done_tape, const c10::optional<at::Tensor>& list_record, const c10::optional<at::Tensor>& metrics,
+                           const c10::optional<at::Tensor>& obs_tape, const c10::optional<at::Tensor>& state_tape) {
     const Env e = checked(arena, handle, kCybersecurity, "cybersecurity_rollout");
+    frz_cybersecurity_env* const env = static_cast<frz_cybersecurity_env*>(e.handle);
     void* block = nullptr;
     int64_t block_bytes = 0;
-    ok(frz_cybersecurity_list_block(static_cast<frz_cybersecurity_env*>(e.handle), &block, &block_bytes), "frz_cybersecurity_list_block");
-    const frz_rollout_spec spec = make_spec(arena, e, e.B * e.U, e.B * e.A, block_bytes, steps, rng_mode, flags, seed_increment, seed_stride, policy_seed,
-                                            first_step, action_tape, randomness_a, randomness_b, actions_out, record_actions, reward_tape, done_tape, list_record,
-                                            metrics);
+    ok(frz_cybersecurity_list_block(env, &block, &block_bytes), "frz_cybersecurity_list_block");
+    frz_rollout_spec spec = make_spec(arena, e, e.B * e.U, e.B * e.A, block_bytes, steps, rng_mode, flags, seed_increment, seed_stride, policy_seed,
+                                      first_step, action_tape, randomness_a, randomness_b, actions_out, record_actions, reward_tape, done_tape, list_record,
+                                      metrics);
+    {
+        void *obs = nullptr, *rows = nullptr, *presence = nullptr;
+        int64_t obs_bytes = 0, rows_bytes = 0, presence_bytes = 0;
+        ok(frz_cybersecurity_obs_block(env, &obs, &obs_bytes), "frz_cybersecurity_obs_block");
+        ok(frz_cybersecurity_state_block(env, &rows, &rows_bytes, &presence, &presence_bytes), "frz_cybersecurity_state_block");
+        spec.obs_tape = tape_or_null<uint8_t>(arena, obs_tape, at::kByte, steps * obs_bytes, "obs_tape");
+        spec.state_tape = tape_or_null<uint8_t>(arena, state_tape, at::kByte, steps * ((rows_bytes + presence_bytes + 255) / 256 * 256), "state_tape");
+    }
     ok(frz_cybersecurity_rollout(static_cast<frz_cybersecurity_env*>(e.handle), &spec, current_stream(arena)), "frz_cybersecurity_rollout");
 }
 
@@ -297,11 +317,11 @@ TORCH_LIBRARY(frz, m) {
     m.def("wildfire_rollout"
           "(Tensor(a!) arena, int handle, int steps, int rng_mode, int flags, int seed_increment, int seed_stride, int policy_seed, int first_step, "
           "Tensor? action_tape, Tensor? randomness_a, Tensor? randomness_b, Tensor(b!)? actions_out, bool record_actions, Tensor(c!)? reward_tape, "
-          "Tensor(d!)? done_tape, Tensor(e!)? list_record, Tensor(f!)? metrics) -> ()");
+          "Tensor(d!)? done_tape, Tensor(e!)? list_record, Tensor(f!)? metrics, Tensor(g!)? obs_tape, Tensor(h!)? state_tape) -> ()");
     m.def("cybersecurity_rollout"
           "(Tensor(a!) arena, int handle, int steps, int rng_mode, int flags, int seed_increment, int seed_stride, int policy_seed, int first_step, "
           "Tensor? action_tape, Tensor? randomness_a, Tensor? randomness_b, Tensor(b!)? actions_out, bool record_actions, Tensor(c!)? reward_tape, "
-          "Tensor(d!)? done_tape, Tensor(e!)? list_record, Tensor(f!)? metrics) -> ()");
+          "Tensor(d!)? done_tape, Tensor(e!)? list_record, Tensor(f!)? metrics, Tensor(g!)? obs_tape, Tensor(h!)? state_tape) -> ()");
     m.def("cybersecurity_reset(Tensor(a!) arena, int handle) -> ()");
     m.def("cybersecurity_rebuild(Tensor(a!) arena, int handle) -> ()");
     m.def("cybersecurity_step(Tensor(a!) arena, int handle, Tensor actions, int rng_mode, Tensor? network_randomness, Tensor? agent_randomness, int agents, "

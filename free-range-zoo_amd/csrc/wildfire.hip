@@ -1128,6 +1128,8 @@ int launch(frz_wildfire_env* env, const WfArgs& args, int rng, int mode, hipStre
             a.reward_tape = spec->reward_tape;
             a.done_tape = spec->done_tape;
             a.actions_out_step = spec->record_actions ? AB2 : 0;
+            a.supp_tape = (spec->flags & FRZ_ROLLOUT_OBS_COMPACT) ? static_cast<float*>(spec->obs_tape) : nullptr;
+            a.state_tape = static_cast<int32_t*>(spec->state_tape);
         }
         return launch_roles(a, env->variant, env->dev.nchunks, rng, mode, stream);  // one workgroup per chunk
     }
@@ -1861,6 +1863,27 @@ int frz_wildfire_list_block(const frz_wildfire_env* env, void** block, int64_t* 
     return FRZ_OK;
 }
 
+int frz_wildfire_obs_block(const frz_wildfire_env* env, void** block, int64_t* bytes, int64_t* others_offset) {
+    if (!env || !block || !bytes || !others_offset) return FRZ_E_INVALID;
+    if (!env->arena) return FRZ_E_UNBOUND;
+    *block = env->arena + env->dev.off_obs_self;
+    *bytes = env->dev.off_task_offsets - env->dev.off_obs_self;
+    *others_offset = env->dev.off_obs_others - env->dev.off_obs_self;
+    return FRZ_OK;
+}
+
+int frz_wildfire_state_block(const frz_wildfire_env* env, void** cells, int64_t* cells_bytes, void** agents, int64_t* agents_bytes) {
+    if (!env || !cells || !cells_bytes || !agents || !agents_bytes) return FRZ_E_INVALID;
+    if (!env->arena) return FRZ_E_UNBOUND;
+    const WfDev& p = env->dev;
+    const int64_t B = p.B;
+    *cells = env->dev.grid ? env->arena + env->gdev.off_cells : env->arena + p.off_rows4 + (int64_t)p.r_fires * B * 4;
+    *cells_bytes = (int64_t)3 * p.HW * B * 4;
+    *agents = env->arena + p.off_rows4 + (int64_t)p.r_supp * B * 4;
+    *agents_bytes = (int64_t)3 * p.A * B * 4;
+    return FRZ_OK;
+}
+
 int frz_wildfire_reset_masked(frz_wildfire_env* env, const uint8_t* mask, int32_t seed_increment, void* stream) {
     if (!env) return FRZ_E_INVALID;
     if (!env->arena) return FRZ_E_UNBOUND;
@@ -1901,7 +1924,9 @@ int frz_wildfire_rollout(frz_wildfire_env* env, const frz_rollout_spec* spec, vo
     const bool mt_reset = reset_first && mode == FRZ_RNG_MT19937;  // the opening reset re-seeds the streams from the host side: separate launches
     if (reset_first) env->saved = frz_wildfire_saved_state{};
     const bool saved_restart = auto_reset && env->saved.fires != nullptr;  // the in-kernel restart fills from the configured tables: not for a saved state
-    if (spec->n_steps > 1 && !saved_restart && frz_wildfire_rollout_launches(env, spec->n_steps, mode) == 1) {  // (a one-step rollout takes the per-step path below: it honours every option)
+    const bool obs_compact = (spec->flags & FRZ_ROLLOUT_OBS_COMPACT) != 0;
+    const bool full_obs_tape = spec->obs_tape != nullptr && !obs_compact;  // whole observation blocks: copied out between the steps' launches
+    if (spec->n_steps > 1 && !saved_restart && !full_obs_tape && frz_wildfire_rollout_launches(env, spec->n_steps, mode) == 1) {  // (a one-step rollout takes the per-step path below: it honours every option)
         frz_rollout_spec inner = *spec;
         if (mt_reset) {
             const int rc = frz_wildfire_reset_reseed(env, spec->seed_increment, stream);
@@ -1971,6 +1996,23 @@ int frz_wildfire_rollout(frz_wildfire_env* env, const frz_rollout_spec* spec, vo
             hipMemcpyAsync(static_cast<char*>(spec->list_record) + (int64_t)t * block_bytes, env->arena + p.off_task_offsets, (size_t)block_bytes,
                            hipMemcpyDeviceToDevice, s) != hipSuccess)
             return FRZ_E_LAUNCH;
+        if (spec->obs_tape) {  // ... and the observations
+            const int64_t supp_bytes = A * B * 4, obs_bytes = p.off_task_offsets - p.off_obs_self;
+            const hipError_t e = obs_compact ? hipMemcpyAsync(static_cast<char*>(spec->obs_tape) + (int64_t)t * supp_bytes,
+                                                              env->arena + p.off_rows4 + (int64_t)p.r_supp * B * 4, (size_t)supp_bytes, hipMemcpyDeviceToDevice, s)
+                                             : hipMemcpyAsync(static_cast<char*>(spec->obs_tape) + (int64_t)t * obs_bytes, env->arena + p.off_obs_self,
+                                                              (size_t)obs_bytes, hipMemcpyDeviceToDevice, s);
+            if (e != hipSuccess) return FRZ_E_LAUNCH;
+        }
+        if (spec->state_tape) {  // ... and the state
+            void *cells = nullptr, *agents = nullptr;
+            int64_t cells_bytes = 0, agents_bytes = 0;
+            if (frz_wildfire_state_block(env, &cells, &cells_bytes, &agents, &agents_bytes) != FRZ_OK) return FRZ_E_INVALID;
+            char* const dst = static_cast<char*>(spec->state_tape) + (int64_t)t * (cells_bytes + agents_bytes);
+            if (hipMemcpyAsync(dst, cells, (size_t)cells_bytes, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+                hipMemcpyAsync(dst + cells_bytes, agents, (size_t)agents_bytes, hipMemcpyDeviceToDevice, s) != hipSuccess)
+                return FRZ_E_LAUNCH;
+        }
     }
     if (spec->metrics && !auto_reset) return frz_wildfire_episode_metrics(env, spec->metrics, stream);
     return FRZ_OK;

@@ -102,6 +102,8 @@ struct WfLaunch {
     float* reward_tape;          // optional float32 [n_steps][A][B]: every step's rewards
     uint8_t* done_tape;          // optional uint8 [n_steps][2][B]: every step's (terminated, truncated)
     int64_t actions_out_step;    // elements between two steps of actions_out (0: every step overwrites the one buffer)
+    float* supp_tape;            // optional float32 [n_steps][A][B]: every step's suppressants (frz_rollout_spec.obs_tape with FRZ_ROLLOUT_OBS_COMPACT)
+    int32_t* state_tape;         // optional: n_steps copies of the state rows [3 HW + 3 A][B] (frz_rollout_spec.state_tape)
 };
 
 struct WfArgs {
@@ -124,6 +126,8 @@ struct WfArgs {
     int64_t tape_actions_step = 0, list_record_delta = 0, list_record_step = 0, actions_out_step = 0;
     float* reward_tape = nullptr;
     uint8_t* done_tape = nullptr;
+    float* supp_tape = nullptr;
+    int32_t* state_tape = nullptr;
 };
 
 // The (CMAX, AMAX) instantiations of the step kernels: X(index, CMAX, AMAX, exact).  An env runs the first entry that holds its shape;
@@ -164,7 +168,7 @@ inline WfLaunch make_launch(const WfArgs& a) {
     const WfDev* host = a.host_dev;
     return WfLaunch{host->B, a.policy ? 1u : 0u, host->off_rows1, host->off_epoch, host->off_totals, host->off_mt_state, (uint32_t)a.policy_seed,
                     (uint32_t)(a.policy_seed >> 32), (uint32_t)a.policy_step, (uint32_t)(a.policy_step >> 32), a.actions_out, a.ticketed ? 1u : 0u, experiment_skip(), a.seed_increment, a.n_steps, a.scratch_delta, a.metrics_out,
-                    a.rollout_flags, a.seed_stride, a.tape_actions_step, a.list_record_delta, a.list_record_step, a.reward_tape, a.done_tape, a.actions_out_step};
+                    a.rollout_flags, a.seed_stride, a.tape_actions_step, a.list_record_delta, a.list_record_step, a.reward_tape, a.done_tape, a.actions_out_step, a.supp_tape, a.state_tape};
 }
 
 // Staging the configuration: the 16-byte piece is requested by the kernel's FIRST vector-memory instruction (before the

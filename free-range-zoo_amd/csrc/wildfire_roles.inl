@@ -795,6 +795,18 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                         fld.nm = fresh ? -1 : fld.nm;  // + 1 below
                     }
                 }
+                if constexpr (EXTRA) {
+                    if (launch.state_tape != nullptr) {  // frz_rollout_spec.state_tape: this step's cell rows (the agent rows: crew role)
+                        int32_t* const st = launch.state_tape + (int64_t)t * (int64_t)(3 * HW + 3 * A) * B;
+#pragma unroll
+                        for (int c = 0; c < CMAX; ++c)
+                            if (c < HW) {
+                                st[(int64_t)(r_fires + c) * B + bl] = f[c];
+                                st[(int64_t)(r_intensity + c) * B + bl] = in[c];
+                                st[(int64_t)(r_fuel + c) * B + bl] = fu[c];
+                            }
+                    }
+                }
 #pragma unroll
                 for (int c = 0; c < CMAX; ++c) lit1 |= (mask_t)(f[c] > 0) << c;
                 x_lit[slot] = lit1;  // as it is also for the lanes that shadow the last env: a multi-step launch steps them like their owner
@@ -1165,6 +1177,24 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                         }
                     }
                     at32(rows, (uint32_t)r_moves * Bu + bl) = fresh ? 0 : nm;
+                    if constexpr (EXTRA) {  // what a learner keeps of the step: the agents' state as the step (and the restart) left it
+                        if (launch.supp_tape != nullptr) {  // FRZ_ROLLOUT_OBS_COMPACT: the one column of the self / others records that moves
+                            float* const tape = launch.supp_tape + (int64_t)t * A * B;
+#pragma unroll
+                            for (int a = 0; a < AMAX; ++a)
+                                if (a < A) tape[(int64_t)a * B + bl] = supp[a];
+                        }
+                        if (launch.state_tape != nullptr) {
+                            int32_t* const st = launch.state_tape + (int64_t)t * (int64_t)(3 * HW + 3 * A) * B;
+#pragma unroll
+                            for (int a = 0; a < AMAX; ++a)
+                                if (a < A) {
+                                    reinterpret_cast<float*>(st)[(int64_t)(r_supp + a) * B + bl] = supp[a];
+                                    reinterpret_cast<float*>(st)[(int64_t)(r_cap + a) * B + bl] = capa[a];
+                                    st[(int64_t)(r_equip + a) * B + bl] = eqs[a];
+                                }
+                        }
+                    }
                 }
                 mask_t ok1[AMAX];
                 uint64_t packed[PW], incl[PW], base[PW];
@@ -1460,7 +1490,7 @@ void launch_roles_variant(const WfArgs& a, const WfDev* dev, int grid, int rng, 
         if (a.n_steps > 1) {  // one launch for the whole rollout (the caller has checked residency and the second list copy)
             // the plain rollout (policy in-kernel, opening reset, metrics) or the one with every option of a frz_rollout_spec
             const bool extra = !a.policy || a.tape_actions_step != 0 || a.list_record_delta != 0 || a.reward_tape || a.done_tape || a.actions_out_step != 0 ||
-                               (a.rollout_flags & FRZ_ROLLOUT_AUTO_RESET) != 0;
+                               (a.rollout_flags & FRZ_ROLLOUT_AUTO_RESET) != 0 || a.supp_tape || a.state_tape;
             if (rng == FRZ_RNG_PHILOX)
                 return extra ? go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_PHILOX, kStep, true, true>) : go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_PHILOX, kStep, true, false>);
             if (rng == FRZ_RNG_MT19937)

@@ -161,6 +161,52 @@ class raw_env(BatchedParallelEnv):
             self.observations[agent] = TensorDict({'self': own, 'others': others, 'tasks': self._tasks[a]}, batch_size=[B],
                                                   device=self.device)
 
+    # ------------------------------------------------------------------------------- what a recorded rollout keeps of every step
+    def _block_bytes(self, which: str) -> int:
+        lib, P, I = self._lib, ctypes.c_void_p, ctypes.c_int64
+        if which == 'obs':
+            block, nbytes = P(), I()
+            _capi.check(lib.frz_cybersecurity_obs_block(self._handle, ctypes.byref(block), ctypes.byref(nbytes)), 'frz_cybersecurity_obs_block')
+            self._obs_block_base = block.value
+            return nbytes.value
+        rows, rows_bytes, presence, presence_bytes = P(), I(), P(), I()
+        _capi.check(lib.frz_cybersecurity_state_block(self._handle, ctypes.byref(rows), ctypes.byref(rows_bytes), ctypes.byref(presence),
+                                                      ctypes.byref(presence_bytes)), 'frz_cybersecurity_state_block')
+        self._state_rows_bytes = rows_bytes.value
+        return (rows_bytes.value + presence_bytes.value + 255) // 256 * 256  # (a step of the tape starts aligned)
+
+    def recorded_state(self, rec: Dict[str, Any], t: int) -> CybersecurityState:
+        """Step ``t`` of ``rollout(..., record_state=True)`` as a CybersecurityState over the tape (views, batch-major like ``env.state()``)."""
+        B, N, D, A = self.parallel_envs, self._N, self._D, len(self.possible_agents)
+        step = rec['state'][t]
+        rows = step[:self._state_rows_bytes].view(torch.int32).view(N + 2 * D, B)
+        presence = step[self._state_rows_bytes:self._state_rows_bytes + A * B].view(torch.bool).view(A, B)
+        return CybersecurityState(network_state=rows[0:N].t(), location=rows[N:N + D].t(), presence=presence.t())
+
+    def recorded_observations(self, rec: Dict[str, Any], t: int) -> Dict[str, TensorDict]:
+        """Step ``t`` of ``rollout(..., record_observations='full')`` as the ``{agent: TensorDict(self, others, tasks)}`` the reference's
+        loop gets back from its t-th ``step()`` (utils/conversions.py:92-99; cybersecurity.py:459-511): views of the tape."""
+        B, A, N, Att, D = self.parallel_envs, len(self.agents), self._N, self._Att, self._D
+        block, base, bufs = rec['observations'][t], self._obs_block_base, self._bufs
+
+        def piece(ptr, shape, dtype):
+            n = 1
+            for v in shape:
+                n *= int(v)
+            nbytes = n * torch.empty((), dtype=dtype).element_size()
+            return block[ptr - base:ptr - base + nbytes].view(dtype).view(*shape)
+
+        f32 = torch.float32
+        self_att, self_def = piece(bufs.obs_self_attackers, (Att, B, 2), f32), piece(bufs.obs_self_defenders, (D, B, 3), f32)
+        others_att = piece(bufs.obs_others_attackers, (Att, B, max(Att - 1, 0), self._ka), f32)
+        others_def = piece(bufs.obs_others_defenders, (D, B, max(D - 1, 0), self._kd), f32)
+        tasks = piece(bufs.obs_tasks, (A, B, N, 2), torch.int64)
+        out = {}
+        for a, agent in enumerate(self.agents):
+            own, others = (self_att[a], others_att[a]) if a < Att else (self_def[a - Att], others_def[a - Att])
+            out[agent] = TensorDict({'self': own, 'others': others, 'tasks': tasks[a]}, batch_size=[B], device=self.device)
+        return out
+
     def _publish_dense(self) -> None:
         self.rewards = {agent: self._rewards[a] for a, agent in enumerate(self.agents)}
         self._cumulative_rewards = {agent: self._cumulative[a] for a, agent in enumerate(self.agents)}

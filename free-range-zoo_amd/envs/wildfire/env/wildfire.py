@@ -530,6 +530,71 @@ class raw_env(BatchedParallelEnv):
         self.infos['burnouts'] = self._burnouts_out
         self.infos['putouts'] = self._putouts_out
 
+    # ------------------------------------------------------------------------------- what a recorded rollout keeps of every step
+    def _block_bytes(self, which: str) -> int:
+        lib, P, I = self._lib, ctypes.c_void_p, ctypes.c_int64
+        if which == 'obs':
+            block, nbytes, others = P(), I(), I()
+            _capi.check(lib.frz_wildfire_obs_block(self._handle, ctypes.byref(block), ctypes.byref(nbytes), ctypes.byref(others)), 'frz_wildfire_obs_block')
+            self._obs_others_offset = others.value
+            return nbytes.value
+        cells, cells_bytes, agents, agents_bytes = P(), I(), P(), I()
+        _capi.check(lib.frz_wildfire_state_block(self._handle, ctypes.byref(cells), ctypes.byref(cells_bytes), ctypes.byref(agents), ctypes.byref(agents_bytes)),
+                    'frz_wildfire_state_block')
+        self._state_cells_bytes = cells_bytes.value
+        return cells_bytes.value + agents_bytes.value
+
+    def recorded_state(self, rec: Dict[str, Any], t: int) -> WildfireState:
+        """Step ``t`` of ``rollout(..., record_state=True)`` as a WildfireState over the tape (views, batch-major like ``env.state()``)."""
+        B, H, W, A = self.parallel_envs, self.max_y, self.max_x, len(self.possible_agents)
+        HW = H * W
+        step = rec['state'][t]
+        cells = step[:self._state_cells_bytes].view(torch.int32)
+        agents_i = step[self._state_cells_bytes:].view(torch.int32).view(3 * A, B)
+        agents_f = step[self._state_cells_bytes:].view(torch.float32).view(3 * A, B)
+        if self._cells_env_major:
+            fires, intensity, fuel = cells.view(3, B, H, W)
+        else:
+            fires, intensity, fuel = (cells.view(3, H, W, B)[k].permute(2, 0, 1) for k in range(3))
+        return WildfireState(fires=fires, intensity=intensity, fuel=fuel, agents=self.agent_config.agents, suppressants=agents_f[0:A].t(),
+                             capacity=agents_f[A:2 * A].t(), equipment=agents_i[2 * A:3 * A].t())
+
+    def recorded_observations(self, rec: Dict[str, Any], t: int) -> Dict[str, TensorDict]:
+        """Step ``t`` of a recorded rollout as the ``{agent: TensorDict(self, others, tasks)}`` the reference's loop gets back from its t-th
+        ``step()`` (utils/conversions.py:92-99; wildfire.py:662-717): ``self`` / ``others`` from the observation tape (the compact form is
+        expanded: positions and base power are configuration, the suppressant column is what the tape holds), ``tasks`` from the list record
+        (``record=True``; the last step's lists are the env's own).  Reads the step's list total from the device."""
+        B, A, k = self.parallel_envs, len(self.agents), self._k
+        steps = rec['observations'].shape[0]
+        self._flush()
+        if rec.get('observations_form') == 'compact':
+            supp = rec['observations'][t]  # [A, B]
+            obs_self = self._obs_self.clone()
+            obs_self[:, :, 3] = supp
+            obs_others = self._obs_others.clone()  # [A, B, A - 1, k]: (y, x[, power][, suppressant])
+            if self.observe_other_suppressant and A > 1:
+                for a, agent in enumerate(self.agents):
+                    obs_others[a, :, :, k - 1] = supp[self.observation_ordering[agent]].t()
+        else:
+            block = rec['observations'][t]
+            obs_self = block[:A * B * 16].view(torch.float32).view(A, B, 4)
+            obs_others = block[self._obs_others_offset:self._obs_others_offset + A * B * max(A - 1, 0) * k * 4].view(torch.float32).view(A, B, max(A - 1, 0), k)
+        if t < steps - 1:
+            if 'lists' not in rec:
+                raise ValueError('the tasks of an intermediate step are in the list record: rollout(..., record=True)')
+            base = self._arena.data_ptr() + rec['list_block_offset']
+            block = rec['lists'][t]
+            offsets = block[self._bufs.task_offsets - base:self._bufs.task_offsets - base + (B + 1) * 8].view(torch.int64)
+            total = int(offsets[-1])
+            values = block[self._bufs.task_values - base:self._bufs.task_values - base + total * 32].view(torch.int64).view(total, 4)
+        else:
+            offsets = self._task_offsets
+            total = int(offsets[-1])
+            values = self._task_values[:total]
+        tasks = jagged(values, offsets)
+        return {agent: TensorDict({'self': obs_self[a], 'others': obs_others[a], 'tasks': tasks}, batch_size=[B], device=self.device)
+                for a, agent in enumerate(self.agents)}
+
     def _launch_deferred(self, n: int, first: int, seed: int) -> None:
         """`n` counted steps of the reference-shaped random loop (policy steps first .. first + n - 1, drawn inside the launch into the
         sample buffer, which afterwards holds the last step's draw — what n single-step launches leave): ONE multi-step launch."""

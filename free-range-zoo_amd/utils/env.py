@@ -458,7 +458,8 @@ class BatchedParallelEnv:
     @torch.no_grad()
     def rollout(self, steps: int, actions: Optional[torch.Tensor] = None, randomness=None, policy_seed: int = 0, first_step: int = 0,
                 reset_first: bool = False, seed_increment: int = 0, auto_reset: bool = False, seed_stride: int = 0,
-                record: bool = False, metrics: Optional[torch.Tensor] = None) -> Dict[str, Any]:
+                record: bool = False, metrics: Optional[torch.Tensor] = None, record_observations: Optional[str] = None,
+                record_state: bool = False) -> Dict[str, Any]:
         """
         ``steps`` x ``step`` as ONE call through the C boundary (``frz_<domain>_rollout``) — one multi-step launch where the library has one
         for the shape (after ``set_exclusive_device``), otherwise one launch per step — with the results a loop over ``step()`` leaves.
@@ -476,6 +477,13 @@ class BatchedParallelEnv:
             record: keep EVERY step's outputs — returns ``{'rewards': [steps, A, B], 'dones': [steps, 2, B], 'actions': [steps, A, B, 2]
                 (policy), 'lists': uint8 [steps - 1, block_bytes]}`` (``lists[t]`` = a copy of the env's packed-list block after step t).
             metrics: float64 ``[A + 2]``, accumulated in place (see ``frz_rollout_spec.metrics``).
+            record_observations: keep every step's observations (what the reference's loop hands back at every step, utils/conversions.py:92-99):
+                ``'full'`` — ``out['observations']`` = uint8 ``[steps, obs_block_bytes]``, copies of the dense observation block;
+                ``'compact'`` (wildfire) — float32 ``[steps, A, B]``, each agent's suppressant, the one column of the self / others records a
+                step changes.  ``recorded_observations(out, t)`` rebuilds step t's ``{agent: TensorDict}`` from either (the jagged ``tasks``
+                come from the list record: use ``record=True`` with it).
+            record_state: ``out['state']`` = uint8 ``[steps, state_block_bytes]``: what ``env.state()`` shows after each step
+                (``recorded_state(out, t)`` wraps step t as the domain's State).
         """
         if not self._has_reset:
             raise RuntimeError('reset() must be called before rollout()')
@@ -523,13 +531,31 @@ class BatchedParallelEnv:
             if metrics.dtype != torch.float64 or metrics.numel() != A + 2 or not metrics.is_contiguous() or metrics.device != self.device:
                 raise ValueError('metrics must be a contiguous float64 [A + 2] tensor on the env device')
             spec.metrics = metrics.data_ptr()
+        obs_tape = state_tape = None
+        if record_observations is not None:
+            if record_observations not in ('full', 'compact'):
+                raise ValueError("record_observations must be None, 'full' or 'compact'")
+            if record_observations == 'compact':
+                if self._domain != 'wildfire':
+                    raise ValueError("record_observations='compact' exists for wildfire (the only column a step changes there is the suppressant)")
+                spec.flags |= _capi.FRZ_ROLLOUT_OBS_COMPACT
+                out['observations'] = torch.zeros((steps, A, B), dtype=torch.float32, device=self.device)
+            else:
+                out['observations'] = torch.zeros((steps, self._block_bytes('obs')), dtype=torch.uint8, device=self.device)
+            out['observations_form'] = record_observations
+            obs_tape = out['observations']
+            spec.obs_tape = obs_tape.data_ptr()
+        if record_state:
+            state_tape = out['state'] = torch.zeros((steps, self._block_bytes('state')), dtype=torch.uint8, device=self.device)
+            spec.state_tape = state_tape.data_ptr()
         if self._ops is not None and hasattr(self._ops, f'{self._domain}_rollout'):  # the same call as a dispatcher-visible op: every tape is an argument
             tapes = randomness if randomness is None else tuple(keep[-2:])
             getattr(self._ops, f'{self._domain}_rollout')(
                 self._arena, self._handle.value, int(steps), int(spec.rng_mode), int(spec.flags),
                 int(seed_increment), int(seed_stride) & 0xFFFFFFFF, int(policy_seed), int(first_step), actions, None if tapes is None else tapes[0],
                 None if tapes is None else tapes[1], None if actions is not None else (out['actions'] if record else self._actions), bool(record and actions is None),
-                out.get('rewards'), out.get('dones'), out['lists'] if (record and steps > 1) else None, metrics)
+                out.get('rewards'), out.get('dones'), out['lists'] if (record and steps > 1) else None, metrics,
+                None if obs_tape is None else obs_tape.view(torch.uint8).reshape(-1), None if state_tape is None else state_tape.reshape(-1))
         else:
             symbol = f'frz_{self._domain}_rollout'
             _capi.check(getattr(self._lib, symbol)(self._handle, ctypes.byref(spec), stream_ptr(self.device)), symbol)
@@ -539,6 +565,11 @@ class BatchedParallelEnv:
 
     def _check_randomness_tapes(self, steps: int, a: torch.Tensor, b: torch.Tensor) -> None:
         raise NotImplementedError
+
+    def _block_bytes(self, which: str) -> int:
+        """Size in bytes of the dense observation block / the state block of the env's arena (include/frz.h: frz_<domain>_obs_block,
+        frz_<domain>_state_block): one step of an observation / state tape."""
+        raise NotImplementedError(f'{self._domain}_v0 rollouts keep no {which} tape')
 
     def _after_rollout(self) -> None:
         self._publish()

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FRZ_ABI_VERSION 4
+#define FRZ_ABI_VERSION 5
 
 #define FRZ_MAX_AGENTS 16
 #define FRZ_MAX_CELLS 1024 /* 32 x 32; grids above 16 cells run one env per wavefront with the cells across its lanes */
@@ -297,6 +297,9 @@ int frz_wildfire_rollout_random_policy_metrics(frz_wildfire_env* env, uint64_t p
                                       rewards / terminations / truncations, so what the step itself produced is read from the reward /
                                       done tapes (or the metrics).  The all-done early-out (utils/env.py:211-213) cannot trigger. */
 
+#define FRZ_ROLLOUT_OBS_COMPACT 4u /* wildfire: obs_tape holds only what a step changes of the self / others records — each agent's suppressant,
+                                      float32 [n_steps][A][B] (positions and base power are configuration: wildfire.py:677-716) */
+
 typedef struct frz_rollout_spec {
     int32_t n_steps;
     int32_t rng_mode;        /* FRZ_RNG_* */
@@ -324,6 +327,13 @@ typedef struct frz_rollout_spec {
     double* metrics;     /* float64 [A + 2], accumulated in place: frz_wildfire_episode_metrics at the end of the rollout; with
                             FRZ_ROLLOUT_AUTO_RESET instead: [a] += returns of the episodes that ENDED inside the rollout (needs
                             track_cumulative_rewards), [A] += env-steps executed, [A + 1] += episodes ended */
+    /* what a learner keeps of a rollout besides rewards / dones / actions (reference: the `observations` the loop of
+     * utils/conversions.py:92-99 hands back at every step, utils/env.py:223-225) — v5 */
+    void* obs_tape;      /* n_steps copies of the dense observation block (frz_<dom>_obs_block: the self rows, then the others rows [,
+                            cybersecurity: then every agent's task rows], as the step — and the reset of FRZ_ROLLOUT_AUTO_RESET — left
+                            them); with FRZ_ROLLOUT_OBS_COMPACT (wildfire) float32 [n_steps][A][B] suppressants instead.  The jagged part
+                            of an observation (wildfire `tasks`) is in the list record */
+    void* state_tape;    /* n_steps copies of the state block (frz_<dom>_state_block: what env.state() shows after the step) */
 } frz_rollout_spec;
 
 /* n_steps steps driven by `spec`; same results as the equivalent loop over frz_wildfire_step / frz_wildfire_step_random_policy (and
@@ -334,6 +344,13 @@ int frz_wildfire_rollout(frz_wildfire_env* env, const frz_rollout_spec* spec, vo
 /* the packed-list block of the bound arena: device pointer and size in bytes (task_offsets, act_map_offsets, bad_map_offsets, task_values,
  * obs_map_values, act_map_values, bad_map_values, contiguous in this order, each 256-byte aligned); a list record holds copies of it */
 int frz_wildfire_list_block(const frz_wildfire_env* env, void** block, int64_t* bytes);
+/* the dense observation block of the bound arena (obs_self float32 [A][B][4], then — 256-byte aligned — obs_others float32
+ * [A][B][A - 1][k]): device pointer, size in bytes, and the byte offset of the others rows inside it; an obs tape holds copies of it */
+int frz_wildfire_obs_block(const frz_wildfire_env* env, void** block, int64_t* bytes, int64_t* others_offset);
+/* the state of the bound arena as env.state() shows it, in two pieces: the cell arrays (fires, intensity, fuel: int32, `[3 H W][B]` rows —
+ * or `[3][B][H W]` env-major for the grid family, frz_wildfire_bufs.cells_env_major) and the agent arrays (suppressants, capacity:
+ * float32, equipment: int32; `[3 A][B]` rows).  One step of a state tape = the cell piece followed by the agent piece. */
+int frz_wildfire_state_block(const frz_wildfire_env* env, void** cells, int64_t* cells_bytes, void** agents, int64_t* agents_bytes);
 /* replaces reset_batches (utils/env.py:162-189 + wildfire.py:376-397) with the selection on the device: env b is reset when mask[b] != 0
  * (mask uint8 [B]), or — mask NULL — when it is finished (all agents terminated or all truncated); seeds[b] += seed_increment (mod 2^32) for
  * the reset envs (the FRZ_RNG_PHILOX key; MT19937 streams are re-seeded by the caller: frz_mt19937_seed_masked); then the observations and
@@ -501,6 +518,12 @@ int frz_cybersecurity_rollout_random_policy(frz_cybersecurity_env* env, uint64_t
  * agents with FRZ_RNG_PHILOX or FRZ_RNG_INJECTED after frz_cybersecurity_set_exclusive_device, otherwise one launch per step. */
 int frz_cybersecurity_rollout(frz_cybersecurity_env* env, const frz_rollout_spec* spec, void* stream);
 int frz_cybersecurity_list_block(const frz_cybersecurity_env* env, void** block, int64_t* bytes);
+/* the dense observation block (attackers' self rows float32 [Att][B][2], defenders' self rows [D][B][3], the others rows of both, every
+ * agent's task rows int64 [A][B][N][2]; each 256-byte aligned, in this order — frz_cybersecurity_bufs has the pointers) and the state
+ * block in two pieces (network state, defender locations, last actions: int32 `[N + 2 D][B]` rows; presence: uint8 `[A][B]` rows).  One step
+ * of a state tape = the rows piece followed by the presence piece, padded to a multiple of 256 bytes. */
+int frz_cybersecurity_obs_block(const frz_cybersecurity_env* env, void** block, int64_t* bytes);
+int frz_cybersecurity_state_block(const frz_cybersecurity_env* env, void** rows, int64_t* rows_bytes, void** presence, int64_t* presence_bytes);
 int frz_cybersecurity_set_exclusive_device(frz_cybersecurity_env* env, int exclusive);
 int frz_cybersecurity_rollout_launches(const frz_cybersecurity_env* env, int32_t n_steps, int rng_mode);
 

@@ -194,6 +194,132 @@ def test_golden_trajectory_through_the_multi_step_launch(name):
 
 
 # ------------------------------------------------------------------------------------------------------------
+# 2b. rollouts a learner can consume: every step's OBSERVATIONS and STATE beside rewards / dones / actions, against the
+#     reference's recordings (the loop of utils/conversions.py:92-99 hands the observations back at every step)
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('form', ['compact', 'full'])
+@pytest.mark.parametrize('name', sorted(configs.WILDFIRE_GOLDEN))
+def test_golden_trajectory_observation_and_state_tapes(name, form):
+    """`rollout(..., record=True, record_observations=form, record_state=True)` over a recorded trajectory of the unmodified reference: step
+    t's `{agent: self, others, tasks}` rebuilt from the tapes (`recorded_observations`) and its state (`recorded_state`) equal what the
+    reference's t-th step() returned / left.  'compact' (the suppressant column only) rides in the ONE multi-step launch where the shape has
+    one; 'full' copies the observation block out between per-step launches."""
+    build, kwargs = configs.WILDFIRE_GOLDEN[name]
+    data = np.load(G.golden_path(f'traj_wildfire_{name}.npz'))
+    cfg = G.load_cfg(data, _capi.frz_wildfire_cfg)
+    B, A, T = cfg.parallel_envs, cfg.num_agents, int(data['steps'])
+    env = make_env(build, B, None if cfg.max_steps < 0 else cfg.max_steps, **kwargs)
+    env.set_exclusive_device(True)
+    acts, field, agent = golden_tapes(data, cfg, T)
+    env.reset(seed=torch.arange(B, dtype=torch.int32))
+    rec = env.rollout(T, actions=acts, randomness=(field, agent), record=True, record_observations=form, record_state=True)
+    for t in range(T):
+        p = f's{t}_'
+        if not bool(data[p + 'stepped']):
+            break  # (a multi-step launch stops stepping with the batch: what it leaves for later steps is unspecified)
+        state = env.recorded_state(rec, t)
+        for key in ('fires', 'intensity', 'fuel', 'suppressants', 'capacity', 'equipment'):
+            want = data[p + key]
+            G.assert_same(np_(getattr(state, key)).reshape(want.shape), want, f'{name} step {t} state tape {key}')
+        if t < T - 1 and not bool(data[f's{t + 1}_stepped']):
+            continue  # (its lists were written once more into the env's own buffers, not into the record: see the list record test)
+        obs = env.recorded_observations(rec, t)
+        for a, agent_name in enumerate(env.agents):
+            G.assert_same(np_(obs[agent_name]['self']), data[f'{p}obs_self_{a}'], f'{name} step {t} {form} observations: self[{a}]')
+            G.assert_same(np_(obs[agent_name]['others']), data[f'{p}obs_others_{a}'], f'{name} step {t} {form} observations: others[{a}]')
+            G.assert_same(np_(obs[agent_name]['tasks'].values()), data[p + 'task_values'], f'{name} step {t} {form} observations: tasks')
+            G.assert_same(np_(obs[agent_name]['tasks'].offsets()), data[p + 'task_offsets'], f'{name} step {t} {form} observations: task offsets')
+    env.check()
+
+
+@pytest.mark.parametrize('family', ['roles', 'lane', 'grid'])
+@pytest.mark.parametrize('auto_reset', [False, True], ids=['episodic', 'auto_reset'])
+def test_observation_and_state_tapes_against_the_oracle(oracle, family, auto_reset, monkeypatch):
+    """The tapes of a policy-driven rollout (in-kernel policy, Philox draws) in every wildfire kernel family, with and without the
+    device-side restart: state and suppressant tapes against the oracle's per-step loop (a restarted env shows its fresh state)."""
+    from free_range_zoo_amd.envs.wildfire.env.structures.configuration import to_cstruct
+    monkeypatch.setenv('FRZ_WF_KERNEL', family)
+    B, horizon, steps, stride = (65536 if family == 'roles' else 3000), 9, 23, 1000003
+    cfg = to_cstruct(configs.wildfire_openness(), B, horizon, track_cumulative_rewards=True, observe_other_suppressant=True)
+    env = make_env(configs.wildfire_openness, B, horizon, rng='philox', track_cumulative_rewards=True, observe_other_suppressant=True)
+    env.set_exclusive_device(True)
+    one_launch = env._lib.frz_wildfire_rollout_launches(env._handle, steps, _capi.FRZ_RNG_PHILOX) == 1
+    assert one_launch == (family == 'roles')
+    seeds = torch.arange(B, dtype=torch.int32) * 7 + 3
+    env.reset(seed=seeds)
+    rec = env.rollout(steps, policy_seed=19, auto_reset=auto_reset, seed_stride=stride, record=True, record_observations='compact', record_state=True)
+    o = oracle.WildfireOracle(cfg)
+    o.reset()
+    s = seeds.numpy().copy()
+    supp_tape = np_(rec['observations'])
+    for t in range(steps):
+        if not auto_reset and bool((o.terminations[0].astype(bool) | o.truncations[0].astype(bool)).all()):
+            break
+        acts = oracle.wildfire_random_policy(cfg, o.agent_task_count, o.env_task_count, s, 19, t)
+        fr, ar = oracle.wildfire_philox_randomness(cfg, s, o.num_moves)
+        o.step(acts, fr, ar)
+        if auto_reset:
+            o.reset_masked(None, s, stride)
+        state = env.recorded_state(rec, t)
+        for key in ('fires', 'intensity', 'fuel', 'suppressants', 'capacity', 'equipment'):
+            want = getattr(o, key)
+            G.assert_same(np_(getattr(state, key)).reshape(want.shape), want, f'{family} step {t} state tape {key}')
+        G.assert_same(supp_tape[t], o.suppressants.T, f'{family} step {t} suppressant tape')
+        if t in (0, 7, steps - 1):
+            obs = env.recorded_observations(rec, t)
+            want_self, want_others = oracle_observations(o)
+            for a, agent_name in enumerate(env.agents):
+                G.assert_same(np_(obs[agent_name]['self']), want_self[a], f'{family} step {t}: self[{a}] rebuilt from the compact tape')
+                G.assert_same(np_(obs[agent_name]['others']), want_others[a], f'{family} step {t}: others[{a}] rebuilt from the compact tape')
+    assert t > horizon or not auto_reset
+    env.check()
+
+
+def oracle_observations(o):
+    """(self [A][B][4], others [A][B][A - 1][k]) of the oracle's current step, as numpy."""
+    snap = oracle_snapshot(o)
+    A = o.cfg.num_agents
+    return [snap[f'obs_self_{a}'] for a in range(A)], [snap[f'obs_others_{a}'] for a in range(A)]
+
+
+@pytest.mark.parametrize('name', sorted(configs.CYBER_GOLDEN))
+def test_cybersecurity_golden_trajectory_observation_and_state_tapes(name):
+    """Cybersecurity: every step's observation rows (self / others / tasks of every agent) and state from the tapes against the reference's
+    recording (the tapes are copied out between per-step launches in this domain)."""
+    import test_hip_cybersecurity as C
+    build, kwargs = configs.CYBER_GOLDEN[name]
+    data = np.load(G.golden_path(f'traj_cybersecurity_{name}.npz'))
+    cfg = G.load_cfg(data, _capi.frz_cybersecurity_cfg)
+    B, N, A, T = cfg.parallel_envs, cfg.num_nodes, cfg.num_attackers + cfg.num_defenders, int(data['steps'])
+    env = C.make_env(build, B, None if cfg.max_steps < 0 else cfg.max_steps, **kwargs)
+    env.set_exclusive_device(True)
+    acts = np.zeros((T, A, B, 2), np.int32)
+    net, agent = np.zeros((T, B, N), np.float32), np.zeros((T, B, A), np.float32)
+    for t in range(T):
+        acts[t] = data[f's{t}_actions']
+        if bool(data[f's{t}_stepped']):
+            net[t], agent[t] = data[f's{t}_network_randomness'].reshape(B, N), data[f's{t}_agent_randomness'].reshape(B, A)
+    acts, net, agent = torch.from_numpy(acts).cuda(), torch.from_numpy(net).cuda(), torch.from_numpy(agent).cuda()
+    env.reset(seed=torch.arange(B, dtype=torch.int32))
+    rec = env.rollout(T, actions=acts, randomness=(net, agent), record=True, record_observations='full', record_state=True)
+    for t in range(T):
+        p = f's{t}_'
+        if not bool(data[p + 'stepped']):
+            break
+        state = env.recorded_state(rec, t)
+        G.assert_same(np_(state.network_state), data[p + 'network_state'], f'{name} step {t} state tape: network_state')
+        G.assert_same(np_(state.location), data[p + 'location'], f'{name} step {t} state tape: location')
+        G.assert_same(np_(state.presence).astype(bool), data[p + 'presence'].astype(bool), f'{name} step {t} state tape: presence')
+        obs = env.recorded_observations(rec, t)
+        for a, agent_name in enumerate(env.agents):
+            for part in ('self', 'others', 'tasks'):
+                G.assert_same(np_(obs[agent_name][part]), data[f'{p}obs_{part}_{a}'], f'{name} step {t} observation tape: {part}[{a}]')
+    with pytest.raises(ValueError, match='compact'):
+        env.rollout(2, policy_seed=1, record_observations='compact')
+    env.check()
+
+
+# ------------------------------------------------------------------------------------------------------------
 # 3. the opening reset inside the launch
 # ------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('B', [65536, 1000])
