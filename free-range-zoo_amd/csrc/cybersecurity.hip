@@ -12,6 +12,7 @@
 // 2^A-entry table built on the host with the same libm tanhf the oracle uses; the kernel looks it up (LDS when small).
 // HBM-bound integer/byte work: no MFMA.  Built with -ffp-contract=off.
 #include "frz_scan.h"
+#include "frz_wave.h"
 
 #include "../../include/frz.h"
 
@@ -528,7 +529,9 @@ __global__ void __launch_bounds__(kBlock) cy_step_kernel(char* __restrict__ aren
                     const int64_t off = (int64_t)excl[a] * N;
                     act_offsets[a * (B + 1) + b] = off;
                     if (b == B - 1) act_offsets[a * (B + 1) + B] = off + (pres[a] ? N : 0);
-                    if (pres[a]) {
+                    // (the packed values are position mod N wherever a segment lies — every segment is arange(N) and starts at a multiple
+                    // of N: cy_prefill_kernel wrote them at bind, a step only moves the offsets)
+                    if (pres[a] && MODE != kStep) {
                         int32_t* v = act_values + a * B * N + off;
 #pragma unroll
                         for (int n = 0; n < NMAX; ++n)
@@ -565,6 +568,12 @@ __global__ void __launch_bounds__(kBlock) cy_step_kernel(char* __restrict__ aren
 // role passes between its store groups.
 // ----------------------------------------------------------------------------------------------------------------
 constexpr int kRoleBlock = 2 * kBlock;
+#ifndef FRZ_CY_TASKS_LDS
+#ifndef FRZ_CY_ROWS_LDS
+#define FRZ_CY_ROWS_LDS 0
+#endif
+#define FRZ_CY_TASKS_LDS 1  // the view role's task rows staged through LDS into whole lines (0: a lane stores its own rows; profiles/r04_experiments.txt)
+#endif
 
 // PERSIST (FRZ_RNG_PHILOX, fused policy): L.n_steps steps in ONE launch, the state role keeping its envs in registers from step to step
 // (frz_cybersecurity_rollout_random_policy).  Same scheme as the wildfire field/crew kernel (wildfire_roles.hip, PERSIST): env-indexed
@@ -588,6 +597,10 @@ __global__ void __launch_bounds__(kRoleBlock, 2) cy_roles_kernel(char* __restric
     __shared__ float s_draw[NMAX + AMAX][kBlock];     // view -> state: this step's uniforms (nodes, then agents)
     __shared__ int s_post[NMAX + 2 * AMAX + 1][kBlock];  // state -> view: state, location, last action, presence bits after the step
     __shared__ int s_stop;  // multi-step launches: the workgroup's verdict on "every env is finished" (one per workgroup: both roles leave at the same barrier)
+#if FRZ_CY_TASKS_LDS
+    // view role: one agent's rows (tasks: N x 16 bytes per env; self / others: up to 3 (AMAX - 1) floats) of a wavefront's 64 envs, in output order
+    __shared__ longlong2 s_task_stage[4][64 * (NMAX > (3 * (AMAX > 1 ? AMAX - 1 : 1) + 3) / 4 ? NMAX : (3 * (AMAX > 1 ? AMAX - 1 : 1) + 3) / 4)];
+#endif
 
     const int tid = threadIdx.x & (kBlock - 1);
     const bool view = threadIdx.x >= kBlock;  // wave-uniform
@@ -827,6 +840,78 @@ __global__ void __launch_bounds__(kRoleBlock, 2) cy_roles_kernel(char* __restric
 #pragma unroll
             for (int a = 0; a < AMAX; ++a) pres[a] = (pres_bits >> a) & 1u;
             frz::scan_chunk_passive_front();
+            // Every row kind below is, for this wavefront's 64 envs, ONE run of consecutive bytes of its output array (row (agent, env) at
+            // (agent * B + env) * K).  The task rows (192 of the step's 420 bytes per env) go through LDS into whole lines (below); doing the
+            // same to the small self / others rows costs more in LDS round trips than their stores do (FRZ_CY_ROWS_LDS, off).
+#if FRZ_CY_TASKS_LDS
+            const int vw = (int)(threadIdx.x >> 6) & 3, ln = (int)(threadIdx.x & 63);
+            const int64_t b_first = (int64_t)chunk * kBlock + vw * 64;
+            const int live = (int)(B - b_first < 64 ? (B - b_first < 0 ? 0 : B - b_first) : 64);
+#endif
+#if FRZ_CY_TASKS_LDS && FRZ_CY_ROWS_LDS  // (the small self / others rows the same way: measured SLOWER, 6.59 against 6.11 us per step — off)
+            float* const stage_f = reinterpret_cast<float*>(&s_task_stage[vw][0]);
+            constexpr int KMAX = 3 * (AMAX > 1 ? AMAX - 1 : 1);
+            auto staged_rows = [&](float* out, const float (&vals)[KMAX], int K) {  // out: the row of the wavefront's FIRST env
+                if (K <= 0) return;
+#pragma unroll
+                for (int j = 0; j < KMAX; ++j)
+                    if (j < K) stage_f[ln * K + j] = vals[j];
+                frz::wave_lds_sync();
+                if (live == 64 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0) {
+                    for (int piece = ln; piece < 16 * K; piece += 64) reinterpret_cast<float4*>(out)[piece] = reinterpret_cast<const float4*>(stage_f)[piece];
+                } else {
+                    for (int piece = ln; piece < live * K; piece += 64) out[piece] = stage_f[piece];
+                }
+                frz::wave_lds_sync();
+            };
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a) {
+                if (a < Att) {  // attackers: (threat, presence) (:481-484)
+                    if (active) reinterpret_cast<float2*>(self_att)[a * B + b] = make_float2(d.threat[a], pres[a] ? 1.0f : 0.0f);
+                    float vals[KMAX];
+                    int col = 0;
+#pragma unroll
+                    for (int o = 0; o < AMAX; ++o)
+                        if (o < Att && o != a) {
+                            if (op) vals[col++] = d.threat[o];
+                            if (opr) vals[col++] = pres[o] ? 1.0f : 0.0f;
+                        }
+                    staged_rows(others_att + ((int64_t)a * B + b_first) * (int64_t)((Att - 1) * ka), vals, (Att - 1) * ka);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < AMAX; ++k) {
+                if (k < D) {  // defenders: (mitigation, presence, location) (:475-479)
+                    bool present_k = false;
+#pragma unroll
+                    for (int a = 0; a < AMAX; ++a) present_k = (a == Att + k) ? pres[a] : present_k;
+                    float own[KMAX];
+                    own[0] = d.mitigation[k];
+                    if (KMAX > 1) own[KMAX > 1 ? 1 : 0] = present_k ? 1.0f : 0.0f;
+                    if (KMAX > 2) own[KMAX > 2 ? 2 : 0] = (float)loc[k];
+                    if (KMAX >= 3) {
+                        staged_rows(self_def + ((int64_t)k * B + b_first) * 3, own, 3);
+                    } else if (active) {
+                        float* self = self_def + (k * B + b) * 3;
+                        self[0] = d.mitigation[k], self[1] = present_k ? 1.0f : 0.0f, self[2] = (float)loc[k];
+                    }
+                    float vals[KMAX];
+                    int col = 0;
+#pragma unroll
+                    for (int o = 0; o < AMAX; ++o)
+                        if (o < D && o != k) {
+                            bool present_o = false;
+#pragma unroll
+                            for (int a = 0; a < AMAX; ++a) present_o = (a == Att + o) ? pres[a] : present_o;
+                            if (op) vals[col++] = d.mitigation[o];
+                            if (opr) vals[col++] = present_o ? 1.0f : 0.0f;
+                            if (ol) vals[col++] = (float)loc[o];
+                        }
+                    staged_rows(others_def + ((int64_t)k * B + b_first) * (int64_t)((D - 1) * kd), vals, (D - 1) * kd);
+                }
+            }
+            if (false) {
+#else
             if (active) {
 #pragma unroll
                 for (int a = 0; a < AMAX; ++a) {
@@ -866,6 +951,8 @@ __global__ void __launch_bounds__(kRoleBlock, 2) cy_roles_kernel(char* __restric
                             }
                     }
                 }
+#endif
+#if !FRZ_CY_TASKS_LDS
                 // tasks (state, criticality) per agent; a defender sees them only right after monitoring (:497, :510-511)
 #pragma unroll
                 for (int a = 0; a < AMAX; ++a) {
@@ -883,7 +970,33 @@ __global__ void __launch_bounds__(kRoleBlock, 2) cy_roles_kernel(char* __restric
                                     hidden ? make_longlong2(-100, -100) : make_longlong2(state[n], d.criticality[n]);
                     }
                 }
+#endif
             }
+#if FRZ_CY_TASKS_LDS
+            {   // tasks (state, criticality) per agent; a defender sees them only right after monitoring (:497, :510-511).  An agent's rows of
+                // this wavefront's 64 envs are 64 * N * 16 CONSECUTIVE bytes of the output: staged in LDS in that order and written as
+                // lane-consecutive 16-byte pieces (whole lines per store instruction) instead of N pieces per lane at a stride of N * 16
+                // bytes — round 4: 7.3 -> 6.3 us per step of the episode launch (the lever was the store pattern, not the bytes)
+                longlong2* const stage = &s_task_stage[vw][0];
+#pragma unroll
+                for (int a = 0; a < AMAX; ++a) {
+                    if (a < A) {
+                        bool hidden = false;
+                        if (flags & kPartial) {
+#pragma unroll
+                            for (int k = 0; k < AMAX; ++k) hidden = (a == Att + k && k < D) ? last[k] != -3 : hidden;
+                        }
+#pragma unroll
+                        for (int n = 0; n < NMAX; ++n)
+                            if (n < N) stage[ln * N + n] = hidden ? make_longlong2(-100, -100) : make_longlong2(state[n], d.criticality[n]);
+                        frz::wave_lds_sync();
+                        longlong2* const out = reinterpret_cast<longlong2*>(tasks) + ((int64_t)a * B + b_first) * N;
+                        for (int piece = ln; piece < live * N; piece += 64) out[piece] = stage[piece];
+                        frz::wave_lds_sync();
+                    }
+                }
+            }
+#endif
             frz::scan_chunk_passive_back();
         }  // steps of this launch
         return;
@@ -910,7 +1023,10 @@ __global__ void __launch_bounds__(kRoleBlock, 2) cy_roles_kernel(char* __restric
 #pragma unroll
     for (int a = 0; a < AMAX; ++a) excl[a] = 0;
     // action mapping: arange(N) while present, empty otherwise (:441-457); `copy`: byte distance to the copy of the packed values to write
-    auto emit_mappings = [&](int64_t copy, int64_t ocopy) {
+    // The packed VALUES are position mod N wherever a segment lies (every segment is arange(N) and starts at a multiple of N): the env's own
+    // buffers hold that pattern since bind (cy_prefill_kernel) and a step only moves the offsets; only a list record — a caller's buffer —
+    // gets the values written (`values`).
+    auto emit_mappings = [&](int64_t copy, int64_t ocopy, bool values) {
         if (active) {
             int32_t* const act_values = reinterpret_cast<int32_t*>(arena + d.off_act_values + copy);
             int64_t* const act_offsets = reinterpret_cast<int64_t*>(arena + d.off_act_offsets + ocopy);
@@ -920,7 +1036,7 @@ __global__ void __launch_bounds__(kRoleBlock, 2) cy_roles_kernel(char* __restric
                     const int64_t off = (int64_t)excl[a] * N;
                     act_offsets[a * (B + 1) + b] = off;
                     if (b == B - 1) act_offsets[a * (B + 1) + B] = off + (pres[a] ? N : 0);
-                    if (pres[a]) {
+                    if (pres[a] && values) {
                         int32_t* v = act_values + a * B * N + off;
 #pragma unroll
                         for (int n = 0; n < NMAX; ++n)
@@ -934,7 +1050,7 @@ __global__ void __launch_bounds__(kRoleBlock, 2) cy_roles_kernel(char* __restric
         // the caller's buffers at the last step only; before it the second copy, or — with a list record — that step's copy of the whole
         // list block, offsets included
         const bool recorded = EXTRA && L.list_record_delta != 0 && t < n_steps - 1;
-        const int64_t copy = (PERSIST && t < n_steps - 1) ? (recorded ? L.list_record_delta + (int64_t)t * L.list_record_step : L.copy_delta) : (int64_t)0;
+        const int64_t copy = recorded ? L.list_record_delta + (int64_t)t * L.list_record_step : (int64_t)0;
         const int64_t ocopy = recorded ? copy : (int64_t)0;
         if constexpr (PERSIST) {
             if (t > 0) {
@@ -1041,7 +1157,7 @@ __global__ void __launch_bounds__(kRoleBlock, 2) cy_roles_kernel(char* __restric
                     }
                     at32(rows1, (uint32_t)d.u_frozen * Bu + bl) = 1;
                 }
-                emit_mappings(0, 0);  // the last mappings went to the second copy: once more, into the caller's buffers
+                emit_mappings(0, 0, false);  // (offsets only: the values never change, see emit_mappings)
                 break;
             }
             if (L.policy && active) {
@@ -1139,7 +1255,7 @@ __global__ void __launch_bounds__(kRoleBlock, 2) cy_roles_kernel(char* __restric
             const frz::ScanLaunch step{epoch_now, epoch_now + 1u, nullptr, ws.totals + (epoch_now & 1u) * frz::kTotalsStride};
             frz::scan_chunk<AMAX>(s_scan, ws, step, cnt, active, active && !trunc, A, chunk, nchunks, excl, &err);
         }
-        emit_mappings(copy, ocopy);
+        emit_mappings(copy, ocopy, recorded);
         executed = t + 1;
     }  // steps of this launch
     if (err) atomicOr(reinterpret_cast<uint32_t*>(arena + d.off_error), err);
@@ -1148,6 +1264,12 @@ __global__ void __launch_bounds__(kRoleBlock, 2) cy_roles_kernel(char* __restric
     if (executed > 0 && chunk == nchunks - 1 && threadIdx.x == 0) *ws.epoch = launch.epoch + (uint32_t)executed;
 }
 
+
+// the packed action-mapping values: position mod N (see emit_mappings), written once per bind over the whole capacity
+__global__ void __launch_bounds__(kBlock) cy_prefill_kernel(int32_t* values, int64_t count, int32_t N) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < count) values[i] = (int32_t)(i % N);
+}
 
 // uniform member of each agent's OneOf action space (spaces/actions.py:11-99), see oracle/frz_oracle_cybersecurity.c
 __global__ void __launch_bounds__(kBlock) cy_policy_kernel(const char* arena, uint32_t seed_lo, uint32_t seed_hi, uint32_t step_lo,
@@ -1418,6 +1540,14 @@ int frz_cybersecurity_bind(frz_cybersecurity_env* env, void* arena, void* stream
     if (hipMemcpyAsync(arena, &env->dev, sizeof(CyDev), hipMemcpyHostToDevice, s) != hipSuccess) return FRZ_E_LAUNCH;
     if (hipMemcpyAsync(env->arena + env->dev.off_lut, env->lut.data(), env->lut.size() * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess)
         return FRZ_E_LAUNCH;
+    {   // every agent's packed values are B * N ints, agent after agent: position mod N within an agent's block
+        const CyDev& p = env->dev;
+        const int64_t per_agent = (int64_t)p.B * p.N;
+        for (int a = 0; a < p.A; ++a)
+            hipLaunchKernelGGL(cy_prefill_kernel, dim3((unsigned)((per_agent + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+                               reinterpret_cast<int32_t*>(env->arena + p.off_act_values) + a * per_agent, per_agent, p.N);
+        if (hipGetLastError() != hipSuccess) return FRZ_E_LAUNCH;
+    }
     return hipStreamSynchronize(s) == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;
 }
 

@@ -10,7 +10,7 @@ from free_range_zoo_amd.utils.env import stream_ptr
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 MAXS = int(sys.argv[3]) if len(sys.argv) > 3 else 50
-dev = torch.device('cuda')
+dev = torch.device('cuda', 0)
 def make():
     e = cybersecurity_v0.parallel_env(configuration=configs.cyber_openness(), parallel_envs=B, max_steps=MAXS, device=dev, rng='philox', exact_shapes=False)
     e.reset(seed=torch.arange(B, dtype=torch.int32))
