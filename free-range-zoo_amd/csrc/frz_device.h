@@ -24,9 +24,12 @@ struct Philox4 {
     uint32_t w[4];
 };
 
+#ifndef FRZ_PHILOX_ROUNDS
+#define FRZ_PHILOX_ROUNDS 10  // (an experiment build may lower it: tools/dbg/ab_persist.py, profiles/r04_experiments.txt)
+#endif
 __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
-    for (int round = 0; round < 10; ++round) {
+    for (int round = 0; round < FRZ_PHILOX_ROUNDS; ++round) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;  // one 32x32->64 multiply each
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         const uint32_t n0 = hi1 ^ c1 ^ k0;
