@@ -553,8 +553,14 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                     const Placement place = placement();
                     const int64_t off_f = channel_offset(place, 0);
                     const pack_t oks = x_ok[slot];
+                    // single-step launch: the odd agents' lists (the crew writes the even ones, both roles finish together).  Multi-step
+                    // launch: EVERY agent's lists — the crew's decode of the next step (which includes the wait for the totals of the step
+                    // that just ended) then runs beside this phase instead of behind it.  (Round 4, from the phase stamps of
+                    // tools/dbg/stamps_multistep.py: the crew was busy for 14 300 of a step's 15 800 cycles, this role for 9 800.  Worth
+                    // 1-2 % only: what bounds a step of the launch is the two dependent agent-scope round trips of its hand-off — the
+                    // look-back behind the rewards, then the batch totals — not either role's instruction count: profiles/r04_experiments.txt.)
 #pragma unroll
-                    for (int a = 1; a < AMAX; a += 2)  // odd agents' lists (the crew writes the even ones)
+                    for (int a = (PERSIST ? 0 : 1); a < AMAX; a += (PERSIST ? 1 : 2))
                         if (a < A) emit_agent_lists(a, lit1, (mask_t)((oks >> (MB * a)) & (pack_t)((1u << MB) - 1u)), off_f, channel_offset(place, a + 1), b, copy, ocopy);
                     int64_t* const task_values = reinterpret_cast<int64_t*>(arena + d.off_task_values + copy);
                     int64_t* const task_offsets = reinterpret_cast<int64_t*>(arena + d.off_task_offsets + ocopy);
@@ -913,6 +919,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
             for (int c = 0; c < CMAX; ++c) lit_before |= (mask_t)(cells.f[c] > 0) << c;
             // phase 6 as a function of (lit cells, attackable cells per agent, copy of the packed lists)
             auto emit_crew = [&](mask_t lit1, const mask_t (&ok1)[AMAX], int64_t copy, int64_t ocopy) {
+                if constexpr (PERSIST) return;  // (the field role writes every list of a multi-step launch, see emit_field)
                 if (active) {
                     const Placement place = placement();
                     const int64_t off_f = channel_offset(place, 0);
