@@ -38,6 +38,7 @@ class raw_env(BatchedParallelEnv):
     """Environment definition for the cybersecurity environment."""
     _rebuild_symbol = 'frz_cybersecurity_rebuild'
     _domain = 'cybersecurity'
+    _hands_out_lazy = True  # step() may count steps instead of launching them (utils/env.py: deferred steps): public tensors are EnvTensors
 
     metadata = {'render.modes': ['human', 'rgb_array'], 'name': 'cybersecurity_v0', 'is_parallelizable': True, 'render_fps': 2,
                 'null_value': -100}
@@ -90,7 +91,9 @@ class raw_env(BatchedParallelEnv):
         self._network_state, self._location = v(bufs.network_state, (N, B), i32), v(bufs.location, (D, B), i32)
         self._presence = v(bufs.presence, (A, B), torch.bool)
         self._last_action = v(bufs.last_action, (D, B), i32)
-        self.num_moves = v(bufs.num_moves, (B, ), i32)
+        lazy = self._lazy  # (underscore names: plain views for the env's own code, which runs pending steps itself; public names: what callers get)
+        self._num_moves = v(bufs.num_moves, (B, ), i32)
+        self.num_moves = lazy(self._num_moves)
         self._rewards, self._cumulative = v(bufs.rewards, (A, B), f32), v(bufs.cumulative_rewards, (A, B), f32)
         self._terminations, self._truncations = v(bufs.terminations, (A, B), torch.bool), v(bufs.truncations, (A, B), torch.bool)
         self._self_att, self._self_def = v(bufs.obs_self_attackers, (Att, B, 2), f32), v(bufs.obs_self_defenders, (D, B, 3), f32)
@@ -99,13 +102,14 @@ class raw_env(BatchedParallelEnv):
         self._tasks = v(bufs.obs_tasks, (A, B, N, 2), i64)
         self._act_map_values, self._act_map_offsets = v(bufs.act_map_values, (A, B * N), i32), v(bufs.act_map_offsets, (A, B + 1), i64)
         self._obs_map_values, self._obs_map_offsets = v(bufs.obs_map_values, (B, N), i32), v(bufs.obs_map_offsets, (B + 1, ), i64)
-        self.environment_task_count, self.agent_task_count = v(bufs.env_task_count, (B, ), i32), v(bufs.agent_task_count, (A, B), i32)
+        self._env_task_count, self._agent_task_count = v(bufs.env_task_count, (B, ), i32), v(bufs.agent_task_count, (A, B), i32)
+        self.environment_task_count, self.agent_task_count = lazy(self._env_task_count), lazy(self._agent_task_count)
         self._frozen_scaled = v(bufs.frozen_scaled, (B, ), u8)
         self._error_flags = v(bufs.error_flags, (1, ), i32)
         self._actions = v(bufs.actions, (A, B, 2), i32)
-        self.generator.attach(seeds=v(bufs.seeds, (B, ), i32), states=v(bufs.mt_state, (624, B), i32), index=v(bufs.mt_index, (B, ), i32))
+        self.generator.attach(seeds=lazy(v(bufs.seeds, (B, ), i32)), states=lazy(v(bufs.mt_state, (624, B), i32)), index=lazy(v(bufs.mt_index, (B, ), i32)))
         self.seeds = self.generator.seeds
-        self._state = CybersecurityState(network_state=self._network_state.t(), location=self._location.t(), presence=self._presence.t())
+        self._state = CybersecurityState(network_state=lazy(self._network_state.t()), location=lazy(self._location.t()), presence=lazy(self._presence.t()))
 
     def _bind_handle(self, allocate: bool) -> None:
         handle = ctypes.c_void_p()
@@ -142,7 +146,7 @@ class raw_env(BatchedParallelEnv):
             act_maps = [jagged(self._act_map_values[a, :totals[a]], self._act_map_offsets[a], max_seqlen=N if totals[a] else 0)
                         for a in range(A)]
         elif getattr(self, '_static_views', None) is None:
-            act_maps = [jagged(self._act_map_values[a], self._act_map_offsets[a], max_seqlen=N, lengths=self.agent_task_count[a])
+            act_maps = [jagged(self._act_map_values[a], self._act_map_offsets[a], max_seqlen=N, lengths=self._agent_task_count[a])
                         for a in range(A)]
             self._static_views = True
         else:
@@ -208,15 +212,20 @@ class raw_env(BatchedParallelEnv):
         return out
 
     def _publish_dense(self) -> None:
-        self.rewards = {agent: self._rewards[a] for a, agent in enumerate(self.agents)}
-        self._cumulative_rewards = {agent: self._cumulative[a] for a, agent in enumerate(self.agents)}
-        self.terminations = {agent: self._terminations[a] for a, agent in enumerate(self.agents)}
-        self.truncations = {agent: self._truncations[a] for a, agent in enumerate(self.agents)}
-        self.actions = {agent: self._actions[a] for a, agent in enumerate(self.agents)}
+        views = self.__dict__.get('_dense_views')
+        if views is None:  # the per-agent rows of the dense blocks: fixed views, made once (a reset builds new dicts over them)
+            lazy, A = self._lazy, len(self.possible_agents)
+            views = self._dense_views = tuple([lazy(block[a]) for a in range(A)]
+                                              for block in (self._rewards, self._cumulative, self._terminations, self._truncations, self._actions))
+        agents = self.agents
+        self.rewards, self._cumulative_rewards = dict(zip(agents, views[0])), dict(zip(agents, views[1]))
+        self.terminations, self.truncations, self.actions = dict(zip(agents, views[2])), dict(zip(agents, views[3])), dict(zip(agents, views[4]))
 
     # ------------------------------------------------------------------------------------------------- reset
     @torch.no_grad()
     def reset(self, seed=None, options: Optional[Dict[str, Any]] = None):
+        self._flush()
+        self._defer_chunk = self._DEFER_MIN if self._defer_chunk else 0  # (an episode starts with short chunks: the device gets work at once)
         self._reset_options(options)
         if options and options.get('skip_seeding'):
             if not self.generator.has_been_seeded:
@@ -245,13 +254,14 @@ class raw_env(BatchedParallelEnv):
     @torch.no_grad()
     def reset_batches(self, batch_indices: torch.Tensor, seed: Optional[List[int]] = None, options: Optional[Dict[str, Any]] = None) -> None:
         """Partial reset (cybersecurity.py:268-292 + utils/env.py:162-189)."""
+        self._flush()
         batch_indices = torch.as_tensor(batch_indices, device=self.device).long()
         self.generator.seed(seed, partial_seeding=batch_indices)
         self._rewards[:, batch_indices] = 0
         self._cumulative[:, batch_indices] = 0
         self._terminations[:, batch_indices] = False
         self._truncations[:, batch_indices] = False
-        self.num_moves[batch_indices] = 0
+        self._num_moves[batch_indices] = 0
         self._frozen_scaled[batch_indices] = 0
         self._last_action[:, batch_indices] = -2
         self._actions[:, batch_indices] = -2
@@ -270,6 +280,11 @@ class raw_env(BatchedParallelEnv):
         """
         if not self._has_reset:
             raise RuntimeError('reset() must be called before step()')
+        if randomness is None:  # the reference's random-rollout loop hands over untouched samples of the action spaces (utils/env.py)
+            out = self._try_fast_step(actions)
+            if out is not None:
+                return out
+        self._flush()
         logged = self._logs_this_step()
         if isinstance(actions, dict):
             self._stage_actions(actions)
@@ -318,6 +333,7 @@ class raw_env(BatchedParallelEnv):
 
     @torch.no_grad()
     def random_policy_actions(self, policy_seed: int, policy_step: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        self._flush()
         out = self._actions if out is None else out
         self._call('random_policy', (policy_seed, policy_step, out.data_ptr()),
                    lambda: (policy_seed, policy_step, out, len(self.agents), self.parallel_envs))
@@ -329,6 +345,7 @@ class raw_env(BatchedParallelEnv):
         ``self.actions`` (not on a step taken after every env has finished, which is a no-op)."""
         if not self._has_reset:
             raise RuntimeError('reset() must be called before step_random_policy()')
+        self._flush()
         logged = self._logs_this_step()
         stream = stream_ptr(self.device)
         if self.rng == 'mt19937':
@@ -351,6 +368,7 @@ class raw_env(BatchedParallelEnv):
         """``[reset] + steps x (step with the random policy sampled in the launch)`` as one HIP graph (see the wildfire env)."""
         if not self._has_reset:
             raise RuntimeError('reset() must be called once before capturing a rollout')
+        self._flush()
         lib, handle, actions = self._lib, self._handle, self._actions.data_ptr()
         mt = self.rng == 'mt19937'
         if mt:
@@ -382,13 +400,14 @@ class raw_env(BatchedParallelEnv):
         if a.numel() != steps * self.parallel_envs * self._N or b.numel() != steps * self.parallel_envs * len(self.agents):
             raise ValueError('randomness tapes must hold [steps, B, N] and [steps, B, A] float32 values')
 
-    def set_exclusive_device(self, exclusive: bool = True) -> bool:
+    def set_exclusive_device(self, exclusive: bool = True, defer_steps: bool = True) -> bool:
         """State that nothing else uses this GPU while the env's rollouts run: allows ``rollout`` / ``rollout_random_policy`` /
         ``capture_random_rollout`` to run a rollout as ONE launch (include/frz.h: frz_cybersecurity_set_exclusive_device; see the wildfire
         env).  Off by default.  False: the library's own residency check refused (the rollouts keep taking one launch per step)."""
         code = self._lib.frz_cybersecurity_set_exclusive_device(self._handle, 1 if exclusive else 0)
         if code not in (0, _capi.DEFINES['FRZ_E_INVALID']):  # (no device, a dead handle: errors, not a refusal)
             _capi.check(code, 'frz_cybersecurity_set_exclusive_device')
+        self._enable_deferral(code == 0 and exclusive, defer_steps)
         return code == 0
 
     @torch.no_grad()
@@ -397,6 +416,7 @@ class raw_env(BatchedParallelEnv):
         the steps are taken one by one)."""
         if not self._has_reset:
             raise RuntimeError('reset() must be called before rollout_random_policy()')
+        self._flush()
         if self.logger is not None or self.rng == 'mt19937' and (self.single_seeding or self.generator.buffer_size):
             out = None
             for t in range(steps):
@@ -418,7 +438,7 @@ class raw_env(BatchedParallelEnv):
         from free_range_zoo_amd.envs.cybersecurity.env.spaces import actions
         index = self.possible_agents.index(agent)
         counts = self.environment_task_count if self.show_bad_actions else self.agent_task_count[index]
-        location = self._location[index - self._Att] if index >= self._Att else None
+        location = self._lazy(self._location[index - self._Att]) if index >= self._Att else None  # (looked at only by code that inspects the members)
         return actions.build_action_space(agent.split('_')[0], self.show_bad_actions, counts, location, sampler=self._space_sampler(index))
 
     def observation_space(self, agent: str):

@@ -239,6 +239,9 @@ class raw_env(BatchedParallelEnv):
         """
         if not self._has_reset:
             raise RuntimeError('reset() must be called before step()')
+        out = self._try_fast_step(actions)  # the reference's random-rollout loop: untouched samples are drawn inside the step's first launch
+        if out is not None:
+            return out
         logged = self._logs_this_step()
         if isinstance(actions, dict):
             self._stage_actions(actions)
@@ -264,6 +267,19 @@ class raw_env(BatchedParallelEnv):
         return out
 
     step_kernels = 'rs_env_kernel + rs_offsets_kernel + rs_emit_kernel (policy sampled in the first launch)'
+
+    # the fused policy + step entry of this domain draws nothing but the policy: frz_rideshare_step_random_policy(env, seed, step, actions_out, stream)
+    def _fused_rng_mode(self) -> int:
+        return _capi.FRZ_RNG_PHILOX
+
+    def _fused_mode_or_none(self):
+        return _capi.FRZ_RNG_PHILOX
+
+    def _single_fused_args(self, mode: int) -> tuple:
+        return ()
+
+    def _fused_ops_tail(self, mode: int) -> tuple:
+        return (len(self.agents), self.parallel_envs)
 
     @torch.no_grad()
     def step_random_policy(self, policy_seed: int, policy_step: int):

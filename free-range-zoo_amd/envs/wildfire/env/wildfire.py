@@ -321,40 +321,10 @@ class raw_env(BatchedParallelEnv):
         """
         if not self._has_reset:
             raise RuntimeError('reset() must be called before step()')
-        if randomness is None and type(actions) is dict and self.__dict__.get('_pending_samples') is not None:
-            # the reference's random-rollout loop hands over untouched samples of the action spaces: drawn inside the step launch
-            draw = self._untouched_samples(actions)
-            if draw is not None:
-                if self.rng == 'mt19937' and (self.single_seeding or self.generator.buffer_size):
-                    self._pending_samples[3] = False  # (these draw through the generator API: the samples are made by the policy launch)
-                elif self._ops is not None:
-                    mode = self._fused_rng_mode()
-                    self._call('step_random_policy', (), lambda: (self.policy_seed, draw, self._sampled_actions, mode, len(self.agents), self.parallel_envs))
-                    return self._after_fused(False)
-                else:
-                    chunk = self._defer_chunk
-                    if chunk:  # the device is this env's alone: the step is counted, not launched (utils/env.py: deferred steps)
-                        n = self._deferred
-                        if n and (self._deferred_first + n != draw or self._deferred_seed != self.policy_seed):
-                            self._flush()
-                            n = 0
-                        if n == 0:
-                            self._deferred_first, self._deferred_seed = draw, self.policy_seed
-                        self._deferred = n + 1
-                        if n + 1 >= chunk:  # nobody looked for a whole chunk: launch it, make the next one longer
-                            self._flush()
-                            self._defer_chunk = min(2 * chunk, self._DEFER_MAX)
-                        return self._after_fast_step()
-                    fast = self.__dict__.get('_fast_step')
-                    if fast is None:  # (entry point, sample buffer address, RNG mode: fixed for the life of the env)
-                        fast = self._fast_step = (self._lib.frz_wildfire_step_random_policy, self._sampled_actions.data_ptr(), self._fused_rng_mode(),
-                                                  self.device.index)
-                    if fast[2] == _capi.FRZ_RNG_MT19937:
-                        self.generator._ensure_streams()  # (a reset with new seeds since the last step: the streams are expanded again)
-                    code = fast[0](self._handle, self.policy_seed, draw, fast[1], fast[2], None, None, torch._C._cuda_getCurrentRawStream(fast[3]))
-                    if code:
-                        _capi.check(code, 'frz_wildfire_step_random_policy')
-                    return self._after_fast_step()
+        if randomness is None:  # the reference's random-rollout loop hands over untouched samples of the action spaces (utils/env.py)
+            out = self._try_fast_step(actions)
+            if out is not None:
+                return out
         self._flush()
         logged = self._logs_this_step()
         if isinstance(actions, dict):
@@ -487,24 +457,11 @@ class raw_env(BatchedParallelEnv):
             self._log_environment()
         return (self._observations_out(), self.rewards, self.terminations, self.truncations, self.infos)
 
-    def _after_fast_step(self):
-        """_after_fused(False) of the exact-shapes default, inlined for the per-step hot path of the reference-shaped rollout loop."""
-        d = self.__dict__
-        if d.get('_global_group', False) is not False:
-            self._exchange_batch_totals()
-        self._epoch_counter += 1
-        if self.exact_shapes:
-            if 'observations' in d or 'task_store' in d:  # (somebody looked at the last step's outputs: they are stale now)
-                for name in self._LAZY_OUTPUTS:
-                    d.pop(name, None)
-            observations = LazyAgentDict(self, self.agents)
-        else:
-            self._materialize()
-            observations = {agent: self.observations[agent] for agent in self.agents}
-        infos = self.infos = {agent: {} for agent in self.agents}
+    def _step_infos(self) -> dict:
+        infos = {agent: {} for agent in self.agents}
         infos['burnouts'] = self._burnouts_out
         infos['putouts'] = self._putouts_out
-        return (observations, self.rewards, self.terminations, self.truncations, infos)
+        return infos
 
     @torch.no_grad()
     def step_random_policy(self, policy_seed: int, policy_step: int):
@@ -595,30 +552,6 @@ class raw_env(BatchedParallelEnv):
         return {agent: TensorDict({'self': obs_self[a], 'others': obs_others[a], 'tasks': tasks}, batch_size=[B], device=self.device)
                 for a, agent in enumerate(self.agents)}
 
-    def _launch_deferred(self, n: int, first: int, seed: int) -> None:
-        """`n` counted steps of the reference-shaped random loop (policy steps first .. first + n - 1, drawn inside the launch into the
-        sample buffer, which afterwards holds the last step's draw — what n single-step launches leave): ONE multi-step launch."""
-        launcher = self.__dict__.get('_deferred_launcher')
-        if launcher is None:
-            spec = _capi.frz_rollout_spec()
-            spec.rng_mode, spec.actions_out = self._fused_rng_mode(), self._sampled_actions.data_ptr()
-            launcher = self._deferred_launcher = (spec, ctypes.byref(spec), self._lib.frz_wildfire_rollout, self._lib.frz_wildfire_step_random_policy,
-                                                  self._sampled_actions.data_ptr(), self.device.index)
-        spec, ref, rollout, single, samples, index = launcher
-        if spec.rng_mode == _capi.FRZ_RNG_MT19937:
-            self.generator._ensure_streams()
-        stream = torch._C._cuda_getCurrentRawStream(index)
-        if n == 1:
-            code = single(self._handle, seed, first, samples, spec.rng_mode, None, None, stream)
-        else:
-            spec.n_steps, spec.policy_seed, spec.first_step = n, seed, first
-            code = rollout(self._handle, ref, stream)
-        log = self.__dict__.get('_deferred_log')
-        if log is not None:  # (tests: the chunk sizes that were launched)
-            log.append(n)
-        if code:
-            _capi.check(code, 'frz_wildfire_rollout (deferred steps)')
-
     def set_exclusive_device(self, exclusive: bool = True, defer_steps: bool = True) -> bool:
         """State that nothing else uses this GPU while the env's rollouts run (no other process, no concurrent stream).  It allows
         ``rollout`` / ``rollout_random_policy`` / ``capture_random_rollout`` to run a whole rollout as ONE launch where the library has a
@@ -633,19 +566,8 @@ class raw_env(BatchedParallelEnv):
         code = self._lib.frz_wildfire_set_exclusive_device(self._handle, 1 if exclusive else 0)
         if code not in (0, _capi.DEFINES['FRZ_E_INVALID']):  # (no device, a dead handle: errors, not a refusal)
             _capi.check(code, 'frz_wildfire_set_exclusive_device')
-        if code == 0 and exclusive and defer_steps and self._can_defer():
-            self._defer_chunk = self._DEFER_MIN
+        self._enable_deferral(code == 0 and exclusive, defer_steps)
         return code == 0
-
-    def _can_defer(self) -> bool:
-        """Deferred steps (utils/env.py) need: a multi-step launch for the shape, the exact-shapes publication (observations are built when
-        looked at), the ctypes dispatch, no logging tap (it reads every step), and the per-env device streams in the MT19937 mode."""
-        if not self.exact_shapes or self._ops is not None or self.logger is not None:
-            return False
-        if self.rng == 'mt19937' and (self.single_seeding or self.generator.buffer_size):
-            return False
-        mode = _capi.FRZ_RNG_MT19937 if self.rng == 'mt19937' else _capi.FRZ_RNG_PHILOX
-        return self._lib.frz_wildfire_rollout_launches(self._handle, 2, mode) == 1
 
     # ------------------------------------------------------------------------ sharded jobs: globally consistent batch semantics (optional)
     def set_global_consistency(self, enabled: bool = True, group=None) -> None:

@@ -316,8 +316,122 @@ class BatchedParallelEnv:
             self._deferred = 0
             self._launch_deferred(n, self._deferred_first, self._deferred_seed)
 
+    # what the fast path of the reference-shaped random loop needs from a domain: how its fused policy + step entry is called
+    # (`_single_fused_args`: what follows (handle, policy seed, policy step, sample buffer)), whether `frz_<domain>_rollout` can run several
+    # such steps as ONE launch (`_deferral_possible`), and what `step()` returns besides the dense dicts (`_step_infos`)
+    def _single_fused_args(self, mode: int) -> tuple:
+        return (mode, None, None)
+
+    def _fused_mode_or_none(self) -> Optional[int]:
+        """RNG mode of the fused policy + step entry, or None where the draws must go through the generator API (single_seeding, buffered
+        draws: the samples are then made by the policy launch and the step takes them as given actions)."""
+        if self.rng == 'mt19937' and (self.single_seeding or self.generator.buffer_size):
+            return None
+        return self._fused_rng_mode()
+
+    def _step_infos(self) -> dict:
+        return {agent: {} for agent in self.agents}
+
+    def _try_fast_step(self, actions):
+        """`step(actions)` of the reference-shaped random loop — `actions` is exactly this step's untouched
+        `{agent: env.action_space(agent).sample_nested()}` — with the samples drawn INSIDE the step launch (one launch per step), or, once the
+        device was declared exclusive, only counted (deferred steps, above).  None: not that case, `step()` goes on as usual."""
+        if type(actions) is not dict or self.__dict__.get('_pending_samples') is None:
+            return None
+        draw = self._untouched_samples(actions)
+        if draw is None:
+            return None
+        if self._fused_mode_or_none() is None:
+            self._pending_samples[3] = False  # (drawn by the policy launch when step() stages them)
+            return None
+        if self._ops is not None:
+            mode = self._fused_rng_mode()
+            self._call('step_random_policy', (), lambda: (self.policy_seed, draw, self._sampled_actions, *self._fused_ops_tail(mode)))
+            return self._after_fused(False)
+        chunk = self._defer_chunk
+        if chunk:  # the device is this env's alone: the step is counted, not launched
+            n = self._deferred
+            if n and (self._deferred_first + n != draw or self._deferred_seed != self.policy_seed):
+                self._flush()
+                n = 0
+            if n == 0:
+                self._deferred_first, self._deferred_seed = draw, self.policy_seed
+            self._deferred = n + 1
+            if n + 1 >= chunk:  # nobody looked for a whole chunk: launch it, make the next one longer
+                self._flush()
+                self._defer_chunk = min(2 * chunk, self._DEFER_MAX)
+            return self._after_fast_step()
+        self._launch_deferred(1, draw, self.policy_seed)
+        return self._after_fast_step()
+
+    def _fused_ops_tail(self, mode: int) -> tuple:
+        """What follows (arena, handle, policy seed, policy step, sample buffer) in `torch.ops.frz.<domain>_step_random_policy`."""
+        return (mode, len(self.agents), self.parallel_envs)
+
     def _launch_deferred(self, n: int, first: int, seed: int) -> None:
-        raise NotImplementedError
+        """`n` counted steps of the reference-shaped random loop (policy steps first .. first + n - 1, drawn inside the launch into the
+        sample buffer, which afterwards holds the last step's draw — what n single-step launches leave): ONE multi-step launch through
+        `frz_<domain>_rollout`; a single step: the fused policy + step entry."""
+        launcher = self.__dict__.get('_deferred_launcher')
+        if launcher is None:
+            spec = _capi.frz_rollout_spec()
+            mode = self._fused_rng_mode()
+            spec.rng_mode, spec.actions_out = mode, self._sampled_actions.data_ptr()
+            launcher = self._deferred_launcher = (spec, ctypes.byref(spec), getattr(self._lib, f'frz_{self._domain}_rollout'),
+                                                  getattr(self._lib, f'frz_{self._domain}_step_random_policy'), self._sampled_actions.data_ptr(),
+                                                  self.device.index, self._single_fused_args(mode), mode)
+        spec, ref, rollout, single, samples, index, tail, mode = launcher
+        if mode == _capi.FRZ_RNG_MT19937:
+            self.generator._ensure_streams()  # (a reset with new seeds since the last step: the streams are expanded again)
+        stream = torch._C._cuda_getCurrentRawStream(index)
+        if n == 1:
+            code = single(self._handle, seed, first, samples, *tail, stream)
+        else:
+            spec.n_steps, spec.policy_seed, spec.first_step = n, seed, first
+            code = rollout(self._handle, ref, stream)
+        log = self.__dict__.get('_deferred_log')
+        if log is not None:  # (tests, bench: the chunk sizes that were launched)
+            log.append(n)
+        if code:
+            _capi.check(code, f'frz_{self._domain}_rollout (counted steps)')
+
+    def _after_fast_step(self):
+        """What `step()` returns on the fast path: the publication of the exact-shapes default inlined (nothing is read from the device)."""
+        d = self.__dict__
+        if d.get('_global_group', False) is not False:
+            self._exchange_batch_totals()
+        self._epoch_counter += 1
+        if self.exact_shapes:
+            if 'observations' in d or 'task_store' in d:  # (somebody looked at the last step's outputs: they are stale now)
+                for name in self._LAZY_OUTPUTS:
+                    d.pop(name, None)
+            observations = LazyAgentDict(self, self.agents)
+        else:
+            self._materialize()
+            observations = {agent: self.observations[agent] for agent in self.agents}
+        self.infos = infos = self._step_infos()
+        return (observations, self.rewards, self.terminations, self.truncations, infos)
+
+    def _after_fused(self, logged: bool):
+        """What a fused policy + step call returns (domains with extra infos override `_step_infos`)."""
+        self._publish()
+        self.infos = self._step_infos()
+        if logged:
+            self._log_environment()
+        return (self._observations_out(), self.rewards, self.terminations, self.truncations, self.infos)
+
+    def _enable_deferral(self, accepted: bool, defer_steps: bool) -> None:
+        """After `frz_<domain>_set_exclusive_device`: counted steps need a multi-step launch for the shape, the exact-shapes publication
+        (observations are built when looked at), the ctypes dispatch, no logging tap (it reads every step), tensors handed out as
+        EnvTensors, and the per-env device streams in the MT19937 mode."""
+        self._defer_chunk = 0
+        if not (accepted and defer_steps and self._hands_out_lazy and self.exact_shapes and self._ops is None and self.logger is None):
+            return
+        if self.rng == 'mt19937' and (self.single_seeding or self.generator.buffer_size):
+            return
+        mode = _capi.FRZ_RNG_MT19937 if self.rng == 'mt19937' else _capi.FRZ_RNG_PHILOX
+        if getattr(self._lib, f'frz_{self._domain}_rollout_launches')(self._handle, 2, mode) == 1:
+            self._defer_chunk = self._DEFER_MIN
 
     def _lazy(self, view: torch.Tensor) -> torch.Tensor:
         """`view` as the env hands it out: an EnvTensor where steps may be deferred."""

@@ -184,6 +184,72 @@ def test_reference_shaped_loop_with_mt19937_streams_across_resets():
     fused.check()
 
 
+@pytest.mark.parametrize('domain', ['cybersecurity', 'rideshare'])
+def test_reference_shaped_random_rollout_in_the_other_domains(domain):
+    """The same loop in cybersecurity and rideshare: untouched `sample_nested()` results are drawn inside the step launch (one launch per
+    step instead of a policy launch + a step launch) with the values the policy launch would have produced."""
+    from free_range_zoo_amd.utils.env import LazySample
+    module, build, kwargs = _domains()[domain]
+    B = 2049
+    fused, plain = [module.parallel_env(configuration=build(), parallel_envs=B, max_steps=9, device=torch.device('cuda'), **kwargs) for _ in range(2)]
+    launches = fused._deferred_log = []
+    for env in (fused, plain):
+        env.reset(seed=torch.arange(B, dtype=torch.int32) + 3)
+    names = {'cybersecurity': ('_network_state', '_location', '_presence', '_rewards', '_act_map_offsets', '_tasks'),
+             'rideshare': ('_rewards', '_task_offsets', '_agent_offsets', '_obs_self')}[domain]
+    for t in range(11):  # past the horizon: the last steps are frozen
+        a = {agent: fused.action_space(agent).sample_nested() for agent in fused.agents}
+        assert all(type(v) is LazySample for v in a.values())
+        live = not bool(fused.finished.all())
+        fused.step(a)
+        acts = plain.random_policy_actions(plain.policy_seed, t).clone()
+        plain.step(acts)
+        if live:
+            for i, agent in enumerate(fused.agents):
+                assert torch.equal(a[agent].as_subclass(torch.Tensor), acts[i]), f'{domain} step {t}: samples drawn inside the step launch, {agent}'
+        for name in names:
+            assert torch.equal(getattr(fused, name), getattr(plain, name)), f'{domain}: {name} at step {t}'
+    assert launches == [1] * 11, 'one fused launch per step'
+    fused.check()
+
+
+def test_deferred_steps_in_cybersecurity():
+    """Counted steps (utils/env.py) for cybersecurity: the reference-shaped loop on an exclusive device runs in multi-step launches and
+    whatever is looked at equals the step-by-step twin."""
+    import random
+    from free_range_zoo_amd.envs import cybersecurity_v0
+    import test_hip_cybersecurity as C
+    B, horizon = 2500, 20
+    lazy, eager = [cybersecurity_v0.parallel_env(configuration=configs.cyber_openness(), parallel_envs=B, max_steps=horizon, device=torch.device('cuda'),
+                                                 rng='philox') for _ in range(2)]
+    assert lazy.set_exclusive_device(True) and lazy._defer_chunk > 0 and eager._defer_chunk == 0
+    lazy._deferred_log = log = []
+    picker = random.Random(3)
+    steps_taken = 0
+    for episode in range(2):
+        seeds = torch.arange(B, dtype=torch.int32) * 5 + episode
+        lazy.reset(seed=seeds), eager.reset(seed=seeds)
+        for t in range(horizon + 3):
+            out_l = lazy.step({agent: lazy.action_space(agent).sample_nested() for agent in lazy.agents})
+            out_e = eager.step({agent: eager.action_space(agent).sample_nested() for agent in eager.agents})
+            steps_taken += 1
+            agent = lazy.agents[picker.randrange(len(lazy.agents))]
+            peek = picker.randrange(9)
+            if peek == 0:
+                assert torch.equal(out_l[1][agent], out_e[1][agent]), f'rewards at {episode}/{t}'
+            elif peek == 1:
+                assert torch.equal(lazy.num_moves, eager.num_moves)
+            elif peek == 2:
+                assert torch.equal(out_l[0][agent]['tasks'], out_e[0][agent]['tasks']) and torch.equal(out_l[0][agent]['self'], out_e[0][agent]['self'])
+            elif peek == 3:
+                assert torch.equal(lazy.state().network_state, eager.state().network_state)
+            elif peek == 4:
+                assert lazy.action_space(agent).spaces[:30] == eager.action_space(agent).spaces[:30]
+        C.compare_snapshots(C.hip_snapshot(lazy), C.hip_snapshot(eager), f'end of episode {episode}')
+    lazy.check()
+    assert sum(log) == steps_taken and max(log) > 2, f'chunks launched: {log}'
+
+
 def test_observations_of_an_earlier_step_refuse_to_fill_late():
     """The dict step() returns stands for THAT step: filled after the next step it would hold the next step's observations — it
     raises instead; looked at in time (or copied) it keeps working."""
