@@ -80,6 +80,10 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
     constexpr bool kPhilox = RNG == FRZ_RNG_PHILOX && MODE == kStep;
     constexpr bool kMt = RNG == FRZ_RNG_MT19937 && MODE == kStep;  // per-env MT19937 streams advanced inside the step
     constexpr bool kInjected = RNG == FRZ_RNG_INJECTED && MODE == kStep;
+    // multi-step launches with in-kernel Philox draws: the field role writes EVERY list (see emit_field).  Not with the per-env MT19937 streams:
+    // there the field role's own phase 1 (66 stream words in, 33 twisted and written back) is the long one, and the old split is faster
+    // (round 4: 12.2 against 10.7 us per step of the default-RNG block when it wrote all the lists too)
+    constexpr bool kFieldWritesAllLists = PERSIST && RNG == FRZ_RNG_PHILOX;
     static_assert(EXACT || !(kPhilox || kMt), "runtime shapes stage their draws (wf_philox_fill_kernel / frz_mt19937_generate)");
 
     __shared__ uint64_t s_wave_scan[frz::kWaves][PW];
@@ -554,13 +558,13 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                     const int64_t off_f = channel_offset(place, 0);
                     const pack_t oks = x_ok[slot];
                     // single-step launch: the odd agents' lists (the crew writes the even ones, both roles finish together).  Multi-step
-                    // launch: EVERY agent's lists — the crew's decode of the next step (which includes the wait for the totals of the step
+                    // launch with Philox draws: EVERY agent's lists — the crew's decode of the next step (which includes the wait for the totals of the step
                     // that just ended) then runs beside this phase instead of behind it.  (Round 4, from the phase stamps of
                     // tools/dbg/stamps_multistep.py: the crew was busy for 14 300 of a step's 15 800 cycles, this role for 9 800.  Worth
                     // 1-2 % only: what bounds a step of the launch is the two dependent agent-scope round trips of its hand-off — the
                     // look-back behind the rewards, then the batch totals — not either role's instruction count: profiles/r04_experiments.txt.)
 #pragma unroll
-                    for (int a = (PERSIST ? 0 : 1); a < AMAX; a += (PERSIST ? 1 : 2))
+                    for (int a = (kFieldWritesAllLists ? 0 : 1); a < AMAX; a += (kFieldWritesAllLists ? 1 : 2))
                         if (a < A) emit_agent_lists(a, lit1, (mask_t)((oks >> (MB * a)) & (pack_t)((1u << MB) - 1u)), off_f, channel_offset(place, a + 1), b, copy, ocopy);
                     int64_t* const task_values = reinterpret_cast<int64_t*>(arena + d.off_task_values + copy);
                     int64_t* const task_offsets = reinterpret_cast<int64_t*>(arena + d.off_task_offsets + ocopy);
@@ -919,7 +923,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
             for (int c = 0; c < CMAX; ++c) lit_before |= (mask_t)(cells.f[c] > 0) << c;
             // phase 6 as a function of (lit cells, attackable cells per agent, copy of the packed lists)
             auto emit_crew = [&](mask_t lit1, const mask_t (&ok1)[AMAX], int64_t copy, int64_t ocopy) {
-                if constexpr (PERSIST) return;  // (the field role writes every list of a multi-step launch, see emit_field)
+                if constexpr (kFieldWritesAllLists) return;  // (the field role writes every list of such a launch, see emit_field)
                 if (active) {
                     const Placement place = placement();
                     const int64_t off_f = channel_offset(place, 0);

@@ -270,7 +270,6 @@ class raw_env(BatchedParallelEnv):
         self._publish()
 
     # -------------------------------------------------------------------------------------------------- step
-    @torch.no_grad()
     def step(self, actions, randomness: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
         """
         One simultaneous step.  ``actions``: ``{agent: IntTensor[B, 2]}`` (attackers ``(node, 0)`` attack / ``(_, -1)`` noop;
@@ -284,6 +283,10 @@ class raw_env(BatchedParallelEnv):
             out = self._try_fast_step(actions)
             if out is not None:
                 return out
+        with torch.no_grad():
+            return self._step_given_actions(actions, randomness)
+
+    def _step_given_actions(self, actions, randomness):
         self._flush()
         logged = self._logs_this_step()
         if isinstance(actions, dict):
@@ -432,14 +435,20 @@ class raw_env(BatchedParallelEnv):
         return (self._observations_out(), self.rewards, self.terminations, self.truncations, self.infos)
 
     # ------------------------------------------------------------------------------------------------ spaces
-    @torch.no_grad()
     def action_space(self, agent: str) -> BatchedOneOfSpace:
         """Per-env OneOf (cybersecurity.py:528-551, spaces/actions.py:11-99)."""
+        try:  # (the object is count-based over views of the env's buffers — it always describes the current step — so one per agent is built)
+            return self._action_spaces[agent]
+        except (AttributeError, KeyError):
+            pass
         from free_range_zoo_amd.envs.cybersecurity.env.spaces import actions
         index = self.possible_agents.index(agent)
         counts = self.environment_task_count if self.show_bad_actions else self.agent_task_count[index]
         location = self._lazy(self._location[index - self._Att]) if index >= self._Att else None  # (looked at only by code that inspects the members)
-        return actions.build_action_space(agent.split('_')[0], self.show_bad_actions, counts, location, sampler=self._space_sampler(index))
+        space = actions.build_action_space(agent.split('_')[0], self.show_bad_actions, counts, location, sampler=self._space_sampler(index),
+                                           epoch=lambda: self._epoch_counter)
+        self.__dict__.setdefault('_action_spaces', {})[agent] = space
+        return space
 
     def observation_space(self, agent: str):
         """The same ``Dict{self, others, tasks}`` for every env (it never changes size; cached like the reference's, cybersecurity.py:553-578)."""

@@ -10,9 +10,9 @@ from free_range_zoo_amd.utils.spaces import BatchedOneOfSpace, Space
 
 
 def build_action_space(agent_type: str, show_bad_actions: bool, environment_task_counts: torch.Tensor, current_location: torch.Tensor = None,
-                       sampler=None) -> BatchedOneOfSpace:
+                       sampler=None, epoch=None) -> BatchedOneOfSpace:
     if agent_type == 'attacker':
-        return BatchedOneOfSpace(environment_task_counts, tail=[-1], sampler=sampler)
+        return BatchedOneOfSpace(environment_task_counts, tail=[-1], sampler=sampler, epoch=epoch)
     if agent_type != 'defender':
         raise ValueError(f'Invalid agent type: {agent_type}')
     counts, location = environment_task_counts, current_location
@@ -22,7 +22,7 @@ def build_action_space(agent_type: str, show_bad_actions: bool, environment_task
         can_patch = has_tasks & (torch.full_like(has_tasks, bool(show_bad_actions)) | (location != -1))
         return torch.stack([torch.ones_like(has_tasks), can_patch, has_tasks], dim=1)
 
-    return BatchedOneOfSpace(counts, tail=[-1, -2, -3], tail_mask=tail_mask, sampler=sampler)
+    return BatchedOneOfSpace(counts, tail=[-1, -2, -3], tail_mask=tail_mask, sampler=sampler, epoch=epoch)
 
 
 @functools.lru_cache(maxsize=100)

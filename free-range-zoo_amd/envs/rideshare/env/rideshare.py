@@ -324,9 +324,12 @@ class raw_env(BatchedParallelEnv):
         return graph
 
     # ------------------------------------------------------------------------------------------------ spaces
-    @torch.no_grad()
     def action_space(self, agent: str) -> BatchedOneOfSpace:
         """Per-env ``OneOf([Discrete(1, start=state_t) for visible task t] + [noop])`` (rideshare.py:469-487, spaces/actions.py:10-50)."""
+        try:  # (count-based over views of the env's buffers, the member starts resolved per step: one object per agent)
+            return self._action_spaces[agent]
+        except (AttributeError, KeyError):
+            pass
         a = self.possible_agents.index(agent)
         counts = self.agent_task_count[a]
 
@@ -338,7 +341,9 @@ class raw_env(BatchedParallelEnv):
             return states.to_padded_tensor(0)
 
         from free_range_zoo_amd.envs.rideshare.env.spaces import actions
-        return actions.build_action_space(starts, counts, sampler=self._space_sampler(a))
+        space = actions.build_action_space(starts, counts, sampler=self._space_sampler(a), epoch=lambda: self._epoch_counter)
+        self.__dict__.setdefault('_action_spaces', {})[agent] = space
+        return space
 
     def observation_space(self, agent: str):
         """Per-env ``Dict{self, others, tasks}`` sized by the tasks the agent sees (rideshare.py:489-504), count-based."""

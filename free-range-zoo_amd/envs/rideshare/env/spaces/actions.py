@@ -8,10 +8,10 @@ from typing import Tuple
 from free_range_zoo_amd.utils.spaces import BatchedOneOfSpace, Space
 
 
-def build_action_space(environment_action_choices, environment_task_counts, sampler=None) -> BatchedOneOfSpace:
+def build_action_space(environment_action_choices, environment_task_counts, sampler=None, epoch=None) -> BatchedOneOfSpace:
     """``environment_action_choices``: padded int tensor [B, max tasks] of the task members' starts, or a zero-argument callable
     producing it on first inspection (it costs host reads); ``environment_task_counts``: tasks per env."""
-    return BatchedOneOfSpace(environment_task_counts, tail=[-1], task_starts=environment_action_choices, sampler=sampler)
+    return BatchedOneOfSpace(environment_task_counts, tail=[-1], task_starts=environment_action_choices, sampler=sampler, epoch=epoch)
 
 
 @functools.lru_cache(maxsize=100)

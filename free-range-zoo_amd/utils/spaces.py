@@ -191,7 +191,7 @@ class BatchedOneOfSpace:
     as rollout code does)."""
 
     def __init__(self, task_counts: torch.Tensor, tail: Sequence[int], task_starts: torch.Tensor = None,
-                 tail_mask: torch.Tensor = None, sampler=None):
+                 tail_mask: torch.Tensor = None, sampler=None, epoch=None):
         """
         task_counts: int tensor [B] — number of task members (Discrete(1, start=task_starts or 0)) per env
         tail:        values of the task-agnostic members appended after the tasks (e.g. [-1] = noop)
@@ -203,21 +203,35 @@ class BatchedOneOfSpace:
         self._task_starts = task_starts  # tensor, None, or a zero-argument callable resolved on first use (it may cost a host read)
         self._tail_mask = tail_mask  # tensor, None, or a zero-argument callable resolved on first use
         self.sampler = sampler  # optional () -> int32 [B, 2]: the env's device-side policy kernel (one launch for all agents)
+        # optional () -> int: the env's step counter.  An env hands out ONE space object per agent for its whole life (the counts are views:
+        # the object always describes the current step); the parts given as callables are then resolved again once the env has moved on
+        self._epoch = epoch
+        self._resolved = {}
 
     def __len__(self):
         return int(self.task_counts.shape[0])
 
+    def _resolve(self, name: str):
+        value = getattr(self, name)
+        if not callable(value):
+            return value
+        if self._epoch is None:  # a space of one step (taken anew every step, as rollout code does): resolved once
+            value = value()
+            setattr(self, name, value)
+            return value
+        epoch = self._epoch()
+        cached = self._resolved.get(name)
+        if cached is None or cached[0] != epoch:
+            cached = self._resolved[name] = (epoch, value())
+        return cached[1]
+
     @property
     def tail_mask(self):
-        if callable(self._tail_mask):
-            self._tail_mask = self._tail_mask()
-        return self._tail_mask
+        return self._resolve('_tail_mask')
 
     @property
     def task_starts(self):
-        if callable(self._task_starts):
-            self._task_starts = self._task_starts()
-        return self._task_starts
+        return self._resolve('_task_starts')
 
     @property
     def spaces(self) -> List[OneOf]:

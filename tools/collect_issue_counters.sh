@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (gpurun -- bash tools/collect_issue_counters.sh r03): SQ issue counters (two passes of eight) and a kernel trace of one
 # 50-step episode of each workload of tools/traffic_run.py; tools/issue_counters.py reduces them to <tag>_issue_counters.txt
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/counters_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

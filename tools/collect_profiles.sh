@@ -5,7 +5,7 @@
 # summary — profiles/hbm_traffic.json carries the fingerprint of the kernel sources — so that the bench lines that follow report
 # `roofline.traffic` from this very build; then the bench lines; then the kernel traces of the same commands.
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -14,6 +14,12 @@ for domain in wildfire wildfire20 cybersecurity rideshare wildfire_grid_8x8 wild
     rocprofv3 --pmc $counter --output-format csv -d $OUT/pmc_${domain}_${counter} -o pmc -- python3 $GRAFT_REPO_ROOT/tools/traffic_run.py $domain > $OUT/pmc_${domain}_${counter}.log 2>&1 || echo "pmc $domain $counter failed"
   done
 done
+# A/B of the cybersecurity task-row stores (round 4): the same episode with the library that stores them lane by lane
+if [ -f $GRAFT_REPO_ROOT/free-range-zoo_amd/csrc/libfrz_hip_cy_direct.so ]; then
+  for counter in FETCH_SIZE WRITE_SIZE; do
+    FRZ_HIP_LIB=$GRAFT_REPO_ROOT/free-range-zoo_amd/csrc/libfrz_hip_cy_direct.so rocprofv3 --pmc $counter --output-format csv -d $OUT/pmc_cybersecurity_direct_${counter} -o pmc -- python3 $GRAFT_REPO_ROOT/tools/traffic_run.py cybersecurity > $OUT/pmc_cybersecurity_direct_${counter}.log 2>&1 || echo "pmc cybersecurity_direct $counter failed"
+  done
+fi
 python3 $GRAFT_REPO_ROOT/tools/traffic_summarise.py $OUT $TAG > $OUT/traffic_summary.json 2> $OUT/traffic_summary.err || echo "traffic summary failed"
 cp $GRAFT_REPO_ROOT/profiles/hbm_traffic.json $GRAFT_REPO_ROOT/profiles/${TAG}_pmc_*_step.csv $OUT/ 2>/dev/null
 python3 $GRAFT_REPO_ROOT/bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/bench_default.err || echo "bench default failed"

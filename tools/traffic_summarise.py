@@ -9,7 +9,9 @@ from bench import source_fingerprint
 
 src, tag = sys.argv[1], sys.argv[2]
 STEP_KERNELS = {'wildfire': ('wf_roles_kernel', ), 'cybersecurity': ('cy_roles_kernel', ), 'rideshare': ('rs_env_kernel', 'rs_offsets_kernel', 'rs_emit_kernel'),
-                'wildfire_grid_8x8': ('wg_env_kernel', 'wg_lists_kernel'), 'wildfire_grid_16x16': ('wg_env_kernel', 'wg_lists_kernel')}
+                'wildfire_grid_8x8': ('wg_env_kernel', 'wg_lists_kernel'), 'wildfire_grid_16x16': ('wg_env_kernel', 'wg_lists_kernel'),
+                # A/B of round 4: the same cybersecurity episode with libfrz_hip_cy_direct.so — every lane stores its own task rows
+                'cybersecurity_direct': ('cy_roles_kernel', )}
 
 
 def per_step(domain, counter):
