@@ -75,6 +75,10 @@ struct CyLaunch {
     float* reward_tape;         // optional float32 [n_steps][A][B]
     uint8_t* done_tape;         // optional uint8 [n_steps][2][B]
     int64_t actions_out_step;   // elements between two steps of actions_out (0: one buffer)
+    int64_t obs_tape_delta;     // bytes from the arena's observation block (off_self_att) to step 0's copy in the observation tape; 0: none
+    int64_t obs_tape_step;      // bytes between two steps' copies
+    char* state_tape;           // optional: n_steps copies of (state rows [N + 2 D][B] int32, presence [A][B] uint8), state_tape_step bytes apart
+    int64_t state_tape_step;
 };
 
 // (plain stores: written through, frz_device.h, the rows of this kernel gained nothing — 11.4 vs 11.3 us — most of its bytes are
@@ -732,114 +736,23 @@ __global__ void __launch_bounds__(kRoleBlock, 2) cy_roles_kernel(char* __restric
 
     if (view) {
         // ================================================================================================ view role
-        for (int t = 0; t < n_steps; ++t) {
-            // (no per-step opaque copies here, unlike wildfire_roles.hip: with them this kernel needs 160 instead of 219 VGPRs and is slower,
-            // 7.7 against 7.4 us per step — its row addresses are better computed once, above the step loop)
-            const int nm_step = nm_in + t;
-            // ---------------------------------------------------------------- the step's draws (streams: cy_step_kernel above)
-            if (RNG == FRZ_RNG_INJECTED) {
-                if constexpr (EXTRA) {
-                    if (t > 0) {  // the randomness tapes' next pair
-#pragma unroll
-                        for (int n = 0; n < NMAX; ++n) r_in[n] = net_rand[((int64_t)t * B + bl) * N + min(n, N - 1)];
-#pragma unroll
-                        for (int a = 0; a < AMAX; ++a) r_in[NMAX + a] = agent_rand[((int64_t)t * B + bl) * A + min(a, A - 1)];
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < NMAX + AMAX; ++k) s_draw[k][tid] = r_in[k];
-            } else if constexpr (RNG == FRZ_RNG_MT19937) {
-                constexpr int U = NMAX + AMAX, kN = 624, kM = 397;
-                static_assert(U <= kN - kM, "a batch must not read a word it rewrites");
-                uint32_t* const mt = reinterpret_cast<uint32_t*>(arena + L.off_mt_state);
-                const int used = N + A;
-                uint32_t w[U + 1], far[U];
-#pragma unroll
-                for (int k = 0; k <= U; ++k) {
-                    int j = mti + k;
-                    j -= j >= kN ? kN : 0;
-                    w[k] = mt[(int64_t)j * B + bl];
-                }
-#pragma unroll
-                for (int k = 0; k < U; ++k) {
-                    int j = mti + k + kM;
-                    j -= j >= kN ? kN : 0;
-                    j -= j >= kN ? kN : 0;
-                    far[k] = mt[(int64_t)j * B + bl];
-                }
-                float uni[U];
-#pragma unroll
-                for (int k = 0; k < U; ++k) {
-                    const uint32_t y = (w[k] & 0x80000000u) | (w[k + 1] & 0x7fffffffu);
-                    uint32_t v = far[k] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-                    int j = mti + k;
-                    j -= j >= kN ? kN : 0;
-                    if (active && k < used) mt[(int64_t)j * B + bl] = v;
-                    v ^= v >> 11;
-                    v ^= (v << 7) & 0x9d2c5680u;
-                    v ^= (v << 15) & 0xefc60000u;
-                    v ^= v >> 18;
-                    uni[k] = (float)(v & 0xFFFFFFu) * (1.0f / 16777216.0f);
-                }
-                if (active) {
-                    int j = mti + used;
-                    j -= j >= kN ? kN : 0;
-                    at32(rows, (uint32_t)(r_seeds + 1) * Bu + bl) = j;
-                }
-#pragma unroll
-                for (int n = 0; n < NMAX; ++n) s_draw[n][tid] = uni[n];  // node n is draw n, agent a is draw N + a
-#pragma unroll
-                for (int a = 0; a < AMAX; ++a) {
-                    float u = 0.0f;
-#pragma unroll
-                    for (int k = 0; k < U; ++k) u = (k == N + a) ? uni[k] : u;
-                    s_draw[NMAX + a][tid] = u;
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < (NMAX + 3) / 4; ++q) {
-                    frz::Philox4 w{{0u, 0u, 0u, 0u}};
-                    const bool drawn = q * 4 < N && (flags & kStochState);
-                    if (drawn) w = frz::philox4x32_10((uint32_t)q, (uint32_t)nm_step, 0u, 0u, seed, 0x46525A01u);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (q * 4 + j < NMAX) s_draw[q * 4 + j][tid] = drawn ? frz::u32_to_unit_float(w.w[j]) : 0.0f;
-                }
-#pragma unroll
-                for (int q = 0; q < (AMAX + 3) / 4; ++q) {
-                    frz::Philox4 w{{0u, 0u, 0u, 0u}};
-                    const bool drawn = q * 4 < A;
-                    if (drawn) w = frz::philox4x32_10((uint32_t)q, (uint32_t)nm_step, 1u, 0u, seed, 0x46525A01u);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (q * 4 + j < AMAX) s_draw[NMAX + q * 4 + j][tid] = drawn ? frz::u32_to_unit_float(w.w[j]) : 0.0f;
-                }
-            }
-            __syncthreads();  // (2) draws ready
-            if constexpr (PERSIST) {
-                if (s_stop) break;  // the state role's verdict (it has looked at the totals of the step that just ended): nothing more happens
-            }
-            // addresses of this env's observation rows, while the state role works
-            float* const self_att = reinterpret_cast<float*>(arena + d.off_self_att);
-            float* const self_def = reinterpret_cast<float*>(arena + d.off_self_def);
-            float* const others_att = reinterpret_cast<float*>(arena + d.off_others_att);
-            float* const others_def = reinterpret_cast<float*>(arena + d.off_others_def);
-            int64_t* const tasks = reinterpret_cast<int64_t*>(arena + d.off_tasks);
+        // The view role's stores of one step as a function of where they go: `delta` = byte distance from the arena's observation block
+        // (self rows, others rows, task rows: contiguous, frz_cybersecurity_obs_block) to the copy being written — 0: the env's own
+        // buffers; a step's copy of an observation tape (frz_rollout_spec.obs_tape) otherwise.  With a tape every step but the launch's
+        // last writes ONLY its tape copy (the env's own rows are rewritten by the next step anyway), the last one both; a launch that
+        // finds the batch finished early writes the last executed step's rows once more, into the env's own buffers (below).
+        uint32_t pres_bits_v = 0;
+        auto emit_obs = [&](int64_t delta) {
+            float* const self_att = reinterpret_cast<float*>(arena + d.off_self_att + delta);
+            float* const self_def = reinterpret_cast<float*>(arena + d.off_self_def + delta);
+            float* const others_att = reinterpret_cast<float*>(arena + d.off_others_att + delta);
+            float* const others_def = reinterpret_cast<float*>(arena + d.off_others_def + delta);
+            int64_t* const tasks = reinterpret_cast<int64_t*>(arena + d.off_tasks + delta);
             const bool op = (flags & kObsPower) != 0, opr = (flags & kObsPresence) != 0, ol = (flags & kObsLocation) != 0;
             const int ka = (op ? 1 : 0) + (opr ? 1 : 0), kd = ka + (ol ? 1 : 0);
-            __syncthreads();  // (3) post-transition state ready
-#pragma unroll
-            for (int n = 0; n < NMAX; ++n) state[n] = s_post[n][tid];
-#pragma unroll
-            for (int k = 0; k < AMAX; ++k) {
-                loc[k] = s_post[NMAX + k][tid];
-                last[k] = s_post[NMAX + AMAX + k][tid];
-            }
-            const uint32_t pres_bits = (uint32_t)s_post[NMAX + 2 * AMAX][tid];
             bool pres[AMAX];
 #pragma unroll
-            for (int a = 0; a < AMAX; ++a) pres[a] = (pres_bits >> a) & 1u;
-            frz::scan_chunk_passive_front();
+            for (int a = 0; a < AMAX; ++a) pres[a] = (pres_bits_v >> a) & 1u;
             // Every row kind below is, for this wavefront's 64 envs, ONE run of consecutive bytes of its output array (row (agent, env) at
             // (agent * B + env) * K).  The task rows (192 of the step's 420 bytes per env) go through LDS into whole lines (below); doing the
             // same to the small self / others rows costs more in LDS round trips than their stores do (FRZ_CY_ROWS_LDS, off).
@@ -997,6 +910,110 @@ __global__ void __launch_bounds__(kRoleBlock, 2) cy_roles_kernel(char* __restric
                 }
             }
 #endif
+        };
+        const int64_t obs_tape_delta = EXTRA ? L.obs_tape_delta : (int64_t)0;
+        for (int t = 0; t < n_steps; ++t) {
+            // (no per-step opaque copies here, unlike wildfire_roles.hip: with them this kernel needs 160 instead of 219 VGPRs and is slower,
+            // 7.7 against 7.4 us per step — its row addresses are better computed once, above the step loop)
+            const int nm_step = nm_in + t;
+            // ---------------------------------------------------------------- the step's draws (streams: cy_step_kernel above)
+            if (RNG == FRZ_RNG_INJECTED) {
+                if constexpr (EXTRA) {
+                    if (t > 0) {  // the randomness tapes' next pair
+#pragma unroll
+                        for (int n = 0; n < NMAX; ++n) r_in[n] = net_rand[((int64_t)t * B + bl) * N + min(n, N - 1)];
+#pragma unroll
+                        for (int a = 0; a < AMAX; ++a) r_in[NMAX + a] = agent_rand[((int64_t)t * B + bl) * A + min(a, A - 1)];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NMAX + AMAX; ++k) s_draw[k][tid] = r_in[k];
+            } else if constexpr (RNG == FRZ_RNG_MT19937) {
+                constexpr int U = NMAX + AMAX, kN = 624, kM = 397;
+                static_assert(U <= kN - kM, "a batch must not read a word it rewrites");
+                uint32_t* const mt = reinterpret_cast<uint32_t*>(arena + L.off_mt_state);
+                const int used = N + A;
+                uint32_t w[U + 1], far[U];
+#pragma unroll
+                for (int k = 0; k <= U; ++k) {
+                    int j = mti + k;
+                    j -= j >= kN ? kN : 0;
+                    w[k] = mt[(int64_t)j * B + bl];
+                }
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    int j = mti + k + kM;
+                    j -= j >= kN ? kN : 0;
+                    j -= j >= kN ? kN : 0;
+                    far[k] = mt[(int64_t)j * B + bl];
+                }
+                float uni[U];
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    const uint32_t y = (w[k] & 0x80000000u) | (w[k + 1] & 0x7fffffffu);
+                    uint32_t v = far[k] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                    int j = mti + k;
+                    j -= j >= kN ? kN : 0;
+                    if (active && k < used) mt[(int64_t)j * B + bl] = v;
+                    v ^= v >> 11;
+                    v ^= (v << 7) & 0x9d2c5680u;
+                    v ^= (v << 15) & 0xefc60000u;
+                    v ^= v >> 18;
+                    uni[k] = (float)(v & 0xFFFFFFu) * (1.0f / 16777216.0f);
+                }
+                if (active) {
+                    int j = mti + used;
+                    j -= j >= kN ? kN : 0;
+                    at32(rows, (uint32_t)(r_seeds + 1) * Bu + bl) = j;
+                }
+#pragma unroll
+                for (int n = 0; n < NMAX; ++n) s_draw[n][tid] = uni[n];  // node n is draw n, agent a is draw N + a
+#pragma unroll
+                for (int a = 0; a < AMAX; ++a) {
+                    float u = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < U; ++k) u = (k == N + a) ? uni[k] : u;
+                    s_draw[NMAX + a][tid] = u;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < (NMAX + 3) / 4; ++q) {
+                    frz::Philox4 w{{0u, 0u, 0u, 0u}};
+                    const bool drawn = q * 4 < N && (flags & kStochState);
+                    if (drawn) w = frz::philox4x32_10((uint32_t)q, (uint32_t)nm_step, 0u, 0u, seed, 0x46525A01u);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (q * 4 + j < NMAX) s_draw[q * 4 + j][tid] = drawn ? frz::u32_to_unit_float(w.w[j]) : 0.0f;
+                }
+#pragma unroll
+                for (int q = 0; q < (AMAX + 3) / 4; ++q) {
+                    frz::Philox4 w{{0u, 0u, 0u, 0u}};
+                    const bool drawn = q * 4 < A;
+                    if (drawn) w = frz::philox4x32_10((uint32_t)q, (uint32_t)nm_step, 1u, 0u, seed, 0x46525A01u);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (q * 4 + j < AMAX) s_draw[NMAX + q * 4 + j][tid] = drawn ? frz::u32_to_unit_float(w.w[j]) : 0.0f;
+                }
+            }
+            __syncthreads();  // (2) draws ready
+            if constexpr (PERSIST) {
+                if (s_stop) {  // the state role's verdict (it has looked at the totals of the step that just ended): nothing more happens
+                    if (obs_tape_delta != 0 && t > 0) emit_obs(0);  // (the last executed step's rows went to its tape copy only)
+                    break;
+                }
+            }
+            __syncthreads();  // (3) post-transition state ready
+#pragma unroll
+            for (int n = 0; n < NMAX; ++n) state[n] = s_post[n][tid];
+#pragma unroll
+            for (int k = 0; k < AMAX; ++k) {
+                loc[k] = s_post[NMAX + k][tid];
+                last[k] = s_post[NMAX + AMAX + k][tid];
+            }
+            pres_bits_v = (uint32_t)s_post[NMAX + 2 * AMAX][tid];
+            frz::scan_chunk_passive_front();
+            if (obs_tape_delta != 0) emit_obs(obs_tape_delta + (int64_t)t * L.obs_tape_step);
+            if (obs_tape_delta == 0 || t == n_steps - 1) emit_obs(0);
             frz::scan_chunk_passive_back();
         }  // steps of this launch
         return;
@@ -1245,6 +1262,20 @@ __global__ void __launch_bounds__(kRoleBlock, 2) cy_roles_kernel(char* __restric
                 }
             at32(rows, (uint32_t)d.r_moves * Bu + bl) = nm;
             if constexpr (EXTRA) {
+                if (L.state_tape != nullptr) {  // frz_rollout_spec.state_tape: this step's state rows, then the presence bytes
+                    char* const step_copy = L.state_tape + (int64_t)t * L.state_tape_step;
+                    int32_t* const st = reinterpret_cast<int32_t*>(step_copy);
+                    uint8_t* const pr = reinterpret_cast<uint8_t*>(step_copy + (int64_t)(N + 2 * D) * B * 4);
+#pragma unroll
+                    for (int n = 0; n < NMAX; ++n)
+                        if (n < N) st[(int64_t)n * B + bl] = state[n];
+#pragma unroll
+                    for (int k = 0; k < AMAX; ++k)
+                        if (k < D) st[(int64_t)(N + k) * B + bl] = loc[k], st[(int64_t)(N + D + k) * B + bl] = last[k];
+#pragma unroll
+                    for (int a = 0; a < AMAX; ++a)
+                        if (a < A) pr[(int64_t)a * B + bl] = (uint8_t)pres[a];
+                }
                 if (L.done_tape != nullptr) {  // terminations never set (cybersecurity.py:298)
                     L.done_tape[((int64_t)t * 2 + 0) * B + bl] = (uint8_t)0;
                     L.done_tape[((int64_t)t * 2 + 1) * B + bl] = (uint8_t)trunc;
@@ -1324,6 +1355,8 @@ struct frz_cybersecurity_env {
         int64_t tape_actions_step = 0, list_record_delta = 0, list_record_step = 0, actions_out_step = 0;
         float* reward_tape = nullptr;
         uint8_t* done_tape = nullptr;
+        int64_t obs_tape_delta = 0, obs_tape_step = 0, state_tape_step = 0;
+        char* state_tape = nullptr;
     } rollout;
 };
 
@@ -1351,7 +1384,8 @@ void launch_variant(frz_cybersecurity_env* env, const int32_t* actions, const fl
                      (uint32_t)policy.seed, (uint32_t)(policy.seed >> 32), (uint32_t)policy.step, (uint32_t)(policy.step >> 32), policy.actions_out,
                      p.off_mt_state, p.off_lut, p.lut_entries, env->rollout_steps, env->copy_delta,
                      env->rollout.flags, 0u, env->rollout.tape_actions_step, env->rollout.list_record_delta, env->rollout.list_record_step,
-                     env->rollout.reward_tape, env->rollout.done_tape, env->rollout.actions_out_step};
+                     env->rollout.reward_tape, env->rollout.done_tape, env->rollout.actions_out_step,
+                     env->rollout.obs_tape_delta, env->rollout.obs_tape_step, env->rollout.state_tape, env->rollout.state_tape_step};
     if constexpr (NMAX <= 8) {
         if (mode == kStep && env->roles) {  // state / view roles: two wavefronts per 64 envs (cy_roles_kernel)
             const dim3 wide(kRoleBlock);
@@ -1750,10 +1784,15 @@ int frz_cybersecurity_rollout(frz_cybersecurity_env* env, const frz_rollout_spec
     const int64_t block_bytes = p.off_obs_map - p.off_act_values;
 
     if (spec->flags & FRZ_ROLLOUT_OBS_COMPACT) return FRZ_E_INVALID;  // (every column of this domain's observation rows can change)
-    const bool dense_tapes = spec->obs_tape != nullptr || spec->state_tape != nullptr;  // whole blocks: copied out between the steps' launches
-    if (spec->n_steps > 1 && !dense_tapes && frz_cybersecurity_rollout_launches(env, spec->n_steps, mode) == 1) {  // ONE multi-step launch
+    const int64_t obs_block_bytes = p.off_act_values - p.off_self_att;
+    const int64_t state_step_bytes = align_up((int64_t)(N + 2 * p.D) * B * 4 + A * B, 256);
+    if (spec->n_steps > 1 && frz_cybersecurity_rollout_launches(env, spec->n_steps, mode) == 1) {  // ONE multi-step launch
         frz_cybersecurity_env::RolloutOptions& o = env->rollout;
-        o.extra = !policy || spec->list_record || spec->reward_tape || spec->done_tape || spec->record_actions || reset_first;
+        o.extra = !policy || spec->list_record || spec->reward_tape || spec->done_tape || spec->record_actions || reset_first || spec->obs_tape || spec->state_tape;
+        o.obs_tape_delta = spec->obs_tape ? static_cast<char*>(spec->obs_tape) - (env->arena + p.off_self_att) : 0;
+        o.obs_tape_step = obs_block_bytes;
+        o.state_tape = static_cast<char*>(spec->state_tape);
+        o.state_tape_step = state_step_bytes;
         o.flags = spec->flags;
         o.tape_actions_step = policy ? 0 : AB2;
         o.list_record_delta = spec->list_record ? static_cast<char*>(spec->list_record) - (env->arena + p.off_act_values) : 0;

@@ -167,6 +167,15 @@ class EnvTensor(torch.Tensor):
             return EnvTensor(out, env)
         return out
 
+    # leaving the process or being copied, an EnvTensor is the plain tensor it shows (never the env behind it)
+    def __reduce_ex__(self, protocol):
+        self._env._flush()
+        return self.as_subclass(torch.Tensor).__reduce_ex__(protocol)
+
+    def __deepcopy__(self, memo):
+        self._env._flush()
+        return self.as_subclass(torch.Tensor).clone()
+
 
 class BatchedParallelEnv:
     """Common constructor / bookkeeping of the three domains."""

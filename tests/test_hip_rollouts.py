@@ -525,6 +525,50 @@ def test_one_step_graph_capture_keeps_the_reset_and_the_metrics(oracle):
     np.testing.assert_allclose(metrics.cpu().numpy(), want, rtol=1e-12)
 
 
+@pytest.mark.parametrize('case', [dict(B=65536, max_steps=50, steps=50), dict(B=1000, max_steps=30, steps=34)], ids=['cfg4_B65536', 'ragged_past_the_horizon'])
+def test_cybersecurity_tapes_in_the_multi_step_launch_against_the_oracle(oracle, case):
+    """Observation and state tapes written INSIDE the one multi-step launch (every step but the last writes only its tape copy of the
+    observation rows; a launch that finds the batch finished writes the last executed step's rows once more into the env's own buffers):
+    every step's state and every agent's self / others / tasks rows against the oracle's loop, then the env's own outputs."""
+    import test_hip_cybersecurity as C
+    from free_range_zoo_amd.envs.cybersecurity.env.structures.configuration import to_cstruct
+    B, steps = case['B'], case['steps']
+    cfg = to_cstruct(configs.cyber_openness(), B, case['max_steps'], **configs.CYBER_DEFAULT_FLAGS)
+    env = C.make_env(configs.cyber_openness, B, case['max_steps'], rng='philox')
+    env.set_exclusive_device(True)
+    assert env._lib.frz_cybersecurity_rollout_launches(env._handle, steps, _capi.FRZ_RNG_PHILOX) == 1
+    seeds = torch.arange(B, dtype=torch.int32) * 3 + 1
+    env.reset(seed=seeds)
+    rec = env.rollout(steps, policy_seed=13, record=True, record_observations='full', record_state=True)
+    o = oracle.CybersecurityOracle(cfg)
+    o.reset()
+    executed = 0
+    for t in range(steps):
+        if bool(o.truncations[0].all()):
+            break
+        acts = oracle.cybersecurity_random_policy(cfg, o.agent_task_count, o.location, seeds.numpy(), 13, t)
+        nr, ar = oracle.cybersecurity_philox_randomness(cfg, seeds.numpy(), o.num_moves)
+        o.step(acts, nr, ar)
+        executed = t + 1
+        if B > 5000 and t % 7 and t != steps - 1:
+            continue
+        want = C.oracle_snapshot(o)
+        state = env.recorded_state(rec, t)
+        G.assert_same(np_(state.network_state), want['network_state'], f'step {t} state tape: network_state')
+        G.assert_same(np_(state.location), want['location'], f'step {t} state tape: location')
+        G.assert_same(np_(state.presence).astype(bool), np.asarray(want['presence']).astype(bool), f'step {t} state tape: presence')
+        obs = env.recorded_observations(rec, t)
+        for a, agent_name in enumerate(env.agents):
+            for part in ('self', 'others', 'tasks'):
+                G.assert_same(np_(obs[agent_name][part]), want[f'obs_{part}_{a}'], f'step {t} observation tape: {part}[{a}]')
+    assert executed == min(steps, case['max_steps'])
+    if executed < steps:  # what the frozen steps leave (rewards summed once per agent) — and the env's own observation rows, rewritten on the way out
+        A = len(env.agents)
+        o.step(np.zeros((A, B, 2), np.int32), np.zeros((1, B, cfg.num_nodes), np.float32), np.zeros((1, B, A), np.float32))
+    C.compare_snapshots(C.hip_snapshot(env), C.oracle_snapshot(o), f'the env after {steps} steps in one launch with tapes')
+    env.check()
+
+
 def test_reset_finished_says_so_where_the_library_has_no_device_side_partial_reset():
     import test_hip_cybersecurity as C
     env = C.make_env(configs.cyber_openness, 64, 10, rng='philox')
