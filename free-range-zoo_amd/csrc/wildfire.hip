@@ -1026,6 +1026,11 @@ struct frz_wildfire_env {
     double* rollout_metrics = nullptr;  // frz_wildfire_rollout_random_policy_metrics: folded into the multi-step launch being enqueued
     const frz_rollout_spec* rollout_spec = nullptr;  // frz_wildfire_rollout: the spec of the multi-step launch being enqueued
     bool exclusive_device = false;  // frz_wildfire_set_exclusive_device: multi-step launches allowed
+    // grid family, overlapped rollouts (wildfire_grid.hip launch_cpl): the second stream and the events of the hand-overs, made on first use
+    hipStream_t side_stream = nullptr;
+    hipEvent_t scan_done = nullptr, lists_done = nullptr;
+    const frz_wf::WgOverlap* overlap = nullptr;  // set for the duration of a step launch of an overlapped rollout
+    int64_t grid_copy_delta = 0;  // bytes from the mask words / lit cells to their second copies
     frz_wildfire_saved_state saved = {};  // frz_wildfire_set_saved_initial: what a partial reset restores (fires == nullptr: the configured state)
     // grids above 16 cells (wildfire_grid.hip): the kernels' configuration and the tables uploaded into the arena at bind
     WgDev gdev;
@@ -1101,7 +1106,7 @@ int launch_lane(frz_wildfire_env* env, const WfArgs& args, int rng, int mode, hi
 }
 
 int launch(frz_wildfire_env* env, const WfArgs& args, int rng, int mode, hipStream_t stream) {
-    if (env->dev.grid) return launch_grid(env->gdev, env->arena, args, rng, mode, env->ticketed, stream);
+    if (env->dev.grid) return launch_grid(env->gdev, env->arena, args, rng, mode, env->ticketed, stream, env->overlap);
     if (!env->dev.roles) {
         WfArgs a = args;
         a.ticketed = env->ticketed;
@@ -1274,6 +1279,10 @@ int create_grid(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
     g.off_litmap = take((int64_t)chunks * B * 8);
     g.off_okmap = take((int64_t)A * chunks * B * 8);
     g.off_lit_cells = take(B * (int64_t)((HW + 1) & ~1) * 8);
+    {   // second copies of the three arrays above, in the same order (steps of odd parity of an overlapped rollout: launch_cpl)
+        const int64_t first = g.off_litmap, bytes = off - g.off_litmap;
+        env->grid_copy_delta = take(bytes) - first;
+    }
     p.off_obs_self = take((int64_t)A * B * 16);
     p.off_obs_others = take((int64_t)A * B * (A - 1) * ok * 4);
     p.off_task_offsets = take((B + 1) * 8);
@@ -1551,6 +1560,9 @@ void frz_wildfire_destroy(frz_wildfire_env* env) {
     if (!env) return;
     frz::handle_unregister(env);
     for (hipEvent_t e : env->timing_events) (void)hipEventDestroy(e);
+    if (env->scan_done) (void)hipEventDestroy(env->scan_done);
+    if (env->lists_done) (void)hipEventDestroy(env->lists_done);
+    if (env->side_stream) (void)hipStreamDestroy(env->side_stream);
     delete env;
 }
 
@@ -1561,6 +1573,12 @@ int frz_wildfire_bind(frz_wildfire_env* env, void* arena, void* stream) {
     if (reinterpret_cast<uintptr_t>(arena) % 256 != 0) return FRZ_E_INVALID;
     env->arena = static_cast<char*>(arena);
     env->was_reset = false;
+    if (env->dev.grid && !env->side_stream) {  // the second stream of overlapped rollouts (never created inside a stream-ordered entry point)
+        if (hipStreamCreateWithFlags(&env->side_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&env->scan_done, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&env->lists_done, hipEventDisableTiming) != hipSuccess)
+            return FRZ_E_LAUNCH;
+    }
     if (hipMemcpyAsync(arena, &env->dev, sizeof(WfDev), hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)) != hipSuccess)
         return FRZ_E_LAUNCH;
     if (env->dev.grid) {
@@ -1962,9 +1980,35 @@ int frz_wildfire_rollout(frz_wildfire_env* env, const frz_rollout_spec* spec, vo
             if (rs != FRZ_OK) return rs;
         }
     }
+    // grid family: the lists of step t beside the env launch of step t + 1 (wildfire_grid.hip launch_cpl) — when nothing between two steps
+    // reads the lists (no list record, no restart of finished envs, no observation / state tapes)
+    // OFF unless FRZ_WG_OVERLAP=1: measured SLOWER than the two launches back to back on one stream (8x8 / 12 agents: 80 against 70 us per
+    // step, 16x16 / 6: 156 against 150) — each step pays two cross-queue hand-overs (~8 us apiece on this part) and the lists launch,
+    // fighting the env launch for CUs, takes 39 instead of 20 us; profiles/r04_experiments.txt section 7.  Kept as a tested option.
+    const char* const overlap_switch = std::getenv("FRZ_WG_OVERLAP");
+    const bool overlap_allowed = overlap_switch && overlap_switch[0] == '1';
+    WgOverlap overlap;
+    const bool overlapped = overlap_allowed && env->dev.grid && env->side_stream && spec->n_steps > 1 && !auto_reset && !spec->list_record && !spec->obs_tape &&
+                            !spec->state_tape;
+    if (overlapped) overlap.side = env->side_stream, overlap.scan_done = env->scan_done, overlap.lists_done = env->lists_done, overlap.copy_delta = env->grid_copy_delta;
+    struct OverlapGuard {  // the step's stream waits for the last lists launch before anything else is enqueued on it
+        frz_wildfire_env* env;
+        hipStream_t s;
+        bool armed = false;
+        ~OverlapGuard() {
+            env->overlap = nullptr;
+            if (armed) (void)hipStreamWaitEvent(s, env->lists_done, 0);
+        }
+    } guard{env, s};
     for (int32_t t = 0; t < spec->n_steps; ++t) {
         const float* ra = spec->randomness_tape_a ? spec->randomness_tape_a + (int64_t)t * 3 * B * HW : nullptr;
         const float* rb = spec->randomness_tape_b ? spec->randomness_tape_b + (int64_t)t * 5 * B * A : nullptr;
+        if (overlapped) {
+            overlap.parity = t & 1;
+            overlap.wait_previous_lists = t > 0;
+            env->overlap = &overlap;
+            guard.armed = true;
+        }
         int rc;
         if (policy)
             rc = frz_wildfire_step_random_policy(env, spec->policy_seed, spec->first_step + (uint64_t)t,

@@ -243,11 +243,20 @@ struct WgDev {
         off_litmap /* uint64 [chunks][B]: the lit cells (fires > 0) of every env as mask words, left by wg_env_kernel for wg_lists_kernel */,
         off_okmap /* uint64 [A][chunks][B]: agent a's attackable cells (lit, in range at its equipment state, suppressant left) */,
         off_lit_cells /* int2 [B][HW rounded up to even]: (fires, intensity) of env b's lit cells in row-major (= task) order */;
+    int32_t parity;  // overlapped rollouts (launch_cpl): which copy of the three arrays above this step's launches use (0 otherwise)
 };
 struct WgPolicy {  // the uniform random policy sampled inside the step launch
     uint32_t on, seed_lo, seed_hi, step_lo, step_hi;
     int32_t* actions_out;
 };
-int launch_grid(const WgDev& dev, char* arena, const WfArgs& args, int rng, int mode, bool ticketed, hipStream_t stream);
+// overlapped steps of a grid-family rollout (wildfire_grid.hip launch_cpl): the lists of step t on a second stream beside the env launch of step t + 1
+struct WgOverlap {
+    hipStream_t side = nullptr;                            // the second stream (owned by the handle)
+    hipEvent_t scan_done = nullptr, lists_done = nullptr;  // scan of this step enqueued on the step's stream / lists of this step enqueued on `side`
+    int64_t copy_delta = 0;                                // bytes from the mask words / lit cells to their second copies (steps of odd parity)
+    int parity = 0;
+    bool wait_previous_lists = false;                      // the previous step's lists launch is (possibly) still reading the offsets this step's scan rewrites
+};
+int launch_grid(const WgDev& dev, char* arena, const WfArgs& args, int rng, int mode, bool ticketed, hipStream_t stream, const WgOverlap* overlap = nullptr);
 
 }  // namespace frz_wf

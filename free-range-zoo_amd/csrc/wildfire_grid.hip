@@ -192,6 +192,10 @@ __global__ void __launch_bounds__(kBlock) wg_env_kernel(char* __restrict__ arena
     if (kStepping) {
         // utils/env.py:211-213 — every per-agent step() is a no-op once ALL envs are terminated or ALL are truncated; the parallel adapter
         // (utils/conversions.py:87-90) then adds the stale aec rewards once per agent call.  (Batch totals: every wavefront takes this branch or none.)
+        // (words 40 / 41 of the epoch block, by the step's parity: "this step changed nothing" — read by the lists launch of an overlapped
+        // rollout, whose mask words of this parity are then not this step's; the lists the previous step left stay as they are)
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            reinterpret_cast<uint32_t*>(arena + d.off_epoch)[40 + (d.parity & 1)] = (left_alive == 0u || left_running == 0u) ? 1u : 0u;
         if (left_alive == 0u || left_running == 0u) {
             if (crew && !frz::at32(rows1, (uint32_t)d.u_frozen * Bu + cbu)) {
                 if (is_agent) {
@@ -748,7 +752,10 @@ __device__ __forceinline__ void output_parallel_list(ListShared<CPL>& sh, const 
         tiles(std::integral_constant<int, 1>{});
 }
 
-template <int AMAX, int CPL, int BITS>
+// SPLIT (round 4: the lists of step t beside the env launch of step t + 1, see launch_cpl): 0 = offsets and lists in one launch (above);
+// 1 = the scan alone, on the step's stream — 256 threads per chunk: offsets, batch totals, epoch, what the NEXT env launch waits for;
+// 2 = the lists alone, on a second stream: the segment starts come back from the offsets arrays the scan launch wrote.
+template <int AMAX, int CPL, int BITS, int SPLIT = 0>
 __global__ void __launch_bounds__(64 * (CPL >= 8 ? 4 : 16)) wg_lists_kernel(char* __restrict__ arena, const WgDev d, uint32_t ticketed) {
     constexpr int kListWaves = CPL >= 8 ? 4 : 16, kListParts = kListWaves / frz::kWaves;
     constexpr int kChannels = AMAX + 1;
@@ -762,8 +769,12 @@ __global__ void __launch_bounds__(64 * (CPL >= 8 ? 4 : 16)) wg_lists_kernel(char
     const int A = d.A, HW = d.HW, Wd = d.W;
     frz::ScanWorkspace ws{reinterpret_cast<uint32_t*>(arena + d.off_epoch), reinterpret_cast<uint32_t*>(arena + d.off_totals),
                           reinterpret_cast<uint64_t*>(arena + d.off_agg), reinterpret_cast<uint64_t*>(arena + d.off_prefix)};
-    const frz::ScanLaunch launch = frz::scan_begin(ws);
-    const int chunk = frz::scan_take_chunk(ws, d.nchunks, ticketed != 0, &s_ticket);
+    frz::ScanLaunch launch{};
+    int chunk = (int)blockIdx.x;
+    if constexpr (SPLIT != 2) {
+        launch = frz::scan_begin(ws);
+        chunk = frz::scan_take_chunk(ws, d.nchunks, ticketed != 0, &s_ticket);
+    }
     const int el = group * 64 + lane;  // the lane's env within the chunk
     const int64_t b = (int64_t)chunk * kBlock + el;
     const bool active = b < B;
@@ -777,7 +788,7 @@ __global__ void __launch_bounds__(64 * (CPL >= 8 ? 4 : 16)) wg_lists_kernel(char
     const uint64_t* const okmap = reinterpret_cast<const uint64_t*>(arena + d.off_okmap);
     uint64_t lit[CPL];
 #pragma unroll
-    for (int k = 0; k < CPL; ++k) lit[k] = active ? litmap[(int64_t)k * B + bl] : 0ull;
+    for (int k = 0; k < CPL; ++k) lit[k] = (active && SPLIT != 1) ? litmap[(int64_t)k * B + bl] : 0ull;
     ListShared<CPL>& sh = s_list[wave];
     {
         int before = 0;
@@ -791,7 +802,21 @@ __global__ void __launch_bounds__(64 * (CPL >= 8 ? 4 : 16)) wg_lists_kernel(char
 
     // ---------------------------------------------------------------- the scan (wavefronts 0-3)
     uint32_t err = 0;
-    if (part == 0) {
+    if constexpr (SPLIT == 2) {  // the scan ran as a launch of its own: every env's segment starts are in the offsets arrays
+        if (part == 0) {
+            const int64_t* const task_offsets = reinterpret_cast<const int64_t*>(arena + d.off_task_offsets);
+            const int64_t* const act_offsets = reinterpret_cast<const int64_t*>(arena + d.off_act_offsets);
+            const int64_t at = b < B ? b : B, chunk_end = (int64_t)(chunk + 1) * kBlock < B ? (int64_t)(chunk + 1) * kBlock : B;
+            s_first[0][el] = (uint32_t)task_offsets[at];
+            if (el == kBlock - 1) s_first[0][kBlock] = (uint32_t)task_offsets[chunk_end];
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a)
+                if (a < A) {
+                    s_first[a + 1][el] = (uint32_t)act_offsets[a * (B + 1) + at];
+                    if (el == kBlock - 1) s_first[a + 1][kBlock] = (uint32_t)act_offsets[a * (B + 1) + chunk_end];
+                }
+        }
+    } else if (part == 0) {
         uint32_t cnt[kChannels], excl[kChannels];
         cnt[0] = active ? (uint32_t)rows8[(int64_t)d.q_etc * B + bl] : 0u;
 #pragma unroll
@@ -826,8 +851,14 @@ __global__ void __launch_bounds__(64 * (CPL >= 8 ? 4 : 16)) wg_lists_kernel(char
         frz::scan_chunk_passive_back();
     }
     __syncthreads();
-    if (err) atomicOr(reinterpret_cast<uint32_t*>(arena + d.off_error), err);
-    frz::scan_end(ws, launch, chunk, d.nchunks);
+    if constexpr (SPLIT != 2) {
+        if (err) atomicOr(reinterpret_cast<uint32_t*>(arena + d.off_error), err);
+        frz::scan_end(ws, launch, chunk, d.nchunks);
+    }
+    if constexpr (SPLIT == 1) return;  // (the lists: a launch of their own, on the second stream)
+    if constexpr (SPLIT == 2) {  // a step that changed nothing (every env finished): its parity's mask words are two steps old, the lists stay
+        if (reinterpret_cast<const uint32_t*>(arena + d.off_epoch)[40 + (d.parity & 1)] != 0u) return;
+    }
 
     // ---------------------------------------------------------------- the lists (wildfire.py:586-717)
     const int64_t cap = B * (int64_t)HW;
@@ -893,7 +924,16 @@ __global__ void __launch_bounds__(64 * (CPL >= 8 ? 4 : 16)) wg_lists_kernel(char
 }
 
 template <int CPL>
-int launch_cpl(const WgDev& dev, char* arena, const WfArgs& args, int rng, int mode, bool ticketed, hipStream_t stream) {
+int launch_cpl(const WgDev& dev_in, char* arena, const WfArgs& args, int rng, int mode, bool ticketed, hipStream_t stream, const WgOverlap* overlap) {
+    // Overlapped steps of a rollout (round 4): the env launch of step t + 1 needs nothing of step t's lists but the batch
+    // totals and the epoch, which the SCAN produces — so the scan runs as a small launch of its own on the step's stream, and the lists
+    // (13-31 us of mostly stores) go to a second stream, beside the next env launch.  What the lists launch reads of the env launch (the
+    // lit / attackable mask words, the lit cells' (fires, intensity)) is double-buffered by the step's parity; the offsets arrays it also
+    // reads are rewritten by the NEXT scan, which therefore waits for this step's lists first (they are long done: an env launch lies between).
+    const bool split = overlap != nullptr && overlap->side != nullptr && mode == kStep;
+    WgDev dev = dev_in;
+    dev.parity = 0;
+    if (split && overlap->parity) dev.off_litmap += overlap->copy_delta, dev.off_okmap += overlap->copy_delta, dev.off_lit_cells += overlap->copy_delta, dev.parity = 1;
     const dim3 waves((unsigned)((dev.B + kEnvsPerBlock - 1) / kEnvsPerBlock)), lanes((unsigned)dev.nchunks), block(kBlock);
     WgPolicy policy{args.policy ? 1u : 0u, (uint32_t)args.policy_seed, (uint32_t)(args.policy_seed >> 32), (uint32_t)args.policy_step,
                     (uint32_t)(args.policy_step >> 32), args.actions_out};
@@ -928,20 +968,31 @@ int launch_cpl(const WgDev& dev, char* arena, const WfArgs& args, int rng, int m
             else
                 hipLaunchKernelGGL(kernel, lanes, list_block, 0, stream, arena, dev, tk);
         };
+        // the split pair: the scan on the step's stream (after the previous step's lists, whose offsets it rewrites), the lists on the second one
+        auto split_pair = [&](auto scan_kernel, auto emit_kernel) {
+            if (overlap->wait_previous_lists) (void)hipStreamWaitEvent(stream, overlap->lists_done, 0);
+            hipLaunchKernelGGL(scan_kernel, lanes, dim3(kBlock), 0, stream, arena, dev, tk);
+            (void)hipEventRecord(overlap->scan_done, stream);
+            (void)hipStreamWaitEvent(overlap->side, overlap->scan_done, 0);
+            hipLaunchKernelGGL(emit_kernel, lanes, list_block, 0, overlap->side, arena, dev, tk);
+            (void)hipEventRecord(overlap->lists_done, overlap->side);
+        };
         constexpr int BITS = CPL <= 2 ? 16 : 32;  // the scan packs 16-bit counts while an env has at most 255 cells
         // (AMAX 12: with the 17 scan channels of AMAX 16 the scan's registers do not fit the 128 a 1024-thread workgroup leaves a
         // wavefront, and the kernel spills)
-        if (CPL == 4 && dev.HW < 256) {
-            if (dev.A <= 4) lists(wg_lists_kernel<4, CPL, 16>);
-            else if (dev.A <= 8) lists(wg_lists_kernel<8, CPL, 16>);
-            else if (dev.A <= 12) lists(wg_lists_kernel<12, CPL, 16>);
-            else lists(wg_lists_kernel<16, CPL, 16>);
-        } else {
-            if (dev.A <= 4) lists(wg_lists_kernel<4, CPL, BITS>);
-            else if (dev.A <= 8) lists(wg_lists_kernel<8, CPL, BITS>);
-            else if (dev.A <= 12) lists(wg_lists_kernel<12, CPL, BITS>);
-            else lists(wg_lists_kernel<16, CPL, BITS>);
-        }
+        auto with = [&](auto amax, auto bits) {
+            constexpr int AM = decltype(amax)::value, BT = decltype(bits)::value;
+            if (split) split_pair(wg_lists_kernel<AM, CPL, BT, 1>, wg_lists_kernel<AM, CPL, BT, 2>);
+            else lists(wg_lists_kernel<AM, CPL, BT, 0>);
+        };
+        auto by_agents = [&](auto bits) {
+            if (dev.A <= 4) with(std::integral_constant<int, 4>{}, bits);
+            else if (dev.A <= 8) with(std::integral_constant<int, 8>{}, bits);
+            else if (dev.A <= 12) with(std::integral_constant<int, 12>{}, bits);
+            else with(std::integral_constant<int, 16>{}, bits);
+        };
+        if (CPL == 4 && dev.HW < 256) by_agents(std::integral_constant<int, 16>{});
+        else by_agents(std::integral_constant<int, BITS>{});
     }
     return hipGetLastError() == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;
 }
@@ -949,13 +1000,13 @@ int launch_cpl(const WgDev& dev, char* arena, const WfArgs& args, int rng, int m
 }  // namespace
 
 // rng: FRZ_RNG_PHILOX (drawn in the launch) or FRZ_RNG_INJECTED (args.field_rand / agent_rand; MT19937 draws are staged by the caller)
-int launch_grid(const WgDev& dev, char* arena, const WfArgs& args, int rng, int mode, bool ticketed, hipStream_t stream) {
+int launch_grid(const WgDev& dev, char* arena, const WfArgs& args, int rng, int mode, bool ticketed, hipStream_t stream, const WgOverlap* overlap) {
     const int cpl = (dev.HW + 63) / 64;
-    if (cpl <= 1) return launch_cpl<1>(dev, arena, args, rng, mode, ticketed, stream);
-    if (cpl <= 2) return launch_cpl<2>(dev, arena, args, rng, mode, ticketed, stream);
-    if (cpl <= 4) return launch_cpl<4>(dev, arena, args, rng, mode, ticketed, stream);
-    if (cpl <= 8) return launch_cpl<8>(dev, arena, args, rng, mode, ticketed, stream);
-    if (cpl <= 16) return launch_cpl<16>(dev, arena, args, rng, mode, ticketed, stream);
+    if (cpl <= 1) return launch_cpl<1>(dev, arena, args, rng, mode, ticketed, stream, overlap);
+    if (cpl <= 2) return launch_cpl<2>(dev, arena, args, rng, mode, ticketed, stream, overlap);
+    if (cpl <= 4) return launch_cpl<4>(dev, arena, args, rng, mode, ticketed, stream, overlap);
+    if (cpl <= 8) return launch_cpl<8>(dev, arena, args, rng, mode, ticketed, stream, overlap);
+    if (cpl <= 16) return launch_cpl<16>(dev, arena, args, rng, mode, ticketed, stream, overlap);
     return FRZ_E_INVALID;
 }
 

@@ -154,3 +154,60 @@ def test_frozen_steps_leave_the_mt19937_streams_alone(which):
     for later in positions[4:]:  # frozen ones do not
         assert torch.equal(later[0], positions[3][0]) and torch.equal(later[1], positions[3][1])
     env.check()
+
+
+@pytest.mark.parametrize('rng', ['philox', 'mt19937'])
+@pytest.mark.parametrize('shape', [(5, 7, 3), (8, 8, 12), (16, 16, 6), (20, 13, 16)], ids=lambda s: 'x'.join(map(str, s)))
+def test_overlapped_rollout_equals_the_step_loop(shape, rng, monkeypatch):
+    """(FRZ_WG_OVERLAP=1: an option, off by default — it measured slower than the plain sequence)  A rollout of the grid family runs the LISTS launch of step t on a second stream beside the ENV launch of step t + 1 (the scan that
+    produces the next step's batch totals stays on the step's stream; what the lists launch reads of the env launch is double-buffered by
+    the step's parity: csrc/wildfire_grid.hip launch_cpl).  Same results as one `step_random_policy` call per step — odd and even step
+    counts, steps past the horizon (which change nothing: their lists launch must leave the last real step's lists alone), a second
+    rollout continuing the first, and a plain step afterwards."""
+    monkeypatch.setenv('FRZ_WG_OVERLAP', '1')
+    H, Wd, A = shape
+    B, horizon = (300 if H * Wd > 256 else 1100), 9
+    a, b = [make_env(lambda: configs.wildfire_grid(H, Wd, A, seed=3), B, horizon, rng=rng) for _ in range(2)]
+    assert a._cells_env_major
+    seeds = torch.arange(B, dtype=torch.int32) + 11
+    for env in (a, b):
+        env.reset(seed=seeds)
+    done = 0
+    for n in (4, 3, 5):  # 4 + 3 = 7 steps inside the episode, then 5 more: two real ones and three past the horizon
+        a.rollout(n, policy_seed=5, first_step=done)
+        for t in range(done, done + n):
+            b.step_random_policy(5, t)
+        done += n
+        compare_snapshots(hip_snapshot(a), hip_snapshot(b), f'{shape} {rng}: after {done} steps')
+    assert bool(a.finished.all())
+    for env in (a, b):
+        env.reset(seed=seeds + 1)
+        env.step_random_policy(6, 0)
+    compare_snapshots(hip_snapshot(a), hip_snapshot(b), f'{shape} {rng}: a plain step after the rollouts')
+    a.check(), b.check()
+
+
+def test_overlapped_rollout_inside_a_graph(monkeypatch):
+    """The same through a captured HIP graph (what bench.py's secondary workloads replay): the second stream joins the capture through the
+    scan's event and is joined back before the capture ends."""
+    monkeypatch.setenv('FRZ_WG_OVERLAP', '1')
+    B, horizon = 2048, 12
+    graphed, eager = [make_env(lambda: configs.wildfire_grid(8, 8, 12, seed=1), B, horizon, rng='philox', exact_shapes=False) for _ in range(2)]
+    seeds = torch.arange(B, dtype=torch.int32)
+    for env in (graphed, eager):
+        env.reset(seed=seeds)
+    graph = graphed.capture_random_rollout(horizon, policy_seed=9, include_reset=True)
+    for _ in range(2):  # the second replay starts from the in-graph reset again
+        graphed.seeds.copy_(seeds)
+        graph.replay()
+    torch.cuda.synchronize()
+    for t in range(horizon):
+        eager.step_random_policy(9, t)
+    for name in ('_fires', '_intensity', '_fuel', '_suppressants', '_rewards', '_task_offsets', '_act_map_offsets', '_obs_self'):
+        assert torch.equal(getattr(eager, name), getattr(graphed, name)), name
+    total = int(eager._task_offsets[-1])
+    assert torch.equal(eager._task_values[:total], graphed._task_values[:total])
+    for k in range(len(eager.agents)):
+        n = int(eager._act_map_offsets[k, -1])
+        assert torch.equal(eager._act_map_values[k, :n], graphed._act_map_values[k, :n])
+    graphed.check()
