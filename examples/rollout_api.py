@@ -42,6 +42,26 @@ print(f"recorded rollout: rewards {tuple(first['rewards'].shape)}, dones {tuple(
       f"the replay from the tape gives the same rewards and flags")
 env.check()
 
+# 2b. ... and a trajectory a learner can consume: every step's observations (compact tape: the suppressant column, expanded on demand) and
+# state beside the rewards / dones / actions — still ONE launch
+env.reset(seed=torch.arange(B, dtype=torch.int32))
+traj = env.rollout(30, policy_seed=7, record=True, record_observations='compact', record_state=True)
+step12 = env.recorded_observations(traj, 12)  # {agent: TensorDict(self [B, 4], others [B, A - 1, k], tasks jagged [B, j, 4])} of step 12
+agent = env.agents[0]
+print(f"recorded trajectory: step 12 of {agent}: self {tuple(step12[agent]['self'].shape)}, others {tuple(step12[agent]['others'].shape)}, "
+      f"{int(step12[agent]['tasks'].values().shape[0])} task rows in the batch; lit fires in the state tape: "
+      f"{int((env.recorded_state(traj, 12).fires > 0).sum())}")
+
+# 2c. the reference's own loop, unchanged, on a GPU this process owns: the steps are counted and run in multi-step launches
+t0 = time.perf_counter()
+for episode in range(4):
+    env.reset(seed=torch.arange(B, dtype=torch.int32, device=device) + episode)
+    while not torch.all(env.finished):
+        for _ in range(50):
+            env.step({name: env.action_space(name).sample_nested() for name in env.agents})
+torch.cuda.synchronize()
+print(f'reference-shaped loop on an exclusive device: {4 * 50 * B / (time.perf_counter() - t0) / 1e9:.2f} G env-steps/s')
+
 # 3. rideshare: the same spec, one launch sequence per step
 ride = rideshare_v0.parallel_env(configuration=configs.rideshare_busy(), parallel_envs=4096, max_steps=32, device=device)
 ride.reset(seed=torch.arange(4096, dtype=torch.int32))

@@ -71,3 +71,6 @@ def test_examples_run(tmp_path):
                           timeout=300)
     assert done.returncode == 0, done.stderr[-2000:]
     assert all(name in done.stdout for name in ('wildfire', 'cybersecurity', 'rideshare'))
+    done = subprocess.run([sys.executable, os.path.join(ROOT, 'examples', 'rollout_api.py')], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert done.returncode == 0, done.stderr[-2000:]
+    assert all(text in done.stdout for text in ('auto-reset rollouts', 'recorded trajectory', 'reference-shaped loop on an exclusive device', 'rideshare rollout'))
