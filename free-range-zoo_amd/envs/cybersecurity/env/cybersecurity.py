@@ -65,6 +65,7 @@ class raw_env(BatchedParallelEnv):
             agent_name=agent_name, observe_other_power=observe_other_power, observe_other_presence=observe_other_presence,
             observe_other_location=observe_other_location)
         self._allocate()
+        self._exclusive_if_forced()
 
     def _view(self, ptr: int, shape, dtype) -> torch.Tensor:
         offset = ptr - self._arena.data_ptr()

@@ -68,6 +68,7 @@ class raw_env(BatchedParallelEnv):
         self.observation_ordering = {agent: agent_ids[agent_ids != i] for i, agent in enumerate(self.possible_agents)}
         self._allocate()
         self._create_handle()
+        self._exclusive_if_forced()
 
     # ------------------------------------------------------------------------------------------------ buffers
     def _view(self, ptr: int, shape, dtype) -> torch.Tensor:

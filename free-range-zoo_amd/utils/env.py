@@ -421,6 +421,13 @@ class BatchedParallelEnv:
         self.infos = infos = self._step_infos()
         return (observations, self.rewards, self.terminations, self.truncations, infos)
 
+    def _exclusive_if_forced(self) -> None:
+        """Test hook: FRZ_FORCE_EXCLUSIVE=1 declares every env's device exclusive at construction, so that a whole test suite runs with counted
+        steps and multi-step launches wherever the library has them (whatever a test then looks at must be what the eager path leaves)."""
+        import os
+        if os.environ.get('FRZ_FORCE_EXCLUSIVE') == '1':
+            self.set_exclusive_device(True)
+
     def _after_fused(self, logged: bool):
         """What a fused policy + step call returns (domains with extra infos override `_step_infos`)."""
         self._publish()
