@@ -25,6 +25,7 @@ frz_rideshare_cfg = STRUCTS['frz_rideshare_cfg']
 frz_rideshare_bufs = STRUCTS['frz_rideshare_bufs']
 frz_rollout_spec = STRUCTS['frz_rollout_spec']
 frz_wildfire_saved_state = STRUCTS['frz_wildfire_saved_state']
+frz_cybersecurity_saved_state = STRUCTS['frz_cybersecurity_saved_state']
 
 _lib = None
 
@@ -86,6 +87,8 @@ SIGNATURES = {
     'frz_rideshare_rollout': (ctypes.c_int, [_P, _P, _P]),
     'frz_rideshare_list_block': (ctypes.c_int, [_P, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64)]),
     'frz_cybersecurity_list_block': (ctypes.c_int, [_P, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64)]),
+    'frz_cybersecurity_reset_masked': (ctypes.c_int, [_P, _P, ctypes.c_int32, _P]),
+    'frz_cybersecurity_set_saved_initial': (ctypes.c_int, [_P, _P]),
     'frz_cybersecurity_obs_block': (ctypes.c_int, [_P, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64)]),
     'frz_cybersecurity_state_block': (ctypes.c_int, [_P, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64)]),
     'frz_cybersecurity_set_exclusive_device': (ctypes.c_int, [_P, ctypes.c_int]),

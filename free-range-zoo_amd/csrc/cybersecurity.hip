@@ -88,6 +88,40 @@ __device__ __forceinline__ T& at32(T* base, uint32_t index) {
     return *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + (uint64_t)(index * (uint32_t)sizeof(T)));
 }
 
+// frz_cybersecurity_reset_masked: the state part of reset_batches (utils/env.py:162-189, cybersecurity.py:268-292) on the envs a device-side
+// mask selects (mask == nullptr: the finished ones — all agents share one truncation value, terminations are never set); the rebuild
+// launch that follows refreshes observations and mappings
+__global__ void __launch_bounds__(kBlock) cy_masked_fill_kernel(char* arena, const uint8_t* mask, uint32_t seed_increment, frz_cybersecurity_saved_state saved) {
+    const CyDev& d = *reinterpret_cast<const CyDev*>(arena);
+    const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x, B = d.B;
+    if (b >= B) return;
+    int32_t* rows = reinterpret_cast<int32_t*>(arena + d.off_rows4);
+    float* rowsf = reinterpret_cast<float*>(arena + d.off_rows4);
+    uint8_t* rows1 = reinterpret_cast<uint8_t*>(arena + d.off_rows1);
+    const bool selected = mask ? mask[b] != 0 : (rows1[d.u_term * B + b] != 0 || rows1[d.u_trunc * B + b] != 0);
+    if (!selected) return;
+    reinterpret_cast<uint32_t*>(rows)[d.r_seeds * B + b] += seed_increment;  // modulo 2^32
+    const bool s = saved.network_state != nullptr;
+    for (int n = 0; n < d.N; ++n)
+        rows[(d.r_state + n) * B + b] = s ? saved.network_state[b * saved.network_state_stride_env + n * saved.network_state_stride_item] : d.initial_state[n];
+    for (int k = 0; k < d.D; ++k) {
+        rows[(d.r_loc + k) * B + b] = s ? saved.location[b * saved.location_stride_env + k * saved.location_stride_item] : d.initial_location[k];
+        rows[(d.r_last + k) * B + b] = -2;
+    }
+    int2* const actions = reinterpret_cast<int2*>(arena + d.off_actions);
+    for (int a = 0; a < d.A; ++a) {
+        rows1[(d.u_presence + a) * B + b] =
+            s ? (uint8_t)(saved.presence[b * saved.presence_stride_env + a * saved.presence_stride_item] != 0) : (uint8_t)(d.initial_presence[a] != 0);
+        rowsf[(d.r_rewards + a) * B + b] = 0.0f;
+        rowsf[(d.r_cum + a) * B + b] = 0.0f;
+        rows1[(d.u_term + a) * B + b] = 0;
+        rows1[(d.u_trunc + a) * B + b] = 0;
+        actions[a * B + b] = make_int2(-2, -2);  // cybersecurity.py:233-236
+    }
+    rows[d.r_moves * B + b] = 0;
+    rows1[d.u_frozen * B + b] = 0;
+}
+
 // cybersecurity.py:218-266 + utils/env.py:137-160
 __global__ void __launch_bounds__(kBlock) cy_fill_kernel(char* arena) {
     const CyDev& d = *reinterpret_cast<const CyDev*>(arena);
@@ -1349,6 +1383,7 @@ struct frz_cybersecurity_env {
     bool exclusive_device = false;
     int64_t copy_delta = 0;
     int32_t rollout_steps = 1;
+    frz_cybersecurity_saved_state saved = {};  // frz_cybersecurity_set_saved_initial: what a partial reset restores (network_state == nullptr: the configured state)
     struct RolloutOptions {  // frz_cybersecurity_rollout: the options of the multi-step launch being enqueued
         bool extra = false;
         uint32_t flags = 0;
@@ -1629,9 +1664,28 @@ int frz_cybersecurity_rebuild(frz_cybersecurity_env* env, void* stream) {
     return launch(env, nullptr, nullptr, nullptr, FRZ_RNG_INJECTED, kRebuild, static_cast<hipStream_t>(stream));
 }
 
+int frz_cybersecurity_reset_masked(frz_cybersecurity_env* env, const uint8_t* mask, int32_t seed_increment, void* stream) {
+    if (!env) return FRZ_E_INVALID;
+    if (!env->arena) return FRZ_E_UNBOUND;
+    if (!env->was_reset) return FRZ_E_INVALID;
+    const int blocks = (env->cfg.parallel_envs + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(cy_masked_fill_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), env->arena, mask, (uint32_t)seed_increment,
+                       env->saved);
+    if (hipGetLastError() != hipSuccess) return FRZ_E_LAUNCH;
+    return frz_cybersecurity_rebuild(env, stream);
+}
+
+int frz_cybersecurity_set_saved_initial(frz_cybersecurity_env* env, const frz_cybersecurity_saved_state* saved) {
+    if (!env) return FRZ_E_INVALID;
+    if (saved && (!saved->network_state || !saved->location || !saved->presence)) return FRZ_E_INVALID;
+    env->saved = saved ? *saved : frz_cybersecurity_saved_state{};
+    return FRZ_OK;
+}
+
 int frz_cybersecurity_reset(frz_cybersecurity_env* env, void* stream) {
     if (!env) return FRZ_E_INVALID;
     if (!env->arena) return FRZ_E_UNBOUND;
+    env->saved = frz_cybersecurity_saved_state{};  // a full reset saves the configured initial state again
     const int blocks = (env->cfg.parallel_envs + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(cy_fill_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), env->arena);
     if (hipGetLastError() != hipSuccess) return FRZ_E_LAUNCH;

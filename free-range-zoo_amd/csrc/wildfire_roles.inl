@@ -947,7 +947,9 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                 }
                 const WfHot& d = PERSIST ? static_cast<const WfHot&>(s_cfg) : d_launch;
                 if constexpr (PERSIST) {
-                    if (t > 0) request_totals();
+                    // (the totals of the step that just ended are requested further down, behind the policy's Philox block: a request issued
+                    // HERE reaches memory before the last chunk's prefix has landed there, finds the old tag, and the retry costs a whole
+                    // round trip more — round 4, `FRZ_WF_SKIP` delay sweep in profiles/r04_experiments.txt: 6.83 -> 6.63 us per step)
                     if (EXTRA && t > 0 && !launch.policy) {  // the action tape's next step (frz_rollout_spec.action_tape)
                         const int2* const tape = reinterpret_cast<const int2*>(actions + (int64_t)t * launch.tape_actions_step);
                         int2 v[AMAX];
@@ -984,6 +986,15 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                         for (int q = 0; q < (AMAX + 3) / 4; ++q)
                             if (q * 4 < A) policy_block[q] = frz::philox4x32_10((uint32_t)q, 0u, (uint32_t)policy_step, (uint32_t)(policy_step >> 32),
                                                                                launch.policy_seed_lo ^ crw.seed, launch.policy_seed_hi);
+                    }
+                    if constexpr (PERSIST) {
+                        if (t > 0) {
+#ifdef FRZ_WF_EXPERIMENT  // timing experiments: FRZ_WF_SKIP bits 8..15 = quarters of a thousand cycles to wait before the totals are requested
+                            for (uint32_t w = 0; w < ((launch.skip >> 8) & 0xFFu); ++w) __builtin_amdgcn_s_sleep(4);
+#endif
+                            if (!launch.policy) __builtin_amdgcn_s_sleep(8);  // (no Philox block in front of the request: wait as long as one takes)
+                            request_totals();
+                        }
                     }
                     // A later step of a multi-step launch decodes BEFORE the totals of the step that just ended are here (they are the launch's
                     // inter-step barrier: a memory round trip after the last chunk has published them), assuming what is true of every

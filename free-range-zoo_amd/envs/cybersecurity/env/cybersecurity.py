@@ -244,6 +244,15 @@ class raw_env(BatchedParallelEnv):
             self._state.load_state(initial_state.to(self.device))
             self._call('rebuild')
         self._state.save_initial()
+        if options is not None and options.get('initial_state') is not None:
+            # the device-side partial reset (reset_finished) restores what was SAVED — the caller's state — like reset_batches (cybersecurity.py:284)
+            saved, desc = self._state.initial_state, _capi.frz_cybersecurity_saved_state()
+            for name in ('network_state', 'location', 'presence'):
+                t = getattr(saved, name)
+                setattr(desc, name, t.data_ptr())
+                setattr(desc, f'{name}_stride_env', t.stride(0))
+                setattr(desc, f'{name}_stride_item', t.stride(1))
+            _capi.check(self._lib.frz_cybersecurity_set_saved_initial(self._handle, ctypes.byref(desc)), 'frz_cybersecurity_set_saved_initial')
         self.infos = {agent: {} for agent in self.agents}
         self._has_reset = True
         self._publish()

@@ -522,6 +522,22 @@ int frz_cybersecurity_list_block(const frz_cybersecurity_env* env, void** block,
  * agent's task rows int64 [A][B][N][2]; each 256-byte aligned, in this order — frz_cybersecurity_bufs has the pointers) and the state
  * block in two pieces (network state, defender locations, last actions: int32 `[N + 2 D][B]` rows; presence: uint8 `[A][B]` rows).  One step
  * of a state tape = the rows piece followed by the presence piece, padded to a multiple of 256 bytes. */
+/* reset_batches with the selection on the device (utils/env.py:162-189 + cybersecurity.py:268-292), as frz_wildfire_reset_masked: env b is
+ * reset when mask[b] != 0 (uint8 [B]) or — mask NULL — when it is finished; seeds[b] += seed_increment (mod 2^32); state, last actions
+ * (-2), the staged actions (-2) and the bookkeeping of the reset envs as a reset leaves them; then observations and mappings of the
+ * batch are rebuilt.  The state put back is the configured initial state, or — after frz_cybersecurity_set_saved_initial — the state the
+ * binding saved at reset (the caller's `options['initial_state']`): strided device arrays, element (env b, item i) at
+ * ptr[b * stride_env + i * stride_item]; NULL clears it (a full reset does too). */
+typedef struct frz_cybersecurity_saved_state {
+    const int32_t* network_state; /* [B][N] */
+    int64_t network_state_stride_env, network_state_stride_item;
+    const int32_t* location; /* [B][D] */
+    int64_t location_stride_env, location_stride_item;
+    const uint8_t* presence; /* [B][A] (bool bytes) */
+    int64_t presence_stride_env, presence_stride_item;
+} frz_cybersecurity_saved_state;
+int frz_cybersecurity_reset_masked(frz_cybersecurity_env* env, const uint8_t* mask, int32_t seed_increment, void* stream);
+int frz_cybersecurity_set_saved_initial(frz_cybersecurity_env* env, const frz_cybersecurity_saved_state* saved);
 int frz_cybersecurity_obs_block(const frz_cybersecurity_env* env, void** block, int64_t* bytes);
 int frz_cybersecurity_state_block(const frz_cybersecurity_env* env, void** rows, int64_t* rows_bytes, void** presence, int64_t* presence_bytes);
 int frz_cybersecurity_set_exclusive_device(frz_cybersecurity_env* env, int exclusive);

@@ -570,11 +570,48 @@ def test_cybersecurity_tapes_in_the_multi_step_launch_against_the_oracle(oracle,
 
 
 def test_reset_finished_says_so_where_the_library_has_no_device_side_partial_reset():
-    import test_hip_cybersecurity as C
-    env = C.make_env(configs.cyber_openness, 64, 10, rng='philox')
+    from free_range_zoo_amd.envs import rideshare_v0
+    env = rideshare_v0.parallel_env(configuration=configs.rideshare_busy(A=4, steps=10, per_step=2, seed=2), parallel_envs=64, max_steps=10,
+                                    device=torch.device('cuda'))
     env.reset(seed=torch.arange(64, dtype=torch.int32))
     with pytest.raises(NotImplementedError, match='reset_batches'):
         env.reset_finished()
+
+
+@pytest.mark.parametrize('custom_initial_state', [False, True], ids=['configured_state', 'saved_state'])
+@pytest.mark.parametrize('rng', ['philox', 'mt19937'])
+def test_cybersecurity_masked_reset_equals_reset_batches(rng, custom_initial_state):
+    """`reset_finished(mask)` for cybersecurity (frz_cybersecurity_reset_masked: reset_batches with the selection on the device) against the
+    host-index `reset_batches` (itself pinned by tests/golden/partial_cybersecurity.npz) on a twin env: an arbitrary mask mid-episode, then
+    the finished envs (mask None) at the horizon — also after `reset(options={'initial_state': ...})`, where both must restore that state."""
+    import test_hip_cybersecurity as C
+    B, horizon = 900, 7
+    a, b = [C.make_env(configs.cyber_openness, B, horizon, rng=rng) for _ in range(2)]
+    seeds = torch.arange(B, dtype=torch.int32) + 9
+    for env in (a, b):
+        env.reset(seed=seeds)
+    if custom_initial_state:
+        a.rollout(3, policy_seed=1)
+        custom = a.state().clone()
+        for env in (a, b):
+            env.reset(seed=seeds, options={'initial_state': custom})
+    picks = torch.zeros(B, dtype=torch.bool)
+    picks[torch.arange(0, B, 7)] = True
+    for t in range(2 * horizon + 1):
+        a.step_random_policy(5, t), b.step_random_policy(5, t)
+        if t == 2:  # an arbitrary selection, mid-episode
+            a.reset_finished(picks.cuda(), seed_increment=21)
+            idx = picks.nonzero().reshape(-1).cuda()
+            b.reset_batches(idx, seed=(b.seeds[idx].to(torch.int64) + 21).to(torch.int32))
+        elif bool(b.finished.any()):  # the envs that reached the horizon (those reset at t == 2 reach it later)
+            a.reset_finished(seed_increment=4)
+            idx = b.finished.nonzero().reshape(-1)
+            b.reset_batches(idx, seed=(b.seeds[idx].to(torch.int64) + 4).to(torch.int32))
+        C.compare_snapshots(C.hip_snapshot(a), C.hip_snapshot(b), f'{rng} step {t}')
+        G.assert_same(np_(a.seeds), np_(b.seeds), f'seeds at step {t}')
+        G.assert_same(np_(a._actions), np_(b._actions), f'staged actions at step {t}')
+    assert int(np_(a.num_moves).min()) < horizon
+    a.check(), b.check()
 
 
 def test_cybersecurity_one_step_rollout_honours_the_spec(oracle):
