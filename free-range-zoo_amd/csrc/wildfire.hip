@@ -1531,7 +1531,7 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
     p.off_epoch = take(256);
     p.off_metrics = take((int64_t)kMetricBlocks * (FRZ_MAX_AGENTS + 2) * 8);  // partial rows of frz_wildfire_episode_metrics
     p.off_totals = take(2 * kTotalsStride * 4);
-    p.off_agg = take((int64_t)p.nchunks * p.nch * 8);
+    p.off_agg = take(2 * (int64_t)p.nchunks * p.nch * 8);  // two copies: a multi-step launch double-buffers its chunk sums by the step's parity
     p.off_prefix = take((int64_t)p.nchunks * p.nch * 8);
     p.off_rand_field = take(3 * B * HW * 4);
     p.off_rand_agent = take(5 * B * A * 4);

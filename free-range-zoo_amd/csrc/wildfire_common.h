@@ -160,8 +160,10 @@ inline uint32_t experiment_skip() {
 }
 #ifdef FRZ_WF_EXPERIMENT
 #define FRZ_SKIP(bit) ((launch.skip >> (bit)) & 1u)
+#define FRZ_WF_LOCAL_PROOF (!FRZ_SKIP(5))  // (A/B: every workgroup waits for the batch totals between the steps of a launch, as rounds 2-3 did)
 #else
 #define FRZ_SKIP(bit) false
+#define FRZ_WF_LOCAL_PROOF true
 #endif
 
 inline WfLaunch make_launch(const WfArgs& a) {

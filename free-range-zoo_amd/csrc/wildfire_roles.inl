@@ -27,13 +27,13 @@ namespace {
 constexpr int kRoleBlock = 2 * kBlock;  // 4 field + 4 crew wavefronts per 256-env chunk
 constexpr int kRound = 256;             // look-back window: a chunk sums at most kRound - 1 predecessors' granules + one prefix granule
 
-// Diagnostic build only (-DFRZ_WF_STAMPS, tools/stamps.py): the first thread of each role of workgroup 0 records the
+// Diagnostic build only (-DFRZ_WF_STAMPS, tools/stamps.py): the first thread of each role of ONE workgroup (0, or bits 16.. of FRZ_WF_SKIP) records the
 // shader clock at phase boundaries into a buffer nothing else reads.  No stamp executes in the production library.
 #ifdef FRZ_WF_STAMPS
 #define FRZ_RSTAMP(i)                                                                                                       \
     do {                                                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                                  \
-        if (blockIdx.x == 0 && slot == 0 && MODE == kStep)                                                                  \
+        if (blockIdx.x == ((launch.skip >> 16) & 0xFFFu) && slot == 0 && MODE == kStep)                                     \
             reinterpret_cast<unsigned long long*>(arena + dev->off_rand_agent)[(crew ? 16 : 0) + (i)] = __builtin_amdgcn_s_memtime(); \
         __builtin_amdgcn_sched_barrier(0);                                                                                  \
     } while (0)
@@ -83,7 +83,12 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
     // multi-step launches with in-kernel Philox draws: the field role writes EVERY list (see emit_field).  Not with the per-env MT19937 streams:
     // there the field role's own phase 1 (66 stream words in, 33 twisted and written back) is the long one, and the old split is faster
     // (round 4: 12.2 against 10.7 us per step of the default-RNG block when it wrote all the lists too)
+#ifndef FRZ_WF_CREW_LISTS
+#define FRZ_WF_CREW_LISTS 0  // agents whose action lists the crew role writes in such a launch (the first n; experiment builds vary it)
+#endif
     constexpr bool kFieldWritesAllLists = PERSIST && RNG == FRZ_RNG_PHILOX;
+    // which role writes agent a's action lists
+    auto crew_writes = [](int a) constexpr { return kFieldWritesAllLists ? a < FRZ_WF_CREW_LISTS : (a & 1) == 0; };
     static_assert(EXACT || !(kPhilox || kMt), "runtime shapes stage their draws (wf_philox_fill_kernel / frz_mt19937_generate)");
 
     __shared__ uint64_t s_wave_scan[frz::kWaves][PW];
@@ -420,17 +425,54 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
     // a wait that hit its bound (workgroups of this launch not resident: the device is shared after all) flags FRZ_ERR_SCAN_TIMEOUT; every
     // later wait of the launch then gives up at once, so that a launch that cannot work ends in seconds, not minutes
     bool gave_up = false;
+    // the chunk sums of a multi-step launch are double-buffered by the parity of the step's epoch (see `owed` below)
+    auto agg_now = [&]() { return agg + (PERSIST ? (int64_t)(epoch_now & 1u) * nchunks * nch : (int64_t)0); };
     uint64_t requested[AMAX + 3];
     auto request_totals = [&]() {
         const uint64_t* const last = prefix + (int64_t)(nchunks - 1) * nch;
 #pragma unroll
         for (int i = 0; i < AMAX + 3; ++i) requested[i] = frz::granule_load(last + (i < nch ? i : 0));
     };
-    auto await_totals = [&]() {
+    // The chunk's OWN sums of the step that just ended (uniform over the workgroup; set where the chunk publishes them).  Everything a step
+    // asks of the batch totals is "is channel i zero?" (an agent nobody can use: wildfire.py:434-435; every env terminated / truncated:
+    // utils/env.py:211-213) — and a channel that is non-zero in this chunk alone is non-zero in the batch.  A workgroup whose own sums
+    // answer every question does not wait for the totals at all (`own_proves`): the launch then has ONE dependent cross-chip hand-off per
+    // step (the look-back) instead of two.  What the totals also were — the inter-step barrier that kept a chunk from overwriting the sums
+    // its successors still read — is kept as a debt (`owed`): the chunk sums are double-buffered by the step's parity, and a chunk looks
+    // at the last chunk's granule of step t - 1 (requested behind barrier 1 of step t, long there by then) before it publishes its sums of step
+    // t over those of step t - 2: the last chunk's look-back of step t - 1 read every chunk's sums of step t - 1, which each chunk published
+    // after its own look-back of step t - 2.
+    uint32_t own[AMAX + 3];
+#pragma unroll
+    for (int i = 0; i < AMAX + 3; ++i) own[i] = 0;
+    bool own_proves = false, owed = false;
+    uint32_t owed_tag = 0;
+    uint64_t owed_granule = 0;  // the last chunk's granule as requested behind barrier 1 of the step that owes the look
+    auto advance_epoch = [&]() {
         epoch_now += 1u;
-        const uint32_t ended = tag;
+        owed_tag = tag;
         tag = epoch_now + 1u;
         cur_totals = totals + (epoch_now & 1u) * kTotalsStride;
+    };
+    auto settle_owed = [&]() {  // before this chunk's sums of the step replace those of two steps ago
+        if (!owed) return;
+        owed = false;
+        const uint64_t* const last = prefix + (int64_t)(nchunks - 1) * nch;
+        bool timed_out = false;
+        uint64_t g = owed_granule;
+        for (int spin = 0; (uint32_t)(g >> 32) != owed_tag; ++spin) {  // bounded
+            if (gave_up || spin >= (1 << 20)) {
+                timed_out = gave_up = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            g = frz::granule_load(last);
+        }
+        if (timed_out && slot == 0) atomicOr(error_word, (uint32_t)FRZ_ERR_SCAN_TIMEOUT);
+    };
+    auto await_totals = [&]() {
+        advance_epoch();
+        const uint32_t ended = owed_tag;
         const uint64_t* const last = prefix + (int64_t)(nchunks - 1) * nch;
         bool timed_out = false;
         for (int spin = 0;; ++spin) {  // bounded
@@ -503,6 +545,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
         for (int c = 0; c < CMAX; ++c) {
             const mask_t below = (mask_t)(((mask_t)1 << c) - 1);
             const int rk = popc(lit1 & below);
+            if (FRZ_SKIP(3)) continue;  // (timing experiments: the list values left out — profiles/r04_experiments.txt §8)
             if ((ok >> c) & 1)
                 av[popc(ok & below)] = rk;
             else if (show_bad && ((lit1 >> c) & 1))
@@ -564,8 +607,8 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                     // 1-2 % only: what bounds a step of the launch is the two dependent agent-scope round trips of its hand-off — the
                     // look-back behind the rewards, then the batch totals — not either role's instruction count: profiles/r04_experiments.txt.)
 #pragma unroll
-                    for (int a = (kFieldWritesAllLists ? 0 : 1); a < AMAX; a += (kFieldWritesAllLists ? 1 : 2))
-                        if (a < A) emit_agent_lists(a, lit1, (mask_t)((oks >> (MB * a)) & (pack_t)((1u << MB) - 1u)), off_f, channel_offset(place, a + 1), b, copy, ocopy);
+                    for (int a = 0; a < AMAX; ++a)
+                        if (a < A && !crew_writes(a)) emit_agent_lists(a, lit1, (mask_t)((oks >> (MB * a)) & (pack_t)((1u << MB) - 1u)), off_f, channel_offset(place, a + 1), b, copy, ocopy);
                     int64_t* const task_values = reinterpret_cast<int64_t*>(arena + d.off_task_values + copy);
                     int64_t* const task_offsets = reinterpret_cast<int64_t*>(arena + d.off_task_offsets + ocopy);
                     int64_t* const obs_map = reinterpret_cast<int64_t*>(arena + d.off_obs_map + copy);
@@ -577,7 +620,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
 #pragma unroll
                     for (int c = 0; c < CMAX; ++c) {
                         const int rk = popc(lit1 & (mask_t)(((mask_t)1 << c) - 1));
-                        if ((lit1 >> c) & 1) {
+                        if (((lit1 >> c) & 1) && !FRZ_SKIP(3)) {
                             const int yx = d.cell_yx[c];
                             longlong2* const row = reinterpret_cast<longlong2*>(trow + rk * 4);
                             row[0] = make_longlong2(yx >> 16, yx & 0xFFFF);
@@ -923,13 +966,13 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
             for (int c = 0; c < CMAX; ++c) lit_before |= (mask_t)(cells.f[c] > 0) << c;
             // phase 6 as a function of (lit cells, attackable cells per agent, copy of the packed lists)
             auto emit_crew = [&](mask_t lit1, const mask_t (&ok1)[AMAX], int64_t copy, int64_t ocopy) {
-                if constexpr (kFieldWritesAllLists) return;  // (the field role writes every list of such a launch, see emit_field)
+                if constexpr (kFieldWritesAllLists && FRZ_WF_CREW_LISTS == 0) return;  // (the field role writes every list of such a launch, see emit_field)
                 if (active) {
                     const Placement place = placement();
                     const int64_t off_f = channel_offset(place, 0);
 #pragma unroll
-                    for (int a = 0; a < AMAX; a += 2)
-                        if (a < A) emit_agent_lists(a, lit1, ok1[a], off_f, channel_offset(place, a + 1), b, copy, ocopy);
+                    for (int a = 0; a < AMAX; ++a)
+                        if (a < A && crew_writes(a)) emit_agent_lists(a, lit1, ok1[a], off_f, channel_offset(place, a + 1), b, copy, ocopy);
                 }
             };
             for (int t = 0; t < n_steps; ++t) {
@@ -992,8 +1035,10 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
 #ifdef FRZ_WF_EXPERIMENT  // timing experiments: FRZ_WF_SKIP bits 8..15 = quarters of a thousand cycles to wait before the totals are requested
                             for (uint32_t w = 0; w < ((launch.skip >> 8) & 0xFFu); ++w) __builtin_amdgcn_s_sleep(4);
 #endif
-                            if (!launch.policy) __builtin_amdgcn_s_sleep(8);  // (no Philox block in front of the request: wait as long as one takes)
-                            request_totals();
+                            if (!(FRZ_WF_LOCAL_PROOF && own_proves)) {  // (a chunk whose own sums answer the step's questions does not ask)
+                                if (!launch.policy) __builtin_amdgcn_s_sleep(8);  // (no Philox block in front of the request: wait as long as one takes)
+                                request_totals();
+                            }
                         }
                     }
                     // A later step of a multi-step launch decodes BEFORE the totals of the step that just ended are here (they are the launch's
@@ -1048,6 +1093,13 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                     }
                     if constexpr (PERSIST) {
                         if (!assume_ordinary) break;
+                        if (FRZ_WF_LOCAL_PROOF && own_proves) {  // this chunk's own sums say "ordinary": nothing to wait for here
+                            advance_epoch();
+#pragma unroll
+                            for (int i = 0; i < AMAX + 3; ++i) prev[i] = own[i];
+                            owed = true;
+                            break;
+                        }
                         await_totals();
                         bool someone_skipped = false;
 #pragma unroll
@@ -1066,6 +1118,10 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                 __syncthreads();  // (1) applied power visible to the field role
                 FRZ_RSTAMP(4);
                 if constexpr (PERSIST) {
+                    // (the debt of a step that did not wait for the totals: asked for HERE, not at the top of the step — a request issued
+                    // there can reach memory a few hundred clocks before the last chunk's granule does, and the second look would then cost a
+                    // whole round trip right where this chunk publishes its sums, which every later chunk's look-back waits for)
+                    if (owed) owed_granule = frz::granule_load(prefix + (int64_t)(nchunks - 1) * nch);
                     stop = s_stop != 0;
                     if (stop) {  // utils/env.py:211-213: nothing more happens in this launch
                         if (t > 0) {  // the last lists went to the second copy: once more, into the caller's buffers
@@ -1279,9 +1335,27 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
 #pragma unroll
                         for (int j = 0; j < frz::kWaves; ++j) my_total += s_wave_live[j][which];
                     }
-                    frz::granule_store(agg + (int64_t)chunk * nch + slot, tag, my_total);
+                    if constexpr (PERSIST) settle_owed();
+                    frz::granule_store(agg_now() + (int64_t)chunk * nch + slot, tag, my_total);
                 }
-
+                FRZ_RSTAMP(13);
+                if constexpr (PERSIST) {  // what this chunk alone can say about the batch totals the next step asks for
+                    bool proves = true;
+#pragma unroll
+                    for (int i = 0; i <= AMAX; ++i) {
+                        uint64_t word = block_total[0];
+#pragma unroll
+                        for (int w = 1; w < PW; ++w) word = (i >> 2) == w ? block_total[w] : word;
+                        own[i] = (uint32_t)((word >> (16 * (i & 3))) & 0xFFFFull);
+                        proves = proves && (i == 0 || i > A || own[i] != 0u);
+                    }
+                    uint32_t live_own[2] = {0u, 0u};
+#pragma unroll
+                    for (int j = 0; j < frz::kWaves; ++j) live_own[0] += s_wave_live[j][0], live_own[1] += s_wave_live[j][1];
+#pragma unroll
+                    for (int i = 0; i < AMAX + 3; ++i) own[i] = i == ch_nt ? live_own[0] : (i == ch_ntr ? live_own[1] : own[i]);
+                    own_proves = proves && (auto_reset || (live_own[0] != 0u && live_own[1] != 0u));
+                }
                 if (MODE == kStep) {
                     // rewards and termination (wildfire.py:534-582)
                     float fire_reward_sum = 0.0f, burnout_total = 0.0f;
@@ -1349,17 +1423,20 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                     at32(rows8, q_burnouts * Bu + bl) = n_burn;
                     at32(rows8, q_putouts * Bu + bl) = n_put;
                 }
+                FRZ_RSTAMP(14);
                 if (active) {
 #pragma unroll
                     for (int a = 0; a < AMAX; ++a)
                         if (a < A) at32(rows, (uint32_t)(r_atc + a) * Bu + bl) = popc(ok1[a]);
                     at32(rows8, q_etc * Bu + bl) = F;
                 }
+                FRZ_RSTAMP(15);
                 // inter-workgroup exclusive prefix (single pass), as in wildfire.hip: crew thread t sums channel (t % NCHP) over
                 // predecessors t / NCHP, t / NCHP + PP, ...; the window's loads are unconditional so they are in flight together
                 bool timed_out = false;
                 uint32_t acc = 0;
                 {
+                    const uint64_t* const agg_step = agg_now();
                     const int ch = slot & (NCHP - 1), pslot = slot / NCHP;
                     constexpr int PP = kBlock / NCHP, UNR = 8;
                     for (int first = round_first; first < (FRZ_SKIP(7) ? round_first : chunk); first += PP * UNR) {  // (bit 7: timing experiments)
@@ -1371,7 +1448,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                             for (int u = 0; u < UNR; ++u) {
                                 const int pred = first + u * PP + pslot;
                                 const bool valid = pred < chunk && ch < nch;
-                                const uint64_t g = frz::granule_load(agg + (valid ? (int64_t)pred * nch + ch : (int64_t)0));
+                                const uint64_t g = frz::granule_load(agg_step + (valid ? (int64_t)pred * nch + ch : (int64_t)0));
                                 all = all && (!valid || (uint32_t)(g >> 32) == tag);
                                 part += valid ? (uint32_t)g : 0u;
                             }

@@ -39,7 +39,10 @@ def assert_same(got, want, what, rtol=0.0):
     if rtol and want.dtype.kind == 'f':
         np.testing.assert_allclose(got, want, rtol=rtol, atol=1e-6, err_msg=what)
     else:
-        assert np.array_equal(got, want), f'{what}: mismatch\n got={got.reshape(-1)[:24]}\nwant={want.reshape(-1)[:24]}'
+        if not np.array_equal(got, want):
+            where = np.flatnonzero(got.reshape(-1) != want.reshape(-1))
+            raise AssertionError(f'{what}: mismatch at {where.size} of {got.size} entries, first at flat index {where[:8]}\n got={got.reshape(-1)[where[:8]]}\n'
+                                 f'want={want.reshape(-1)[where[:8]]}')
 
 
 # rewards: BASELINE.json north_star tolerance for float rewards (integer state is bit-exact)

@@ -711,6 +711,35 @@ def test_device_side_partial_resets_restore_the_saved_state(oracle, family, via,
         env.check()
 
 
+def test_multi_step_launch_where_some_chunks_cannot_answer_for_the_batch(oracle):
+    """Between the steps of a multi-step launch a workgroup whose OWN 256 envs already show that every batch total a step asks about is
+    non-zero (an attackable task for every agent, an env that is not terminated, one that is not truncated) does not wait for the
+    totals (round 4); a workgroup whose own sums leave a question open still does.  A batch built so that both kinds sit in one launch:
+    chunk 0 without any fire (no tasks at all: its sums are zero in every list channel), chunk 1 with agent 0 out of suppressant (that
+    agent's channel zero there), the other chunks ordinary — against the same rollout run one launch per step on a twin env."""
+    B, horizon, steps = 1100, 40, 14
+    envs = [make_env(configs.wildfire_openness, B, horizon, rng='philox') for _ in range(2)]
+    seeds = torch.arange(B, dtype=torch.int32) * 5 + 1
+    for env in envs:
+        env.reset(seed=seeds)
+    custom = envs[0].state().clone()
+    custom.fires[:256] = -custom.fires[:256].abs()   # unlit everywhere: nothing to fight in chunk 0
+    custom.intensity[:256] = 0
+    custom.suppressants[256:512, 0] = 0.0            # agent 0 cannot fight anywhere in chunk 1
+    for env in envs:
+        env.reset(seed=seeds, options={'initial_state': custom})
+    a, b = envs
+    a.set_exclusive_device(True)
+    assert a._lib.frz_wildfire_rollout_launches(a._handle, steps, _capi.FRZ_RNG_PHILOX) == 1
+    ra = a.rollout(steps, policy_seed=9, first_step=0, record=True)
+    rb = b.rollout(steps, policy_seed=9, first_step=0, record=True)  # (not declared exclusive: one launch per step)
+    for key in ('rewards', 'dones', 'actions'):
+        G.assert_same(np_(ra[key]), np_(rb[key]), f'recorded {key}')
+    compare_snapshots(hip_snapshot(a), hip_snapshot(b), 'one launch against one launch per step')
+    for env in envs:
+        env.check()
+
+
 @pytest.mark.parametrize('family', ['roles', 'lane', 'grid'])
 def test_masked_reset_of_the_finished_envs_in_every_kernel_family(oracle, family, monkeypatch):
     """reset_finished() (mask=None: the finished envs, decided on the device) against the oracle's reset_batches in each kernel family —
