@@ -541,11 +541,32 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
             frz::store_through(&bad_offsets[a * (B + 1) + b], off_f - off_a);
             if (b == B - 1) bad_offsets[a * (B + 1) + B] = (off_f - off_a) + (F - fa);
         }
+        if (FRZ_SKIP(3)) return;  // (timing experiments: the list values left out — profiles/r04_experiments.txt §8)
+        if (!FRZ_SKIP(4)) {
+            // entry by entry instead of cell by cell: the j-th store instruction writes every env's j-th entry, and the wavefront stops at
+            // the longest list among its 64 envs (2-3 entries at the bench shape's list sizes, not CMAX cells)
+            uint32_t m = (uint32_t)ok;
+#pragma unroll
+            for (int j = 0; j < CMAX; ++j) {
+                if (!__any(m != 0u)) break;
+                if (m != 0u) av[j] = popc(lit1 & (mask_t)((m & (0u - m)) - 1u));
+                m &= m - 1u;
+            }
+            if (show_bad) {
+                m = (uint32_t)(mask_t)(lit1 & ~ok);
+#pragma unroll
+                for (int j = 0; j < CMAX; ++j) {
+                    if (!__any(m != 0u)) break;
+                    if (m != 0u) bv[j] = popc(lit1 & (mask_t)((m & (0u - m)) - 1u));
+                    m &= m - 1u;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) {
             const mask_t below = (mask_t)(((mask_t)1 << c) - 1);
             const int rk = popc(lit1 & below);
-            if (FRZ_SKIP(3)) continue;  // (timing experiments: the list values left out — profiles/r04_experiments.txt §8)
             if ((ok >> c) & 1)
                 av[popc(ok & below)] = rk;
             else if (show_bad && ((lit1 >> c) & 1))
@@ -617,6 +638,25 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                     // row of cell c's task inside the env's segment = number of lit cells below it
                     int64_t* const trow = task_values + off_f * 4;
                     int64_t* const omap = obs_map + off_f;
+                    if (!FRZ_SKIP(4) && !FRZ_SKIP(3)) {  // entry by entry, as in emit_agent_lists: row j = the env's j-th lit cell
+                        uint32_t m = (uint32_t)lit1;
+#pragma unroll
+                        for (int j = 0; j < CMAX; ++j) {
+                            if (!__any(m != 0u)) break;
+                            if (m != 0u) {
+                                const int c = __ffs((int)m) - 1;
+                                int fc = f[0], ic = in[0];
+#pragma unroll
+                                for (int k = 1; k < CMAX; ++k) fc = c == k ? f[k] : fc, ic = c == k ? in[k] : ic;
+                                const int yx = s_cfg.cell_yx[c];
+                                longlong2* const row = reinterpret_cast<longlong2*>(trow + j * 4);
+                                row[0] = make_longlong2(yx >> 16, yx & 0xFFFF);
+                                row[1] = make_longlong2(fc, ic);
+                                omap[j] = j;
+                            }
+                            m &= m - 1u;
+                        }
+                    } else
 #pragma unroll
                     for (int c = 0; c < CMAX; ++c) {
                         const int rk = popc(lit1 & (mask_t)(((mask_t)1 << c) - 1));
