@@ -141,7 +141,11 @@ struct RowRef {
     T* p;
     __device__ __forceinline__ operator T() const { return *p; }
     __device__ __forceinline__ const RowRef& operator=(T v) const {
+#ifdef FRZ_ROWS_PLAIN  // (experiment builds: the rows left to the L2's write-back)
+        *p = v;
+#else
         store_through(p, v);
+#endif
         return *this;
     }
     __device__ __forceinline__ const RowRef& operator=(const RowRef& o) const { return *this = (T)o; }

@@ -424,6 +424,19 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
     // round trip of an agent-scope load passes behind the work in between; only a wavefront that was too early polls)
     // a wait that hit its bound (workgroups of this launch not resident: the device is shared after all) flags FRZ_ERR_SCAN_TIMEOUT; every
     // later wait of the launch then gives up at once, so that a launch that cannot work ends in seconds, not minutes
+    // The five barriers of a step carry LDS data from role to role.  __syncthreads() also waits for every global store the wavefront has
+    // in flight (s_waitcnt vmcnt(0)) — five drains of the store queue per step that nothing in a multi-step Philox / injected-randomness
+    // launch needs: its roles hand nothing to each other through global memory (the MT19937 streams are: their kernels keep the full
+    // barrier, and so do the single-step kernels).
+    auto role_barrier = [&]() {
+        if constexpr (PERSIST && !kMt) {
+            if (!FRZ_SKIP(4)) {  // (bit 4: timing experiments — the full barrier)
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                return;
+            }
+        }
+        __syncthreads();
+    };
     bool gave_up = false;
     // the chunk sums of a multi-step launch are double-buffered by the parity of the step's epoch (see `owed` below)
     auto agg_now = [&]() { return agg + (PERSIST ? (int64_t)(epoch_now & 1u) * nchunks * nch : (int64_t)0); };
@@ -763,7 +776,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                         for (int c = 0; c < CMAX; ++c) asm volatile("" : "+v"(r_field[e][c]));
                 }
                 FRZ_RSTAMP(3);
-                __syncthreads();  // (1) applied power visible
+                role_barrier();  // (1) applied power visible
                 FRZ_RSTAMP(4);
                 if constexpr (PERSIST) {
                     // Is the batch finished (utils/env.py:211-213: nothing more happens in this launch)?  The crew's first wavefront has
@@ -906,11 +919,11 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                 lit1 = active ? lit1 : (mask_t)0;
                 x_fate[slot] = (fate_t)burned | ((fate_t)put_out << MB) | ((fate_t)dead << (2 * MB));
                 FRZ_RSTAMP(5);
-                __syncthreads();  // (2) lit mask and fates visible to the crew
+                role_barrier();  // (2) lit mask and fates visible to the crew
                 FRZ_RSTAMP(6);
 
                 // ---- phase 3: cell rows (the crew scans meanwhile)
-                if ((MODE == kStep || MODE == kReset) && !FRZ_SKIP(2)) {
+                if ((MODE == kStep || MODE == kReset) && !(FRZ_SKIP(2) && PERSIST && t < n_steps - 1)) {  // (bit 2: timing experiments — the cell rows of the launch's last step only)
 #pragma unroll
                     for (int c = 0; c < CMAX; ++c)
                         if (c < HW) {
@@ -961,7 +974,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                         }
                 }
                 FRZ_RSTAMP(7);
-                __syncthreads();  // (3) wavefront sums visible
+                role_barrier();  // (3) wavefront sums visible
 
                 // ---- phase 4 belongs to the crew (hand-off)
                 if constexpr (kPhilox && PERSIST) {
@@ -973,8 +986,8 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                     }
                 }
                 FRZ_RSTAMP(8);
-                __syncthreads();  // (4)
-                __syncthreads();  // (5) chunk prefix visible
+                role_barrier();  // (4)
+                role_barrier();  // (5) chunk prefix visible
                 FRZ_RSTAMP(9);
 
                 // ---- phase 6: task list (wildfire.py:586-717)
@@ -1155,7 +1168,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                     }
                 }
                 FRZ_RSTAMP(3);
-                __syncthreads();  // (1) applied power visible to the field role
+                role_barrier();  // (1) applied power visible to the field role
                 FRZ_RSTAMP(4);
                 if constexpr (PERSIST) {
                     // (the debt of a step that did not wait for the totals: asked for HERE, not at the top of the step — a request issued
@@ -1266,7 +1279,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                 for (int a = 0; a < AMAX; ++a)
                     if (a < A) x_supp[a][slot] = supp[a];  // the field role stores the agent observations
                 FRZ_RSTAMP(5);
-                __syncthreads();  // (2) lit mask and fates visible
+                role_barrier();  // (2) lit mask and fates visible
                 FRZ_RSTAMP(6);
 
                 // ---- phase 3: open-task sets, per-env counts, wavefront scan
@@ -1347,7 +1360,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                     x_ok[slot] = oks;
                 }
                 FRZ_RSTAMP(7);
-                __syncthreads();  // (3) wavefront sums visible
+                role_barrier();  // (3) wavefront sums visible
 
                 // ---- phase 4: chunk sums published; rewards / bookkeeping hide the hand-off; look-back
                 const int round_first = chunk & ~(kRound - 1);  // chunks are handed off in windows of kRound
@@ -1507,7 +1520,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                     if (lane < NCHP) s_reduce[wave][lane] = acc;
                 }
                 FRZ_RSTAMP(8);
-                __syncthreads();  // (4) look-back partial sums visible
+                role_barrier();  // (4) look-back partial sums visible
 
                 // ---- phase 5: chunk prefix
                 if (slot < nch) {
@@ -1521,7 +1534,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                         if (chunk == nchunks - 1) cur_totals[slot] = s + my_total;  // batch totals, read by the next launch
                     }
                 }
-                __syncthreads();  // (5) chunk prefix visible
+                role_barrier();  // (5) chunk prefix visible
                 FRZ_RSTAMP(9);
                 if (timed_out) err |= FRZ_ERR_SCAN_TIMEOUT;
 
