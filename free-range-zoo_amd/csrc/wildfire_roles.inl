@@ -33,7 +33,7 @@ constexpr int kRound = 256;             // look-back window: a chunk sums at mos
 #define FRZ_RSTAMP(i)                                                                                                       \
     do {                                                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                                  \
-        if (blockIdx.x == ((launch.skip >> 16) & 0xFFFu) && slot == 0 && MODE == kStep)                                     \
+        if (blockIdx.x == ((launch.skip >> 16) & 0xFFFu) && slot == 0 && MODE == kStep && frz_stamp_step)                  \
             reinterpret_cast<unsigned long long*>(arena + dev->off_rand_agent)[(crew ? 16 : 0) + (i)] = __builtin_amdgcn_s_memtime(); \
         __builtin_amdgcn_sched_barrier(0);                                                                                  \
     } while (0)
@@ -285,6 +285,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
         return e;
     };
 
+    bool frz_stamp_step = true;  // (stamp builds: which step of a multi-step launch leaves its stamps — the one before the last, an ordinary step)
     FRZ_RSTAMP(0);
     FRZ_RWALL(0);
     // One chunk per workgroup.  A launch with no more chunks than resident workgroups maps chunk = blockIdx.x; a larger one
@@ -684,6 +685,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                 }
             };
             for (int t = 0; t < n_steps; ++t) {
+                frz_stamp_step = t == (n_steps > 1 ? n_steps - 2 : 0);
                 const int64_t copy = list_copy(t), ocopy = offsets_copy(t);
                 // per-step opaque copies: the flag tests stay next to their uses, and in a multi-step launch so do the row addresses — hoisted
                 // out of the step loop, the ~100 store addresses and ~40 row bases of a step would all be live from the top of the kernel
@@ -1029,6 +1031,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                 }
             };
             for (int t = 0; t < n_steps; ++t) {
+                frz_stamp_step = t == (n_steps > 1 ? n_steps - 2 : 0);
                 const int64_t copy = list_copy(t), ocopy = offsets_copy(t);
                 // per-step opaque copies: the flag tests stay next to their uses, and in a multi-step launch so do the row addresses — hoisted
                 // out of the step loop, the ~100 store addresses and ~40 row bases of a step would all be live from the top of the kernel

@@ -1,4 +1,4 @@
-"""Phase stamps of the LAST step of a multi-step launch (diagnostic build libfrz_hip_stamps.so), workgroup argv[1] (default 0)."""
+"""Phase stamps of the step BEFORE THE LAST (an ordinary step: the last one draws nothing for a next step) of a multi-step launch (diagnostic build libfrz_hip_stamps.so), workgroup argv[1] (default 0)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ['FRZ_HIP_LIB'] = os.path.join(ROOT, 'free-range-zoo_amd', 'csrc', 'libfrz_hip_stamps.so')
@@ -24,6 +24,6 @@ for rep in range(8):
     rows.append(env._arena[off:off + 32 * 8].view(torch.int64).cpu().numpy().astype(np.int64).copy())
 st = np.array(rows[2:])
 base = st[:, 3:4]  # field: phase 1 done of the last step
-print(f'workgroup {WG}: cycles relative to the field role finishing phase 1 of the last step (stamps 0-2 are from the launch start)')
+print(f'workgroup {WG}: cycles relative to the field role finishing phase 1 of the stamped step (stamps 0-2 are from the launch start)')
 for i, n in enumerate(names):
     print(f'  {n:20s} field {int(np.median(st[:, i] - base[:, 0])):8d}   crew {int(np.median(st[:, 16 + i] - base[:, 0])):8d}')
