@@ -1114,7 +1114,8 @@ int launch(frz_wildfire_env* env, const WfArgs& args, int rng, int mode, hipStre
     }
     {
         WfArgs a = args;
-        if (!kVariants[env->variant].exact && mode == kStep && rng == FRZ_RNG_PHILOX) stage_philox(a, rng, stream);
+        // (runtime shapes: a single step reads staged draws; their multi-step launch draws in the kernel)
+        if (!kVariants[env->variant].exact && mode == kStep && rng == FRZ_RNG_PHILOX && env->rollout_steps <= 1) stage_philox(a, rng, stream);
         a.ticketed = env->ticketed;
         a.n_steps = env->rollout_steps;
         a.scratch_delta = env->list_copy_delta;
@@ -1538,7 +1539,8 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
     p.off_mt_state = take(624 * B * 4);
     // second copy of the packed list buffers (task rows, observation map, action / bad-action maps: contiguous above) for the
     // multi-step launches of the exact field/crew kernels
-    const bool multi_step = p.roles && kVariants[env->variant].exact;
+    // (round 4: the runtime-shape field/crew variants of <= 4 agents have a multi-step launch too)
+    const bool multi_step = p.roles && (kVariants[env->variant].exact || kVariants[env->variant].amax <= 4);
     if (multi_step) env->list_copy_delta = take(p.off_actions - p.off_task_values) - p.off_task_values;
     p.total_bytes = off;
 
@@ -1816,7 +1818,8 @@ int frz_wildfire_import_totals(frz_wildfire_env* env, const int32_t* staging, vo
 int frz_wildfire_rollout_launches(const frz_wildfire_env* env, int32_t n_steps, int rng_mode) {
     if (!env || n_steps < 0) return FRZ_E_INVALID;
     const bool one = n_steps > 1 && env->exclusive_device && env->list_copy_delta != 0 && !env->ticketed &&
-                     (rng_mode == FRZ_RNG_PHILOX || rng_mode == FRZ_RNG_MT19937 || rng_mode == FRZ_RNG_INJECTED) && env->dev.roles && !env->dev.grid;
+                     (rng_mode == FRZ_RNG_PHILOX || rng_mode == FRZ_RNG_INJECTED || (rng_mode == FRZ_RNG_MT19937 && kVariants[env->variant].exact)) &&
+                     env->dev.roles && !env->dev.grid;  // (runtime shapes keep their MT19937 streams outside the step kernel: one launch per step)
     return one ? 1 : n_steps;
 }
 

@@ -89,7 +89,10 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
     constexpr bool kFieldWritesAllLists = PERSIST && RNG == FRZ_RNG_PHILOX;
     // which role writes agent a's action lists
     auto crew_writes = [](int a) constexpr { return kFieldWritesAllLists ? a < FRZ_WF_CREW_LISTS : (a & 1) == 0; };
-    static_assert(EXACT || !(kPhilox || kMt), "runtime shapes stage their draws (wf_philox_fill_kernel / frz_mt19937_generate)");
+    // runtime shapes: a single step reads staged draws (wf_philox_fill_kernel / frz_mt19937_generate); a MULTI-step launch draws in the kernel
+    // like the exact shapes do, its draw indices (which depend on H * W and A) resolved through an LDS scratch column per env (x_uni)
+    static_assert(EXACT || !kMt, "runtime shapes keep their MT19937 streams outside the step kernel (frz_mt19937_generate)");
+    static_assert(EXACT || !kPhilox || PERSIST, "runtime shapes stage the draws of a single step (wf_philox_fill_kernel)");
 
     __shared__ uint64_t s_wave_scan[frz::kWaves][PW];
     __shared__ uint32_t s_wave_live[frz::kWaves][2];
@@ -105,6 +108,9 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
     // field -> crew: the step's agent draws (in-kernel RNG).  Two copies in a multi-step Philox launch: the field parks the NEXT step's
     // draws in copy (t + 1) & 1 as soon as it has made them, instead of holding 5 * AMAX registers across its list phase and the loop's
     // back edge (they were spilled)
+    // runtime shapes, in-kernel Philox: draw u of the env (u = e * H * W + c for the field events, 3 * H * W + e * A + a for the agent events)
+    constexpr int kUniRows = (!EXACT && kPhilox) ? 5 * ((3 * CMAX + 5 * AMAX + 4) / 5) : 1;
+    __shared__ float x_uni[kUniRows][(!EXACT && kPhilox) ? kBlock : 1];
     constexpr int kDrawCopies = (RNG == FRZ_RNG_PHILOX && PERSIST) ? 2 : 1;
     __shared__ float x_draw[kDrawCopies][(kPhilox || kMt) ? 5 * AMAX : 1][kBlock];
     // FRZ_ROLLOUT_AUTO_RESET: returns of the episodes that ended inside this launch (float64, per env slot: deterministic) and their number
@@ -332,7 +338,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
     const int ch_nt = A + 1, ch_ntr = A + 2;
     const uint32_t flags_word = d.flags;
 
-    static_assert(!PERSIST || (EXACT && MODE == kStep), "the multi-step launch exists for the exact step kernels");
+    static_assert(!PERSIST || MODE == kStep, "the multi-step launch is a loop of steps");
     static_assert(!EXTRA || PERSIST, "the rollout options belong to the multi-step launch");
     static_assert(!(PERSIST && kInjected) || EXTRA, "randomness tapes are a rollout option");
     const int n_steps = PERSIST ? launch.n_steps : 1;
@@ -374,7 +380,8 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                 const mask_t ok = s_cfg.init_suppressant > 0.0f ? (lit_init & (mask_t)s_cfg.range_mask[a][s_cfg.init_equipment]) : (mask_t)0;
                 prev[1 + a] = Bu * (uint32_t)popc(ok);
             }
-            prev[AMAX + 1] = prev[AMAX + 2] = Bu;  // (exact shapes: A == AMAX) nobody is terminated, nobody truncated
+#pragma unroll
+            for (int i = 0; i < AMAX + 3; ++i) prev[i] = (i == ch_nt || i == ch_ntr) ? Bu : prev[i];  // nobody is terminated, nobody truncated
         }
     }
 
@@ -603,9 +610,10 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
             // e * HW + c, agent event e of agent a is draw 3 * HW + e * A + a.  The field role draws for both roles while the crew decodes
             // the actions; agent events 1..4 are only drawn when something reads them.
             auto philox_draws = [&](int moves, uint32_t flags, float (&field_out)[3][CMAX], float (&agent_out)[5 * AMAX]) {
-                constexpr int U = 3 * CMAX + 5 * AMAX, NB = (U + 4) / 5, NB_EVENT0 = (3 * CMAX + AMAX + 4) / 5;
+                constexpr int U = 3 * CMAX + 5 * AMAX, NB = (U + 4) / 5;
+                const int nb_all = EXACT ? NB : (3 * HW + 5 * A + 4) / 5, nb_event0 = EXACT ? (3 * CMAX + AMAX + 4) / 5 : (3 * HW + A + 4) / 5;
                 const bool need_late = (flags & (kStochRepair | kStochDegrade | kCritical | kStochRefill | kStochSwitch)) != 0 || s_cfg.K > 1;
-                const int nb_needed = need_late ? NB : NB_EVENT0;
+                const int nb_needed = need_late ? nb_all : nb_event0;
                 float uni[NB * 5];
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
@@ -619,12 +627,26 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                         uni[5 * j + 4] = frz::philox_unit24<4>(w);
                     }
                 }
+                if constexpr (EXACT) {
 #pragma unroll
-                for (int e = 0; e < 3; ++e)
+                    for (int e = 0; e < 3; ++e)
 #pragma unroll
-                    for (int c = 0; c < CMAX; ++c) field_out[e][c] = uni[e * CMAX + c];
+                        for (int c = 0; c < CMAX; ++c) field_out[e][c] = uni[e * CMAX + c];
 #pragma unroll
-                for (int i = 0; i < 5 * AMAX; ++i) agent_out[i] = uni[3 * CMAX + i];
+                    for (int i = 0; i < 5 * AMAX; ++i) agent_out[i] = uni[3 * CMAX + i];
+                } else {
+                    // the draw numbers depend on the runtime H * W and A: through this env's scratch column (no other thread touches it)
+#pragma unroll
+                    for (int u = 0; u < NB * 5; ++u) x_uni[u][slot] = uni[u];
+#pragma unroll
+                    for (int e = 0; e < 3; ++e)
+#pragma unroll
+                        for (int c = 0; c < CMAX; ++c) field_out[e][c] = c < HW ? x_uni[e * HW + c][slot] : 1.0f;
+#pragma unroll
+                    for (int e = 0; e < 5; ++e)
+#pragma unroll
+                        for (int a = 0; a < AMAX; ++a) agent_out[e * AMAX + a] = a < A ? x_uni[3 * HW + e * A + a][slot] : 1.0f;
+                }
             };
             // multi-step launches: the NEXT step's draws (a function of the env seed and the step number only), made while this role
             // waits for the crew's hand-off — between barriers 3 and 4 it has nothing else to do for about as long as the draws take
@@ -1641,6 +1663,16 @@ void launch_roles_variant(const WfArgs& a, const WfDev* dev, int grid, int rng, 
     auto go = [&](auto kernel) { launch_step_kernel(a, kernel, grid, kRoleBlock, stream, a.arena, dev, a.actions, a.field_rand, a.agent_rand, batch); };
     if (mode == kReset) return go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kReset>);
     if (mode == kRebuild) return go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kRebuild>);
+    if constexpr (!EXACT && AMAX <= 4) {  // (the <8, 8> variant's scratch columns would not fit the LDS: one launch per step there)
+        if (a.n_steps > 1) {  // runtime shapes: the multi-step launch draws in the kernel (Philox) or reads the tapes; MT19937 streams stay outside
+            const bool extra = !a.policy || a.tape_actions_step != 0 || a.list_record_delta != 0 || a.reward_tape || a.done_tape || a.actions_out_step != 0 ||
+                               (a.rollout_flags & FRZ_ROLLOUT_AUTO_RESET) != 0 || a.supp_tape || a.state_tape;
+            if (rng == FRZ_RNG_PHILOX)
+                return extra ? go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_PHILOX, kStep, true, true>) : go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_PHILOX, kStep, true, false>);
+            if (rng == FRZ_RNG_INJECTED) return go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kStep, true, true>);
+            return;  // (frz_wildfire_rollout_launches never sends MT19937 here)
+        }
+    }
     if constexpr (EXACT) {
         if (a.n_steps > 1) {  // one launch for the whole rollout (the caller has checked residency and the second list copy)
             // the plain rollout (policy in-kernel, opening reset, metrics) or the one with every option of a frz_rollout_spec
@@ -1687,8 +1719,9 @@ int FRZ_WF_CONCAT(launch_roles_group_, FRZ_WF_ROLES_GROUP)(const WfArgs& args, i
 // resident workgroups per CU: the MINIMUM over every multi-step instantiation frz_wildfire_rollout can launch for the shape (three RNG
 // modes, with and without the EXTRA options — the EXTRA kernels use 7-9 KB more LDS and some spill: ADVICE r3), so that the residency
 // guard of frz_wildfire_set_exclusive_device holds for whichever of them a spec picks
-template <int C, int A>
+template <int C, int A, bool E>
 int persist_occupancy_min() {
+    if constexpr (!E && A > 4) return 0;  // (no multi-step instantiation: see launch_roles_variant)
     int least = 1 << 30;
     auto probe = [&least](auto kernel) {
         int blocks = 0;
@@ -1698,11 +1731,15 @@ int persist_occupancy_min() {
         }
         if (blocks < least) least = blocks;
     };
-    probe(wf_roles_kernel<C, A, true, FRZ_RNG_PHILOX, kStep, true, false>);
-    probe(wf_roles_kernel<C, A, true, FRZ_RNG_PHILOX, kStep, true, true>);
-    probe(wf_roles_kernel<C, A, true, FRZ_RNG_MT19937, kStep, true, false>);
-    probe(wf_roles_kernel<C, A, true, FRZ_RNG_MT19937, kStep, true, true>);
-    probe(wf_roles_kernel<C, A, true, FRZ_RNG_INJECTED, kStep, true, true>);
+    if constexpr (E || A <= 4) {
+        probe(wf_roles_kernel<C, A, E, FRZ_RNG_PHILOX, kStep, true, false>);
+        probe(wf_roles_kernel<C, A, E, FRZ_RNG_PHILOX, kStep, true, true>);
+        if constexpr (E) {
+            probe(wf_roles_kernel<C, A, E, FRZ_RNG_MT19937, kStep, true, false>);
+            probe(wf_roles_kernel<C, A, E, FRZ_RNG_MT19937, kStep, true, true>);
+        }
+        probe(wf_roles_kernel<C, A, E, FRZ_RNG_INJECTED, kStep, true, true>);
+    }
     return least;
 }
 
@@ -1712,8 +1749,8 @@ int FRZ_WF_CONCAT(roles_persist_occupancy_group_, FRZ_WF_ROLES_GROUP)(int varian
     switch (variant) {
 #define FRZ_X(i, c, a, e)                                                                                                                  \
     case i:                                                                                                                                \
-        if constexpr ((i) % FRZ_WF_ROLES_GROUPS == FRZ_WF_ROLES_GROUP && e && c <= 16 && a * (c <= 8 ? 8 : 16) <= 64) {                      \
-            blocks = persist_occupancy_min<c, a>();                                                                                         \
+        if constexpr ((i) % FRZ_WF_ROLES_GROUPS == FRZ_WF_ROLES_GROUP && c <= 16 && a * (c <= 8 ? 8 : 16) <= 64) {                           \
+            blocks = persist_occupancy_min<c, a, e>();                                                                                      \
         }                                                                                                                                  \
         break;
         FRZ_WF_VARIANT_LIST(FRZ_X)

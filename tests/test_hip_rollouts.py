@@ -76,10 +76,14 @@ ORACLE_CASES = [
     dict(build=configs.wildfire_openness, B=1000, max_steps=50, steps=50, kwargs={}),                                    # ragged last chunk
     dict(build=configs.wildfire_openness, B=3001, max_steps=30, steps=34, kwargs=dict(show_bad_actions=True, observe_other_suppressant=True)),
     dict(build=lambda: configs.wildfire_grid(3, 3, 4, seed=5), B=2049, max_steps=25, steps=20, kwargs={}),               # 16-bit cell masks
+    # runtime shapes (no exact instantiation: <8, 4> and <16, 4> with H * W and A read from the configuration): in-kernel Philox through the
+    # per-env scratch column (round 4)
+    dict(build=lambda: configs.wildfire_grid(1, 7, 3, seed=2), B=1500, max_steps=30, steps=24, kwargs={}),
+    dict(build=lambda: configs.wildfire_grid(3, 5, 2, seed=4), B=700, max_steps=12, steps=16, kwargs=dict(show_bad_actions=True, observe_other_power=True)),
 ]
 
 
-@pytest.mark.parametrize('case', ORACLE_CASES, ids=['cfg2_B65536', 'cfg2_ragged', 'bad_actions_past_the_horizon', '3x3a4'])
+@pytest.mark.parametrize('case', ORACLE_CASES, ids=['cfg2_B65536', 'cfg2_ragged', 'bad_actions_past_the_horizon', '3x3a4', 'runtime_1x7a3', 'runtime_3x5a2_past_the_horizon'])
 def test_multi_step_launch_against_the_oracle(oracle, case):
     """rollout(n) as ONE launch (frz_wildfire_rollout_launches == 1) vs n oracle steps: the sampled actions, rewards, terminations /
     truncations and every packed list OF EVERY STEP (tapes + list record), then the whole final state."""
