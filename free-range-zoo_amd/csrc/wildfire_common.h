@@ -159,7 +159,7 @@ inline uint32_t experiment_skip() {
 #endif
 }
 #ifdef FRZ_WF_EXPERIMENT
-#define FRZ_SKIP(bit) ((launch.skip >> (bit)) & 1u)
+#define FRZ_SKIP(bit) (EXACT && ((launch.skip >> (bit)) & 1u))  // (the exact-shape kernels only: the bench shape is what the experiments are about)
 #define FRZ_WF_LOCAL_PROOF (!FRZ_SKIP(5))  // (A/B: every workgroup waits for the batch totals between the steps of a launch, as rounds 2-3 did)
 #else
 #define FRZ_SKIP(bit) false

@@ -33,14 +33,14 @@ constexpr int kRound = 256;             // look-back window: a chunk sums at mos
 #define FRZ_RSTAMP(i)                                                                                                       \
     do {                                                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                                  \
-        if (blockIdx.x == ((launch.skip >> 16) & 0xFFFu) && slot == 0 && MODE == kStep && frz_stamp_step)                  \
+        if (EXACT && blockIdx.x == ((launch.skip >> 16) & 0xFFFu) && slot == 0 && MODE == kStep && frz_stamp_step)         \
             reinterpret_cast<unsigned long long*>(arena + dev->off_rand_agent)[(crew ? 16 : 0) + (i)] = __builtin_amdgcn_s_memtime(); \
         __builtin_amdgcn_sched_barrier(0);                                                                                  \
     } while (0)
 // per-workgroup wall clock (100 MHz): [2 * blockIdx.x] = first instruction, [2 * blockIdx.x + 1] = last, both roles' minimum/maximum
 #define FRZ_RWALL(which)                                                                                                     \
     do {                                                                                                                     \
-        if (slot == 0 && MODE == kStep)                                                                                      \
+        if (EXACT && slot == 0 && MODE == kStep)                                                                             \
             reinterpret_cast<unsigned long long*>(arena + dev->off_rand_field)[4 * blockIdx.x + 2 * (crew ? 1 : 0) + (which)] = \
                 __builtin_amdgcn_s_memrealtime();                                                                            \
     } while (0)
