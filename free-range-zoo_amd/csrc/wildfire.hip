@@ -831,13 +831,24 @@ __global__ void __launch_bounds__(kBlock) wf_step_kernel(char* __restrict__ aren
                         bad_offsets[a * (B + 1) + b] = off_f - off_a;
                         if (b == B - 1) bad_offsets[a * (B + 1) + B] = (off_f - off_a) + (F - fa);
                     }
-#pragma unroll
-                    for (int c = 0; c < CMAX; ++c) {
-                        const mask_t below = (mask_t)(((mask_t)1 << c) - 1);
-                        if ((ok1[a] >> c) & 1)
-                            av[popc(ok1[a] & below)] = rk[c];
-                        else if (show_bad && ((lit1 >> c) & 1))
-                            bv[popc(lit1 & ~ok1[a] & below)] = rk[c];
+                    // entry by entry (as in wildfire_roles.inl, round 4): the j-th store writes every env's j-th entry — the row number of the
+                    // j-th member cell — and the wavefront stops at the longest list among its envs, instead of one predicated store per
+                    // cell whatever the lists hold (24 cells x 8 agents here)
+                    {
+                        mask_t m = ok1[a];
+                        for (int j = 0; j < CMAX; ++j) {
+                            if (!__any(m != 0)) break;
+                            if (m != 0) av[j] = popc(lit1 & (mask_t)((m & (mask_t)(0 - m)) - 1));
+                            m &= (mask_t)(m - 1);
+                        }
+                        if (show_bad) {
+                            m = lit1 & ~ok1[a];
+                            for (int j = 0; j < CMAX; ++j) {
+                                if (!__any(m != 0)) break;
+                                if (m != 0) bv[j] = popc(lit1 & (mask_t)((m & (mask_t)(0 - m)) - 1));
+                                m &= (mask_t)(m - 1);
+                            }
+                        }
                     }
                 }
         }
