@@ -1711,8 +1711,9 @@ int frz_wildfire_step(frz_wildfire_env* env, const int32_t* actions, int rng_mod
         if (!field_randomness || !agent_randomness) return FRZ_E_INVALID;
         args.field_rand = field_randomness;
         args.agent_rand = agent_randomness;
-    } else if (rng_mode == FRZ_RNG_MT19937 && env->dev.roles && !env->dev.grid && kVariants[env->variant].exact) {
-        // the field/crew kernel advances the per-env MT19937 streams itself (wildfire_roles.hip)
+    } else if (rng_mode == FRZ_RNG_MT19937 && env->dev.roles && !env->dev.grid &&
+               (kVariants[env->variant].exact || (env->rollout_steps > 1 && env->list_copy_delta != 0))) {
+        // the field/crew kernel advances the per-env MT19937 streams itself (wildfire_roles.hip; runtime shapes: in their multi-step launch only)
     } else if (rng_mode == FRZ_RNG_MT19937) {
         // per-env MT19937 streams: field draws first, then agent draws (wildfire.py:409-410), staged in the arena
         const int64_t B = c.parallel_envs;
@@ -1829,8 +1830,7 @@ int frz_wildfire_import_totals(frz_wildfire_env* env, const int32_t* staging, vo
 int frz_wildfire_rollout_launches(const frz_wildfire_env* env, int32_t n_steps, int rng_mode) {
     if (!env || n_steps < 0) return FRZ_E_INVALID;
     const bool one = n_steps > 1 && env->exclusive_device && env->list_copy_delta != 0 && !env->ticketed &&
-                     (rng_mode == FRZ_RNG_PHILOX || rng_mode == FRZ_RNG_INJECTED || (rng_mode == FRZ_RNG_MT19937 && kVariants[env->variant].exact)) &&
-                     env->dev.roles && !env->dev.grid;  // (runtime shapes keep their MT19937 streams outside the step kernel: one launch per step)
+                     (rng_mode == FRZ_RNG_PHILOX || rng_mode == FRZ_RNG_INJECTED || rng_mode == FRZ_RNG_MT19937) && env->dev.roles && !env->dev.grid;
     return one ? 1 : n_steps;
 }
 

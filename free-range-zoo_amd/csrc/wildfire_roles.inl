@@ -91,8 +91,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
     auto crew_writes = [](int a) constexpr { return kFieldWritesAllLists ? a < FRZ_WF_CREW_LISTS : (a & 1) == 0; };
     // runtime shapes: a single step reads staged draws (wf_philox_fill_kernel / frz_mt19937_generate); a MULTI-step launch draws in the kernel
     // like the exact shapes do, its draw indices (which depend on H * W and A) resolved through an LDS scratch column per env (x_uni)
-    static_assert(EXACT || !kMt, "runtime shapes keep their MT19937 streams outside the step kernel (frz_mt19937_generate)");
-    static_assert(EXACT || !kPhilox || PERSIST, "runtime shapes stage the draws of a single step (wf_philox_fill_kernel)");
+    static_assert(EXACT || !(kPhilox || kMt) || PERSIST, "runtime shapes stage the draws of a single step (wf_philox_fill_kernel / frz_mt19937_generate)");
 
     __shared__ uint64_t s_wave_scan[frz::kWaves][PW];
     __shared__ uint32_t s_wave_live[frz::kWaves][2];
@@ -109,8 +108,8 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
     // draws in copy (t + 1) & 1 as soon as it has made them, instead of holding 5 * AMAX registers across its list phase and the loop's
     // back edge (they were spilled)
     // runtime shapes, in-kernel Philox: draw u of the env (u = e * H * W + c for the field events, 3 * H * W + e * A + a for the agent events)
-    constexpr int kUniRows = (!EXACT && kPhilox) ? 5 * ((3 * CMAX + 5 * AMAX + 4) / 5) : 1;
-    __shared__ float x_uni[kUniRows][(!EXACT && kPhilox) ? kBlock : 1];
+    constexpr int kUniRows = (!EXACT && (kPhilox || kMt)) ? 5 * ((3 * CMAX + 5 * AMAX + 4) / 5) : 1;
+    __shared__ float x_uni[kUniRows][(!EXACT && (kPhilox || kMt)) ? kBlock : 1];
     constexpr int kDrawCopies = (RNG == FRZ_RNG_PHILOX && PERSIST) ? 2 : 1;
     __shared__ float x_draw[kDrawCopies][(kPhilox || kMt) ? 5 * AMAX : 1][kBlock];
     // FRZ_ROLLOUT_AUTO_RESET: returns of the episodes that ended inside this launch (float64, per env slot: deterministic) and their number
@@ -783,12 +782,25 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                             uni[k] = (float)(v & 0xFFFFFFu) * (1.0f / 16777216.0f);
                         }
                         mt_first = i0;
+                        if constexpr (EXACT) {
 #pragma unroll
-                        for (int e = 0; e < 3; ++e)
+                            for (int e = 0; e < 3; ++e)
 #pragma unroll
-                            for (int c = 0; c < CMAX; ++c) r_field[e][c] = uni[e * CMAX + c];
+                                for (int c = 0; c < CMAX; ++c) r_field[e][c] = uni[e * CMAX + c];
 #pragma unroll
-                        for (int i = 0; i < 5 * AMAX; ++i) x_draw[0][i][slot] = uni[3 * CMAX + i];
+                            for (int i = 0; i < 5 * AMAX; ++i) x_draw[0][i][slot] = uni[3 * CMAX + i];
+                        } else {  // runtime H * W and A: the step uses the first 3 H W + 5 A words, picked up through this env's scratch column
+#pragma unroll
+                            for (int u = 0; u < U; ++u) x_uni[u][slot] = uni[u];
+#pragma unroll
+                            for (int e = 0; e < 3; ++e)
+#pragma unroll
+                                for (int c = 0; c < CMAX; ++c) r_field[e][c] = c < HW ? x_uni[e * HW + c][slot] : 1.0f;
+#pragma unroll
+                            for (int e = 0; e < 5; ++e)
+#pragma unroll
+                                for (int a = 0; a < AMAX; ++a) x_draw[0][e * AMAX + a][slot] = a < A ? x_uni[3 * HW + e * A + a][slot] : 1.0f;
+                        }
                     }
                 }
                 if (MODE == kStep) {
@@ -820,14 +832,15 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                 }
                 if constexpr (kMt) {  // the stream moves on: twisted words in place, new position
                     constexpr int U = 3 * CMAX + 5 * AMAX, kN = 624;
+                    const int used = EXACT ? U : 3 * HW + 5 * A;  // words the step consumed (runtime shapes: fewer than the unrolled U)
                     uint32_t* const mt = reinterpret_cast<uint32_t*>(arena + launch.off_mt_state);
 #pragma unroll
                     for (int k = 0; k < U; ++k) {
                         int j = mt_first + k;
                         j -= j >= kN ? kN : 0;
-                        mt[(int64_t)j * B + bl] = mt_twisted[k];
+                        if (EXACT || k < used) mt[(int64_t)j * B + bl] = mt_twisted[k];
                     }
-                    int j = mt_first + U;
+                    int j = mt_first + used;
                     j -= j >= kN ? kN : 0;
                     at32(rows, (uint32_t)(r_seeds + 1) * Bu + bl) = j;
                     if constexpr (PERSIST) fld.mti = j;
@@ -1664,13 +1677,14 @@ void launch_roles_variant(const WfArgs& a, const WfDev* dev, int grid, int rng, 
     if (mode == kReset) return go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kReset>);
     if (mode == kRebuild) return go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kRebuild>);
     if constexpr (!EXACT && AMAX <= 4) {  // (the <8, 8> variant's scratch columns would not fit the LDS: one launch per step there)
-        if (a.n_steps > 1) {  // runtime shapes: the multi-step launch draws in the kernel (Philox) or reads the tapes; MT19937 streams stay outside
+        if (a.n_steps > 1) {  // runtime shapes: the multi-step launch draws in the kernel (Philox, or the env's MT19937 stream) or reads the tapes
             const bool extra = !a.policy || a.tape_actions_step != 0 || a.list_record_delta != 0 || a.reward_tape || a.done_tape || a.actions_out_step != 0 ||
                                (a.rollout_flags & FRZ_ROLLOUT_AUTO_RESET) != 0 || a.supp_tape || a.state_tape;
             if (rng == FRZ_RNG_PHILOX)
                 return extra ? go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_PHILOX, kStep, true, true>) : go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_PHILOX, kStep, true, false>);
-            if (rng == FRZ_RNG_INJECTED) return go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kStep, true, true>);
-            return;  // (frz_wildfire_rollout_launches never sends MT19937 here)
+            if (rng == FRZ_RNG_MT19937)
+                return extra ? go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_MT19937, kStep, true, true>) : go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_MT19937, kStep, true, false>);
+            return go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kStep, true, true>);
         }
     }
     if constexpr (EXACT) {
@@ -1734,10 +1748,8 @@ int persist_occupancy_min() {
     if constexpr (E || A <= 4) {
         probe(wf_roles_kernel<C, A, E, FRZ_RNG_PHILOX, kStep, true, false>);
         probe(wf_roles_kernel<C, A, E, FRZ_RNG_PHILOX, kStep, true, true>);
-        if constexpr (E) {
-            probe(wf_roles_kernel<C, A, E, FRZ_RNG_MT19937, kStep, true, false>);
-            probe(wf_roles_kernel<C, A, E, FRZ_RNG_MT19937, kStep, true, true>);
-        }
+        probe(wf_roles_kernel<C, A, E, FRZ_RNG_MT19937, kStep, true, false>);
+        probe(wf_roles_kernel<C, A, E, FRZ_RNG_MT19937, kStep, true, true>);
         probe(wf_roles_kernel<C, A, E, FRZ_RNG_INJECTED, kStep, true, true>);
     }
     return least;

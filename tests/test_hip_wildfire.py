@@ -740,6 +740,34 @@ EXACT_SHAPES = [(2, 3, 3), (2, 3, 2), (3, 3, 3), (3, 3, 4), (2, 4, 3), (2, 4, 4)
                 (2, 4, 2), (3, 3, 2), (3, 4, 2), (4, 4, 2), (2, 3, 4)]
 
 
+RUNTIME_SHAPES = [(1, 7, 3), (3, 5, 2), (2, 5, 4), (1, 5, 1), (2, 7, 4), (1, 3, 2)]
+
+
+@pytest.mark.parametrize('shape', RUNTIME_SHAPES, ids=lambda s: 'x'.join(map(str, s)))
+def test_multi_step_launch_of_runtime_shapes(shape):
+    """Grids without an exact instantiation run the runtime-shape field/crew variants (<8, 4>, <16, 4>: H * W and A read from the
+    configuration); since round 4 those have a multi-step kernel too — in-kernel Philox and in-kernel MT19937 streams with the draw numbers
+    resolved at run time.  Each against single-step launches (which read STAGED draws: wf_philox_fill_kernel / frz_mt19937_generate), fully
+    stochastic configuration, ragged batch, both RNG modes."""
+    H, Wd, A = shape
+    B = 777
+    for rng, mode in (('philox', _capi.FRZ_RNG_PHILOX), ('mt19937', _capi.FRZ_RNG_MT19937)):
+        build = lambda: configs.wildfire_grid(H, Wd, A, seed=H * 5 + Wd * 3 + A)  # noqa: E731
+        one, many = [make_env(build, B, 30, rng=rng, exact_shapes=False) for _ in range(2)]
+        many.set_exclusive_device(True)
+        assert many._lib.frz_wildfire_rollout_launches(many._handle, 7, mode) == 1, f'{shape} has no multi-step launch'
+        for env in (one, many):
+            env.reset(seed=torch.arange(B, dtype=torch.int32) + 2)
+        for t in range(7):
+            one.step_random_policy(policy_seed=9, policy_step=t)
+        many.rollout_random_policy(7, policy_seed=9, first_step=0)
+        assert_same_env(one, many, f'{shape} {rng}')
+        if rng == 'mt19937':
+            assert torch.equal(one.generator.generator_index, many.generator.generator_index), 'stream positions'
+            assert torch.equal(one.generator.generator_states, many.generator.generator_states), 'stream states'
+        many.check()
+
+
 @pytest.mark.parametrize('shape', EXACT_SHAPES, ids=lambda s: 'x'.join(map(str, s)))
 def test_multi_step_launch_of_every_exact_shape(shape):
     """Every shape with an exact field/crew instantiation (FRZ_WF_VARIANT_LIST) has a multi-step kernel: each against single-step launches,
