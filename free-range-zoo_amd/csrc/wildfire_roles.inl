@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
     // which role writes agent a's action lists
     auto crew_writes = [](int a) constexpr { return kFieldWritesAllLists ? a < FRZ_WF_CREW_LISTS : (a & 1) == 0; };
     // runtime shapes: a single step reads staged draws (wf_philox_fill_kernel / frz_mt19937_generate); a MULTI-step launch draws in the kernel
-    // like the exact shapes do, its draw indices (which depend on H * W and A) resolved through an LDS scratch column per env (x_uni)
+    // like the exact shapes do, its draw indices (which depend on H * W and A) resolved by scattering them to their places in LDS (x_fd, x_draw)
     static_assert(EXACT || !(kPhilox || kMt) || PERSIST, "runtime shapes stage the draws of a single step (wf_philox_fill_kernel / frz_mt19937_generate)");
 
     __shared__ uint64_t s_wave_scan[frz::kWaves][PW];
@@ -108,8 +108,13 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
     // draws in copy (t + 1) & 1 as soon as it has made them, instead of holding 5 * AMAX registers across its list phase and the loop's
     // back edge (they were spilled)
     // runtime shapes, in-kernel Philox: draw u of the env (u = e * H * W + c for the field events, 3 * H * W + e * A + a for the agent events)
-    constexpr int kUniRows = (!EXACT && (kPhilox || kMt)) ? 5 * ((3 * CMAX + 5 * AMAX + 4) / 5) : 1;
-    __shared__ float x_uni[kUniRows][(!EXACT && (kPhilox || kMt)) ? kBlock : 1];
+    // Two ways, by LDS budget: a scratch column per env that holds every draw of the step, read back at the runtime positions (x_uni: the
+    // faster one — 1 x 7 / 3 agents 10.1 against 12.8 us per step — but 65 KB at <8, 8>, which would take that kernel past the 160 KB of
+    // LDS), or every draw stored to ITS place (x_fd[e * CMAX + c] for the field draws, the crew's x_draw rows for the agent draws)
+    constexpr bool kRuntimeDraws = !EXACT && (kPhilox || kMt);
+    constexpr bool kGatherDraws = kRuntimeDraws && AMAX <= 4, kScatterDraws = kRuntimeDraws && AMAX > 4;
+    __shared__ float x_uni[kGatherDraws ? 5 * ((3 * CMAX + 5 * AMAX + 4) / 5) : 1][kGatherDraws ? kBlock : 1];
+    __shared__ float x_fd[kScatterDraws ? 3 * CMAX : 1][kScatterDraws ? kBlock : 1];
     constexpr int kDrawCopies = (RNG == FRZ_RNG_PHILOX && PERSIST) ? 2 : 1;
     __shared__ float x_draw[kDrawCopies][(kPhilox || kMt) ? 5 * AMAX : 1][kBlock];
     // FRZ_ROLLOUT_AUTO_RESET: returns of the episodes that ended inside this launch (float64, per env slot: deterministic) and their number
@@ -608,7 +613,49 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
             // FRZ_RNG_PHILOX (include/frz.h): draw u = 24-bit field u % 5 of block (u / 5, step, 0, 0); field event e of cell c is draw
             // e * HW + c, agent event e of agent a is draw 3 * HW + e * A + a.  The field role draws for both roles while the crew decodes
             // the actions; agent events 1..4 are only drawn when something reads them.
-            auto philox_draws = [&](int moves, uint32_t flags, float (&field_out)[3][CMAX], float (&agent_out)[5 * AMAX]) {
+            // Runtime shapes: draw u (a compile-time position of `uni`) is field event u / HW of cell u % HW for u < 3 HW, agent event
+            // (u - 3 HW) / A of agent (u - 3 HW) % A behind that — places known at run time only.  Each draw is stored to ITS place in LDS
+            // (the field draws in x_fd, the agent draws in copy `copy` of x_draw, where the crew reads them anyway), the event / cell / agent
+            // counters running along in scalar registers; the field draws are then read back at compile-time rows.  Only this thread
+            // touches its column: no barrier.
+            auto scatter_draws = [&](const auto& uni, int copy, float (&field_out)[3][CMAX]) {
+                constexpr int N = (int)(sizeof(uni) / sizeof(float));
+                if constexpr (kGatherDraws) {  // through this env's scratch column (only this thread touches it: no barrier)
+#pragma unroll
+                    for (int u = 0; u < N; ++u) x_uni[u][slot] = uni[u];
+#pragma unroll
+                    for (int ev = 0; ev < 3; ++ev)
+#pragma unroll
+                        for (int cc = 0; cc < CMAX; ++cc) field_out[ev][cc] = cc < HW ? x_uni[ev * HW + cc][slot] : 1.0f;
+#pragma unroll
+                    for (int ev = 0; ev < 5; ++ev)
+#pragma unroll
+                        for (int a = 0; a < AMAX; ++a) x_draw[copy][ev * AMAX + a][slot] = a < A ? x_uni[3 * HW + ev * A + a][slot] : 1.0f;
+                    return;
+                }
+                int e = 0, c = 0, ea = 0, aa = 0;
+#pragma unroll
+                for (int u = 0; u < N; ++u) {
+                    if (u < 3 * HW) {
+                        x_fd[e * CMAX + c][slot] = uni[u];
+                        if (++c == HW) c = 0, ++e;
+                    } else if (u < 3 * HW + 5 * A) {
+                        x_draw[copy][ea * AMAX + aa][slot] = uni[u];
+                        if (++aa == A) aa = 0, ++ea;
+                    }
+                }
+#pragma unroll
+                for (int ev = 0; ev < 5; ++ev)
+#pragma unroll
+                    for (int a = 0; a < AMAX; ++a)
+                        if (a >= A) x_draw[copy][ev * AMAX + a][slot] = 1.0f;  // (agents the env does not have: what the staged path leaves there)
+#pragma unroll
+                for (int ev = 0; ev < 3; ++ev)
+#pragma unroll
+                    for (int cc = 0; cc < CMAX; ++cc) field_out[ev][cc] = cc < HW ? x_fd[ev * CMAX + cc][slot] : 1.0f;
+            };
+            // (runtime shapes: the agent draws are left in copy `copy` of x_draw, `agent_out` stays untouched)
+            auto philox_draws = [&](int moves, uint32_t flags, float (&field_out)[3][CMAX], float (&agent_out)[5 * AMAX], int copy) {
                 constexpr int U = 3 * CMAX + 5 * AMAX, NB = (U + 4) / 5;
                 const int nb_all = EXACT ? NB : (3 * HW + 5 * A + 4) / 5, nb_event0 = EXACT ? (3 * CMAX + AMAX + 4) / 5 : (3 * HW + A + 4) / 5;
                 const bool need_late = (flags & (kStochRepair | kStochDegrade | kCritical | kStochRefill | kStochSwitch)) != 0 || s_cfg.K > 1;
@@ -634,17 +681,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
 #pragma unroll
                     for (int i = 0; i < 5 * AMAX; ++i) agent_out[i] = uni[3 * CMAX + i];
                 } else {
-                    // the draw numbers depend on the runtime H * W and A: through this env's scratch column (no other thread touches it)
-#pragma unroll
-                    for (int u = 0; u < NB * 5; ++u) x_uni[u][slot] = uni[u];
-#pragma unroll
-                    for (int e = 0; e < 3; ++e)
-#pragma unroll
-                        for (int c = 0; c < CMAX; ++c) field_out[e][c] = c < HW ? x_uni[e * HW + c][slot] : 1.0f;
-#pragma unroll
-                    for (int e = 0; e < 5; ++e)
-#pragma unroll
-                        for (int a = 0; a < AMAX; ++a) agent_out[e * AMAX + a] = a < A ? x_uni[3 * HW + e * A + a][slot] : 1.0f;
+                    if constexpr (kRuntimeDraws) scatter_draws(uni, copy, field_out);
                 }
             };
             // multi-step launches: the NEXT step's draws (a function of the env seed and the step number only), made while this role
@@ -742,9 +779,11 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                                 for (int c = 0; c < CMAX; ++c) r_field[e][c] = next_field[e][c];
                         } else {
                             float agent_draws[5 * AMAX];
-                            philox_draws(fld.nm, flags, r_field, agent_draws);
+                            philox_draws(fld.nm, flags, r_field, agent_draws, 0);
+                            if constexpr (EXACT) {
 #pragma unroll
-                            for (int i = 0; i < 5 * AMAX; ++i) x_draw[0][i][slot] = agent_draws[i];  // (t == 0: copy 0)
+                                for (int i = 0; i < 5 * AMAX; ++i) x_draw[0][i][slot] = agent_draws[i];  // (t == 0: copy 0)
+                            }
                         }
                     } else if constexpr (kMt) {
                         // FRZ_RNG_MT19937: the env's own MT19937 stream (mt19937.hip: state word j of env b at [j][b], twisted
@@ -789,17 +828,8 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                                 for (int c = 0; c < CMAX; ++c) r_field[e][c] = uni[e * CMAX + c];
 #pragma unroll
                             for (int i = 0; i < 5 * AMAX; ++i) x_draw[0][i][slot] = uni[3 * CMAX + i];
-                        } else {  // runtime H * W and A: the step uses the first 3 H W + 5 A words, picked up through this env's scratch column
-#pragma unroll
-                            for (int u = 0; u < U; ++u) x_uni[u][slot] = uni[u];
-#pragma unroll
-                            for (int e = 0; e < 3; ++e)
-#pragma unroll
-                                for (int c = 0; c < CMAX; ++c) r_field[e][c] = c < HW ? x_uni[e * HW + c][slot] : 1.0f;
-#pragma unroll
-                            for (int e = 0; e < 5; ++e)
-#pragma unroll
-                                for (int a = 0; a < AMAX; ++a) x_draw[0][e * AMAX + a][slot] = a < A ? x_uni[3 * HW + e * A + a][slot] : 1.0f;
+                        } else {  // runtime H * W and A: the step uses the first 3 H W + 5 A words, each stored to its place (scatter_draws)
+                            if constexpr (kRuntimeDraws) scatter_draws(uni, 0, r_field);
                         }
                     }
                 }
@@ -1017,9 +1047,11 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                 if constexpr (kPhilox && PERSIST) {
                     if (t + 1 < n_steps) {
                         float next_agent[5 * AMAX];
-                        philox_draws(fld.nm + 1, flags, next_field, next_agent);
+                        philox_draws(fld.nm + 1, flags, next_field, next_agent, (t + 1) & (kDrawCopies - 1));
+                        if constexpr (EXACT) {
 #pragma unroll
-                        for (int i = 0; i < 5 * AMAX; ++i) x_draw[(t + 1) & (kDrawCopies - 1)][i][slot] = next_agent[i];
+                            for (int i = 0; i < 5 * AMAX; ++i) x_draw[(t + 1) & (kDrawCopies - 1)][i][slot] = next_agent[i];
+                        }
                     }
                 }
                 FRZ_RSTAMP(8);
@@ -1676,7 +1708,7 @@ void launch_roles_variant(const WfArgs& a, const WfDev* dev, int grid, int rng, 
     auto go = [&](auto kernel) { launch_step_kernel(a, kernel, grid, kRoleBlock, stream, a.arena, dev, a.actions, a.field_rand, a.agent_rand, batch); };
     if (mode == kReset) return go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kReset>);
     if (mode == kRebuild) return go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kRebuild>);
-    if constexpr (!EXACT && AMAX <= 4) {  // (the <8, 8> variant's scratch columns would not fit the LDS: one launch per step there)
+    if constexpr (!EXACT) {
         if (a.n_steps > 1) {  // runtime shapes: the multi-step launch draws in the kernel (Philox, or the env's MT19937 stream) or reads the tapes
             const bool extra = !a.policy || a.tape_actions_step != 0 || a.list_record_delta != 0 || a.reward_tape || a.done_tape || a.actions_out_step != 0 ||
                                (a.rollout_flags & FRZ_ROLLOUT_AUTO_RESET) != 0 || a.supp_tape || a.state_tape;
@@ -1735,7 +1767,6 @@ int FRZ_WF_CONCAT(launch_roles_group_, FRZ_WF_ROLES_GROUP)(const WfArgs& args, i
 // guard of frz_wildfire_set_exclusive_device holds for whichever of them a spec picks
 template <int C, int A, bool E>
 int persist_occupancy_min() {
-    if constexpr (!E && A > 4) return 0;  // (no multi-step instantiation: see launch_roles_variant)
     int least = 1 << 30;
     auto probe = [&least](auto kernel) {
         int blocks = 0;
@@ -1745,7 +1776,7 @@ int persist_occupancy_min() {
         }
         if (blocks < least) least = blocks;
     };
-    if constexpr (E || A <= 4) {
+    {
         probe(wf_roles_kernel<C, A, E, FRZ_RNG_PHILOX, kStep, true, false>);
         probe(wf_roles_kernel<C, A, E, FRZ_RNG_PHILOX, kStep, true, true>);
         probe(wf_roles_kernel<C, A, E, FRZ_RNG_MT19937, kStep, true, false>);
