@@ -1421,20 +1421,30 @@ void launch_variant(frz_cybersecurity_env* env, const int32_t* actions, const fl
                      env->rollout.flags, 0u, env->rollout.tape_actions_step, env->rollout.list_record_delta, env->rollout.list_record_step,
                      env->rollout.reward_tape, env->rollout.done_tape, env->rollout.actions_out_step,
                      env->rollout.obs_tape_delta, env->rollout.obs_tape_step, env->rollout.state_tape, env->rollout.state_tape_step};
-    if constexpr (NMAX <= 8) {
+    if constexpr (AMAX <= 8) {  // (the state / view kernel stages the danger table of 2^A entries in LDS: up to 8 agents; up to 16 nodes since round 4)
         if (mode == kStep && env->roles) {  // state / view roles: two wavefronts per 64 envs (cy_roles_kernel)
             const dim3 wide(kRoleBlock);
-            if (rng == FRZ_RNG_INJECTED && env->rollout_steps > 1)
-                hipLaunchKernelGGL((cy_roles_kernel<NMAX, AMAX, ATT, FRZ_RNG_INJECTED, true, true>), grid, wide, 0, stream, env->arena, dev, actions, nr, ar, L);
-            else if (rng == FRZ_RNG_PHILOX && env->rollout_steps > 1 && env->rollout.extra)
-                hipLaunchKernelGGL((cy_roles_kernel<NMAX, AMAX, ATT, FRZ_RNG_PHILOX, true, true>), grid, wide, 0, stream, env->arena, dev, actions, nr, ar, L);
-            else if (rng == FRZ_RNG_PHILOX && env->rollout_steps > 1)
-                hipLaunchKernelGGL((cy_roles_kernel<NMAX, AMAX, ATT, FRZ_RNG_PHILOX, true>), grid, wide, 0, stream, env->arena, dev, actions, nr, ar, L);
-            else if (rng == FRZ_RNG_PHILOX)
+            // (the multi-step instantiations exist up to 8 nodes: at <16, 8> they need 256 VGPRs plus ~1 KB of scratch per lane and run SLOWER
+            // than one launch per step — 42 against 31 us per step at 12 nodes, 89 against 47 at 16: round 4, tools/dbg/cy_nodes_probe.py)
+            bool launched = false;
+            if constexpr (NMAX <= 8) {
+                launched = true;
+                if (rng == FRZ_RNG_INJECTED && env->rollout_steps > 1)
+                    hipLaunchKernelGGL((cy_roles_kernel<NMAX, AMAX, ATT, FRZ_RNG_INJECTED, true, true>), grid, wide, 0, stream, env->arena, dev, actions, nr, ar, L);
+                else if (rng == FRZ_RNG_PHILOX && env->rollout_steps > 1 && env->rollout.extra)
+                    hipLaunchKernelGGL((cy_roles_kernel<NMAX, AMAX, ATT, FRZ_RNG_PHILOX, true, true>), grid, wide, 0, stream, env->arena, dev, actions, nr, ar, L);
+                else if (rng == FRZ_RNG_PHILOX && env->rollout_steps > 1)
+                    hipLaunchKernelGGL((cy_roles_kernel<NMAX, AMAX, ATT, FRZ_RNG_PHILOX, true>), grid, wide, 0, stream, env->arena, dev, actions, nr, ar, L);
+                else
+                    launched = false;
+            }
+            if (launched) return;
+            if (rng == FRZ_RNG_PHILOX)
                 hipLaunchKernelGGL((cy_roles_kernel<NMAX, AMAX, ATT, FRZ_RNG_PHILOX>), grid, wide, 0, stream, env->arena, dev, actions, nr, ar, L);
-            else if (rng == FRZ_RNG_MT19937)
-                hipLaunchKernelGGL((cy_roles_kernel<NMAX, AMAX, ATT, FRZ_RNG_MT19937>), grid, wide, 0, stream, env->arena, dev, actions, nr, ar, L);
-            else
+            else if (rng == FRZ_RNG_MT19937) {
+                if constexpr (kMtInKernel<NMAX, AMAX>)  // (otherwise the draws were staged and rng arrives as FRZ_RNG_INJECTED)
+                    hipLaunchKernelGGL((cy_roles_kernel<NMAX, AMAX, ATT, FRZ_RNG_MT19937>), grid, wide, 0, stream, env->arena, dev, actions, nr, ar, L);
+            } else
                 hipLaunchKernelGGL((cy_roles_kernel<NMAX, AMAX, ATT, FRZ_RNG_INJECTED>), grid, wide, 0, stream, env->arena, dev, actions, nr, ar, L);
             return;
         }
@@ -1457,6 +1467,7 @@ int launch(frz_cybersecurity_env* env, const int32_t* actions, const float* nr, 
         case 0: launch_variant<4, 4>(env, actions, nr, ar, rng, mode, stream, policy); break;
         case 1: launch_variant<8, 8>(env, actions, nr, ar, rng, mode, stream, policy); break;
         case 3: launch_variant<3, 4, 2>(env, actions, nr, ar, rng, mode, stream, policy); break;  // exact: 3 nodes, 2 attackers, 2 defenders
+        case 4: launch_variant<16, 8>(env, actions, nr, ar, rng, mode, stream, policy); break;  // 9-16 nodes, up to 8 agents: state / view kernel too (round 4)
         default: launch_variant<16, 16>(env, actions, nr, ar, rng, mode, stream, policy); break;
     }
     return hipGetLastError() == hipSuccess ? FRZ_OK : FRZ_E_LAUNCH;
@@ -1480,7 +1491,7 @@ int frz_cybersecurity_create(const frz_cybersecurity_cfg* cfg, frz_cybersecurity
     frz_cybersecurity_env* env = new (std::nothrow) frz_cybersecurity_env();
     if (!env) return FRZ_E_INVALID;
     env->cfg = *cfg;
-    env->variant = (N <= 4 && A <= 4) ? 0 : ((N <= 8 && A <= 8) ? 1 : 2);
+    env->variant = (N <= 4 && A <= 4) ? 0 : ((N <= 8 && A <= 8) ? 1 : (A <= 8 ? 4 : 2));
     if (N == 3 && Att == 2 && D == 2) env->variant = 3;  // the reference's own test / competition shape gets an exact instantiation
     const char* family = std::getenv("FRZ_CY_KERNEL");
     env->roles = env->variant != 2 && !(family && std::strcmp(family, "lane") == 0);
@@ -1580,7 +1591,8 @@ int frz_cybersecurity_create(const frz_cybersecurity_cfg* cfg, frz_cybersecurity
     p.off_rand_net = take(B * N * 4);
     p.off_rand_agent = take(B * A * 4);
     p.off_mt_state = take(624 * B * 4);
-    if (env->roles) env->copy_delta = take((int64_t)A * B * N * 4) - p.off_act_values;  // second copy of the packed action-mapping values
+    // second copy of the packed action-mapping values: where the shape has a multi-step launch (state / view kernel, up to 8 nodes)
+    if (env->roles && env->variant != 4) env->copy_delta = take((int64_t)A * B * N * 4) - p.off_act_values;
     p.total_bytes = off;
 
     int device = 0, cus = 256;
@@ -1719,9 +1731,9 @@ static int step_impl(frz_cybersecurity_env* env, const int32_t* actions, int rng
     const CyDev& p = env->dev;
     if (rng_mode == FRZ_RNG_INJECTED) {
         if (!network_randomness || !agent_randomness) return FRZ_E_INVALID;
-    } else if (rng_mode == FRZ_RNG_MT19937 && env->variant != 2) {
+    } else if (rng_mode == FRZ_RNG_MT19937 && env->variant != 2 && env->variant != 4) {
         // the step kernel advances the env's own stream (network draws first, then agent draws, cybersecurity.py:304-315)
-    } else if (rng_mode == FRZ_RNG_MT19937) {  // 16-node / 16-agent variant: the same draws staged in the arena by a generator launch
+    } else if (rng_mode == FRZ_RNG_MT19937) {  // the 16-node variants: the same draws staged in the arena by a generator launch
         const int64_t B = p.B;
         uint32_t* mt_state = at<uint32_t>(env->arena, p.off_mt_state);
         int32_t* mt_index = at<int32_t>(env->arena, p.off_rows4 + (int64_t)p.r_mti * B * 4);

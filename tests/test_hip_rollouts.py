@@ -785,8 +785,12 @@ def cyber_list_views(env, block: np.ndarray):
 
 @pytest.mark.parametrize('case', [dict(B=65536, max_steps=50, steps=50, kwargs={}),                       # cfg4 as bench.py's secondary workload runs it
                                   dict(B=1000, max_steps=30, steps=34, kwargs={}),                          # ragged, past the horizon
-                                  dict(B=2500, max_steps=40, steps=21, kwargs=dict(show_bad_actions=False, observe_other_presence=True))],
-                         ids=['cfg4_B65536', 'ragged_past_the_horizon', 'no_bad_actions'])
+                                  dict(B=2500, max_steps=40, steps=21, kwargs=dict(show_bad_actions=False, observe_other_presence=True)),
+                                  # 9-16 nodes (round 4: the state / view kernel reaches 16 nodes with up to 8 agents; its multi-step instantiation there
+                                  # spills and is slower than one launch per step, so `rollout` runs these one launch per step — same results)
+                                  dict(B=1300, max_steps=25, steps=20, kwargs={}, build=lambda: configs.cyber_grid(12, 3, 3)),
+                                  dict(B=700, max_steps=12, steps=15, kwargs=dict(partially_observable=True), build=lambda: configs.cyber_grid(16, 4, 4, seed=5))],
+                         ids=['cfg4_B65536', 'ragged_past_the_horizon', 'no_bad_actions', '12_nodes', '16_nodes_past_the_horizon'])
 def test_cybersecurity_multi_step_launch_against_the_oracle(oracle, case):
     """frz_cybersecurity_rollout as ONE launch vs the oracle's steps (frz_oracle_cybersecurity_rollout's loop, unrolled here to look at every
     step): sampled actions, rewards, truncations and action mappings of every step, then the whole final state."""
@@ -795,10 +799,11 @@ def test_cybersecurity_multi_step_launch_against_the_oracle(oracle, case):
     B, steps, kwargs = case['B'], case['steps'], case['kwargs']
     flags = dict(configs.CYBER_DEFAULT_FLAGS)
     flags.update(kwargs)
-    cfg = to_cstruct(configs.cyber_openness(), B, case['max_steps'], **flags)
-    env = C.make_env(configs.cyber_openness, B, case['max_steps'], rng='philox', **kwargs)
+    build = case.get('build', configs.cyber_openness)
+    cfg = to_cstruct(build(), B, case['max_steps'], **flags)
+    env = C.make_env(build, B, case['max_steps'], rng='philox', **kwargs)
     env.set_exclusive_device(True)
-    assert env._lib.frz_cybersecurity_rollout_launches(env._handle, steps, _capi.FRZ_RNG_PHILOX) == 1
+    assert env._lib.frz_cybersecurity_rollout_launches(env._handle, steps, _capi.FRZ_RNG_PHILOX) == (1 if env._N <= 8 else steps)
     seeds = torch.arange(B, dtype=torch.int32) * 3 + 2
     env.reset(seed=seeds)
     rec = env.rollout(steps, policy_seed=31, record=True)
