@@ -15,6 +15,23 @@ from free_range_zoo_amd.envs import rideshare_v0, wildfire_v0
 device = torch.device('cuda')
 B = 65536
 
+
+def granted_cores():
+    """cores this process may really use (scheduler affinity cut down to the cgroup's CPU quota): torch's intra-op pool is capped at it below — on a
+    box that shows 256 host threads and grants 16 cores' worth of time, a CPU tensor op of B elements otherwise wakes 128 spinning workers, the quota of
+    the 100 ms period is gone in ~12 ms and every thread of the process — the one enqueueing launches included — is frozen for the rest"""
+    cores = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            cores = max(1, min(cores, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
+torch.set_num_threads(min(torch.get_num_threads(), granted_cores()))
+
 # 1. continuous rollouts: every env always mid-episode, returns of the episodes that ended accumulated on the device
 env = wildfire_v0.parallel_env(configuration=configs.wildfire_openness(), parallel_envs=B, max_steps=50, device=device, rng='philox')
 env.reset(seed=torch.arange(B, dtype=torch.int32))
@@ -53,14 +70,17 @@ print(f"recorded trajectory: step 12 of {agent}: self {tuple(step12[agent]['self
       f"{int((env.recorded_state(traj, 12).fires > 0).sum())}")
 
 # 2c. the reference's own loop, unchanged, on a GPU this process owns: the steps are counted and run in multi-step launches
-t0 = time.perf_counter()
-for episode in range(4):
-    env.reset(seed=torch.arange(B, dtype=torch.int32, device=device) + episode)
-    while not torch.all(env.finished):
-        for _ in range(50):
-            env.step({name: env.action_space(name).sample_nested() for name in env.agents})
-torch.cuda.synchronize()
-print(f'reference-shaped loop on an exclusive device: {4 * 50 * B / (time.perf_counter() - t0) / 1e9:.2f} G env-steps/s')
+for timed in (False, True):  # (one untimed pass first: the action-space objects and the step chunks are built on first use)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for episode in range(4):
+        env.reset(seed=torch.arange(B, dtype=torch.int32, device=device) + episode)
+        while not torch.all(env.finished):
+            for _ in range(50):
+                env.step({name: env.action_space(name).sample_nested() for name in env.agents})
+    torch.cuda.synchronize()
+    if timed:
+        print(f'reference-shaped loop on an exclusive device: {4 * 50 * B / (time.perf_counter() - t0) / 1e9:.2f} G env-steps/s')
 
 # 3. rideshare: the same spec, one launch sequence per step
 ride = rideshare_v0.parallel_env(configuration=configs.rideshare_busy(), parallel_envs=4096, max_steps=32, device=device)
