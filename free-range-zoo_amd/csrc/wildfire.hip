@@ -1395,8 +1395,11 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
     // Kernel choice for grids of <= 8 cells: the field/crew wavefront-pair kernel (wildfire_roles.hip, two wavefronts per
     // 64 envs) or the lane-per-env kernel below; FRZ_WF_KERNEL=lane|roles overrides the default.
     const char* want = std::getenv("FRZ_WF_KERNEL");
-    const bool small = HW <= 16 && A * (HW <= 8 ? 8 : 16) <= 64;  // shapes the field/crew kernel has an instantiation for
-    p.roles = small ? 1 : 0;
+    const bool small = HW <= 24 && A <= 8;  // shapes the field/crew kernel has an instantiation for (round 4: up to <24, 8>)
+    // default: the field/crew kernel up to 16 cells; on 17-24 cells only from six agents on (measured per step at B = 65 536, lane -> field/crew:
+    // 3x4 / 5 agents 52 -> 46 us, 4x4 / 6 67 -> 56, 4x6 / 8 99 -> 85, 4x5 / 6 72 -> 70, but 4x6 / 5 73 -> 77, 4x5 / 4 62 -> 68, 3x6 / 3 55 -> 62:
+    // tools/dbg/lane_probe.py)
+    p.roles = (small && (HW <= 16 || A >= 6)) ? 1 : 0;
     if (want && std::strcmp(want, "lane") == 0) p.roles = 0;
     if (want && std::strcmp(want, "roles") == 0 && small) p.roles = 1;
     const int envs_per_chunk = kBlock;
@@ -1457,7 +1460,7 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
     std::memcpy(p.ignition, cfg->ignition_temp, sizeof(p.ignition));
     std::memcpy(p.fire_types, cfg->fire_types, sizeof(p.fire_types));
     std::memcpy(p.lit, cfg->lit, sizeof(p.lit));
-    for (int c = 0; c < HW && c < 16; ++c) {  // the configured initial state of a cell (wildfire.py:347-351)
+    for (int c = 0; c < HW && c < 24; ++c) {  // the configured initial state of a cell (wildfire.py:347-351)
         const int f0 = cfg->lit[c] ? cfg->fire_types[c] : -cfg->fire_types[c];
         p.init_fires[c] = f0;
         p.init_intensity[c] = cfg->lit[c] ? cfg->ignition_temp[c] : 0;
@@ -1550,7 +1553,8 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
     p.off_mt_state = take(624 * B * 4);
     // second copy of the packed list buffers (task rows, observation map, action / bad-action maps: contiguous above) for the
     // multi-step launches of the exact field/crew kernels
-    const bool multi_step = p.roles;  // (round 4: the runtime-shape field/crew variants have a multi-step launch too)
+    // (round 4: the runtime-shape field/crew variants have a multi-step launch too — except <16, 8> and <24, 8>, whose scratch would not fit the LDS)
+    const bool multi_step = p.roles && (kVariants[env->variant].exact || !(kVariants[env->variant].cmax > 8 && kVariants[env->variant].amax > 4));
     if (multi_step) env->list_copy_delta = take(p.off_actions - p.off_task_values) - p.off_task_values;
     p.total_bytes = off;
 

@@ -61,9 +61,9 @@ struct WfStaged : WfHot {
     float caps[FRZ_MAX_CAPACITIES];
     float eq[FRZ_MAX_EQUIPMENT_STATES][4];  // (capacity, power, range, -)
     uint64_t range_mask[FRZ_MAX_AGENTS][FRZ_MAX_EQUIPMENT_STATES];  // cells agent a reaches at equipment state s
-    // the configured initial state (wildfire.py:347-354) of the field/crew kernels' grids (<= 16 cells): what a multi-step launch that
+    // the configured initial state (wildfire.py:347-354) of the field/crew kernels' grids (<= 24 cells): what a multi-step launch that
     // starts with a reset, or resets finished envs between its steps, puts in its registers
-    int32_t init_fires[16], init_intensity[16], init_fuel[16];
+    int32_t init_fires[24], init_intensity[24], init_fuel[24];
     int32_t init_equipment;
     float init_suppressant, init_capacity;
     int32_t pad2_;

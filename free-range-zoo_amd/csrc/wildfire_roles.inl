@@ -71,10 +71,13 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                                                                const float* __restrict__ agent_rand, const WfLaunch launch) {
     const int32_t batch = launch.batch;
     using mask_t = uint32_t;
-    constexpr int MB = CMAX <= 8 ? 8 : 16;                                  // bits of a cell mask in the exchange words
-    static_assert(CMAX <= 16 && AMAX * MB <= 64, "cell masks travel between the roles as 8- or 16-bit fields of one word, one per agent");
-    using pack_t = std::conditional_t<(AMAX * MB <= 32), uint32_t, uint64_t>;  // one mask per agent
-    using fate_t = std::conditional_t<(MB == 8), uint32_t, uint64_t>;           // burned | put_out << MB | dead << 2 MB
+    constexpr int MB = CMAX <= 8 ? 8 : (CMAX <= 16 ? 16 : 32);             // bits of a cell mask in the exchange words
+    static_assert(CMAX <= 24, "cell masks are 32-bit words");
+    // the agents' attackable-cell masks travel crew -> field as 8- or 16-bit fields of ONE word where they fit (<= 64 bits: every shape of
+    // rounds 1-3), as a word per agent otherwise (<16, 8>, <24, 8>: round 4)
+    constexpr bool kOkPacked = MB <= 16 && AMAX * MB <= 64;
+    using pack_t = std::conditional_t<(kOkPacked && AMAX * MB <= 32), uint32_t, uint64_t>;  // one mask per agent
+    using fate_t = std::conditional_t<(MB == 8), uint32_t, uint64_t>;  // burned | put_out << MB | dead << 2 MB (MB == 32: dead travels in x_dead)
     constexpr int PW = (AMAX + 1 + 3) / 4;                                // packed scan words (four 16-bit channels each)
     constexpr int NCHP = AMAX + 3 <= 8 ? 8 : (AMAX + 3 <= 16 ? 16 : 32);  // scan channels padded to a power of two
     constexpr bool kPhilox = RNG == FRZ_RNG_PHILOX && MODE == kStep;
@@ -102,7 +105,9 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
     __shared__ uint32_t x_lit[kBlock];       // field -> crew: lit cells after the transitions
     __shared__ fate_t x_fate[kBlock];        // field -> crew: burned | put_out << MB | dead << 2 MB
     __shared__ uint64_t x_excl[PW][kBlock];  // crew -> both: packed per-env counts of the preceding envs of the same wavefront
-    __shared__ pack_t x_ok[kBlock];          // crew -> both: attackable cells of agent a in field a (MB bits each, AMAX * MB <= 64)
+    __shared__ pack_t x_ok[kOkPacked ? kBlock : 1];  // crew -> both: attackable cells of agent a in field a (MB bits each, AMAX * MB <= 64)
+    __shared__ uint32_t x_okv[kOkPacked ? 1 : AMAX][kOkPacked ? 1 : kBlock];  // ... or a word per agent
+    __shared__ uint8_t x_dead[MB == 32 ? kBlock : 1];
     __shared__ float x_supp[AMAX][kBlock];   // crew -> field: suppressant after the agent transitions (agent observations)
     // field -> crew: the step's agent draws (in-kernel RNG).  Two copies in a multi-step Philox launch: the field parks the NEXT step's
     // draws in copy (t + 1) & 1 as soon as it has made them, instead of holding 5 * AMAX registers across its list phase and the loop's
@@ -692,7 +697,10 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                 if (active) {
                     const Placement place = placement();
                     const int64_t off_f = channel_offset(place, 0);
-                    const pack_t oks = x_ok[slot];
+                    auto ok_of = [&](int a) -> mask_t {
+                        if constexpr (kOkPacked) return (mask_t)((x_ok[slot] >> (MB * a)) & (pack_t)((1u << (MB & 31)) - 1u));
+                        else return (mask_t)x_okv[a][slot];
+                    };
                     // single-step launch: the odd agents' lists (the crew writes the even ones, both roles finish together).  Multi-step
                     // launch with Philox draws: EVERY agent's lists — the crew's decode of the next step (which includes the wait for the totals of the step
                     // that just ended) then runs beside this phase instead of behind it.  (Round 4, from the phase stamps of
@@ -701,7 +709,7 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                     // look-back behind the rewards, then the batch totals — not either role's instruction count: profiles/r04_experiments.txt.)
 #pragma unroll
                     for (int a = 0; a < AMAX; ++a)
-                        if (a < A && !crew_writes(a)) emit_agent_lists(a, lit1, (mask_t)((oks >> (MB * a)) & (pack_t)((1u << MB) - 1u)), off_f, channel_offset(place, a + 1), b, copy, ocopy);
+                        if (a < A && !crew_writes(a)) emit_agent_lists(a, lit1, ok_of(a), off_f, channel_offset(place, a + 1), b, copy, ocopy);
                     int64_t* const task_values = reinterpret_cast<int64_t*>(arena + d.off_task_values + copy);
                     int64_t* const task_offsets = reinterpret_cast<int64_t*>(arena + d.off_task_offsets + ocopy);
                     int64_t* const obs_map = reinterpret_cast<int64_t*>(arena + d.off_obs_map + copy);
@@ -984,7 +992,12 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                 for (int c = 0; c < CMAX; ++c) lit1 |= (mask_t)(f[c] > 0) << c;
                 x_lit[slot] = lit1;  // as it is also for the lanes that shadow the last env: a multi-step launch steps them like their owner
                 lit1 = active ? lit1 : (mask_t)0;
-                x_fate[slot] = (fate_t)burned | ((fate_t)put_out << MB) | ((fate_t)dead << (2 * MB));
+                if constexpr (MB == 32) {
+                    x_fate[slot] = (fate_t)burned | ((fate_t)put_out << 32);
+                    x_dead[slot] = (uint8_t)dead;
+                } else {
+                    x_fate[slot] = (fate_t)burned | ((fate_t)put_out << MB) | ((fate_t)dead << (2 * MB));
+                }
                 FRZ_RSTAMP(5);
                 role_barrier();  // (2) lit mask and fates visible to the crew
                 FRZ_RSTAMP(6);
@@ -1356,8 +1369,11 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                 const mask_t lit_all = x_lit[slot];
                 const mask_t lit1 = active ? lit_all : (mask_t)0;
                 const fate_t fate = x_fate[slot];
-                const mask_t burned = (mask_t)(fate & (fate_t)((1u << MB) - 1u)), put_out = (mask_t)((fate >> MB) & (fate_t)((1u << MB) - 1u));
-                const bool dead = ((fate >> (2 * MB)) & 1u) != 0;
+                constexpr fate_t kFateMask = MB == 32 ? (fate_t)0xFFFFFFFFull : (fate_t)((1u << (MB & 31)) - 1u);
+                const mask_t burned = (mask_t)(fate & kFateMask), put_out = (mask_t)((fate >> MB) & kFateMask);
+                bool dead;
+                if constexpr (MB == 32) dead = x_dead[slot] != 0;
+                else dead = ((fate >> ((2 * MB) & 63)) & 1u) != 0;
                 bool term = term0, trunc = trunc0;
                 bool fresh = false;  // FRZ_ROLLOUT_AUTO_RESET: this step finished the env and it starts over (this role's share below)
                 if (MODE == kStep) {
@@ -1423,11 +1439,14 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
                 }
 #pragma unroll
                 for (int w = 0; w < PW; ++w) x_excl[w][slot] = incl[w] - packed[w];
-                {
+                if constexpr (kOkPacked) {
                     pack_t oks = 0;
 #pragma unroll
-                    for (int a = 0; a < AMAX; ++a) oks |= (pack_t)ok1[a] << (MB * a);
+                    for (int a = 0; a < AMAX; ++a) oks |= (pack_t)ok1[a] << ((MB * a) & 63);
                     x_ok[slot] = oks;
+                } else {
+#pragma unroll
+                    for (int a = 0; a < AMAX; ++a) x_okv[a][slot] = (uint32_t)ok1[a];
                 }
                 FRZ_RSTAMP(7);
                 role_barrier();  // (3) wavefront sums visible
@@ -1708,7 +1727,7 @@ void launch_roles_variant(const WfArgs& a, const WfDev* dev, int grid, int rng, 
     auto go = [&](auto kernel) { launch_step_kernel(a, kernel, grid, kRoleBlock, stream, a.arena, dev, a.actions, a.field_rand, a.agent_rand, batch); };
     if (mode == kReset) return go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kReset>);
     if (mode == kRebuild) return go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kRebuild>);
-    if constexpr (!EXACT) {
+    if constexpr (!EXACT && !(CMAX > 8 && AMAX > 4)) {  // (<16, 8> and <24, 8>: single steps only — their multi-step instantiations would not fit the LDS)
         if (a.n_steps > 1) {  // runtime shapes: the multi-step launch draws in the kernel (Philox, or the env's MT19937 stream) or reads the tapes
             const bool extra = !a.policy || a.tape_actions_step != 0 || a.list_record_delta != 0 || a.reward_tape || a.done_tape || a.actions_out_step != 0 ||
                                (a.rollout_flags & FRZ_ROLLOUT_AUTO_RESET) != 0 || a.supp_tape || a.state_tape;
@@ -1750,7 +1769,7 @@ int FRZ_WF_CONCAT(launch_roles_group_, FRZ_WF_ROLES_GROUP)(const WfArgs& args, i
     switch (variant) {
 #define FRZ_X(i, c, a, e)                                                                                                          \
     case i:                                                                                                                        \
-        if constexpr ((i) % FRZ_WF_ROLES_GROUPS == FRZ_WF_ROLES_GROUP && c <= 16 && a * (c <= 8 ? 8 : 16) <= 64)                     \
+        if constexpr ((i) % FRZ_WF_ROLES_GROUPS == FRZ_WF_ROLES_GROUP && c <= 24)                                                   \
             launch_roles_variant<c, a, e>(args, dev, grid, rng, mode, stream);                                                     \
         else return FRZ_E_INVALID;                                                                                                 \
         break;
@@ -1767,6 +1786,7 @@ int FRZ_WF_CONCAT(launch_roles_group_, FRZ_WF_ROLES_GROUP)(const WfArgs& args, i
 // guard of frz_wildfire_set_exclusive_device holds for whichever of them a spec picks
 template <int C, int A, bool E>
 int persist_occupancy_min() {
+    if constexpr (!E && C > 8 && A > 4) return 0;  // (no multi-step instantiation: see launch_roles_variant)
     int least = 1 << 30;
     auto probe = [&least](auto kernel) {
         int blocks = 0;
@@ -1776,7 +1796,7 @@ int persist_occupancy_min() {
         }
         if (blocks < least) least = blocks;
     };
-    {
+    if constexpr (E || !(C > 8 && A > 4)) {
         probe(wf_roles_kernel<C, A, E, FRZ_RNG_PHILOX, kStep, true, false>);
         probe(wf_roles_kernel<C, A, E, FRZ_RNG_PHILOX, kStep, true, true>);
         probe(wf_roles_kernel<C, A, E, FRZ_RNG_MT19937, kStep, true, false>);
@@ -1792,7 +1812,7 @@ int FRZ_WF_CONCAT(roles_persist_occupancy_group_, FRZ_WF_ROLES_GROUP)(int varian
     switch (variant) {
 #define FRZ_X(i, c, a, e)                                                                                                                  \
     case i:                                                                                                                                \
-        if constexpr ((i) % FRZ_WF_ROLES_GROUPS == FRZ_WF_ROLES_GROUP && c <= 16 && a * (c <= 8 ? 8 : 16) <= 64) {                           \
+        if constexpr ((i) % FRZ_WF_ROLES_GROUPS == FRZ_WF_ROLES_GROUP && c <= 24) {                                                         \
             blocks = persist_occupancy_min<c, a, e>();                                                                                      \
         }                                                                                                                                  \
         break;
