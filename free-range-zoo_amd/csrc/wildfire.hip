@@ -1553,8 +1553,8 @@ int frz_wildfire_create(const frz_wildfire_cfg* cfg, frz_wildfire_env** out) {
     p.off_mt_state = take(624 * B * 4);
     // second copy of the packed list buffers (task rows, observation map, action / bad-action maps: contiguous above) for the
     // multi-step launches of the exact field/crew kernels
-    // (round 4: the runtime-shape field/crew variants have a multi-step launch too — except <16, 8> and <24, 8>, whose scratch would not fit the LDS)
-    const bool multi_step = p.roles && (kVariants[env->variant].exact || !(kVariants[env->variant].cmax > 8 && kVariants[env->variant].amax > 4));
+    // (round 4: the runtime-shape field/crew variants have a multi-step launch too — except <24, 8>, whose scratch would not fit the LDS)
+    const bool multi_step = p.roles && (kVariants[env->variant].exact || !(kVariants[env->variant].cmax > 16 && kVariants[env->variant].amax > 4));
     if (multi_step) env->list_copy_delta = take(p.off_actions - p.off_task_values) - p.off_task_values;
     p.total_bytes = off;
 

@@ -120,7 +120,9 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
     constexpr bool kGatherDraws = kRuntimeDraws && AMAX <= 4, kScatterDraws = kRuntimeDraws && AMAX > 4;
     __shared__ float x_uni[kGatherDraws ? 5 * ((3 * CMAX + 5 * AMAX + 4) / 5) : 1][kGatherDraws ? kBlock : 1];
     __shared__ float x_fd[kScatterDraws ? 3 * CMAX : 1][kScatterDraws ? kBlock : 1];
-    constexpr int kDrawCopies = (RNG == FRZ_RNG_PHILOX && PERSIST) ? 2 : 1;
+    // (the 8-agent runtime-shape variants keep ONE copy, 40 KB instead of 80: the next step's draws are parked behind barrier 3, by when the
+    // crew has long moved this step's into registers — phase 2 — so the second copy only buys slack the exact kernels' schedule wants)
+    constexpr int kDrawCopies = (RNG == FRZ_RNG_PHILOX && PERSIST && !(!EXACT && AMAX > 4)) ? 2 : 1;
     __shared__ float x_draw[kDrawCopies][(kPhilox || kMt) ? 5 * AMAX : 1][kBlock];
     // FRZ_ROLLOUT_AUTO_RESET: returns of the episodes that ended inside this launch (float64, per env slot: deterministic) and their number
     __shared__ double x_return[EXTRA ? AMAX : 1][EXTRA ? kBlock : 1];
@@ -1727,7 +1729,7 @@ void launch_roles_variant(const WfArgs& a, const WfDev* dev, int grid, int rng, 
     auto go = [&](auto kernel) { launch_step_kernel(a, kernel, grid, kRoleBlock, stream, a.arena, dev, a.actions, a.field_rand, a.agent_rand, batch); };
     if (mode == kReset) return go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kReset>);
     if (mode == kRebuild) return go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kRebuild>);
-    if constexpr (!EXACT && !(CMAX > 8 && AMAX > 4)) {  // (<16, 8> and <24, 8>: single steps only — their multi-step instantiations would not fit the LDS)
+    if constexpr (!EXACT && !(CMAX > 16 && AMAX > 4)) {  // (<24, 8>: single steps only — its multi-step instantiation would not fit the LDS)
         if (a.n_steps > 1) {  // runtime shapes: the multi-step launch draws in the kernel (Philox, or the env's MT19937 stream) or reads the tapes
             const bool extra = !a.policy || a.tape_actions_step != 0 || a.list_record_delta != 0 || a.reward_tape || a.done_tape || a.actions_out_step != 0 ||
                                (a.rollout_flags & FRZ_ROLLOUT_AUTO_RESET) != 0 || a.supp_tape || a.state_tape;
@@ -1786,7 +1788,7 @@ int FRZ_WF_CONCAT(launch_roles_group_, FRZ_WF_ROLES_GROUP)(const WfArgs& args, i
 // guard of frz_wildfire_set_exclusive_device holds for whichever of them a spec picks
 template <int C, int A, bool E>
 int persist_occupancy_min() {
-    if constexpr (!E && C > 8 && A > 4) return 0;  // (no multi-step instantiation: see launch_roles_variant)
+    if constexpr (!E && C > 16 && A > 4) return 0;  // (no multi-step instantiation: see launch_roles_variant)
     int least = 1 << 30;
     auto probe = [&least](auto kernel) {
         int blocks = 0;
@@ -1796,7 +1798,7 @@ int persist_occupancy_min() {
         }
         if (blocks < least) least = blocks;
     };
-    if constexpr (E || !(C > 8 && A > 4)) {
+    if constexpr (E || !(C > 16 && A > 4)) {
         probe(wf_roles_kernel<C, A, E, FRZ_RNG_PHILOX, kStep, true, false>);
         probe(wf_roles_kernel<C, A, E, FRZ_RNG_PHILOX, kStep, true, true>);
         probe(wf_roles_kernel<C, A, E, FRZ_RNG_MT19937, kStep, true, false>);

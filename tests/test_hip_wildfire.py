@@ -740,12 +740,13 @@ EXACT_SHAPES = [(2, 3, 3), (2, 3, 2), (3, 3, 3), (3, 3, 4), (2, 4, 3), (2, 4, 4)
                 (2, 4, 2), (3, 3, 2), (3, 4, 2), (4, 4, 2), (2, 3, 4)]
 
 
-RUNTIME_SHAPES = [(1, 7, 3), (3, 5, 2), (2, 5, 4), (1, 5, 1), (2, 7, 4), (1, 3, 2), (2, 4, 8), (1, 6, 5), (2, 3, 7)]  # <8, 4>, <16, 4> and <8, 8>
+RUNTIME_SHAPES = [(1, 7, 3), (3, 5, 2), (2, 5, 4), (1, 5, 1), (2, 7, 4), (1, 3, 2), (2, 4, 8), (1, 6, 5), (2, 3, 7), (3, 4, 5), (4, 4, 6),
+                  (3, 3, 8)]  # <8, 4>, <16, 4>, <8, 8> and <16, 8>
 
 
 @pytest.mark.parametrize('shape', RUNTIME_SHAPES, ids=lambda s: 'x'.join(map(str, s)))
 def test_multi_step_launch_of_runtime_shapes(shape):
-    """Grids without an exact instantiation run the runtime-shape field/crew variants (<8, 4>, <16, 4>, <8, 8>: H * W and A read from the
+    """Grids without an exact instantiation run the runtime-shape field/crew variants (<8, 4>, <16, 4>, <8, 8>, <16, 8>: H * W and A read from the
     configuration); since round 4 those have a multi-step kernel too — in-kernel Philox and in-kernel MT19937 streams with the draw numbers
     resolved at run time.  Each against single-step launches (which read STAGED draws: wf_philox_fill_kernel / frz_mt19937_generate), fully
     stochastic configuration, ragged batch, both RNG modes."""
