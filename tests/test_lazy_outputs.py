@@ -106,8 +106,9 @@ def test_reference_shaped_random_rollout_draws_inside_the_step_launch():
     fused.check()
 
 
-@pytest.mark.parametrize('rng', ['philox', 'mt19937'])
-def test_deferred_steps_of_the_reference_shaped_loop_equal_step_by_step(rng):
+@pytest.mark.parametrize('rng,shape', [('philox', None), ('mt19937', None), ('philox', (1, 7, 3)), ('mt19937', (3, 4, 5))],
+                         ids=['philox', 'mt19937', 'philox_runtime_1x7a3', 'mt19937_runtime_3x4a5'])
+def test_deferred_steps_of_the_reference_shaped_loop_equal_step_by_step(rng, shape):
     """With the device declared exclusive the reference-shaped random loop only COUNTS its steps and runs them in chunks — one multi-step
     launch per chunk (utils/env.py: deferred steps).  Whatever is looked at, whenever, must be what a step-by-step execution leaves: a twin env
     that launches every step is stepped alongside, and at seeded-random points one of the things a caller can look at is compared — the
@@ -117,8 +118,9 @@ def test_deferred_steps_of_the_reference_shaped_loop_equal_step_by_step(rng):
     from free_range_zoo_amd.utils.env import EnvTensor
     from test_hip_wildfire import compare_snapshots, hip_snapshot
     B, horizon = 3001, 30
-    lazy, eager = [wildfire_v0.parallel_env(configuration=configs.wildfire_openness(), parallel_envs=B, max_steps=horizon, device=torch.device('cuda'),
-                                            rng=rng) for _ in range(2)]
+    # (shape: a grid without an exact kernel instantiation — round 4: those count their steps too, <8, 4> and <16, 8> here)
+    build = configs.wildfire_openness if shape is None else (lambda: configs.wildfire_grid(*shape))
+    lazy, eager = [wildfire_v0.parallel_env(configuration=build(), parallel_envs=B, max_steps=horizon, device=torch.device('cuda'), rng=rng) for _ in range(2)]
     assert lazy.set_exclusive_device(True) and lazy._defer_chunk > 0 and eager._defer_chunk == 0
     lazy._deferred_log = log = []
     picker = random.Random(7)
