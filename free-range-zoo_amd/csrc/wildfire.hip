@@ -1125,8 +1125,9 @@ int launch(frz_wildfire_env* env, const WfArgs& args, int rng, int mode, hipStre
     }
     {
         WfArgs a = args;
-        // (runtime shapes: a single step reads staged draws; their multi-step launch draws in the kernel)
-        if (!kVariants[env->variant].exact && mode == kStep && rng == FRZ_RNG_PHILOX && env->rollout_steps <= 1) stage_philox(a, rng, stream);
+        // (round 4: the runtime-shape field/crew variants up to 16 cells draw in the kernel, single steps included; <24, 8> and the lane-per-env
+        // kernel read staged draws)
+        if (!kVariants[env->variant].exact && kVariants[env->variant].cmax > 16 && mode == kStep && rng == FRZ_RNG_PHILOX) stage_philox(a, rng, stream);
         a.ticketed = env->ticketed;
         a.n_steps = env->rollout_steps;
         a.scratch_delta = env->list_copy_delta;
@@ -1832,8 +1833,20 @@ int frz_wildfire_import_totals(frz_wildfire_env* env, const int32_t* staging, vo
 
 int frz_wildfire_rollout_launches(const frz_wildfire_env* env, int32_t n_steps, int rng_mode) {
     if (!env || n_steps < 0) return FRZ_E_INVALID;
-    const bool one = n_steps > 1 && env->exclusive_device && env->list_copy_delta != 0 && !env->ticketed &&
-                     (rng_mode == FRZ_RNG_PHILOX || rng_mode == FRZ_RNG_INJECTED || rng_mode == FRZ_RNG_MT19937) && env->dev.roles && !env->dev.grid;
+    bool one = n_steps > 1 && env->exclusive_device && env->list_copy_delta != 0 && !env->ticketed &&
+               (rng_mode == FRZ_RNG_PHILOX || rng_mode == FRZ_RNG_INJECTED || rng_mode == FRZ_RNG_MT19937) && env->dev.roles && !env->dev.grid;
+    if (one && !kVariants[env->variant].exact) {
+        // Runtime-shape variants: the multi-step kernel exists for all of them up to <16, 8>, but it is only CHOSEN where it is the faster way
+        // (50-step rollouts at B = 65 536, one launch per step against one launch, us per step — since round 4 a single step of these shapes draws
+        // in the kernel too, which halved it: profiles/r04_experiments.txt section 12): Philox <8, 4> 13.6 / 10.4, <16, 4> 20.3 / 24.7, <8, 8>
+        // 23.3 / 25.9, <16, 8> 27.2 / 35.4; MT19937 (a single step reads streams staged by a generator launch) <8, 4> 35.6 / 19.0, <16, 4>
+        // 65.4 / 46.0, <8, 8> 63.9 / 50.9, <16, 8> 69.1 / 76.4.  FRZ_WF_MULTI_STEP=all takes it wherever it exists (the parity tests do).
+        const Variant& v = kVariants[env->variant];
+        const bool big = v.cmax > 8 && v.amax > 4;
+        const bool faster = rng_mode == FRZ_RNG_INJECTED || (rng_mode == FRZ_RNG_PHILOX && v.cmax <= 8 && v.amax <= 4) || (rng_mode == FRZ_RNG_MT19937 && !big);
+        const char* const force = std::getenv("FRZ_WF_MULTI_STEP");
+        one = faster || (force && std::strcmp(force, "all") == 0);
+    }
     return one ? 1 : n_steps;
 }
 

@@ -92,9 +92,9 @@ __global__ void __launch_bounds__(kRoleBlock, ((RNG == FRZ_RNG_MT19937 || CMAX >
     constexpr bool kFieldWritesAllLists = PERSIST && RNG == FRZ_RNG_PHILOX;
     // which role writes agent a's action lists
     auto crew_writes = [](int a) constexpr { return kFieldWritesAllLists ? a < FRZ_WF_CREW_LISTS : (a & 1) == 0; };
-    // runtime shapes: a single step reads staged draws (wf_philox_fill_kernel / frz_mt19937_generate); a MULTI-step launch draws in the kernel
+    // runtime shapes draw in the kernel too (round 4; their MT19937 streams only in a multi-step launch: a single step reads frz_mt19937_generate's output)
     // like the exact shapes do, its draw indices (which depend on H * W and A) resolved by scattering them to their places in LDS (x_fd, x_draw)
-    static_assert(EXACT || !(kPhilox || kMt) || PERSIST, "runtime shapes stage the draws of a single step (wf_philox_fill_kernel / frz_mt19937_generate)");
+    static_assert(EXACT || !kMt || PERSIST, "runtime shapes keep their MT19937 streams outside a single step's kernel (frz_mt19937_generate)");
 
     __shared__ uint64_t s_wave_scan[frz::kWaves][PW];
     __shared__ uint32_t s_wave_live[frz::kWaves][2];
@@ -1753,6 +1753,9 @@ void launch_roles_variant(const WfArgs& a, const WfDev* dev, int grid, int rng, 
         }
         if (rng == FRZ_RNG_PHILOX) return go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_PHILOX, kStep>);
         if (rng == FRZ_RNG_MT19937) return go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_MT19937, kStep>);
+    }
+    if constexpr (!EXACT && CMAX <= 16) {  // (round 4: a single step of a runtime shape draws in the kernel as well — the staging launch cost more than the step; not <24, 8>: LDS)
+        if (rng == FRZ_RNG_PHILOX) return go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_PHILOX, kStep>);
     }
     if (rng == FRZ_RNG_INJECTED) go(wf_roles_kernel<CMAX, AMAX, EXACT, FRZ_RNG_INJECTED, kStep>);
 }

@@ -84,9 +84,10 @@ ORACLE_CASES = [
 
 
 @pytest.mark.parametrize('case', ORACLE_CASES, ids=['cfg2_B65536', 'cfg2_ragged', 'bad_actions_past_the_horizon', '3x3a4', 'runtime_1x7a3', 'runtime_3x5a2_past_the_horizon'])
-def test_multi_step_launch_against_the_oracle(oracle, case):
+def test_multi_step_launch_against_the_oracle(oracle, case, monkeypatch):
     """rollout(n) as ONE launch (frz_wildfire_rollout_launches == 1) vs n oracle steps: the sampled actions, rewards, terminations /
     truncations and every packed list OF EVERY STEP (tapes + list record), then the whole final state."""
+    monkeypatch.setenv('FRZ_WF_MULTI_STEP', 'all')  # (runtime shapes: the multi-step kernel wherever it exists, not only where it is the default)
     check_policy_rollout_against_the_oracle(oracle, case, one_launch=True)
 
 

@@ -745,11 +745,12 @@ RUNTIME_SHAPES = [(1, 7, 3), (3, 5, 2), (2, 5, 4), (1, 5, 1), (2, 7, 4), (1, 3, 
 
 
 @pytest.mark.parametrize('shape', RUNTIME_SHAPES, ids=lambda s: 'x'.join(map(str, s)))
-def test_multi_step_launch_of_runtime_shapes(shape):
+def test_multi_step_launch_of_runtime_shapes(shape, monkeypatch):
     """Grids without an exact instantiation run the runtime-shape field/crew variants (<8, 4>, <16, 4>, <8, 8>, <16, 8>: H * W and A read from the
     configuration); since round 4 those have a multi-step kernel too — in-kernel Philox and in-kernel MT19937 streams with the draw numbers
     resolved at run time.  Each against single-step launches (which read STAGED draws: wf_philox_fill_kernel / frz_mt19937_generate), fully
     stochastic configuration, ragged batch, both RNG modes."""
+    monkeypatch.setenv('FRZ_WF_MULTI_STEP', 'all')  # (by default the library takes the multi-step kernel of a runtime shape only where it is the faster way)
     H, Wd, A = shape
     B = 777
     for rng, mode in (('philox', _capi.FRZ_RNG_PHILOX), ('mt19937', _capi.FRZ_RNG_MT19937)):

@@ -108,12 +108,13 @@ def test_reference_shaped_random_rollout_draws_inside_the_step_launch():
 
 @pytest.mark.parametrize('rng,shape', [('philox', None), ('mt19937', None), ('philox', (1, 7, 3)), ('mt19937', (3, 4, 5))],
                          ids=['philox', 'mt19937', 'philox_runtime_1x7a3', 'mt19937_runtime_3x4a5'])
-def test_deferred_steps_of_the_reference_shaped_loop_equal_step_by_step(rng, shape):
+def test_deferred_steps_of_the_reference_shaped_loop_equal_step_by_step(rng, shape, monkeypatch):
     """With the device declared exclusive the reference-shaped random loop only COUNTS its steps and runs them in chunks — one multi-step
     launch per chunk (utils/env.py: deferred steps).  Whatever is looked at, whenever, must be what a step-by-step execution leaves: a twin env
     that launches every step is stepped alongside, and at seeded-random points one of the things a caller can look at is compared — the
     returned dicts, public attributes, the state object taken BEFORE the steps, spaces, an old sample — then everything at every episode end."""
     import random
+    monkeypatch.setenv('FRZ_WF_MULTI_STEP', 'all')
     from free_range_zoo_amd.envs import wildfire_v0
     from free_range_zoo_amd.utils.env import EnvTensor
     from test_hip_wildfire import compare_snapshots, hip_snapshot
